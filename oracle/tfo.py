@@ -1,0 +1,333 @@
+"""ctypes binding of the CPU oracle (oracle/libtf_oracle.so).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py.  The product package (twenty-first_amd/) never imports this.
+
+All arrays are numpy uint64 arrays of raw Montgomery words (BFE 1 word, XFE 3, Digest 5).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libtf_oracle.so")
+
+P = 0xFFFFFFFF00000001
+
+
+def build(force: bool = False) -> str:
+    """Compile the oracle with gcc (idempotent)."""
+    src = os.path.join(_HERE, "tf_oracle.c")
+    hdr = os.path.join(_HERE, "tf_oracle.h")
+    stale = (not os.path.exists(_SO)) or any(
+        os.path.getmtime(f) > os.path.getmtime(_SO) for f in (src, hdr)
+    )
+    if force or stale:
+        subprocess.check_call(["make", "-C", _HERE, "-B", "libtf_oracle.so"], stdout=subprocess.DEVNULL)
+    return _SO
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_SO)
+        u64, sz, i32 = C.c_uint64, C.c_size_t, C.c_int
+        pu = C.POINTER(C.c_uint64)
+        sig = {
+            "tfo_montyred": (u64, [u64, u64]),
+            "tfo_bfe_new": (u64, [u64]),
+            "tfo_bfe_value": (u64, [u64]),
+            "tfo_bfe_add": (u64, [u64, u64]),
+            "tfo_bfe_sub": (u64, [u64, u64]),
+            "tfo_bfe_neg": (u64, [u64]),
+            "tfo_bfe_mul": (u64, [u64, u64]),
+            "tfo_bfe_mod_pow": (u64, [u64, u64]),
+            "tfo_bfe_inverse": (u64, [u64]),
+            "tfo_bfe_primitive_root": (u64, [u64]),
+            "tfo_xfe_add": (None, [pu, pu, pu]),
+            "tfo_xfe_sub": (None, [pu, pu, pu]),
+            "tfo_xfe_mul": (None, [pu, pu, pu]),
+            "tfo_xfe_mul_bfe": (None, [pu, u64, pu]),
+            "tfo_ntt": (i32, [pu, sz, i32]),
+            "tfo_intt": (i32, [pu, sz, i32]),
+            "tfo_ntt_batch": (i32, [pu, sz, sz, i32, i32, i32]),
+            "tfo_poly_scale": (None, [pu, sz, i32, u64]),
+            "tfo_coset_evaluate": (i32, [pu, sz, i32, u64, pu, sz]),
+            "tfo_coset_interpolate": (i32, [pu, sz, i32, u64, pu]),
+            "tfo_poly_eval": (None, [pu, sz, i32, u64, pu]),
+            "tfo_tip5_permutation": (None, [pu]),
+            "tfo_tip5_permutation_naive": (None, [pu]),
+            "tfo_tip5_hash_10": (None, [pu, pu]),
+            "tfo_tip5_hash_pair": (None, [pu, pu, pu]),
+            "tfo_tip5_hash_varlen": (None, [pu, sz, pu]),
+            "tfo_tip5_absorb": (None, [pu, pu]),
+            "tfo_tip5_hash_pairs": (None, [pu, pu, sz]),
+            "tfo_tip5_hash_varlen_rows": (None, [pu, sz, sz, pu]),
+            "tfo_merkle_build": (i32, [pu, sz, pu]),
+            "tfo_merkle_build_par": (i32, [pu, sz, pu, i32, sz]),
+            "tfo_merkle_frugal_root": (i32, [pu, sz, pu]),
+            "tfo_fill_random": (None, [pu, sz, u64]),
+            "tfo_digest_to_hex": (None, [pu, C.c_char_p]),
+        }
+        for name, (res, args) in sig.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def _p(a: np.ndarray):
+    assert a.dtype == np.uint64 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(C.POINTER(C.c_uint64))
+
+
+def _arr(x, n=None) -> np.ndarray:
+    a = np.ascontiguousarray(np.asarray(x, dtype=np.uint64))
+    if n is not None:
+        assert a.size == n, (a.size, n)
+    return a
+
+
+# ---- scalars -------------------------------------------------------------------------
+
+def bfe_new(v: int) -> int:
+    return lib().tfo_bfe_new(v % (1 << 64))
+
+
+def bfe_value(raw: int) -> int:
+    return lib().tfo_bfe_value(raw)
+
+
+def bfe_add(a, b):
+    return lib().tfo_bfe_add(a, b)
+
+
+def bfe_sub(a, b):
+    return lib().tfo_bfe_sub(a, b)
+
+
+def bfe_neg(a):
+    return lib().tfo_bfe_neg(a)
+
+
+def bfe_mul(a, b):
+    return lib().tfo_bfe_mul(a, b)
+
+
+def bfe_mod_pow(a, e):
+    return lib().tfo_bfe_mod_pow(a, e)
+
+
+def bfe_inverse(a):
+    return lib().tfo_bfe_inverse(a)
+
+
+def primitive_root(n: int) -> int:
+    return lib().tfo_bfe_primitive_root(n)
+
+
+def to_raw(values) -> np.ndarray:
+    """canonical values -> raw Montgomery words (vectorised through python ints; small inputs)."""
+    flat = [bfe_new(int(v)) for v in np.asarray(values, dtype=object).ravel()]
+    return np.array(flat, dtype=np.uint64).reshape(np.shape(values))
+
+
+def to_values(raw) -> np.ndarray:
+    flat = [bfe_value(int(v)) for v in np.asarray(raw, dtype=np.uint64).ravel()]
+    return np.array(flat, dtype=np.uint64).reshape(np.shape(raw))
+
+
+def xfe_mul(a, b):
+    a, b = _arr(a, 3), _arr(b, 3)
+    out = np.zeros(3, dtype=np.uint64)
+    lib().tfo_xfe_mul(_p(a), _p(b), _p(out))
+    return out
+
+
+def xfe_add(a, b):
+    a, b = _arr(a, 3), _arr(b, 3)
+    out = np.zeros(3, dtype=np.uint64)
+    lib().tfo_xfe_add(_p(a), _p(b), _p(out))
+    return out
+
+
+def xfe_sub(a, b):
+    a, b = _arr(a, 3), _arr(b, 3)
+    out = np.zeros(3, dtype=np.uint64)
+    lib().tfo_xfe_sub(_p(a), _p(b), _p(out))
+    return out
+
+
+# ---- NTT -----------------------------------------------------------------------------
+
+class OraclePanic(Exception):
+    """The reference would panic / return an error here; .code is the oracle's return code."""
+
+    def __init__(self, code):
+        super().__init__(f"oracle error code {code}")
+        self.code = code
+
+
+def ntt(x, width: int = 1, inverse: bool = False, batch: int = 1, threads: int = 1) -> np.ndarray:
+    """Returns a transformed copy.  x holds batch * n * width words."""
+    x = _arr(x).copy().reshape(-1)
+    assert x.size % (batch * width) == 0
+    n = x.size // (batch * width) if batch else 0
+    rc = lib().tfo_ntt_batch(_p(x), n, batch, width, int(inverse), threads)
+    if rc:
+        raise OraclePanic(rc)
+    return x
+
+
+def intt(x, width: int = 1, batch: int = 1, threads: int = 1) -> np.ndarray:
+    return ntt(x, width=width, inverse=True, batch=batch, threads=threads)
+
+
+def ntt_raw_len(x: np.ndarray, n: int, width: int = 1, inverse: bool = False):
+    """Call the single-slice entry point with an explicit length (for error-path tests)."""
+    x = _arr(x).copy()
+    fn = lib().tfo_intt if inverse else lib().tfo_ntt
+    rc = fn(_p(x), n, width)
+    if rc:
+        raise OraclePanic(rc)
+    return x
+
+
+def coset_evaluate(coeffs, offset_raw: int, order: int, width: int = 1) -> np.ndarray:
+    c = _arr(coeffs).reshape(-1)
+    n_coeffs = c.size // width
+    out = np.zeros(order * width, dtype=np.uint64)
+    rc = lib().tfo_coset_evaluate(_p(c) if c.size else _p(np.zeros(1, np.uint64)), n_coeffs, width, offset_raw, _p(out) if out.size else _p(np.zeros(1, np.uint64)), order)
+    if rc:
+        raise OraclePanic(rc)
+    return out
+
+
+def coset_interpolate(values, offset_raw: int, width: int = 1) -> np.ndarray:
+    v = _arr(values).reshape(-1)
+    n = v.size // width
+    out = np.zeros_like(v)
+    rc = lib().tfo_coset_interpolate(_p(v), n, width, offset_raw, _p(out))
+    if rc:
+        raise OraclePanic(rc)
+    return out
+
+
+def poly_eval(coeffs, point_raw: int, width: int = 1) -> np.ndarray:
+    c = _arr(coeffs).reshape(-1)
+    out = np.zeros(width, dtype=np.uint64)
+    lib().tfo_poly_eval(_p(c), c.size // width, width, point_raw, _p(out))
+    return out
+
+
+def poly_scale(coeffs, alpha_raw: int, width: int = 1) -> np.ndarray:
+    c = _arr(coeffs).copy().reshape(-1)
+    lib().tfo_poly_scale(_p(c), c.size // width, width, alpha_raw)
+    return c
+
+
+# ---- Tip5 ----------------------------------------------------------------------------
+
+def tip5_permutation(state, naive: bool = False) -> np.ndarray:
+    s = _arr(state, 16).copy()
+    (lib().tfo_tip5_permutation_naive if naive else lib().tfo_tip5_permutation)(_p(s))
+    return s
+
+
+def hash_10(inp) -> np.ndarray:
+    i = _arr(inp, 10)
+    out = np.zeros(5, dtype=np.uint64)
+    lib().tfo_tip5_hash_10(_p(i), _p(out))
+    return out
+
+
+def hash_pair(l, r) -> np.ndarray:
+    l, r = _arr(l, 5), _arr(r, 5)
+    out = np.zeros(5, dtype=np.uint64)
+    lib().tfo_tip5_hash_pair(_p(l), _p(r), _p(out))
+    return out
+
+
+def hash_varlen(inp) -> np.ndarray:
+    i = _arr(inp).reshape(-1)
+    out = np.zeros(5, dtype=np.uint64)
+    buf = i if i.size else np.zeros(1, dtype=np.uint64)
+    lib().tfo_tip5_hash_varlen(_p(buf), i.size, _p(out))
+    return out
+
+
+def absorb(state, inp) -> np.ndarray:
+    s = _arr(state, 16).copy()
+    lib().tfo_tip5_absorb(_p(s), _p(_arr(inp, 10)))
+    return s
+
+
+def hash_pairs(inp) -> np.ndarray:
+    i = _arr(inp).reshape(-1)
+    count = i.size // 10
+    out = np.zeros(count * 5, dtype=np.uint64)
+    if count:
+        lib().tfo_tip5_hash_pairs(_p(i), _p(out), count)
+    return out
+
+
+def hash_varlen_rows(rows, row_len: int) -> np.ndarray:
+    r = _arr(rows).reshape(-1)
+    n_rows = r.size // row_len if row_len else 0
+    out = np.zeros(n_rows * 5, dtype=np.uint64)
+    if n_rows:
+        lib().tfo_tip5_hash_varlen_rows(_p(r), row_len, n_rows, _p(out))
+    return out
+
+
+# ---- Merkle --------------------------------------------------------------------------
+
+def merkle_build(leaves, threads: int = 0, cutoff: int = 512) -> np.ndarray:
+    """Full node array (2n digests).  threads=0: sequential_new; >0: par_new restatement."""
+    l = _arr(leaves).reshape(-1)
+    n = l.size // 5
+    nodes = np.zeros(max(10 * n, 1), dtype=np.uint64)
+    buf = l if l.size else np.zeros(1, dtype=np.uint64)
+    if threads > 0:
+        rc = lib().tfo_merkle_build_par(_p(buf), n, _p(nodes), threads, cutoff)
+    else:
+        rc = lib().tfo_merkle_build(_p(buf), n, _p(nodes))
+    if rc:
+        raise OraclePanic(rc)
+    return nodes[: 10 * n]
+
+
+def merkle_frugal_root(leaves) -> np.ndarray:
+    l = _arr(leaves).reshape(-1)
+    n = l.size // 5
+    root = np.zeros(5, dtype=np.uint64)
+    buf = l if l.size else np.zeros(1, dtype=np.uint64)
+    rc = lib().tfo_merkle_frugal_root(_p(buf), n, _p(root))
+    if rc:
+        raise OraclePanic(rc)
+    return root
+
+
+# ---- helpers -------------------------------------------------------------------------
+
+def fill_random(count: int, seed: int) -> np.ndarray:
+    out = np.zeros(count, dtype=np.uint64)
+    if count:
+        lib().tfo_fill_random(_p(out), count, seed)
+    return out
+
+
+def digest_hex(d) -> str:
+    d = _arr(d, 5)
+    buf = C.create_string_buffer(81)
+    lib().tfo_digest_to_hex(_p(d), buf)
+    return buf.value.decode()
