@@ -1,0 +1,130 @@
+/*
+ * tf_hip.h -- C ABI of libtf_hip.so: the MI355X (gfx950) backend for the data-parallel hot path of
+ * Neptune-Crypto/twenty-first (Goldilocks NTT/iNTT, fast_coset_evaluate, Tip5, Merkle builder).
+ *
+ * The reference has no FFI of its own (it is a pure-Rust crate); each entry point below replaces the
+ * body of one Rust function, cited as file:line relative to twenty-first/src/.  INTEGRATION.md shows
+ * the Rust `extern "C"` shim a maintainer would add.
+ *
+ * Data contract (identical to the reference's in-memory layout, so `&mut [BFieldElement]` can be
+ * passed as `*mut u64` without conversion):
+ *   BFieldElement  = 1 little-endian u64: x * 2^64 mod p, canonical (< p)   math/b_field_element.rs:84-86 (#[repr(transparent)])
+ *   XFieldElement  = 3 consecutive BFieldElements [c0, c1, c2]              math/x_field_element.rs:56-59 (#[repr(transparent)])
+ *   Digest         = 5 consecutive BFieldElements                           tip5/digest.rs:29
+ *   Tip5 state     = 16 consecutive BFieldElements                          tip5/mod.rs:159-165
+ * Inputs must be canonical (true for anything built through BFieldElement::new); outputs always are.
+ * All pointers 8-byte aligned.  Results are bit-identical to the reference's CPU path.
+ *
+ * Two flavours of every entry point:
+ *   tf_xxx(...)            host pointers; copies in, runs on the current HIP device, copies out, returns when done.
+ *   tf_xxx_dev(..., stream) device pointers (memory of the current HIP device); work is enqueued on `stream`
+ *                          (a hipStream_t, NULL = default stream) and the call returns without synchronising.
+ * Every function is re-entrant and may be called concurrently from many host threads
+ * (the reference's ntt is called from rayon workers, math/ntt.rs:250-274).
+ *
+ * There is NO CPU fallback: without a usable HIP device every call returns TF_ERR_NO_DEVICE.
+ *
+ * Return value: 0 on success, otherwise one of the codes below.  Codes 1-3 are the reference's
+ * MerkleTreeError variants (util_types/merkle_tree.rs:933-965); codes 4-6 replace panics.
+ */
+#ifndef TF_HIP_H
+#define TF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum tf_status {
+    TF_OK = 0,
+    TF_ERR_TOO_FEW_LEAFS = 1,              /* MerkleTreeError::TooFewLeafs            merkle_tree.rs:394-396 */
+    TF_ERR_INCORRECT_NUMBER_OF_LEAFS = 2,  /* MerkleTreeError::IncorrectNumberOfLeafs merkle_tree.rs:398-401 */
+    TF_ERR_TREE_TOO_HIGH = 3,              /* MerkleTreeError::TreeTooHigh (allocation failure) :405-410 */
+    TF_ERR_LEN_NOT_POWER_OF_TWO = 4,       /* ntt/intt panic: assert!(len == 0 || len.is_power_of_two()) math/ntt.rs:137 */
+    TF_ERR_LEN_TOO_LARGE = 5,              /* ntt/intt panic: len > u32::MAX (math/ntt.rs:136); this backend: len > 2^30 */
+    TF_ERR_ORDER_NOT_ABOVE_DEGREE = 6,     /* fast_coset_evaluate panic: order <= degree  math/polynomial.rs:1388-1392 */
+    TF_ERR_NULL_POINTER = 7,
+    TF_ERR_NO_DEVICE = 8,                  /* no HIP device / HIP runtime unusable */
+    TF_ERR_HIP = 9,                        /* a HIP call failed; see tf_last_error() */
+    TF_ERR_OUT_OF_MEMORY = 10
+};
+
+/* Human-readable name of a status code. */
+const char *tf_status_string(int status);
+/* Text of the last HIP failure on the calling thread ("" if none). */
+const char *tf_last_error(void);
+/* Library/ABI version (major * 1000 + minor). */
+int tf_version(void);
+/* Number of visible HIP devices (0 if the runtime is unusable). */
+int tf_device_count(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * NTT / iNTT            replaces  pub fn ntt<FF>(x: &mut [FF])   math/ntt.rs:67-82
+ *                                 pub fn intt<FF>(x: &mut [FF])  math/ntt.rs:109-125
+ * x: `batch` contiguous slices of n elements each, transformed in place, natural order in and out.
+ * batch = 1 reproduces one Rust call; n = 0 and n = 1 are no-ops exactly as in the reference.
+ * inverse != 0 selects intt (w^-1 twiddles and the n^-1 unscale of ntt.rs:220-228).
+ * Errors: n not 0/power of two -> TF_ERR_LEN_NOT_POWER_OF_TWO; n > 2^30 -> TF_ERR_LEN_TOO_LARGE.
+ */
+int tf_ntt_bfe(uint64_t *x, size_t n, size_t batch, int inverse);
+int tf_ntt_xfe(uint64_t *x /* 3n words per slice */, size_t n, size_t batch, int inverse);
+int tf_ntt_bfe_dev(uint64_t *d_x, size_t n, size_t batch, int inverse, void *stream);
+int tf_ntt_xfe_dev(uint64_t *d_x, size_t n, size_t batch, int inverse, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Coset evaluation      replaces  Polynomial::fast_coset_evaluate(&self, offset, order) -> Vec<FF>
+ *                                 math/polynomial.rs:1374-1399  (= scale :760-773, zero-pad, ntt)
+ * coeffs: `batch` polynomials of n_coeffs coefficients each (low to high degree), read only;
+ * out:    `batch` x `order` evaluations: out[i] = f(offset * w_order^i).
+ * offset_raw is a BFieldElement (raw Montgomery word); an XFieldElement offset stays on the caller's side.
+ * Errors: n_coeffs > order -> TF_ERR_ORDER_NOT_ABOVE_DEGREE (trim leading zero coefficients first, as
+ * Polynomial::degree() does); order not a power of two / too large as for tf_ntt_*.
+ */
+int tf_coset_eval_bfe(const uint64_t *coeffs, size_t n_coeffs, uint64_t offset_raw, uint64_t *out, size_t order, size_t batch);
+int tf_coset_eval_xfe(const uint64_t *coeffs, size_t n_coeffs, uint64_t offset_raw, uint64_t *out, size_t order, size_t batch);
+int tf_coset_eval_bfe_dev(const uint64_t *d_coeffs, size_t n_coeffs, uint64_t offset_raw, uint64_t *d_out, size_t order, size_t batch, void *stream);
+int tf_coset_eval_xfe_dev(const uint64_t *d_coeffs, size_t n_coeffs, uint64_t offset_raw, uint64_t *d_out, size_t order, size_t batch, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Tip5                  replaces  Tip5::permutation  tip5/mod.rs:529-533   (states: count x 16 words, in place)
+ *                                 Tip5::hash_10 / hash_pair  :559-586       (in: count x 10 words, out: count x 5)
+ *                                 Tip5::hash_varlen  :617-623 (+ sponge.rs:41-55)   one digest per row
+ * Batching is the only reason to cross the boundary; a single hash_pair belongs on the CPU.
+ */
+int tf_tip5_permute(uint64_t *states, size_t count);
+int tf_tip5_hash_pairs(const uint64_t *in, uint64_t *out, size_t count);
+int tf_tip5_hash_varlen_rows(const uint64_t *rows, size_t row_len, size_t n_rows, uint64_t *out);
+int tf_tip5_permute_dev(uint64_t *d_states, size_t count, void *stream);
+int tf_tip5_hash_pairs_dev(const uint64_t *d_in, uint64_t *d_out, size_t count, void *stream);
+int tf_tip5_hash_varlen_rows_dev(const uint64_t *d_rows, size_t row_len, size_t n_rows, uint64_t *d_out, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Merkle tree           replaces  MerkleTree::par_new / sequential_new   util_types/merkle_tree.rs:149-212
+ *                                 MerkleTree::par_frugal_root / sequential_frugal_root   :299-364
+ * leaves:    `batch` x n_leaves digests.
+ * nodes_out: `batch` x 2*n_leaves digests in the reference's heap layout: nodes[0] = all-zero dummy,
+ *            nodes[1] = root, nodes[i] = hash_pair(nodes[2i], nodes[2i+1]), leaves at nodes[n..2n).
+ * root_out:  `batch` digests.
+ * Errors: n_leaves == 0 -> TF_ERR_TOO_FEW_LEAFS (as par_new/sequential_new :394-396 and sequential_frugal_root
+ * :300-302; par_frugal_root reports IncorrectNumberOfLeafs for 0 leaves, :333-335 -- its shim checks that first);
+ * not a power of two -> TF_ERR_INCORRECT_NUMBER_OF_LEAFS; device allocation failure -> TF_ERR_TREE_TOO_HIGH.
+ */
+int tf_merkle_build(const uint64_t *leaves, size_t n_leaves, uint64_t *nodes_out, size_t batch);
+int tf_merkle_root(const uint64_t *leaves, size_t n_leaves, uint64_t *root_out, size_t batch);
+int tf_merkle_build_dev(const uint64_t *d_leaves, size_t n_leaves, uint64_t *d_nodes_out, size_t batch, void *stream);
+int tf_merkle_root_dev(const uint64_t *d_leaves, size_t n_leaves, uint64_t *d_root_out, size_t batch, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Tuning knobs (process-wide; also read once from the environment):
+ *   TF_NTT_TILE_BYTES : bytes of batch processed between the passes of a multi-pass NTT (scratch size),
+ *                       chosen so the inter-pass intermediate stays in the 256 MiB Infinity Cache.
+ */
+void tf_set_ntt_tile_bytes(size_t bytes);
+size_t tf_get_ntt_tile_bytes(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TF_HIP_H */

@@ -1,0 +1,379 @@
+"""Parity of the HIP path (through the C ABI of libtf_hip.so) against the KAT-pinned CPU oracle.
+
+Bit-exact comparison of raw Montgomery words -- all arithmetic on this path is integer.
+Run with `pytest -m gpu` on an MI355X box.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+P = 0xFFFFFFFF00000001
+MAX = P - 1
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu(tf):
+    assert tf.lib().tf_device_count() > 0, "no HIP device visible: the product has no CPU fallback"
+
+
+# ------------------------------------------------------------------ reference KATs through the GPU path
+
+def test_kat_ntt_basic(tf, oracle):
+    """math/ntt.rs:424-445, :448-469, :512-560 on the GPU"""
+    x = oracle.to_raw([1, 4, 0, 0])
+    y = x.copy()
+    tf.ntt(y)
+    assert list(y) == list(oracle.to_raw([5, 1125899906842625, 18446744069414584318, 18445618169507741698]))
+    tf.intt(y)
+    assert list(y) == list(x)
+    m = oracle.to_raw([MAX, 0, 0, 0])
+    tf.ntt(m)
+    assert list(m) == list(oracle.to_raw([MAX] * 4))
+    x32 = oracle.to_raw([1, 4, 0, 0, 0, 0, 0, 0] * 4)
+    expected = [0] * 32
+    for i, v in enumerate([20, 18446744069146148869, 4503599627370500, 18446726477228544005,
+                           18446744069414584309, 268435460, 18442240469787213829, 17592186040324]):
+        expected[4 * i] = v
+    y = x32.copy()
+    tf.ntt(y)
+    assert list(y) == list(oracle.to_raw(expected))
+    tf.intt(y)
+    assert list(y) == list(x32)
+
+
+def test_kat_xfield_basic_ntt(tf, oracle):
+    """math/ntt.rs:398-421"""
+    x = oracle.to_raw([1, 0, 0] + [0, 0, 0] * 3)
+    y = x.copy()
+    tf.ntt(y, width=3)
+    assert list(y) == list(oracle.to_raw([1, 0, 0] * 4))
+    tf.intt(y, width=3)
+    assert list(y) == list(x)
+
+
+def test_kat_tip5_snapshots(tf, oracle):
+    """tip5/mod.rs:1294-1306, :1309-1325, :1328-1362, :1146-1206, mmr_accumulator.rs:1038-1046 on the GPU"""
+    from tests.test_oracle_kat import DEGENERATE_IN, DEGENERATE_OUT, SNAPSHOT_OUT, SNAPSHOT_STATE
+
+    out = tf.Tip5.permutation(np.array(SNAPSHOT_STATE, dtype=np.uint64))
+    assert [int(v) for v in out[:5]] == SNAPSHOT_OUT
+    out = tf.Tip5.permutation(oracle.to_raw(DEGENERATE_IN))
+    assert list(out) == list(oracle.to_raw(DEGENERATE_OUT))
+    pre = np.zeros(10, dtype=np.uint64)
+    for i in range(6):
+        pre[i:i + 5] = tf.Tip5.hash_10(pre)
+    assert tf.Digest.to_hex(tf.Tip5.hash_10(pre)) == (
+        "109cc2fe453bd9962f754b96d8f5b919b60af030940a275f5540da195fef65ee651c1b6fa19b2c6a")
+    acc = [0] * 5
+    for i in range(20):
+        d = tf.Tip5.hash_varlen(oracle.to_raw(list(range(i))) if i else np.zeros(0, np.uint64))
+        acc = [oracle.bfe_add(a, int(b)) for a, b in zip(acc, d)]
+    assert tf.Digest.to_hex(acc) == "efbafa86622a9c69652f8a1c4ffd734f021ad23a0a8085412a877de0f9170b18ea4ff69b6fff9a03"
+    assert tf.Digest.to_hex(tf.Tip5.hash_10(np.zeros(10, dtype=np.uint64))) == (
+        "cd65052100640f0d27e5654f97c47e49899add2f265967ccbefee7264e9bc08f588542d9dc3d5ac5")
+
+
+def test_merkle_root_goldens(tf, oracle):
+    gold = json.load(open(os.path.join(HERE, "golden", "merkle_roots.json")))
+    for h, hexroot in gold["test_tree_of_height_roots"].items():
+        leaves = np.concatenate([oracle.hash_varlen(oracle.to_raw([i])) for i in range(1 << int(h))])
+        tree = tf.MerkleTree.par_new(leaves)
+        assert tf.Digest.to_hex(tree.root()) == hexroot
+        assert tf.Digest.to_hex(tf.MerkleTree.par_frugal_root(leaves)) == hexroot
+
+
+# ------------------------------------------------------------------ NTT vs oracle
+
+@pytest.mark.parametrize("log_n", list(range(0, 15)) + [16, 18, 20, 21, 22])
+@pytest.mark.parametrize("inverse", [False, True])
+def test_ntt_bfe_matches_oracle(tf, oracle, log_n, inverse):
+    n = 1 << log_n
+    batch = 5 if log_n <= 12 else (3 if log_n <= 18 else 1)
+    x = oracle.fill_random(n * batch, 1000 + log_n)
+    want = oracle.ntt(x, inverse=inverse, batch=batch, threads=8)
+    got = x.copy()
+    tf.ntt(got, batch=batch, _inverse=inverse)
+    assert np.array_equal(got, want)
+    assert (got < np.uint64(P)).all()
+
+
+@pytest.mark.parametrize("log_n", [0, 1, 2, 4, 5, 6, 9, 10, 11, 13, 16, 20, 21])
+@pytest.mark.parametrize("inverse", [False, True])
+def test_ntt_xfe_matches_oracle(tf, oracle, log_n, inverse):
+    n = 1 << log_n
+    batch = 3 if log_n <= 13 else 1
+    x = oracle.fill_random(3 * n * batch, 2000 + log_n)
+    want = oracle.ntt(x, width=3, inverse=inverse, batch=batch, threads=8)
+    got = x.copy()
+    tf.ntt(got, width=3, batch=batch, _inverse=inverse)
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("n,batch", [(32, 1), (32, 257), (64, 100), (1024, 1), (1024, 33), (2048, 9), (4096, 17), (1 << 15, 7)])
+def test_ntt_ragged_batches(tf, oracle, n, batch):
+    """tile edges: batch counts that do not divide the per-workgroup tile"""
+    x = oracle.fill_random(n * batch, 31 * n + batch)
+    want = oracle.ntt(x, batch=batch, threads=8)
+    got = x.copy()
+    tf.ntt(got, batch=batch)
+    assert np.array_equal(got, want)
+    tf.intt(got, batch=batch)
+    assert np.array_equal(got, x)
+
+
+def test_ntt_edge_values(tf, oracle):
+    """all-zero, all-(p-1), single spike: extreme operands of the shift/reduce paths"""
+    for n in [64, 1024, 4096, 1 << 16]:
+        for fill in ("zero", "max", "spike", "alt"):
+            if fill == "zero":
+                x = np.zeros(n, dtype=np.uint64)
+            elif fill == "max":
+                x = np.full(n, oracle.bfe_new(MAX), dtype=np.uint64)
+            elif fill == "spike":
+                x = np.zeros(n, dtype=np.uint64)
+                x[n - 1] = np.uint64(P - 1)  # raw p-1
+            else:
+                x = np.array([P - 1, 0xFFFFFFFF, 0xFFFFFFFF00000000, 1] * (n // 4), dtype=np.uint64)
+            want = oracle.ntt(x)
+            got = x.copy()
+            tf.ntt(got)
+            assert np.array_equal(got, want), (n, fill)
+            want_i = oracle.intt(x)
+            got = x.copy()
+            tf.intt(got)
+            assert np.array_equal(got, want_i), (n, fill)
+
+
+def test_ntt_panics(tf):
+    """math/ntt.rs:135-140: not a power of two -> panic; empty and length-1 slices are fine"""
+    for n in [3, 5, 6, 12, 1000, 3 << 10]:
+        with pytest.raises(tf.NttPanic) as e:
+            tf.ntt(np.zeros(n, dtype=np.uint64))
+        assert e.value.code == 4
+    tf.ntt(np.zeros(0, dtype=np.uint64))
+    one = np.array([12345], dtype=np.uint64)
+    tf.ntt(one)
+    tf.intt(one)
+    assert int(one[0]) == 12345
+
+
+# ------------------------------------------------------------------ coset evaluation
+
+@pytest.mark.parametrize("width", [1, 3])
+@pytest.mark.parametrize("n_coeffs,order", [(1, 1), (1, 2), (3, 4), (11, 16), (16, 16), (20, 32), (700, 1024), (1024, 1024),
+                                            (1500, 2048), (5000, 8192), (1 << 16, 1 << 16), (300000, 1 << 20)])
+def test_coset_evaluate_matches_oracle(tf, oracle, width, n_coeffs, order):
+    batch = 2 if order <= 8192 else 1
+    c = oracle.fill_random(n_coeffs * width * batch, 77 + n_coeffs)
+    offset = oracle.bfe_new(7)  # benches/polynomial_coset.rs:20
+    got = tf.fast_coset_evaluate(c, offset, order, width=width, batch=batch).reshape(batch, -1)
+    for b in range(batch):
+        want = oracle.coset_evaluate(c[b * n_coeffs * width:(b + 1) * n_coeffs * width], offset, order, width=width)
+        assert np.array_equal(got[b], want)
+
+
+def test_coset_evaluate_other_offsets_and_polynomial_api(tf, oracle):
+    c = oracle.fill_random(100, 5)
+    for off_val in [1, 2, 7, MAX, 1234567890123456789]:
+        off = oracle.bfe_new(off_val)
+        assert np.array_equal(tf.fast_coset_evaluate(c, off, 128), oracle.coset_evaluate(c, off, 128))
+    poly = tf.Polynomial(np.concatenate([c, np.zeros(60, np.uint64)]))  # leading zeros are not degree
+    assert poly.degree() == 99
+    assert np.array_equal(poly.fast_coset_evaluate(oracle.bfe_new(7), 128), oracle.coset_evaluate(c, oracle.bfe_new(7), 128))
+    with pytest.raises(tf.NttPanic):  # polynomial.rs:1388-1392
+        poly.fast_coset_evaluate(oracle.bfe_new(7), 64)
+    with pytest.raises(tf.NttPanic):
+        tf.fast_coset_evaluate(c, oracle.bfe_new(7), 96)
+    zero = tf.fast_coset_evaluate(np.zeros(0, np.uint64), oracle.bfe_new(7), 16)
+    assert not zero.any() and zero.size == 16
+
+
+# ------------------------------------------------------------------ Tip5
+
+def test_tip5_random_batches(tf, oracle):
+    x = oracle.fill_random(10 * 20011, 42)
+    assert np.array_equal(tf.Tip5.hash_pairs(x), oracle.hash_pairs(x))
+    st = oracle.fill_random(16 * 1000, 43)
+    got = st.copy()
+    tf.Tip5.permute_states(got)
+    want = np.concatenate([oracle.tip5_permutation(st[16 * i:16 * i + 16]) for i in range(1000)])
+    assert np.array_equal(got, want)
+    l, r = x[:5], x[5:10]
+    assert np.array_equal(tf.Tip5.hash_pair(l, r), oracle.hash_pair(l, r))
+
+
+def test_tip5_degenerate_words_after_lookup(tf, oracle):
+    """states whose first four words look up to >= p patterns (tip5/mod.rs:222-242)"""
+    rows = []
+    for b in [0x00, 0xFE, 0xFF, 0x01, 0x80]:
+        w = int.from_bytes(bytes([b] * 8), "little") % P
+        rows.append([w] * 16)
+    st = np.array(rows, dtype=np.uint64).reshape(-1)
+    got = st.copy()
+    tf.Tip5.permute_states(got)
+    want = np.concatenate([oracle.tip5_permutation(st[16 * i:16 * i + 16]) for i in range(len(rows))])
+    assert np.array_equal(got, want)
+    assert (got < np.uint64(P)).all()
+
+
+@pytest.mark.parametrize("row_len", [0, 1, 5, 9, 10, 11, 19, 20, 21, 37, 100])
+def test_hash_varlen_rows(tf, oracle, row_len):
+    n_rows = 301
+    rows = oracle.fill_random(n_rows * row_len, 900 + row_len)
+    got = tf.Tip5.hash_varlen_rows(rows, row_len) if row_len else np.concatenate(
+        [tf.Tip5.hash_varlen(np.zeros(0, np.uint64)) for _ in range(3)])
+    if row_len:
+        assert np.array_equal(got, oracle.hash_varlen_rows(rows, row_len))
+    else:
+        assert np.array_equal(got, np.concatenate([oracle.hash_varlen(np.zeros(0, np.uint64))] * 3))
+
+
+# ------------------------------------------------------------------ Merkle
+
+@pytest.mark.parametrize("height", list(range(0, 14)) + [16])
+def test_merkle_build_matches_oracle(tf, oracle, height):
+    n = 1 << height
+    leaves = oracle.fill_random(5 * n, 300 + height)
+    tree = tf.MerkleTree.par_new(leaves)
+    want = oracle.merkle_build(leaves, threads=8).reshape(2 * n, 5)
+    assert np.array_equal(tree.nodes, want)
+    assert not tree.nodes[0].any()
+    assert tree.num_leafs() == n and tree.height() == height
+    assert np.array_equal(tf.MerkleTree.par_frugal_root(leaves), want[1])
+    assert np.array_equal(tf.MerkleTree.sequential_frugal_root(leaves), want[1])
+
+
+def test_merkle_batch_of_trees(tf, oracle):
+    for n, batch in [(1, 3), (8, 5), (256, 3), (512, 3), (4096, 7)]:
+        leaves = oracle.fill_random(5 * n * batch, 17 * n + batch)
+        got = tf.MerkleTree.build_batch(leaves, n)
+        roots = tf.MerkleTree.roots_batch(leaves, n)
+        for b in range(batch):
+            want = oracle.merkle_build(leaves[5 * n * b:5 * n * (b + 1)]).reshape(2 * n, 5)
+            assert np.array_equal(got[b], want)
+            assert np.array_equal(roots[b], want[1])
+
+
+def test_merkle_errors(tf, oracle):
+    """util_types/merkle_tree.rs:393-410, :933-965, :299-309, :332-335"""
+    with pytest.raises(tf.MerkleTreeError) as e:
+        tf.MerkleTree.par_new(np.zeros(0, np.uint64))
+    assert e.value.variant == "TooFewLeafs"
+    with pytest.raises(tf.MerkleTreeError) as e:
+        tf.MerkleTree.sequential_frugal_root(np.zeros(0, np.uint64))
+    assert e.value.variant == "TooFewLeafs"
+    with pytest.raises(tf.MerkleTreeError) as e:
+        tf.MerkleTree.par_frugal_root(np.zeros(0, np.uint64))
+    assert e.value.variant == "IncorrectNumberOfLeafs"
+    for n in [3, 5, 6, 7, 12, 1000]:
+        leaves = oracle.fill_random(5 * n, 1)
+        for fn in (tf.MerkleTree.par_new, tf.MerkleTree.par_frugal_root, tf.MerkleTree.sequential_frugal_root):
+            with pytest.raises(tf.MerkleTreeError) as e:
+                fn(leaves)
+            assert e.value.variant == "IncorrectNumberOfLeafs"
+
+
+# ------------------------------------------------------------------ device-pointer API, BASELINE sizes
+
+def _to_dev(a):
+    import torch
+
+    return torch.from_numpy(a.view(np.int64)).cuda()
+
+
+def _to_host(t):
+    return t.cpu().numpy().view(np.uint64)
+
+
+def test_device_api_small(tf, oracle):
+    import torch
+
+    n, batch = 1 << 12, 6
+    x = oracle.fill_random(n * batch, 5)
+    d = _to_dev(x)
+    tf.device.ntt_(d, n, batch=batch)
+    torch.cuda.synchronize()
+    assert np.array_equal(_to_host(d), oracle.ntt(x, batch=batch, threads=8))
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        tf.device.ntt_(d, n, batch=batch, inverse=True)
+    s.synchronize()
+    assert np.array_equal(_to_host(d), x)
+    leaves = oracle.fill_random(5 * 2048, 6)
+    dl = _to_dev(leaves)
+    nodes = torch.empty(10 * 2048, dtype=torch.int64, device="cuda")
+    root = torch.empty(5, dtype=torch.int64, device="cuda")
+    tf.device.merkle_build(dl, 2048, nodes)
+    tf.device.merkle_root(dl, 2048, root)
+    torch.cuda.synchronize()
+    want = oracle.merkle_build(leaves)
+    assert np.array_equal(_to_host(nodes), want)
+    assert np.array_equal(_to_host(root), want[5:10])
+
+
+def test_config2_256x2pow20_roundtrip_and_samples(tf, oracle):
+    """BASELINE config 2: 256 x 2^20 BFE on one GPU.  Full-size properties: intt(ntt(x)) == x for all
+    2^28 elements; sampled transforms are compared word for word with the oracle."""
+    import torch
+
+    n, batch = 1 << 20, 256
+    chunk = 16
+    d = torch.empty(n * batch, dtype=torch.int64, device="cuda")
+    host_chunks = {}
+    for c0 in range(0, batch, chunk):
+        h = oracle.fill_random(n * chunk, 0x7F210002 + c0)
+        if c0 in (0, 128, 240):
+            host_chunks[c0] = h
+        d[c0 * n:(c0 + chunk) * n] = _to_dev(h)
+    orig = d.clone()
+    tf.device.ntt_(d, n, batch=batch)
+    torch.cuda.synchronize()
+    for c0, h in host_chunks.items():
+        for b in (0, chunk - 1):
+            want = oracle.ntt(h[b * n:(b + 1) * n])
+            got = _to_host(d[(c0 + b) * n:(c0 + b + 1) * n])
+            assert np.array_equal(got, want), (c0, b)
+    tf.device.ntt_(d, n, batch=batch, inverse=True)
+    torch.cuda.synchronize()
+    assert torch.equal(d, orig)
+
+
+def test_config3_merkle_2pow24(tf, oracle):
+    """BASELINE config 3: 2^24-leaf tree on one GPU; root and every node match the CPU oracle
+    (oracle runs the par_new restatement on the host cores)."""
+    import torch
+
+    n = 1 << 24
+    leaves = oracle.fill_random(5 * n, 0x7F210003)
+    dl = _to_dev(leaves)
+    nodes = torch.empty(10 * n, dtype=torch.int64, device="cuda")
+    tf.device.merkle_build(dl, n, nodes)
+    torch.cuda.synchronize()
+    got = _to_host(nodes)
+    threads = min(64, os.cpu_count() or 8)
+    want = oracle.merkle_build(leaves, threads=threads)
+    assert np.array_equal(got[5:10], want[5:10]), "root mismatch"
+    assert np.array_equal(got, want)
+
+
+def test_config4_xfe_coset_eval_2pow22(tf, oracle):
+    """BASELINE config 4 shape (XFE, 2^22 coefficients, order 2^22, offset 7) on a batch of 2;
+    compared word for word with the oracle."""
+    import torch
+
+    n, batch = 1 << 22, 2
+    c = oracle.fill_random(3 * n * batch, 0x7F210004)
+    dc = _to_dev(c)
+    out = torch.empty(3 * n * batch, dtype=torch.int64, device="cuda")
+    off = oracle.bfe_new(7)
+    tf.device.coset_evaluate(dc, n, off, out, n, batch=batch, width=3)
+    torch.cuda.synchronize()
+    got = _to_host(out)
+    for b in range(batch):
+        want = oracle.coset_evaluate(c[3 * n * b:3 * n * (b + 1)], off, n, width=3)
+        assert np.array_equal(got[3 * n * b:3 * n * (b + 1)], want)

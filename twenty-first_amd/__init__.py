@@ -1,0 +1,320 @@
+"""twenty_first_amd -- host-side mirror of the reference's API for the hot path, on top of the
+C ABI of libtf_hip.so (include/tf_hip.h).  Python is only the harness language here (tests,
+bench); the C++ mirror of the same interface is host/twenty_first.hpp.
+
+Names, argument meaning and error behaviour follow the Rust crate (paths relative to
+/root/reference/twenty-first/src/):
+
+    ntt / intt                       math/ntt.rs:67-82, :109-125
+    Polynomial.fast_coset_evaluate   math/polynomial.rs:1374-1399
+    Tip5.hash_10 / hash_pair / hash_varlen / permutation   tip5/mod.rs:529-623
+    MerkleTree.par_new / sequential_new / par_frugal_root / sequential_frugal_root
+                                     util_types/merkle_tree.rs:149-364
+    MerkleTreeError                  util_types/merkle_tree.rs:933-965
+
+Data are numpy uint64 arrays of RAW Montgomery words exactly as the Rust types lay them out
+(BFieldElement 1 word, XFieldElement 3, Digest 5); `BFieldElement.new/value` convert single values.
+Every operation runs on the GPU through the C ABI; there is no CPU fallback -- a missing library
+or device raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+__all__ = [
+    "P", "BFieldElement", "ntt", "intt", "Polynomial", "fast_coset_evaluate", "Tip5", "Digest", "MerkleTree",
+    "MerkleTreeError", "TwentyFirstError", "NttPanic", "lib", "device",
+]
+
+P = 0xFFFFFFFF00000001  # BFieldElement::P, math/b_field_element.rs:225
+_R = 1 << 64
+_R_INV = pow(_R, P - 2, P)
+
+
+def lib():
+    return _lib.lib()
+
+
+# ----------------------------------------------------------------------------- errors
+class TwentyFirstError(RuntimeError):
+    def __init__(self, code: int, where: str = ""):
+        name = lib().tf_status_string(code).decode()
+        detail = lib().tf_last_error().decode()
+        msg = f"{where}: {name}" if where else name
+        if detail and code >= 8:
+            msg += f" ({detail})"
+        super().__init__(msg)
+        self.code = code
+
+
+class NttPanic(TwentyFirstError):
+    """Raised where the reference panics (math/ntt.rs:135-140, math/polynomial.rs:1388-1392)."""
+
+
+class MerkleTreeError(TwentyFirstError):
+    """util_types/merkle_tree.rs:933-965; .variant is the Rust variant name."""
+
+    VARIANTS = {1: "TooFewLeafs", 2: "IncorrectNumberOfLeafs", 3: "TreeTooHigh"}
+
+    def __init__(self, code: int, where: str = ""):
+        super().__init__(code, where)
+        self.variant = self.VARIANTS.get(code, "Unknown")
+
+
+def _check(rc: int, where: str):
+    if rc == 0:
+        return
+    if rc in (1, 2, 3):
+        raise MerkleTreeError(rc, where)
+    if rc in (4, 5, 6):
+        raise NttPanic(rc, where)
+    raise TwentyFirstError(rc, where)
+
+
+# ----------------------------------------------------------------------------- scalars
+class BFieldElement:
+    """Conversions between canonical values and raw Montgomery words (host-side convenience;
+    math/b_field_element.rs:235-237, :248-250)."""
+
+    P = P
+    MAX = P - 1
+
+    @staticmethod
+    def new(value: int) -> int:
+        return (value % (1 << 64)) % P * _R % P
+
+    @staticmethod
+    def value(raw: int) -> int:
+        return int(raw) * _R_INV % P
+
+    @staticmethod
+    def generator() -> int:
+        return BFieldElement.new(7)  # :312-314
+
+    @staticmethod
+    def primitive_root_of_unity(n: int):
+        """:814-818; raw word, or None if n is not 0/1/a power of two <= 2^32."""
+        if n in (0, 1):
+            return BFieldElement.new(1)
+        if n & (n - 1) or n > (1 << 32):
+            return None
+        return BFieldElement.new(pow(7, (P - 1) // n, P))
+
+
+def _words(x, name="x") -> np.ndarray:
+    if not isinstance(x, np.ndarray) or x.dtype != np.uint64 or not x.flags["C_CONTIGUOUS"]:
+        raise TypeError(f"{name} must be a C-contiguous numpy uint64 array of raw Montgomery words")
+    return x
+
+
+def _ptr(a: np.ndarray):
+    return C.c_void_p(a.ctypes.data) if a.size else C.c_void_p(0)
+
+
+# ----------------------------------------------------------------------------- NTT
+def ntt(x: np.ndarray, width: int = 1, batch: int = 1, _inverse: bool = False) -> None:
+    """In-place NTT of `batch` contiguous slices (math/ntt.rs:67-82).  width 1 = BFieldElement slice,
+    3 = XFieldElement slice.  Raises NttPanic where the reference panics."""
+    x = _words(x)
+    if width not in (1, 3):
+        raise ValueError("width must be 1 (BFieldElement) or 3 (XFieldElement)")
+    if batch < 0 or (batch and x.size % (batch * width)):
+        raise ValueError("array size is not batch * n * width")
+    n = x.size // (batch * width) if batch else 0
+    fn = lib().tf_ntt_bfe if width == 1 else lib().tf_ntt_xfe
+    _check(fn(_ptr(x), n, batch, int(_inverse)), "intt" if _inverse else "ntt")
+
+
+def intt(x: np.ndarray, width: int = 1, batch: int = 1) -> None:
+    """In-place inverse NTT (math/ntt.rs:109-125)."""
+    ntt(x, width=width, batch=batch, _inverse=True)
+
+
+def fast_coset_evaluate(coeffs: np.ndarray, offset_raw: int, order: int, width: int = 1, batch: int = 1) -> np.ndarray:
+    """`batch` polynomials of equal length -> `batch` x `order` evaluations (math/polynomial.rs:1374-1399)."""
+    coeffs = _words(coeffs, "coeffs")
+    if batch and coeffs.size % (batch * width):
+        raise ValueError("coeffs size is not batch * n_coeffs * width")
+    n_coeffs = coeffs.size // (batch * width) if batch else 0
+    out = np.empty(batch * order * width, dtype=np.uint64)
+    fn = lib().tf_coset_eval_bfe if width == 1 else lib().tf_coset_eval_xfe
+    _check(fn(_ptr(coeffs), n_coeffs, C.c_uint64(offset_raw), _ptr(out), order, batch), "fast_coset_evaluate")
+    return out
+
+
+class Polynomial:
+    """Coefficients low -> high degree (math/polynomial.rs:78-84); only the hot-path members."""
+
+    def __init__(self, coefficients: np.ndarray, width: int = 1):
+        c = _words(np.ascontiguousarray(coefficients, dtype=np.uint64), "coefficients").reshape(-1)
+        self.width = width
+        n = c.size // width
+        c = c.reshape(n, width)
+        while n and not c[n - 1].any():  # Polynomial::new normalises: leading zeros do not count (:degree)
+            n -= 1
+        self.coefficients = np.ascontiguousarray(c[:n]).reshape(-1)
+
+    def degree(self) -> int:
+        return self.coefficients.size // self.width - 1
+
+    def fast_coset_evaluate(self, offset_raw: int, order: int) -> np.ndarray:
+        if order <= self.degree():  # :1388-1392
+            raise NttPanic(6, "fast_coset_evaluate")
+        return fast_coset_evaluate(self.coefficients, offset_raw, order, width=self.width, batch=1)
+
+
+# ----------------------------------------------------------------------------- Tip5
+class Digest:
+    LEN = 5  # tip5/digest.rs:49
+    BYTES = 40
+
+    @staticmethod
+    def to_hex(d) -> str:
+        """Canonical values as little-endian bytes (tip5/digest.rs:85-90, :144-153)."""
+        return b"".join(BFieldElement.value(int(v)).to_bytes(8, "little") for v in d).hex()
+
+
+class Tip5:
+    RATE = 10
+    STATE_SIZE = 16
+
+    @staticmethod
+    def permute_states(states: np.ndarray) -> None:
+        """In-place Tip5::permutation on count x 16 raw words (tip5/mod.rs:529-533)."""
+        states = _words(states, "states")
+        if states.size % 16:
+            raise ValueError("states must hold a multiple of 16 words")
+        _check(lib().tf_tip5_permute(_ptr(states), states.size // 16), "Tip5::permutation")
+
+    @staticmethod
+    def permutation(state: np.ndarray) -> np.ndarray:
+        s = np.ascontiguousarray(state, dtype=np.uint64).copy()
+        Tip5.permute_states(s)
+        return s
+
+    @staticmethod
+    def hash_pairs(inp: np.ndarray) -> np.ndarray:
+        """count x 10 words -> count x 5 words; row i is hash_10 of its 10 words (tip5/mod.rs:559-586)."""
+        inp = _words(inp, "in")
+        if inp.size % 10:
+            raise ValueError("input must hold a multiple of 10 words")
+        out = np.empty(inp.size // 2, dtype=np.uint64)
+        _check(lib().tf_tip5_hash_pairs(_ptr(inp), _ptr(out), inp.size // 10), "Tip5::hash_pair")
+        return out
+
+    @staticmethod
+    def hash_10(inp) -> np.ndarray:
+        a = np.ascontiguousarray(inp, dtype=np.uint64)
+        if a.size != 10:
+            raise ValueError("hash_10 takes exactly 10 elements")
+        return Tip5.hash_pairs(a)
+
+    @staticmethod
+    def hash_pair(left, right) -> np.ndarray:
+        a = np.concatenate([np.asarray(left, dtype=np.uint64), np.asarray(right, dtype=np.uint64)])
+        if a.size != 10:
+            raise ValueError("hash_pair takes two digests")
+        return Tip5.hash_pairs(a)
+
+    @staticmethod
+    def hash_varlen_rows(rows: np.ndarray, row_len: int) -> np.ndarray:
+        rows = _words(rows, "rows")
+        if row_len < 0 or (row_len and rows.size % row_len):
+            raise ValueError("rows size is not n_rows * row_len")
+        n_rows = rows.size // row_len if row_len else 0
+        out = np.empty(n_rows * 5, dtype=np.uint64)
+        _check(lib().tf_tip5_hash_varlen_rows(_ptr(rows), row_len, n_rows, _ptr(out)), "Tip5::hash_varlen")
+        return out
+
+    @staticmethod
+    def hash_varlen(inp) -> np.ndarray:
+        """tip5/mod.rs:617-623.  (One row; the empty input is one row of length 0.)"""
+        a = np.ascontiguousarray(inp, dtype=np.uint64).reshape(-1)
+        out = np.empty(5, dtype=np.uint64)
+        _check(lib().tf_tip5_hash_varlen_rows(_ptr(a), a.size, 1, _ptr(out)), "Tip5::hash_varlen")
+        return out
+
+
+# ----------------------------------------------------------------------------- Merkle tree
+class MerkleTree:
+    """nodes: (2n, 5) raw words in the reference's heap layout (util_types/merkle_tree.rs:85-88):
+    nodes[0] dummy, nodes[1] root, leaves at nodes[n:]."""
+
+    ROOT_INDEX = 1
+
+    def __init__(self, nodes: np.ndarray):
+        self.nodes = nodes
+
+    @classmethod
+    def par_new(cls, leafs: np.ndarray) -> "MerkleTree":  # :165-212
+        leafs = _words(np.ascontiguousarray(leafs, dtype=np.uint64).reshape(-1), "leafs")
+        if leafs.size % 5:
+            raise ValueError("leafs must hold whole digests (5 words each)")
+        n = leafs.size // 5
+        nodes = np.empty(max(10 * n, 1), dtype=np.uint64)
+        _check(lib().tf_merkle_build(_ptr(leafs), n, _ptr(nodes), 1), "MerkleTree::par_new")
+        return cls(nodes[: 10 * n].reshape(2 * n, 5))
+
+    sequential_new = par_new  # :149-153 -- same result by construction (tests :1059-1087)
+
+    @staticmethod
+    def build_batch(leafs: np.ndarray, n_leafs: int) -> np.ndarray:
+        """`batch` independent trees of n_leafs leaves each -> (batch, 2n, 5)."""
+        leafs = _words(leafs, "leafs")
+        if n_leafs <= 0 or leafs.size % (5 * n_leafs):
+            if n_leafs == 0:
+                raise MerkleTreeError(1, "MerkleTree::par_new")
+            raise ValueError("leafs size is not batch * n_leafs * 5")
+        batch = leafs.size // (5 * n_leafs)
+        nodes = np.empty(batch * 10 * n_leafs, dtype=np.uint64)
+        _check(lib().tf_merkle_build(_ptr(leafs), n_leafs, _ptr(nodes), batch), "MerkleTree::par_new")
+        return nodes.reshape(batch, 2 * n_leafs, 5)
+
+    @staticmethod
+    def sequential_frugal_root(leafs: np.ndarray) -> np.ndarray:  # :299-309
+        leafs = _words(np.ascontiguousarray(leafs, dtype=np.uint64).reshape(-1), "leafs")
+        n = leafs.size // 5
+        root = np.empty(5, dtype=np.uint64)
+        _check(lib().tf_merkle_root(_ptr(leafs), n, _ptr(root), 1), "MerkleTree::sequential_frugal_root")
+        return root
+
+    @staticmethod
+    def par_frugal_root(leafs: np.ndarray) -> np.ndarray:  # :332-364
+        a = np.asarray(leafs)
+        if a.size == 0:  # is_power_of_two() is false for 0  (:333-335)
+            raise MerkleTreeError(2, "MerkleTree::par_frugal_root")
+        return MerkleTree.sequential_frugal_root(leafs)
+
+    @staticmethod
+    def roots_batch(leafs: np.ndarray, n_leafs: int) -> np.ndarray:
+        leafs = _words(leafs, "leafs")
+        batch = leafs.size // (5 * n_leafs) if n_leafs else 0
+        roots = np.empty(max(batch, 1) * 5, dtype=np.uint64)
+        _check(lib().tf_merkle_root(_ptr(leafs), n_leafs, _ptr(roots), batch), "MerkleTree::par_frugal_root")
+        return roots[: batch * 5].reshape(batch, 5)
+
+    def root(self) -> np.ndarray:  # :624-626
+        return self.nodes[1]
+
+    def num_leafs(self) -> int:  # :628-631
+        return self.nodes.shape[0] // 2
+
+    def height(self) -> int:  # :633-636
+        return self.num_leafs().bit_length() - 1
+
+    def node(self, i: int):  # :638-645
+        return self.nodes[i] if 0 <= i < self.nodes.shape[0] else None
+
+    def leafs(self) -> np.ndarray:  # :647-652
+        return self.nodes[self.num_leafs():]
+
+    def leaf(self, i: int):  # :654-661
+        n = self.num_leafs()
+        return self.nodes[n + i] if 0 <= i < n else None
+
+
+from . import device  # noqa: E402  (torch device-pointer API)

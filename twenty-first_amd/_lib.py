@@ -1,0 +1,99 @@
+"""ctypes loader for libtf_hip.so (the C ABI of include/tf_hip.h).
+
+The library is the product: if it is missing or does not load, importing this module raises --
+there is no Python/CPU fallback for any operation.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "libtf_hip.so")
+HEADER = os.path.join(os.path.dirname(_HERE), "include", "tf_hip.h")
+
+_u64p = C.POINTER(C.c_uint64)
+_sz = C.c_size_t
+_vp = C.c_void_p
+
+# name -> (restype, argtypes); must list every function declared in include/tf_hip.h
+SIGNATURES = {
+    "tf_status_string": (C.c_char_p, [C.c_int]),
+    "tf_last_error": (C.c_char_p, []),
+    "tf_version": (C.c_int, []),
+    "tf_device_count": (C.c_int, []),
+    "tf_ntt_bfe": (C.c_int, [_vp, _sz, _sz, C.c_int]),
+    "tf_ntt_xfe": (C.c_int, [_vp, _sz, _sz, C.c_int]),
+    "tf_ntt_bfe_dev": (C.c_int, [_vp, _sz, _sz, C.c_int, _vp]),
+    "tf_ntt_xfe_dev": (C.c_int, [_vp, _sz, _sz, C.c_int, _vp]),
+    "tf_coset_eval_bfe": (C.c_int, [_vp, _sz, C.c_uint64, _vp, _sz, _sz]),
+    "tf_coset_eval_xfe": (C.c_int, [_vp, _sz, C.c_uint64, _vp, _sz, _sz]),
+    "tf_coset_eval_bfe_dev": (C.c_int, [_vp, _sz, C.c_uint64, _vp, _sz, _sz, _vp]),
+    "tf_coset_eval_xfe_dev": (C.c_int, [_vp, _sz, C.c_uint64, _vp, _sz, _sz, _vp]),
+    "tf_tip5_permute": (C.c_int, [_vp, _sz]),
+    "tf_tip5_hash_pairs": (C.c_int, [_vp, _vp, _sz]),
+    "tf_tip5_hash_varlen_rows": (C.c_int, [_vp, _sz, _sz, _vp]),
+    "tf_tip5_permute_dev": (C.c_int, [_vp, _sz, _vp]),
+    "tf_tip5_hash_pairs_dev": (C.c_int, [_vp, _vp, _sz, _vp]),
+    "tf_tip5_hash_varlen_rows_dev": (C.c_int, [_vp, _sz, _sz, _vp, _vp]),
+    "tf_merkle_build": (C.c_int, [_vp, _sz, _vp, _sz]),
+    "tf_merkle_root": (C.c_int, [_vp, _sz, _vp, _sz]),
+    "tf_merkle_build_dev": (C.c_int, [_vp, _sz, _vp, _sz, _vp]),
+    "tf_merkle_root_dev": (C.c_int, [_vp, _sz, _vp, _sz, _vp]),
+    "tf_set_ntt_tile_bytes": (None, [_sz]),
+    "tf_get_ntt_tile_bytes": (_sz, []),
+}
+
+
+def build(force: bool = False) -> str:
+    """Compile libtf_hip.so for gfx950 with hipcc (works without a GPU)."""
+    csrc = os.path.join(_HERE, "csrc")
+    args = ["make", "-C", csrc]
+    if force:
+        args.append("-B")
+    subprocess.check_call(args, stdout=subprocess.DEVNULL)
+    return SO_PATH
+
+
+_lib = None
+
+
+def _load_hip_runtime() -> None:
+    """libtf_hip.so is linked without DT_NEEDED on libamdhip64 (csrc/Makefile) so that the process
+    holds exactly ONE HIP runtime: the one torch ships when torch is used for device memory/streams
+    (two runtimes in one process cannot share a device), otherwise /opt/rocm's."""
+    candidates = []
+    try:
+        import torch  # noqa: F401  (maps torch/lib/libamdhip64.so)
+
+        candidates.append(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
+    except Exception:  # torch absent: fine, the library itself never needs it
+        pass
+    candidates += ["/opt/rocm/lib/libamdhip64.so", "libamdhip64.so"]
+    errors = []
+    for path in candidates:
+        try:
+            C.CDLL(path, mode=C.RTLD_GLOBAL)
+            return
+        except OSError as e:
+            errors.append(f"{path}: {e}")
+    raise ImportError("cannot load a HIP runtime (libamdhip64): " + "; ".join(errors))
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise ImportError(
+                f"{SO_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  There is no CPU fallback."
+            )
+        _load_hip_runtime()
+        L = C.CDLL(SO_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError if the .so does not export what the header declares
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib

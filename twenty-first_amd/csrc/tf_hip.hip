@@ -1,0 +1,1008 @@
+// tf_hip.hip -- host side of libtf_hip.so: C ABI (include/tf_hip.h), pass planner, table cache.
+//
+// One process drives one or more MI355X devices; all state is per HIP device and guarded by a mutex,
+// kernels are enqueued on the caller's stream, and nothing here synchronises the device except the
+// one-off construction of a twiddle table.  There is no CPU fallback anywhere in this file.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/tf_hip.h"
+#include "gl64.h"
+#include "ntt_kernels.h"
+#include "tip5_kernels.h"
+
+using gl::u32;
+using gl::u64;
+
+namespace {
+
+// ------------------------------------------------------------------------------------ errors
+thread_local std::string t_last_error;
+
+int hip_fail(hipError_t e, const char* what, const char* file, int line) {
+    char buf[512];
+    snprintf(buf, sizeof(buf), "%s failed: %s (%s:%d)", what, hipGetErrorString(e), file, line);
+    t_last_error = buf;
+    (void)hipGetLastError();
+    if (e == hipErrorNoDevice || e == hipErrorInvalidDevice || e == hipErrorInsufficientDriver || e == hipErrorNotInitialized)
+        return TF_ERR_NO_DEVICE;
+    if (e == hipErrorOutOfMemory || e == hipErrorMemoryAllocation) return TF_ERR_OUT_OF_MEMORY;
+    return TF_ERR_HIP;
+}
+#define HIPCHK(call)                                                        \
+    do {                                                                    \
+        hipError_t e_ = (call);                                             \
+        if (e_ != hipSuccess) return hip_fail(e_, #call, __FILE__, __LINE__); \
+    } while (0)
+
+// ------------------------------------------------------------------------------------ field helpers (host)
+// w_n = 7^((p-1)/n): equals every entry of PRIMITIVE_ROOTS (b_field_element.rs:43-78).
+u64 root_of_unity_mont(int log_n) { return gl::mont_pow(gl::to_mont(7), (gl::P - 1) >> log_n); }
+
+int ilog2(size_t v) {
+    int l = 0;
+    while ((size_t(1) << l) < v) ++l;
+    return l;
+}
+
+// ------------------------------------------------------------------------------------ Tip5 constants
+// ROUND_CONSTANTS, tip5/mod.rs:68-149 (canonical values; converted to Montgomery form at upload).
+const u64 kRoundConstants[80] = {
+    13630775303355457758ULL, 16896927574093233874ULL, 10379449653650130495ULL, 1965408364413093495ULL,
+    15232538947090185111ULL, 15892634398091747074ULL, 3989134140024871768ULL,  2851411912127730865ULL,
+    8709136439293758776ULL,  3694858669662939734ULL,  12692440244315327141ULL, 10722316166358076749ULL,
+    12745429320441639448ULL, 17932424223723990421ULL, 7558102534867937463ULL,  15551047435855531404ULL,
+    17532528648579384106ULL, 5216785850422679555ULL,  15418071332095031847ULL, 11921929762955146258ULL,
+    9738718993677019874ULL,  3464580399432997147ULL,  13408434769117164050ULL, 264428218649616431ULL,
+    4436247869008081381ULL,  4063129435850804221ULL,  2865073155741120117ULL,  5749834437609765994ULL,
+    6804196764189408435ULL,  17060469201292988508ULL, 9475383556737206708ULL,  12876344085611465020ULL,
+    13835756199368269249ULL, 1648753455944344172ULL,  9836124473569258483ULL,  12867641597107932229ULL,
+    11254152636692960595ULL, 16550832737139861108ULL, 11861573970480733262ULL, 1256660473588673495ULL,
+    13879506000676455136ULL, 10564103842682358721ULL, 16142842524796397521ULL, 3287098591948630584ULL,
+    685911471061284805ULL,   5285298776918878023ULL,  18310953571768047354ULL, 3142266350630002035ULL,
+    549990724933663297ULL,   4901984846118077401ULL,  11458643033696775769ULL, 8706785264119212710ULL,
+    12521758138015724072ULL, 11877914062416978196ULL, 11333318251134523752ULL, 3933899631278608623ULL,
+    16635128972021157924ULL, 10291337173108950450ULL, 4142107155024199350ULL,  16973934533787743537ULL,
+    11068111539125175221ULL, 17546769694830203606ULL, 5315217744825068993ULL,  4609594252909613081ULL,
+    3350107164315270407ULL,  17715942834299349177ULL, 9600609149219873996ULL,  12894357635820003949ULL,
+    4597649658040514631ULL,  7735563950920491847ULL,  1663379455870887181ULL,  13889298103638829706ULL,
+    7375530351220884434ULL,  3502022433285269151ULL,  9231805330431056952ULL,  9252272755288523725ULL,
+    10014268662326746219ULL, 15565031632950843234ULL, 1209725273521819323ULL,  6024642864597845108ULL,
+};
+
+// ------------------------------------------------------------------------------------ per-device context
+struct DeviceCtx {
+    std::mutex mu;
+    std::map<u64, u64*> tables;           // twiddle tables, never freed while the process lives
+    std::map<std::pair<u64, u64>, u64*> pow_tables;  // (offset_raw, n) -> offset^j table
+    bool tip5_ready = false;
+};
+
+constexpr int kMaxDevices = 64;
+DeviceCtx g_ctx[kMaxDevices];
+
+int current_ctx(DeviceCtx** out) {
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) {
+        t_last_error = std::string("no usable HIP device: ") + hipGetErrorString(e);
+        (void)hipGetLastError();
+        return TF_ERR_NO_DEVICE;
+    }
+    int dev = 0;
+    HIPCHK(hipGetDevice(&dev));
+    if (dev < 0 || dev >= kMaxDevices) return TF_ERR_NO_DEVICE;
+    *out = &g_ctx[dev];
+    return TF_OK;
+}
+
+size_t g_tile_bytes = 0;
+std::once_flag g_env_once;
+void read_env() {
+    std::call_once(g_env_once, [] {
+        if (g_tile_bytes == 0) {
+            const char* s = getenv("TF_NTT_TILE_BYTES");
+            g_tile_bytes = s ? strtoull(s, nullptr, 10) : (size_t(96) << 20);
+            if (g_tile_bytes == 0) g_tile_bytes = size_t(96) << 20;
+        }
+    });
+}
+
+int upload_table(const std::vector<u64>& host, u64** dev) {
+    u64* d = nullptr;
+    HIPCHK(hipMalloc(&d, host.size() * sizeof(u64)));
+    hipError_t e = hipMemcpy(d, host.data(), host.size() * sizeof(u64), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        (void)hipFree(d);
+        return hip_fail(e, "hipMemcpy(table)", __FILE__, __LINE__);
+    }
+    *dev = d;
+    return TF_OK;
+}
+
+// split powers: hi[i] = base^(i << h), lo[i] = base^i  (both Montgomery)
+void split_powers(u64 base, int log_total, int* h_out, std::vector<u64>* hi, std::vector<u64>* lo) {
+    int h = (log_total + 1) / 2;
+    size_t nlo = size_t(1) << h, nhi = size_t(1) << (log_total - h);
+    lo->resize(nlo);
+    hi->resize(nhi);
+    u64 acc = gl::ONE;
+    for (size_t i = 0; i < nlo; ++i) {
+        (*lo)[i] = acc;
+        acc = gl::mont_mul(acc, base);
+    }
+    u64 step = acc;  // base^(2^h)
+    acc = gl::ONE;
+    for (size_t i = 0; i < nhi; ++i) {
+        (*hi)[i] = acc;
+        acc = gl::mont_mul(acc, step);
+    }
+    *h_out = h;
+}
+
+enum : u64 { TAG_INNER = 1, TAG_POST = 2, TAG_TINY = 3 };
+u64 make_key(u64 tag, u64 a, u64 b, u64 c, u64 d) { return (tag << 56) | (a << 40) | (b << 24) | (c << 8) | d; }
+
+// inner[g*32 + k1] = w_R^(+-g*k1) * (scale_log_n ? n^-1 : 1),  R = 32 << p2
+int get_inner_table(DeviceCtx* ctx, int a, bool inverse, int scale_log_n, const u64** out) {
+    const int p2 = a - 5;
+    if (p2 == 0 && scale_log_n == 0) {
+        *out = nullptr;
+        return TF_OK;
+    }
+    const u64 key = make_key(TAG_INNER, a, inverse, scale_log_n, 0);
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    auto it = ctx->tables.find(key);
+    if (it != ctx->tables.end()) {
+        *out = it->second;
+        return TF_OK;
+    }
+    const int P2 = 1 << p2;
+    u64 w = root_of_unity_mont(a);
+    if (inverse) w = gl::mont_inverse(w);
+    u64 scale = gl::ONE;
+    if (scale_log_n) scale = gl::mont_inverse(gl::to_mont(u64(1) << scale_log_n));
+    std::vector<u64> t(size_t(P2) * 32);
+    u64 wg = gl::ONE;  // w^g
+    for (int g = 0; g < P2; ++g) {
+        u64 acc = scale;
+        for (int k = 0; k < 32; ++k) {
+            t[size_t(g) * 32 + k] = acc;
+            acc = gl::mont_mul(acc, wg);
+        }
+        wg = gl::mont_mul(wg, w);
+    }
+    u64* d = nullptr;
+    int rc = upload_table(t, &d);
+    if (rc) return rc;
+    ctx->tables[key] = d;
+    *out = d;
+    return TF_OK;
+}
+
+// T[k*B + b] = w_M^(+-k*b), k < R = 2^a, b < B = M / R
+int get_post_table(DeviceCtx* ctx, int log_m, int a, bool inverse, const u64** out) {
+    const u64 key = make_key(TAG_POST, log_m, a, inverse, 0);
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    auto it = ctx->tables.find(key);
+    if (it != ctx->tables.end()) {
+        *out = it->second;
+        return TF_OK;
+    }
+    u64 w = root_of_unity_mont(log_m);
+    if (inverse) w = gl::mont_inverse(w);
+    int h = 0;
+    std::vector<u64> hi, lo;
+    split_powers(w, log_m, &h, &hi, &lo);
+    u64 *d_hi = nullptr, *d_lo = nullptr, *d = nullptr;
+    int rc = upload_table(hi, &d_hi);
+    if (rc) return rc;
+    rc = upload_table(lo, &d_lo);
+    if (rc) return rc;
+    const long long M = 1ll << log_m, R = 1ll << a, B = M / R;
+    HIPCHK(hipMalloc(&d, size_t(M) * sizeof(u64)));
+    const int threads = 256;
+    const long long blocks = (M + threads - 1) / threads;
+    hipLaunchKernelGGL(tfk::build_post_tw_kernel, dim3((unsigned)blocks), dim3(threads), 0, 0, d, d_hi, d_lo, h, R, B);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(0));
+    HIPCHK(hipFree(d_hi));
+    HIPCHK(hipFree(d_lo));
+    ctx->tables[key] = d;
+    *out = d;
+    return TF_OK;
+}
+
+// stage tables of the reference (ntt.rs:309-324) for n <= 16
+int get_tiny_table(DeviceCtx* ctx, int log_n, bool inverse, const u64** out) {
+    const u64 key = make_key(TAG_TINY, log_n, inverse, 0, 0);
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    auto it = ctx->tables.find(key);
+    if (it != ctx->tables.end()) {
+        *out = it->second;
+        return TF_OK;
+    }
+    const int n = 1 << log_n;
+    std::vector<u64> t(std::max(1, n - 1), gl::ONE);
+    u64 w = root_of_unity_mont(log_n);
+    if (inverse) w = gl::mont_inverse(w);
+    for (int i = 0; i < log_n; ++i) {
+        const int m = 1 << i;
+        u64 wm = gl::mont_pow(w, u64(n / (2 * m)));
+        u64 acc = gl::ONE;
+        for (int j = 0; j < m; ++j) {
+            t[m - 1 + j] = acc;
+            acc = gl::mont_mul(acc, wm);
+        }
+    }
+    u64* d = nullptr;
+    int rc = upload_table(t, &d);
+    if (rc) return rc;
+    ctx->tables[key] = d;
+    *out = d;
+    return TF_OK;
+}
+
+// offset^j, j < n  (the power chain of Polynomial::scale, polynomial.rs:766-771)
+int get_pow_table(DeviceCtx* ctx, u64 offset_raw, size_t n, const u64** out) {
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    auto key = std::make_pair(offset_raw, u64(n));
+    auto it = ctx->pow_tables.find(key);
+    if (it != ctx->pow_tables.end()) {
+        *out = it->second;
+        return TF_OK;
+    }
+    if (ctx->pow_tables.size() >= 16) {  // bounded cache: drop everything (callers hold no references across calls)
+        HIPCHK(hipDeviceSynchronize());
+        for (auto& kv : ctx->pow_tables) (void)hipFree(kv.second);
+        ctx->pow_tables.clear();
+    }
+    const int log_total = std::max(1, ilog2(n));
+    int h = 0;
+    std::vector<u64> hi, lo;
+    split_powers(offset_raw, log_total, &h, &hi, &lo);
+    u64 *d_hi = nullptr, *d_lo = nullptr, *d = nullptr;
+    int rc = upload_table(hi, &d_hi);
+    if (rc) return rc;
+    rc = upload_table(lo, &d_lo);
+    if (rc) return rc;
+    HIPCHK(hipMalloc(&d, std::max<size_t>(n, 1) * sizeof(u64)));
+    const int threads = 256;
+    const long long blocks = ((long long)n + threads - 1) / threads;
+    if (n) {
+        hipLaunchKernelGGL(tfk::build_pow_table_kernel, dim3((unsigned)blocks), dim3(threads), 0, 0, d, d_hi, d_lo, h,
+                           (long long)n);
+        HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipStreamSynchronize(0));
+    HIPCHK(hipFree(d_hi));
+    HIPCHK(hipFree(d_lo));
+    ctx->pow_tables[key] = d;
+    *out = d;
+    return TF_OK;
+}
+
+int ensure_tip5(DeviceCtx* ctx) {
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (ctx->tip5_ready) return TF_OK;
+    tfk::Tip5Consts c;
+    for (int i = 0; i < 80; ++i) c.rc[i] = gl::to_mont(kRoundConstants[i]);
+    unsigned char lut[256];
+    for (int x = 0; x < 256; ++x) {  // L(x) = ((x+1)^3 mod 257) - 1, tip5/mod.rs:1022-1026 (table :50-64)
+        u64 xx = u64(x) + 1;
+        lut[x] = (unsigned char)(((xx * xx * xx) + 256) % 257);
+    }
+    memcpy(c.lut, lut, 256);
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(tfk::g_tip5), &c, sizeof(c)));
+    HIPCHK(hipDeviceSynchronize());
+    ctx->tip5_ready = true;
+    return TF_OK;
+}
+
+// ------------------------------------------------------------------------------------ NTT planner
+struct Launch {
+    tfk::NttPassArgs a;
+    unsigned tiles;
+    unsigned threads;
+    size_t lds_bytes;
+};
+
+int pad_to_residue(int base, int residue) {  // smallest s >= base with s == residue (mod 32)
+    int r = ((residue - base) % 32 + 32) % 32;
+    return base + r;
+}
+
+// Column pass ("type A"): view [batch][outer][R][B*L words]; DFT along R for each column; in-place geometry.
+Launch plan_column_pass(const u64* in, u64* out, long long in_bs, long long out_bs, size_t batch, long long outer, int a,
+                        long long B, int L) {
+    Launch l{};
+    tfk::NttPassArgs& A = l.a;
+    const int p2 = a - 5, P2 = 1 << p2;
+    const long long R = 1ll << a, Bw = B * L;
+    int nc = 256 / P2;
+    if (nc > Bw) nc = (int)Bw;
+    A.in = in;
+    A.out = out;
+    A.p2 = p2;
+    A.nc = nc;
+    A.L = L;
+    A.d1 = (u32)outer;
+    A.d2 = (u32)((Bw + nc - 1) / nc);
+    A.ib0 = in_bs;
+    A.ib1 = R * Bw;
+    A.ib2 = nc;
+    A.ob0 = out_bs;
+    A.ob1 = R * Bw;
+    A.ob2 = nc;
+    A.in_cs_hi = L;
+    A.out_cs_hi = L;
+    A.in_rs = Bw;
+    A.out_rs = Bw;
+    A.tw_rs = B;
+    A.ps_rs = B;
+    A.ps_col = 1;
+    A.col_limit = (int)Bw;
+    A.load_rowfast = 0;
+    A.store_rowfast = 0;
+    A.n_coeffs = -1;
+    A.s3 = L;
+    A.s2 = nc;
+    A.s1 = pad_to_residue(P2 * nc, nc % 32);
+    l.tiles = (unsigned)(batch * outer * A.d2);
+    l.threads = (unsigned)(nc * P2);
+    l.lds_bytes = size_t(32) * A.s1 * sizeof(u64);
+    return l;
+}
+
+int rows_per_tile(int P2, int L) { return L == 1 ? std::max(1, 256 / P2) : std::max(1, 128 / P2); }
+
+// Last pass of a multi-pass transform ("type B"): rows (k1, rho) of R contiguous elements; DFT along the row;
+// output element k of row (k1, rho) goes to  k1 + N1 * (rho + Q * k).
+Launch plan_transpose_pass(const u64* in, u64* out, long long in_bs, long long out_bs, size_t batch, int a, long long N1,
+                           long long Q, int L) {
+    Launch l{};
+    tfk::NttPassArgs& A = l.a;
+    const int p2 = a - 5, P2 = 1 << p2;
+    const long long R = 1ll << a;
+    int T = rows_per_tile(P2, L);
+    if (T > N1) T = (int)N1;
+    const int nc = T * L;
+    A.in = in;
+    A.out = out;
+    A.p2 = p2;
+    A.nc = nc;
+    A.L = L;
+    A.d1 = (u32)Q;
+    A.d2 = (u32)((N1 + T - 1) / T);
+    A.ib0 = in_bs;
+    A.ib1 = R * L;
+    A.ib2 = (long long)T * Q * R * L;
+    A.in_cs_hi = Q * R * L;
+    A.in_rs = L;
+    A.ob0 = out_bs;
+    A.ob1 = N1 * L;
+    A.ob2 = (long long)T * L;
+    A.out_cs_hi = L;
+    A.out_rs = N1 * Q * L;
+    A.col_limit = (int)(N1 * L);
+    A.load_rowfast = 1;
+    A.store_rowfast = 0;
+    A.n_coeffs = -1;
+    A.s3 = L;
+    A.s2 = nc | 1;
+    A.s1 = pad_to_residue(P2 * A.s2, nc % 32);
+    l.tiles = (unsigned)(batch * Q * A.d2);
+    l.threads = (unsigned)(nc * P2);
+    l.lds_bytes = size_t(32) * A.s1 * sizeof(u64);
+    return l;
+}
+
+// Single pass (n <= 1024, "type C"): a tile is T whole transforms; natural-order output in the same place.
+Launch plan_row_pass(const u64* in, u64* out, long long in_bs, long long out_bs, size_t batch, int a, int L) {
+    Launch l{};
+    tfk::NttPassArgs& A = l.a;
+    const int p2 = a - 5, P2 = 1 << p2;
+    int T = rows_per_tile(P2, L);
+    if ((size_t)T > batch) T = (int)batch;
+    const int nc = T * L;
+    A.in = in;
+    A.out = out;
+    A.p2 = p2;
+    A.nc = nc;
+    A.L = L;
+    A.d1 = 1;
+    A.d2 = (u32)((batch + T - 1) / T);
+    A.ib2 = (long long)T * in_bs;
+    A.ob2 = (long long)T * out_bs;
+    A.in_cs_hi = in_bs;
+    A.out_cs_hi = out_bs;
+    A.in_rs = L;
+    A.out_rs = L;
+    A.col_limit = (int)std::min<size_t>(batch * L, 0x7fffffff);
+    A.load_rowfast = 1;
+    A.store_rowfast = 1;
+    A.ps_rs = 1;
+    A.ps_col = 0;
+    A.n_coeffs = -1;
+    A.s2 = L;
+    A.s3 = P2 * L;
+    A.s1 = pad_to_residue(T * A.s3, L % 32);
+    l.tiles = A.d2;
+    l.threads = (unsigned)(nc * P2);
+    l.lds_bytes = size_t(32) * A.s1 * sizeof(u64);
+    return l;
+}
+
+int launch_pass(const Launch& l, bool inverse, hipStream_t stream) {
+    if (l.tiles == 0) return TF_OK;
+    if (inverse) {
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&tfk::ntt_pass_kernel<true>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        hipLaunchKernelGGL(tfk::ntt_pass_kernel<true>, dim3(l.tiles), dim3(l.threads), l.lds_bytes, stream, l.a);
+    } else {
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&tfk::ntt_pass_kernel<false>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        hipLaunchKernelGGL(tfk::ntt_pass_kernel<false>, dim3(l.tiles), dim3(l.threads), l.lds_bytes, stream, l.a);
+    }
+    HIPCHK(hipGetLastError());
+    return TF_OK;
+}
+
+int check_len(size_t n) {
+    if (n != 0 && (n & (n - 1))) return TF_ERR_LEN_NOT_POWER_OF_TWO;  // ntt.rs:137
+    if (n > (size_t(1) << 30)) return TF_ERR_LEN_TOO_LARGE;           // ntt.rs:136 (u32) / this backend's 3-pass limit
+    return TF_OK;
+}
+
+// The transform proper.  in/out are device pointers; in == out for ntt/intt, distinct for coset evaluation
+// (then pre_scale != null and rows >= n_coeffs read as zero).  in_bs/out_bs: words per polynomial.
+int run_ntt(DeviceCtx* ctx, const u64* in, u64* out, long long in_bs, long long out_bs, size_t n, size_t batch, int L,
+            bool inverse, const u64* pre_scale, long long n_coeffs, hipStream_t stream) {
+    if (n == 0 || batch == 0) return TF_OK;
+    const int log_n = ilog2(n);
+    int rc;
+    if (log_n <= 4) {
+        const u64* tw = nullptr;
+        rc = get_tiny_table(ctx, log_n, inverse, &tw);
+        if (rc) return rc;
+        tfk::NttTinyArgs A{};
+        A.in = in;
+        A.out = out;
+        A.tw = tw;
+        A.pre_scale = pre_scale;
+        A.n_coeffs = n_coeffs;
+        A.in_bs = in_bs;
+        A.out_bs = out_bs;
+        A.count = (long long)batch * L;
+        A.scale = (inverse && log_n > 0) ? gl::mont_inverse(gl::to_mont(u64(n))) : 0;
+        A.log_n = log_n;
+        A.L = L;
+        const long long blocks = (A.count + 255) / 256;
+        hipLaunchKernelGGL(tfk::ntt_tiny_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, A);
+        HIPCHK(hipGetLastError());
+        return TF_OK;
+    }
+    if (log_n <= 10) {
+        const u64* inner = nullptr;
+        rc = get_inner_table(ctx, log_n, inverse, inverse ? log_n : 0, &inner);
+        if (rc) return rc;
+        // 2^31 columns limit per launch: split huge batches
+        const size_t max_batch = size_t(1) << 24;
+        for (size_t b0 = 0; b0 < batch; b0 += max_batch) {
+            const size_t nb = std::min(max_batch, batch - b0);
+            Launch l = plan_row_pass(in + b0 * in_bs, out + b0 * out_bs, in_bs, out_bs, nb, log_n, L);
+            l.a.inner_tw = inner;
+            l.a.pre_scale = pre_scale;
+            l.a.n_coeffs = n_coeffs;
+            rc = launch_pass(l, inverse, stream);
+            if (rc) return rc;
+        }
+        return TF_OK;
+    }
+    // multi-pass: n = N1 * N2 (* N3)
+    int a1, a2, a3 = 0;
+    if (log_n <= 20) {
+        a1 = (log_n + 1) / 2;
+        a2 = log_n - a1;
+    } else {
+        a1 = (log_n + 2) / 3;
+        a2 = (log_n - a1 + 1) / 2;
+        a3 = log_n - a1 - a2;
+    }
+    const bool three = a3 != 0;
+    const long long N1 = 1ll << a1, N2 = 1ll << a2, N3 = three ? (1ll << a3) : 1;
+    const u64 *inner1, *inner2, *inner3 = nullptr, *post1, *post2 = nullptr;
+    rc = get_inner_table(ctx, a1, inverse, 0, &inner1);
+    if (rc) return rc;
+    rc = get_inner_table(ctx, a2, inverse, (!three && inverse) ? log_n : 0, &inner2);
+    if (rc) return rc;
+    rc = get_post_table(ctx, log_n, a1, inverse, &post1);
+    if (rc) return rc;
+    if (three) {
+        rc = get_inner_table(ctx, a3, inverse, inverse ? log_n : 0, &inner3);
+        if (rc) return rc;
+        rc = get_post_table(ctx, a2 + a3, a2, inverse, &post2);
+        if (rc) return rc;
+    }
+    read_env();
+    const size_t poly_bytes = n * size_t(L) * sizeof(u64);
+    size_t tb = std::max<size_t>(1, g_tile_bytes / poly_bytes);
+    tb = std::min(tb, batch);
+    u64* scratch = nullptr;
+    {
+        hipError_t e = hipMallocAsync(reinterpret_cast<void**>(&scratch), tb * poly_bytes, stream);
+        if (e != hipSuccess) return hip_fail(e, "hipMallocAsync(ntt scratch)", __FILE__, __LINE__);
+    }
+    const long long sbs = (long long)n * L;  // scratch batch stride
+    for (size_t b0 = 0; b0 < batch && rc == TF_OK; b0 += tb) {
+        const size_t nb = std::min(tb, batch - b0);
+        const u64* tin = in + (long long)b0 * in_bs;
+        u64* tout = out + (long long)b0 * out_bs;
+        if (!three) {
+            Launch p1 = plan_column_pass(tin, scratch, in_bs, sbs, nb, 1, a1, N2, L);
+            p1.a.inner_tw = inner1;
+            p1.a.post_tw = post1;
+            p1.a.pre_scale = pre_scale;
+            p1.a.n_coeffs = n_coeffs;
+            rc = launch_pass(p1, inverse, stream);
+            if (rc) break;
+            Launch p2 = plan_transpose_pass(scratch, tout, sbs, out_bs, nb, a2, N1, 1, L);
+            p2.a.inner_tw = inner2;
+            rc = launch_pass(p2, inverse, stream);
+        } else {
+            Launch p1 = plan_column_pass(tin, tout, in_bs, out_bs, nb, 1, a1, N2 * N3, L);
+            p1.a.inner_tw = inner1;
+            p1.a.post_tw = post1;
+            p1.a.pre_scale = pre_scale;
+            p1.a.n_coeffs = n_coeffs;
+            rc = launch_pass(p1, inverse, stream);
+            if (rc) break;
+            Launch p2 = plan_column_pass(tout, scratch, out_bs, sbs, nb, N1, a2, N3, L);
+            p2.a.inner_tw = inner2;
+            p2.a.post_tw = post2;
+            rc = launch_pass(p2, inverse, stream);
+            if (rc) break;
+            Launch p3 = plan_transpose_pass(scratch, tout, sbs, out_bs, nb, a3, N1, N2, L);
+            p3.a.inner_tw = inner3;
+            rc = launch_pass(p3, inverse, stream);
+        }
+    }
+    hipError_t e = hipFreeAsync(scratch, stream);
+    if (rc) return rc;
+    if (e != hipSuccess) return hip_fail(e, "hipFreeAsync(ntt scratch)", __FILE__, __LINE__);
+    return TF_OK;
+}
+
+int ntt_dev(u64* d_x, size_t n, size_t batch, int L, int inverse, void* stream) {
+    int rc = check_len(n);
+    if (rc) return rc;
+    if (n <= 1 || batch == 0) return TF_OK;  // ntt.rs:170-173 ; length 1 is the identity (n^-1 = 1)
+    if (!d_x) return TF_ERR_NULL_POINTER;
+    DeviceCtx* ctx = nullptr;
+    rc = current_ctx(&ctx);
+    if (rc) return rc;
+    return run_ntt(ctx, d_x, d_x, (long long)n * L, (long long)n * L, n, batch, L, inverse != 0, nullptr, -1,
+                   static_cast<hipStream_t>(stream));
+}
+
+int coset_eval_dev(const u64* d_coeffs, size_t n_coeffs, u64 offset_raw, u64* d_out, size_t order, size_t batch, int L,
+                   void* stream) {
+    if (n_coeffs > order) return TF_ERR_ORDER_NOT_ABOVE_DEGREE;  // polynomial.rs:1388-1392
+    int rc = check_len(order);
+    if (rc) return rc;
+    if (order == 0 || batch == 0) return TF_OK;
+    if (!d_out || (n_coeffs && !d_coeffs)) return TF_ERR_NULL_POINTER;
+    DeviceCtx* ctx = nullptr;
+    rc = current_ctx(&ctx);
+    if (rc) return rc;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (n_coeffs == 0) {  // the zero polynomial evaluates to zero everywhere
+        HIPCHK(hipMemsetAsync(d_out, 0, order * batch * size_t(L) * sizeof(u64), s));
+        return TF_OK;
+    }
+    const u64* pw = nullptr;
+    rc = get_pow_table(ctx, offset_raw, n_coeffs, &pw);
+    if (rc) return rc;
+    return run_ntt(ctx, d_coeffs, d_out, (long long)n_coeffs * L, (long long)order * L, order, batch, L, false, pw,
+                   (long long)n_coeffs, s);
+}
+
+// ------------------------------------------------------------------------------------ Tip5 / Merkle
+int tip5_permute_dev(u64* d_states, size_t count, void* stream) {
+    if (count == 0) return TF_OK;
+    if (!d_states) return TF_ERR_NULL_POINTER;
+    DeviceCtx* ctx = nullptr;
+    int rc = current_ctx(&ctx);
+    if (rc) return rc;
+    rc = ensure_tip5(ctx);
+    if (rc) return rc;
+    const long long blocks = ((long long)count + 255) / 256;
+    hipLaunchKernelGGL(tfk::tip5_permute_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       d_states, (long long)count);
+    HIPCHK(hipGetLastError());
+    return TF_OK;
+}
+
+int launch_hash_pairs(const u64* in, u64* out, u64* leaf_copy, long long count, long long per_tree, long long in_ts,
+                      long long out_ts, long long copy_ts, hipStream_t s) {
+    if (count == 0) return TF_OK;
+    const long long blocks = (count + 255) / 256;
+    hipLaunchKernelGGL(tfk::tip5_hash_pairs_kernel, dim3((unsigned)blocks), dim3(256), 0, s, in, out, leaf_copy, count,
+                       per_tree, in_ts, out_ts, copy_ts);
+    HIPCHK(hipGetLastError());
+    return TF_OK;
+}
+
+int tip5_hash_pairs_dev(const u64* d_in, u64* d_out, size_t count, void* stream) {
+    if (count == 0) return TF_OK;
+    if (!d_in || !d_out) return TF_ERR_NULL_POINTER;
+    DeviceCtx* ctx = nullptr;
+    int rc = current_ctx(&ctx);
+    if (rc) return rc;
+    rc = ensure_tip5(ctx);
+    if (rc) return rc;
+    return launch_hash_pairs(d_in, d_out, nullptr, (long long)count, (long long)count, 0, 0, 0,
+                             static_cast<hipStream_t>(stream));
+}
+
+int tip5_hash_varlen_rows_dev(const u64* d_rows, size_t row_len, size_t n_rows, u64* d_out, void* stream) {
+    if (n_rows == 0) return TF_OK;
+    if (!d_out || (row_len && !d_rows)) return TF_ERR_NULL_POINTER;
+    DeviceCtx* ctx = nullptr;
+    int rc = current_ctx(&ctx);
+    if (rc) return rc;
+    rc = ensure_tip5(ctx);
+    if (rc) return rc;
+    const long long blocks = ((long long)n_rows + 255) / 256;
+    hipLaunchKernelGGL(tfk::tip5_hash_varlen_rows_kernel, dim3((unsigned)blocks), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), d_rows, (long long)row_len, (long long)n_rows, d_out);
+    HIPCHK(hipGetLastError());
+    return TF_OK;
+}
+
+int check_leaves(size_t n) {
+    if (n == 0) return TF_ERR_TOO_FEW_LEAFS;                  // merkle_tree.rs:394-396
+    if (n & (n - 1)) return TF_ERR_INCORRECT_NUMBER_OF_LEAFS;  // :398-401
+    return TF_OK;
+}
+
+constexpr long long kTopWidth = 256;  // levels of at most this many nodes finish in one workgroup per tree
+
+// nodes layout per tree: 2n digests (merkle_tree.rs:85-88, :393-429).
+int merkle_build_dev(const u64* d_leaves, size_t n, u64* d_nodes, size_t batch, void* stream) {
+    int rc = check_leaves(n);
+    if (rc) return rc;
+    if (batch == 0) return TF_OK;
+    if (!d_leaves || !d_nodes) return TF_ERR_NULL_POINTER;
+    DeviceCtx* ctx = nullptr;
+    rc = current_ctx(&ctx);
+    if (rc) return rc;
+    rc = ensure_tip5(ctx);
+    if (rc) return rc;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const long long N = (long long)n, nodes_ts = 10 * N, leaves_ts = 5 * N;
+    if (N <= kTopWidth) {
+        hipLaunchKernelGGL(tfk::merkle_top_kernel, dim3((unsigned)batch), dim3(256), 0, s, d_leaves, leaves_ts, (int)N,
+                           d_nodes, nodes_ts, (u64*)nullptr, d_leaves, leaves_ts);
+        HIPCHK(hipGetLastError());
+        return TF_OK;
+    }
+    // first level: read leaves, write the leaf copy nodes[n..2n) and the parents nodes[n/2..n)
+    long long w = N / 2;
+    rc = launch_hash_pairs(d_leaves, d_nodes + 5 * w, d_nodes + 5 * N, w * (long long)batch, w, leaves_ts, nodes_ts,
+                           nodes_ts, s);
+    if (rc) return rc;
+    while (w > kTopWidth) {  // nodes[w/2 .. w) from nodes[w .. 2w)
+        const long long nw = w / 2;
+        rc = launch_hash_pairs(d_nodes + 5 * w, d_nodes + 5 * nw, nullptr, nw * (long long)batch, nw, nodes_ts, nodes_ts, 0,
+                               s);
+        if (rc) return rc;
+        w = nw;
+    }
+    hipLaunchKernelGGL(tfk::merkle_top_kernel, dim3((unsigned)batch), dim3(256), 0, s, d_nodes + 5 * w, nodes_ts, (int)w,
+                       d_nodes, nodes_ts, (u64*)nullptr, (const u64*)nullptr, 0ll);
+    HIPCHK(hipGetLastError());
+    return TF_OK;
+}
+
+int merkle_root_dev(const u64* d_leaves, size_t n, u64* d_root, size_t batch, void* stream) {
+    int rc = check_leaves(n);
+    if (rc) return rc;
+    if (batch == 0) return TF_OK;
+    if (!d_leaves || !d_root) return TF_ERR_NULL_POINTER;
+    DeviceCtx* ctx = nullptr;
+    rc = current_ctx(&ctx);
+    if (rc) return rc;
+    rc = ensure_tip5(ctx);
+    if (rc) return rc;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const long long N = (long long)n, leaves_ts = 5 * N;
+    if (N <= kTopWidth) {
+        hipLaunchKernelGGL(tfk::merkle_top_kernel, dim3((unsigned)batch), dim3(256), 0, s, d_leaves, leaves_ts, (int)N,
+                           (u64*)nullptr, 0ll, d_root, (const u64*)nullptr, 0ll);
+        HIPCHK(hipGetLastError());
+        return TF_OK;
+    }
+    // ping-pong level buffers: n/2 + n/4 digests per tree
+    u64* buf = nullptr;
+    const size_t words = size_t(batch) * size_t(5) * size_t(N / 2 + N / 4);
+    hipError_t e = hipMallocAsync(reinterpret_cast<void**>(&buf), words * sizeof(u64), s);
+    if (e != hipSuccess) {
+        hip_fail(e, "hipMallocAsync(merkle levels)", __FILE__, __LINE__);
+        return TF_ERR_TREE_TOO_HIGH;
+    }
+    u64* a = buf;
+    u64* b = buf + size_t(batch) * 5 * size_t(N / 2);
+    long long w = N / 2;
+    rc = launch_hash_pairs(d_leaves, a, nullptr, w * (long long)batch, w, leaves_ts, 5 * w, 0, s);
+    while (rc == TF_OK && w > kTopWidth) {
+        const long long nw = w / 2;
+        rc = launch_hash_pairs(a, b, nullptr, nw * (long long)batch, nw, 5 * w, 5 * nw, 0, s);
+        std::swap(a, b);
+        w = nw;
+    }
+    if (rc == TF_OK) {
+        hipLaunchKernelGGL(tfk::merkle_top_kernel, dim3((unsigned)batch), dim3(256), 0, s, a, 5 * w, (int)w, (u64*)nullptr,
+                           0ll, d_root, (const u64*)nullptr, 0ll);
+        hipError_t le = hipGetLastError();
+        if (le != hipSuccess) rc = hip_fail(le, "merkle_top_kernel", __FILE__, __LINE__);
+    }
+    e = hipFreeAsync(buf, s);
+    if (rc) return rc;
+    if (e != hipSuccess) return hip_fail(e, "hipFreeAsync", __FILE__, __LINE__);
+    return TF_OK;
+}
+
+// ------------------------------------------------------------------------------------ host-pointer wrappers
+struct DevBuf {
+    u64* p = nullptr;
+    hipStream_t s;
+    explicit DevBuf(hipStream_t st) : s(st) {}
+    int alloc(size_t words) {
+        if (words == 0) return TF_OK;
+        hipError_t e = hipMallocAsync(reinterpret_cast<void**>(&p), words * sizeof(u64), s);
+        if (e != hipSuccess) return hip_fail(e, "hipMallocAsync", __FILE__, __LINE__);
+        return TF_OK;
+    }
+    ~DevBuf() {
+        if (p) (void)hipFreeAsync(p, s);
+    }
+};
+
+// Host buffers are pageable: the runtime stages such copies, and a staged H2D chunk was observed to land
+// AFTER a kernel enqueued behind it on the same stream had already rewritten the destination in place.
+// The host-pointer entry points therefore wait for the upload before enqueueing compute.
+int h2d(u64* d, const u64* h, size_t words, hipStream_t s) {
+    if (!words) return TF_OK;
+    HIPCHK(hipMemcpyAsync(d, h, words * sizeof(u64), hipMemcpyHostToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return TF_OK;
+}
+
+// One private non-blocking stream per (host thread, device) for the host-pointer entry points.
+hipStream_t host_stream() {
+    thread_local hipStream_t streams[kMaxDevices] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return nullptr;
+    if (!streams[dev]) {
+        if (hipStreamCreateWithFlags(&streams[dev], hipStreamNonBlocking) != hipSuccess) {
+            (void)hipGetLastError();
+            streams[dev] = nullptr;
+        }
+    }
+    return streams[dev];
+}
+int d2h(u64* h, const u64* d, size_t words, hipStream_t s) {
+    if (!words) return TF_OK;
+    HIPCHK(hipMemcpyAsync(h, d, words * sizeof(u64), hipMemcpyDeviceToHost, s));
+    return TF_OK;
+}
+int sync(hipStream_t s) {
+    HIPCHK(hipStreamSynchronize(s));
+    return TF_OK;
+}
+
+#define TRY(x)            \
+    do {                  \
+        int rc_ = (x);    \
+        if (rc_) return rc_; \
+    } while (0)
+
+int ntt_host(u64* x, size_t n, size_t batch, int L, int inverse) {
+    TRY(check_len(n));
+    if (n <= 1 || batch == 0) return TF_OK;
+    if (!x) return TF_ERR_NULL_POINTER;
+    DeviceCtx* ctx = nullptr;
+    TRY(current_ctx(&ctx));
+    hipStream_t s = host_stream();
+    DevBuf d(s);
+    const size_t words = n * batch * L;
+    TRY(d.alloc(words));
+    TRY(h2d(d.p, x, words, s));
+    TRY(ntt_dev(d.p, n, batch, L, inverse, s));
+    TRY(d2h(x, d.p, words, s));
+    return sync(s);
+}
+
+int coset_eval_host(const u64* coeffs, size_t n_coeffs, u64 offset_raw, u64* out, size_t order, size_t batch, int L) {
+    if (n_coeffs > order) return TF_ERR_ORDER_NOT_ABOVE_DEGREE;
+    TRY(check_len(order));
+    if (order == 0 || batch == 0) return TF_OK;
+    if (!out || (n_coeffs && !coeffs)) return TF_ERR_NULL_POINTER;
+    DeviceCtx* ctx = nullptr;
+    TRY(current_ctx(&ctx));
+    hipStream_t s = host_stream();
+    DevBuf din(s), dout(s);
+    TRY(din.alloc(n_coeffs * batch * L));
+    TRY(dout.alloc(order * batch * L));
+    TRY(h2d(din.p, coeffs, n_coeffs * batch * L, s));
+    TRY(coset_eval_dev(din.p, n_coeffs, offset_raw, dout.p, order, batch, L, s));
+    TRY(d2h(out, dout.p, order * batch * L, s));
+    return sync(s);
+}
+
+}  // namespace
+
+// ==================================================================================== C ABI
+extern "C" {
+
+const char* tf_status_string(int status) {
+    switch (status) {
+        case TF_OK: return "TF_OK";
+        case TF_ERR_TOO_FEW_LEAFS: return "TF_ERR_TOO_FEW_LEAFS";
+        case TF_ERR_INCORRECT_NUMBER_OF_LEAFS: return "TF_ERR_INCORRECT_NUMBER_OF_LEAFS";
+        case TF_ERR_TREE_TOO_HIGH: return "TF_ERR_TREE_TOO_HIGH";
+        case TF_ERR_LEN_NOT_POWER_OF_TWO: return "TF_ERR_LEN_NOT_POWER_OF_TWO";
+        case TF_ERR_LEN_TOO_LARGE: return "TF_ERR_LEN_TOO_LARGE";
+        case TF_ERR_ORDER_NOT_ABOVE_DEGREE: return "TF_ERR_ORDER_NOT_ABOVE_DEGREE";
+        case TF_ERR_NULL_POINTER: return "TF_ERR_NULL_POINTER";
+        case TF_ERR_NO_DEVICE: return "TF_ERR_NO_DEVICE";
+        case TF_ERR_HIP: return "TF_ERR_HIP";
+        case TF_ERR_OUT_OF_MEMORY: return "TF_ERR_OUT_OF_MEMORY";
+        default: return "TF_ERR_UNKNOWN";
+    }
+}
+
+const char* tf_last_error(void) { return t_last_error.c_str(); }
+int tf_version(void) { return 1000; }
+
+int tf_device_count(void) {
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return count;
+}
+
+void tf_set_ntt_tile_bytes(size_t bytes) {
+    read_env();
+    g_tile_bytes = bytes ? bytes : (size_t(96) << 20);
+}
+size_t tf_get_ntt_tile_bytes(void) {
+    read_env();
+    return g_tile_bytes;
+}
+
+int tf_ntt_bfe(uint64_t* x, size_t n, size_t batch, int inverse) { return ntt_host(x, n, batch, 1, inverse); }
+int tf_ntt_xfe(uint64_t* x, size_t n, size_t batch, int inverse) { return ntt_host(x, n, batch, 3, inverse); }
+int tf_ntt_bfe_dev(uint64_t* d_x, size_t n, size_t batch, int inverse, void* stream) {
+    return ntt_dev(d_x, n, batch, 1, inverse, stream);
+}
+int tf_ntt_xfe_dev(uint64_t* d_x, size_t n, size_t batch, int inverse, void* stream) {
+    return ntt_dev(d_x, n, batch, 3, inverse, stream);
+}
+
+int tf_coset_eval_bfe(const uint64_t* c, size_t nc, uint64_t off, uint64_t* out, size_t order, size_t batch) {
+    return coset_eval_host(c, nc, off, out, order, batch, 1);
+}
+int tf_coset_eval_xfe(const uint64_t* c, size_t nc, uint64_t off, uint64_t* out, size_t order, size_t batch) {
+    return coset_eval_host(c, nc, off, out, order, batch, 3);
+}
+int tf_coset_eval_bfe_dev(const uint64_t* c, size_t nc, uint64_t off, uint64_t* out, size_t order, size_t batch,
+                          void* stream) {
+    return coset_eval_dev(c, nc, off, out, order, batch, 1, stream);
+}
+int tf_coset_eval_xfe_dev(const uint64_t* c, size_t nc, uint64_t off, uint64_t* out, size_t order, size_t batch,
+                          void* stream) {
+    return coset_eval_dev(c, nc, off, out, order, batch, 3, stream);
+}
+
+int tf_tip5_permute_dev(uint64_t* d_states, size_t count, void* stream) { return tip5_permute_dev(d_states, count, stream); }
+int tf_tip5_hash_pairs_dev(const uint64_t* d_in, uint64_t* d_out, size_t count, void* stream) {
+    return tip5_hash_pairs_dev(d_in, d_out, count, stream);
+}
+int tf_tip5_hash_varlen_rows_dev(const uint64_t* d_rows, size_t row_len, size_t n_rows, uint64_t* d_out, void* stream) {
+    return tip5_hash_varlen_rows_dev(d_rows, row_len, n_rows, d_out, stream);
+}
+int tf_merkle_build_dev(const uint64_t* d_leaves, size_t n, uint64_t* d_nodes, size_t batch, void* stream) {
+    return merkle_build_dev(d_leaves, n, d_nodes, batch, stream);
+}
+int tf_merkle_root_dev(const uint64_t* d_leaves, size_t n, uint64_t* d_root, size_t batch, void* stream) {
+    return merkle_root_dev(d_leaves, n, d_root, batch, stream);
+}
+
+int tf_tip5_permute(uint64_t* states, size_t count) {
+    if (count == 0) return TF_OK;
+    if (!states) return TF_ERR_NULL_POINTER;
+    DeviceCtx* ctx = nullptr;
+    TRY(current_ctx(&ctx));
+    hipStream_t s = host_stream();
+    DevBuf d(s);
+    TRY(d.alloc(count * 16));
+    TRY(h2d(d.p, states, count * 16, s));
+    TRY(tip5_permute_dev(d.p, count, s));
+    TRY(d2h(states, d.p, count * 16, s));
+    return sync(s);
+}
+
+int tf_tip5_hash_pairs(const uint64_t* in, uint64_t* out, size_t count) {
+    if (count == 0) return TF_OK;
+    if (!in || !out) return TF_ERR_NULL_POINTER;
+    DeviceCtx* ctx = nullptr;
+    TRY(current_ctx(&ctx));
+    hipStream_t s = host_stream();
+    DevBuf din(s), dout(s);
+    TRY(din.alloc(count * 10));
+    TRY(dout.alloc(count * 5));
+    TRY(h2d(din.p, in, count * 10, s));
+    TRY(tip5_hash_pairs_dev(din.p, dout.p, count, s));
+    TRY(d2h(out, dout.p, count * 5, s));
+    return sync(s);
+}
+
+int tf_tip5_hash_varlen_rows(const uint64_t* rows, size_t row_len, size_t n_rows, uint64_t* out) {
+    if (n_rows == 0) return TF_OK;
+    if (!out || (row_len && !rows)) return TF_ERR_NULL_POINTER;
+    DeviceCtx* ctx = nullptr;
+    TRY(current_ctx(&ctx));
+    hipStream_t s = host_stream();
+    DevBuf din(s), dout(s);
+    TRY(din.alloc(std::max<size_t>(1, n_rows * row_len)));
+    TRY(dout.alloc(n_rows * 5));
+    TRY(h2d(din.p, rows, n_rows * row_len, s));
+    TRY(tip5_hash_varlen_rows_dev(din.p, row_len, n_rows, dout.p, s));
+    TRY(d2h(out, dout.p, n_rows * 5, s));
+    return sync(s);
+}
+
+int tf_merkle_build(const uint64_t* leaves, size_t n, uint64_t* nodes_out, size_t batch) {
+    TRY(check_leaves(n));
+    if (batch == 0) return TF_OK;
+    if (!leaves || !nodes_out) return TF_ERR_NULL_POINTER;
+    DeviceCtx* ctx = nullptr;
+    TRY(current_ctx(&ctx));
+    hipStream_t s = host_stream();
+    DevBuf din(s), dout(s);
+    if (din.alloc(n * batch * 5) || dout.alloc(n * batch * 10)) return TF_ERR_TREE_TOO_HIGH;  // merkle_tree.rs:405-410
+    TRY(h2d(din.p, leaves, n * batch * 5, s));
+    TRY(merkle_build_dev(din.p, n, dout.p, batch, s));
+    TRY(d2h(nodes_out, dout.p, n * batch * 10, s));
+    return sync(s);
+}
+
+int tf_merkle_root(const uint64_t* leaves, size_t n, uint64_t* root_out, size_t batch) {
+    TRY(check_leaves(n));
+    if (batch == 0) return TF_OK;
+    if (!leaves || !root_out) return TF_ERR_NULL_POINTER;
+    DeviceCtx* ctx = nullptr;
+    TRY(current_ctx(&ctx));
+    hipStream_t s = host_stream();
+    DevBuf din(s), dout(s);
+    if (din.alloc(n * batch * 5)) return TF_ERR_TREE_TOO_HIGH;
+    TRY(dout.alloc(batch * 5));
+    TRY(h2d(din.p, leaves, n * batch * 5, s));
+    TRY(merkle_root_dev(din.p, n, dout.p, batch, s));
+    TRY(d2h(root_out, dout.p, batch * 5, s));
+    return sync(s);
+}
+
+}  // extern "C"

@@ -1,0 +1,205 @@
+// tip5_kernels.h -- Tip5 permutation / sponge and the Merkle level sweep for gfx950 (device side).
+//
+// Reference: twenty-first/src/tip5/mod.rs
+//   round :175-181 = sbox_layer :184-194 (4 x split_and_lookup :197-207 on the RAW Montgomery bytes,
+//   12 x x^7) -> mds_generated :210-253 -> + ROUND_CONSTANTS :68-149;  permutation :529-533;
+//   hash_10 :559-569; hash_pair :577-586; hash_varlen :617-623 + util_types/sponge.rs:41-55.
+// Merkle: twenty-first/src/util_types/merkle_tree.rs:149-222 (nodes[i] = hash_pair(nodes[2i], nodes[2i+1])).
+//
+// GPU mapping: one lane = one permutation, whole state in registers (16 x u64), 64-bit integer VALU
+// only (no MFMA: there is no dense contraction).  The MDS is the plain integer circulant product
+//   out[r] = sum_c M[(r-c) mod 16] * raw[c]        (tip5/naive.rs:54-68, mod.rs:154-157)
+// accumulated per 32-bit half with v_mad_u64_u32 (16-bit x 32-bit + 64-bit; a half-sum is < 2^52, the
+// same bound mds_generated relies on, mod.rs:244), then reduced with 2^64 = 2^32 - 1 and made canonical
+// explicitly after adding the round constant (the reference gets there through a quirk of Add,
+// mod.rs:222-242 / :1098-1142; the canonical result is the same word).
+#pragma once
+
+#include "gl64.h"
+
+namespace tfk {
+
+using gl::u32;
+using gl::u64;
+
+struct Tip5Consts {
+    u64 rc[80];        // Montgomery form of ROUND_CONSTANTS (mod.rs:68-149)
+    u32 lut[64];       // LOOKUP_TABLE (mod.rs:50-64) packed 4 bytes per word
+};
+__constant__ Tip5Consts g_tip5;
+
+__device__ __forceinline__ constexpr u32 mds_entry(int i) {
+    // MDS_MATRIX_FIRST_COLUMN, mod.rs:154-157
+    constexpr u32 col[16] = {61402, 1108, 28750, 33823, 7454, 43244, 53865, 12034,
+                             56951, 27521, 41351, 40901, 12021, 59689, 26798, 17845};
+    return col[i & 15];
+}
+
+__device__ __forceinline__ u32 lookup4(u32 w, const unsigned char* lut) {
+    u32 b0 = lut[w & 0xff], b1 = lut[(w >> 8) & 0xff], b2 = lut[(w >> 16) & 0xff], b3 = lut[w >> 24];
+    return b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
+}
+
+__device__ __forceinline__ void tip5_round(u64 (&s)[16], int round, const unsigned char* lut) {
+    // S-box layer (mod.rs:184-194)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        u32 lo = lookup4((u32)s[i], lut), hi = lookup4((u32)(s[i] >> 32), lut);
+        s[i] = ((u64)hi << 32) | lo;  // may be >= p, exactly like the reference
+    }
+#pragma unroll
+    for (int i = 4; i < 16; ++i) {
+        u64 sq = gl::mont_mul(s[i], s[i]);
+        u64 qu = gl::mont_mul(sq, sq);
+        s[i] = gl::mont_mul(s[i], gl::mont_mul(sq, qu));
+    }
+    // MDS on 32-bit halves + round constant
+    u32 lo[16], hi[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        lo[i] = (u32)s[i];
+        hi[i] = (u32)(s[i] >> 32);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        u64 alo = 0, ahi = 0;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            const u32 m = mds_entry(16 + r - c);
+            alo += (u64)m * lo[c];
+            ahi += (u64)m * hi[c];
+        }
+        // value = alo + ahi * 2^32  (< 2^84)  =  l64 + h32 * 2^64  ==  l64 + h32 * (2^32 - 1)
+        u64 l64 = alo + (ahi << 32);
+        u64 h32 = (ahi >> 32) + (l64 < alo);
+        u64 v = gl::add(l64, (h32 << 32) - h32);
+        s[r] = gl::add(v, g_tip5.rc[round * 16 + r]);
+    }
+}
+
+__device__ __forceinline__ void tip5_permutation(u64 (&s)[16], const unsigned char* lut) {
+#pragma unroll 1
+    for (int r = 0; r < 5; ++r) tip5_round(s, r, lut);
+}
+
+__device__ __forceinline__ void stage_lut(unsigned char* lut_lds) {
+    // 256-byte table into LDS; every workgroup does this once.
+    u32* w = reinterpret_cast<u32*>(lut_lds);
+    for (int i = threadIdx.x; i < 64; i += blockDim.x) w[i] = g_tip5.lut[i];
+    __syncthreads();
+}
+
+// states: count x 16 words, permuted in place (Tip5::permutation, mod.rs:529-533)
+__global__ void __launch_bounds__(256) tip5_permute_kernel(u64* states, long long count) {
+    __shared__ __attribute__((aligned(16))) unsigned char lut[256];
+    stage_lut(lut);
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    u64 s[16];
+    u64* p = states + i * 16;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s[k] = p[k];
+    tip5_permutation(s, lut);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) p[k] = s[k];
+}
+
+// out[i] = hash_10(in[10 i .. 10 i + 10)) = hash_pair(left, right)  (mod.rs:559-586).
+// If leaf_copy != null the 10 input words are also copied there (Merkle leaf level, merkle_tree.rs:426).
+// Addressing: item i belongs to tree i / per_tree; its input is in + tree * in_ts + 10 * (i % per_tree), etc.
+__global__ void __launch_bounds__(256) tip5_hash_pairs_kernel(const u64* in, u64* out, u64* leaf_copy, long long count,
+                                                              long long per_tree, long long in_ts, long long out_ts,
+                                                              long long copy_ts) {
+    __shared__ __attribute__((aligned(16))) unsigned char lut[256];
+    stage_lut(lut);
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const long long tree = i / per_tree, j = i - tree * per_tree;
+    const u64* p = in + tree * in_ts + 10 * j;
+    u64 s[16];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) s[k] = p[k];
+    if (leaf_copy) {
+        u64* q = leaf_copy + tree * copy_ts + 10 * j;
+#pragma unroll
+        for (int k = 0; k < 10; ++k) q[k] = s[k];
+    }
+#pragma unroll
+    for (int k = 10; k < 16; ++k) s[k] = gl::ONE;  // Tip5::new(Domain::FixedLength), mod.rs:511-526
+    tip5_permutation(s, lut);
+    u64* o = out + tree * out_ts + 5 * j;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) o[k] = s[k];
+}
+
+// hash_varlen of n_rows rows of row_len words each (mod.rs:617-623; padding sponge.rs:41-55)
+__global__ void __launch_bounds__(256) tip5_hash_varlen_rows_kernel(const u64* rows, long long row_len, long long n_rows,
+                                                                    u64* out) {
+    __shared__ __attribute__((aligned(16))) unsigned char lut[256];
+    stage_lut(lut);
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_rows) return;
+    const u64* p = rows + i * row_len;
+    u64 s[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s[k] = 0;  // Domain::VariableLength
+    long long full = row_len / 10;
+    for (long long c = 0; c < full; ++c) {
+#pragma unroll
+        for (int k = 0; k < 10; ++k) s[k] = p[c * 10 + k];  // overwrite-mode absorb, mod.rs:684-691
+        tip5_permutation(s, lut);
+    }
+    const int rem = (int)(row_len - full * 10);
+#pragma unroll
+    for (int k = 0; k < 10; ++k) s[k] = (k < rem) ? p[full * 10 + k] : ((k == rem) ? gl::ONE : 0);
+    tip5_permutation(s, lut);
+    u64* o = out + i * 5;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) o[k] = s[k];
+}
+
+// Top of a tree in one workgroup per tree: given level `width` (<= 256 nodes, i.e. nodes[width .. 2 width)),
+// compute nodes[1 .. width) level by level through LDS and write them out; also zero nodes[0]
+// (merkle_tree.rs:415-419).  Mirrors sequentially_fill_tree (:216-222) below the parallelisation cutoff.
+// level_in: pointer to the `width` digests of the starting level for tree 0, stride in_ts words per tree.
+// nodes: node array (may be null when only the root is wanted); root_out: 5 words per tree or null.
+__global__ void __launch_bounds__(256) merkle_top_kernel(const u64* level_in, long long in_ts, int width, u64* nodes,
+                                                         long long nodes_ts, u64* root_out, const u64* leaves_to_copy,
+                                                         long long leaves_ts) {
+    __shared__ __attribute__((aligned(16))) unsigned char lut[256];
+    __shared__ u64 cur[256 * 5];
+    stage_lut(lut);
+    const long long tree = blockIdx.x;
+    const int t = threadIdx.x;
+    const u64* src = level_in + tree * in_ts;
+    u64* nd = nodes ? nodes + tree * nodes_ts : nullptr;
+    for (int k = t; k < width * 5; k += blockDim.x) {
+        u64 v = src[k];
+        cur[k] = v;
+        if (leaves_to_copy && nd) nd[(long long)width * 5 + k] = v;  // starting level is the leaf level
+    }
+    if (nd && t < 5) nd[t] = 0;
+    __syncthreads();
+    for (int w = width / 2; w >= 1; w /= 2) {
+        u64 s[16];
+        if (t < w) {
+#pragma unroll
+            for (int k = 0; k < 10; ++k) s[k] = cur[10 * t + k];
+#pragma unroll
+            for (int k = 10; k < 16; ++k) s[k] = gl::ONE;
+            tip5_permutation(s, lut);
+        }
+        __syncthreads();
+        if (t < w) {
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                cur[5 * t + k] = s[k];
+                if (nd) nd[(long long)(w + t) * 5 + k] = s[k];
+            }
+        }
+        __syncthreads();
+    }
+    if (root_out && t < 5) root_out[tree * 5 + t] = cur[t];
+}
+
+}  // namespace tfk
