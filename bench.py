@@ -1,0 +1,269 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+Workload = BASELINE.json configs[1]: a batch of 256 x 2^20-point BFieldElement forward NTTs per GPU,
+device-resident in and out, in place (math/ntt.rs:67-82 semantics, bit-exact).  One "step" = one pass of
+the hot path over the whole batch = one tf_ntt_bfe_dev call.  Independent transforms shard across ranks
+with no data-path collective, so N ranks run N x 256 transforms: weak scaling.
+
+Prints ONE JSON line (rank 0).  `value` = (N * 256 * 2^20 * K elements) / (max-over-ranks time of the K steps).
+  roofline    : dominant kernel ntt_pass_kernel; achieved = algorithmic bytes per launch / average launch
+                duration from HIP events over the timed region.  A 2^20 transform is 2 launches of that
+                kernel (one per pass), and SURVEY.md 8(d) prices a transform at 16 B/element, so one
+                launch carries 8 B/element x (elements it touches).
+  cpu_baseline: the CPU oracle (C restatement of the reference algorithm, kind "port") timed on this box's
+                host cores on the same 256 x 2^20 workload, one transform per thread (what a rayon caller
+                of the single-threaded ntt() does).  Rank 0, N = 1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+P = 0xFFFFFFFF00000001
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def synth_words(numel, device, seed):
+    """Synthetic canonical field elements: uniform 64-bit words with the (2^-32 fraction of) words >= p
+    folded back into range."""
+    import torch
+
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    x = torch.randint(-(2 ** 63), 2 ** 63 - 1, (numel,), dtype=torch.int64, device=device, generator=g)
+    bad = (x < 0) & (x >= -(2 ** 32 - 1))  # as u64: >= p
+    x = torch.where(bad, x + 2 ** 32, x)
+    return x
+
+
+def cpu_baseline_ntt(log_n, batch, sample_host_words):
+    """Oracle leg: time the CPU restatement on the same workload shape; returns (dict, outputs of the sample)."""
+    import numpy as np
+
+    from oracle import tfo
+
+    n = 1 << log_n
+    cores = os.cpu_count() or 1
+    threads = max(1, min(cores, batch, 64))
+    x = tfo.fill_random(n * batch, 0x7F210002)
+    tfo.ntt(x[:n].copy())  # build the oracle's twiddle cache outside the timed region (the reference caches too)
+    t0 = time.perf_counter()
+    tfo.ntt(x[: n * 4].copy(), batch=4, threads=1)
+    t1 = time.perf_counter()
+    single = 4 * n / (t1 - t0) / 1e9
+    t0 = time.perf_counter()
+    tfo.ntt(x, batch=batch, threads=threads)
+    t1 = time.perf_counter()
+    multi = batch * n / (t1 - t0) / 1e9
+    sample_out = None
+    if sample_host_words is not None:
+        k = sample_host_words.size // n
+        sample_out = tfo.ntt(sample_host_words, batch=k, threads=min(threads, k))
+    info = {
+        "value": round(multi, 4),
+        "unit": "GFelts/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": f"{batch} x 2^{log_n} BFE forward NTT (the full workload shape), one transform per thread on {threads} threads "
+                  f"of {cores} host CPUs; C restatement of math/ntt.rs:153-215 (oracle/tf_oracle.c)",
+        "single_thread_value": round(single, 5),
+    }
+    return info, sample_out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--log-n", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=256, help="transforms per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the Merkle / coset-evaluation side measurements")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    import twenty_first_amd as tf
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with nproc-per-node {args.gpus} (WORLD_SIZE={world})")
+    if not torch.cuda.is_available() or tf.lib().tf_device_count() <= 0:
+        raise SystemExit("bench.py needs an MI355X: the product has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    log_n, batch = args.log_n, args.batch
+    n = 1 << log_n
+    x = synth_words(n * batch, dev, 0x7F210002 + rank)
+
+    # in-run parity sample: first 2 transforms of this rank's batch
+    sample_in = x[: 2 * n].clone()
+
+    launches_per_step = tf.lib().tf_ntt_launch_count(n, batch, 1)
+
+    # warmup (also builds the twiddle tables)
+    for _ in range(max(1, args.warmup)):
+        tf.device.ntt_(x, n, batch=batch)
+    barrier()
+
+    # parity of the first warmup step is checked on a fresh run of the sample (x has been transformed W times)
+    sample_gpu = sample_in.clone()
+    tf.device.ntt_(sample_gpu, n, batch=2)
+    torch.cuda.synchronize()
+
+    ev0 = torch.cuda.Event(enable_timing=True)
+    ev1 = torch.cuda.Event(enable_timing=True)
+    barrier()
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(args.steps):
+        tf.device.ntt_(x, n, batch=batch)
+    ev1.record()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    ev_ms = ev0.elapsed_time(ev1)
+    barrier()
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    total_elems = world * batch * n * args.steps
+    value = total_elems / elapsed / 1e9
+    ms_per_step = elapsed / args.steps * 1e3
+
+    # roofline of the dominant kernel (this rank)
+    launches = launches_per_step * args.steps
+    avg_launch_ms = ev_ms / launches
+    alg_bytes_per_launch = 16.0 * batch * n / launches_per_step  # 16 B/element per transform, spread over its launches
+    achieved = alg_bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "hbm_traffic_ntt.json")
+    if os.path.exists(tpath):
+        try:
+            tj = json.load(open(tpath))
+            if tj.get("log_n") == log_n and tj.get("batch") == batch:
+                traffic = tj.get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    roofline = {
+        "bound": "hbm",
+        "kernel": "tfk::ntt_pass_kernel<false>",
+        "achieved": round(achieved, 1),
+        "peak": HBM_PEAK_GBS,
+        "unit": "GB/s",
+        "frac": round(achieved / HBM_PEAK_GBS, 4),
+        "traffic": traffic,
+        "algorithmic_bytes_per_launch": alg_bytes_per_launch,
+        "avg_launch_ms": round(avg_launch_ms, 5),
+        "launches_per_step": launches_per_step,
+    }
+
+    out = {
+        "metric": "goldilocks_ntt_gfelts_per_s",
+        "value": round(value, 3),
+        "unit": "GFelts/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u64",
+        "data": "synthetic",
+        "config": {
+            "workload": f"{batch} x 2^{log_n}-point BFieldElement forward NTT per GPU, in place, device-resident (BASELINE configs[1])",
+            "batch_per_gpu": batch,
+            "n": n,
+            "parallelism": f"batch-sharded x{world}, no data-path collective",
+        },
+        "roofline": roofline,
+    }
+
+    if rank == 0:
+        # ---- cpu baseline + in-run parity (oracle = checker only)
+        if world == 1 and not args.no_cpu_baseline:
+            sample_host = sample_in.cpu().numpy().view(np.uint64)
+            info, sample_out = cpu_baseline_ntt(log_n, batch, sample_host)
+            out["cpu_baseline"] = info
+            got = sample_gpu.cpu().numpy().view(np.uint64)
+            out["parity"] = "bit-exact vs oracle on 2 transforms" if np.array_equal(got, sample_out) else "MISMATCH"
+            if out["parity"] == "MISMATCH":
+                print(json.dumps(out))
+                raise SystemExit("GPU output differs from the oracle")
+        elif world == 1:
+            out["cpu_baseline"] = None
+        # ---- side measurements (not part of `value`): Merkle leaves/s and XFE coset evaluation
+        if world == 1 and not args.no_extra:
+            out["extra"] = side_measurements(tf, torch, dev)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def side_measurements(tf, torch, dev):
+    """BASELINE configs[2] and [3] shapes, a few iterations each (reported, not the headline value)."""
+    extra = {}
+    try:
+        nl = 1 << 24
+        leaves = synth_words(5 * nl, dev, 3)
+        nodes = torch.empty(10 * nl, dtype=torch.int64, device=dev)
+        tf.device.merkle_build(leaves, nl, nodes)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        iters = 3
+        e0.record()
+        for _ in range(iters):
+            tf.device.merkle_build(leaves, nl, nodes)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / iters
+        extra["merkle_2p24"] = {"ms": round(ms, 3), "leaves_per_s": round(nl / ms * 1e3, 1),
+                                "hbm_frac_at_120B_per_leaf": round(120.0 * nl / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        del leaves, nodes
+        n, b = 1 << 22, 16
+        c = synth_words(3 * n * b, dev, 4)
+        o = torch.empty(3 * n * b, dtype=torch.int64, device=dev)
+        off = tf.BFieldElement.new(7)
+        tf.device.coset_evaluate(c, n, off, o, n, batch=b, width=3)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(iters):
+            tf.device.coset_evaluate(c, n, off, o, n, batch=b, width=3)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / iters
+        extra["xfe_coset_eval_16x2p22"] = {"ms": round(ms, 3), "gfelts_per_s": round(n * b / ms / 1e6, 3),
+                                          "hbm_frac_at_48B_per_point": round(48.0 * n * b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+    except Exception as e:  # side measurements never invalidate the headline line
+        extra["error"] = repr(e)
+    return extra
+
+
+if __name__ == "__main__":
+    main()

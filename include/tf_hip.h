@@ -122,6 +122,9 @@ int tf_merkle_root_dev(const uint64_t *d_leaves, size_t n_leaves, uint64_t *d_ro
  *                       chosen so the inter-pass intermediate stays in the 256 MiB Infinity Cache.
  */
 void tf_set_ntt_tile_bytes(size_t bytes);
+/* Number of ntt_pass_kernel launches one tf_ntt_*_dev call enqueues for this shape (diagnostic; used by
+ * bench.py to turn a HIP-event interval into an average launch duration). */
+int tf_ntt_launch_count(size_t n, size_t batch, int width);
 size_t tf_get_ntt_tile_bytes(void);
 
 #ifdef __cplusplus

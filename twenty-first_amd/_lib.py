@@ -41,6 +41,7 @@ SIGNATURES = {
     "tf_merkle_root": (C.c_int, [_vp, _sz, _vp, _sz]),
     "tf_merkle_build_dev": (C.c_int, [_vp, _sz, _vp, _sz, _vp]),
     "tf_merkle_root_dev": (C.c_int, [_vp, _sz, _vp, _sz, _vp]),
+    "tf_ntt_launch_count": (C.c_int, [_sz, _sz, C.c_int]),
     "tf_set_ntt_tile_bytes": (None, [_sz]),
     "tf_get_ntt_tile_bytes": (_sz, []),
 }

@@ -892,6 +892,17 @@ size_t tf_get_ntt_tile_bytes(void) {
     return g_tile_bytes;
 }
 
+int tf_ntt_launch_count(size_t n, size_t batch, int width) {
+    if (check_len(n) || n <= 1 || batch == 0 || (width != 1 && width != 3)) return 0;
+    const int log_n = ilog2(n);
+    if (log_n <= 10) return (int)((batch + (size_t(1) << 24) - 1) >> 24);
+    read_env();
+    const size_t poly_bytes = n * size_t(width) * sizeof(u64);
+    size_t tb = std::min(std::max<size_t>(1, g_tile_bytes / poly_bytes), batch);
+    const size_t tiles = (batch + tb - 1) / tb;
+    return (int)(tiles * (log_n <= 20 ? 2 : 3));
+}
+
 int tf_ntt_bfe(uint64_t* x, size_t n, size_t batch, int inverse) { return ntt_host(x, n, batch, 1, inverse); }
 int tf_ntt_xfe(uint64_t* x, size_t n, size_t batch, int inverse) { return ntt_host(x, n, batch, 3, inverse); }
 int tf_ntt_bfe_dev(uint64_t* d_x, size_t n, size_t batch, int inverse, void* stream) {
