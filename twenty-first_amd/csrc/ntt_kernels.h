@@ -43,13 +43,16 @@ struct NttPassArgs {
     long long tw_rs;                         // row stride of post_tw (= B)
     long long ps_rs;                         // pre_scale index j = r * ps_rs + (ps_col ? b : 0)
     u32 d1, d2;                              // tile id = (i0 * d1 + i1) * d2 + i2
+    u32 d01;                                 // d0 * d1 (for the XCD-aware order)
     int p2;                                  // log2 P2  (R = 32 << p2)
-    int nc;                                  // columns per tile
+    int nc;                                  // columns per tile; thread t owns column t % nc, row group t / nc
     int L;                                   // words per element (1 BFE, 3 XFE)
     int col_limit;                           // valid columns along i2: min(nc, col_limit - i2 * nc)
-    int load_rowfast, store_rowfast;         // lane order: 1 = (limb, g) fastest, 0 = column fastest
     int ps_col;
-    int s1, s2, s3;                          // LDS strides in u64: idx = k1*s1 + g*s2 + (c/L)*s3 + c%L
+    int cpr, nrounds;                        // LDS exchange in `nrounds` rounds of `cpr` columns (bounds the LDS footprint)
+    int s1, s2;                              // LDS strides in u64: idx = k1*s1 + g*s2 + (c % cpr)
+    int xcd_order;                           // 1: block b -> XCD b%8 works on column tiles = b%8 (mod 8) for all (i0,i1)
+    u32 nc_magic;                            // t / nc == umulhi(t, nc_magic) for every t < blockDim (checked by the planner)
 };
 
 // ---- radix-2^k DIT network with power-of-two twiddles --------------------------------------
@@ -100,54 +103,80 @@ __device__ __forceinline__ constexpr int brev5(int q) {
     return ((q & 1) << 4) | ((q & 2) << 2) | (q & 4) | ((q & 8) >> 2) | ((q & 16) >> 4);
 }
 
-template <bool INV>
-__global__ void __launch_bounds__(512) ntt_pass_kernel(const NttPassArgs A) {
+__device__ __forceinline__ u32 div_by_L(u32 v, int L) {  // v / L for L in {1, 3}
+    return L == 1 ? v : (u32)(((unsigned long long)v * 0xAAAAAAABull) >> 33);
+}
+
+// COSET: the first pass of fast_coset_evaluate -- multiply coefficient j by offset^j on load and read rows
+//        beyond n_coeffs as zero (polynomial.rs:760-773, :1394-1395).
+// MODE: 0 = product kernel.  1 / 2 are measurement-only ablations (TF_NTT_ABLATE, never the default):
+//   1 = no global loads/stores (synthetic operands), 2 = no arithmetic (loads, LDS exchange, stores only).
+template <bool INV, bool COSET, int MODE = 0>
+__global__ void __launch_bounds__(512, 4) ntt_pass_kernel(const NttPassArgs A) {
     extern __shared__ __attribute__((aligned(16))) u64 lds[];
     const int t = threadIdx.x;
     const int p2 = A.p2;
     const int P2 = 1 << p2;
     const int L = A.L;
 
-    const u32 tile = blockIdx.x;
-    const u32 i2 = tile % A.d2;
-    const u32 rest = tile / A.d2;
-    const u32 i1 = rest % A.d1;
-    const u32 i0 = rest / A.d1;
+    u32 i0, i1, i2;
+    if (A.xcd_order) {
+        // Blocks are dealt round-robin to the 8 XCDs (b % 8).  Give XCD x the column tiles = x (mod 8) and let
+        // it walk all (batch, outer) indices of one column tile back to back, so the slice of the inter-pass
+        // twiddle table that tile needs stays in that XCD's L2.  Placement only affects speed.
+        const u32 xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+        i2 = ((slot / A.d01) << 3) | xcd;
+        const u32 rest = slot % A.d01;
+        i1 = rest % A.d1;
+        i0 = rest / A.d1;
+    } else {
+        const u32 tile = blockIdx.x;
+        i2 = tile % A.d2;
+        const u32 rest = tile / A.d2;
+        i1 = rest % A.d1;
+        i0 = rest / A.d1;
+    }
     const u64* in = A.in + (long long)i0 * A.ib0 + (long long)i1 * A.ib1 + (long long)i2 * A.ib2;
     u64* out = A.out + (long long)i0 * A.ob0 + (long long)i1 * A.ob1 + (long long)i2 * A.ob2;
     const int col0 = (int)i2 * A.nc;
     const int ncv = min(A.nc, A.col_limit - col0);
 
+    const int g = A.nc == 1 ? t : (int)__umulhi((u32)t, A.nc_magic);  // t / nc
+    const int c = t - g * A.nc;                        // t % nc
+    const bool act = c < ncv;
+    const int ch = (int)div_by_L((u32)c, L), cl = c - ch * L;
+    const long long bcol = (long long)div_by_L((u32)(col0 + c), L);
+
+    // Addressing: every global access is  uniform 64-bit base (SGPRs, one per register slot q)  +  32-bit
+    // per-thread offset (one VGPR for all 32 slots), so the load and store bursts cost (almost) no vector ALU
+    // work.  VALU arbitration favours the OLDER workgroup on a CU, so a young workgroup whose loads needed
+    // address arithmetic would not get them issued until the old one finished computing; together with the
+    // s_setprio brackets this is what lets one workgroup's memory phase overlap the other's arithmetic.
     u64 x[32];
-    // ------------------------------------------------------------------ load + step 1
-    {
-        int c, g;
-        if (A.load_rowfast) {
-            int limb = t % L, q = t / L;
-            g = q & (P2 - 1);
-            c = (q >> p2) * L + limb;
-        } else {
-            c = t % A.nc;
-            g = t / A.nc;
-        }
-        const bool act = c < ncv;
-        const int ch = c / L, cl = c - ch * L;
-        const u64* src = in + (long long)ch * A.in_cs_hi + cl;
-        const long long bcol = A.ps_col ? (long long)((col0 + c) / L) : 0;
+#pragma unroll
+    for (int q = 0; q < 32; ++q) x[q] = 0;
+    // ------------------------------------------------------------------ load + step 1 (radix 32 over i, rows g + P2*i)
+    __builtin_amdgcn_s_setprio(3);
+    if constexpr (MODE == 1) {
+#pragma unroll
+        for (int q = 0; q < 32; ++q) x[q] = (u64)(t * 32 + q) * 0x9e3779b97f4a7c15ULL >> 1;
+    } else if (act) {
+        const u32 toff = (u32)(((long long)ch * A.in_cs_hi + cl + (long long)g * A.in_rs) * 8);
+        const char* base = reinterpret_cast<const char*>(in);
 #pragma unroll
         for (int q = 0; q < 32; ++q) {
-            const int r = g + (brev5(q) << p2);
-            u64 v = 0;
-            if (act) {
-                if (A.pre_scale) {
-                    const long long j = (long long)r * A.ps_rs + bcol;
-                    if (A.n_coeffs < 0 || j < A.n_coeffs) v = gl::mont_mul(src[(long long)r * A.in_rs], A.pre_scale[j]);
-                } else {
-                    v = src[(long long)r * A.in_rs];
-                }
+            const long long ur = (long long)(brev5(q) << p2);  // uniform part of the row index
+            const u64* ptr = reinterpret_cast<const u64*>(base + ur * A.in_rs * 8 + toff);
+            if constexpr (COSET) {
+                const long long j = (ur + g) * A.ps_rs + (A.ps_col ? bcol : 0);
+                if (j < A.n_coeffs) x[q] = gl::mont_mul(*ptr, A.pre_scale[j]);
+            } else {
+                x[q] = *ptr;
             }
-            x[q] = v;
         }
+    }
+    __builtin_amdgcn_s_setprio(0);
+    if constexpr (MODE != 2) {
         dit_level<INV, 1>(x);
         dit_level<INV, 2>(x);
         dit_level<INV, 3>(x);
@@ -158,49 +187,78 @@ __global__ void __launch_bounds__(512) ntt_pass_kernel(const NttPassArgs A) {
 #pragma unroll
             for (int q = 0; q < 32; ++q) x[q] = gl::mont_mul(x[q], tw[q]);
         }
-        u64* dst = lds + g * A.s2 + ch * A.s3 + cl;
-#pragma unroll
-        for (int q = 0; q < 32; ++q) dst[q * A.s1] = x[q];
     }
-    __syncthreads();
-    // ------------------------------------------------------------------ step 2 + store
+    // ------------------------------------------------------------------ LDS exchange, `nrounds` rounds of `cpr` columns
+    // Element (k1, g) of a column goes from the thread that owns row group g to the thread that owns k1 mod P2.
+    // A thread writes its 32 values and reads its 32 new values in the SAME round, so only 32 are ever live.
     {
-        int c, g;
-        if (A.store_rowfast) {
-            int limb = t % L, q = t / L;
-            g = q & (P2 - 1);
-            c = (q >> p2) * L + limb;
-        } else {
-            c = t % A.nc;
-            g = t / A.nc;
-        }
-        const bool act = c < ncv;
-        const int ch = c / L, cl = c - ch * L;
-        const u64* srcl = lds + ch * A.s3 + cl;
+        const int myround = c / A.cpr;
+        const int cc = c - myround * A.cpr;
+        u64* wr = lds + g * A.s2 + cc;
+        const u64* rd = lds + cc;
+#pragma unroll 1
+        for (int r = 0; r < A.nrounds; ++r) {
+            if (r) __syncthreads();
+            if (myround == r) {
 #pragma unroll
-        for (int q = 0; q < 32; ++q) {
-            const int s = q >> p2;                 // uniform
-            const int gbr = q & (P2 - 1);          // uniform
-            const int gg = p2 ? (int)(__brev((unsigned)gbr) >> (32 - p2)) : 0;
-            const int k1 = g + (s << p2);
-            x[q] = srcl[k1 * A.s1 + gg * A.s2];
+                for (int q = 0; q < 32; ++q) wr[q * A.s1] = x[q];
+            }
+            __syncthreads();
+            if (myround == r) {
+#pragma unroll
+                for (int q = 0; q < 32; ++q) {
+                    const int s = q >> p2;         // uniform
+                    const int gbr = q & (P2 - 1);  // uniform
+                    const int gg = p2 ? (int)(__brev((unsigned)gbr) >> (32 - p2)) : 0;
+                    const int k1 = g + (s << p2);
+                    x[q] = rd[k1 * A.s1 + gg * A.s2];
+                }
+            }
         }
+    }
+    // ------------------------------------------------------------------ step 2 (radix P2 over g) + store
+    if constexpr (MODE != 2) {
         if (p2 >= 1) dit_level<INV, 1>(x);
         if (p2 >= 2) dit_level<INV, 2>(x);
         if (p2 >= 3) dit_level<INV, 3>(x);
         if (p2 >= 4) dit_level<INV, 4>(x);
         if (p2 >= 5) dit_level<INV, 5>(x);
-        u64* dstg = out + (long long)ch * A.out_cs_hi + cl;
-        const long long b = (long long)((col0 + c) / L);
-        if (act) {
+    }
+    if constexpr (MODE == 1) {
+        u64 acc = 0;
+#pragma unroll
+        for (int q = 0; q < 32; ++q) acc ^= x[q];
+        if (acc == 0x123456789abcdefULL) out[t] = acc;  // keeps the arithmetic live; never true in practice
+    } else if (act) {
+        const u32 toff = (u32)(((long long)ch * A.out_cs_hi + cl + (long long)g * A.out_rs) * 8);
+        char* base = reinterpret_cast<char*>(out);
+        if (MODE != 2 && A.post_tw) {
+            // inter-pass twiddle: 8 table words at a time (bounded register footprint), multiply, store
+            const u32 twoff = (u32)(((long long)g * A.tw_rs + bcol) * 8);
+            const char* tbase = reinterpret_cast<const char*>(A.post_tw);
+#pragma unroll
+            for (int q0 = 0; q0 < 32; q0 += 8) {
+                u64 w[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int q = q0 + i;
+                    const long long uk = (long long)(((q >> p2) << p2) + ((q & (P2 - 1)) << 5));  // uniform part of k
+                    w[i] = *reinterpret_cast<const u64*>(tbase + uk * A.tw_rs * 8 + twoff);
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int q = q0 + i;
+                    const long long uk = (long long)(((q >> p2) << p2) + ((q & (P2 - 1)) << 5));
+                    *reinterpret_cast<u64*>(base + uk * A.out_rs * 8 + toff) = gl::mont_mul(x[q], w[i]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+            __builtin_amdgcn_s_setprio(3);
 #pragma unroll
             for (int q = 0; q < 32; ++q) {
-                const int s = q >> p2;
-                const int k2 = q & (P2 - 1);
-                const int k = g + (s << p2) + (k2 << 5);
-                u64 v = x[q];
-                if (A.post_tw) v = gl::mont_mul(v, A.post_tw[(long long)k * A.tw_rs + b]);
-                dstg[(long long)k * A.out_rs] = v;
+                const long long uk = (long long)(((q >> p2) << p2) + ((q & (P2 - 1)) << 5));
+                *reinterpret_cast<u64*>(base + uk * A.out_rs * 8 + toff) = x[q];
             }
         }
     }

@@ -84,6 +84,7 @@ struct DeviceCtx {
     std::map<u64, u64*> tables;           // twiddle tables, never freed while the process lives
     std::map<std::pair<u64, u64>, u64*> pow_tables;  // (offset_raw, n) -> offset^j table
     bool tip5_ready = false;
+    bool pool_ready = false;
 };
 
 constexpr int kMaxDevices = 64;
@@ -101,6 +102,20 @@ int current_ctx(DeviceCtx** out) {
     HIPCHK(hipGetDevice(&dev));
     if (dev < 0 || dev >= kMaxDevices) return TF_ERR_NO_DEVICE;
     *out = &g_ctx[dev];
+    if (!g_ctx[dev].pool_ready) {
+        // Keep freed stream-ordered allocations cached in the device's default pool (default threshold 0 hands
+        // the memory back to the OS at every synchronisation, which makes the per-call scratch expensive).
+        std::lock_guard<std::mutex> lk(g_ctx[dev].mu);
+        if (!g_ctx[dev].pool_ready) {
+            hipMemPool_t pool = nullptr;
+            if (hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess && pool) {
+                uint64_t thr = UINT64_MAX;
+                (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &thr);
+            }
+            (void)hipGetLastError();
+            g_ctx[dev].pool_ready = true;
+        }
+    }
     return TF_OK;
 }
 
@@ -320,22 +335,43 @@ int pad_to_residue(int base, int residue) {  // smallest s >= base with s == res
     return base + r;
 }
 
-// Column pass ("type A"): view [batch][outer][R][B*L words]; DFT along R for each column; in-place geometry.
+constexpr int kMaxThreads = 512;      // per workgroup; with <= 128 VGPRs two such workgroups share a CU (4 waves/SIMD)
+constexpr int kRoundElems = 8192;     // elements parked in LDS per exchange round (64 KiB): two workgroups fit 160 KiB
+
+// thread / LDS geometry shared by all pass types: nc columns, exchanged in rounds of cpr columns
+void finish_geometry(Launch* l, int nc, int p2) {
+    tfk::NttPassArgs& A = l->a;
+    const int P2 = 1 << p2, R = 32 << p2;
+    A.p2 = p2;
+    A.nc = nc;
+    A.cpr = std::max(1, std::min(nc, kRoundElems / R));
+    A.nrounds = (nc + A.cpr - 1) / A.cpr;
+    A.s2 = A.cpr;
+    A.s1 = pad_to_residue(P2 * A.cpr, A.cpr % 32);  // consecutive k1 rows land cpr banks apart: conflict-free reads
+    l->threads = (unsigned)(nc * P2);
+    l->lds_bytes = size_t(32) * A.s1 * sizeof(u64);
+    A.nc_magic = nc > 1 ? (u32)((u64(1) << 32) / (u64)nc + 1) : 0;  // umulhi(t, magic) == t / nc (nc == 1: kernel uses t)
+    for (u32 t = 0; t < l->threads; ++t) {
+        const u32 q = (u32)(((u64)t * A.nc_magic) >> 32);
+        if (nc != 1 && q != t / (u32)nc) abort();  // unreachable: exactness proven for the ranges used
+    }
+}
+
+// Column pass: view [batch][outer][R][B*L words]; DFT along R for each of the B*L word-columns; same position in and out.
 Launch plan_column_pass(const u64* in, u64* out, long long in_bs, long long out_bs, size_t batch, long long outer, int a,
                         long long B, int L) {
     Launch l{};
     tfk::NttPassArgs& A = l.a;
     const int p2 = a - 5, P2 = 1 << p2;
     const long long R = 1ll << a, Bw = B * L;
-    int nc = 256 / P2;
-    if (nc > Bw) nc = (int)Bw;
+    int nc = (int)std::min<long long>(std::max(1, kMaxThreads / P2), Bw);
+    if (nc > 16 && P2 == 32) nc = 16;
     A.in = in;
     A.out = out;
-    A.p2 = p2;
-    A.nc = nc;
     A.L = L;
     A.d1 = (u32)outer;
     A.d2 = (u32)((Bw + nc - 1) / nc);
+    A.d01 = (u32)(batch * outer);
     A.ib0 = in_bs;
     A.ib1 = R * Bw;
     A.ib2 = nc;
@@ -350,38 +386,38 @@ Launch plan_column_pass(const u64* in, u64* out, long long in_bs, long long out_
     A.ps_rs = B;
     A.ps_col = 1;
     A.col_limit = (int)Bw;
-    A.load_rowfast = 0;
-    A.store_rowfast = 0;
     A.n_coeffs = -1;
-    A.s3 = L;
-    A.s2 = nc;
-    A.s1 = pad_to_residue(P2 * nc, nc % 32);
+    A.xcd_order = (A.d2 % 8 == 0) ? 1 : 0;
+    finish_geometry(&l, nc, p2);
     l.tiles = (unsigned)(batch * outer * A.d2);
-    l.threads = (unsigned)(nc * P2);
-    l.lds_bytes = size_t(32) * A.s1 * sizeof(u64);
     return l;
 }
 
-int rows_per_tile(int P2, int L) { return L == 1 ? std::max(1, 256 / P2) : std::max(1, 128 / P2); }
+// rows (independent DFTs) per tile for the passes whose columns are whole rows of elements
+int rows_per_tile(int P2, int L, long long limit) {
+    int nc_max = std::max(1, kMaxThreads / P2);
+    if (P2 == 32) nc_max = 16;
+    int T = std::max(1, nc_max / L);
+    return (int)std::min<long long>(T, limit);
+}
 
-// Last pass of a multi-pass transform ("type B"): rows (k1, rho) of R contiguous elements; DFT along the row;
-// output element k of row (k1, rho) goes to  k1 + N1 * (rho + Q * k).
+// Last pass of a multi-pass transform: rows (k1, rho) of R contiguous elements; DFT along the row;
+// output element k of row (k1, rho) goes to  k1 + N1 * (rho + Q * k)  (digit reversal = natural order).
+// A tile is T consecutive k1: its T*L word-columns are contiguous on the OUTPUT side.
 Launch plan_transpose_pass(const u64* in, u64* out, long long in_bs, long long out_bs, size_t batch, int a, long long N1,
                            long long Q, int L) {
     Launch l{};
     tfk::NttPassArgs& A = l.a;
     const int p2 = a - 5, P2 = 1 << p2;
     const long long R = 1ll << a;
-    int T = rows_per_tile(P2, L);
-    if (T > N1) T = (int)N1;
+    const int T = rows_per_tile(P2, L, N1);
     const int nc = T * L;
     A.in = in;
     A.out = out;
-    A.p2 = p2;
-    A.nc = nc;
     A.L = L;
     A.d1 = (u32)Q;
     A.d2 = (u32)((N1 + T - 1) / T);
+    A.d01 = (u32)(batch * Q);
     A.ib0 = in_bs;
     A.ib1 = R * L;
     A.ib2 = (long long)T * Q * R * L;
@@ -393,33 +429,26 @@ Launch plan_transpose_pass(const u64* in, u64* out, long long in_bs, long long o
     A.out_cs_hi = L;
     A.out_rs = N1 * Q * L;
     A.col_limit = (int)(N1 * L);
-    A.load_rowfast = 1;
-    A.store_rowfast = 0;
     A.n_coeffs = -1;
-    A.s3 = L;
-    A.s2 = nc | 1;
-    A.s1 = pad_to_residue(P2 * A.s2, nc % 32);
+    A.xcd_order = 0;
+    finish_geometry(&l, nc, p2);
     l.tiles = (unsigned)(batch * Q * A.d2);
-    l.threads = (unsigned)(nc * P2);
-    l.lds_bytes = size_t(32) * A.s1 * sizeof(u64);
     return l;
 }
 
-// Single pass (n <= 1024, "type C"): a tile is T whole transforms; natural-order output in the same place.
+// Single pass (32 <= n <= 1024): a tile is T whole transforms, output in natural order at the same place.
 Launch plan_row_pass(const u64* in, u64* out, long long in_bs, long long out_bs, size_t batch, int a, int L) {
     Launch l{};
     tfk::NttPassArgs& A = l.a;
     const int p2 = a - 5, P2 = 1 << p2;
-    int T = rows_per_tile(P2, L);
-    if ((size_t)T > batch) T = (int)batch;
+    const int T = rows_per_tile(P2, L, (long long)batch);
     const int nc = T * L;
     A.in = in;
     A.out = out;
-    A.p2 = p2;
-    A.nc = nc;
     A.L = L;
     A.d1 = 1;
     A.d2 = (u32)((batch + T - 1) / T);
+    A.d01 = 1;
     A.ib2 = (long long)T * in_bs;
     A.ob2 = (long long)T * out_bs;
     A.in_cs_hi = in_bs;
@@ -427,33 +456,37 @@ Launch plan_row_pass(const u64* in, u64* out, long long in_bs, long long out_bs,
     A.in_rs = L;
     A.out_rs = L;
     A.col_limit = (int)std::min<size_t>(batch * L, 0x7fffffff);
-    A.load_rowfast = 1;
-    A.store_rowfast = 1;
     A.ps_rs = 1;
     A.ps_col = 0;
     A.n_coeffs = -1;
-    A.s2 = L;
-    A.s3 = P2 * L;
-    A.s1 = pad_to_residue(T * A.s3, L % 32);
+    A.xcd_order = 0;
+    finish_geometry(&l, nc, p2);
     l.tiles = A.d2;
-    l.threads = (unsigned)(nc * P2);
-    l.lds_bytes = size_t(32) * A.s1 * sizeof(u64);
     return l;
 }
 
-int launch_pass(const Launch& l, bool inverse, hipStream_t stream) {
-    if (l.tiles == 0) return TF_OK;
-    if (inverse) {
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&tfk::ntt_pass_kernel<true>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        hipLaunchKernelGGL(tfk::ntt_pass_kernel<true>, dim3(l.tiles), dim3(l.threads), l.lds_bytes, stream, l.a);
-    } else {
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&tfk::ntt_pass_kernel<false>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        hipLaunchKernelGGL(tfk::ntt_pass_kernel<false>, dim3(l.tiles), dim3(l.threads), l.lds_bytes, stream, l.a);
-    }
+template <bool INV, bool COSET, int MODE>
+int launch_pass_t(const Launch& l, hipStream_t stream) {
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&tfk::ntt_pass_kernel<INV, COSET, MODE>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    hipLaunchKernelGGL((tfk::ntt_pass_kernel<INV, COSET, MODE>), dim3(l.tiles), dim3(l.threads), l.lds_bytes, stream, l.a);
     HIPCHK(hipGetLastError());
     return TF_OK;
+}
+
+int g_ablate = -1;  // measurement only (TF_NTT_ABLATE=1|2 selects an ablated forward kernel; results are then garbage)
+
+int launch_pass(const Launch& l, bool inverse, hipStream_t stream) {
+    if (l.tiles == 0) return TF_OK;
+    if (g_ablate < 0) {
+        const char* e = getenv("TF_NTT_ABLATE");
+        g_ablate = e ? atoi(e) : 0;
+    }
+    if (l.a.pre_scale) return launch_pass_t<false, true, 0>(l, stream);  // coset evaluation is always forward
+    if (inverse) return launch_pass_t<true, false, 0>(l, stream);
+    if (g_ablate == 1) return launch_pass_t<false, false, 1>(l, stream);
+    if (g_ablate == 2) return launch_pass_t<false, false, 2>(l, stream);
+    return launch_pass_t<false, false, 0>(l, stream);
 }
 
 int check_len(size_t n) {
