@@ -119,7 +119,8 @@ int tf_merkle_root_dev(const uint64_t *d_leaves, size_t n_leaves, uint64_t *d_ro
 /* ---------------------------------------------------------------------------------------------
  * Tuning knobs (process-wide; also read once from the environment):
  *   TF_NTT_TILE_BYTES : bytes of batch processed between the passes of a multi-pass NTT (scratch size),
- *                       chosen so the inter-pass intermediate stays in the 256 MiB Infinity Cache.
+ *                       (default 512 MiB: measured on MI355X the pass kernels are VALU-bound and larger
+ *                       launches overlap better than Infinity-Cache-sized ones).
  */
 void tf_set_ntt_tile_bytes(size_t bytes);
 /* Number of ntt_pass_kernel launches one tf_ntt_*_dev call enqueues for this shape (diagnostic; used by

@@ -125,8 +125,8 @@ void read_env() {
     std::call_once(g_env_once, [] {
         if (g_tile_bytes == 0) {
             const char* s = getenv("TF_NTT_TILE_BYTES");
-            g_tile_bytes = s ? strtoull(s, nullptr, 10) : (size_t(96) << 20);
-            if (g_tile_bytes == 0) g_tile_bytes = size_t(96) << 20;
+            g_tile_bytes = s ? strtoull(s, nullptr, 10) : (size_t(512) << 20);
+            if (g_tile_bytes == 0) g_tile_bytes = size_t(512) << 20;
         }
     });
 }
@@ -918,7 +918,7 @@ int tf_device_count(void) {
 
 void tf_set_ntt_tile_bytes(size_t bytes) {
     read_env();
-    g_tile_bytes = bytes ? bytes : (size_t(96) << 20);
+    g_tile_bytes = bytes ? bytes : (size_t(512) << 20);
 }
 size_t tf_get_ntt_tile_bytes(void) {
     read_env();
