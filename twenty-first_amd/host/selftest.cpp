@@ -1,0 +1,129 @@
+// selftest.cpp -- the reference's own known-answer tests, written against the C++ host mirror
+// (twenty_first.hpp), i.e. through the C ABI onto the GPU.  Each block names the Rust test it restates.
+// Exit code 0 = all passed; 77 = no GPU (skipped); anything else = failure.
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "twenty_first.hpp"
+
+using namespace twenty_first;
+
+static int failures = 0;
+#define EXPECT(cond)                                                         \
+    do {                                                                     \
+        if (!(cond)) {                                                       \
+            ++failures;                                                      \
+            fprintf(stderr, "FAIL %s:%d: %s\n", __FILE__, __LINE__, #cond);  \
+        }                                                                    \
+    } while (0)
+
+static std::vector<BFieldElement> bfe_vec(std::initializer_list<uint64_t> v) {
+    std::vector<BFieldElement> out;
+    for (auto x : v) out.push_back(BFieldElement::new_(x));
+    return out;
+}
+
+int main() {
+    if (tf_device_count() <= 0) {
+        fprintf(stderr, "no HIP device: the backend has no CPU fallback; skipping\n");
+        try {
+            auto x = bfe_vec({1, 4, 0, 0});
+            ntt(x);
+            fprintf(stderr, "ERROR: ntt succeeded without a device\n");
+            return 1;
+        } catch (const BackendError& e) {
+            if (e.code != TF_ERR_NO_DEVICE) return 1;
+        }
+        return 77;
+    }
+    {  // bfield_basic_test_of_chu_ntt, math/ntt.rs:424-445
+        auto x = bfe_vec({1, 4, 0, 0});
+        auto orig = x;
+        ntt(x);
+        EXPECT(x == bfe_vec({5, 1125899906842625ULL, 18446744069414584318ULL, 18445618169507741698ULL}));
+        intt(x);
+        EXPECT(x == orig);
+    }
+    {  // bfield_max_value_test_of_chu_ntt, math/ntt.rs:448-469
+        auto x = bfe_vec({BFieldElement::MAX, 0, 0, 0});
+        ntt(x);
+        EXPECT(x == bfe_vec({BFieldElement::MAX, BFieldElement::MAX, BFieldElement::MAX, BFieldElement::MAX}));
+    }
+    {  // xfield_basic_test_of_chu_ntt, math/ntt.rs:398-421
+        std::vector<XFieldElement> x(4);
+        x[0].coefficients[0] = BFieldElement::new_(1);
+        auto orig = x;
+        ntt(x);
+        for (auto& e : x) EXPECT(e.coefficients[0] == BFieldElement::new_(1) && e.coefficients[1].raw == 0 && e.coefficients[2].raw == 0);
+        intt(x);
+        EXPECT(x == orig);
+    }
+    {  // ntt panics on a non-power-of-two length, math/ntt.rs:135-140
+        auto x = bfe_vec({1, 2, 3});
+        bool panicked = false;
+        try { ntt(x); } catch (const NttPanic&) { panicked = true; }
+        EXPECT(panicked);
+        std::vector<BFieldElement> empty;
+        ntt(empty);  // the empty slice is fine
+    }
+    {  // hash10_test_vectors_snapshot, tip5/mod.rs:1294-1306
+        std::array<BFieldElement, 10> pre{};
+        for (int i = 0; i < 6; ++i) {
+            auto d = Tip5::hash_10(pre);
+            for (int k = 0; k < 5; ++k) pre[i + k] = d[k];
+        }
+        EXPECT(Digest{Tip5::hash_10(pre)}.to_hex() == "109cc2fe453bd9962f754b96d8f5b919b60af030940a275f5540da195fef65ee651c1b6fa19b2c6a");
+    }
+    {  // hash_varlen_test_vectors, tip5/mod.rs:1309-1325 (sum of digests checked by the Python suite; here: padding sanity)
+        std::vector<BFieldElement> none;
+        Digest a = Tip5::hash_varlen(none);
+        Digest b = Tip5::hash_varlen(bfe_vec({0}));
+        EXPECT(!(a == b));
+    }
+    {  // snapshot, tip5/mod.rs:1328-1362 (raw Montgomery words)
+        Tip5 t;
+        const uint64_t st[16] = {0x0000000ffffffff0ULL, 0x00000000ffffffffULL, 0x00000000ffffffffULL, 0x00000028ffffffd7ULL,
+                                 0x00000006fffffff9ULL, 0x00000002fffffffdULL, 0x00000000ffffffffULL, 0x00000030ffffffcfULL,
+                                 0x00000397fffffc68ULL, 0x0000000ffffffff0ULL, 0x316bfb7236382123ULL, 0x216f521b66ef83f5ULL,
+                                 0x5689d7b363f52df0ULL, 0xeb2f59e3aeae25fcULL, 0xb08299d277cbb4dcULL, 0xcbe3d9fdc5349140ULL};
+        for (int i = 0; i < 16; ++i) t.state[i] = BFieldElement::from_raw_u64(st[i]);
+        t.permutation();
+        const uint64_t want[5] = {0x15d38ea929f6632aULL, 0xf988e509ff738bb4ULL, 0x48bcdfae88a2e9f3ULL, 0x87339e832daac02aULL, 0x511e41268150fdacULL};
+        for (int i = 0; i < 5; ++i) EXPECT(t.state[i].raw == want[i]);
+    }
+    {  // MerkleTree structure + errors, util_types/merkle_tree.rs:393-429, :933-965, :1089-1116
+        std::vector<Digest> leafs(8);
+        for (size_t i = 0; i < leafs.size(); ++i) leafs[i] = Tip5::hash_varlen(bfe_vec({(uint64_t)i}));  // test_tree_of_height, :980-987
+        MerkleTree tree = MerkleTree::par_new(leafs);
+        EXPECT(tree.num_leafs() == 8 && tree.height() == 3);
+        for (auto& v : tree.nodes[0].values) EXPECT(v.raw == 0);
+        for (size_t i = 1; i < 8; ++i) EXPECT(tree.nodes[i] == Tip5::hash_pair(tree.nodes[2 * i], tree.nodes[2 * i + 1]));
+        for (size_t i = 0; i < 8; ++i) EXPECT(*tree.leaf(i) == leafs[i]);
+        EXPECT(MerkleTree::par_frugal_root(leafs) == tree.root());
+        EXPECT(tree.root().to_hex() == MerkleTree::sequential_new(leafs).root().to_hex());
+        bool e1 = false, e2 = false;
+        try { MerkleTree::par_new({}); } catch (const MerkleTreeError& e) { e1 = e.variant == MerkleTreeError::TooFewLeafs; }
+        leafs.pop_back();
+        try { MerkleTree::par_new(leafs); } catch (const MerkleTreeError& e) { e2 = e.variant == MerkleTreeError::IncorrectNumberOfLeafs; }
+        EXPECT(e1 && e2);
+    }
+    {  // fast_coset_evaluate == ntt of the scaled, zero-padded coefficients (polynomial.rs:1394-1396) and the order check
+        auto c = bfe_vec({3, 1, 4, 1, 5});
+        Polynomial<BFieldElement> p(c);
+        auto ev = p.fast_coset_evaluate(BFieldElement::new_(1), 8);  // offset 1: plain ntt of the padded coefficients
+        auto x = c;
+        x.resize(8);
+        ntt(x);
+        EXPECT(ev == x);
+        bool panicked = false;
+        try { p.fast_coset_evaluate(BFieldElement::generator(), 4); } catch (const NttPanic&) { panicked = true; }
+        EXPECT(panicked);
+    }
+    if (failures) {
+        fprintf(stderr, "%d failure(s)\n", failures);
+        return 1;
+    }
+    printf("twenty_first.hpp selftest: all reference KATs pass on the GPU\n");
+    return 0;
+}

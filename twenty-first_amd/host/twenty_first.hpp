@@ -1,0 +1,188 @@
+// twenty_first.hpp -- C++ host-side mirror of the reference's Rust API for the hot path, on top of the
+// C ABI of libtf_hip.so (include/tf_hip.h).  The reference is a Rust crate; no Rust toolchain exists in
+// the build image, so the host layer a Rust maintainer would write as an `extern "C"` shim
+//  is provided here in C++ with the same names, argument meaning and error behaviour:
+//
+//   twenty_first::ntt / intt                          math/ntt.rs:67-82, :109-125   (panics -> NttPanic)
+//   twenty_first::Polynomial<FF>::fast_coset_evaluate math/polynomial.rs:1374-1399
+//   twenty_first::Tip5::{hash_10, hash_pair, hash_varlen, permutation}   tip5/mod.rs:529-623
+//   twenty_first::MerkleTree::{par_new, sequential_new, par_frugal_root, sequential_frugal_root}
+//                                                     util_types/merkle_tree.rs:149-364
+//   twenty_first::MerkleTreeError                     util_types/merkle_tree.rs:933-965
+//
+// Everything executes on the GPU through the C ABI; there is no CPU fallback in this header.
+#pragma once
+
+#include <array>
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/tf_hip.h"
+
+namespace twenty_first {
+
+// #[repr(transparent)] over one u64 in Montgomery form (math/b_field_element.rs:84-86)
+struct BFieldElement {
+    uint64_t raw = 0;
+    static constexpr uint64_t P = 0xffffffff00000001ULL;  // :225
+    static constexpr uint64_t MAX = P - 1;
+
+    static uint64_t montyred(unsigned __int128 x) {  // :357-370
+        uint64_t xl = (uint64_t)x, xh = (uint64_t)(x >> 64);
+        uint64_t a = xl + (xl << 32);
+        uint64_t e = a < xl;
+        uint64_t b = a - (a >> 32) - e;
+        uint64_t r = xh - b;
+        return xh < b ? r - 0xffffffffULL : r;
+    }
+    static BFieldElement new_(uint64_t value) {  // BFieldElement::new, :235-237
+        return BFieldElement{montyred((unsigned __int128)value * 0xfffffffe00000001ULL)};
+    }
+    static BFieldElement from_raw_u64(uint64_t r) { return BFieldElement{r}; }
+    uint64_t value() const { return montyred((unsigned __int128)raw); }  // :248-250
+    uint64_t raw_u64() const { return raw; }
+    static BFieldElement generator() { return new_(7); }  // :312-314
+    bool operator==(const BFieldElement& o) const { return raw == o.raw; }
+    bool operator!=(const BFieldElement& o) const { return raw != o.raw; }
+};
+static_assert(sizeof(BFieldElement) == 8, "layout contract of the C ABI");
+
+// #[repr(transparent)] over [BFieldElement; 3] (math/x_field_element.rs:56-59)
+struct XFieldElement {
+    std::array<BFieldElement, 3> coefficients{};
+    bool operator==(const XFieldElement& o) const { return coefficients == o.coefficients; }
+};
+static_assert(sizeof(XFieldElement) == 24, "layout contract of the C ABI");
+
+struct Digest {  // tip5/digest.rs:29
+    std::array<BFieldElement, 5> values{};
+    static constexpr size_t LEN = 5;
+    bool operator==(const Digest& o) const { return values == o.values; }
+    std::string to_hex() const {  // canonical values, little-endian bytes (digest.rs:85-90, :144-153)
+        static const char* hx = "0123456789abcdef";
+        std::string s;
+        for (auto& v : values) {
+            uint64_t c = v.value();
+            for (int b = 0; b < 8; ++b) {
+                unsigned byte = (c >> (8 * b)) & 0xff;
+                s.push_back(hx[byte >> 4]);
+                s.push_back(hx[byte & 15]);
+            }
+        }
+        return s;
+    }
+};
+static_assert(sizeof(Digest) == 40, "layout contract of the C ABI");
+
+// ---- errors -------------------------------------------------------------------------------------
+struct BackendError : std::runtime_error {
+    int code;
+    BackendError(int c, const std::string& where)
+        : std::runtime_error(where + ": " + tf_status_string(c) + (c >= TF_ERR_NO_DEVICE ? std::string(" (") + tf_last_error() + ")" : "")), code(c) {}
+};
+// where the reference panics (math/ntt.rs:135-140, math/polynomial.rs:1388-1392)
+struct NttPanic : BackendError {
+    using BackendError::BackendError;
+};
+// util_types/merkle_tree.rs:933-965
+struct MerkleTreeError : BackendError {
+    enum Variant { TooFewLeafs = 1, IncorrectNumberOfLeafs = 2, TreeTooHigh = 3 } variant;
+    MerkleTreeError(int c, const std::string& where) : BackendError(c, where), variant((Variant)c) {}
+};
+
+inline void check(int rc, const char* where) {
+    if (rc == TF_OK) return;
+    if (rc >= 1 && rc <= 3) throw MerkleTreeError(rc, where);
+    if (rc >= 4 && rc <= 6) throw NttPanic(rc, where);
+    throw BackendError(rc, where);
+}
+
+// ---- ntt / intt (math/ntt.rs:67-82, :109-125) ----------------------------------------------------
+inline void ntt(std::vector<BFieldElement>& x) { check(tf_ntt_bfe(reinterpret_cast<uint64_t*>(x.data()), x.size(), 1, 0), "ntt"); }
+inline void intt(std::vector<BFieldElement>& x) { check(tf_ntt_bfe(reinterpret_cast<uint64_t*>(x.data()), x.size(), 1, 1), "intt"); }
+inline void ntt(std::vector<XFieldElement>& x) { check(tf_ntt_xfe(reinterpret_cast<uint64_t*>(x.data()), x.size(), 1, 0), "ntt"); }
+inline void intt(std::vector<XFieldElement>& x) { check(tf_ntt_xfe(reinterpret_cast<uint64_t*>(x.data()), x.size(), 1, 1), "intt"); }
+// many equal-length slices in one call (what a rayon caller of ntt() does, ntt.rs:250-274)
+inline void ntt_batch(BFieldElement* x, size_t n, size_t batch, bool inverse = false) {
+    check(tf_ntt_bfe(reinterpret_cast<uint64_t*>(x), n, batch, inverse), inverse ? "intt" : "ntt");
+}
+
+// ---- Polynomial (math/polynomial.rs:78-84): only the hot-path members ------------------------------
+template <class FF>
+struct Polynomial {
+    std::vector<FF> coefficients;  // low -> high degree
+    explicit Polynomial(std::vector<FF> c) : coefficients(std::move(c)) {
+        while (!coefficients.empty() && coefficients.back() == FF{}) coefficients.pop_back();  // Polynomial::new normalises
+    }
+    long degree() const { return (long)coefficients.size() - 1; }
+    // fast_coset_evaluate (polynomial.rs:1374-1399); offset is a BFieldElement (the documented fast case, :1366-1368)
+    std::vector<FF> fast_coset_evaluate(BFieldElement offset, size_t order) const {
+        if ((long)order <= degree()) throw NttPanic(TF_ERR_ORDER_NOT_ABOVE_DEGREE, "fast_coset_evaluate");  // :1388-1392
+        std::vector<FF> out(order);
+        const uint64_t* c = reinterpret_cast<const uint64_t*>(coefficients.data());
+        uint64_t* o = reinterpret_cast<uint64_t*>(out.data());
+        if constexpr (sizeof(FF) == 8)
+            check(tf_coset_eval_bfe(c, coefficients.size(), offset.raw, o, order, 1), "fast_coset_evaluate");
+        else
+            check(tf_coset_eval_xfe(c, coefficients.size(), offset.raw, o, order, 1), "fast_coset_evaluate");
+        return out;
+    }
+};
+
+// ---- Tip5 (tip5/mod.rs) ---------------------------------------------------------------------------
+struct Tip5 {
+    std::array<BFieldElement, 16> state{};  // :159-165
+    static constexpr size_t RATE = 10;
+    void permutation() { check(tf_tip5_permute(reinterpret_cast<uint64_t*>(state.data()), 1), "Tip5::permutation"); }  // :529-533
+    static std::array<BFieldElement, 5> hash_10(const std::array<BFieldElement, 10>& in) {  // :559-569
+        std::array<BFieldElement, 5> out;
+        check(tf_tip5_hash_pairs(reinterpret_cast<const uint64_t*>(in.data()), reinterpret_cast<uint64_t*>(out.data()), 1), "Tip5::hash_10");
+        return out;
+    }
+    static Digest hash_pair(const Digest& l, const Digest& r) {  // :577-586
+        std::array<BFieldElement, 10> in;
+        for (int i = 0; i < 5; ++i) { in[i] = l.values[i]; in[5 + i] = r.values[i]; }
+        return Digest{hash_10(in)};
+    }
+    static Digest hash_varlen(const std::vector<BFieldElement>& in) {  // :617-623
+        Digest d;
+        check(tf_tip5_hash_varlen_rows(reinterpret_cast<const uint64_t*>(in.data()), in.size(), 1, reinterpret_cast<uint64_t*>(d.values.data())), "Tip5::hash_varlen");
+        return d;
+    }
+    // batched forms -- the reason to cross the boundary at all
+    static std::vector<Digest> hash_pairs(const std::vector<Digest>& pairs) {  // pairs.size() even: (l0, r0, l1, r1, ...)
+        std::vector<Digest> out(pairs.size() / 2);
+        check(tf_tip5_hash_pairs(reinterpret_cast<const uint64_t*>(pairs.data()), reinterpret_cast<uint64_t*>(out.data()), out.size()), "Tip5::hash_pair");
+        return out;
+    }
+};
+
+// ---- MerkleTree (util_types/merkle_tree.rs:85-88) -----------------------------------------------------
+struct MerkleTree {
+    std::vector<Digest> nodes;  // nodes[0] dummy, nodes[1] root, leaves at nodes[n..2n)
+    static MerkleTree par_new(const std::vector<Digest>& leafs) {  // :165-212
+        MerkleTree t;
+        t.nodes.resize(2 * leafs.size() + (leafs.empty() ? 1 : 0));
+        check(tf_merkle_build(reinterpret_cast<const uint64_t*>(leafs.data()), leafs.size(), reinterpret_cast<uint64_t*>(t.nodes.data()), 1), "MerkleTree::par_new");
+        return t;
+    }
+    static MerkleTree sequential_new(const std::vector<Digest>& leafs) { return par_new(leafs); }  // :149-153, same result
+    static Digest sequential_frugal_root(const std::vector<Digest>& leafs) {  // :299-309
+        Digest r;
+        check(tf_merkle_root(reinterpret_cast<const uint64_t*>(leafs.data()), leafs.size(), reinterpret_cast<uint64_t*>(r.values.data()), 1), "MerkleTree::sequential_frugal_root");
+        return r;
+    }
+    static Digest par_frugal_root(const std::vector<Digest>& leafs) {  // :332-364
+        if (leafs.empty()) throw MerkleTreeError(TF_ERR_INCORRECT_NUMBER_OF_LEAFS, "MerkleTree::par_frugal_root");  // :333-335
+        return sequential_frugal_root(leafs);
+    }
+    const Digest& root() const { return nodes[1]; }            // :624-626
+    size_t num_leafs() const { return nodes.size() / 2; }       // :628-631
+    unsigned height() const { unsigned h = 0; for (size_t n = num_leafs(); n > 1; n >>= 1) ++h; return h; }  // :633-636
+    const Digest* node(size_t i) const { return i < nodes.size() ? &nodes[i] : nullptr; }  // :638-645
+    const Digest* leaf(size_t i) const { return i < num_leafs() ? &nodes[num_leafs() + i] : nullptr; }  // :654-661
+};
+
+}  // namespace twenty_first
