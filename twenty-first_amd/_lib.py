@@ -10,7 +10,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libtf_hip.so")
+SO_PATH = os.environ.get("TF_HIP_LIBRARY") or os.path.join(_HERE, "libtf_hip.so")  # override: A/B builds only
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "tf_hip.h")
 
 _u64p = C.POINTER(C.c_uint64)

@@ -61,16 +61,51 @@ GL_HD u64 mulhi64(u64 a, u64 b) {
 }
 
 // Montgomery reduction of the 128-bit value hi*2^64 + lo (b_field_element.rs:357-370).
+//   a = lo + (lo << 32) (carry e);  b = a - (a >> 32) - e;  r = hi - b, +p on borrow.
+// Written on 32-bit limbs with carry builtins so that hipcc emits one carry chain
+// (v_add_co / v_subb_co / v_subbrev_co / v_sub_co / v_subb_co, then one select): 8 VALU instructions.
 GL_HD u64 montyred(u64 lo, u64 hi) {
+#if defined(__clang__)
+    const u32 l0 = (u32)lo, l1 = (u32)(lo >> 32);
+    unsigned e, c1, c2, c3, unused;
+    const u32 a1 = __builtin_addc(l1, l0, 0u, &e);      // high word of a; its low word is l0
+    const u32 b0 = __builtin_subc(l0, a1, e, &c1);      // b = (a1:l0) - a1 - e
+    const u32 b1 = __builtin_subc(a1, 0u, c1, &unused);
+    const u32 r0 = __builtin_subc((u32)hi, b0, 0u, &c2);
+    const u32 r1 = __builtin_subc((u32)(hi >> 32), b1, c2, &c3);
+    const u64 r = ((u64)r1 << 32) | r0;
+    return c3 ? r + P : r;
+#else
     u64 a = lo + (lo << 32);
     u64 e = a < lo;
     u64 b = a - (a >> 32) - e;
     u64 r = hi - b;
     return (hi < b) ? r - EPS : r;
+#endif
 }
 
-// Montgomery product: a * b * 2^-64 mod p.
-GL_HD u64 mont_mul(u64 a, u64 b) { return montyred(a * b, mulhi64(a, b)); }
+// 64 x 64 -> 128 schoolbook product on 32-bit limbs: four v_mad_u64_u32 (32 x 32 + 64) and one 64-bit add.
+GL_HD void mul_wide(u64 a, u64 b, u64& lo, u64& hi) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+    const u64 p0 = (u64)a0 * b0;
+    const u64 p1 = (u64)a0 * b1 + (p0 >> 32);
+    const u64 p2 = (u64)a1 * b0 + (u32)p1;
+    hi = (u64)a1 * b1 + (p1 >> 32) + (p2 >> 32);
+    lo = (p2 << 32) | (u32)p0;
+#else
+    unsigned __int128 p = (unsigned __int128)a * b;
+    lo = (u64)p;
+    hi = (u64)(p >> 64);
+#endif
+}
+
+// Montgomery product: a * b * 2^-64 mod p  (b_field_element.rs:755-762).  18 VALU instructions on gfx950.
+GL_HD u64 mont_mul(u64 a, u64 b) {
+    u64 lo, hi;
+    mul_wide(a, b, lo, hi);
+    return montyred(lo, hi);
+}
 
 GL_HD u64 to_mont(u64 v) { return mont_mul(v, R2); }     // BFieldElement::new  (:235-237)
 GL_HD u64 from_mont(u64 raw) { return montyred(raw, 0); } // BFieldElement::value (:248-250)
@@ -86,38 +121,58 @@ GL_HD u64 mont_pow(u64 base, u64 exp) {
 
 GL_HD u64 mont_inverse(u64 a) { return mont_pow(a, P - 2); }  // 0 -> 0
 
-// x * 2^K mod p for canonical x, 0 <= K < 96.  (Plain integer power of two: multiplying a
-// Montgomery word by it keeps the Montgomery form.)
+// ---- multiplication by a power of two (the twiddles inside a radix-<=64 butterfly) -----------------
+// Two building blocks, both returning canonical words for ANY 64-bit input x:
+//
+//   shl_fold<K>(x), 0 < K < 32:   x * 2^K  =  (x << K) + hi * 2^64  =  (x << K) + hi * (2^32 - 1)
+//                                 one v_mad_u64_u32 does the fold; 8 VALU instructions.
+//   shl_monty<S>(x), 0 <= S < 64: montyred(x << S) = x * 2^(S-64) = x * 2^(S+128) = -(x * 2^(S+32))
+//                                 because 2^192 = 1 and 2^96 = -1 (mod p): the Montgomery reduction IS the
+//                                 multiplication by 2^(S+32) up to a sign the butterfly absorbs; 10 instructions.
+template <int K>
+GL_HD u64 shl_fold(u64 x) {
+    static_assert(K > 0 && K < 32, "");
+    const u64 lo = x << K;
+    const u32 hi = (u32)(x >> (64 - K));
+    const u64 t = (u64)hi * 0xffffffffu + lo;  // < 2^65
+    const bool c = t < lo;
+    const u64 u = t + EPS;  // t - p (mod 2^64)
+    const bool c2 = u < t;
+    return (c | c2) ? u : t;
+}
+
+template <int S>
+GL_HD u64 shl_monty(u64 x) {
+    static_assert(S >= 0 && S < 64, "");
+    const u64 lo = x << S;
+    const u64 hi = S ? (x >> ((64 - S) & 63)) : 0;
+    return montyred(lo, hi);  // x * 2^S < 2^127 < p * 2^64: a valid Montgomery-reduction input
+}
+
+// x * 2^E mod p as (value, sign): E taken mod 192; returns v with  x * 2^E = negate ? -v : v.
+template <int E>
+struct Pow2Mul {
+    static constexpr int e96 = ((E % 192) + 192) % 192 % 96;
+    static constexpr bool high = (((E % 192) + 192) % 192) >= 96;  // 2^96 = -1
+    static constexpr bool via_monty = e96 >= 32;
+    static constexpr bool negate = high != via_monty;
+    static GL_HD u64 apply(u64 x) {
+        if constexpr (e96 == 0) {
+            return x;
+        } else if constexpr (e96 < 32) {
+            return shl_fold<e96>(x);
+        } else {
+            return shl_monty<e96 - 32>(x);
+        }
+    }
+};
+
+// x * 2^K mod p (canonical), 0 <= K < 192
 template <int K>
 GL_HD u64 mul_pow2(u64 x) {
-    static_assert(K >= 0 && K < 96, "fold 2^96 = -1 into the butterfly sign");
-    if constexpr (K == 0) {
-        return x;
-    } else if constexpr (K < 32) {
-        // x * 2^K = lo + hi * 2^64 = lo + hi * EPS   (hi < 2^K)
-        u64 lo = x << K;
-        u64 hi = x >> (64 - K);
-        u64 t = (hi << 32) - hi;  // hi * EPS < 2^63
-        return add(lo, t);        // true sum < 2^64 + 2^63: add() still canonicalises
-    } else if constexpr (K < 64) {
-        // y = x << (K - 32) = y0 + y1 2^32 + y2 2^64 ; y * 2^32 = y0 2^32 + y1 EPS - y2
-        constexpr int J = K - 32;
-        u64 ylo = x << J;
-        u64 y2 = (J == 0) ? 0 : (x >> ((64 - J) & 63));
-        u64 y0 = ylo & 0xffffffffULL, y1 = ylo >> 32;
-        u64 a = y0 << 32;          // <= p - 1
-        u64 b = (y1 << 32) - y1;   // y1 * EPS < p
-        return sub(add(a, b), y2);
-    } else {
-        // y = x << (K - 64) ; y * 2^64 = y0 EPS - y1 - y2 2^32
-        constexpr int J = K - 64;
-        u64 ylo = x << J;
-        u64 y2 = (J == 0) ? 0 : (x >> ((64 - J) & 63));
-        u64 y0 = ylo & 0xffffffffULL, y1 = ylo >> 32;
-        u64 a = (y0 << 32) - y0;   // y0 * EPS < p
-        u64 b = y1 + (y2 << 32);   // < 2^32 + 2^63 < p
-        return sub(a, b);
-    }
+    const u64 v = Pow2Mul<K>::apply(x);
+    if constexpr (Pow2Mul<K>::negate) return neg(v);
+    return v;
 }
 
 }  // namespace gl

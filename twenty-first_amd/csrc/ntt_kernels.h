@@ -65,14 +65,14 @@ struct TwExp {
 
 template <int E>
 __device__ __forceinline__ void butterfly_pow2(u64& a, u64& b) {
-    if constexpr (E < 96) {
-        u64 v = gl::mul_pow2<E>(b);
-        u64 s = gl::add(a, v);
+    // (a, b) -> (a + b * 2^E, a - b * 2^E); the sign of the power-of-two product is folded into add/sub
+    const u64 v = gl::Pow2Mul<E>::apply(b);
+    if constexpr (!gl::Pow2Mul<E>::negate) {
+        const u64 s = gl::add(a, v);
         b = gl::sub(a, v);
         a = s;
-    } else {  // 2^E = -2^(E-96)
-        u64 v = gl::mul_pow2<E - 96>(b);
-        u64 s = gl::sub(a, v);
+    } else {
+        const u64 s = gl::sub(a, v);
         b = gl::add(a, v);
         a = s;
     }
