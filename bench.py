@@ -172,7 +172,7 @@ def main():
             traffic = None
     roofline = {
         "bound": "hbm",
-        "kernel": "tfk::ntt_pass_kernel<false>",
+        "kernel": "tfk::ntt_pass_kernel<false, false, 0>",
         "achieved": round(achieved, 1),
         "peak": HBM_PEAK_GBS,
         "unit": "GB/s",

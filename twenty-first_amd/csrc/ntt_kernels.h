@@ -51,7 +51,7 @@ struct NttPassArgs {
     int ps_col;
     int cpr, nrounds;                        // LDS exchange in `nrounds` rounds of `cpr` columns (bounds the LDS footprint)
     int s1, s2;                              // LDS strides in u64: idx = k1*s1 + g*s2 + (c % cpr)
-    int xcd_order;                           // 1: block b -> XCD b%8 works on column tiles = b%8 (mod 8) for all (i0,i1)
+    int xcd_order;                           // G > 0: XCD-aware tile order in groups of G adjacent column tiles (0: natural order)
     u32 nc_magic;                            // t / nc == umulhi(t, nc_magic) for every t < blockDim (checked by the planner)
 };
 
@@ -124,9 +124,13 @@ __global__ void __launch_bounds__(512, 4) ntt_pass_kernel(const NttPassArgs A) {
         // Blocks are dealt round-robin to the 8 XCDs (b % 8).  Give XCD x the column tiles = x (mod 8) and let
         // it walk all (batch, outer) indices of one column tile back to back, so the slice of the inter-pass
         // twiddle table that tile needs stays in that XCD's L2.  Placement only affects speed.
+        // xcd_order = G (1 or 2): groups of G adjacent column tiles stay together; with G = 2 the two 64-byte
+        // halves of every 128-byte line are requested back to back from the same XCD (second one hits its L2).
+        const u32 G = (u32)A.xcd_order;
         const u32 xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
-        i2 = ((slot / A.d01) << 3) | xcd;
-        const u32 rest = slot % A.d01;
+        const u32 grp = slot / (G * A.d01), within = slot % (G * A.d01);
+        i2 = ((grp << 3) | xcd) * G + within % G;
+        const u32 rest = within / G;
         i1 = rest % A.d1;
         i0 = rest / A.d1;
     } else {
@@ -171,7 +175,11 @@ __global__ void __launch_bounds__(512, 4) ntt_pass_kernel(const NttPassArgs A) {
                 const long long j = (ur + g) * A.ps_rs + (A.ps_col ? bcol : 0);
                 if (j < A.n_coeffs) x[q] = gl::mont_mul(*ptr, A.pre_scale[j]);
             } else {
+#ifdef TF_NT
+                x[q] = __builtin_nontemporal_load(ptr);
+#else
                 x[q] = *ptr;
+#endif
             }
         }
     }
@@ -249,7 +257,11 @@ __global__ void __launch_bounds__(512, 4) ntt_pass_kernel(const NttPassArgs A) {
                 for (int i = 0; i < 8; ++i) {
                     const int q = q0 + i;
                     const long long uk = (long long)(((q >> p2) << p2) + ((q & (P2 - 1)) << 5));
+#ifdef TF_NT
+                    __builtin_nontemporal_store(gl::mont_mul(x[q], w[i]), reinterpret_cast<u64*>(base + uk * A.out_rs * 8 + toff));
+#else
                     *reinterpret_cast<u64*>(base + uk * A.out_rs * 8 + toff) = gl::mont_mul(x[q], w[i]);
+#endif
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -258,7 +270,11 @@ __global__ void __launch_bounds__(512, 4) ntt_pass_kernel(const NttPassArgs A) {
 #pragma unroll
             for (int q = 0; q < 32; ++q) {
                 const long long uk = (long long)(((q >> p2) << p2) + ((q & (P2 - 1)) << 5));
+#ifdef TF_NT
+                __builtin_nontemporal_store(x[q], reinterpret_cast<u64*>(base + uk * A.out_rs * 8 + toff));
+#else
                 *reinterpret_cast<u64*>(base + uk * A.out_rs * 8 + toff) = x[q];
+#endif
             }
         }
     }

@@ -335,8 +335,19 @@ int pad_to_residue(int base, int residue) {  // smallest s >= base with s == res
     return base + r;
 }
 
-constexpr int kMaxThreads = 512;      // per workgroup; with <= 128 VGPRs two such workgroups share a CU (4 waves/SIMD)
-constexpr int kRoundElems = 8192;     // elements parked in LDS per exchange round (64 KiB): two workgroups fit 160 KiB
+// Workgroup geometry (tunable for A/B runs through TF_NTT_WG_THREADS = 256 | 512):
+//   512 threads: 16 columns per tile (128-byte segments), 64 KiB exchange rounds, 2 workgroups per CU;
+//   256 threads:  8 columns per tile (64-byte segments, adjacent tiles paired on one XCD), 32 KiB rounds, 4 per CU.
+int g_wg_threads = 0;
+int wg_threads() {
+    if (!g_wg_threads) {
+        const char* e = getenv("TF_NTT_WG_THREADS");
+        g_wg_threads = (e && atoi(e) == 512) ? 512 : ((e && atoi(e) == 256) ? 256 : 512);
+    }
+    return g_wg_threads;
+}
+#define kMaxThreads (wg_threads())
+#define kRoundElems (wg_threads() * 16)   // elements parked in LDS per exchange round: 64 KiB or 32 KiB
 
 // thread / LDS geometry shared by all pass types: nc columns, exchanged in rounds of cpr columns
 void finish_geometry(Launch* l, int nc, int p2) {
@@ -365,7 +376,6 @@ Launch plan_column_pass(const u64* in, u64* out, long long in_bs, long long out_
     const int p2 = a - 5, P2 = 1 << p2;
     const long long R = 1ll << a, Bw = B * L;
     int nc = (int)std::min<long long>(std::max(1, kMaxThreads / P2), Bw);
-    if (nc > 16 && P2 == 32) nc = 16;
     A.in = in;
     A.out = out;
     A.L = L;
@@ -387,7 +397,10 @@ Launch plan_column_pass(const u64* in, u64* out, long long in_bs, long long out_
     A.ps_col = 1;
     A.col_limit = (int)Bw;
     A.n_coeffs = -1;
-    A.xcd_order = (A.d2 % 8 == 0) ? 1 : 0;
+    {
+        const int G = (nc * (int)sizeof(u64) < 128) ? 2 : 1;  // pair tiles narrower than a 128-byte line
+        A.xcd_order = (A.d2 % (8 * G) == 0) ? G : ((A.d2 % 8 == 0) ? 1 : 0);
+    }
     finish_geometry(&l, nc, p2);
     l.tiles = (unsigned)(batch * outer * A.d2);
     return l;
@@ -396,7 +409,6 @@ Launch plan_column_pass(const u64* in, u64* out, long long in_bs, long long out_
 // rows (independent DFTs) per tile for the passes whose columns are whole rows of elements
 int rows_per_tile(int P2, int L, long long limit) {
     int nc_max = std::max(1, kMaxThreads / P2);
-    if (P2 == 32) nc_max = 16;
     int T = std::max(1, nc_max / L);
     return (int)std::min<long long>(T, limit);
 }
@@ -430,7 +442,7 @@ Launch plan_transpose_pass(const u64* in, u64* out, long long in_bs, long long o
     A.out_rs = N1 * Q * L;
     A.col_limit = (int)(N1 * L);
     A.n_coeffs = -1;
-    A.xcd_order = 0;
+    A.xcd_order = (nc * (int)sizeof(u64) < 128 && A.d2 % 16 == 0) ? 2 : 0;  // output segments narrower than a line: pair them
     finish_geometry(&l, nc, p2);
     l.tiles = (unsigned)(batch * Q * A.d2);
     return l;
