@@ -48,7 +48,10 @@ enum tf_status {
     TF_ERR_NULL_POINTER = 7,
     TF_ERR_NO_DEVICE = 8,                  /* no HIP device / HIP runtime unusable */
     TF_ERR_HIP = 9,                        /* a HIP call failed; see tf_last_error() */
-    TF_ERR_OUT_OF_MEMORY = 10
+    TF_ERR_OUT_OF_MEMORY = 10,
+    TF_ERR_LEAF_INDEX_INVALID = 11,        /* MerkleTreeError::LeafIndexInvalid  merkle_tree.rs:486-488 */
+    TF_ERR_INVERSE_OF_ZERO = 12,           /* offset.inverse() of zero panics    b_field_element.rs:264-268 */
+    TF_ERR_BUFFER_TOO_SMALL = 13
 };
 
 /* Human-readable name of a status code. */
@@ -115,6 +118,45 @@ int tf_merkle_build(const uint64_t *leaves, size_t n_leaves, uint64_t *nodes_out
 int tf_merkle_root(const uint64_t *leaves, size_t n_leaves, uint64_t *root_out, size_t batch);
 int tf_merkle_build_dev(const uint64_t *d_leaves, size_t n_leaves, uint64_t *d_nodes_out, size_t batch, void *stream);
 int tf_merkle_root_dev(const uint64_t *d_leaves, size_t n_leaves, uint64_t *d_root_out, size_t batch, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * "Next" rows of the scope table: the callers on either side of the path, kept in HBM.
+ *
+ * Coset interpolation   replaces  Polynomial::fast_coset_interpolate(offset, values)  math/polynomial.rs:1907-1918
+ *   values: batch x n evaluations on {offset * w_n^i}; out: batch x n coefficients (intt, then coefficient j
+ *   times offset^-j, fused into the last pass).  offset_raw == 0 -> TF_ERR_INVERSE_OF_ZERO.
+ * Hadamard product      the pointwise product inside fast_multiply  math/polynomial.rs:920-925
+ *   (BFieldElement b_field_element.rs:755-762; XFieldElement x_field_element.rs:512-536); out may alias a or b.
+ * Polynomial product    replaces  Polynomial::fast_multiply  math/polynomial.rs:900-932
+ *   a: batch x na coefficients, b: batch x nb, out: batch x (na + nb - 1); zero-pad to the next power of two,
+ *   ntt both, pointwise product, intt, truncate -- all on the device.  na == 0 or nb == 0: nothing is written.
+ * Low-degree extension  fast_coset_interpolate followed by fast_coset_evaluate with the coefficients staying in HBM:
+ *   values on {offset_in * w_n^i} -> values on {offset_out * w_m^i}, m >= n, both powers of two.
+ * Rows -> Merkle tree   Tip5::hash_varlen of every row (tip5/mod.rs:617-623) written straight into the leaf level
+ *   of the tree (util_types/merkle_tree.rs:165-212); rows: batch x n_rows x row_len words; nodes_out as tf_merkle_build.
+ * Authentication structure  replaces MerkleTree::authentication_structure_node_indices / authentication_structure
+ *   util_types/merkle_tree.rs:449-504, :614-622: node indices (needed minus computable, descending) and the gather of
+ *   those digests from a device-resident node array.  *out_count receives the number of nodes; leaf index >=
+ *   num_leafs -> TF_ERR_LEAF_INDEX_INVALID; num_leafs not a power of two -> TF_ERR_INCORRECT_NUMBER_OF_LEAFS.
+ *   tf_merkle_authentication_structure_dev synchronises `stream` (its result is host data).
+ */
+int tf_coset_interpolate_bfe(const uint64_t *values, size_t n, uint64_t offset_raw, uint64_t *out, size_t batch);
+int tf_coset_interpolate_xfe(const uint64_t *values, size_t n, uint64_t offset_raw, uint64_t *out, size_t batch);
+int tf_coset_interpolate_bfe_dev(const uint64_t *d_values, size_t n, uint64_t offset_raw, uint64_t *d_out, size_t batch, void *stream);
+int tf_coset_interpolate_xfe_dev(const uint64_t *d_values, size_t n, uint64_t offset_raw, uint64_t *d_out, size_t batch, void *stream);
+int tf_hadamard_bfe_dev(const uint64_t *d_a, const uint64_t *d_b, uint64_t *d_out, size_t count, void *stream);
+int tf_hadamard_xfe_dev(const uint64_t *d_a, const uint64_t *d_b, uint64_t *d_out, size_t count, void *stream);
+int tf_poly_mul_bfe(const uint64_t *a, size_t na, const uint64_t *b, size_t nb, uint64_t *out, size_t batch);
+int tf_poly_mul_xfe(const uint64_t *a, size_t na, const uint64_t *b, size_t nb, uint64_t *out, size_t batch);
+int tf_poly_mul_bfe_dev(const uint64_t *d_a, size_t na, const uint64_t *d_b, size_t nb, uint64_t *d_out, size_t batch, void *stream);
+int tf_poly_mul_xfe_dev(const uint64_t *d_a, size_t na, const uint64_t *d_b, size_t nb, uint64_t *d_out, size_t batch, void *stream);
+int tf_lde_bfe_dev(const uint64_t *d_values, size_t n, uint64_t offset_in_raw, uint64_t *d_out, size_t m, uint64_t offset_out_raw, size_t batch, void *stream);
+int tf_lde_xfe_dev(const uint64_t *d_values, size_t n, uint64_t offset_in_raw, uint64_t *d_out, size_t m, uint64_t offset_out_raw, size_t batch, void *stream);
+int tf_merkle_from_rows(const uint64_t *rows, size_t row_len, size_t n_rows, uint64_t *nodes_out, size_t batch);
+int tf_merkle_from_rows_dev(const uint64_t *d_rows, size_t row_len, size_t n_rows, uint64_t *d_nodes_out, size_t batch, void *stream);
+int tf_merkle_auth_structure_indices(size_t num_leafs, const uint64_t *leaf_indices, size_t k, uint64_t *out_indices, size_t capacity, size_t *out_count);
+int tf_merkle_authentication_structure_dev(const uint64_t *d_nodes, size_t num_leafs, const uint64_t *leaf_indices, size_t k,
+                                           uint64_t *out_digests, size_t capacity_digests, size_t *out_count, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Tuning knobs (process-wide; also read once from the environment):

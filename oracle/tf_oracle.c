@@ -663,6 +663,99 @@ int tfo_merkle_frugal_root(const uint64_t *leaves, size_t n, uint64_t root[5]) {
     return 0;
 }
 
+/* ------------------------------------------------------------------ "next" rows */
+
+/* schoolbook product: ground truth for fast_multiply (polynomial.rs:900-932 computes the same polynomial) */
+void tfo_poly_mul_naive(const uint64_t *a, size_t na, const uint64_t *b, size_t nb, int width, uint64_t *out) {
+    if (na == 0 || nb == 0) return;
+    size_t n_out = na + nb - 1;
+    memset(out, 0, n_out * (size_t)width * sizeof(u64));
+    for (size_t i = 0; i < na; i++) {
+        for (size_t j = 0; j < nb; j++) {
+            if (width == 1) {
+                out[i + j] = bfe_add(out[i + j], bfe_mul(a[i], b[j]));
+            } else {
+                u64 prod[3];
+                tfo_xfe_mul(a + 3 * i, b + 3 * j, prod);
+                for (int c = 0; c < 3; c++) out[3 * (i + j) + c] = bfe_add(out[3 * (i + j) + c], prod[c]);
+            }
+        }
+    }
+}
+
+/* Polynomial::fast_multiply restated literally (polynomial.rs:900-932): pad to order, ntt, pointwise, intt, truncate */
+int tfo_poly_mul_fast(const uint64_t *a, size_t na, const uint64_t *b, size_t nb, int width, uint64_t *out) {
+    if (na == 0 || nb == 0) return 0;
+    size_t n_out = na + nb - 1, order = 1;
+    while (order < n_out) order <<= 1;
+    u64 *l = (u64 *)calloc(order * (size_t)width, sizeof(u64));
+    u64 *r = (u64 *)calloc(order * (size_t)width, sizeof(u64));
+    memcpy(l, a, na * (size_t)width * sizeof(u64));
+    memcpy(r, b, nb * (size_t)width * sizeof(u64));
+    int rc = ntt_any(l, order, width, 0);
+    if (!rc) rc = ntt_any(r, order, width, 0);
+    if (!rc) {
+        for (size_t i = 0; i < order; i++) {
+            if (width == 1)
+                l[i] = bfe_mul(l[i], r[i]);
+            else
+                tfo_xfe_mul(l + 3 * i, r + 3 * i, l + 3 * i);
+        }
+        rc = ntt_any(l, order, width, 1);
+    }
+    if (!rc) memcpy(out, l, n_out * (size_t)width * sizeof(u64));
+    free(l);
+    free(r);
+    return rc;
+}
+
+static int cmp_u64_desc(const void *x, const void *y) {
+    u64 a = *(const u64 *)x, b = *(const u64 *)y;
+    return a < b ? 1 : (a > b ? -1 : 0);
+}
+static int contains_sorted_desc(const u64 *v, size_t n, u64 key) {
+    size_t lo = 0, hi = n;
+    while (lo < hi) {
+        size_t mid = (lo + hi) / 2;
+        if (v[mid] == key) return 1;
+        if (v[mid] > key) lo = mid + 1; else hi = mid;
+    }
+    return 0;
+}
+
+/* MerkleTree::authentication_structure_node_indices (merkle_tree.rs:449-504).
+ * rc: 2 IncorrectNumberOfLeafs, 11 LeafIndexInvalid.  out gets *count indices, descending. */
+int tfo_auth_structure_indices(size_t num_leafs, const uint64_t *leaf_indices, size_t k, uint64_t *out, size_t cap, size_t *count) {
+    if (num_leafs == 0 || ((num_leafs - 1) & num_leafs)) return 2;
+    size_t height = 0;
+    for (size_t v = num_leafs; v > 1; v >>= 1) height++;
+    size_t maxn = k * (height + 1) + 1;
+    u64 *needed = (u64 *)malloc(maxn * sizeof(u64)), *comp = (u64 *)malloc(maxn * sizeof(u64));
+    size_t nn = 0, nc = 0;
+    for (size_t i = 0; i < k; i++) {
+        if (leaf_indices[i] >= num_leafs) { free(needed); free(comp); return 11; }
+        u64 node = leaf_indices[i] + num_leafs;
+        while (node > 1) {
+            comp[nc++] = node;
+            needed[nn++] = node ^ 1;
+            node /= 2;
+        }
+    }
+    qsort(needed, nn, sizeof(u64), cmp_u64_desc);
+    qsort(comp, nc, sizeof(u64), cmp_u64_desc);
+    size_t w = 0;
+    for (size_t i = 0; i < nn; i++) {
+        if (i && needed[i] == needed[i - 1]) continue;          /* set semantics */
+        if (contains_sorted_desc(comp, nc, needed[i])) continue; /* difference */
+        if (w < cap) out[w] = needed[i];
+        w++;
+    }
+    *count = w;
+    free(needed);
+    free(comp);
+    return 0;
+}
+
 /* ------------------------------------------------------------------ helpers */
 
 uint64_t tfo_splitmix64(uint64_t *state) {

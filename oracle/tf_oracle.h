@@ -85,6 +85,11 @@ int tfo_merkle_build(const uint64_t *leaves, size_t n_leaves, uint64_t *nodes /*
 int tfo_merkle_build_par(const uint64_t *leaves, size_t n_leaves, uint64_t *nodes, int threads, size_t cutoff);
 int tfo_merkle_frugal_root(const uint64_t *leaves, size_t n_leaves, uint64_t root[5]); /* :299-309 via mmr_accumulator.rs:96-115 */
 
+/* ---- "next" rows ---- */
+void tfo_poly_mul_naive(const uint64_t *a, size_t na, const uint64_t *b, size_t nb, int width, uint64_t *out); /* schoolbook */
+int tfo_poly_mul_fast(const uint64_t *a, size_t na, const uint64_t *b, size_t nb, int width, uint64_t *out);   /* polynomial.rs:900-932 */
+int tfo_auth_structure_indices(size_t num_leafs, const uint64_t *leaf_indices, size_t k, uint64_t *out, size_t cap, size_t *count); /* merkle_tree.rs:449-504 */
+
 /* ---- helpers for tests/bench ---- */
 uint64_t tfo_splitmix64(uint64_t *state);
 /* fill `count` raw BFE words: new(splitmix64(seed ^ (b<<32) ^ i) mod p)   */

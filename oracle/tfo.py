@@ -74,6 +74,9 @@ def lib() -> C.CDLL:
             "tfo_merkle_build": (i32, [pu, sz, pu]),
             "tfo_merkle_build_par": (i32, [pu, sz, pu, i32, sz]),
             "tfo_merkle_frugal_root": (i32, [pu, sz, pu]),
+            "tfo_poly_mul_naive": (None, [pu, sz, pu, sz, i32, pu]),
+            "tfo_poly_mul_fast": (i32, [pu, sz, pu, sz, i32, pu]),
+            "tfo_auth_structure_indices": (i32, [sz, pu, sz, pu, sz, C.POINTER(C.c_size_t)]),
             "tfo_fill_random": (None, [pu, sz, u64]),
             "tfo_digest_to_hex": (None, [pu, C.c_char_p]),
         }
@@ -315,6 +318,46 @@ def merkle_frugal_root(leaves) -> np.ndarray:
     if rc:
         raise OraclePanic(rc)
     return root
+
+
+# ---- "next" rows ---------------------------------------------------------------------
+
+def poly_mul(a, b, width: int = 1, naive: bool = False) -> np.ndarray:
+    a, b = _arr(a).reshape(-1), _arr(b).reshape(-1)
+    na, nb = a.size // width, b.size // width
+    if na == 0 or nb == 0:
+        return np.zeros(0, dtype=np.uint64)
+    out = np.zeros((na + nb - 1) * width, dtype=np.uint64)
+    if naive:
+        lib().tfo_poly_mul_naive(_p(a), na, _p(b), nb, width, _p(out))
+    else:
+        rc = lib().tfo_poly_mul_fast(_p(a), na, _p(b), nb, width, _p(out))
+        if rc:
+            raise OraclePanic(rc)
+    return out
+
+
+def hadamard(a, b, width: int = 1) -> np.ndarray:
+    a, b = _arr(a).reshape(-1), _arr(b).reshape(-1)
+    if width == 1:
+        return np.array([bfe_mul(int(x), int(y)) for x, y in zip(a, b)], dtype=np.uint64)
+    return np.concatenate([xfe_mul(a[3 * i:3 * i + 3], b[3 * i:3 * i + 3]) for i in range(a.size // 3)])
+
+
+def auth_structure_indices(num_leafs: int, leaf_indices) -> np.ndarray:
+    li = _arr(leaf_indices).reshape(-1)
+    cap = max(1, li.size * 70)
+    out = np.zeros(cap, dtype=np.uint64)
+    cnt = C.c_size_t(0)
+    buf = li if li.size else np.zeros(1, dtype=np.uint64)
+    rc = lib().tfo_auth_structure_indices(num_leafs, _p(buf), li.size, _p(out), cap, C.byref(cnt))
+    if rc:
+        raise OraclePanic(rc)
+    return out[: cnt.value].copy()
+
+
+def merkle_from_rows(rows, row_len: int) -> np.ndarray:
+    return merkle_build(hash_varlen_rows(rows, row_len))
 
 
 # ---- helpers -------------------------------------------------------------------------

@@ -1,0 +1,151 @@
+"""GPU parity for the "next" rows of the scope table: coset interpolation, Hadamard /
+fast_multiply, low-degree extension, rows -> Merkle tree, authentication structures.  Bit-exact vs the oracle."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+P = 0xFFFFFFFF00000001
+
+
+def _to_dev(a):
+    import torch
+
+    return torch.from_numpy(a.view(np.int64)).cuda()
+
+
+def _to_host(t):
+    return t.cpu().numpy().view(np.uint64)
+
+
+@pytest.mark.parametrize("width", [1, 3])
+@pytest.mark.parametrize("log_n", [0, 1, 3, 5, 8, 10, 11, 14, 16, 20, 21])
+def test_coset_interpolate_matches_oracle(tf, oracle, width, log_n):
+    """math/polynomial.rs:1907-1918; and interpolate(evaluate(f)) == f (tests :3665-3680 style)"""
+    n = 1 << log_n
+    batch = 3 if log_n <= 14 else 1
+    v = oracle.fill_random(n * width * batch, 400 + log_n)
+    off = oracle.bfe_new(7)
+    got = tf.fast_coset_interpolate(v, off, width=width, batch=batch).reshape(batch, -1)
+    for b in range(batch):
+        want = oracle.coset_interpolate(v[b * n * width:(b + 1) * n * width], off, width=width)
+        assert np.array_equal(got[b], want)
+    back = tf.fast_coset_evaluate(got.reshape(-1), off, n, width=width, batch=batch)
+    assert np.array_equal(back, v)
+
+
+def test_coset_interpolate_errors_and_polynomial_api(tf, oracle):
+    v = oracle.fill_random(16, 1)
+    with pytest.raises(tf.NttPanic) as e:
+        tf.fast_coset_interpolate(v, 0)  # offset.inverse() of zero
+    assert e.value.code == 12
+    with pytest.raises(tf.NttPanic):
+        tf.fast_coset_interpolate(v[:12], oracle.bfe_new(7))
+    for off_val in [1, 2, 7, P - 1]:
+        off = oracle.bfe_new(off_val)
+        p = tf.Polynomial.fast_coset_interpolate(off, v)
+        want = oracle.coset_interpolate(v, off)
+        assert np.array_equal(p.coefficients, want[: p.coefficients.size]) and not want[p.coefficients.size:].any()
+
+
+@pytest.mark.parametrize("width", [1, 3])
+@pytest.mark.parametrize("na,nb", [(1, 1), (2, 3), (7, 5), (16, 16), (17, 16), (100, 29), (300, 513), (4096, 4097)])
+def test_fast_multiply_matches_oracle(tf, oracle, width, na, nb):
+    """math/polynomial.rs:900-932 vs the literal restatement; small cases also vs schoolbook"""
+    batch = 2 if na * nb < 100000 else 1
+    a = oracle.fill_random(na * width * batch, 50 + na)
+    b = oracle.fill_random(nb * width * batch, 60 + nb)
+    got = tf.fast_multiply(a, b, width=width, batch=batch).reshape(batch, -1)
+    for k in range(batch):
+        ak, bk = a[k * na * width:(k + 1) * na * width], b[k * nb * width:(k + 1) * nb * width]
+        assert np.array_equal(got[k], oracle.poly_mul(ak, bk, width=width))
+        if na * nb <= 4096:
+            assert np.array_equal(got[k], oracle.poly_mul(ak, bk, width=width, naive=True))
+
+
+def test_polynomial_fast_multiply_api(tf, oracle):
+    a = tf.Polynomial(np.concatenate([oracle.fill_random(9, 3), np.zeros(4, np.uint64)]))
+    b = tf.Polynomial(oracle.fill_random(5, 4))
+    prod = a.fast_multiply(b)
+    assert prod.degree() == 12
+    assert np.array_equal(prod.coefficients, oracle.poly_mul(a.coefficients, b.coefficients, naive=True))
+    zero = tf.Polynomial(np.zeros(3, np.uint64))
+    assert a.fast_multiply(zero).degree() == -1  # polynomial.rs:907-909
+
+
+@pytest.mark.parametrize("width", [1, 3])
+def test_hadamard_and_lde_device(tf, oracle, width):
+    import torch
+
+    n = 1 << 10
+    a = oracle.fill_random(n * width, 11)
+    b = oracle.fill_random(n * width, 12)
+    da, db = _to_dev(a), _to_dev(b)
+    out = torch.empty_like(da)
+    tf.device.hadamard(da, db, out, width=width)
+    torch.cuda.synchronize()
+    assert np.array_equal(_to_host(out), oracle.hadamard(a, b, width=width))
+    # low-degree extension: values on the order-n coset of offset 1 -> order-4n coset of offset 7
+    m = 4 * n
+    ext = torch.empty(m * width, dtype=torch.int64, device="cuda")
+    one, seven = oracle.bfe_new(1), oracle.bfe_new(7)
+    tf.device.lde(da, n, one, ext, m, seven, width=width)
+    torch.cuda.synchronize()
+    coeffs = oracle.coset_interpolate(a, one, width=width)
+    assert np.array_equal(_to_host(ext), oracle.coset_evaluate(coeffs, seven, m, width=width))
+    # device fast_multiply
+    prod = torch.empty((2 * n - 1) * width, dtype=torch.int64, device="cuda")
+    tf.device.poly_mul(da, n, db, n, prod, width=width)
+    torch.cuda.synchronize()
+    assert np.array_equal(_to_host(prod), oracle.poly_mul(a, b, width=width))
+
+
+@pytest.mark.parametrize("n_rows,row_len", [(1, 3), (2, 0), (8, 1), (64, 10), (256, 23), (512, 9), (4096, 30)])
+def test_merkle_from_rows(tf, oracle, n_rows, row_len):
+    rows = oracle.fill_random(n_rows * row_len, 70 + n_rows)
+    if row_len == 0:
+        with_rows = np.zeros(0, dtype=np.uint64)
+        nodes = np.empty(10 * n_rows, dtype=np.uint64)
+        import ctypes as C
+
+        rc = tf.lib().tf_merkle_from_rows(C.c_void_p(0), 0, n_rows, C.c_void_p(nodes.ctypes.data), 1)
+        assert rc == 0
+        leaves = np.concatenate([oracle.hash_varlen(with_rows)] * n_rows)
+        assert np.array_equal(nodes, oracle.merkle_build(leaves))
+        return
+    tree = tf.MerkleTree.from_rows(rows, row_len)
+    want = oracle.merkle_from_rows(rows, row_len).reshape(2 * n_rows, 5)
+    assert np.array_equal(tree.nodes, want)
+    with pytest.raises(tf.MerkleTreeError):
+        tf.MerkleTree.from_rows(oracle.fill_random(3 * 4, 1), 4)
+
+
+def test_authentication_structure(tf, oracle):
+    """util_types/merkle_tree.rs:449-504, :604-622 (doc example: leafs 0 and 2 of 8 -> nodes [11, 9, 3])"""
+    import random
+
+    import torch
+
+    assert list(tf.MerkleTree.authentication_structure_node_indices(8, [0, 2])) == [11, 9, 3]
+    assert list(tf.MerkleTree.authentication_structure_node_indices(8, [])) == []
+    with pytest.raises(tf.MerkleTreeError) as e:
+        tf.MerkleTree.authentication_structure_node_indices(8, [8])
+    assert e.value.variant == "LeafIndexInvalid"
+    with pytest.raises(tf.MerkleTreeError) as e:
+        tf.MerkleTree.authentication_structure_node_indices(12, [1])
+    assert e.value.variant == "IncorrectNumberOfLeafs"
+    rng = random.Random(5)
+    for height in [0, 1, 4, 10]:
+        n = 1 << height
+        leaves = oracle.fill_random(5 * n, 900 + height)
+        dn = torch.empty(10 * n, dtype=torch.int64, device="cuda")
+        tf.device.merkle_build(_to_dev(leaves), n, dn)
+        torch.cuda.synchronize()
+        host_nodes = oracle.merkle_build(leaves).reshape(2 * n, 5)
+        tree = tf.MerkleTree(host_nodes)
+        for k in [0, 1, 3, 17]:
+            idx = [rng.randrange(n) for _ in range(k)]
+            want_idx = oracle.auth_structure_indices(n, idx)
+            assert np.array_equal(tf.MerkleTree.authentication_structure_node_indices(n, idx), want_idx)
+            got = tf.device.authentication_structure(dn, n, idx)
+            assert np.array_equal(got, host_nodes[want_idx.astype(np.int64)])
+            assert np.array_equal(tree.authentication_structure(idx), got)

@@ -26,7 +26,7 @@ import numpy as np
 from . import _lib
 
 __all__ = [
-    "P", "BFieldElement", "ntt", "intt", "Polynomial", "fast_coset_evaluate", "Tip5", "Digest", "MerkleTree",
+    "P", "BFieldElement", "ntt", "intt", "Polynomial", "fast_coset_evaluate", "fast_coset_interpolate", "fast_multiply", "Tip5", "Digest", "MerkleTree",
     "MerkleTreeError", "TwentyFirstError", "NttPanic", "lib", "device",
 ]
 
@@ -58,7 +58,7 @@ class NttPanic(TwentyFirstError):
 class MerkleTreeError(TwentyFirstError):
     """util_types/merkle_tree.rs:933-965; .variant is the Rust variant name."""
 
-    VARIANTS = {1: "TooFewLeafs", 2: "IncorrectNumberOfLeafs", 3: "TreeTooHigh"}
+    VARIANTS = {1: "TooFewLeafs", 2: "IncorrectNumberOfLeafs", 3: "TreeTooHigh", 11: "LeafIndexInvalid"}
 
     def __init__(self, code: int, where: str = ""):
         super().__init__(code, where)
@@ -68,9 +68,9 @@ class MerkleTreeError(TwentyFirstError):
 def _check(rc: int, where: str):
     if rc == 0:
         return
-    if rc in (1, 2, 3):
+    if rc in (1, 2, 3, 11):
         raise MerkleTreeError(rc, where)
-    if rc in (4, 5, 6):
+    if rc in (4, 5, 6, 12):
         raise NttPanic(rc, where)
     raise TwentyFirstError(rc, where)
 
@@ -146,6 +146,32 @@ def fast_coset_evaluate(coeffs: np.ndarray, offset_raw: int, order: int, width: 
     return out
 
 
+def fast_coset_interpolate(values: np.ndarray, offset_raw: int, width: int = 1, batch: int = 1) -> np.ndarray:
+    """`batch` x n evaluations on {offset * w^i} -> `batch` x n coefficients (math/polynomial.rs:1907-1918)."""
+    values = _words(values, "values")
+    if batch and values.size % (batch * width):
+        raise ValueError("values size is not batch * n * width")
+    n = values.size // (batch * width) if batch else 0
+    out = np.empty_like(values)
+    fn = lib().tf_coset_interpolate_bfe if width == 1 else lib().tf_coset_interpolate_xfe
+    _check(fn(_ptr(values), n, C.c_uint64(offset_raw), _ptr(out), batch), "fast_coset_interpolate")
+    return out
+
+
+def fast_multiply(a: np.ndarray, b: np.ndarray, width: int = 1, batch: int = 1) -> np.ndarray:
+    """Coefficient arrays of `batch` polynomial pairs -> `batch` x (na + nb - 1) product coefficients
+    (math/polynomial.rs:900-932, untrimmed)."""
+    a, b = _words(a, "a"), _words(b, "b")
+    na = a.size // (batch * width) if batch else 0
+    nb = b.size // (batch * width) if batch else 0
+    if na == 0 or nb == 0:
+        return np.zeros(0, dtype=np.uint64)
+    out = np.empty(batch * (na + nb - 1) * width, dtype=np.uint64)
+    fn = lib().tf_poly_mul_bfe if width == 1 else lib().tf_poly_mul_xfe
+    _check(fn(_ptr(a), na, _ptr(b), nb, _ptr(out), batch), "fast_multiply")
+    return out
+
+
 class Polynomial:
     """Coefficients low -> high degree (math/polynomial.rs:78-84); only the hot-path members."""
 
@@ -165,6 +191,20 @@ class Polynomial:
         if order <= self.degree():  # :1388-1392
             raise NttPanic(6, "fast_coset_evaluate")
         return fast_coset_evaluate(self.coefficients, offset_raw, order, width=self.width, batch=1)
+
+    @classmethod
+    def fast_coset_interpolate(cls, offset_raw: int, values: np.ndarray, width: int = 1) -> "Polynomial":
+        """math/polynomial.rs:1907-1918; panics (NttPanic) unless len(values) is a power of two."""
+        v = np.ascontiguousarray(values, dtype=np.uint64).reshape(-1)
+        return cls(fast_coset_interpolate(v, offset_raw, width=width), width=width)
+
+    def fast_multiply(self, other: "Polynomial") -> "Polynomial":
+        """math/polynomial.rs:900-932 (same field on both sides)."""
+        if self.width != other.width:
+            raise ValueError("mixed-field products stay on the caller's side")
+        if self.degree() < 0 or other.degree() < 0:
+            return Polynomial(np.zeros(0, dtype=np.uint64), width=self.width)
+        return Polynomial(fast_multiply(self.coefficients, other.coefficients, width=self.width), width=self.width)
 
 
 # ----------------------------------------------------------------------------- Tip5
@@ -296,6 +336,33 @@ class MerkleTree:
         roots = np.empty(max(batch, 1) * 5, dtype=np.uint64)
         _check(lib().tf_merkle_root(_ptr(leafs), n_leafs, _ptr(roots), batch), "MerkleTree::par_frugal_root")
         return roots[: batch * 5].reshape(batch, 5)
+
+    @classmethod
+    def from_rows(cls, rows: np.ndarray, row_len: int) -> "MerkleTree":
+        """Leaves = Tip5::hash_varlen of every row (tip5/mod.rs:617-623), then par_new -- one device pipeline."""
+        rows = _words(np.ascontiguousarray(rows, dtype=np.uint64).reshape(-1), "rows")
+        n = rows.size // row_len if row_len else 0
+        nodes = np.empty(max(10 * n, 1), dtype=np.uint64)
+        _check(lib().tf_merkle_from_rows(_ptr(rows), row_len, n, _ptr(nodes), 1), "MerkleTree::par_new")
+        return cls(nodes[: 10 * n].reshape(2 * n, 5))
+
+    @staticmethod
+    def authentication_structure_node_indices(num_leafs: int, leaf_indices) -> np.ndarray:
+        """util_types/merkle_tree.rs:449-504 (descending node indices); raises MerkleTreeError variants."""
+        li = np.ascontiguousarray(leaf_indices, dtype=np.uint64).reshape(-1)
+        cap = max(1, li.size * 66)
+        out = np.empty(cap, dtype=np.uint64)
+        cnt = C.c_size_t(0)
+        rc = lib().tf_merkle_auth_structure_indices(num_leafs, _ptr(li), li.size, _ptr(out), cap, C.byref(cnt))
+        if rc == 11:
+            raise MerkleTreeError(rc, "MerkleTree::authentication_structure")
+        _check(rc, "MerkleTree::authentication_structure")
+        return out[: cnt.value].copy()
+
+    def authentication_structure(self, leaf_indices) -> np.ndarray:
+        """util_types/merkle_tree.rs:614-622: the digests at authentication_structure_node_indices, in that order."""
+        idx = self.authentication_structure_node_indices(self.num_leafs(), leaf_indices)
+        return self.nodes[idx.astype(np.int64)]
 
     def root(self) -> np.ndarray:  # :624-626
         return self.nodes[1]

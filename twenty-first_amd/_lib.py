@@ -41,6 +41,22 @@ SIGNATURES = {
     "tf_merkle_root": (C.c_int, [_vp, _sz, _vp, _sz]),
     "tf_merkle_build_dev": (C.c_int, [_vp, _sz, _vp, _sz, _vp]),
     "tf_merkle_root_dev": (C.c_int, [_vp, _sz, _vp, _sz, _vp]),
+    "tf_coset_interpolate_bfe": (C.c_int, [_vp, _sz, C.c_uint64, _vp, _sz]),
+    "tf_coset_interpolate_xfe": (C.c_int, [_vp, _sz, C.c_uint64, _vp, _sz]),
+    "tf_coset_interpolate_bfe_dev": (C.c_int, [_vp, _sz, C.c_uint64, _vp, _sz, _vp]),
+    "tf_coset_interpolate_xfe_dev": (C.c_int, [_vp, _sz, C.c_uint64, _vp, _sz, _vp]),
+    "tf_hadamard_bfe_dev": (C.c_int, [_vp, _vp, _vp, _sz, _vp]),
+    "tf_hadamard_xfe_dev": (C.c_int, [_vp, _vp, _vp, _sz, _vp]),
+    "tf_poly_mul_bfe": (C.c_int, [_vp, _sz, _vp, _sz, _vp, _sz]),
+    "tf_poly_mul_xfe": (C.c_int, [_vp, _sz, _vp, _sz, _vp, _sz]),
+    "tf_poly_mul_bfe_dev": (C.c_int, [_vp, _sz, _vp, _sz, _vp, _sz, _vp]),
+    "tf_poly_mul_xfe_dev": (C.c_int, [_vp, _sz, _vp, _sz, _vp, _sz, _vp]),
+    "tf_lde_bfe_dev": (C.c_int, [_vp, _sz, C.c_uint64, _vp, _sz, C.c_uint64, _sz, _vp]),
+    "tf_lde_xfe_dev": (C.c_int, [_vp, _sz, C.c_uint64, _vp, _sz, C.c_uint64, _sz, _vp]),
+    "tf_merkle_from_rows": (C.c_int, [_vp, _sz, _sz, _vp, _sz]),
+    "tf_merkle_from_rows_dev": (C.c_int, [_vp, _sz, _sz, _vp, _sz, _vp]),
+    "tf_merkle_auth_structure_indices": (C.c_int, [_sz, _vp, _sz, _vp, _sz, C.POINTER(C.c_size_t)]),
+    "tf_merkle_authentication_structure_dev": (C.c_int, [_vp, _sz, _vp, _sz, _vp, _sz, C.POINTER(C.c_size_t), _vp]),
     "tf_ntt_launch_count": (C.c_int, [_sz, _sz, C.c_int]),
     "tf_set_ntt_tile_bytes": (None, [_sz]),
     "tf_get_ntt_tile_bytes": (_sz, []),

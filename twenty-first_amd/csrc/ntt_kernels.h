@@ -36,6 +36,8 @@ struct NttPassArgs {
     const u64* inner_tw;   // [P2][32] Montgomery words: w_R^(+-g*k1) (times n^-1 for the last inverse pass); may be null
     const u64* post_tw;    // inter-pass twiddles T[k * tw_rs + b] (Montgomery words) or null
     const u64* pre_scale;  // coset powers S[j] (Montgomery words) or null        (polynomial.rs:760-773)
+    const u64* post_scale; // interpolation powers offset^-j applied to output element j, or null (polynomial.rs:1907-1918)
+    long long js_i1, js_i2, js_c, js_k;  // output element index j = i1*js_i1 + i2*js_i2 + (c/L)*js_c + k*js_k (last pass only)
     long long n_coeffs;    // elements present per input polynomial; rows beyond are zero (polynomial.rs:1395); <0: no padding
     long long ib0, ib1, ib2, ob0, ob1, ob2;  // tile base strides (words)
     long long in_cs_hi, out_cs_hi;           // column c -> (c / L) * cs_hi + (c % L)
@@ -107,11 +109,13 @@ __device__ __forceinline__ u32 div_by_L(u32 v, int L) {  // v / L for L in {1, 3
     return L == 1 ? v : (u32)(((unsigned long long)v * 0xAAAAAAABull) >> 33);
 }
 
-// COSET: the first pass of fast_coset_evaluate -- multiply coefficient j by offset^j on load and read rows
-//        beyond n_coeffs as zero (polynomial.rs:760-773, :1394-1395).
+// SCALE = 1: first pass of fast_coset_evaluate -- multiply coefficient j by offset^j on load and read rows beyond
+//            n_coeffs as zero (polynomial.rs:760-773, :1394-1395).
+// SCALE = 2: last pass of fast_coset_interpolate -- multiply output coefficient j by offset^-j on store
+//            (polynomial.rs:1907-1918: intt, then scale by the inverse offset).
 // MODE: 0 = product kernel.  1 / 2 are measurement-only ablations (TF_NTT_ABLATE, never the default):
 //   1 = no global loads/stores (synthetic operands), 2 = no arithmetic (loads, LDS exchange, stores only).
-template <bool INV, bool COSET, int MODE = 0>
+template <bool INV, int SCALE, int MODE = 0>
 __global__ void __launch_bounds__(512, 4) ntt_pass_kernel(const NttPassArgs A) {
     extern __shared__ __attribute__((aligned(16))) u64 lds[];
     const int t = threadIdx.x;
@@ -171,7 +175,7 @@ __global__ void __launch_bounds__(512, 4) ntt_pass_kernel(const NttPassArgs A) {
         for (int q = 0; q < 32; ++q) {
             const long long ur = (long long)(brev5(q) << p2);  // uniform part of the row index
             const u64* ptr = reinterpret_cast<const u64*>(base + ur * A.in_rs * 8 + toff);
-            if constexpr (COSET) {
+            if constexpr (SCALE == 1) {
                 const long long j = (ur + g) * A.ps_rs + (A.ps_col ? bcol : 0);
                 if (j < A.n_coeffs) x[q] = gl::mont_mul(*ptr, A.pre_scale[j]);
             } else {
@@ -265,6 +269,25 @@ __global__ void __launch_bounds__(512, 4) ntt_pass_kernel(const NttPassArgs A) {
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+        } else if constexpr (SCALE == 2) {
+            const long long j0 = (long long)i1 * A.js_i1 + (long long)i2 * A.js_i2 + (long long)ch * A.js_c + (long long)g * A.js_k;
+#pragma unroll
+            for (int q0 = 0; q0 < 32; q0 += 8) {
+                u64 w[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int q = q0 + i;
+                    const long long uk = (long long)(((q >> p2) << p2) + ((q & (P2 - 1)) << 5));
+                    w[i] = A.post_scale[j0 + uk * A.js_k];
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int q = q0 + i;
+                    const long long uk = (long long)(((q >> p2) << p2) + ((q & (P2 - 1)) << 5));
+                    *reinterpret_cast<u64*>(base + uk * A.out_rs * 8 + toff) = gl::mont_mul(x[q], w[i]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
         } else {
             __builtin_amdgcn_s_setprio(3);
 #pragma unroll
@@ -286,6 +309,7 @@ struct NttTinyArgs {
     u64* out;
     const u64* tw;         // stage tables back to back: stage i (m = 2^i) at offset m - 1 (ntt.rs:309-324)
     const u64* pre_scale;  // or null
+    const u64* post_scale; // or null: output element j times post_scale[j]
     long long n_coeffs;    // < 0: none
     long long in_bs, out_bs;  // batch strides in words
     long long count;       // batch * L
@@ -329,6 +353,7 @@ __global__ void __launch_bounds__(256) ntt_tiny_kernel(const NttTinyArgs A) {
         if (j < n) {
             u64 v = x[j];
             if (A.scale) v = gl::mont_mul(v, A.scale);
+            if (A.post_scale) v = gl::mont_mul(v, A.post_scale[j]);
             dst[(long long)j * L] = v;
         }
     }
@@ -350,6 +375,50 @@ __global__ void __launch_bounds__(256) build_pow_table_kernel(u64* out, const u6
     long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= n) return;
     out[id] = gl::mont_mul(hi[id >> h], lo[id & ((1ll << h) - 1)]);
+}
+
+// ---- pointwise products (Hadamard) ---------------------------------------------------------------
+// out[i] = a[i] * b[i] over BFieldElement (b_field_element.rs:755-762)
+__global__ void __launch_bounds__(256) hadamard_bfe_kernel(const u64* a, const u64* b, u64* out, long long count) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (; i < count; i += stride) out[i] = gl::mont_mul(a[i], b[i]);
+}
+
+// out[i] = a[i] * b[i] over XFieldElement = F_p[x]/(x^3 - x + 1)  (x_field_element.rs:512-536):
+// with self = [c, b, a], other = [f, e, d]:  r0 = cf - ae - bd;  r1 = bf + ce - ad + ae + bd;  r2 = af + be + cd + ad
+__global__ void __launch_bounds__(256) hadamard_xfe_kernel(const u64* pa, const u64* pb, u64* out, long long count) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (; i < count; i += stride) {
+        const u64 c = pa[3 * i], b = pa[3 * i + 1], a = pa[3 * i + 2];
+        const u64 f = pb[3 * i], e = pb[3 * i + 1], d = pb[3 * i + 2];
+        const u64 ae = gl::mont_mul(a, e), bd = gl::mont_mul(b, d), ad = gl::mont_mul(a, d);
+        const u64 r0 = gl::sub(gl::sub(gl::mont_mul(c, f), ae), bd);
+        const u64 r1 = gl::add(gl::add(gl::sub(gl::add(gl::mont_mul(b, f), gl::mont_mul(c, e)), ad), ae), bd);
+        const u64 r2 = gl::add(gl::add(gl::add(gl::mont_mul(a, f), gl::mont_mul(b, e)), gl::mont_mul(c, d)), ad);
+        out[3 * i] = r0;
+        out[3 * i + 1] = r1;
+        out[3 * i + 2] = r2;
+    }
+}
+
+// dst[b][0..n_dst) = src[b][0..min(n_src, n_dst)) then zeros (resize(order, ZERO), polynomial.rs:913-914); words, not elements
+__global__ void __launch_bounds__(256) pad_copy_kernel(const u64* src, u64* dst, long long n_src, long long n_dst, long long batch) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (; i < n_dst * batch; i += stride) {
+        const long long b = i / n_dst, j = i - b * n_dst;
+        dst[i] = j < n_src ? src[b * n_src + j] : 0;
+    }
+}
+
+// out[k] = nodes[idx[k]] for digests (5 words): authentication structures from a device-resident tree
+__global__ void __launch_bounds__(256) gather_digests_kernel(const u64* nodes, const unsigned long long* idx, long long count, u64* out) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count * 5) return;
+    const long long k = i / 5, w = i - 5 * k;
+    out[i] = nodes[idx[k] * 5 + w];
 }
 
 }  // namespace tfk

@@ -11,6 +11,7 @@
 #include <cstring>
 #include <map>
 #include <mutex>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -442,6 +443,10 @@ Launch plan_transpose_pass(const u64* in, u64* out, long long in_bs, long long o
     A.out_rs = N1 * Q * L;
     A.col_limit = (int)(N1 * L);
     A.n_coeffs = -1;
+    A.js_i1 = N1;
+    A.js_i2 = T;
+    A.js_c = 1;
+    A.js_k = N1 * Q;
     A.xcd_order = (nc * (int)sizeof(u64) < 128 && A.d2 % 16 == 0) ? 2 : 0;  // output segments narrower than a line: pair them
     finish_geometry(&l, nc, p2);
     l.tiles = (unsigned)(batch * Q * A.d2);
@@ -471,17 +476,18 @@ Launch plan_row_pass(const u64* in, u64* out, long long in_bs, long long out_bs,
     A.ps_rs = 1;
     A.ps_col = 0;
     A.n_coeffs = -1;
+    A.js_k = 1;  // single pass: output element index = k
     A.xcd_order = 0;
     finish_geometry(&l, nc, p2);
     l.tiles = A.d2;
     return l;
 }
 
-template <bool INV, bool COSET, int MODE>
+template <bool INV, int SCALE, int MODE>
 int launch_pass_t(const Launch& l, hipStream_t stream) {
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&tfk::ntt_pass_kernel<INV, COSET, MODE>),
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&tfk::ntt_pass_kernel<INV, SCALE, MODE>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    hipLaunchKernelGGL((tfk::ntt_pass_kernel<INV, COSET, MODE>), dim3(l.tiles), dim3(l.threads), l.lds_bytes, stream, l.a);
+    hipLaunchKernelGGL((tfk::ntt_pass_kernel<INV, SCALE, MODE>), dim3(l.tiles), dim3(l.threads), l.lds_bytes, stream, l.a);
     HIPCHK(hipGetLastError());
     return TF_OK;
 }
@@ -494,11 +500,12 @@ int launch_pass(const Launch& l, bool inverse, hipStream_t stream) {
         const char* e = getenv("TF_NTT_ABLATE");
         g_ablate = e ? atoi(e) : 0;
     }
-    if (l.a.pre_scale) return launch_pass_t<false, true, 0>(l, stream);  // coset evaluation is always forward
-    if (inverse) return launch_pass_t<true, false, 0>(l, stream);
-    if (g_ablate == 1) return launch_pass_t<false, false, 1>(l, stream);
-    if (g_ablate == 2) return launch_pass_t<false, false, 2>(l, stream);
-    return launch_pass_t<false, false, 0>(l, stream);
+    if (l.a.pre_scale) return launch_pass_t<false, 1, 0>(l, stream);   // coset evaluation: forward, scale on load
+    if (l.a.post_scale) return launch_pass_t<true, 2, 0>(l, stream);   // coset interpolation: inverse, scale on store
+    if (inverse) return launch_pass_t<true, 0, 0>(l, stream);
+    if (g_ablate == 1) return launch_pass_t<false, 0, 1>(l, stream);
+    if (g_ablate == 2) return launch_pass_t<false, 0, 2>(l, stream);
+    return launch_pass_t<false, 0, 0>(l, stream);
 }
 
 int check_len(size_t n) {
@@ -510,7 +517,7 @@ int check_len(size_t n) {
 // The transform proper.  in/out are device pointers; in == out for ntt/intt, distinct for coset evaluation
 // (then pre_scale != null and rows >= n_coeffs read as zero).  in_bs/out_bs: words per polynomial.
 int run_ntt(DeviceCtx* ctx, const u64* in, u64* out, long long in_bs, long long out_bs, size_t n, size_t batch, int L,
-            bool inverse, const u64* pre_scale, long long n_coeffs, hipStream_t stream) {
+            bool inverse, const u64* pre_scale, long long n_coeffs, hipStream_t stream, const u64* post_scale = nullptr) {
     if (n == 0 || batch == 0) return TF_OK;
     const int log_n = ilog2(n);
     int rc;
@@ -523,6 +530,7 @@ int run_ntt(DeviceCtx* ctx, const u64* in, u64* out, long long in_bs, long long 
         A.out = out;
         A.tw = tw;
         A.pre_scale = pre_scale;
+        A.post_scale = post_scale;
         A.n_coeffs = n_coeffs;
         A.in_bs = in_bs;
         A.out_bs = out_bs;
@@ -546,6 +554,7 @@ int run_ntt(DeviceCtx* ctx, const u64* in, u64* out, long long in_bs, long long 
             Launch l = plan_row_pass(in + b0 * in_bs, out + b0 * out_bs, in_bs, out_bs, nb, log_n, L);
             l.a.inner_tw = inner;
             l.a.pre_scale = pre_scale;
+            l.a.post_scale = post_scale;
             l.a.n_coeffs = n_coeffs;
             rc = launch_pass(l, inverse, stream);
             if (rc) return rc;
@@ -601,6 +610,7 @@ int run_ntt(DeviceCtx* ctx, const u64* in, u64* out, long long in_bs, long long 
             if (rc) break;
             Launch p2 = plan_transpose_pass(scratch, tout, sbs, out_bs, nb, a2, N1, 1, L);
             p2.a.inner_tw = inner2;
+            p2.a.post_scale = post_scale;
             rc = launch_pass(p2, inverse, stream);
         } else {
             Launch p1 = plan_column_pass(tin, tout, in_bs, out_bs, nb, 1, a1, N2 * N3, L);
@@ -617,6 +627,7 @@ int run_ntt(DeviceCtx* ctx, const u64* in, u64* out, long long in_bs, long long 
             if (rc) break;
             Launch p3 = plan_transpose_pass(scratch, tout, sbs, out_bs, nb, a3, N1, N2, L);
             p3.a.inner_tw = inner3;
+            p3.a.post_scale = post_scale;
             rc = launch_pass(p3, inverse, stream);
         }
     }
@@ -708,7 +719,8 @@ int tip5_hash_varlen_rows_dev(const u64* d_rows, size_t row_len, size_t n_rows, 
     if (rc) return rc;
     const long long blocks = ((long long)n_rows + 255) / 256;
     hipLaunchKernelGGL(tfk::tip5_hash_varlen_rows_kernel, dim3((unsigned)blocks), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), d_rows, (long long)row_len, (long long)n_rows, d_out);
+                       static_cast<hipStream_t>(stream), d_rows, (long long)row_len, (long long)n_rows, d_out,
+                       (long long)n_rows, 0ll);
     HIPCHK(hipGetLastError());
     return TF_OK;
 }
@@ -720,6 +732,43 @@ int check_leaves(size_t n) {
 }
 
 constexpr long long kTopWidth = 256;  // levels of at most this many nodes finish in one workgroup per tree
+
+// Levels above the leaf level for trees whose leaves are already at nodes[n..2n) (nodes[0] gets zeroed).
+int merkle_levels_in_place(u64* d_nodes, long long N, size_t batch, hipStream_t s) {
+    const long long nodes_ts = 10 * N;
+    long long w = N;
+    while (w > kTopWidth) {  // nodes[w/2 .. w) from nodes[w .. 2w)
+        const long long nw = w / 2;
+        int rc = launch_hash_pairs(d_nodes + 5 * w, d_nodes + 5 * nw, nullptr, nw * (long long)batch, nw, nodes_ts, nodes_ts, 0, s);
+        if (rc) return rc;
+        w = nw;
+    }
+    hipLaunchKernelGGL(tfk::merkle_top_kernel, dim3((unsigned)batch), dim3(256), 0, s, d_nodes + 5 * w, nodes_ts, (int)w,
+                       d_nodes, nodes_ts, (u64*)nullptr, (const u64*)nullptr, 0ll);
+    HIPCHK(hipGetLastError());
+    return TF_OK;
+}
+
+// Rows of a row-major table -> leaf digests (hash_varlen per row, tip5/mod.rs:617-623) -> Merkle tree, without the
+// leaves ever leaving HBM.  rows: batch x n_rows x row_len words.
+int merkle_from_rows_dev(const u64* d_rows, size_t row_len, size_t n_rows, u64* d_nodes, size_t batch, void* stream) {
+    int rc = check_leaves(n_rows);
+    if (rc) return rc;
+    if (batch == 0) return TF_OK;
+    if (!d_nodes || (row_len && !d_rows)) return TF_ERR_NULL_POINTER;
+    DeviceCtx* ctx = nullptr;
+    rc = current_ctx(&ctx);
+    if (rc) return rc;
+    rc = ensure_tip5(ctx);
+    if (rc) return rc;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const long long N = (long long)n_rows, total = N * (long long)batch;
+    const long long blocks = (total + 255) / 256;
+    hipLaunchKernelGGL(tfk::tip5_hash_varlen_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, s, d_rows, (long long)row_len,
+                       total, d_nodes + 5 * N, N, 10 * N);
+    HIPCHK(hipGetLastError());
+    return merkle_levels_in_place(d_nodes, N, batch, s);
+}
 
 // nodes layout per tree: 2n digests (merkle_tree.rs:85-88, :393-429).
 int merkle_build_dev(const u64* d_leaves, size_t n, u64* d_nodes, size_t batch, void* stream) {
@@ -803,6 +852,124 @@ int merkle_root_dev(const u64* d_leaves, size_t n, u64* d_root, size_t batch, vo
     e = hipFreeAsync(buf, s);
     if (rc) return rc;
     if (e != hipSuccess) return hip_fail(e, "hipFreeAsync", __FILE__, __LINE__);
+    return TF_OK;
+}
+
+// ------------------------------------------------------------------------------------ device-resident chain
+// fast_coset_interpolate (polynomial.rs:1907-1918): intt, then coefficient j times offset^-j (fused into the last pass).
+int coset_interp_dev(const u64* d_values, size_t n, u64 offset_raw, u64* d_out, size_t batch, int L, void* stream) {
+    int rc = check_len(n);
+    if (rc) return rc;
+    if (n == 0 || batch == 0) return TF_OK;
+    if (!d_values || !d_out) return TF_ERR_NULL_POINTER;
+    if (offset_raw == 0) return TF_ERR_INVERSE_OF_ZERO;  // offset.inverse() panics on zero (b_field_element.rs:264-268)
+    DeviceCtx* ctx = nullptr;
+    rc = current_ctx(&ctx);
+    if (rc) return rc;
+    const u64* pw = nullptr;
+    rc = get_pow_table(ctx, gl::mont_inverse(offset_raw), n, &pw);
+    if (rc) return rc;
+    return run_ntt(ctx, d_values, d_out, (long long)n * L, (long long)n * L, n, batch, L, true, nullptr, -1,
+                   static_cast<hipStream_t>(stream), pw);
+}
+
+int hadamard_dev(const u64* a, const u64* b, u64* out, size_t count, int L, void* stream) {
+    if (count == 0) return TF_OK;
+    if (!a || !b || !out) return TF_ERR_NULL_POINTER;
+    DeviceCtx* ctx = nullptr;
+    int rc = current_ctx(&ctx);
+    if (rc) return rc;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const long long blocks = std::min<long long>(((long long)count + 255) / 256, 256 * 32);
+    if (L == 1)
+        hipLaunchKernelGGL(tfk::hadamard_bfe_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a, b, out, (long long)count);
+    else
+        hipLaunchKernelGGL(tfk::hadamard_xfe_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a, b, out, (long long)count);
+    HIPCHK(hipGetLastError());
+    return TF_OK;
+}
+
+int pad_copy(const u64* src, u64* dst, long long n_src_words, long long n_dst_words, long long batch, hipStream_t s) {
+    if (n_dst_words * batch == 0) return TF_OK;
+    const long long blocks = std::min<long long>((n_dst_words * batch + 255) / 256, 256 * 32);
+    hipLaunchKernelGGL(tfk::pad_copy_kernel, dim3((unsigned)blocks), dim3(256), 0, s, src, dst, n_src_words, n_dst_words, batch);
+    HIPCHK(hipGetLastError());
+    return TF_OK;
+}
+
+// Polynomial::fast_multiply (polynomial.rs:900-932): zero-pad both to order = next_power_of_two(deg a + deg b + 1),
+// ntt both, pointwise product, intt, truncate to na + nb - 1 coefficients.  (The reference then trims leading zero
+// coefficients in Polynomial::new; the caller does that -- the length here is data independent.)
+int poly_mul_dev(const u64* a, size_t na, const u64* b, size_t nb, u64* out, size_t batch, int L, void* stream) {
+    if (batch == 0 || na == 0 || nb == 0) return TF_OK;  // a zero polynomial: empty product
+    if (!a || !b || !out) return TF_ERR_NULL_POINTER;
+    const size_t n_out = na + nb - 1;
+    size_t order = 1;
+    while (order < n_out) order <<= 1;
+    int rc = check_len(order);
+    if (rc) return rc;
+    DeviceCtx* ctx = nullptr;
+    rc = current_ctx(&ctx);
+    if (rc) return rc;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    u64* tmp = nullptr;
+    const size_t half = batch * order * size_t(L);
+    hipError_t e = hipMallocAsync(reinterpret_cast<void**>(&tmp), 2 * half * sizeof(u64), s);
+    if (e != hipSuccess) return hip_fail(e, "hipMallocAsync(poly_mul)", __FILE__, __LINE__);
+    rc = pad_copy(a, tmp, (long long)na * L, (long long)order * L, (long long)batch, s);
+    if (!rc) rc = pad_copy(b, tmp + half, (long long)nb * L, (long long)order * L, (long long)batch, s);
+    if (!rc) rc = run_ntt(ctx, tmp, tmp, (long long)order * L, (long long)order * L, order, 2 * batch, L, false, nullptr, -1, s);
+    if (!rc) rc = hadamard_dev(tmp, tmp + half, tmp, batch * order, L, s);
+    if (!rc) rc = run_ntt(ctx, tmp, tmp, (long long)order * L, (long long)order * L, order, batch, L, true, nullptr, -1, s);
+    if (!rc) rc = pad_copy(tmp, out, (long long)order * L, (long long)n_out * L, (long long)batch, s);
+    hipError_t e2 = hipFreeAsync(tmp, s);
+    if (rc) return rc;
+    if (e2 != hipSuccess) return hip_fail(e2, "hipFreeAsync", __FILE__, __LINE__);
+    return TF_OK;
+}
+
+// Low-degree extension: values on {offset_in * w_n^i} -> values on {offset_out * w_m^i}, m >= n
+// (= fast_coset_interpolate then fast_coset_evaluate with the coefficients staying in HBM).
+int lde_dev(const u64* values, size_t n, u64 offset_in, u64* out, size_t m, u64 offset_out, size_t batch, int L, void* stream) {
+    if (n > m) return TF_ERR_ORDER_NOT_ABOVE_DEGREE;
+    int rc = check_len(n);
+    if (!rc) rc = check_len(m);
+    if (rc) return rc;
+    if (m == 0 || batch == 0) return TF_OK;
+    if (!out || (n && !values)) return TF_ERR_NULL_POINTER;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (n == 0) {
+        HIPCHK(hipMemsetAsync(out, 0, m * batch * size_t(L) * sizeof(u64), s));
+        return TF_OK;
+    }
+    u64* coeffs = nullptr;
+    hipError_t e = hipMallocAsync(reinterpret_cast<void**>(&coeffs), batch * n * size_t(L) * sizeof(u64), s);
+    if (e != hipSuccess) return hip_fail(e, "hipMallocAsync(lde)", __FILE__, __LINE__);
+    rc = coset_interp_dev(values, n, offset_in, coeffs, batch, L, s);
+    if (!rc) rc = coset_eval_dev(coeffs, n, offset_out, out, m, batch, L, s);
+    hipError_t e2 = hipFreeAsync(coeffs, s);
+    if (rc) return rc;
+    if (e2 != hipSuccess) return hip_fail(e2, "hipFreeAsync", __FILE__, __LINE__);
+    return TF_OK;
+}
+
+// ------------------------------------------------------------------------------------ authentication structures
+// MerkleTree::authentication_structure_node_indices (merkle_tree.rs:449-504): needed minus computable, descending.
+int auth_structure_indices(size_t num_leafs, const uint64_t* leaf_indices, size_t k, std::vector<unsigned long long>* out) {
+    if (num_leafs == 0 || (num_leafs & (num_leafs - 1))) return TF_ERR_INCORRECT_NUMBER_OF_LEAFS;  // :468-470
+    std::set<unsigned long long> needed, computable;
+    for (size_t i = 0; i < k; ++i) {
+        if (leaf_indices[i] >= num_leafs) return TF_ERR_LEAF_INDEX_INVALID;  // :486-488
+        unsigned long long node = leaf_indices[i] + num_leafs;
+        while (node > 1) {
+            computable.insert(node);
+            needed.insert(node ^ 1ull);
+            node /= 2;
+        }
+    }
+    out->clear();
+    for (auto it = needed.rbegin(); it != needed.rend(); ++it)
+        if (!computable.count(*it)) out->push_back(*it);
     return TF_OK;
 }
 
@@ -894,6 +1061,22 @@ int coset_eval_host(const u64* coeffs, size_t n_coeffs, u64 offset_raw, u64* out
     return sync(s);
 }
 
+template <class F>
+int host_roundtrip(const uint64_t* in1, size_t w1, const uint64_t* in2, size_t w2, uint64_t* out, size_t wo, F&& body) {
+    DeviceCtx* ctx = nullptr;
+    TRY(current_ctx(&ctx));
+    hipStream_t s = host_stream();
+    DevBuf d1(s), d2(s), dout(s);
+    TRY(d1.alloc(w1));
+    TRY(d2.alloc(w2));
+    TRY(dout.alloc(wo));
+    TRY(h2d(d1.p, in1, w1, s));
+    TRY(h2d(d2.p, in2, w2, s));
+    TRY(body(d1.p, d2.p, dout.p, s));
+    TRY(d2h(out, dout.p, wo, s));
+    return sync(s);
+}
+
 }  // namespace
 
 // ==================================================================================== C ABI
@@ -912,6 +1095,9 @@ const char* tf_status_string(int status) {
         case TF_ERR_NO_DEVICE: return "TF_ERR_NO_DEVICE";
         case TF_ERR_HIP: return "TF_ERR_HIP";
         case TF_ERR_OUT_OF_MEMORY: return "TF_ERR_OUT_OF_MEMORY";
+        case TF_ERR_LEAF_INDEX_INVALID: return "TF_ERR_LEAF_INDEX_INVALID";
+        case TF_ERR_INVERSE_OF_ZERO: return "TF_ERR_INVERSE_OF_ZERO";
+        case TF_ERR_BUFFER_TOO_SMALL: return "TF_ERR_BUFFER_TOO_SMALL";
         default: return "TF_ERR_UNKNOWN";
     }
 }
@@ -1058,6 +1244,105 @@ int tf_merkle_root(const uint64_t* leaves, size_t n, uint64_t* root_out, size_t 
     TRY(h2d(din.p, leaves, n * batch * 5, s));
     TRY(merkle_root_dev(din.p, n, dout.p, batch, s));
     TRY(d2h(root_out, dout.p, batch * 5, s));
+    return sync(s);
+}
+
+// ---- SURVEY 8(f1)-(f3) ---------------------------------------------------------------------------
+int tf_coset_interpolate_bfe_dev(const uint64_t* v, size_t n, uint64_t off, uint64_t* out, size_t batch, void* stream) {
+    return coset_interp_dev(v, n, off, out, batch, 1, stream);
+}
+int tf_coset_interpolate_xfe_dev(const uint64_t* v, size_t n, uint64_t off, uint64_t* out, size_t batch, void* stream) {
+    return coset_interp_dev(v, n, off, out, batch, 3, stream);
+}
+int tf_hadamard_bfe_dev(const uint64_t* a, const uint64_t* b, uint64_t* out, size_t count, void* stream) {
+    return hadamard_dev(a, b, out, count, 1, stream);
+}
+int tf_hadamard_xfe_dev(const uint64_t* a, const uint64_t* b, uint64_t* out, size_t count, void* stream) {
+    return hadamard_dev(a, b, out, count, 3, stream);
+}
+int tf_poly_mul_bfe_dev(const uint64_t* a, size_t na, const uint64_t* b, size_t nb, uint64_t* out, size_t batch, void* stream) {
+    return poly_mul_dev(a, na, b, nb, out, batch, 1, stream);
+}
+int tf_poly_mul_xfe_dev(const uint64_t* a, size_t na, const uint64_t* b, size_t nb, uint64_t* out, size_t batch, void* stream) {
+    return poly_mul_dev(a, na, b, nb, out, batch, 3, stream);
+}
+int tf_lde_bfe_dev(const uint64_t* v, size_t n, uint64_t off_in, uint64_t* out, size_t m, uint64_t off_out, size_t batch, void* stream) {
+    return lde_dev(v, n, off_in, out, m, off_out, batch, 1, stream);
+}
+int tf_lde_xfe_dev(const uint64_t* v, size_t n, uint64_t off_in, uint64_t* out, size_t m, uint64_t off_out, size_t batch, void* stream) {
+    return lde_dev(v, n, off_in, out, m, off_out, batch, 3, stream);
+}
+int tf_merkle_from_rows_dev(const uint64_t* d_rows, size_t row_len, size_t n_rows, uint64_t* d_nodes, size_t batch, void* stream) {
+    return merkle_from_rows_dev(d_rows, row_len, n_rows, d_nodes, batch, stream);
+}
+
+int tf_coset_interpolate_bfe(const uint64_t* v, size_t n, uint64_t off, uint64_t* out, size_t batch) {
+    TRY(check_len(n));
+    if (n == 0 || batch == 0) return TF_OK;
+    if (!v || !out) return TF_ERR_NULL_POINTER;
+    if (off == 0) return TF_ERR_INVERSE_OF_ZERO;
+    return host_roundtrip(v, n * batch, nullptr, 0, out, n * batch,
+                          [&](u64* a, u64*, u64* o, hipStream_t s) { return coset_interp_dev(a, n, off, o, batch, 1, s); });
+}
+int tf_coset_interpolate_xfe(const uint64_t* v, size_t n, uint64_t off, uint64_t* out, size_t batch) {
+    TRY(check_len(n));
+    if (n == 0 || batch == 0) return TF_OK;
+    if (!v || !out) return TF_ERR_NULL_POINTER;
+    if (off == 0) return TF_ERR_INVERSE_OF_ZERO;
+    return host_roundtrip(v, 3 * n * batch, nullptr, 0, out, 3 * n * batch,
+                          [&](u64* a, u64*, u64* o, hipStream_t s) { return coset_interp_dev(a, n, off, o, batch, 3, s); });
+}
+int tf_poly_mul_bfe(const uint64_t* a, size_t na, const uint64_t* b, size_t nb, uint64_t* out, size_t batch) {
+    if (batch == 0 || na == 0 || nb == 0) return TF_OK;
+    if (!a || !b || !out) return TF_ERR_NULL_POINTER;
+    return host_roundtrip(a, na * batch, b, nb * batch, out, (na + nb - 1) * batch,
+                          [&](u64* x, u64* y, u64* o, hipStream_t s) { return poly_mul_dev(x, na, y, nb, o, batch, 1, s); });
+}
+int tf_poly_mul_xfe(const uint64_t* a, size_t na, const uint64_t* b, size_t nb, uint64_t* out, size_t batch) {
+    if (batch == 0 || na == 0 || nb == 0) return TF_OK;
+    if (!a || !b || !out) return TF_ERR_NULL_POINTER;
+    return host_roundtrip(a, 3 * na * batch, b, 3 * nb * batch, out, 3 * (na + nb - 1) * batch,
+                          [&](u64* x, u64* y, u64* o, hipStream_t s) { return poly_mul_dev(x, na, y, nb, o, batch, 3, s); });
+}
+int tf_merkle_from_rows(const uint64_t* rows, size_t row_len, size_t n_rows, uint64_t* nodes_out, size_t batch) {
+    TRY(check_leaves(n_rows));
+    if (batch == 0) return TF_OK;
+    if (!nodes_out || (row_len && !rows)) return TF_ERR_NULL_POINTER;
+    return host_roundtrip(rows, n_rows * row_len * batch, nullptr, 0, nodes_out, n_rows * batch * 10,
+                          [&](u64* r, u64*, u64* o, hipStream_t s) { return merkle_from_rows_dev(r, row_len, n_rows, o, batch, s); });
+}
+
+int tf_merkle_auth_structure_indices(size_t num_leafs, const uint64_t* leaf_indices, size_t k, uint64_t* out_indices,
+                                     size_t capacity, size_t* out_count) {
+    if ((k && !leaf_indices) || !out_count) return TF_ERR_NULL_POINTER;
+    std::vector<unsigned long long> idx;
+    TRY(auth_structure_indices(num_leafs, leaf_indices, k, &idx));
+    *out_count = idx.size();
+    if (out_indices)
+        for (size_t i = 0; i < idx.size() && i < capacity; ++i) out_indices[i] = idx[i];
+    return TF_OK;
+}
+
+int tf_merkle_authentication_structure_dev(const uint64_t* d_nodes, size_t num_leafs, const uint64_t* leaf_indices, size_t k,
+                                           uint64_t* out_digests, size_t capacity_digests, size_t* out_count, void* stream) {
+    if (!d_nodes || (k && !leaf_indices) || !out_count) return TF_ERR_NULL_POINTER;
+    std::vector<unsigned long long> idx;
+    TRY(auth_structure_indices(num_leafs, leaf_indices, k, &idx));
+    *out_count = idx.size();
+    if (idx.empty() || !out_digests) return TF_OK;
+    if (capacity_digests < idx.size()) return TF_ERR_BUFFER_TOO_SMALL;
+    DeviceCtx* ctx = nullptr;
+    TRY(current_ctx(&ctx));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    DevBuf didx(s), dout(s);
+    TRY(didx.alloc(idx.size()));
+    TRY(dout.alloc(idx.size() * 5));
+    TRY(h2d(didx.p, reinterpret_cast<const u64*>(idx.data()), idx.size(), s));
+    const long long total = (long long)idx.size() * 5;
+    hipLaunchKernelGGL(tfk::gather_digests_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, d_nodes,
+                       reinterpret_cast<const unsigned long long*>(didx.p), (long long)idx.size(), dout.p);
+    HIPCHK(hipGetLastError());
+    TRY(d2h(out_digests, dout.p, idx.size() * 5, s));
     return sync(s);
 }
 

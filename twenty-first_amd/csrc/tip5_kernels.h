@@ -133,8 +133,10 @@ __global__ void __launch_bounds__(256) tip5_hash_pairs_kernel(const u64* in, u64
 }
 
 // hash_varlen of n_rows rows of row_len words each (mod.rs:617-623; padding sponge.rs:41-55)
+// Row i belongs to tree i / per_tree; its digest goes to out + tree * out_ts + 5 * (i % per_tree)  (out_ts = 0 and
+// per_tree = n_rows: a flat digest array; out_ts = 10 n, out = nodes + 5 n: straight into the leaf level of a tree).
 __global__ void __launch_bounds__(256) tip5_hash_varlen_rows_kernel(const u64* rows, long long row_len, long long n_rows,
-                                                                    u64* out) {
+                                                                    u64* out, long long per_tree, long long out_ts) {
     __shared__ __attribute__((aligned(16))) unsigned char lut[256];
     stage_lut(lut);
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -153,7 +155,8 @@ __global__ void __launch_bounds__(256) tip5_hash_varlen_rows_kernel(const u64* r
 #pragma unroll
     for (int k = 0; k < 10; ++k) s[k] = (k < rem) ? p[full * 10 + k] : ((k == rem) ? gl::ONE : 0);
     tip5_permutation(s, lut);
-    u64* o = out + i * 5;
+    const long long tree = i / per_tree;
+    u64* o = out + tree * out_ts + (i - tree * per_tree) * 5;
 #pragma unroll
     for (int k = 0; k < 5; ++k) o[k] = s[k];
 }

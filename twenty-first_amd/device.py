@@ -84,3 +84,54 @@ def merkle_build(leaves, n_leaves: int, nodes_out, batch: int = 1, stream=None) 
 def merkle_root(leaves, n_leaves: int, root_out, batch: int = 1, stream=None) -> None:
     leaves, root_out = _t(leaves, "leaves"), _t(root_out, "root_out")
     _chk(_lib.lib().tf_merkle_root_dev(_p(leaves), n_leaves, _p(root_out), batch, _stream(stream)), "MerkleTree::par_frugal_root")
+
+
+# ---- the callers on either side of the path, kept in HBM --------------------------------
+
+def coset_interpolate(values, n: int, offset_raw: int, out, batch: int = 1, width: int = 1, stream=None) -> None:
+    """math/polynomial.rs:1907-1918 on device buffers (out: batch * n * width words; may alias values)."""
+    values, out = _t(values, "values"), _t(out, "out")
+    fn = _lib.lib().tf_coset_interpolate_bfe_dev if width == 1 else _lib.lib().tf_coset_interpolate_xfe_dev
+    _chk(fn(_p(values), n, C.c_uint64(offset_raw), _p(out), batch, _stream(stream)), "fast_coset_interpolate")
+
+
+def hadamard(a, b, out, width: int = 1, stream=None) -> None:
+    """Pointwise field product (math/polynomial.rs:920-925); out may alias a or b."""
+    a, b, out = _t(a, "a"), _t(b, "b"), _t(out, "out")
+    fn = _lib.lib().tf_hadamard_bfe_dev if width == 1 else _lib.lib().tf_hadamard_xfe_dev
+    _chk(fn(_p(a), _p(b), _p(out), a.numel() // width, _stream(stream)), "hadamard")
+
+
+def poly_mul(a, na: int, b, nb: int, out, batch: int = 1, width: int = 1, stream=None) -> None:
+    """Polynomial::fast_multiply on device (math/polynomial.rs:900-932): out = batch x (na + nb - 1) coefficients."""
+    a, b, out = _t(a, "a"), _t(b, "b"), _t(out, "out")
+    fn = _lib.lib().tf_poly_mul_bfe_dev if width == 1 else _lib.lib().tf_poly_mul_xfe_dev
+    _chk(fn(_p(a), na, _p(b), nb, _p(out), batch, _stream(stream)), "fast_multiply")
+
+
+def lde(values, n: int, offset_in_raw: int, out, m: int, offset_out_raw: int, batch: int = 1, width: int = 1, stream=None) -> None:
+    """Low-degree extension: interpolate on {offset_in w_n^i}, evaluate on {offset_out w_m^i}; coefficients stay in HBM."""
+    values, out = _t(values, "values"), _t(out, "out")
+    fn = _lib.lib().tf_lde_bfe_dev if width == 1 else _lib.lib().tf_lde_xfe_dev
+    _chk(fn(_p(values), n, C.c_uint64(offset_in_raw), _p(out), m, C.c_uint64(offset_out_raw), batch, _stream(stream)), "lde")
+
+
+def merkle_from_rows(rows, row_len: int, n_rows: int, nodes_out, batch: int = 1, stream=None) -> None:
+    """hash_varlen of every row -> leaf level -> tree, without the leaves leaving HBM."""
+    rows, nodes_out = _t(rows, "rows"), _t(nodes_out, "nodes_out")
+    _chk(_lib.lib().tf_merkle_from_rows_dev(_p(rows), row_len, n_rows, _p(nodes_out), batch, _stream(stream)), "MerkleTree::par_new")
+
+
+def authentication_structure(nodes, num_leafs: int, leaf_indices):
+    """util_types/merkle_tree.rs:614-622 from a device-resident node array: returns a (k, 5) numpy array."""
+    import numpy as np
+
+    nodes = _t(nodes, "nodes")
+    li = np.ascontiguousarray(leaf_indices, dtype=np.uint64).reshape(-1)
+    cap = max(1, li.size * 66)
+    out = np.empty(cap * 5, dtype=np.uint64)
+    cnt = C.c_size_t(0)
+    rc = _lib.lib().tf_merkle_authentication_structure_dev(_p(nodes), num_leafs, C.c_void_p(li.ctypes.data) if li.size else C.c_void_p(0),
+                                                           li.size, C.c_void_p(out.ctypes.data), cap, C.byref(cnt), _stream(None))
+    _chk(rc, "MerkleTree::authentication_structure")
+    return out[: cnt.value * 5].reshape(-1, 5).copy()
