@@ -168,6 +168,8 @@ void tf_set_ntt_tile_bytes(size_t bytes);
 /* Number of ntt_pass_kernel launches one tf_ntt_*_dev call enqueues for this shape (diagnostic; used by
  * bench.py to turn a HIP-event interval into an average launch duration). */
 int tf_ntt_launch_count(size_t n, size_t batch, int width);
+/* Measurement helper for tools/phase_timeline.py (TF_NTT_ABLATE=3): per-wave phase cycle stamps of the NTT pass kernel. */
+int tf_debug_stamps(unsigned long long *host_out, size_t words);
 size_t tf_get_ntt_tile_bytes(void);
 
 #ifdef __cplusplus

@@ -89,7 +89,7 @@ def test_merkle_root_goldens(tf, oracle):
 
 # ------------------------------------------------------------------ NTT vs oracle
 
-@pytest.mark.parametrize("log_n", list(range(0, 15)) + [16, 18, 20, 21, 22])
+@pytest.mark.parametrize("log_n", list(range(0, 15)) + [16, 18, 20, 21, 22, 24, 25])
 @pytest.mark.parametrize("inverse", [False, True])
 def test_ntt_bfe_matches_oracle(tf, oracle, log_n, inverse):
     n = 1 << log_n
@@ -102,7 +102,7 @@ def test_ntt_bfe_matches_oracle(tf, oracle, log_n, inverse):
     assert (got < np.uint64(P)).all()
 
 
-@pytest.mark.parametrize("log_n", [0, 1, 2, 4, 5, 6, 9, 10, 11, 13, 16, 20, 21])
+@pytest.mark.parametrize("log_n", [0, 1, 2, 4, 5, 6, 9, 10, 11, 13, 16, 20, 21, 23])
 @pytest.mark.parametrize("inverse", [False, True])
 def test_ntt_xfe_matches_oracle(tf, oracle, log_n, inverse):
     n = 1 << log_n

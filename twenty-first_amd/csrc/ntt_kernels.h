@@ -55,6 +55,7 @@ struct NttPassArgs {
     int s1, s2;                              // LDS strides in u64: idx = k1*s1 + g*s2 + (c % cpr)
     int xcd_order;                           // G > 0: XCD-aware tile order in groups of G adjacent column tiles (0: natural order)
     u32 nc_magic;                            // t / nc == umulhi(t, nc_magic) for every t < blockDim (checked by the planner)
+    unsigned long long* dbg;                 // MODE 3 only: per-wave cycle stamps (6 per wave)
 };
 
 // ---- radix-2^k DIT network with power-of-two twiddles --------------------------------------
@@ -160,6 +161,8 @@ __global__ void __launch_bounds__(512, 4) ntt_pass_kernel(const NttPassArgs A) {
     // work.  VALU arbitration favours the OLDER workgroup on a CU, so a young workgroup whose loads needed
     // address arithmetic would not get them issued until the old one finished computing; together with the
     // s_setprio brackets this is what lets one workgroup's memory phase overlap the other's arithmetic.
+    unsigned long long stamp[6];
+    if constexpr (MODE == 3) stamp[0] = __builtin_readcyclecounter();
     u64 x[32];
 #pragma unroll
     for (int q = 0; q < 32; ++q) x[q] = 0;
@@ -188,6 +191,11 @@ __global__ void __launch_bounds__(512, 4) ntt_pass_kernel(const NttPassArgs A) {
         }
     }
     __builtin_amdgcn_s_setprio(0);
+    if constexpr (MODE == 3) {
+        stamp[1] = __builtin_readcyclecounter();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stamp[2] = __builtin_readcyclecounter();
+    }
     if constexpr (MODE != 2) {
         dit_level<INV, 1>(x);
         dit_level<INV, 2>(x);
@@ -200,6 +208,7 @@ __global__ void __launch_bounds__(512, 4) ntt_pass_kernel(const NttPassArgs A) {
             for (int q = 0; q < 32; ++q) x[q] = gl::mont_mul(x[q], tw[q]);
         }
     }
+    if constexpr (MODE == 3) { asm volatile("" :: "v"(x[0]), "v"(x[31])); stamp[3] = __builtin_readcyclecounter(); }
     // ------------------------------------------------------------------ LDS exchange, `nrounds` rounds of `cpr` columns
     // Element (k1, g) of a column goes from the thread that owns row group g to the thread that owns k1 mod P2.
     // A thread writes its 32 values and reads its 32 new values in the SAME round, so only 32 are ever live.
@@ -228,6 +237,7 @@ __global__ void __launch_bounds__(512, 4) ntt_pass_kernel(const NttPassArgs A) {
             }
         }
     }
+    if constexpr (MODE == 3) { asm volatile("" :: "v"(x[0]), "v"(x[31])); stamp[4] = __builtin_readcyclecounter(); }
     // ------------------------------------------------------------------ step 2 (radix P2 over g) + store
     if constexpr (MODE != 2) {
         if (p2 >= 1) dit_level<INV, 1>(x);
@@ -299,6 +309,13 @@ __global__ void __launch_bounds__(512, 4) ntt_pass_kernel(const NttPassArgs A) {
                 *reinterpret_cast<u64*>(base + uk * A.out_rs * 8 + toff) = x[q];
 #endif
             }
+        }
+    }
+    if constexpr (MODE == 3) {
+        stamp[5] = __builtin_readcyclecounter();
+        if (A.dbg && (t & 63) == 0 && blockIdx.x < 4096) {
+            unsigned long long* d = A.dbg + ((size_t)blockIdx.x * 8 + (t >> 6)) * 6;
+            for (int i = 0; i < 6; ++i) d[i] = stamp[i];
         }
     }
 }

@@ -492,6 +492,7 @@ int launch_pass_t(const Launch& l, hipStream_t stream) {
     return TF_OK;
 }
 
+unsigned long long* g_dbg_buf = nullptr;  // TF_NTT_ABLATE=3: per-wave phase stamps of the last launch (tf_debug_stamps)
 int g_ablate = -1;  // measurement only (TF_NTT_ABLATE=1|2 selects an ablated forward kernel; results are then garbage)
 
 int launch_pass(const Launch& l, bool inverse, hipStream_t stream) {
@@ -505,6 +506,11 @@ int launch_pass(const Launch& l, bool inverse, hipStream_t stream) {
     if (inverse) return launch_pass_t<true, 0, 0>(l, stream);
     if (g_ablate == 1) return launch_pass_t<false, 0, 1>(l, stream);
     if (g_ablate == 2) return launch_pass_t<false, 0, 2>(l, stream);
+    if (g_ablate == 3) {
+        Launch l2 = l;
+        l2.a.dbg = g_dbg_buf;
+        return launch_pass_t<false, 0, 3>(l2, stream);
+    }
     return launch_pass_t<false, 0, 0>(l, stream);
 }
 
@@ -1121,6 +1127,19 @@ void tf_set_ntt_tile_bytes(size_t bytes) {
 size_t tf_get_ntt_tile_bytes(void) {
     read_env();
     return g_tile_bytes;
+}
+
+// measurement helper (not part of the drop-in boundary): allocate / fetch the MODE-3 stamp buffer
+int tf_debug_stamps(unsigned long long* host_out, size_t words) {
+    if (!g_dbg_buf) {
+        if (hipMalloc(reinterpret_cast<void**>(&g_dbg_buf), 4096 * 8 * 6 * 8) != hipSuccess) return TF_ERR_HIP;
+        (void)hipMemset(g_dbg_buf, 0, 4096 * 8 * 6 * 8);
+    }
+    if (host_out && words) {
+        if (hipDeviceSynchronize() != hipSuccess) return TF_ERR_HIP;
+        if (hipMemcpy(host_out, g_dbg_buf, std::min<size_t>(words, 4096 * 8 * 6) * 8, hipMemcpyDeviceToHost) != hipSuccess) return TF_ERR_HIP;
+    }
+    return TF_OK;
 }
 
 int tf_ntt_launch_count(size_t n, size_t batch, int width) {
