@@ -161,7 +161,7 @@ int tf_merkle_authentication_structure_dev(const uint64_t *d_nodes, size_t num_l
 /* ---------------------------------------------------------------------------------------------
  * Tuning knobs (process-wide; also read once from the environment):
  *   TF_NTT_TILE_BYTES : bytes of batch processed between the passes of a multi-pass NTT (scratch size),
- *                       (default 512 MiB: measured on MI355X the pass kernels are VALU-bound and larger
+ *                       (default 2 GiB: measured on MI355X the pass kernels are VALU-bound and larger
  *                       launches overlap better than Infinity-Cache-sized ones).
  */
 void tf_set_ntt_tile_bytes(size_t bytes);

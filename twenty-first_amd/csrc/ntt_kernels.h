@@ -117,7 +117,10 @@ __device__ __forceinline__ u32 div_by_L(u32 v, int L) {  // v / L for L in {1, 3
 // MODE: 0 = product kernel.  1 / 2 are measurement-only ablations (TF_NTT_ABLATE, never the default):
 //   1 = no global loads/stores (synthetic operands), 2 = no arithmetic (loads, LDS exchange, stores only).
 template <bool INV, int SCALE, int MODE = 0>
-__global__ void __launch_bounds__(512, 4) ntt_pass_kernel(const NttPassArgs A) {
+#ifndef TF_NTT_WAVES
+#define TF_NTT_WAVES 4
+#endif
+__global__ void __launch_bounds__(512, TF_NTT_WAVES) ntt_pass_kernel(const NttPassArgs A) {
     extern __shared__ __attribute__((aligned(16))) u64 lds[];
     const int t = threadIdx.x;
     const int p2 = A.p2;

@@ -126,8 +126,8 @@ void read_env() {
     std::call_once(g_env_once, [] {
         if (g_tile_bytes == 0) {
             const char* s = getenv("TF_NTT_TILE_BYTES");
-            g_tile_bytes = s ? strtoull(s, nullptr, 10) : (size_t(512) << 20);
-            if (g_tile_bytes == 0) g_tile_bytes = size_t(512) << 20;
+            g_tile_bytes = s ? strtoull(s, nullptr, 10) : (size_t(2048) << 20);
+            if (g_tile_bytes == 0) g_tile_bytes = size_t(2048) << 20;
         }
     });
 }
@@ -348,7 +348,16 @@ int wg_threads() {
     return g_wg_threads;
 }
 #define kMaxThreads (wg_threads())
-#define kRoundElems (wg_threads() * 16)   // elements parked in LDS per exchange round: 64 KiB or 32 KiB
+int g_round_elems = 0;
+int round_elems() {
+    if (!g_round_elems) {
+        const char* e = getenv("TF_NTT_ROUND_ELEMS");
+        g_round_elems = e ? atoi(e) : wg_threads() * 16;
+        if (g_round_elems < 1024) g_round_elems = wg_threads() * 16;
+    }
+    return g_round_elems;
+}
+#define kRoundElems (round_elems())   // elements parked in LDS per exchange round: 64 KiB (512 threads) or 32 KiB (256)
 
 // thread / LDS geometry shared by all pass types: nc columns, exchanged in rounds of cpr columns
 void finish_geometry(Launch* l, int nc, int p2) {
@@ -1122,7 +1131,7 @@ int tf_device_count(void) {
 
 void tf_set_ntt_tile_bytes(size_t bytes) {
     read_env();
-    g_tile_bytes = bytes ? bytes : (size_t(512) << 20);
+    g_tile_bytes = bytes ? bytes : (size_t(2048) << 20);
 }
 size_t tf_get_ntt_tile_bytes(void) {
     read_env();
