@@ -57,3 +57,39 @@ def test_fuzz_merkle_and_hash_shapes(tf, oracle):
         rows = oracle.fill_random(max(1, n_rows * row_len), rng.getrandbits(40))[: n_rows * row_len]
         if row_len:
             assert np.array_equal(tf.Tip5.hash_varlen_rows(rows, row_len), oracle.hash_varlen_rows(rows, row_len))
+
+
+def test_reentrant_from_many_host_threads(tf, oracle):
+    """The ABI is called concurrently from host threads (the reference's ntt is called from rayon workers,
+    math/ntt.rs:250-274): 8 threads, mixed entry points and sizes, every result checked."""
+    import threading
+
+    errors = []
+
+    def worker(k):
+        try:
+            rng = random.Random(1000 + k)
+            for it in range(6):
+                log_n = rng.choice([5, 9, 10, 12, 14, 16])
+                n = 1 << log_n
+                x = oracle.fill_random(n * 2, rng.getrandbits(40))
+                got = x.copy()
+                tf.ntt(got, batch=2, _inverse=bool(it & 1))
+                if not np.array_equal(got, oracle.ntt(x, batch=2, inverse=bool(it & 1))):
+                    errors.append(("ntt", k, it))
+                leaves = oracle.fill_random(5 * 512, rng.getrandbits(40))
+                if not np.array_equal(tf.MerkleTree.par_new(leaves).nodes.reshape(-1), oracle.merkle_build(leaves)):
+                    errors.append(("merkle", k, it))
+                c = oracle.fill_random(300, rng.getrandbits(40))
+                off = oracle.bfe_new(rng.randrange(1, P))  # > 16 distinct offsets overall: exercises the uncached path
+                if not np.array_equal(tf.fast_coset_evaluate(c, off, 512), oracle.coset_evaluate(c, off, 512)):
+                    errors.append(("coset", k, it))
+        except Exception as e:  # noqa: BLE001
+            errors.append(("exception", k, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(8)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors

@@ -267,41 +267,65 @@ int get_tiny_table(DeviceCtx* ctx, int log_n, bool inverse, const u64** out) {
     return TF_OK;
 }
 
-// offset^j, j < n  (the power chain of Polynomial::scale, polynomial.rs:766-771)
-int get_pow_table(DeviceCtx* ctx, u64 offset_raw, size_t n, const u64** out) {
-    std::lock_guard<std::mutex> lk(ctx->mu);
+// offset^j, j < n  (the power chain of Polynomial::scale, polynomial.rs:766-771).
+// Up to 16 tables per device are cached for the life of the process; beyond that a table is built into a
+// stream-ordered temporary (*temp = true) that the caller releases with hipFreeAsync after its launches, so no
+// table another thread may still be using is ever freed.
+int build_pow_table(u64 offset_raw, size_t n, u64* d, hipStream_t s, bool sync_after) {
+    const int log_total = std::max(1, ilog2(n));
+    int h = 0;
+    std::vector<u64> hi, lo;
+    split_powers(offset_raw, log_total, &h, &hi, &lo);
+    u64 *d_hi = nullptr, *d_lo = nullptr;
+    int rc = upload_table(hi, &d_hi);
+    if (rc) return rc;
+    rc = upload_table(lo, &d_lo);
+    if (rc) {
+        (void)hipFree(d_hi);
+        return rc;
+    }
+    const int threads = 256;
+    const long long blocks = ((long long)n + threads - 1) / threads;
+    if (n) {
+        hipLaunchKernelGGL(tfk::build_pow_table_kernel, dim3((unsigned)blocks), dim3(threads), 0, s, d, d_hi, d_lo, h,
+                           (long long)n);
+        HIPCHK(hipGetLastError());
+    }
+    (void)sync_after;
+    HIPCHK(hipStreamSynchronize(s));  // hi/lo are freed below; the build kernel is microseconds
+    HIPCHK(hipFree(d_hi));
+    HIPCHK(hipFree(d_lo));
+    return TF_OK;
+}
+
+int get_pow_table(DeviceCtx* ctx, u64 offset_raw, size_t n, hipStream_t stream, const u64** out, bool* temp) {
+    *temp = false;
+    std::unique_lock<std::mutex> lk(ctx->mu);
     auto key = std::make_pair(offset_raw, u64(n));
     auto it = ctx->pow_tables.find(key);
     if (it != ctx->pow_tables.end()) {
         *out = it->second;
         return TF_OK;
     }
-    if (ctx->pow_tables.size() >= 16) {  // bounded cache: drop everything (callers hold no references across calls)
-        HIPCHK(hipDeviceSynchronize());
-        for (auto& kv : ctx->pow_tables) (void)hipFree(kv.second);
-        ctx->pow_tables.clear();
+    const bool cacheable = ctx->pow_tables.size() < 16;
+    u64* d = nullptr;
+    if (cacheable) {
+        HIPCHK(hipMalloc(&d, std::max<size_t>(n, 1) * sizeof(u64)));
+        int rc = build_pow_table(offset_raw, n, d, 0, true);
+        if (rc) return rc;
+        ctx->pow_tables[key] = d;
+        *out = d;
+        return TF_OK;
     }
-    const int log_total = std::max(1, ilog2(n));
-    int h = 0;
-    std::vector<u64> hi, lo;
-    split_powers(offset_raw, log_total, &h, &hi, &lo);
-    u64 *d_hi = nullptr, *d_lo = nullptr, *d = nullptr;
-    int rc = upload_table(hi, &d_hi);
-    if (rc) return rc;
-    rc = upload_table(lo, &d_lo);
-    if (rc) return rc;
-    HIPCHK(hipMalloc(&d, std::max<size_t>(n, 1) * sizeof(u64)));
-    const int threads = 256;
-    const long long blocks = ((long long)n + threads - 1) / threads;
-    if (n) {
-        hipLaunchKernelGGL(tfk::build_pow_table_kernel, dim3((unsigned)blocks), dim3(threads), 0, 0, d, d_hi, d_lo, h,
-                           (long long)n);
-        HIPCHK(hipGetLastError());
+    lk.unlock();
+    hipError_t e = hipMallocAsync(reinterpret_cast<void**>(&d), std::max<size_t>(n, 1) * sizeof(u64), stream);
+    if (e != hipSuccess) return hip_fail(e, "hipMallocAsync(pow table)", __FILE__, __LINE__);
+    int rc = build_pow_table(offset_raw, n, d, stream, true);
+    if (rc) {
+        (void)hipFreeAsync(d, stream);
+        return rc;
     }
-    HIPCHK(hipStreamSynchronize(0));
-    HIPCHK(hipFree(d_hi));
-    HIPCHK(hipFree(d_lo));
-    ctx->pow_tables[key] = d;
+    *temp = true;
     *out = d;
     return TF_OK;
 }
@@ -680,10 +704,13 @@ int coset_eval_dev(const u64* d_coeffs, size_t n_coeffs, u64 offset_raw, u64* d_
         return TF_OK;
     }
     const u64* pw = nullptr;
-    rc = get_pow_table(ctx, offset_raw, n_coeffs, &pw);
+    bool temp = false;
+    rc = get_pow_table(ctx, offset_raw, n_coeffs, s, &pw, &temp);
     if (rc) return rc;
-    return run_ntt(ctx, d_coeffs, d_out, (long long)n_coeffs * L, (long long)order * L, order, batch, L, false, pw,
-                   (long long)n_coeffs, s);
+    rc = run_ntt(ctx, d_coeffs, d_out, (long long)n_coeffs * L, (long long)order * L, order, batch, L, false, pw,
+                 (long long)n_coeffs, s);
+    if (temp) (void)hipFreeAsync(const_cast<u64*>(pw), s);
+    return rc;
 }
 
 // ------------------------------------------------------------------------------------ Tip5 / Merkle
@@ -882,10 +909,13 @@ int coset_interp_dev(const u64* d_values, size_t n, u64 offset_raw, u64* d_out, 
     rc = current_ctx(&ctx);
     if (rc) return rc;
     const u64* pw = nullptr;
-    rc = get_pow_table(ctx, gl::mont_inverse(offset_raw), n, &pw);
+    bool temp = false;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    rc = get_pow_table(ctx, gl::mont_inverse(offset_raw), n, s, &pw, &temp);
     if (rc) return rc;
-    return run_ntt(ctx, d_values, d_out, (long long)n * L, (long long)n * L, n, batch, L, true, nullptr, -1,
-                   static_cast<hipStream_t>(stream), pw);
+    rc = run_ntt(ctx, d_values, d_out, (long long)n * L, (long long)n * L, n, batch, L, true, nullptr, -1, s, pw);
+    if (temp) (void)hipFreeAsync(const_cast<u64*>(pw), s);
+    return rc;
 }
 
 int hadamard_dev(const u64* a, const u64* b, u64* out, size_t count, int L, void* stream) {
