@@ -117,6 +117,12 @@ __device__ __forceinline__ u32 div_by_L(u32 v, int L) {  // v / L for L in {1, 3
 // MODE: 0 = product kernel.  1 / 2 are measurement-only ablations (TF_NTT_ABLATE, never the default):
 //   1 = no global loads/stores (synthetic operands), 2 = no arithmetic (loads, LDS exchange, stores only).
 template <bool INV, int SCALE, int MODE = 0>
+#ifndef TF_PRIO_LOAD
+#define TF_PRIO_LOAD 3
+#endif
+#ifndef TF_PRIO_STEP2
+#define TF_PRIO_STEP2 0
+#endif
 #ifndef TF_NTT_WAVES
 #define TF_NTT_WAVES 4
 #endif
@@ -170,7 +176,7 @@ __global__ void __launch_bounds__(512, TF_NTT_WAVES) ntt_pass_kernel(const NttPa
 #pragma unroll
     for (int q = 0; q < 32; ++q) x[q] = 0;
     // ------------------------------------------------------------------ load + step 1 (radix 32 over i, rows g + P2*i)
-    __builtin_amdgcn_s_setprio(3);
+    __builtin_amdgcn_s_setprio(TF_PRIO_LOAD);
     if constexpr (MODE == 1) {
 #pragma unroll
         for (int q = 0; q < 32; ++q) x[q] = (u64)(t * 32 + q) * 0x9e3779b97f4a7c15ULL >> 1;
@@ -242,6 +248,7 @@ __global__ void __launch_bounds__(512, TF_NTT_WAVES) ntt_pass_kernel(const NttPa
     }
     if constexpr (MODE == 3) { asm volatile("" :: "v"(x[0]), "v"(x[31])); stamp[4] = __builtin_readcyclecounter(); }
     // ------------------------------------------------------------------ step 2 (radix P2 over g) + store
+    __builtin_amdgcn_s_setprio(TF_PRIO_STEP2);
     if constexpr (MODE != 2) {
         if (p2 >= 1) dit_level<INV, 1>(x);
         if (p2 >= 2) dit_level<INV, 2>(x);
