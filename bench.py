@@ -166,13 +166,13 @@ def main():
     if os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))
-            if tj.get("log_n") == log_n and tj.get("batch") == batch:
+            if tj.get("log_n") == log_n and tj.get("batch") == batch and tj.get("launches_per_step") == launches_per_step:
                 traffic = tj.get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
     roofline = {
         "bound": "hbm",
-        "kernel": "tfk::ntt_pass_kernel<false, false, 0>",
+        "kernel": "tfk::ntt_pass_kernel<false, 0, 0>",
         "achieved": round(achieved, 1),
         "peak": HBM_PEAK_GBS,
         "unit": "GB/s",
