@@ -260,6 +260,20 @@ def side_measurements(tf, torch, dev):
         ms = e0.elapsed_time(e1) / iters
         extra["xfe_coset_eval_16x2p22"] = {"ms": round(ms, 3), "gfelts_per_s": round(n * b / ms / 1e6, 3),
                                           "hbm_frac_at_48B_per_point": round(48.0 * n * b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        del c, o
+        # PCIe-inclusive figure of the host-pointer entry point (pageable numpy buffers, 32 x 2^20 BFE = 256 MiB each way)
+        import time as _t
+
+        import numpy as _np
+
+        hb = 32
+        hx = _np.random.default_rng(5).integers(0, 2 ** 63, size=hb * (1 << 20), dtype=_np.uint64)
+        tf.ntt(hx, batch=hb)
+        t0 = _t.perf_counter()
+        tf.ntt(hx, batch=hb)
+        dt = _t.perf_counter() - t0
+        extra["host_pointer_ntt_32x2p20"] = {"ms": round(dt * 1e3, 2), "gfelts_per_s": round(hb * (1 << 20) / dt / 1e9, 3),
+                                             "note": "tf_ntt_bfe on pageable host memory: H2D + 2 passes + D2H, synchronous"}
     except Exception as e:  # side measurements never invalidate the headline line
         extra["error"] = repr(e)
     return extra

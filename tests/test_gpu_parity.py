@@ -89,7 +89,7 @@ def test_merkle_root_goldens(tf, oracle):
 
 # ------------------------------------------------------------------ NTT vs oracle
 
-@pytest.mark.parametrize("log_n", list(range(0, 15)) + [16, 18, 20, 21, 22, 24, 25])
+@pytest.mark.parametrize("log_n", list(range(0, 15)) + [16, 18, 20, 21, 22, 24, 25, 26])
 @pytest.mark.parametrize("inverse", [False, True])
 def test_ntt_bfe_matches_oracle(tf, oracle, log_n, inverse):
     n = 1 << log_n

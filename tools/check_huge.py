@@ -1,0 +1,18 @@
+#!/usr/bin/env python3
+"""One-off parity check of the largest single transforms (not part of the pytest suite: the oracle needs minutes)."""
+import sys, time, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import twenty_first_amd as tf
+from oracle import tfo
+for log_n in [int(a) for a in sys.argv[1:]] or [26, 28]:
+    n = 1 << log_n
+    x = tfo.fill_random(n, 0xABC + log_n)
+    t0 = time.time(); want = tfo.ntt(x); t1 = time.time()
+    d = torch.from_numpy(x.view(np.int64)).cuda()
+    tf.device.ntt_(d, n); torch.cuda.synchronize()
+    t2 = time.time(); tf.device.ntt_(d, n, inverse=True); tf.device.ntt_(d, n); torch.cuda.synchronize(); t3 = time.time()
+    got = d.cpu().numpy().view(np.uint64)
+    print(f"2^{log_n}: match={np.array_equal(got, want)}  oracle {t1-t0:.1f}s  gpu fwd+inv pair {(t3-t2)*1e3:.1f} ms", flush=True)
+    del d, got, want, x
+    torch.cuda.empty_cache()
