@@ -150,6 +150,11 @@ int tf_poly_mul_bfe(const uint64_t *a, size_t na, const uint64_t *b, size_t nb, 
 int tf_poly_mul_xfe(const uint64_t *a, size_t na, const uint64_t *b, size_t nb, uint64_t *out, size_t batch);
 int tf_poly_mul_bfe_dev(const uint64_t *d_a, size_t na, const uint64_t *d_b, size_t nb, uint64_t *d_out, size_t batch, void *stream);
 int tf_poly_mul_xfe_dev(const uint64_t *d_a, size_t na, const uint64_t *d_b, size_t nb, uint64_t *d_out, size_t batch, void *stream);
+/* Polynomial::fast_square  math/polynomial.rs:780-798: out = batch x (2 na - 1) coefficients (one forward transform). */
+int tf_poly_square_bfe(const uint64_t *a, size_t na, uint64_t *out, size_t batch);
+int tf_poly_square_xfe(const uint64_t *a, size_t na, uint64_t *out, size_t batch);
+int tf_poly_square_bfe_dev(const uint64_t *d_a, size_t na, uint64_t *d_out, size_t batch, void *stream);
+int tf_poly_square_xfe_dev(const uint64_t *d_a, size_t na, uint64_t *d_out, size_t batch, void *stream);
 int tf_lde_bfe_dev(const uint64_t *d_values, size_t n, uint64_t offset_in_raw, uint64_t *d_out, size_t m, uint64_t offset_out_raw, size_t batch, void *stream);
 int tf_lde_xfe_dev(const uint64_t *d_values, size_t n, uint64_t offset_in_raw, uint64_t *d_out, size_t m, uint64_t offset_out_raw, size_t batch, void *stream);
 int tf_merkle_from_rows(const uint64_t *rows, size_t row_len, size_t n_rows, uint64_t *nodes_out, size_t batch);

@@ -149,3 +149,16 @@ def test_authentication_structure(tf, oracle):
             got = tf.device.authentication_structure(dn, n, idx)
             assert np.array_equal(got, host_nodes[want_idx.astype(np.int64)])
             assert np.array_equal(tree.authentication_structure(idx), got)
+
+
+@pytest.mark.parametrize("width", [1, 3])
+@pytest.mark.parametrize("na", [1, 2, 9, 64, 1000, 5000])
+def test_fast_square_matches_oracle(tf, oracle, width, na):
+    """math/polynomial.rs:780-798: square == product with itself"""
+    a = oracle.fill_random(na * width * 2, 300 + na)
+    got = tf.fast_square(a, width=width, batch=2).reshape(2, -1)
+    for k in range(2):
+        ak = a[k * na * width:(k + 1) * na * width]
+        assert np.array_equal(got[k], oracle.poly_mul(ak, ak, width=width))
+    p = tf.Polynomial(a[: na * width], width=width)
+    assert np.array_equal(p.fast_square().coefficients, tf.Polynomial(oracle.poly_mul(p.coefficients, p.coefficients, width=width), width=width).coefficients)

@@ -26,7 +26,7 @@ import numpy as np
 from . import _lib
 
 __all__ = [
-    "P", "BFieldElement", "ntt", "intt", "Polynomial", "fast_coset_evaluate", "fast_coset_interpolate", "fast_multiply", "Tip5", "Digest", "MerkleTree",
+    "P", "BFieldElement", "ntt", "intt", "Polynomial", "fast_coset_evaluate", "fast_coset_interpolate", "fast_multiply", "fast_square", "Tip5", "Digest", "MerkleTree",
     "MerkleTreeError", "TwentyFirstError", "NttPanic", "lib", "device",
 ]
 
@@ -172,6 +172,19 @@ def fast_multiply(a: np.ndarray, b: np.ndarray, width: int = 1, batch: int = 1) 
     return out
 
 
+def fast_square(a: np.ndarray, width: int = 1, batch: int = 1) -> np.ndarray:
+    """`batch` polynomials of na coefficients -> `batch` x (2 na - 1) coefficients of their squares
+    (math/polynomial.rs:780-798, untrimmed)."""
+    a = _words(a, "a")
+    na = a.size // (batch * width) if batch else 0
+    if na == 0:
+        return np.zeros(0, dtype=np.uint64)
+    out = np.empty(batch * (2 * na - 1) * width, dtype=np.uint64)
+    fn = lib().tf_poly_square_bfe if width == 1 else lib().tf_poly_square_xfe
+    _check(fn(_ptr(a), na, _ptr(out), batch), "fast_square")
+    return out
+
+
 class Polynomial:
     """Coefficients low -> high degree (math/polynomial.rs:78-84); only the hot-path members."""
 
@@ -197,6 +210,12 @@ class Polynomial:
         """math/polynomial.rs:1907-1918; panics (NttPanic) unless len(values) is a power of two."""
         v = np.ascontiguousarray(values, dtype=np.uint64).reshape(-1)
         return cls(fast_coset_interpolate(v, offset_raw, width=width), width=width)
+
+    def fast_square(self) -> "Polynomial":
+        """math/polynomial.rs:780-798"""
+        if self.degree() < 0:
+            return Polynomial(np.zeros(0, dtype=np.uint64), width=self.width)
+        return Polynomial(fast_square(self.coefficients, width=self.width), width=self.width)
 
     def fast_multiply(self, other: "Polynomial") -> "Polynomial":
         """math/polynomial.rs:900-932 (same field on both sides)."""

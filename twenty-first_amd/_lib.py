@@ -51,6 +51,10 @@ SIGNATURES = {
     "tf_poly_mul_xfe": (C.c_int, [_vp, _sz, _vp, _sz, _vp, _sz]),
     "tf_poly_mul_bfe_dev": (C.c_int, [_vp, _sz, _vp, _sz, _vp, _sz, _vp]),
     "tf_poly_mul_xfe_dev": (C.c_int, [_vp, _sz, _vp, _sz, _vp, _sz, _vp]),
+    "tf_poly_square_bfe": (C.c_int, [_vp, _sz, _vp, _sz]),
+    "tf_poly_square_xfe": (C.c_int, [_vp, _sz, _vp, _sz]),
+    "tf_poly_square_bfe_dev": (C.c_int, [_vp, _sz, _vp, _sz, _vp]),
+    "tf_poly_square_xfe_dev": (C.c_int, [_vp, _sz, _vp, _sz, _vp]),
     "tf_lde_bfe_dev": (C.c_int, [_vp, _sz, C.c_uint64, _vp, _sz, C.c_uint64, _sz, _vp]),
     "tf_lde_xfe_dev": (C.c_int, [_vp, _sz, C.c_uint64, _vp, _sz, C.c_uint64, _sz, _vp]),
     "tf_merkle_from_rows": (C.c_int, [_vp, _sz, _sz, _vp, _sz]),

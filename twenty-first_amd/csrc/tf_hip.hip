@@ -973,6 +973,34 @@ int poly_mul_dev(const u64* a, size_t na, const u64* b, size_t nb, u64* out, siz
     return TF_OK;
 }
 
+// Polynomial::fast_square (polynomial.rs:780-798): one forward transform instead of two.
+int poly_square_dev(const u64* a, size_t na, u64* out, size_t batch, int L, void* stream) {
+    if (batch == 0 || na == 0) return TF_OK;
+    if (!a || !out) return TF_ERR_NULL_POINTER;
+    const size_t n_out = 2 * na - 1;
+    size_t order = 1;
+    while (order < n_out) order <<= 1;
+    int rc = check_len(order);
+    if (rc) return rc;
+    DeviceCtx* ctx = nullptr;
+    rc = current_ctx(&ctx);
+    if (rc) return rc;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    u64* tmp = nullptr;
+    const size_t words = batch * order * size_t(L);
+    hipError_t e = hipMallocAsync(reinterpret_cast<void**>(&tmp), words * sizeof(u64), s);
+    if (e != hipSuccess) return hip_fail(e, "hipMallocAsync(poly_square)", __FILE__, __LINE__);
+    rc = pad_copy(a, tmp, (long long)na * L, (long long)order * L, (long long)batch, s);
+    if (!rc) rc = run_ntt(ctx, tmp, tmp, (long long)order * L, (long long)order * L, order, batch, L, false, nullptr, -1, s);
+    if (!rc) rc = hadamard_dev(tmp, tmp, tmp, batch * order, L, s);
+    if (!rc) rc = run_ntt(ctx, tmp, tmp, (long long)order * L, (long long)order * L, order, batch, L, true, nullptr, -1, s);
+    if (!rc) rc = pad_copy(tmp, out, (long long)order * L, (long long)n_out * L, (long long)batch, s);
+    hipError_t e2 = hipFreeAsync(tmp, s);
+    if (rc) return rc;
+    if (e2 != hipSuccess) return hip_fail(e2, "hipFreeAsync", __FILE__, __LINE__);
+    return TF_OK;
+}
+
 // Low-degree extension: values on {offset_in * w_n^i} -> values on {offset_out * w_m^i}, m >= n
 // (= fast_coset_interpolate then fast_coset_evaluate with the coefficients staying in HBM).
 int lde_dev(const u64* values, size_t n, u64 offset_in, u64* out, size_t m, u64 offset_out, size_t batch, int L, void* stream) {
@@ -1324,6 +1352,12 @@ int tf_poly_mul_bfe_dev(const uint64_t* a, size_t na, const uint64_t* b, size_t 
 int tf_poly_mul_xfe_dev(const uint64_t* a, size_t na, const uint64_t* b, size_t nb, uint64_t* out, size_t batch, void* stream) {
     return poly_mul_dev(a, na, b, nb, out, batch, 3, stream);
 }
+int tf_poly_square_bfe_dev(const uint64_t* a, size_t na, uint64_t* out, size_t batch, void* stream) {
+    return poly_square_dev(a, na, out, batch, 1, stream);
+}
+int tf_poly_square_xfe_dev(const uint64_t* a, size_t na, uint64_t* out, size_t batch, void* stream) {
+    return poly_square_dev(a, na, out, batch, 3, stream);
+}
 int tf_lde_bfe_dev(const uint64_t* v, size_t n, uint64_t off_in, uint64_t* out, size_t m, uint64_t off_out, size_t batch, void* stream) {
     return lde_dev(v, n, off_in, out, m, off_out, batch, 1, stream);
 }
@@ -1361,6 +1395,18 @@ int tf_poly_mul_xfe(const uint64_t* a, size_t na, const uint64_t* b, size_t nb, 
     if (!a || !b || !out) return TF_ERR_NULL_POINTER;
     return host_roundtrip(a, 3 * na * batch, b, 3 * nb * batch, out, 3 * (na + nb - 1) * batch,
                           [&](u64* x, u64* y, u64* o, hipStream_t s) { return poly_mul_dev(x, na, y, nb, o, batch, 3, s); });
+}
+int tf_poly_square_bfe(const uint64_t* a, size_t na, uint64_t* out, size_t batch) {
+    if (batch == 0 || na == 0) return TF_OK;
+    if (!a || !out) return TF_ERR_NULL_POINTER;
+    return host_roundtrip(a, na * batch, nullptr, 0, out, (2 * na - 1) * batch,
+                          [&](u64* x, u64*, u64* o, hipStream_t s) { return poly_square_dev(x, na, o, batch, 1, s); });
+}
+int tf_poly_square_xfe(const uint64_t* a, size_t na, uint64_t* out, size_t batch) {
+    if (batch == 0 || na == 0) return TF_OK;
+    if (!a || !out) return TF_ERR_NULL_POINTER;
+    return host_roundtrip(a, 3 * na * batch, nullptr, 0, out, 3 * (2 * na - 1) * batch,
+                          [&](u64* x, u64*, u64* o, hipStream_t s) { return poly_square_dev(x, na, o, batch, 3, s); });
 }
 int tf_merkle_from_rows(const uint64_t* rows, size_t row_len, size_t n_rows, uint64_t* nodes_out, size_t batch) {
     TRY(check_leaves(n_rows));
