@@ -12,9 +12,10 @@
 //
 // Inside a pass a workgroup owns a tile of `nc` independent length-R DFTs ("columns"), R = 32 * P2:
 //   step 1: every thread holds 32 rows of one column in registers and runs a radix-32 DIT network
-//           whose twiddles are all powers of two (gl::mul_pow2 - shifts, no 64x64 multiply);
+//           whose twiddles are all powers of two (gl::Pow2Mul: shl_fold / shl_monty, no 64x64 multiply);
 //   inner twiddle w_R^(g k1) (one Montgomery multiply per element; n^-1 of the inverse folded in);
-//   one LDS exchange (also the transposition that makes the global stores coalesced);
+//   one LDS exchange, done in rounds of `cpr` columns so two workgroups fit the 160 KiB LDS (the thread
+//           that owned row group g of a column now owns the outputs k1 = g (mod P2) of that column);
 //   step 2: radix-P2 DIT network on the other index, again shift-only;
 //   inter-pass twiddle (one Montgomery multiply), coalesced store.
 // So an element costs 2-3 general multiplies per n = 2^20 transform instead of 10.

@@ -371,7 +371,6 @@ int wg_threads() {
     }
     return g_wg_threads;
 }
-#define kMaxThreads (wg_threads())
 int g_round_elems = 0;
 int round_elems() {
     if (!g_round_elems) {
@@ -381,7 +380,6 @@ int round_elems() {
     }
     return g_round_elems;
 }
-#define kRoundElems (round_elems())   // elements parked in LDS per exchange round: 64 KiB (512 threads) or 32 KiB (256)
 
 // thread / LDS geometry shared by all pass types: nc columns, exchanged in rounds of cpr columns
 void finish_geometry(Launch* l, int nc, int p2) {
@@ -389,7 +387,7 @@ void finish_geometry(Launch* l, int nc, int p2) {
     const int P2 = 1 << p2, R = 32 << p2;
     A.p2 = p2;
     A.nc = nc;
-    A.cpr = std::max(1, std::min(nc, kRoundElems / R));
+    A.cpr = std::max(1, std::min(nc, round_elems() / R));
     A.nrounds = (nc + A.cpr - 1) / A.cpr;
     A.s2 = A.cpr;
     A.s1 = pad_to_residue(P2 * A.cpr, A.cpr % 32);  // consecutive k1 rows land cpr banks apart: conflict-free reads
@@ -409,7 +407,7 @@ Launch plan_column_pass(const u64* in, u64* out, long long in_bs, long long out_
     tfk::NttPassArgs& A = l.a;
     const int p2 = a - 5, P2 = 1 << p2;
     const long long R = 1ll << a, Bw = B * L;
-    int nc = (int)std::min<long long>(std::max(1, kMaxThreads / P2), Bw);
+    int nc = (int)std::min<long long>(std::max(1, wg_threads() / P2), Bw);
     A.in = in;
     A.out = out;
     A.L = L;
@@ -442,7 +440,7 @@ Launch plan_column_pass(const u64* in, u64* out, long long in_bs, long long out_
 
 // rows (independent DFTs) per tile for the passes whose columns are whole rows of elements
 int rows_per_tile(int P2, int L, long long limit) {
-    int nc_max = std::max(1, kMaxThreads / P2);
+    int nc_max = std::max(1, wg_threads() / P2);
     int T = std::max(1, nc_max / L);
     return (int)std::min<long long>(T, limit);
 }
