@@ -103,6 +103,23 @@ struct DitGroups {
 template <bool INV, int LVL>
 __device__ __forceinline__ void dit_level(u64 (&x)[32]) { DitGroups<INV, LVL, 0>::run(x); }
 
+// levels 1..4 restricted to the 16 register slots starting at FIRST (0 or 16)
+template <bool INV, int LVL, int BASE, int END>
+struct DitGroupsRange {
+    static __device__ __forceinline__ void run(u64 (&x)[32]) {
+        constexpr int H = 1 << (LVL - 1);
+        DitInner<INV, LVL, BASE, 0>::run(x);
+        if constexpr (BASE + 2 * H < END) DitGroupsRange<INV, LVL, BASE + 2 * H, END>::run(x);
+    }
+};
+template <bool INV, int FIRST>
+__device__ __forceinline__ void dit_half(u64 (&x)[32]) {
+    DitGroupsRange<INV, 1, FIRST, FIRST + 16>::run(x);
+    DitGroupsRange<INV, 2, FIRST, FIRST + 16>::run(x);
+    DitGroupsRange<INV, 3, FIRST, FIRST + 16>::run(x);
+    DitGroupsRange<INV, 4, FIRST, FIRST + 16>::run(x);
+}
+
 __device__ __forceinline__ constexpr int brev5(int q) {
     return ((q & 1) << 4) | ((q & 2) << 2) | (q & 4) | ((q & 8) >> 2) | ((q & 16) >> 4);
 }
@@ -201,16 +218,19 @@ __global__ void __launch_bounds__(512, TF_NTT_WAVES) ntt_pass_kernel(const NttPa
         }
     }
     __builtin_amdgcn_s_setprio(0);
+    if constexpr (MODE != 2) {
+        // Levels 1-4 of the first 16 slots need only the first 16 loads: start on them while the second half of the
+        // burst is still in flight (the levels below 5 never mix the two halves).  Measured: 2.56 -> 2.44 ms.
+        dit_half<INV, 0>(x);
+        __builtin_amdgcn_sched_barrier(0);
+    }
     if constexpr (MODE == 3) {
         stamp[1] = __builtin_readcyclecounter();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         stamp[2] = __builtin_readcyclecounter();
     }
     if constexpr (MODE != 2) {
-        dit_level<INV, 1>(x);
-        dit_level<INV, 2>(x);
-        dit_level<INV, 3>(x);
-        dit_level<INV, 4>(x);
+        dit_half<INV, 16>(x);
         dit_level<INV, 5>(x);
         if (A.inner_tw) {
             const u64* tw = A.inner_tw + g * 32;
