@@ -120,6 +120,23 @@ __device__ __forceinline__ void dit_half(u64 (&x)[32]) {
     DitGroupsRange<INV, 4, FIRST, FIRST + 16>::run(x);
 }
 
+// Level 5 of the radix-32 network for the four butterflies (Q0+i, Q0+i+16), i < 4, followed by their eight stores.
+template <bool INV, int Q0>
+__device__ __forceinline__ void tail_p5(u64 (&x)[32], bool act, char* obase, u32 toff, long long out_rs_bytes) {
+    butterfly_pow2<TwExp<INV, 5, Q0 + 0>::value>(x[Q0 + 0], x[Q0 + 16]);
+    butterfly_pow2<TwExp<INV, 5, Q0 + 1>::value>(x[Q0 + 1], x[Q0 + 17]);
+    butterfly_pow2<TwExp<INV, 5, Q0 + 2>::value>(x[Q0 + 2], x[Q0 + 18]);
+    butterfly_pow2<TwExp<INV, 5, Q0 + 3>::value>(x[Q0 + 3], x[Q0 + 19]);
+    if (act) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<u64*>(obase + (long long)(32 * (Q0 + i)) * out_rs_bytes + toff) = x[Q0 + i];
+            *reinterpret_cast<u64*>(obase + (long long)(32 * (Q0 + i + 16)) * out_rs_bytes + toff) = x[Q0 + i + 16];
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
 __device__ __forceinline__ constexpr int brev5(int q) {
     return ((q & 1) << 4) | ((q & 2) << 2) | (q & 4) | ((q & 8) >> 2) | ((q & 16) >> 4);
 }
@@ -134,7 +151,7 @@ __device__ __forceinline__ u32 div_by_L(u32 v, int L) {  // v / L for L in {1, 3
 //            (polynomial.rs:1907-1918: intt, then scale by the inverse offset).
 // MODE: 0 = product kernel.  1 / 2 are measurement-only ablations (TF_NTT_ABLATE, never the default):
 //   1 = no global loads/stores (synthetic operands), 2 = no arithmetic (loads, LDS exchange, stores only).
-template <bool INV, int SCALE, int MODE = 0>
+template <bool INV, int SCALE, int MODE = 0, bool LAST1024 = false>
 #ifndef TF_PRIO_LOAD
 #define TF_PRIO_LOAD 3
 #endif
@@ -147,7 +164,7 @@ template <bool INV, int SCALE, int MODE = 0>
 __global__ void __launch_bounds__(512, TF_NTT_WAVES) ntt_pass_kernel(const NttPassArgs A) {
     extern __shared__ __attribute__((aligned(16))) u64 lds[];
     const int t = threadIdx.x;
-    const int p2 = A.p2;
+    const int p2 = LAST1024 ? 5 : A.p2;  // LAST1024: R = 1024, no output multiplier (last pass of a forward/inverse NTT)
     const int P2 = 1 << p2;
     const int L = A.L;
 
@@ -270,6 +287,19 @@ __global__ void __launch_bounds__(512, TF_NTT_WAVES) ntt_pass_kernel(const NttPa
     if constexpr (MODE == 3) { asm volatile("" :: "v"(x[0]), "v"(x[31])); stamp[4] = __builtin_readcyclecounter(); }
     // ------------------------------------------------------------------ step 2 (radix P2 over g) + store
     __builtin_amdgcn_s_setprio(TF_PRIO_STEP2);
+    if constexpr (LAST1024) {
+        // R = 1024 and nothing to multiply: level 5 is fused with the stores, four butterflies (eight outputs) at a
+        // time, so the store burst overlaps the end of the arithmetic.  Slot q holds output row k = g + 32 q.
+        dit_half<INV, 0>(x);
+        dit_half<INV, 16>(x);
+        const u32 toff = (u32)(((long long)ch * A.out_cs_hi + cl + (long long)g * A.out_rs) * 8);
+        char* base = reinterpret_cast<char*>(out);
+        tail_p5<INV, 0>(x, act, base, toff, A.out_rs * 8);
+        tail_p5<INV, 4>(x, act, base, toff, A.out_rs * 8);
+        tail_p5<INV, 8>(x, act, base, toff, A.out_rs * 8);
+        tail_p5<INV, 12>(x, act, base, toff, A.out_rs * 8);
+        return;
+    }
     if constexpr (MODE != 2) {
         if (p2 >= 1) dit_level<INV, 1>(x);
         if (p2 >= 2) dit_level<INV, 2>(x);

@@ -514,11 +514,12 @@ Launch plan_row_pass(const u64* in, u64* out, long long in_bs, long long out_bs,
     return l;
 }
 
-template <bool INV, int SCALE, int MODE>
+template <bool INV, int SCALE, int MODE, bool LAST1024 = false>
 int launch_pass_t(const Launch& l, hipStream_t stream) {
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&tfk::ntt_pass_kernel<INV, SCALE, MODE>),
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&tfk::ntt_pass_kernel<INV, SCALE, MODE, LAST1024>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    hipLaunchKernelGGL((tfk::ntt_pass_kernel<INV, SCALE, MODE>), dim3(l.tiles), dim3(l.threads), l.lds_bytes, stream, l.a);
+    hipLaunchKernelGGL((tfk::ntt_pass_kernel<INV, SCALE, MODE, LAST1024>), dim3(l.tiles), dim3(l.threads), l.lds_bytes, stream,
+                       l.a);
     HIPCHK(hipGetLastError());
     return TF_OK;
 }
@@ -534,7 +535,10 @@ int launch_pass(const Launch& l, bool inverse, hipStream_t stream) {
     }
     if (l.a.pre_scale) return launch_pass_t<false, 1, 0>(l, stream);   // coset evaluation: forward, scale on load
     if (l.a.post_scale) return launch_pass_t<true, 2, 0>(l, stream);   // coset interpolation: inverse, scale on store
-    if (inverse) return launch_pass_t<true, 0, 0>(l, stream);
+    // last pass of a plain transform with R = 1024: specialised kernel (constant P2, stores fused with level 5)
+    const bool last1024 = l.a.p2 == 5 && !l.a.post_tw && g_ablate == 0 && getenv("TF_NTT_NO_LAST1024") == nullptr;
+    if (inverse) return last1024 ? launch_pass_t<true, 0, 0, true>(l, stream) : launch_pass_t<true, 0, 0>(l, stream);
+    if (last1024) return launch_pass_t<false, 0, 0, true>(l, stream);
     if (g_ablate == 1) return launch_pass_t<false, 0, 1>(l, stream);
     if (g_ablate == 2) return launch_pass_t<false, 0, 2>(l, stream);
     if (g_ablate == 3) {
