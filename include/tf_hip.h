@@ -157,6 +157,12 @@ int tf_poly_square_bfe_dev(const uint64_t *d_a, size_t na, uint64_t *d_out, size
 int tf_poly_square_xfe_dev(const uint64_t *d_a, size_t na, uint64_t *d_out, size_t batch, void *stream);
 int tf_lde_bfe_dev(const uint64_t *d_values, size_t n, uint64_t offset_in_raw, uint64_t *d_out, size_t m, uint64_t offset_out_raw, size_t batch, void *stream);
 int tf_lde_xfe_dev(const uint64_t *d_values, size_t n, uint64_t offset_in_raw, uint64_t *d_out, size_t m, uint64_t offset_out_raw, size_t batch, void *stream);
+/* Polynomial::batch_evaluate / iterative_batch_evaluate  math/polynomial.rs:1840-1878: out[i] = f(points[i]),
+ * points in the same field as the coefficients (bfe: 1 word per point, xfe: 3), Horner per point on the device. */
+int tf_poly_batch_evaluate_bfe(const uint64_t *coeffs, size_t n_coeffs, const uint64_t *points, size_t n_points, uint64_t *out);
+int tf_poly_batch_evaluate_xfe(const uint64_t *coeffs, size_t n_coeffs, const uint64_t *points, size_t n_points, uint64_t *out);
+int tf_poly_batch_evaluate_bfe_dev(const uint64_t *d_coeffs, size_t n_coeffs, const uint64_t *d_points, size_t n_points, uint64_t *d_out, void *stream);
+int tf_poly_batch_evaluate_xfe_dev(const uint64_t *d_coeffs, size_t n_coeffs, const uint64_t *d_points, size_t n_points, uint64_t *d_out, void *stream);
 int tf_merkle_from_rows(const uint64_t *rows, size_t row_len, size_t n_rows, uint64_t *nodes_out, size_t batch);
 int tf_merkle_from_rows_dev(const uint64_t *d_rows, size_t row_len, size_t n_rows, uint64_t *d_nodes_out, size_t batch, void *stream);
 int tf_merkle_auth_structure_indices(size_t num_leafs, const uint64_t *leaf_indices, size_t k, uint64_t *out_indices, size_t capacity, size_t *out_count);

@@ -756,6 +756,17 @@ int tfo_auth_structure_indices(size_t num_leafs, const uint64_t *leaf_indices, s
     return 0;
 }
 
+/* Horner at an XFieldElement point (Polynomial::evaluate with Ind = Eval = XFieldElement, polynomial.rs:309-325) */
+void tfo_poly_eval_xfe_point(const uint64_t *c, size_t n_coeffs, const uint64_t point[3], uint64_t out[3]) {
+    u64 acc[3] = {0, 0, 0};
+    for (size_t i = n_coeffs; i-- > 0;) {
+        u64 t[3];
+        tfo_xfe_mul(acc, point, t);
+        for (int k = 0; k < 3; k++) acc[k] = bfe_add(t[k], c[3 * i + k]);
+    }
+    memcpy(out, acc, sizeof(acc));
+}
+
 /* ------------------------------------------------------------------ helpers */
 
 uint64_t tfo_splitmix64(uint64_t *state) {

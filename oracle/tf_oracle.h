@@ -90,6 +90,8 @@ void tfo_poly_mul_naive(const uint64_t *a, size_t na, const uint64_t *b, size_t 
 int tfo_poly_mul_fast(const uint64_t *a, size_t na, const uint64_t *b, size_t nb, int width, uint64_t *out);   /* polynomial.rs:900-932 */
 int tfo_auth_structure_indices(size_t num_leafs, const uint64_t *leaf_indices, size_t k, uint64_t *out, size_t cap, size_t *count); /* merkle_tree.rs:449-504 */
 
+void tfo_poly_eval_xfe_point(const uint64_t *coeffs, size_t n_coeffs, const uint64_t point[3], uint64_t out[3]); /* polynomial.rs:309-325 */
+
 /* ---- helpers for tests/bench ---- */
 uint64_t tfo_splitmix64(uint64_t *state);
 /* fill `count` raw BFE words: new(splitmix64(seed ^ (b<<32) ^ i) mod p)   */

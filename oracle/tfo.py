@@ -77,6 +77,7 @@ def lib() -> C.CDLL:
             "tfo_poly_mul_naive": (None, [pu, sz, pu, sz, i32, pu]),
             "tfo_poly_mul_fast": (i32, [pu, sz, pu, sz, i32, pu]),
             "tfo_auth_structure_indices": (i32, [sz, pu, sz, pu, sz, C.POINTER(C.c_size_t)]),
+            "tfo_poly_eval_xfe_point": (None, [pu, sz, pu, pu]),
             "tfo_fill_random": (None, [pu, sz, u64]),
             "tfo_digest_to_hex": (None, [pu, C.c_char_p]),
         }
@@ -354,6 +355,15 @@ def auth_structure_indices(num_leafs: int, leaf_indices) -> np.ndarray:
     if rc:
         raise OraclePanic(rc)
     return out[: cnt.value].copy()
+
+
+def poly_eval_xfe_point(coeffs, point) -> np.ndarray:
+    c = _arr(coeffs).reshape(-1)
+    pt = _arr(point, 3)
+    out = np.zeros(3, dtype=np.uint64)
+    buf = c if c.size else np.zeros(3, dtype=np.uint64)
+    lib().tfo_poly_eval_xfe_point(_p(buf), c.size // 3, _p(pt), _p(out))
+    return out
 
 
 def merkle_from_rows(rows, row_len: int) -> np.ndarray:

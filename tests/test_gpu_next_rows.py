@@ -162,3 +162,27 @@ def test_fast_square_matches_oracle(tf, oracle, width, na):
         assert np.array_equal(got[k], oracle.poly_mul(ak, ak, width=width))
     p = tf.Polynomial(a[: na * width], width=width)
     assert np.array_equal(p.fast_square().coefficients, tf.Polynomial(oracle.poly_mul(p.coefficients, p.coefficients, width=width), width=width).coefficients)
+
+
+@pytest.mark.parametrize("n_coeffs,n_points", [(0, 5), (1, 1), (7, 300), (100, 1000), (1025, 4097)])
+def test_batch_evaluate_matches_horner(tf, oracle, n_coeffs, n_points):
+    """math/polynomial.rs:1840-1878: values of f on an arbitrary domain, BFE and XFE"""
+    c = oracle.fill_random(n_coeffs, 11 + n_coeffs)
+    pts = oracle.fill_random(n_points, 13 + n_points)
+    got = tf.Polynomial(c).batch_evaluate(pts) if n_coeffs else np.zeros(n_points, np.uint64)
+    if n_coeffs:
+        pc = tf.Polynomial(c).coefficients
+        for i in list(range(min(n_points, 40))) + [n_points - 1]:
+            assert int(got[i]) == int(oracle.poly_eval(pc, int(pts[i]))[0])
+    cx = oracle.fill_random(3 * max(n_coeffs, 1), 17 + n_coeffs)
+    px = oracle.fill_random(3 * n_points, 19 + n_points)
+    gx = tf.Polynomial(cx, width=3).batch_evaluate(px).reshape(-1, 3)
+    pcx = tf.Polynomial(cx, width=3).coefficients
+    for i in list(range(min(n_points, 25))) + [n_points - 1]:
+        assert np.array_equal(gx[i], oracle.poly_eval_xfe_point(pcx, px[3 * i:3 * i + 3]))
+    # the coset evaluation is the batch evaluation on the explicit coset (polynomial.rs:3646-3662)
+    if 0 < n_coeffs <= 128:
+        order, off = 128, oracle.bfe_new(7)
+        omega = oracle.primitive_root(order)
+        coset = np.array([oracle.bfe_mul(off, oracle.bfe_mod_pow(omega, i)) for i in range(order)], dtype=np.uint64)
+        assert np.array_equal(tf.Polynomial(c).batch_evaluate(coset), tf.fast_coset_evaluate(tf.Polynomial(c).coefficients, off, order))

@@ -211,6 +211,15 @@ class Polynomial:
         v = np.ascontiguousarray(values, dtype=np.uint64).reshape(-1)
         return cls(fast_coset_interpolate(v, offset_raw, width=width), width=width)
 
+    def batch_evaluate(self, domain: np.ndarray) -> np.ndarray:
+        """math/polynomial.rs:1840-1852: f at every point of `domain` (points of the same field as the coefficients)."""
+        pts = _words(np.ascontiguousarray(domain, dtype=np.uint64).reshape(-1), "domain")
+        n_points = pts.size // self.width
+        out = np.empty(n_points * self.width, dtype=np.uint64)
+        fn = lib().tf_poly_batch_evaluate_bfe if self.width == 1 else lib().tf_poly_batch_evaluate_xfe
+        _check(fn(_ptr(self.coefficients), self.coefficients.size // self.width, _ptr(pts), n_points, _ptr(out)), "batch_evaluate")
+        return out
+
     def fast_square(self) -> "Polynomial":
         """math/polynomial.rs:780-798"""
         if self.degree() < 0:

@@ -491,6 +491,45 @@ __global__ void __launch_bounds__(256) pad_copy_kernel(const u64* src, u64* dst,
     }
 }
 
+// out[i] = f(points[i]) by Horner's rule, one lane per point (Polynomial::iterative_batch_evaluate,
+// polynomial.rs:1876-1878; same values as batch_evaluate :1840-1852).  The coefficient reads are wave-uniform.
+__device__ __forceinline__ void xfe_mul(const u64 (&s)[3], const u64 (&o)[3], u64 (&r)[3]) {
+    // x_field_element.rs:512-536 with self = [c, b, a], other = [f, e, d]
+    const u64 c = s[0], b = s[1], a = s[2], f = o[0], e = o[1], d = o[2];
+    const u64 ae = gl::mont_mul(a, e), bd = gl::mont_mul(b, d), ad = gl::mont_mul(a, d);
+    r[0] = gl::sub(gl::sub(gl::mont_mul(c, f), ae), bd);
+    r[1] = gl::add(gl::add(gl::sub(gl::add(gl::mont_mul(b, f), gl::mont_mul(c, e)), ad), ae), bd);
+    r[2] = gl::add(gl::add(gl::add(gl::mont_mul(a, f), gl::mont_mul(b, e)), gl::mont_mul(c, d)), ad);
+}
+
+__global__ void __launch_bounds__(256) batch_evaluate_bfe_kernel(const u64* coeffs, long long n_coeffs, const u64* points,
+                                                                long long n_points, u64* out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_points) return;
+    const u64 x = points[i];
+    u64 acc = 0;
+    for (long long k = n_coeffs - 1; k >= 0; --k) acc = gl::add(gl::mont_mul(acc, x), coeffs[k]);
+    out[i] = acc;
+}
+
+__global__ void __launch_bounds__(256) batch_evaluate_xfe_kernel(const u64* coeffs, long long n_coeffs, const u64* points,
+                                                                long long n_points, u64* out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_points) return;
+    const u64 x[3] = {points[3 * i], points[3 * i + 1], points[3 * i + 2]};
+    u64 acc[3] = {0, 0, 0};
+    for (long long k = n_coeffs - 1; k >= 0; --k) {
+        u64 t[3];
+        xfe_mul(acc, x, t);
+        acc[0] = gl::add(t[0], coeffs[3 * k]);
+        acc[1] = gl::add(t[1], coeffs[3 * k + 1]);
+        acc[2] = gl::add(t[2], coeffs[3 * k + 2]);
+    }
+    out[3 * i] = acc[0];
+    out[3 * i + 1] = acc[1];
+    out[3 * i + 2] = acc[2];
+}
+
 // out[k] = nodes[idx[k]] for digests (5 words): authentication structures from a device-resident tree
 __global__ void __launch_bounds__(256) gather_digests_kernel(const u64* nodes, const unsigned long long* idx, long long count, u64* out) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;

@@ -1038,6 +1038,27 @@ int lde_dev(const u64* values, size_t n, u64 offset_in, u64* out, size_t m, u64 
     return TF_OK;
 }
 
+// ------------------------------------------------------------------------------------ batch evaluation
+// Polynomial::batch_evaluate / iterative_batch_evaluate (polynomial.rs:1840-1878): f at arbitrary points of the same
+// field, Horner per point (data parallel over the points; no zerofier tree).
+int batch_evaluate_dev(const u64* coeffs, size_t n_coeffs, const u64* points, size_t n_points, u64* out, int L, void* stream) {
+    if (n_points == 0) return TF_OK;
+    if (!points || !out || (n_coeffs && !coeffs)) return TF_ERR_NULL_POINTER;
+    DeviceCtx* ctx = nullptr;
+    int rc = current_ctx(&ctx);
+    if (rc) return rc;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const long long blocks = ((long long)n_points + 255) / 256;
+    if (L == 1)
+        hipLaunchKernelGGL(tfk::batch_evaluate_bfe_kernel, dim3((unsigned)blocks), dim3(256), 0, s, coeffs, (long long)n_coeffs,
+                           points, (long long)n_points, out);
+    else
+        hipLaunchKernelGGL(tfk::batch_evaluate_xfe_kernel, dim3((unsigned)blocks), dim3(256), 0, s, coeffs, (long long)n_coeffs,
+                           points, (long long)n_points, out);
+    HIPCHK(hipGetLastError());
+    return TF_OK;
+}
+
 // ------------------------------------------------------------------------------------ authentication structures
 // MerkleTree::authentication_structure_node_indices (merkle_tree.rs:449-504): needed minus computable, descending.
 int auth_structure_indices(size_t num_leafs, const uint64_t* leaf_indices, size_t k, std::vector<unsigned long long>* out) {
@@ -1376,6 +1397,12 @@ int tf_lde_bfe_dev(const uint64_t* v, size_t n, uint64_t off_in, uint64_t* out, 
 int tf_lde_xfe_dev(const uint64_t* v, size_t n, uint64_t off_in, uint64_t* out, size_t m, uint64_t off_out, size_t batch, void* stream) {
     return lde_dev(v, n, off_in, out, m, off_out, batch, 3, stream);
 }
+int tf_poly_batch_evaluate_bfe_dev(const uint64_t* c, size_t nc, const uint64_t* pts, size_t np, uint64_t* out, void* stream) {
+    return batch_evaluate_dev(c, nc, pts, np, out, 1, stream);
+}
+int tf_poly_batch_evaluate_xfe_dev(const uint64_t* c, size_t nc, const uint64_t* pts, size_t np, uint64_t* out, void* stream) {
+    return batch_evaluate_dev(c, nc, pts, np, out, 3, stream);
+}
 int tf_merkle_from_rows_dev(const uint64_t* d_rows, size_t row_len, size_t n_rows, uint64_t* d_nodes, size_t batch, void* stream) {
     return merkle_from_rows_dev(d_rows, row_len, n_rows, d_nodes, batch, stream);
 }
@@ -1419,6 +1446,18 @@ int tf_poly_square_xfe(const uint64_t* a, size_t na, uint64_t* out, size_t batch
     if (!a || !out) return TF_ERR_NULL_POINTER;
     return host_roundtrip(a, 3 * na * batch, nullptr, 0, out, 3 * (2 * na - 1) * batch,
                           [&](u64* x, u64*, u64* o, hipStream_t s) { return poly_square_dev(x, na, o, batch, 3, s); });
+}
+int tf_poly_batch_evaluate_bfe(const uint64_t* c, size_t nc, const uint64_t* pts, size_t np, uint64_t* out) {
+    if (np == 0) return TF_OK;
+    if (!pts || !out || (nc && !c)) return TF_ERR_NULL_POINTER;
+    return host_roundtrip(c, nc, pts, np, out, np,
+                          [&](u64* dc, u64* dp, u64* o, hipStream_t s) { return batch_evaluate_dev(dc, nc, dp, np, o, 1, s); });
+}
+int tf_poly_batch_evaluate_xfe(const uint64_t* c, size_t nc, const uint64_t* pts, size_t np, uint64_t* out) {
+    if (np == 0) return TF_OK;
+    if (!pts || !out || (nc && !c)) return TF_ERR_NULL_POINTER;
+    return host_roundtrip(c, 3 * nc, pts, 3 * np, out, 3 * np,
+                          [&](u64* dc, u64* dp, u64* o, hipStream_t s) { return batch_evaluate_dev(dc, nc, dp, np, o, 3, s); });
 }
 int tf_merkle_from_rows(const uint64_t* rows, size_t row_len, size_t n_rows, uint64_t* nodes_out, size_t batch) {
     TRY(check_leaves(n_rows));

@@ -135,3 +135,12 @@ def authentication_structure(nodes, num_leafs: int, leaf_indices):
                                                            li.size, C.c_void_p(out.ctypes.data), cap, C.byref(cnt), _stream(None))
     _chk(rc, "MerkleTree::authentication_structure")
     return out[: cnt.value * 5].reshape(-1, 5).copy()
+
+
+def batch_evaluate(coeffs, n_coeffs: int, points, out, width: int = 1, stream=None) -> None:
+    """Polynomial::batch_evaluate (math/polynomial.rs:1840-1878) on device buffers: out[i] = f(points[i])."""
+    coeffs, points, out = _t(coeffs, "coeffs"), _t(points, "points"), _t(out, "out")
+    if points.numel() != out.numel() or coeffs.numel() != n_coeffs * width:
+        raise ValueError("buffer sizes do not match n_coeffs/points/width")
+    fn = _lib.lib().tf_poly_batch_evaluate_bfe_dev if width == 1 else _lib.lib().tf_poly_batch_evaluate_xfe_dev
+    _chk(fn(_p(coeffs), n_coeffs, _p(points), points.numel() // width, _p(out), _stream(stream)), "batch_evaluate")
