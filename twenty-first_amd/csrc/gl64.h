@@ -52,6 +52,39 @@ GL_HD u64 sub(u64 a, u64 b) {
 
 GL_HD u64 neg(u64 a) { return a ? P - a : 0; }
 
+#if defined(__HIPCC__)
+// (a, v) -> (a + v, a - v) for canonical a, v: ten VALU instructions on two interleaved carry chains.
+//   n = p - v;  s = a - n;  d = a - v;  each difference gets +p on borrow as
+//   lo += borrow (carry c), hi -= borrow & ~c   (p = 2^64 - 2^32 + 1: +1 on the low word, -1 on the high word),
+// with the borrow masks combined on the scalar unit.  The s_nop's keep the two wait states gfx950 wants between a
+// VALU writing a carry mask and a VALU reading it.
+__device__ __forceinline__ void add_sub(u64 a, u64 v, u64& sum, u64& diff) {
+    const u32 a0 = (u32)a, a1 = (u32)(a >> 32), v0 = (u32)v, v1 = (u32)(v >> 32);
+    u32 s0, s1, d0, d1, n0, n1;
+    u64 ma, mb;
+    asm("v_sub_co_u32_e32 %4, vcc, 1, %10\n\t"
+        "v_sub_co_u32_e64 %2, %6, %8, %10\n\t"
+        "s_nop 0\n\t"
+        "v_subb_co_u32_e32 %5, vcc, -1, %11, vcc\n\t"
+        "v_subb_co_u32_e64 %3, %6, %9, %11, %6\n\t"
+        "v_sub_co_u32_e32 %0, vcc, %8, %4\n\t"
+        "s_nop 0\n\t"
+        "v_addc_co_u32_e64 %2, %7, 0, %2, %6\n\t"
+        "v_subb_co_u32_e32 %1, vcc, %9, %5, vcc\n\t"
+        "s_andn2_b64 %6, %6, %7\n\t"
+        "s_nop 0\n\t"
+        "v_addc_co_u32_e64 %0, %7, 0, %0, vcc\n\t"
+        "v_subbrev_co_u32_e64 %3, %6, 0, %3, %6\n\t"
+        "s_andn2_b64 vcc, vcc, %7\n\t"
+        "v_subbrev_co_u32_e32 %1, vcc, 0, %1, vcc"
+        : "=&v"(s0), "=&v"(s1), "=&v"(d0), "=&v"(d1), "=&v"(n0), "=&v"(n1), "=&s"(ma), "=&s"(mb)
+        : "v"(a0), "v"(a1), "v"(v0), "v"(v1)
+        : "vcc", "scc");
+    sum = ((u64)s1 << 32) | s0;
+    diff = ((u64)d1 << 32) | d0;
+}
+#endif
+
 GL_HD u64 mulhi64(u64 a, u64 b) {
 #if defined(__HIP_DEVICE_COMPILE__)
     return __umul64hi(a, b);

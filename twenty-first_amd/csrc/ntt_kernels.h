@@ -67,10 +67,19 @@ struct TwExp {
     static constexpr int value = INV ? (192 - fwd) % 192 : fwd;
 };
 
+#ifndef TF_ASM_BFLY
+#define TF_ASM_BFLY 1  // 0: the compiler's compare-and-select add/sub (12 VALU per butterfly instead of 10)
+#endif
+
 template <int E>
 __device__ __forceinline__ void butterfly_pow2(u64& a, u64& b) {
     // (a, b) -> (a + b * 2^E, a - b * 2^E); the sign of the power-of-two product is folded into add/sub
     const u64 v = gl::Pow2Mul<E>::apply(b);
+#if TF_ASM_BFLY
+    if constexpr (!gl::Pow2Mul<E>::negate) gl::add_sub(a, v, a, b);
+    else gl::add_sub(a, v, b, a);
+    return;
+#endif
     if constexpr (!gl::Pow2Mul<E>::negate) {
         const u64 s = gl::add(a, v);
         b = gl::sub(a, v);
