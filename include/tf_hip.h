@@ -163,6 +163,13 @@ int tf_poly_batch_evaluate_bfe(const uint64_t *coeffs, size_t n_coeffs, const ui
 int tf_poly_batch_evaluate_xfe(const uint64_t *coeffs, size_t n_coeffs, const uint64_t *points, size_t n_points, uint64_t *out);
 int tf_poly_batch_evaluate_bfe_dev(const uint64_t *d_coeffs, size_t n_coeffs, const uint64_t *d_points, size_t n_points, uint64_t *d_out, void *stream);
 int tf_poly_batch_evaluate_xfe_dev(const uint64_t *d_coeffs, size_t n_coeffs, const uint64_t *d_points, size_t n_points, uint64_t *d_out, void *stream);
+/* Polynomial::coset_extrapolate :2117-2128 / batch_coset_extrapolate :2196-2208 (and the par_ variant :2262): for each of
+ * `batch` codewords of length n (a power of two, else TF_ERR_LEN_NOT_POWER_OF_TWO) given on {offset * w_n^i}, the values of
+ * its interpolant at `points` (same field as the codeword): out[(b * n_points + i) * width]. */
+int tf_coset_extrapolate_bfe(uint64_t offset_raw, const uint64_t *codewords, size_t n, size_t batch, const uint64_t *points, size_t n_points, uint64_t *out);
+int tf_coset_extrapolate_xfe(uint64_t offset_raw, const uint64_t *codewords, size_t n, size_t batch, const uint64_t *points, size_t n_points, uint64_t *out);
+int tf_coset_extrapolate_bfe_dev(uint64_t offset_raw, const uint64_t *d_codewords, size_t n, size_t batch, const uint64_t *d_points, size_t n_points, uint64_t *d_out, void *stream);
+int tf_coset_extrapolate_xfe_dev(uint64_t offset_raw, const uint64_t *d_codewords, size_t n, size_t batch, const uint64_t *d_points, size_t n_points, uint64_t *d_out, void *stream);
 int tf_merkle_from_rows(const uint64_t *rows, size_t row_len, size_t n_rows, uint64_t *nodes_out, size_t batch);
 int tf_merkle_from_rows_dev(const uint64_t *d_rows, size_t row_len, size_t n_rows, uint64_t *d_nodes_out, size_t batch, void *stream);
 int tf_merkle_auth_structure_indices(size_t num_leafs, const uint64_t *leaf_indices, size_t k, uint64_t *out_indices, size_t capacity, size_t *out_count);

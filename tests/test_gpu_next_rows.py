@@ -186,3 +186,56 @@ def test_batch_evaluate_matches_horner(tf, oracle, n_coeffs, n_points):
         omega = oracle.primitive_root(order)
         coset = np.array([oracle.bfe_mul(off, oracle.bfe_mod_pow(omega, i)) for i in range(order)], dtype=np.uint64)
         assert np.array_equal(tf.Polynomial(c).batch_evaluate(coset), tf.fast_coset_evaluate(tf.Polynomial(c).coefficients, off, order))
+
+
+@pytest.mark.parametrize("width", [1, 3])
+@pytest.mark.parametrize("n_coeffs,n_points", [(1024, 3), (4096 + 5, 17), (1 << 16, 2)])
+def test_batch_evaluate_long_polynomials(tf, oracle, width, n_coeffs, n_points):
+    """the coefficient-split kernel (n_coeffs >= 1024), ragged tail included"""
+    c = oracle.fill_random(n_coeffs * width, 23 + n_coeffs)
+    pts = oracle.fill_random(n_points * width, 29 + n_points)
+    poly = tf.Polynomial(c, width=width)
+    got = poly.batch_evaluate(pts).reshape(n_points, width)
+    for i in range(n_points):
+        if width == 1:
+            assert int(got[i, 0]) == int(oracle.poly_eval(poly.coefficients, int(pts[i]))[0])
+        else:
+            assert np.array_equal(got[i], oracle.poly_eval_xfe_point(poly.coefficients, pts[3 * i:3 * i + 3]))
+
+
+@pytest.mark.parametrize("width", [1, 3])
+@pytest.mark.parametrize("log_n,batch,n_points", [(0, 1, 4), (5, 2, 2), (8, 3, 33), (12, 2, 5), (16, 1, 3)])
+def test_coset_extrapolate(tf, oracle, width, log_n, batch, n_points):
+    """math/polynomial.rs:2117-2208: values of the coset interpolants at new points (doc example :2183-2195 included below)"""
+    n = 1 << log_n
+    off = oracle.bfe_new(7)
+    cw = oracle.fill_random(batch * n * width, 31 + log_n)
+    pts = oracle.fill_random(n_points * width, 37 + log_n)
+    got = tf.Polynomial.batch_coset_extrapolate(off, n, cw, pts, width=width).reshape(batch, n_points, width)
+    for b in range(batch):
+        coeffs = oracle.coset_interpolate(cw[b * n * width:(b + 1) * n * width], off, width=width)
+        for i in range(n_points):
+            if width == 1:
+                assert int(got[b, i, 0]) == int(oracle.poly_eval(coeffs, int(pts[i]))[0])
+            else:
+                assert np.array_equal(got[b, i], oracle.poly_eval_xfe_point(coeffs, pts[3 * i:3 * i + 3]))
+    one = tf.Polynomial.coset_extrapolate(off, cw[:n * width], pts, width=width)
+    assert np.array_equal(one.reshape(n_points, width), got[0])
+
+
+def test_coset_extrapolate_doc_example_and_panics(tf, oracle):
+    """polynomial.rs:2183-2195: constant codewords extrapolate to the constant; :2194 panics on a non-power-of-two length"""
+    n = 32
+    cw = np.concatenate([oracle.to_raw([3] * n), oracle.to_raw([2] * n)])
+    pts = oracle.to_raw([0, 1])
+    got = tf.Polynomial.batch_coset_extrapolate(oracle.bfe_new(7), n, cw, pts)
+    assert list(got) == list(oracle.to_raw([3, 3, 2, 2]))
+    with pytest.raises(tf.NttPanic):
+        tf.Polynomial.batch_coset_extrapolate(oracle.bfe_new(7), 24, oracle.to_raw([1] * 24), pts)
+    with pytest.raises(tf.TwentyFirstError):
+        tf.Polynomial.batch_coset_extrapolate(0, n, cw, pts)  # offset.inverse() panics on zero
+    # points on the coset itself give the codeword back
+    omega = oracle.primitive_root(n)
+    coset = np.array([oracle.bfe_mul(oracle.bfe_new(7), oracle.bfe_mod_pow(omega, i)) for i in range(n)], dtype=np.uint64)
+    c1 = oracle.fill_random(n, 41)
+    assert np.array_equal(tf.Polynomial.coset_extrapolate(oracle.bfe_new(7), c1, coset), c1)

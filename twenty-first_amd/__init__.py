@@ -220,6 +220,27 @@ class Polynomial:
         _check(fn(_ptr(self.coefficients), self.coefficients.size // self.width, _ptr(pts), n_points, _ptr(out)), "batch_evaluate")
         return out
 
+    @staticmethod
+    def batch_coset_extrapolate(domain_offset_raw: int, codeword_length: int, codewords: np.ndarray, points: np.ndarray,
+                                width: int = 1) -> np.ndarray:
+        """math/polynomial.rs:2196-2208 (and par_ :2262): every codeword's interpolant at every point, codeword-major.
+        Panics (NttPanic) unless codeword_length is a power of two."""
+        cw = _words(np.ascontiguousarray(codewords, dtype=np.uint64).reshape(-1), "codewords")
+        pts = _words(np.ascontiguousarray(points, dtype=np.uint64).reshape(-1), "points")
+        n = int(codeword_length)
+        batch = cw.size // (n * width) if n else 0
+        n_points = pts.size // width
+        out = np.empty(batch * n_points * width, dtype=np.uint64)
+        fn = lib().tf_coset_extrapolate_bfe if width == 1 else lib().tf_coset_extrapolate_xfe
+        _check(fn(C.c_uint64(domain_offset_raw), _ptr(cw), n, batch, _ptr(pts), n_points, _ptr(out)), "batch_coset_extrapolate")
+        return out
+
+    @staticmethod
+    def coset_extrapolate(domain_offset_raw: int, codeword: np.ndarray, points: np.ndarray, width: int = 1) -> np.ndarray:
+        """math/polynomial.rs:2117-2128"""
+        cw = np.ascontiguousarray(codeword, dtype=np.uint64).reshape(-1)
+        return Polynomial.batch_coset_extrapolate(domain_offset_raw, cw.size // width, cw, points, width=width)
+
     def fast_square(self) -> "Polynomial":
         """math/polynomial.rs:780-798"""
         if self.degree() < 0:

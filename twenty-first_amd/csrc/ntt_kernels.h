@@ -511,32 +511,83 @@ __device__ __forceinline__ void xfe_mul(const u64 (&s)[3], const u64 (&o)[3], u6
     r[2] = gl::add(gl::add(gl::add(gl::mont_mul(a, f), gl::mont_mul(b, e)), gl::mont_mul(c, d)), ad);
 }
 
-__global__ void __launch_bounds__(256) batch_evaluate_bfe_kernel(const u64* coeffs, long long n_coeffs, const u64* points,
-                                                                long long n_points, u64* out) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_points) return;
-    const u64 x = points[i];
-    u64 acc = 0;
-    for (long long k = n_coeffs - 1; k >= 0; --k) acc = gl::add(gl::mont_mul(acc, x), coeffs[k]);
-    out[i] = acc;
+// Field element of width L (1: BFieldElement, 3: XFieldElement) for the evaluation kernels.
+template <int L>
+__device__ __forceinline__ void fe_mul(const u64 (&a)[L], const u64 (&b)[L], u64 (&r)[L]) {
+    if constexpr (L == 1) r[0] = gl::mont_mul(a[0], b[0]);
+    else xfe_mul(a, b, r);
 }
 
-__global__ void __launch_bounds__(256) batch_evaluate_xfe_kernel(const u64* coeffs, long long n_coeffs, const u64* points,
-                                                                long long n_points, u64* out) {
+// Lane per point: the right shape for short polynomials at many points.  grid = (ceil(m / 256), batch).
+template <int L>
+__global__ void __launch_bounds__(256) batch_evaluate_kernel(const u64* coeffs, long long n_coeffs, long long poly_stride,
+                                                            const u64* points, long long n_points, u64* out) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_points) return;
-    const u64 x[3] = {points[3 * i], points[3 * i + 1], points[3 * i + 2]};
-    u64 acc[3] = {0, 0, 0};
-    for (long long k = n_coeffs - 1; k >= 0; --k) {
-        u64 t[3];
-        xfe_mul(acc, x, t);
-        acc[0] = gl::add(t[0], coeffs[3 * k]);
-        acc[1] = gl::add(t[1], coeffs[3 * k + 1]);
-        acc[2] = gl::add(t[2], coeffs[3 * k + 2]);
+    const u64* c = coeffs + (long long)blockIdx.y * poly_stride;
+    u64 x[L], acc[L];
+#pragma unroll
+    for (int k = 0; k < L; ++k) { x[k] = points[L * i + k]; acc[k] = 0; }
+    for (long long j = n_coeffs - 1; j >= 0; --j) {
+        u64 t[L];
+        fe_mul<L>(acc, x, t);
+#pragma unroll
+        for (int k = 0; k < L; ++k) acc[k] = gl::add(t[k], c[L * j + k]);
     }
-    out[3 * i] = acc[0];
-    out[3 * i + 1] = acc[1];
-    out[3 * i + 2] = acc[2];
+    u64* o = out + ((long long)blockIdx.y * n_points + i) * L;
+#pragma unroll
+    for (int k = 0; k < L; ++k) o[k] = acc[k];
+}
+
+// Workgroup per (point, polynomial): thread t runs Horner in X = x^256 over coefficients t, t + 256, ... (coalesced
+// reads), scales by x^t, and the 256 partial values are summed through LDS:
+//   f(x) = sum_t x^t * sum_j c[t + 256 j] X^j.   grid = (m, batch).
+template <int L>
+__global__ void __launch_bounds__(256) batch_evaluate_split_kernel(const u64* coeffs, long long n_coeffs, long long poly_stride,
+                                                                  const u64* points, long long n_points, u64* out) {
+    __shared__ u64 part[256 * L];
+    const int t = threadIdx.x;
+    const long long i = blockIdx.x;
+    const u64* c = coeffs + (long long)blockIdx.y * poly_stride;
+    u64 x[L], X[L], acc[L], pw[L], sq[L], tmp[L];
+#pragma unroll
+    for (int k = 0; k < L; ++k) { x[k] = points[L * i + k]; X[k] = x[k]; sq[k] = x[k]; acc[k] = 0; pw[k] = k ? 0 : gl::ONE; }
+#pragma unroll 1
+    for (int b = 0; b < 8; ++b) {  // X = x^256 and pw = x^t by square-and-multiply on the bits of t
+        if ((t >> b) & 1) {
+            fe_mul<L>(pw, sq, tmp);
+#pragma unroll
+            for (int k = 0; k < L; ++k) pw[k] = tmp[k];
+        }
+        fe_mul<L>(sq, sq, tmp);
+#pragma unroll
+        for (int k = 0; k < L; ++k) sq[k] = tmp[k];
+    }
+#pragma unroll
+    for (int k = 0; k < L; ++k) X[k] = sq[k];
+    if (t < n_coeffs) {
+        for (long long j = (n_coeffs - 1 - t) >> 8; j >= 0; --j) {
+            fe_mul<L>(acc, X, tmp);
+            const u64* cj = c + (t + (j << 8)) * L;
+#pragma unroll
+            for (int k = 0; k < L; ++k) acc[k] = gl::add(tmp[k], cj[k]);
+        }
+        fe_mul<L>(acc, pw, tmp);
+#pragma unroll
+        for (int k = 0; k < L; ++k) acc[k] = tmp[k];
+    }
+#pragma unroll
+    for (int k = 0; k < L; ++k) part[t * L + k] = acc[k];
+    __syncthreads();
+#pragma unroll 1
+    for (int h = 128; h > 0; h >>= 1) {
+        if (t < h) {
+#pragma unroll
+            for (int k = 0; k < L; ++k) part[t * L + k] = gl::add(part[t * L + k], part[(t + h) * L + k]);
+        }
+        __syncthreads();
+    }
+    if (t < L) out[((long long)blockIdx.y * n_points + i) * L + t] = part[t];
 }
 
 // out[k] = nodes[idx[k]] for digests (5 words): authentication structures from a device-resident tree

@@ -1040,22 +1040,66 @@ int lde_dev(const u64* values, size_t n, u64 offset_in, u64* out, size_t m, u64 
 
 // ------------------------------------------------------------------------------------ batch evaluation
 // Polynomial::batch_evaluate / iterative_batch_evaluate (polynomial.rs:1840-1878): f at arbitrary points of the same
-// field, Horner per point (data parallel over the points; no zerofier tree).
-int batch_evaluate_dev(const u64* coeffs, size_t n_coeffs, const u64* points, size_t n_points, u64* out, int L, void* stream) {
-    if (n_points == 0) return TF_OK;
+// field.  Exact arithmetic makes every evaluation scheme return the reference's values, so the device uses Horner:
+// lane per point for short polynomials, workgroup per (point, polynomial) with a 256-way split of the coefficients
+// otherwise.  `batch` polynomials of n_coeffs coefficients (poly_stride words apart) share the points;
+// out[(b * n_points + i) * L ..] = f_b(points[i]).
+int batch_evaluate_dev(const u64* coeffs, size_t n_coeffs, size_t poly_stride, size_t batch, const u64* points, size_t n_points,
+                       u64* out, int L, void* stream) {
+    if (n_points == 0 || batch == 0) return TF_OK;
     if (!points || !out || (n_coeffs && !coeffs)) return TF_ERR_NULL_POINTER;
     DeviceCtx* ctx = nullptr;
     int rc = current_ctx(&ctx);
     if (rc) return rc;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const long long blocks = ((long long)n_points + 255) / 256;
-    if (L == 1)
-        hipLaunchKernelGGL(tfk::batch_evaluate_bfe_kernel, dim3((unsigned)blocks), dim3(256), 0, s, coeffs, (long long)n_coeffs,
-                           points, (long long)n_points, out);
-    else
-        hipLaunchKernelGGL(tfk::batch_evaluate_xfe_kernel, dim3((unsigned)blocks), dim3(256), 0, s, coeffs, (long long)n_coeffs,
-                           points, (long long)n_points, out);
-    HIPCHK(hipGetLastError());
+    const bool split = n_coeffs >= 1024 && n_points < (size_t(1) << 31);
+    // grid.y is limited to 65535: walk the batch in slabs
+    for (size_t b0 = 0; b0 < batch; b0 += 65535) {
+        const unsigned nb = (unsigned)std::min<size_t>(65535, batch - b0);
+        const u64* c = coeffs + b0 * poly_stride;
+        u64* o = out + b0 * n_points * size_t(L);
+        const dim3 grid = split ? dim3((unsigned)n_points, nb) : dim3((unsigned)((n_points + 255) / 256), nb);
+        if (split && L == 1)
+            hipLaunchKernelGGL(tfk::batch_evaluate_split_kernel<1>, grid, dim3(256), 0, s, c, (long long)n_coeffs, (long long)poly_stride,
+                               points, (long long)n_points, o);
+        else if (split)
+            hipLaunchKernelGGL(tfk::batch_evaluate_split_kernel<3>, grid, dim3(256), 0, s, c, (long long)n_coeffs, (long long)poly_stride,
+                               points, (long long)n_points, o);
+        else if (L == 1)
+            hipLaunchKernelGGL(tfk::batch_evaluate_kernel<1>, grid, dim3(256), 0, s, c, (long long)n_coeffs, (long long)poly_stride,
+                               points, (long long)n_points, o);
+        else
+            hipLaunchKernelGGL(tfk::batch_evaluate_kernel<3>, grid, dim3(256), 0, s, c, (long long)n_coeffs, (long long)poly_stride,
+                               points, (long long)n_points, o);
+        HIPCHK(hipGetLastError());
+    }
+    return TF_OK;
+}
+
+// Polynomial::{coset_extrapolate, batch_coset_extrapolate} (polynomial.rs:2117-2331): the values, at `points`, of the
+// degree-< n interpolants of `batch` codewords given on the coset {offset * w_n^i}.  Both of the reference's routes
+// (naive :2145-2156, fast :2158-2170) compute exactly interpolant(point), which is what this does:
+// coset-interpolate on the device, then the batched evaluation above; the coefficients never leave HBM.
+int coset_extrapolate_dev(u64 offset_raw, const u64* codewords, size_t n, size_t batch, const u64* points, size_t n_points, u64* out,
+                          int L, void* stream) {
+    if (n == 0) return TF_ERR_LEN_NOT_POWER_OF_TWO;  // "Panics if the codeword_length is not a power of two" (:2194)
+    int rc = check_len(n);
+    if (rc) return rc;
+    if (batch == 0 || n_points == 0) return TF_OK;
+    if (!codewords || !points || !out) return TF_ERR_NULL_POINTER;
+    if (offset_raw == 0) return TF_ERR_INVERSE_OF_ZERO;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    DeviceCtx* ctx = nullptr;
+    rc = current_ctx(&ctx);
+    if (rc) return rc;
+    u64* coeffs = nullptr;
+    hipError_t e = hipMallocAsync(reinterpret_cast<void**>(&coeffs), batch * n * size_t(L) * sizeof(u64), s);
+    if (e != hipSuccess) return hip_fail(e, "hipMallocAsync(coset_extrapolate)", __FILE__, __LINE__);
+    rc = coset_interp_dev(codewords, n, offset_raw, coeffs, batch, L, s);
+    if (!rc) rc = batch_evaluate_dev(coeffs, n, n * size_t(L), batch, points, n_points, out, L, s);
+    hipError_t e2 = hipFreeAsync(coeffs, s);
+    if (rc) return rc;
+    if (e2 != hipSuccess) return hip_fail(e2, "hipFreeAsync", __FILE__, __LINE__);
     return TF_OK;
 }
 
@@ -1398,10 +1442,18 @@ int tf_lde_xfe_dev(const uint64_t* v, size_t n, uint64_t off_in, uint64_t* out, 
     return lde_dev(v, n, off_in, out, m, off_out, batch, 3, stream);
 }
 int tf_poly_batch_evaluate_bfe_dev(const uint64_t* c, size_t nc, const uint64_t* pts, size_t np, uint64_t* out, void* stream) {
-    return batch_evaluate_dev(c, nc, pts, np, out, 1, stream);
+    return batch_evaluate_dev(c, nc, nc, 1, pts, np, out, 1, stream);
 }
 int tf_poly_batch_evaluate_xfe_dev(const uint64_t* c, size_t nc, const uint64_t* pts, size_t np, uint64_t* out, void* stream) {
-    return batch_evaluate_dev(c, nc, pts, np, out, 3, stream);
+    return batch_evaluate_dev(c, nc, 3 * nc, 1, pts, np, out, 3, stream);
+}
+int tf_coset_extrapolate_bfe_dev(uint64_t offset, const uint64_t* cw, size_t n, size_t batch, const uint64_t* pts, size_t np,
+                                 uint64_t* out, void* stream) {
+    return coset_extrapolate_dev(offset, cw, n, batch, pts, np, out, 1, stream);
+}
+int tf_coset_extrapolate_xfe_dev(uint64_t offset, const uint64_t* cw, size_t n, size_t batch, const uint64_t* pts, size_t np,
+                                 uint64_t* out, void* stream) {
+    return coset_extrapolate_dev(offset, cw, n, batch, pts, np, out, 3, stream);
 }
 int tf_merkle_from_rows_dev(const uint64_t* d_rows, size_t row_len, size_t n_rows, uint64_t* d_nodes, size_t batch, void* stream) {
     return merkle_from_rows_dev(d_rows, row_len, n_rows, d_nodes, batch, stream);
@@ -1451,13 +1503,31 @@ int tf_poly_batch_evaluate_bfe(const uint64_t* c, size_t nc, const uint64_t* pts
     if (np == 0) return TF_OK;
     if (!pts || !out || (nc && !c)) return TF_ERR_NULL_POINTER;
     return host_roundtrip(c, nc, pts, np, out, np,
-                          [&](u64* dc, u64* dp, u64* o, hipStream_t s) { return batch_evaluate_dev(dc, nc, dp, np, o, 1, s); });
+                          [&](u64* dc, u64* dp, u64* o, hipStream_t s) { return batch_evaluate_dev(dc, nc, nc, 1, dp, np, o, 1, s); });
 }
 int tf_poly_batch_evaluate_xfe(const uint64_t* c, size_t nc, const uint64_t* pts, size_t np, uint64_t* out) {
     if (np == 0) return TF_OK;
     if (!pts || !out || (nc && !c)) return TF_ERR_NULL_POINTER;
     return host_roundtrip(c, 3 * nc, pts, 3 * np, out, 3 * np,
-                          [&](u64* dc, u64* dp, u64* o, hipStream_t s) { return batch_evaluate_dev(dc, nc, dp, np, o, 3, s); });
+                          [&](u64* dc, u64* dp, u64* o, hipStream_t s) { return batch_evaluate_dev(dc, nc, 3 * nc, 1, dp, np, o, 3, s); });
+}
+static int coset_extrapolate_host(uint64_t offset, const uint64_t* cw, size_t n, size_t batch, const uint64_t* pts, size_t np,
+                                  uint64_t* out, int L) {
+    if (n == 0) return TF_ERR_LEN_NOT_POWER_OF_TWO;
+    int rc = check_len(n);
+    if (rc) return rc;
+    if (batch == 0 || np == 0) return TF_OK;
+    if (!cw || !pts || !out) return TF_ERR_NULL_POINTER;
+    if (offset == 0) return TF_ERR_INVERSE_OF_ZERO;
+    return host_roundtrip(cw, batch * n * L, pts, np * L, out, batch * np * L, [&](u64* dc, u64* dp, u64* o, hipStream_t s) {
+        return coset_extrapolate_dev(offset, dc, n, batch, dp, np, o, L, s);
+    });
+}
+int tf_coset_extrapolate_bfe(uint64_t offset, const uint64_t* cw, size_t n, size_t batch, const uint64_t* pts, size_t np, uint64_t* out) {
+    return coset_extrapolate_host(offset, cw, n, batch, pts, np, out, 1);
+}
+int tf_coset_extrapolate_xfe(uint64_t offset, const uint64_t* cw, size_t n, size_t batch, const uint64_t* pts, size_t np, uint64_t* out) {
+    return coset_extrapolate_host(offset, cw, n, batch, pts, np, out, 3);
 }
 int tf_merkle_from_rows(const uint64_t* rows, size_t row_len, size_t n_rows, uint64_t* nodes_out, size_t batch) {
     TRY(check_leaves(n_rows));

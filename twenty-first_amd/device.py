@@ -144,3 +144,14 @@ def batch_evaluate(coeffs, n_coeffs: int, points, out, width: int = 1, stream=No
         raise ValueError("buffer sizes do not match n_coeffs/points/width")
     fn = _lib.lib().tf_poly_batch_evaluate_bfe_dev if width == 1 else _lib.lib().tf_poly_batch_evaluate_xfe_dev
     _chk(fn(_p(coeffs), n_coeffs, _p(points), points.numel() // width, _p(out), _stream(stream)), "batch_evaluate")
+
+
+def coset_extrapolate(offset_raw: int, codewords, n: int, points, out, batch: int = 1, width: int = 1, stream=None) -> None:
+    """Polynomial::batch_coset_extrapolate (math/polynomial.rs:2196-2208) on device buffers:
+    out[(b * n_points + i) * width] = interpolant_b(points[i])."""
+    codewords, points, out = _t(codewords, "codewords"), _t(points, "points"), _t(out, "out")
+    n_points = points.numel() // width
+    if codewords.numel() != batch * n * width or out.numel() != batch * n_points * width:
+        raise ValueError("buffer sizes do not match n/batch/points/width")
+    fn = _lib.lib().tf_coset_extrapolate_bfe_dev if width == 1 else _lib.lib().tf_coset_extrapolate_xfe_dev
+    _chk(fn(C.c_uint64(offset_raw), _p(codewords), n, batch, _p(points), n_points, _p(out), _stream(stream)), "batch_coset_extrapolate")
