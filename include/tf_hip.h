@@ -43,7 +43,7 @@ enum tf_status {
     TF_ERR_INCORRECT_NUMBER_OF_LEAFS = 2,  /* MerkleTreeError::IncorrectNumberOfLeafs merkle_tree.rs:398-401 */
     TF_ERR_TREE_TOO_HIGH = 3,              /* MerkleTreeError::TreeTooHigh (allocation failure) :405-410 */
     TF_ERR_LEN_NOT_POWER_OF_TWO = 4,       /* ntt/intt panic: assert!(len == 0 || len.is_power_of_two()) math/ntt.rs:137 */
-    TF_ERR_LEN_TOO_LARGE = 5,              /* ntt/intt panic: len > u32::MAX (math/ntt.rs:136); this backend: len > 2^30 */
+    TF_ERR_LEN_TOO_LARGE = 5,              /* ntt/intt panic: len > u32::MAX (math/ntt.rs:134-139), i.e. a power of two above 2^31 */
     TF_ERR_ORDER_NOT_ABOVE_DEGREE = 6,     /* fast_coset_evaluate panic: order <= degree  math/polynomial.rs:1388-1392 */
     TF_ERR_NULL_POINTER = 7,
     TF_ERR_NO_DEVICE = 8,                  /* no HIP device / HIP runtime unusable */
@@ -69,7 +69,7 @@ int tf_device_count(void);
  * x: `batch` contiguous slices of n elements each, transformed in place, natural order in and out.
  * batch = 1 reproduces one Rust call; n = 0 and n = 1 are no-ops exactly as in the reference.
  * inverse != 0 selects intt (w^-1 twiddles and the n^-1 unscale of ntt.rs:220-228).
- * Errors: n not 0/power of two -> TF_ERR_LEN_NOT_POWER_OF_TWO; n > 2^30 -> TF_ERR_LEN_TOO_LARGE.
+ * Errors: n not 0/power of two -> TF_ERR_LEN_NOT_POWER_OF_TWO; n > 2^31 -> TF_ERR_LEN_TOO_LARGE.
  */
 int tf_ntt_bfe(uint64_t *x, size_t n, size_t batch, int inverse);
 int tf_ntt_xfe(uint64_t *x /* 3n words per slice */, size_t n, size_t batch, int inverse);
@@ -183,6 +183,9 @@ int tf_merkle_authentication_structure_dev(const uint64_t *d_nodes, size_t num_l
  *                       launches overlap better than Infinity-Cache-sized ones).
  */
 void tf_set_ntt_tile_bytes(size_t bytes);
+/* Test hook: plan at least `passes` (2..4) global passes whenever n >= 32^passes, so the three- and four-pass paths
+ * (normally n > 2^20 and n = 2^31) can be checked against the oracle at small sizes.  0 restores the automatic plan. */
+void tf_set_ntt_min_passes(int passes);
 /* Number of ntt_pass_kernel launches one tf_ntt_*_dev call enqueues for this shape (diagnostic; used by
  * bench.py to turn a HIP-event interval into an average launch duration). */
 int tf_ntt_launch_count(size_t n, size_t batch, int width);

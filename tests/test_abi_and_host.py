@@ -115,3 +115,16 @@ def test_shard_ranges():
     assert shard_range(4096, 8, 3) == (1536, 2048)  # BASELINE config 5: 4096 NTTs over 8 GPUs
     with pytest.raises(ValueError):
         shard_range(4, 2, 2)
+
+
+def test_length_checks_precede_any_device_work(tf):
+    """math/ntt.rs:134-139: the length panics are decided on the host before a device is touched, so they hold here too"""
+    import ctypes as C
+    lib = tf._lib.lib()
+    buf = (C.c_uint64 * 4)()
+    assert lib.tf_ntt_bfe_dev(buf, 12, 1, 0, None) == 4           # neither 0 nor a power of two
+    assert lib.tf_ntt_bfe_dev(buf, 1 << 32, 1, 0, None) == 5      # longer than u32::MAX
+    assert lib.tf_ntt_xfe_dev(buf, 1 << 33, 1, 1, None) == 5
+    assert lib.tf_ntt_launch_count(1 << 31, 1, 1) == 4            # 2^31 is in range: three column passes + one last pass
+    assert lib.tf_ntt_launch_count(1 << 20, 256, 1) == 2
+    assert lib.tf_ntt_launch_count(1 << 32, 1, 1) == 0

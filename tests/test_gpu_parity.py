@@ -377,3 +377,26 @@ def test_config4_xfe_coset_eval_2pow22(tf, oracle):
     for b in range(batch):
         want = oracle.coset_evaluate(c[3 * n * b:3 * n * (b + 1)], off, n, width=3)
         assert np.array_equal(got[3 * n * b:3 * n * (b + 1)], want)
+
+
+@pytest.mark.parametrize("passes,log_n,width,batch", [(3, 15, 1, 3), (3, 18, 3, 2), (4, 20, 1, 2), (4, 21, 3, 1), (4, 23, 1, 1)])
+def test_deeper_pass_plans_match_oracle(tf, oracle, passes, log_n, width, batch):
+    """the three- and four-pass plans (n > 2^20, n = 2^31) forced at sizes the oracle finishes quickly; forward,
+    inverse, coset evaluation and interpolation all run through the same planner"""
+    n = 1 << log_n
+    x = oracle.fill_random(batch * n * width, 600 + log_n)
+    lib = tf._lib.lib()
+    lib.tf_set_ntt_min_passes(passes)
+    try:
+        y = x.copy()
+        tf.ntt(y, width=width, batch=batch)
+        assert np.array_equal(y, oracle.ntt(x, width=width, batch=batch, threads=8))
+        tf.intt(y, width=width, batch=batch)
+        assert np.array_equal(y, x)
+        off = oracle.bfe_new(7)
+        one = x[:n * width]
+        ev = tf.fast_coset_evaluate(one[: (n // 2 + 3) * width], off, n, width=width)
+        assert np.array_equal(ev, oracle.coset_evaluate(one[: (n // 2 + 3) * width], off, n, width=width))
+        assert np.array_equal(tf.fast_coset_interpolate(one, off, width=width), oracle.coset_interpolate(one, off, width=width))
+    finally:
+        lib.tf_set_ntt_min_passes(0)

@@ -11,8 +11,12 @@ for log_n in [int(a) for a in sys.argv[1:]] or [26, 28]:
     t0 = time.time(); want = tfo.ntt(x); t1 = time.time()
     d = torch.from_numpy(x.view(np.int64)).cuda()
     tf.device.ntt_(d, n); torch.cuda.synchronize()
-    t2 = time.time(); tf.device.ntt_(d, n, inverse=True); tf.device.ntt_(d, n); torch.cuda.synchronize(); t3 = time.time()
     got = d.cpu().numpy().view(np.uint64)
-    print(f"2^{log_n}: match={np.array_equal(got, want)}  oracle {t1-t0:.1f}s  gpu fwd+inv pair {(t3-t2)*1e3:.1f} ms", flush=True)
-    del d, got, want, x
+    ok_fwd = np.array_equal(got, want)
+    del got, want
+    t2 = time.time(); tf.device.ntt_(d, n, inverse=True); torch.cuda.synchronize(); t3 = time.time()
+    back = d.cpu().numpy().view(np.uint64)
+    ok_inv = np.array_equal(back, x)
+    print(f"2^{log_n}: forward match={ok_fwd}  inverse round trip={ok_inv}  oracle {t1-t0:.1f}s  gpu inverse {(t3-t2)*1e3:.1f} ms", flush=True)
+    del d, back, x
     torch.cuda.empty_cache()

@@ -72,6 +72,7 @@ SIGNATURES = {
     "tf_ntt_launch_count": (C.c_int, [_sz, _sz, C.c_int]),
     "tf_debug_stamps": (C.c_int, [_vp, _sz]),
     "tf_set_ntt_tile_bytes": (None, [_sz]),
+    "tf_set_ntt_min_passes": (None, [C.c_int]),
     "tf_get_ntt_tile_bytes": (_sz, []),
 }
 

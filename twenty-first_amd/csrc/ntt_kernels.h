@@ -38,7 +38,7 @@ struct NttPassArgs {
     const u64* post_tw;    // inter-pass twiddles T[k * tw_rs + b] (Montgomery words) or null
     const u64* pre_scale;  // coset powers S[j] (Montgomery words) or null        (polynomial.rs:760-773)
     const u64* post_scale; // interpolation powers offset^-j applied to output element j, or null (polynomial.rs:1907-1918)
-    long long js_i1, js_i2, js_c, js_k;  // output element index j = i1*js_i1 + i2*js_i2 + (c/L)*js_c + k*js_k (last pass only)
+    long long js_i0, js_i1, js_i2, js_c, js_k;  // output element index j = i0*js_i0 + i1*js_i1 + i2*js_i2 + (c/L)*js_c + k*js_k (last pass only)
     long long n_coeffs;    // elements present per input polynomial; rows beyond are zero (polynomial.rs:1395); <0: no padding
     long long ib0, ib1, ib2, ob0, ob1, ob2;  // tile base strides (words)
     long long in_cs_hi, out_cs_hi;           // column c -> (c / L) * cs_hi + (c % L)
@@ -350,7 +350,7 @@ __global__ void __launch_bounds__(512, TF_NTT_WAVES) ntt_pass_kernel(const NttPa
                 __builtin_amdgcn_sched_barrier(0);
             }
         } else if constexpr (SCALE == 2) {
-            const long long j0 = (long long)i1 * A.js_i1 + (long long)i2 * A.js_i2 + (long long)ch * A.js_c + (long long)g * A.js_k;
+            const long long j0 = (long long)i0 * A.js_i0 + (long long)i1 * A.js_i1 + (long long)i2 * A.js_i2 + (long long)ch * A.js_c + (long long)g * A.js_k;
 #pragma unroll
             for (int q0 = 0; q0 < 32; q0 += 8) {
                 u64 w[8];

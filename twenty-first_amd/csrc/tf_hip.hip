@@ -206,13 +206,20 @@ int get_inner_table(DeviceCtx* ctx, int a, bool inverse, int scale_log_n, const 
 }
 
 // T[k*B + b] = w_M^(+-k*b), k < R = 2^a, b < B = M / R
-int get_post_table(DeviceCtx* ctx, int log_m, int a, bool inverse, const u64** out) {
+// Inter-pass twiddles T[k * B + b] = w_M^(k * b), M = 2^log_m = R * B.  Tables up to 2^28 entries (2 GiB) are built once
+// and cached; larger ones (single transforms of 2^29 .. 2^31 points) are stream-ordered temporaries: *temp = true and
+// the caller releases them with hipFreeAsync after the pass that reads them.
+constexpr int kMaxCachedPostLog = 28;
+int get_post_table(DeviceCtx* ctx, int log_m, int a, bool inverse, hipStream_t stream, const u64** out, bool* temp) {
+    *temp = log_m > kMaxCachedPostLog;
     const u64 key = make_key(TAG_POST, log_m, a, inverse, 0);
-    std::lock_guard<std::mutex> lk(ctx->mu);
-    auto it = ctx->tables.find(key);
-    if (it != ctx->tables.end()) {
-        *out = it->second;
-        return TF_OK;
+    std::unique_lock<std::mutex> lk(ctx->mu);
+    if (!*temp) {
+        auto it = ctx->tables.find(key);
+        if (it != ctx->tables.end()) {
+            *out = it->second;
+            return TF_OK;
+        }
     }
     u64 w = root_of_unity_mont(log_m);
     if (inverse) w = gl::mont_inverse(w);
@@ -225,15 +232,26 @@ int get_post_table(DeviceCtx* ctx, int log_m, int a, bool inverse, const u64** o
     rc = upload_table(lo, &d_lo);
     if (rc) return rc;
     const long long M = 1ll << log_m, R = 1ll << a, B = M / R;
-    HIPCHK(hipMalloc(&d, size_t(M) * sizeof(u64)));
+    if (*temp) {
+        lk.unlock();
+        hipError_t e = hipMallocAsync(reinterpret_cast<void**>(&d), size_t(M) * sizeof(u64), stream);
+        if (e != hipSuccess) {
+            (void)hipFree(d_hi);
+            (void)hipFree(d_lo);
+            return hip_fail(e, "hipMallocAsync(twiddle table)", __FILE__, __LINE__);
+        }
+    } else {
+        HIPCHK(hipMalloc(&d, size_t(M) * sizeof(u64)));
+    }
     const int threads = 256;
     const long long blocks = (M + threads - 1) / threads;
-    hipLaunchKernelGGL(tfk::build_post_tw_kernel, dim3((unsigned)blocks), dim3(threads), 0, 0, d, d_hi, d_lo, h, R, B);
+    hipStream_t bs = *temp ? stream : hipStream_t(0);
+    hipLaunchKernelGGL(tfk::build_post_tw_kernel, dim3((unsigned)blocks), dim3(threads), 0, bs, d, d_hi, d_lo, h, R, B);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(0));
+    HIPCHK(hipStreamSynchronize(bs));
     HIPCHK(hipFree(d_hi));
     HIPCHK(hipFree(d_lo));
-    ctx->tables[key] = d;
+    if (!*temp) ctx->tables[key] = d;
     *out = d;
     return TF_OK;
 }
@@ -449,13 +467,22 @@ int rows_per_tile(int P2, int L, long long limit) {
 // Last pass of a multi-pass transform: rows (k1, rho) of R contiguous elements; DFT along the row;
 // output element k of row (k1, rho) goes to  k1 + N1 * (rho + Q * k)  (digit reversal = natural order).
 // A tile is T consecutive k1: its T*L word-columns are contiguous on the OUTPUT side.
+// split = N2 > 0 (four-pass transforms, one polynomial per launch): rho = k2 * (Q / N2) + k3 on the input side but
+// k2 + N2 * k3 on the output side; the kernel's batch index carries k2 and its rho index carries k3.
 Launch plan_transpose_pass(const u64* in, u64* out, long long in_bs, long long out_bs, size_t batch, int a, long long N1,
-                           long long Q, int L) {
+                           long long Q, int L, long long split = 0) {
     Launch l{};
     tfk::NttPassArgs& A = l.a;
     const int p2 = a - 5, P2 = 1 << p2;
     const long long R = 1ll << a;
-    const int T = rows_per_tile(P2, L, N1);
+    int T = rows_per_tile(P2, L, N1);
+    {
+        // the kernel addresses its loads as uniform 64-bit base + 32-bit per-thread byte offset; the offset spans the
+        // tile's T rows, Q * R * L words apart: keep it below 2^32 (only binds for n = 2^31)
+        const long long row_words = Q * R * L;
+        const long long t_max = ((1ll << 29) - (1ll << 16)) / row_words;
+        if (t_max < T) T = (int)std::max<long long>(1, t_max);
+    }
     const int nc = T * L;
     A.in = in;
     A.out = out;
@@ -480,6 +507,16 @@ Launch plan_transpose_pass(const u64* in, u64* out, long long in_bs, long long o
     A.js_c = 1;
     A.js_k = N1 * Q;
     A.xcd_order = (nc * (int)sizeof(u64) < 128 && A.d2 % 16 == 0) ? 2 : 0;  // output segments narrower than a line: pair them
+    if (split) {
+        const long long N3 = Q / split;
+        A.d1 = (u32)N3;
+        A.ib0 = N3 * R * L;
+        A.ob0 = N1 * L;
+        A.ob1 = N1 * split * L;
+        A.js_i0 = N1;
+        A.js_i1 = N1 * split;
+        batch = 1;
+    }
     finish_geometry(&l, nc, p2);
     l.tiles = (unsigned)(batch * Q * A.d2);
     return l;
@@ -561,8 +598,17 @@ int launch_pass(const Launch& l, bool inverse, hipStream_t stream) {
 
 int check_len(size_t n) {
     if (n != 0 && (n & (n - 1))) return TF_ERR_LEN_NOT_POWER_OF_TWO;  // ntt.rs:137
-    if (n > (size_t(1) << 30)) return TF_ERR_LEN_TOO_LARGE;           // ntt.rs:136 (u32) / this backend's 3-pass limit
+    if (n > (size_t(1) << 31)) return TF_ERR_LEN_TOO_LARGE;           // ntt.rs:134-139: lengths beyond u32::MAX panic
     return TF_OK;
+}
+
+std::atomic<int> g_min_passes{0};  // tf_set_ntt_min_passes
+
+int pass_count(int log_n) {  // global passes of a transform with log_n > 10
+    int P = log_n <= 20 ? 2 : (log_n <= 30 ? 3 : 4);
+    const int want = g_min_passes.load(std::memory_order_relaxed);  // test hook: deeper plans at small sizes
+    if (want > P && want <= 4 && log_n >= 5 * want) P = want;
+    return P;
 }
 
 // The transform proper.  in/out are device pointers; in == out for ntt/intt, distinct for coset evaluation
@@ -612,30 +658,39 @@ int run_ntt(DeviceCtx* ctx, const u64* in, u64* out, long long in_bs, long long 
         }
         return TF_OK;
     }
-    // multi-pass: n = N1 * N2 (* N3)
-    int a1, a2, a3 = 0;
-    if (log_n <= 20) {
-        a1 = (log_n + 1) / 2;
-        a2 = log_n - a1;
-    } else {
-        a1 = (log_n + 2) / 3;
-        a2 = (log_n - a1 + 1) / 2;
-        a3 = log_n - a1 - a2;
+    // multi-pass: n = N_1 * ... * N_P, every N_i = 2^(a_i) <= 1024.  Passes 1 .. P-1 are column passes (DFT over digit i,
+    // inter-pass twiddle, same position in and out); the last pass transforms the contiguous rows of N_P elements and
+    // scatters output digit k_P to  k_1 + N_1 k_2 + ... + N_1..N_{P-1} k_P  (natural order).
+    int a[4] = {0, 0, 0, 0};
+    const int P = pass_count(log_n);
+    {
+        int rest = log_n;
+        for (int i = 0; i < P; ++i) {
+            a[i] = (rest + (P - i) - 1) / (P - i);  // as even as possible, larger radices first (31 -> 8, 8, 8, 7)
+            rest -= a[i];
+        }
     }
-    const bool three = a3 != 0;
-    const long long N1 = 1ll << a1, N2 = 1ll << a2, N3 = three ? (1ll << a3) : 1;
-    const u64 *inner1, *inner2, *inner3 = nullptr, *post1, *post2 = nullptr;
-    rc = get_inner_table(ctx, a1, inverse, 0, &inner1);
-    if (rc) return rc;
-    rc = get_inner_table(ctx, a2, inverse, (!three && inverse) ? log_n : 0, &inner2);
-    if (rc) return rc;
-    rc = get_post_table(ctx, log_n, a1, inverse, &post1);
-    if (rc) return rc;
-    if (three) {
-        rc = get_inner_table(ctx, a3, inverse, inverse ? log_n : 0, &inner3);
+    const u64* inner[4] = {nullptr, nullptr, nullptr, nullptr};
+    for (int i = 0; i < P; ++i) {
+        rc = get_inner_table(ctx, a[i], inverse, (i == P - 1 && inverse) ? log_n : 0, &inner[i]);  // n^-1 rides on the last pass
         if (rc) return rc;
-        rc = get_post_table(ctx, a2 + a3, a2, inverse, &post2);
-        if (rc) return rc;
+    }
+    const u64* post[3] = {nullptr, nullptr, nullptr};
+    bool post_temp[3] = {false, false, false};
+    auto release_tables = [&]() {
+        for (int i = 0; i < 3; ++i)
+            if (post_temp[i] && post[i]) (void)hipFreeAsync(const_cast<u64*>(post[i]), stream);
+    };
+    {
+        int rest = log_n;
+        for (int i = 0; i + 1 < P; ++i) {
+            rc = get_post_table(ctx, rest, a[i], inverse, stream, &post[i], &post_temp[i]);
+            if (rc) {
+                release_tables();
+                return rc;
+            }
+            rest -= a[i];
+        }
     }
     read_env();
     const size_t poly_bytes = n * size_t(L) * sizeof(u64);
@@ -644,45 +699,58 @@ int run_ntt(DeviceCtx* ctx, const u64* in, u64* out, long long in_bs, long long 
     u64* scratch = nullptr;
     {
         hipError_t e = hipMallocAsync(reinterpret_cast<void**>(&scratch), tb * poly_bytes, stream);
-        if (e != hipSuccess) return hip_fail(e, "hipMallocAsync(ntt scratch)", __FILE__, __LINE__);
+        if (e != hipSuccess) {
+            release_tables();
+            return hip_fail(e, "hipMallocAsync(ntt scratch)", __FILE__, __LINE__);
+        }
     }
     const long long sbs = (long long)n * L;  // scratch batch stride
+    long long N[4];
+    for (int i = 0; i < 4; ++i) N[i] = 1ll << a[i];
     for (size_t b0 = 0; b0 < batch && rc == TF_OK; b0 += tb) {
         const size_t nb = std::min(tb, batch - b0);
         const u64* tin = in + (long long)b0 * in_bs;
         u64* tout = out + (long long)b0 * out_bs;
-        if (!three) {
-            Launch p1 = plan_column_pass(tin, scratch, in_bs, sbs, nb, 1, a1, N2, L);
-            p1.a.inner_tw = inner1;
-            p1.a.post_tw = post1;
-            p1.a.pre_scale = pre_scale;
-            p1.a.n_coeffs = n_coeffs;
-            rc = launch_pass(p1, inverse, stream);
-            if (rc) break;
-            Launch p2 = plan_transpose_pass(scratch, tout, sbs, out_bs, nb, a2, N1, 1, L);
-            p2.a.inner_tw = inner2;
-            p2.a.post_scale = post_scale;
-            rc = launch_pass(p2, inverse, stream);
+        // column passes: the first reads the caller's input, the last writes the scratch tile, the ones between work
+        // in place on the output
+        const u64* src = tin;
+        long long src_bs = in_bs;
+        long long outer = 1, B = (long long)n;
+        for (int i = 0; i + 1 < P && rc == TF_OK; ++i) {
+            B >>= a[i];
+            const bool to_scratch = i == P - 2;
+            u64* dst = to_scratch ? scratch : tout;
+            const long long dst_bs = to_scratch ? sbs : out_bs;
+            Launch p = plan_column_pass(src, dst, src_bs, dst_bs, nb, outer, a[i], B, L);
+            p.a.inner_tw = inner[i];
+            p.a.post_tw = post[i];
+            if (i == 0) {
+                p.a.pre_scale = pre_scale;
+                p.a.n_coeffs = n_coeffs;
+            }
+            rc = launch_pass(p, inverse, stream);
+            src = dst;
+            src_bs = dst_bs;
+            outer <<= a[i];
+        }
+        if (rc) break;
+        if (P < 4) {
+            Launch pl = plan_transpose_pass(scratch, tout, sbs, out_bs, nb, a[P - 1], N[0], P == 3 ? N[1] : 1, L);
+            pl.a.inner_tw = inner[P - 1];
+            pl.a.post_scale = post_scale;
+            rc = launch_pass(pl, inverse, stream);
         } else {
-            Launch p1 = plan_column_pass(tin, tout, in_bs, out_bs, nb, 1, a1, N2 * N3, L);
-            p1.a.inner_tw = inner1;
-            p1.a.post_tw = post1;
-            p1.a.pre_scale = pre_scale;
-            p1.a.n_coeffs = n_coeffs;
-            rc = launch_pass(p1, inverse, stream);
-            if (rc) break;
-            Launch p2 = plan_column_pass(tout, scratch, out_bs, sbs, nb, N1, a2, N3, L);
-            p2.a.inner_tw = inner2;
-            p2.a.post_tw = post2;
-            rc = launch_pass(p2, inverse, stream);
-            if (rc) break;
-            Launch p3 = plan_transpose_pass(scratch, tout, sbs, out_bs, nb, a3, N1, N2, L);
-            p3.a.inner_tw = inner3;
-            p3.a.post_scale = post_scale;
-            rc = launch_pass(p3, inverse, stream);
+            for (size_t b = 0; b < nb && rc == TF_OK; ++b) {
+                Launch pl = plan_transpose_pass(scratch + (long long)b * sbs, tout + (long long)b * out_bs, sbs, out_bs, 1, a[3], N[0],
+                                                N[1] * N[2], L, N[1]);
+                pl.a.inner_tw = inner[3];
+                pl.a.post_scale = post_scale;
+                rc = launch_pass(pl, inverse, stream);
+            }
         }
     }
     hipError_t e = hipFreeAsync(scratch, stream);
+    release_tables();
     if (rc) return rc;
     if (e != hipSuccess) return hip_fail(e, "hipFreeAsync(ntt scratch)", __FILE__, __LINE__);
     return TF_OK;
@@ -1286,6 +1354,7 @@ int tf_debug_stamps(unsigned long long* host_out, size_t words) {
     return TF_OK;
 }
 
+void tf_set_ntt_min_passes(int passes) { g_min_passes.store(passes, std::memory_order_relaxed); }
 int tf_ntt_launch_count(size_t n, size_t batch, int width) {
     if (check_len(n) || n <= 1 || batch == 0 || (width != 1 && width != 3)) return 0;
     const int log_n = ilog2(n);
@@ -1294,7 +1363,9 @@ int tf_ntt_launch_count(size_t n, size_t batch, int width) {
     const size_t poly_bytes = n * size_t(width) * sizeof(u64);
     size_t tb = std::min(std::max<size_t>(1, g_tile_bytes / poly_bytes), batch);
     const size_t tiles = (batch + tb - 1) / tb;
-    return (int)(tiles * (log_n <= 20 ? 2 : 3));
+    const int P = pass_count(log_n);
+    if (P == 4) return (int)(tiles * 3 + batch);  // the last pass of a four-pass plan is launched per polynomial
+    return (int)(tiles * P);
 }
 
 int tf_ntt_bfe(uint64_t* x, size_t n, size_t batch, int inverse) { return ntt_host(x, n, batch, 1, inverse); }
