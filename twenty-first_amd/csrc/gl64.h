@@ -140,6 +140,65 @@ GL_HD u64 mont_mul(u64 a, u64 b) {
     return montyred(lo, hi);
 }
 
+#if defined(__HIPCC__)
+// Two independent Montgomery products, 15 VALU instructions each (mont_mul above compiles to 18: the compiler needs a
+// v_mov per 32-bit addend of v_mad_u64_u32 and a compare + two selects for the final "+ p").  Per product:
+//   p0 = a0 b0, q = a1 b0, hh = a1 b1               three v_mad_u64_u32 with a zero addend
+//   m  = a0 b1 + q, carry cm                         one v_mad_u64_u32, its carry-out kept in an SGPR pair
+//   (l1, h0, h1) = the upper three words of p0 + (m << 32) + (hh << 64) + (cm << 96)      four carry-chain adds
+//   Montgomery reduction of (h1:h0:l1:p0l) as in montyred, the final "+ p" done as  r0 += c, r1 -= c & ~carry.
+// The two carry chains are interleaved (one on vcc, one on an SGPR pair) so that, with one s_nop per step, every
+// carry is read at least two wait states after it was written.
+__device__ __forceinline__ void mont_mul2(u64 a, u64 b, u64 c, u64 d, u64& ab, u64& cd) {
+    const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+    const u32 c0 = (u32)c, c1 = (u32)(c >> 32), d0 = (u32)d, d1 = (u32)(d >> 32);
+    const u64 xp = (u64)a0 * b0, xq = (u64)a1 * b0, xh = (u64)a1 * b1;
+    const u64 yp = (u64)c0 * d0, yq = (u64)c1 * d0, yh = (u64)c1 * d1;
+    u64 xm, xc, ym, yc;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(xm), "=s"(xc) : "v"(a0), "v"(b1), "v"(xq));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(ym), "=s"(yc) : "v"(c0), "v"(d1), "v"(yq));
+    u32 xr0, xr1, xu, xw, yr0, yr1, yu, yw;
+    u64 st, su, sy;
+    asm("v_add_co_u32_e32 %2, vcc, %12, %13\n\t"            // X1  l1 = p0h + ml
+        "v_add_co_u32_e64 %6, %10, %19, %20\n\t"            // Y1
+        "s_nop 0\n\t"
+        "v_addc_co_u32_e32 %0, vcc, %15, %14, vcc\n\t"      // X2  h0 = hl + mh + c
+        "v_addc_co_u32_e64 %4, %10, %22, %21, %10\n\t"      // Y2
+        "s_nop 0\n\t"
+        "v_addc_co_u32_e32 %1, vcc, 0, %16, vcc\n\t"        // X3  h1 = hh + c
+        "v_addc_co_u32_e64 %5, %10, 0, %23, %10\n\t"        // Y3
+        "v_addc_co_u32_e64 %1, %8, 0, %1, %17\n\t"          // X4  h1 += cm
+        "v_addc_co_u32_e64 %5, %9, 0, %5, %24\n\t"          // Y4
+        "v_add_co_u32_e32 %2, vcc, %2, %11\n\t"             // X5  a1 = l1 + l0
+        "v_add_co_u32_e64 %6, %10, %6, %18\n\t"             // Y5
+        "s_nop 0\n\t"
+        "v_subb_co_u32_e32 %3, vcc, %11, %2, vcc\n\t"       // X6  b0 = l0 - a1 - e
+        "v_subb_co_u32_e64 %7, %10, %18, %6, %10\n\t"       // Y6
+        "s_nop 0\n\t"
+        "v_subbrev_co_u32_e32 %2, vcc, 0, %2, vcc\n\t"      // X7  b1 = a1 - borrow
+        "v_subbrev_co_u32_e64 %6, %10, 0, %6, %10\n\t"      // Y7
+        "v_sub_co_u32_e32 %0, vcc, %0, %3\n\t"              // X8  r0 = h0 - b0
+        "v_sub_co_u32_e64 %4, %10, %4, %7\n\t"              // Y8
+        "s_nop 0\n\t"
+        "v_subb_co_u32_e32 %1, vcc, %1, %2, vcc\n\t"        // X9  r1 = h1 - b1 - borrow
+        "v_subb_co_u32_e64 %5, %10, %5, %6, %10\n\t"        // Y9
+        "s_nop 0\n\t"
+        "v_addc_co_u32_e64 %0, %8, 0, %0, vcc\n\t"          // X10 r0 += borrow
+        "v_addc_co_u32_e64 %4, %9, 0, %4, %10\n\t"          // Y10
+        "s_andn2_b64 vcc, vcc, %8\n\t"                      // X11
+        "s_andn2_b64 %10, %10, %9\n\t"                      // Y11
+        "v_subbrev_co_u32_e32 %1, vcc, 0, %1, vcc\n\t"      // X12 r1 -= borrow & ~carry
+        "v_subbrev_co_u32_e64 %5, %10, 0, %5, %10"            // Y12
+        : "=&v"(xr0), "=&v"(xr1), "=&v"(xu), "=&v"(xw), "=&v"(yr0), "=&v"(yr1), "=&v"(yu), "=&v"(yw), "=&s"(st), "=&s"(su),
+          "=&s"(sy)
+        : "v"((u32)xp), "v"((u32)(xp >> 32)), "v"((u32)xm), "v"((u32)(xm >> 32)), "v"((u32)xh), "v"((u32)(xh >> 32)), "s"(xc),
+          "v"((u32)yp), "v"((u32)(yp >> 32)), "v"((u32)ym), "v"((u32)(ym >> 32)), "v"((u32)yh), "v"((u32)(yh >> 32)), "s"(yc)
+        : "vcc", "scc");
+    ab = ((u64)xr1 << 32) | xr0;
+    cd = ((u64)yr1 << 32) | yr0;
+}
+#endif
+
 GL_HD u64 to_mont(u64 v) { return mont_mul(v, R2); }     // BFieldElement::new  (:235-237)
 GL_HD u64 from_mont(u64 raw) { return montyred(raw, 0); } // BFieldElement::value (:248-250)
 

@@ -261,7 +261,7 @@ __global__ void __launch_bounds__(512, TF_NTT_WAVES) ntt_pass_kernel(const NttPa
         if (A.inner_tw) {
             const u64* tw = A.inner_tw + g * 32;
 #pragma unroll
-            for (int q = 0; q < 32; ++q) x[q] = gl::mont_mul(x[q], tw[q]);
+            for (int q = 0; q < 32; q += 2) gl::mont_mul2(x[q], tw[q], x[q + 1], tw[q + 1], x[q], x[q + 1]);
         }
     }
     if constexpr (MODE == 3) { asm volatile("" :: "v"(x[0]), "v"(x[31])); stamp[3] = __builtin_readcyclecounter(); }
@@ -338,14 +338,14 @@ __global__ void __launch_bounds__(512, TF_NTT_WAVES) ntt_pass_kernel(const NttPa
                     w[i] = *reinterpret_cast<const u64*>(tbase + uk * A.tw_rs * 8 + twoff);
                 }
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
+                for (int i = 0; i < 8; i += 2) {
                     const int q = q0 + i;
-                    const long long uk = (long long)(((q >> p2) << p2) + ((q & (P2 - 1)) << 5));
-#ifdef TF_NT
-                    __builtin_nontemporal_store(gl::mont_mul(x[q], w[i]), reinterpret_cast<u64*>(base + uk * A.out_rs * 8 + toff));
-#else
-                    *reinterpret_cast<u64*>(base + uk * A.out_rs * 8 + toff) = gl::mont_mul(x[q], w[i]);
-#endif
+                    const long long uk0 = (long long)(((q >> p2) << p2) + ((q & (P2 - 1)) << 5));  // uniform part of k
+                    const long long uk1 = (long long)((((q + 1) >> p2) << p2) + (((q + 1) & (P2 - 1)) << 5));
+                    u64 r0, r1;
+                    gl::mont_mul2(x[q], w[i], x[q + 1], w[i + 1], r0, r1);
+                    *reinterpret_cast<u64*>(base + uk0 * A.out_rs * 8 + toff) = r0;
+                    *reinterpret_cast<u64*>(base + uk1 * A.out_rs * 8 + toff) = r1;
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -361,10 +361,14 @@ __global__ void __launch_bounds__(512, TF_NTT_WAVES) ntt_pass_kernel(const NttPa
                     w[i] = A.post_scale[j0 + uk * A.js_k];
                 }
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
+                for (int i = 0; i < 8; i += 2) {
                     const int q = q0 + i;
-                    const long long uk = (long long)(((q >> p2) << p2) + ((q & (P2 - 1)) << 5));
-                    *reinterpret_cast<u64*>(base + uk * A.out_rs * 8 + toff) = gl::mont_mul(x[q], w[i]);
+                    const long long uk0 = (long long)(((q >> p2) << p2) + ((q & (P2 - 1)) << 5));
+                    const long long uk1 = (long long)((((q + 1) >> p2) << p2) + (((q + 1) & (P2 - 1)) << 5));
+                    u64 r0, r1;
+                    gl::mont_mul2(x[q], w[i], x[q + 1], w[i + 1], r0, r1);
+                    *reinterpret_cast<u64*>(base + uk0 * A.out_rs * 8 + toff) = r0;
+                    *reinterpret_cast<u64*>(base + uk1 * A.out_rs * 8 + toff) = r1;
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }

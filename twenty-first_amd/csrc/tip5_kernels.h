@@ -48,10 +48,12 @@ __device__ __forceinline__ void tip5_round(u64 (&s)[16], int round, const unsign
         s[i] = ((u64)hi << 32) | lo;  // may be >= p, exactly like the reference
     }
 #pragma unroll
-    for (int i = 4; i < 16; ++i) {
-        u64 sq = gl::mont_mul(s[i], s[i]);
-        u64 qu = gl::mont_mul(sq, sq);
-        s[i] = gl::mont_mul(s[i], gl::mont_mul(sq, qu));
+    for (int i = 4; i < 16; i += 2) {  // x^7 = x * (x^2 * x^4), two elements per hand-scheduled product pair
+        u64 sq0, sq1, qu0, qu1, t0, t1;
+        gl::mont_mul2(s[i], s[i], s[i + 1], s[i + 1], sq0, sq1);
+        gl::mont_mul2(sq0, sq0, sq1, sq1, qu0, qu1);
+        gl::mont_mul2(sq0, qu0, sq1, qu1, t0, t1);
+        gl::mont_mul2(s[i], t0, s[i + 1], t1, s[i], s[i + 1]);
     }
     // MDS on 32-bit halves + round constant
     u32 lo[16], hi[16];
@@ -69,11 +71,22 @@ __device__ __forceinline__ void tip5_round(u64 (&s)[16], int round, const unsign
             alo += (u64)m * lo[c];
             ahi += (u64)m * hi[c];
         }
-        // value = alo + ahi * 2^32  (< 2^84)  =  l64 + h32 * 2^64  ==  l64 + h32 * (2^32 - 1)
-        u64 l64 = alo + (ahi << 32);
-        u64 h32 = (ahi >> 32) + (l64 < alo);
-        u64 v = gl::add(l64, (h32 << 32) - h32);
-        s[r] = gl::add(v, g_tip5.rc[round * 16 + r]);
+        // value + round constant = alo + ahi * 2^32 + rc  (< 2^85)  as three 32-bit carry-chain words (t2 : t1 : t0), then one
+        // fold of t2 * 2^64 == t2 * (2^32 - 1) and one conditional subtraction: the canonical word of the reference's
+        // reduce-then-add (mod.rs:244-252, :178-180), because every step is exact
+        const u64 rc = g_tip5.rc[round * 16 + r];
+        unsigned c0, c1, c2, c3, c4;
+        const u32 w1 = __builtin_addc((u32)(alo >> 32), (u32)ahi, 0u, &c0);
+        const u32 w2 = __builtin_addc((u32)(ahi >> 32), 0u, c0, &c1);
+        const u32 t0 = __builtin_addc((u32)alo, (u32)rc, 0u, &c2);
+        const u32 t1 = __builtin_addc(w1, (u32)(rc >> 32), c2, &c3);
+        const u32 t2 = __builtin_addc(w2, 0u, c3, &c4);  // < 2^22
+        const u64 l64 = ((u64)t1 << 32) | t0;
+        const u64 t = (u64)t2 * 0xffffffffu + l64;  // true value < 2^64 + 2^54
+        const bool ca = t < l64;
+        const u64 u = t + gl::EPS;  // t - p (mod 2^64)
+        const bool cb = u < t;
+        s[r] = (ca | cb) ? u : t;
     }
 }
 
