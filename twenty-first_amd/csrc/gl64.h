@@ -236,9 +236,25 @@ GL_HD u64 shl_fold(u64 x) {
 template <int S>
 GL_HD u64 shl_monty(u64 x) {
     static_assert(S >= 0 && S < 64, "");
+#if defined(__HIP_DEVICE_COMPILE__)
+    // the 128-bit shifted value on 32-bit limbs: at most three instructions (shift, funnel shift, shift)
+    const u32 x0 = (u32)x, x1 = (u32)(x >> 32);
+    u32 l0, l1, h0, h1;
+    if constexpr (S == 0) {
+        l0 = x0, l1 = x1, h0 = 0, h1 = 0;
+    } else if constexpr (S < 32) {
+        l0 = x0 << S, l1 = __builtin_amdgcn_alignbit(x1, x0, 32 - S), h0 = x1 >> (32 - S), h1 = 0;
+    } else if constexpr (S == 32) {
+        l0 = 0, l1 = x0, h0 = x1, h1 = 0;
+    } else {
+        l0 = 0, l1 = x0 << (S - 32), h0 = __builtin_amdgcn_alignbit(x1, x0, 64 - S), h1 = x1 >> (64 - S);
+    }
+    return montyred(((u64)l1 << 32) | l0, ((u64)h1 << 32) | h0);
+#else
     const u64 lo = x << S;
     const u64 hi = S ? (x >> ((64 - S) & 63)) : 0;
     return montyred(lo, hi);  // x * 2^S < 2^127 < p * 2^64: a valid Montgomery-reduction input
+#endif
 }
 
 // x * 2^E mod p as (value, sign): E taken mod 192; returns v with  x * 2^E = negate ? -v : v.
