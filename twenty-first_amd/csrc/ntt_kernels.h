@@ -160,7 +160,7 @@ __device__ __forceinline__ u32 div_by_L(u32 v, int L) {  // v / L for L in {1, 3
 //            (polynomial.rs:1907-1918: intt, then scale by the inverse offset).
 // MODE: 0 = product kernel.  1 / 2 are measurement-only ablations (TF_NTT_ABLATE, never the default):
 //   1 = no global loads/stores (synthetic operands), 2 = no arithmetic (loads, LDS exchange, stores only).
-template <bool INV, int SCALE, int MODE = 0, bool LAST1024 = false>
+template <bool INV, int SCALE, int MODE = 0, bool LAST1024 = false, bool R1024 = false>
 #ifndef TF_PRIO_LOAD
 #define TF_PRIO_LOAD 3
 #endif
@@ -173,7 +173,9 @@ template <bool INV, int SCALE, int MODE = 0, bool LAST1024 = false>
 __global__ void __launch_bounds__(512, TF_NTT_WAVES) ntt_pass_kernel(const NttPassArgs A) {
     extern __shared__ __attribute__((aligned(16))) u64 lds[];
     const int t = threadIdx.x;
-    const int p2 = LAST1024 ? 5 : A.p2;  // LAST1024: R = 1024, no output multiplier (last pass of a forward/inverse NTT)
+    // LAST1024: R = 1024, no output multiplier (last pass of a forward/inverse NTT).  R1024: R = 1024 with the generic
+    // tail (a column pass of a 2^20-point transform): the constant P2 folds the slot index arithmetic at compile time.
+    const int p2 = (LAST1024 || R1024) ? 5 : A.p2;
     const int P2 = 1 << p2;
     const int L = A.L;
 

@@ -552,7 +552,7 @@ Launch plan_row_pass(const u64* in, u64* out, long long in_bs, long long out_bs,
     return l;
 }
 
-template <bool INV, int SCALE, int MODE, bool LAST1024 = false>
+template <bool INV, int SCALE, int MODE, bool LAST1024 = false, bool R1024 = false>
 int launch_pass_t(const Launch& l, hipStream_t stream) {
     // one attribute call per (instantiation, device): the kernels use up to the full 160 KiB of dynamic LDS
     static std::atomic<unsigned long long> done_mask{0};
@@ -560,11 +560,11 @@ int launch_pass_t(const Launch& l, hipStream_t stream) {
     HIPCHK(hipGetDevice(&dev));
     const unsigned long long bit = 1ull << (dev & 63);
     if (!(done_mask.load(std::memory_order_acquire) & bit)) {
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&tfk::ntt_pass_kernel<INV, SCALE, MODE, LAST1024>),
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&tfk::ntt_pass_kernel<INV, SCALE, MODE, LAST1024, R1024>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         done_mask.fetch_or(bit, std::memory_order_release);
     }
-    hipLaunchKernelGGL((tfk::ntt_pass_kernel<INV, SCALE, MODE, LAST1024>), dim3(l.tiles), dim3(l.threads), l.lds_bytes, stream,
+    hipLaunchKernelGGL((tfk::ntt_pass_kernel<INV, SCALE, MODE, LAST1024, R1024>), dim3(l.tiles), dim3(l.threads), l.lds_bytes, stream,
                        l.a);
     HIPCHK(hipGetLastError());
     return TF_OK;
@@ -584,8 +584,14 @@ int launch_pass(const Launch& l, bool inverse, hipStream_t stream) {
     // last pass of a plain transform with R = 1024: specialised kernel (constant P2, stores fused with level 5)
     static const bool no_last1024 = getenv("TF_NTT_NO_LAST1024") != nullptr;  // A/B switch
     const bool last1024 = l.a.p2 == 5 && !l.a.post_tw && g_ablate == 0 && !no_last1024;
-    if (inverse) return last1024 ? launch_pass_t<true, 0, 0, true>(l, stream) : launch_pass_t<true, 0, 0>(l, stream);
+    static const bool no_r1024 = getenv("TF_NTT_NO_R1024") != nullptr;  // A/B switch
+    const bool r1024 = l.a.p2 == 5 && l.a.post_tw && g_ablate == 0 && !no_r1024;  // column pass with R = 1024
+    if (inverse) {
+        if (last1024) return launch_pass_t<true, 0, 0, true>(l, stream);
+        return r1024 ? launch_pass_t<true, 0, 0, false, true>(l, stream) : launch_pass_t<true, 0, 0>(l, stream);
+    }
     if (last1024) return launch_pass_t<false, 0, 0, true>(l, stream);
+    if (r1024) return launch_pass_t<false, 0, 0, false, true>(l, stream);
     if (g_ablate == 1) return launch_pass_t<false, 0, 1>(l, stream);
     if (g_ablate == 2) return launch_pass_t<false, 0, 2>(l, stream);
     if (g_ablate == 3) {
