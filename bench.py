@@ -172,7 +172,7 @@ def main():
             traffic = None
     roofline = {
         "bound": "hbm",
-        "kernel": "tfk::ntt_pass_kernel<false, 0, 0, false> (pass 1) and <false, 0, 0, true> (pass 2), one launch of each per step",
+        "kernel": "tfk::ntt_pass_kernel<false, 0, 0, false, true> (pass 1) and <false, 0, 0, true, false> (pass 2), one launch of each per step",
         "achieved": round(achieved, 1),
         "peak": HBM_PEAK_GBS,
         "unit": "GB/s",

@@ -400,3 +400,30 @@ def test_deeper_pass_plans_match_oracle(tf, oracle, passes, log_n, width, batch)
         assert np.array_equal(tf.fast_coset_interpolate(one, off, width=width), oracle.coset_interpolate(one, off, width=width))
     finally:
         lib.tf_set_ntt_min_passes(0)
+
+
+@pytest.mark.parametrize("length", [0, 1, 9, 10, 11, 25, 40])
+def test_sponge_absorb_squeeze_matches_oracle(tf, oracle, length):
+    """impl Sponge for Tip5 (tip5/mod.rs:677-699) + pad_and_absorb_all (sponge.rs:41-55), three sponges stepped together"""
+    batch = 3
+    data = oracle.fill_random(batch * max(length, 1), 700 + length).reshape(batch, -1)[:, :length]
+    sp = tf.Tip5Sponge.init(batch)
+    sp.pad_and_absorb_all(data)
+    for b in range(batch):
+        # the digest of hash_varlen is the first five words of the state after padding and absorbing (mod.rs:617-623)
+        assert np.array_equal(sp.state[b, :5], oracle.hash_varlen(data[b]))
+    # squeeze twice: rate part, then permutation (mod.rs:693-698)
+    want = sp.state.copy()
+    for _ in range(2):
+        got = sp.squeeze()
+        for b in range(batch):
+            assert np.array_equal(got[b], want[b, :10])
+            want[b] = oracle.tip5_permutation(want[b])
+        assert np.array_equal(sp.state, want)
+    # a further absorb overwrites the rate part only (mod.rs:684-691)
+    chunk = oracle.fill_random(batch * 10, 800 + length).reshape(batch, 10)
+    sp.absorb(chunk)
+    for b in range(batch):
+        assert np.array_equal(sp.state[b], oracle.absorb(want[b], chunk[b]))
+    fixed = tf.Tip5Sponge(1, fixed_length=True)
+    assert list(fixed.state[0]) == [0] * 10 + [0xFFFFFFFF] * 6  # Tip5::new(Domain::FixedLength), mod.rs:511-526

@@ -26,7 +26,7 @@ import numpy as np
 from . import _lib
 
 __all__ = [
-    "P", "BFieldElement", "ntt", "intt", "Polynomial", "fast_coset_evaluate", "fast_coset_interpolate", "fast_multiply", "fast_square", "Tip5", "Digest", "MerkleTree",
+    "P", "BFieldElement", "ntt", "intt", "Polynomial", "fast_coset_evaluate", "fast_coset_interpolate", "fast_multiply", "fast_square", "Tip5", "Tip5Sponge", "Digest", "MerkleTree",
     "MerkleTreeError", "TwentyFirstError", "NttPanic", "lib", "device",
 ]
 
@@ -82,6 +82,8 @@ class BFieldElement:
 
     P = P
     MAX = P - 1
+    ZERO_RAW = 0             # :691-693
+    ONE_RAW = 0xFFFFFFFF     # :707-709 (2^64 mod p)
 
     @staticmethod
     def new(value: int) -> int:
@@ -326,6 +328,52 @@ class Tip5:
         out = np.empty(5, dtype=np.uint64)
         _check(lib().tf_tip5_hash_varlen_rows(_ptr(a), a.size, 1, _ptr(out)), "Tip5::hash_varlen")
         return out
+
+
+class Tip5Sponge:
+    """`batch` independent Tip5 sponges stepped together (impl Sponge for Tip5, tip5/mod.rs:677-699; trait
+    util_types/sponge.rs:33-55).  The state lives in a (batch, 16) array of raw words; every absorb / squeeze is one
+    batched Tip5::permutation on the device."""
+
+    RATE = Tip5.RATE
+
+    def __init__(self, batch: int = 1, fixed_length: bool = False):
+        self.state = np.zeros((batch, Tip5.STATE_SIZE), dtype=np.uint64)  # Domain::VariableLength (tip5/mod.rs:511-526)
+        if fixed_length:
+            self.state[:, Tip5.RATE:] = BFieldElement.ONE_RAW
+
+    @classmethod
+    def init(cls, batch: int = 1) -> "Tip5Sponge":
+        return cls(batch)
+
+    def _permute(self) -> None:
+        flat = self.state.reshape(-1)
+        Tip5.permute_states(flat)
+
+    def absorb(self, inp) -> None:
+        """Overwrite-mode absorb of RATE elements per sponge (tip5/mod.rs:684-691)."""
+        a = np.ascontiguousarray(inp, dtype=np.uint64).reshape(self.state.shape[0], Tip5.RATE)
+        self.state[:, :Tip5.RATE] = a
+        self._permute()
+
+    def squeeze(self) -> np.ndarray:
+        """tip5/mod.rs:693-698: the rate part, then one permutation."""
+        out = self.state[:, :Tip5.RATE].copy()
+        self._permute()
+        return out
+
+    def pad_and_absorb_all(self, inp) -> None:
+        """util_types/sponge.rs:41-55: full chunks, then the remainder padded with 1, 0, 0, ...  (equal lengths per sponge)."""
+        b = self.state.shape[0]
+        a = np.ascontiguousarray(inp, dtype=np.uint64).reshape(b, -1)
+        full = a.shape[1] // Tip5.RATE
+        for c in range(full):
+            self.absorb(a[:, c * Tip5.RATE:(c + 1) * Tip5.RATE])
+        rem = a.shape[1] - full * Tip5.RATE
+        last = np.zeros((b, Tip5.RATE), dtype=np.uint64)
+        last[:, :rem] = a[:, full * Tip5.RATE:]
+        last[:, rem] = BFieldElement.ONE_RAW
+        self.absorb(last)
 
 
 # ----------------------------------------------------------------------------- Merkle tree

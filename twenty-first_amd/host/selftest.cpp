@@ -120,6 +120,52 @@ int main() {
         try { p.fast_coset_evaluate(BFieldElement::generator(), 4); } catch (const NttPanic&) { panicked = true; }
         EXPECT(panicked);
     }
+    {  // fast_coset_interpolate inverts fast_coset_evaluate (polynomial.rs:3646-3662), fast_multiply against the schoolbook product
+        auto c = bfe_vec({3, 1, 4, 1, 5, 9, 2, 6});
+        Polynomial<BFieldElement> p(c);
+        auto ev = p.fast_coset_evaluate(BFieldElement::generator(), 8);
+        EXPECT(Polynomial<BFieldElement>::fast_coset_interpolate(BFieldElement::generator(), ev).coefficients == c);
+        Polynomial<BFieldElement> a(bfe_vec({1, 2, 3})), b(bfe_vec({4, 5}));
+        EXPECT(a.fast_multiply(b).coefficients == bfe_vec({4, 13, 22, 15}));
+        EXPECT(a.fast_multiply(Polynomial<BFieldElement>({})).degree() == -1);
+        // batch_evaluate: 1 + 2x + 3x^2 at 0, 1, 2, 10
+        EXPECT(a.batch_evaluate(bfe_vec({0, 1, 2, 10})) == bfe_vec({1, 6, 17, 321}));
+    }
+    {  // batch_coset_extrapolate doc example, polynomial.rs:2183-2195: constant codewords extrapolate to the constant
+        const size_t n = 32;
+        std::vector<BFieldElement> codewords;
+        for (size_t i = 0; i < n; ++i) codewords.push_back(BFieldElement::new_(3));
+        for (size_t i = 0; i < n; ++i) codewords.push_back(BFieldElement::new_(2));
+        auto got = Polynomial<BFieldElement>::batch_coset_extrapolate(BFieldElement::new_(7), n, codewords, bfe_vec({0, 1}));
+        EXPECT(got == bfe_vec({3, 3, 2, 2}));
+        bool panicked = false;
+        try { Polynomial<BFieldElement>::batch_coset_extrapolate(BFieldElement::new_(7), 24, bfe_vec({1, 2, 3}), bfe_vec({0})); } catch (const NttPanic&) { panicked = true; }
+        EXPECT(panicked);
+    }
+    {  // Sponge: hash_varlen == init, pad_and_absorb_all, first five of the state (tip5/mod.rs:617-623); squeeze returns the rate part
+        auto input = bfe_vec({1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13});
+        Tip5 sp = Tip5::init();
+        sp.pad_and_absorb_all(input);
+        Digest d = Tip5::hash_varlen(input);
+        for (int i = 0; i < 5; ++i) EXPECT(sp.state[i] == d.values[i]);
+        Tip5 before = sp;
+        auto out = sp.squeeze();
+        for (size_t i = 0; i < Tip5::RATE; ++i) EXPECT(out[i] == before.state[i]);
+        before.permutation();
+        EXPECT(before.state == sp.state);
+    }
+    {  // authentication structure of a height-3 tree for leaves {0, 5}: nodes 13, 5 ... (merkle_tree.rs:449-504), and from_rows
+        std::vector<BFieldElement> rows;
+        for (uint64_t i = 0; i < 8 * 3; ++i) rows.push_back(BFieldElement::new_(i));
+        MerkleTree tree = MerkleTree::from_rows(rows, 3);
+        for (size_t i = 0; i < 8; ++i) EXPECT(*tree.leaf(i) == Tip5::hash_varlen(std::vector<BFieldElement>(rows.begin() + 3 * i, rows.begin() + 3 * i + 3)));
+        auto auth = tree.authentication_structure({0, 5});
+        // needed: siblings 9, 12 and uncles 5, 7 minus computable ones -> {12, 9, 7, 5} descending (merkle_tree.rs:493-503)
+        EXPECT(auth.size() == 4 && auth[0] == tree.nodes[12] && auth[1] == tree.nodes[9] && auth[2] == tree.nodes[7] && auth[3] == tree.nodes[5]);
+        bool bad = false;
+        try { tree.authentication_structure({8}); } catch (const BackendError& e) { bad = e.code == TF_ERR_LEAF_INDEX_INVALID; }
+        EXPECT(bad);
+    }
     if (failures) {
         fprintf(stderr, "%d failure(s)\n", failures);
         return 1;

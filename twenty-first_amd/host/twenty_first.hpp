@@ -129,6 +129,61 @@ struct Polynomial {
             check(tf_coset_eval_xfe(c, coefficients.size(), offset.raw, o, order, 1), "fast_coset_evaluate");
         return out;
     }
+    // fast_coset_interpolate (polynomial.rs:1907-1918): values on {offset * w^i} -> the interpolant; panics unless the
+    // number of values is a power of two
+    static Polynomial fast_coset_interpolate(BFieldElement offset, const std::vector<FF>& values) {
+        std::vector<FF> c(values.size());
+        const uint64_t* v = reinterpret_cast<const uint64_t*>(values.data());
+        uint64_t* o = reinterpret_cast<uint64_t*>(c.data());
+        if constexpr (sizeof(FF) == 8)
+            check(tf_coset_interpolate_bfe(v, values.size(), offset.raw, o, 1), "fast_coset_interpolate");
+        else
+            check(tf_coset_interpolate_xfe(v, values.size(), offset.raw, o, 1), "fast_coset_interpolate");
+        return Polynomial(std::move(c));
+    }
+    // fast_multiply (polynomial.rs:900-932), same field on both sides; the zero polynomial annihilates
+    Polynomial fast_multiply(const Polynomial& other) const {
+        if (degree() < 0 || other.degree() < 0) return Polynomial({});
+        std::vector<FF> out(coefficients.size() + other.coefficients.size() - 1);
+        const uint64_t* a = reinterpret_cast<const uint64_t*>(coefficients.data());
+        const uint64_t* b = reinterpret_cast<const uint64_t*>(other.coefficients.data());
+        uint64_t* o = reinterpret_cast<uint64_t*>(out.data());
+        if constexpr (sizeof(FF) == 8)
+            check(tf_poly_mul_bfe(a, coefficients.size(), b, other.coefficients.size(), o, 1), "fast_multiply");
+        else
+            check(tf_poly_mul_xfe(a, coefficients.size(), b, other.coefficients.size(), o, 1), "fast_multiply");
+        return Polynomial(std::move(out));
+    }
+    // batch_evaluate (polynomial.rs:1840-1852): f at every point of `domain`
+    std::vector<FF> batch_evaluate(const std::vector<FF>& domain) const {
+        std::vector<FF> out(domain.size());
+        const uint64_t* c = reinterpret_cast<const uint64_t*>(coefficients.data());
+        const uint64_t* d = reinterpret_cast<const uint64_t*>(domain.data());
+        uint64_t* o = reinterpret_cast<uint64_t*>(out.data());
+        if constexpr (sizeof(FF) == 8)
+            check(tf_poly_batch_evaluate_bfe(c, coefficients.size(), d, domain.size(), o), "batch_evaluate");
+        else
+            check(tf_poly_batch_evaluate_xfe(c, coefficients.size(), d, domain.size(), o), "batch_evaluate");
+        return out;
+    }
+    // batch_coset_extrapolate (polynomial.rs:2196-2208, par_ :2262): codeword-major values of every interpolant at
+    // every point; panics unless codeword_length is a power of two
+    static std::vector<FF> batch_coset_extrapolate(BFieldElement domain_offset, size_t codeword_length, const std::vector<FF>& codewords,
+                                                   const std::vector<FF>& points) {
+        const size_t batch = codeword_length ? codewords.size() / codeword_length : 0;
+        std::vector<FF> out(batch * points.size());
+        const uint64_t* c = reinterpret_cast<const uint64_t*>(codewords.data());
+        const uint64_t* p = reinterpret_cast<const uint64_t*>(points.data());
+        uint64_t* o = reinterpret_cast<uint64_t*>(out.data());
+        if constexpr (sizeof(FF) == 8)
+            check(tf_coset_extrapolate_bfe(domain_offset.raw, c, codeword_length, batch, p, points.size(), o), "batch_coset_extrapolate");
+        else
+            check(tf_coset_extrapolate_xfe(domain_offset.raw, c, codeword_length, batch, p, points.size(), o), "batch_coset_extrapolate");
+        return out;
+    }
+    static std::vector<FF> coset_extrapolate(BFieldElement domain_offset, const std::vector<FF>& codeword, const std::vector<FF>& points) {  // :2117-2128
+        return batch_coset_extrapolate(domain_offset, codeword.size(), codeword, points);
+    }
 };
 
 // ---- Tip5 (tip5/mod.rs) ---------------------------------------------------------------------------
@@ -150,6 +205,31 @@ struct Tip5 {
         Digest d;
         check(tf_tip5_hash_varlen_rows(reinterpret_cast<const uint64_t*>(in.data()), in.size(), 1, reinterpret_cast<uint64_t*>(d.values.data())), "Tip5::hash_varlen");
         return d;
+    }
+    // impl Sponge for Tip5 (:677-699) and Sponge::pad_and_absorb_all (util_types/sponge.rs:41-55)
+    static Tip5 init() { return Tip5{}; }  // Domain::VariableLength: the all-zero state
+    void absorb(const std::array<BFieldElement, RATE>& input) {
+        for (size_t i = 0; i < RATE; ++i) state[i] = input[i];
+        permutation();
+    }
+    std::array<BFieldElement, RATE> squeeze() {
+        std::array<BFieldElement, RATE> produce;
+        for (size_t i = 0; i < RATE; ++i) produce[i] = state[i];
+        permutation();
+        return produce;
+    }
+    void pad_and_absorb_all(const std::vector<BFieldElement>& input) {
+        size_t i = 0;
+        std::array<BFieldElement, RATE> chunk;
+        for (; i + RATE <= input.size(); i += RATE) {
+            for (size_t k = 0; k < RATE; ++k) chunk[k] = input[i + k];
+            absorb(chunk);
+        }
+        chunk.fill(BFieldElement{});
+        const size_t rem = input.size() - i;
+        for (size_t k = 0; k < rem; ++k) chunk[k] = input[i + k];
+        chunk[rem] = BFieldElement::from_raw_u64(0xffffffffULL);  // BFieldElement::ONE
+        absorb(chunk);
     }
     // batched forms -- the reason to cross the boundary at all
     static std::vector<Digest> hash_pairs(const std::vector<Digest>& pairs) {  // pairs.size() even: (l0, r0, l1, r1, ...)
@@ -177,6 +257,23 @@ struct MerkleTree {
     static Digest par_frugal_root(const std::vector<Digest>& leafs) {  // :332-364
         if (leafs.empty()) throw MerkleTreeError(TF_ERR_INCORRECT_NUMBER_OF_LEAFS, "MerkleTree::par_frugal_root");  // :333-335
         return sequential_frugal_root(leafs);
+    }
+    // hash_varlen of every row -> leaves -> tree in one device pipeline (the producer idiom of tip5/mod.rs:617-623)
+    static MerkleTree from_rows(const std::vector<BFieldElement>& rows, size_t row_len) {
+        const size_t n_rows = row_len ? rows.size() / row_len : 0;
+        MerkleTree t;
+        t.nodes.resize(2 * n_rows + (n_rows ? 0 : 1));
+        check(tf_merkle_from_rows(reinterpret_cast<const uint64_t*>(rows.data()), row_len, n_rows, reinterpret_cast<uint64_t*>(t.nodes.data()), 1), "MerkleTree::par_new");
+        return t;
+    }
+    // authentication_structure (:614-622) over authentication_structure_node_indices (:449-504)
+    std::vector<Digest> authentication_structure(const std::vector<size_t>& leaf_indices) const {
+        std::vector<uint64_t> li(leaf_indices.begin(), leaf_indices.end()), idx(leaf_indices.size() * 64 + 1);
+        size_t count = 0;
+        check(tf_merkle_auth_structure_indices(num_leafs(), li.data(), li.size(), idx.data(), idx.size(), &count), "MerkleTree::authentication_structure");
+        std::vector<Digest> out(count);
+        for (size_t i = 0; i < count; ++i) out[i] = nodes[idx[i]];
+        return out;
     }
     const Digest& root() const { return nodes[1]; }            // :624-626
     size_t num_leafs() const { return nodes.size() / 2; }       // :628-631
