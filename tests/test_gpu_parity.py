@@ -427,3 +427,26 @@ def test_sponge_absorb_squeeze_matches_oracle(tf, oracle, length):
         assert np.array_equal(sp.state[b], oracle.absorb(want[b], chunk[b]))
     fixed = tf.Tip5Sponge(1, fixed_length=True)
     assert list(fixed.state[0]) == [0] * 10 + [0xFFFFFFFF] * 6  # Tip5::new(Domain::FixedLength), mod.rs:511-526
+
+
+@pytest.mark.parametrize("count", [1, 15, 17, 32768, 32769, 40000])
+def test_tip5_both_kernel_shapes_match_oracle(tf, oracle, count):
+    """launches of <= 2^15 permutation chains run 16 lanes per permutation, larger ones one lane per permutation:
+    permutation, hash_pair and hash_varlen on both sides of the switch"""
+    states = oracle.fill_random(count * 16, 900 + count)
+    got = states.copy()
+    tf.Tip5.permute_states(got)
+    idx = sorted(set([0, min(1, count - 1), count // 2, count - 1]))
+    for i in idx:
+        assert np.array_equal(got[16 * i:16 * i + 16], oracle.tip5_permutation(states[16 * i:16 * i + 16]))
+    pairs = states[:count * 10]
+    assert np.array_equal(tf.Tip5.hash_pairs(pairs), oracle.hash_pairs(pairs))
+    for row_len in (0, 7, 13):
+        rows = states[:count * row_len]
+        assert np.array_equal(tf.Tip5.hash_varlen_rows(rows, row_len), oracle.hash_varlen_rows(rows, row_len))
+
+
+def test_hash_varlen_one_long_input(tf, oracle):
+    """a single long input is a sequential absorb chain (tip5/mod.rs:617-623): 16-lane path, 1000 permutations"""
+    data = oracle.fill_random(9999, 77)
+    assert np.array_equal(tf.Tip5.hash_varlen(data), oracle.hash_varlen(data))

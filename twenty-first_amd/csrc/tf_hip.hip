@@ -800,6 +800,10 @@ int coset_eval_dev(const u64* d_coeffs, size_t n_coeffs, u64 offset_raw, u64* d_
 }
 
 // ------------------------------------------------------------------------------------ Tip5 / Merkle
+// Launches of at most this many permutation chains use the 16-lanes-per-permutation kernels (measured crossover: one
+// permutation per lane costs ~19 us however few there are; 2^15 items x 16 lanes = 2 waves per SIMD)
+constexpr long long kCoopMaxCount = 1ll << 15;
+
 int tip5_permute_dev(u64* d_states, size_t count, void* stream) {
     if (count == 0) return TF_OK;
     if (!d_states) return TF_ERR_NULL_POINTER;
@@ -808,9 +812,14 @@ int tip5_permute_dev(u64* d_states, size_t count, void* stream) {
     if (rc) return rc;
     rc = ensure_tip5(ctx);
     if (rc) return rc;
-    const long long blocks = ((long long)count + 255) / 256;
-    hipLaunchKernelGGL(tfk::tip5_permute_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       d_states, (long long)count);
+    if ((long long)count <= kCoopMaxCount) {
+        hipLaunchKernelGGL(tfk::tip5_permute_coop_kernel, dim3((unsigned)((count + 15) / 16)), dim3(256), 0,
+                           static_cast<hipStream_t>(stream), d_states, (long long)count);
+    } else {
+        const long long blocks = ((long long)count + 255) / 256;
+        hipLaunchKernelGGL(tfk::tip5_permute_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                           d_states, (long long)count);
+    }
     HIPCHK(hipGetLastError());
     return TF_OK;
 }
@@ -818,9 +827,32 @@ int tip5_permute_dev(u64* d_states, size_t count, void* stream) {
 int launch_hash_pairs(const u64* in, u64* out, u64* leaf_copy, long long count, long long per_tree, long long in_ts,
                       long long out_ts, long long copy_ts, hipStream_t s) {
     if (count == 0) return TF_OK;
+    if (count <= kCoopMaxCount && !leaf_copy) {
+        // fewer permutations than the GPU has lanes: latency, not throughput, is what this launch costs -> 16 lanes each
+        const long long blocks = (count + 15) / 16;
+        hipLaunchKernelGGL(tfk::tip5_hash_pairs_coop_kernel, dim3((unsigned)blocks), dim3(256), 0, s, in, out, count, per_tree, in_ts,
+                           out_ts);
+        HIPCHK(hipGetLastError());
+        return TF_OK;
+    }
     const long long blocks = (count + 255) / 256;
     hipLaunchKernelGGL(tfk::tip5_hash_pairs_kernel, dim3((unsigned)blocks), dim3(256), 0, s, in, out, leaf_copy, count,
                        per_tree, in_ts, out_ts, copy_ts);
+    HIPCHK(hipGetLastError());
+    return TF_OK;
+}
+
+// hash_varlen of n_rows rows: few rows (or one long input) are latency-bound -> 16 lanes per row
+int launch_hash_varlen_rows(const u64* rows, long long row_len, long long n_rows, u64* out, long long per_tree, long long out_ts,
+                            hipStream_t s) {
+    if (n_rows == 0) return TF_OK;
+    if (n_rows <= kCoopMaxCount) {
+        hipLaunchKernelGGL(tfk::tip5_hash_varlen_rows_coop_kernel, dim3((unsigned)((n_rows + 15) / 16)), dim3(256), 0, s, rows, row_len,
+                           n_rows, out, per_tree, out_ts);
+    } else {
+        hipLaunchKernelGGL(tfk::tip5_hash_varlen_rows_kernel, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, s, rows, row_len,
+                           n_rows, out, per_tree, out_ts);
+    }
     HIPCHK(hipGetLastError());
     return TF_OK;
 }
@@ -845,12 +877,8 @@ int tip5_hash_varlen_rows_dev(const u64* d_rows, size_t row_len, size_t n_rows, 
     if (rc) return rc;
     rc = ensure_tip5(ctx);
     if (rc) return rc;
-    const long long blocks = ((long long)n_rows + 255) / 256;
-    hipLaunchKernelGGL(tfk::tip5_hash_varlen_rows_kernel, dim3((unsigned)blocks), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), d_rows, (long long)row_len, (long long)n_rows, d_out,
-                       (long long)n_rows, 0ll);
-    HIPCHK(hipGetLastError());
-    return TF_OK;
+    return launch_hash_varlen_rows(d_rows, (long long)row_len, (long long)n_rows, d_out, (long long)n_rows, 0ll,
+                                   static_cast<hipStream_t>(stream));
 }
 
 int check_leaves(size_t n) {
@@ -871,7 +899,7 @@ int merkle_levels_in_place(u64* d_nodes, long long N, size_t batch, hipStream_t 
         if (rc) return rc;
         w = nw;
     }
-    hipLaunchKernelGGL(tfk::merkle_top_kernel, dim3((unsigned)batch), dim3(256), 0, s, d_nodes + 5 * w, nodes_ts, (int)w,
+    hipLaunchKernelGGL(tfk::merkle_top_kernel, dim3((unsigned)batch), dim3(1024), 0, s, d_nodes + 5 * w, nodes_ts, (int)w,
                        d_nodes, nodes_ts, (u64*)nullptr, (const u64*)nullptr, 0ll);
     HIPCHK(hipGetLastError());
     return TF_OK;
@@ -891,10 +919,8 @@ int merkle_from_rows_dev(const u64* d_rows, size_t row_len, size_t n_rows, u64* 
     if (rc) return rc;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const long long N = (long long)n_rows, total = N * (long long)batch;
-    const long long blocks = (total + 255) / 256;
-    hipLaunchKernelGGL(tfk::tip5_hash_varlen_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, s, d_rows, (long long)row_len,
-                       total, d_nodes + 5 * N, N, 10 * N);
-    HIPCHK(hipGetLastError());
+    rc = launch_hash_varlen_rows(d_rows, (long long)row_len, total, d_nodes + 5 * N, N, 10 * N, s);
+    if (rc) return rc;
     return merkle_levels_in_place(d_nodes, N, batch, s);
 }
 
@@ -912,7 +938,7 @@ int merkle_build_dev(const u64* d_leaves, size_t n, u64* d_nodes, size_t batch, 
     hipStream_t s = static_cast<hipStream_t>(stream);
     const long long N = (long long)n, nodes_ts = 10 * N, leaves_ts = 5 * N;
     if (N <= kTopWidth) {
-        hipLaunchKernelGGL(tfk::merkle_top_kernel, dim3((unsigned)batch), dim3(256), 0, s, d_leaves, leaves_ts, (int)N,
+        hipLaunchKernelGGL(tfk::merkle_top_kernel, dim3((unsigned)batch), dim3(1024), 0, s, d_leaves, leaves_ts, (int)N,
                            d_nodes, nodes_ts, (u64*)nullptr, d_leaves, leaves_ts);
         HIPCHK(hipGetLastError());
         return TF_OK;
@@ -929,7 +955,7 @@ int merkle_build_dev(const u64* d_leaves, size_t n, u64* d_nodes, size_t batch, 
         if (rc) return rc;
         w = nw;
     }
-    hipLaunchKernelGGL(tfk::merkle_top_kernel, dim3((unsigned)batch), dim3(256), 0, s, d_nodes + 5 * w, nodes_ts, (int)w,
+    hipLaunchKernelGGL(tfk::merkle_top_kernel, dim3((unsigned)batch), dim3(1024), 0, s, d_nodes + 5 * w, nodes_ts, (int)w,
                        d_nodes, nodes_ts, (u64*)nullptr, (const u64*)nullptr, 0ll);
     HIPCHK(hipGetLastError());
     return TF_OK;
@@ -948,7 +974,7 @@ int merkle_root_dev(const u64* d_leaves, size_t n, u64* d_root, size_t batch, vo
     hipStream_t s = static_cast<hipStream_t>(stream);
     const long long N = (long long)n, leaves_ts = 5 * N;
     if (N <= kTopWidth) {
-        hipLaunchKernelGGL(tfk::merkle_top_kernel, dim3((unsigned)batch), dim3(256), 0, s, d_leaves, leaves_ts, (int)N,
+        hipLaunchKernelGGL(tfk::merkle_top_kernel, dim3((unsigned)batch), dim3(1024), 0, s, d_leaves, leaves_ts, (int)N,
                            (u64*)nullptr, 0ll, d_root, (const u64*)nullptr, 0ll);
         HIPCHK(hipGetLastError());
         return TF_OK;
@@ -972,7 +998,7 @@ int merkle_root_dev(const u64* d_leaves, size_t n, u64* d_root, size_t batch, vo
         w = nw;
     }
     if (rc == TF_OK) {
-        hipLaunchKernelGGL(tfk::merkle_top_kernel, dim3((unsigned)batch), dim3(256), 0, s, a, 5 * w, (int)w, (u64*)nullptr,
+        hipLaunchKernelGGL(tfk::merkle_top_kernel, dim3((unsigned)batch), dim3(1024), 0, s, a, 5 * w, (int)w, (u64*)nullptr,
                            0ll, d_root, (const u64*)nullptr, 0ll);
         hipError_t le = hipGetLastError();
         if (le != hipSuccess) rc = hip_fail(le, "merkle_top_kernel", __FILE__, __LINE__);

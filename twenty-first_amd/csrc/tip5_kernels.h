@@ -174,48 +174,147 @@ __global__ void __launch_bounds__(256) tip5_hash_varlen_rows_kernel(const u64* r
     for (int k = 0; k < 5; ++k) o[k] = s[k];
 }
 
+// ---- cooperative form: the 16 lanes of a DPP row hold the 16 state words of ONE permutation ------------------
+// The lane-per-permutation kernels above are throughput-optimal but one permutation is a dependent chain of ~8 200
+// instructions (~19 us), which is what every level of a Merkle tree with fewer nodes than the GPU has lanes costs.
+// Here lane j of a row owns state[j]: the S-box is one lookup or one x^7 per lane, and because the MDS matrix is
+// circulant, out[r] = sum_k M[k] * state[(r - k) mod 16] is 16 row rotations (v_mov_b32 row_ror:k) each followed by one
+// v_mad_u64_u32 with the same constant M[k] in every lane.  ~1 600 instructions per permutation (the lookup lanes and
+// the x^7 lanes take turns): 3x the total work of the lane-per-permutation form, 1/5 of its latency -- measured 4.6 us
+// per tree level instead of 19 us.  Used for launches of at most kCoopMaxCount permutation chains (tf_hip.hip).
+template <int K>
+__device__ __forceinline__ void mds_coop_terms(u32 lo, u32 hi, u64& alo, u64& ahi) {
+    if constexpr (K < 16) {
+        const u32 rl = (u32)__builtin_amdgcn_mov_dpp((int)lo, 0x120 + K, 0xf, 0xf, true);  // row_ror:K: lane r <- lane (r - K) mod 16
+        const u32 rh = (u32)__builtin_amdgcn_mov_dpp((int)hi, 0x120 + K, 0xf, 0xf, true);
+        alo += (u64)mds_entry(K) * rl;
+        ahi += (u64)mds_entry(K) * rh;
+        mds_coop_terms<K + 1>(lo, hi, alo, ahi);
+    }
+}
+
+// s = state[j] of the permutation shared by the 16 lanes of this row; all 16 lanes must be active.
+__device__ __forceinline__ void tip5_permutation_coop(u64& s, int j, const unsigned char* lut) {
+    u64 rcs[5];
+#pragma unroll
+    for (int r = 0; r < 5; ++r) rcs[r] = g_tip5.rc[r * 16 + j];
+#pragma unroll 1
+    for (int round = 0; round < 5; ++round) {
+        if (j < 4) {  // split_and_lookup (mod.rs:197-207)
+            const u32 l = lookup4((u32)s, lut), h = lookup4((u32)(s >> 32), lut);
+            s = ((u64)h << 32) | l;
+        } else {  // x^7
+            const u64 sq = gl::mont_mul(s, s);
+            const u64 qu = gl::mont_mul(sq, sq);
+            s = gl::mont_mul(s, gl::mont_mul(sq, qu));
+        }
+        const u32 lo = (u32)s, hi = (u32)(s >> 32);
+        u64 alo = (u64)mds_entry(0) * lo, ahi = (u64)mds_entry(0) * hi;
+        mds_coop_terms<1>(lo, hi, alo, ahi);
+        // same single-fold reduction as tip5_round
+        const u64 rc = rcs[round];
+        unsigned c0, c1, c2, c3, c4;
+        const u32 w1 = __builtin_addc((u32)(alo >> 32), (u32)ahi, 0u, &c0);
+        const u32 w2 = __builtin_addc((u32)(ahi >> 32), 0u, c0, &c1);
+        const u32 t0 = __builtin_addc((u32)alo, (u32)rc, 0u, &c2);
+        const u32 t1 = __builtin_addc(w1, (u32)(rc >> 32), c2, &c3);
+        const u32 t2 = __builtin_addc(w2, 0u, c3, &c4);
+        const u64 l64 = ((u64)t1 << 32) | t0;
+        const u64 t = (u64)t2 * 0xffffffffu + l64;
+        const bool ca = t < l64;
+        const u64 u = t + gl::EPS;
+        const bool cb = u < t;
+        s = (ca | cb) ? u : t;
+    }
+}
+
+// hash_pair per 16-lane row: item i = blockIdx.x * 16 + threadIdx.x / 16.  Same addressing as tip5_hash_pairs_kernel.
+__global__ void __launch_bounds__(256) tip5_hash_pairs_coop_kernel(const u64* in, u64* out, long long count, long long per_tree,
+                                                                   long long in_ts, long long out_ts) {
+    __shared__ __attribute__((aligned(16))) unsigned char lut[256];
+    stage_lut(lut);
+    const int j = threadIdx.x & 15;
+    const long long i = (long long)blockIdx.x * 16 + (threadIdx.x >> 4);
+    if (i >= count) return;  // whole rows leave together
+    const long long tree = i / per_tree, k = i - tree * per_tree;
+    u64 s = j < 10 ? in[tree * in_ts + 10 * k + j] : gl::ONE;
+    tip5_permutation_coop(s, j, lut);
+    if (j < 5) out[tree * out_ts + 5 * k + j] = s;
+}
+
+// hash_varlen of row i by the 16 lanes of row-group i (few rows, or one long input: the absorb chain is sequential)
+__global__ void __launch_bounds__(256) tip5_hash_varlen_rows_coop_kernel(const u64* rows, long long row_len, long long n_rows,
+                                                                         u64* out, long long per_tree, long long out_ts) {
+    __shared__ __attribute__((aligned(16))) unsigned char lut[256];
+    stage_lut(lut);
+    const int j = threadIdx.x & 15;
+    const long long i = (long long)blockIdx.x * 16 + (threadIdx.x >> 4);
+    if (i >= n_rows) return;
+    const u64* p = rows + i * row_len;
+    u64 s = 0;  // Domain::VariableLength
+    const long long full = row_len / 10;
+    for (long long c = 0; c < full; ++c) {
+        if (j < 10) s = p[c * 10 + j];  // overwrite-mode absorb, mod.rs:684-691
+        tip5_permutation_coop(s, j, lut);
+    }
+    const int rem = (int)(row_len - full * 10);
+    if (j < 10) s = (j < rem) ? p[full * 10 + j] : ((j == rem) ? gl::ONE : 0);
+    tip5_permutation_coop(s, j, lut);
+    const long long tree = i / per_tree;
+    if (j < 5) out[tree * out_ts + (i - tree * per_tree) * 5 + j] = s;
+}
+
+// Tip5::permutation of state i by row-group i
+__global__ void __launch_bounds__(256) tip5_permute_coop_kernel(u64* states, long long count) {
+    __shared__ __attribute__((aligned(16))) unsigned char lut[256];
+    stage_lut(lut);
+    const int j = threadIdx.x & 15;
+    const long long i = (long long)blockIdx.x * 16 + (threadIdx.x >> 4);
+    if (i >= count) return;
+    u64 s = states[i * 16 + j];
+    tip5_permutation_coop(s, j, lut);
+    states[i * 16 + j] = s;
+}
+
 // Top of a tree in one workgroup per tree: given level `width` (<= 256 nodes, i.e. nodes[width .. 2 width)),
 // compute nodes[1 .. width) level by level through LDS and write them out; also zero nodes[0]
 // (merkle_tree.rs:415-419).  Mirrors sequentially_fill_tree (:216-222) below the parallelisation cutoff.
 // level_in: pointer to the `width` digests of the starting level for tree 0, stride in_ts words per tree.
 // nodes: node array (may be null when only the root is wanted); root_out: 5 words per tree or null.
-__global__ void __launch_bounds__(256) merkle_top_kernel(const u64* level_in, long long in_ts, int width, u64* nodes,
-                                                         long long nodes_ts, u64* root_out, const u64* leaves_to_copy,
-                                                         long long leaves_ts) {
+__global__ void __launch_bounds__(1024) merkle_top_kernel(const u64* level_in, long long in_ts, int width, u64* nodes,
+                                                          long long nodes_ts, u64* root_out, const u64* leaves_to_copy,
+                                                          long long leaves_ts) {
     __shared__ __attribute__((aligned(16))) unsigned char lut[256];
-    __shared__ u64 cur[256 * 5];
+    __shared__ u64 buf[2][256 * 5];
     stage_lut(lut);
     const long long tree = blockIdx.x;
-    const int t = threadIdx.x;
+    const int t = threadIdx.x, j = t & 15, row = t >> 4;  // 64 rows of 16 lanes: one hash_pair per row at a time
     const u64* src = level_in + tree * in_ts;
     u64* nd = nodes ? nodes + tree * nodes_ts : nullptr;
     for (int k = t; k < width * 5; k += blockDim.x) {
         u64 v = src[k];
-        cur[k] = v;
+        buf[0][k] = v;
         if (leaves_to_copy && nd) nd[(long long)width * 5 + k] = v;  // starting level is the leaf level
     }
     if (nd && t < 5) nd[t] = 0;
     __syncthreads();
+    int cur = 0;
     for (int w = width / 2; w >= 1; w /= 2) {
-        u64 s[16];
-        if (t < w) {
-#pragma unroll
-            for (int k = 0; k < 10; ++k) s[k] = cur[10 * t + k];
-#pragma unroll
-            for (int k = 10; k < 16; ++k) s[k] = gl::ONE;
-            tip5_permutation(s, lut);
-        }
-        __syncthreads();
-        if (t < w) {
-#pragma unroll
-            for (int k = 0; k < 5; ++k) {
-                cur[5 * t + k] = s[k];
-                if (nd) nd[(long long)(w + t) * 5 + k] = s[k];
+        for (int base = 0; base < w; base += 64) {
+            const int i = base + row;
+            if (i < w) {  // whole rows take the branch together
+                u64 s = j < 10 ? buf[cur][10 * i + j] : gl::ONE;
+                tip5_permutation_coop(s, j, lut);
+                if (j < 5) {
+                    buf[cur ^ 1][5 * i + j] = s;
+                    if (nd) nd[(long long)(w + i) * 5 + j] = s;
+                }
             }
         }
         __syncthreads();
+        cur ^= 1;
     }
-    if (root_out && t < 5) root_out[tree * 5 + t] = cur[t];
+    if (root_out && t < 5) root_out[tree * 5 + t] = buf[cur][t];
 }
 
 }  // namespace tfk
