@@ -450,3 +450,79 @@ def test_hash_varlen_one_long_input(tf, oracle):
     """a single long input is a sequential absorb chain (tip5/mod.rs:617-623): 16-lane path, 1000 permutations"""
     data = oracle.fill_random(9999, 77)
     assert np.array_equal(tf.Tip5.hash_varlen(data), oracle.hash_varlen(data))
+
+
+def _dev_random(numel, seed):
+    """canonical raw words generated on the device (uniform below 2^62 < p): full-size property tests only"""
+    import torch
+
+    g = torch.Generator(device="cuda")
+    g.manual_seed(seed)
+    return torch.randint(0, 1 << 62, (numel,), dtype=torch.int64, device="cuda", generator=g)
+
+
+def test_config4_full_size_64_xfe_polys_roundtrip(tf, oracle):
+    """BASELINE config 4 at full size: 64 XFE polynomials x 2^22 coefficients on the coset 7 * <w>.  Properties over all
+    2^28 points: interpolation returns the coefficients; evaluation is linear (f + g); one polynomial is checked word
+    for word in test_config4_xfe_coset_eval_2pow22."""
+    import torch
+
+    n, batch = 1 << 22, 64
+    off = oracle.bfe_new(7)
+    c = _dev_random(3 * n * batch, 44)
+    ev = torch.empty_like(c)
+    tf.device.coset_evaluate(c, n, off, ev, n, batch=batch, width=3)
+    back = torch.empty_like(c)
+    tf.device.coset_interpolate(ev, n, off, back, batch=batch, width=3)
+    torch.cuda.synchronize()
+    assert torch.equal(back, c)
+    # linearity on the first two polynomials: eval(f) + eval(g) == eval(f + g), field addition done by the oracle on a sample
+    f, g = _to_host(c[:3 * 4096]), _to_host(c[3 * n:3 * n + 3 * 4096])
+    idx = np.arange(0, 3 * n, 3 * 4099)[:64]
+    h = _to_dev(np.array([oracle.bfe_add(int(a), int(b)) for a, b in zip(f, g)], dtype=np.uint64))
+    # low-degree pair: the first 4096 coefficients of f and g and their sum, evaluated on the full 2^22 coset
+    e = [torch.empty(3 * n, dtype=torch.int64, device="cuda") for _ in range(3)]
+    for src, dst in ((c[:3 * 4096], e[0]), (c[3 * n:3 * n + 3 * 4096], e[1]), (h, e[2])):
+        tf.device.coset_evaluate(src.contiguous(), 4096, off, dst, n, batch=1, width=3)
+    torch.cuda.synchronize()
+    ef, eg, eh = (_to_host(t) for t in e)
+    for i in idx:
+        assert int(eh[i]) == oracle.bfe_add(int(ef[i]), int(eg[i]))
+
+
+def test_config5_one_rank_of_eight(tf, oracle):
+    """BASELINE config 5 as rank 0 of 8 sees it (sharding.shard_range): 512 of the 4096 x 2^20 NTTs and 32 of the 256 trees
+    of 2^20 leaves.  Round trip over the whole shard; first and last transform and tree against the oracle."""
+    import torch
+    from twenty_first_amd import sharding
+
+    n = 1 << 20
+    lo, hi = sharding.shard_range(4096, 8, 0)
+    batch = hi - lo
+    assert batch == 512
+    d = _dev_random(n * batch, 55)
+    orig = d.clone()
+    tf.device.ntt_(d, n, batch=batch)
+    torch.cuda.synchronize()
+    for b in (0, batch - 1):
+        assert np.array_equal(_to_host(d[b * n:(b + 1) * n]), oracle.ntt(_to_host(orig[b * n:(b + 1) * n])))
+    tf.device.ntt_(d, n, batch=batch, inverse=True)
+    torch.cuda.synchronize()
+    assert torch.equal(d, orig)
+    del d, orig
+    tlo, thi = sharding.shard_range(256, 8, 0)
+    trees = thi - tlo
+    assert trees == 32
+    leaves = _dev_random(5 * n * trees, 56)
+    nodes = torch.empty(10 * n * trees, dtype=torch.int64, device="cuda")
+    roots = torch.empty(5 * trees, dtype=torch.int64, device="cuda")
+    tf.device.merkle_build(leaves, n, nodes, batch=trees)
+    tf.device.merkle_root(leaves, n, roots, batch=trees)
+    torch.cuda.synchronize()
+    threads = min(64, os.cpu_count() or 8)
+    for t in (0, trees - 1):
+        want = oracle.merkle_build(_to_host(leaves[5 * n * t:5 * n * (t + 1)]), threads=threads)
+        assert np.array_equal(_to_host(nodes[10 * n * t:10 * n * (t + 1)]), want)
+    got_roots = _to_host(roots).reshape(trees, 5)
+    all_nodes = nodes.view(trees, 2 * n, 5)
+    assert np.array_equal(got_roots, _to_host(all_nodes[:, 1, :].contiguous().view(-1)).reshape(trees, 5))  # frugal root == node 1
