@@ -83,10 +83,11 @@ def cpu_baseline_ntt(log_n, batch, sample_host_words):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--log-n", type=int, default=20)
     ap.add_argument("--batch", type=int, default=256, help="transforms per GPU")
+    ap.add_argument("--no-settle", action="store_true", help="skip the untimed stabilisation passes before the warmup")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the Merkle / coset-evaluation side measurements")
     args = ap.parse_args()
@@ -124,8 +125,22 @@ def main():
 
     launches_per_step = tf.lib().tf_ntt_launch_count(n, batch, 1)
 
-    # warmup (also builds the twiddle tables)
-    for _ in range(max(1, args.warmup)):
+    # settle: untimed passes until the step time is stable (twiddle tables built, scratch pool grown, clocks ramped --
+    # on a cold GPU the first ~10 passes run 4.2 -> 2.3 ms, tools/step_times.py), at most 40; then the W warmup steps
+    settle = 0
+    if not args.no_settle:
+        hist = []
+        while settle < 40:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            tf.device.ntt_(x, n, batch=batch)
+            e1.record()
+            torch.cuda.synchronize()
+            hist.append(e0.elapsed_time(e1))
+            settle += 1
+            if len(hist) >= 6 and max(hist[-5:]) <= 1.03 * min(hist[-5:]):
+                break
+    for _ in range(args.warmup):
         tf.device.ntt_(x, n, batch=batch)
     barrier()
 
@@ -134,18 +149,18 @@ def main():
     tf.device.ntt_(sample_gpu, n, batch=2)
     torch.cuda.synchronize()
 
-    ev0 = torch.cuda.Event(enable_timing=True)
-    ev1 = torch.cuda.Event(enable_timing=True)
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     barrier()
     t0 = time.perf_counter()
-    ev0.record()
-    for _ in range(args.steps):
+    evs[0].record()
+    for i in range(args.steps):
         tf.device.ntt_(x, n, batch=batch)
-    ev1.record()
+        evs[i + 1].record()
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     elapsed = t1 - t0
-    ev_ms = ev0.elapsed_time(ev1)
+    ev_ms = evs[0].elapsed_time(evs[-1])
+    step_ms = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps))
     barrier()
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -203,6 +218,8 @@ def main():
             "parallelism": f"batch-sharded x{world}, no data-path collective",
         },
         "roofline": roofline,
+        "step_ms": {"min": round(step_ms[0], 4), "median": round(step_ms[len(step_ms) // 2], 4), "max": round(step_ms[-1], 4)},
+        "settle_steps": settle,
     }
 
     if rank == 0:
