@@ -239,3 +239,25 @@ def test_coset_extrapolate_doc_example_and_panics(tf, oracle):
     coset = np.array([oracle.bfe_mul(oracle.bfe_new(7), oracle.bfe_mod_pow(omega, i)) for i in range(n)], dtype=np.uint64)
     c1 = oracle.fill_random(n, 41)
     assert np.array_equal(tf.Polynomial.coset_extrapolate(oracle.bfe_new(7), c1, coset), c1)
+
+
+@pytest.mark.parametrize("width", [1, 3])
+@pytest.mark.parametrize("n_coeffs,order,batch,force", [(1 << 11, 1 << 15, 3, 3), ((1 << 12) + 5, 1 << 16, 2, 3), (1500, 1 << 15, 1, 3),
+                                                        (1 << 14, 1 << 15, 2, 3), (1 << 16, 1 << 19, 2, 0), (1 << 18, 1 << 21, 1, 0),
+                                                        (1 << 20, 1 << 22, 1, 0), ((1 << 20) + 1, 1 << 22, 1, 0)])
+def test_blown_up_coset_evaluation(tf, oracle, width, n_coeffs, order, batch, force):
+    """fast_coset_evaluate with order >= 2 * degree (math/polynomial.rs:1374-1399).  When the padded coefficient length len
+    needs a global pass fewer than the order, the device evaluates order / len interleaved cosets of length len; the
+    small cases force that plan through tf_set_ntt_min_passes (three passes from 2^15).  Same words as the oracle's
+    zero-pad-and-transform either way."""
+    off = oracle.bfe_new(7)
+    c = oracle.fill_random(batch * n_coeffs * width, 1000 + n_coeffs % 97)
+    lib = tf._lib.lib()
+    lib.tf_set_ntt_min_passes(force)
+    try:
+        got = tf.fast_coset_evaluate(c, off, order, width=width, batch=batch)
+    finally:
+        lib.tf_set_ntt_min_passes(0)
+    for b in range(batch):
+        want = oracle.coset_evaluate(c[b * n_coeffs * width:(b + 1) * n_coeffs * width], off, order, width=width)
+        assert np.array_equal(got[b * order * width:(b + 1) * order * width], want)

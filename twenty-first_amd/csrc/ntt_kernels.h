@@ -40,6 +40,7 @@ struct NttPassArgs {
     const u64* post_scale; // interpolation powers offset^-j applied to output element j, or null (polynomial.rs:1907-1918)
     long long js_i0, js_i1, js_i2, js_c, js_k;  // output element index j = i0*js_i0 + i1*js_i1 + i2*js_i2 + (c/L)*js_c + k*js_k (last pass only)
     long long n_coeffs;    // elements present per input polynomial; rows beyond are zero (polynomial.rs:1395); <0: no padding
+    long long ps_i1;                         // pre_scale index offset per outer index i1 (blown-up coset evaluation: table c)
     long long ib0, ib1, ib2, ob0, ob1, ob2;  // tile base strides (words)
     long long in_cs_hi, out_cs_hi;           // column c -> (c / L) * cs_hi + (c % L)
     long long in_rs, out_rs;                 // row strides (words)
@@ -235,7 +236,7 @@ __global__ void __launch_bounds__(512, TF_NTT_WAVES) ntt_pass_kernel(const NttPa
             const u64* ptr = reinterpret_cast<const u64*>(base + ur * A.in_rs * 8 + toff);
             if constexpr (SCALE == 1) {
                 const long long j = (ur + g) * A.ps_rs + (A.ps_col ? bcol : 0);
-                if (j < A.n_coeffs) x[q] = gl::mont_mul(*ptr, A.pre_scale[j]);
+                if (j < A.n_coeffs) x[q] = gl::mont_mul(*ptr, A.pre_scale[j + (long long)i1 * A.ps_i1]);
             } else {
 #ifdef TF_NT
                 x[q] = __builtin_nontemporal_load(ptr);
