@@ -689,10 +689,36 @@ int run_ntt(DeviceCtx* ctx, const u64* in, u64* out, long long in_bs, long long 
     int a[4] = {0, 0, 0, 0};
     const int P = pass_count(log_n);
     {
-        int rest = log_n;
-        for (int i = 0; i < P; ++i) {
-            a[i] = (rest + (P - i) - 1) / (P - i);  // as even as possible, larger radices first (31 -> 8, 8, 8, 7)
-            rest -= a[i];
+        // The last pass gets the largest radix it can (R = 1024 whenever possible: the specialised kernel with constant P2
+        // and stores fused into level 5, 128-byte output segments); the column passes share the rest evenly, larger first.
+        // Measured against the even split (tools/split3.py, 2^28 words per call): 2^15 1.92 vs 2.62 ms, 2^18 2.20 vs 2.48,
+        // 2^22 3.18 vs 3.49, 2^24 3.31 vs 4.15, 2^26 3.58 vs 3.99.
+        // XFieldElement slices (L = 3) are the exception: a last pass with R = 1024 has only 5 rows (15 word-columns) per
+        // workgroup, and the sweep prefers R = 32 (170 rows per tile) for the smaller lengths and R = 512 above.
+        int last = std::min(10, log_n - 5 * (P - 1));
+        if (L == 3 && P == 2 && log_n < 20) last = log_n <= 15 ? 5 : 9;
+        if (L == 3 && P == 3 && log_n < 30) last = log_n <= 25 ? 5 : 9;
+        a[P - 1] = last;
+        int rest = log_n - last;
+        if (L == 3 && P == 3 && log_n <= 25) {  // (log_n - 15, 10, 5)
+            a[1] = std::min(10, rest - 5);
+            a[0] = rest - a[1];
+        } else {
+            for (int i = 0; i + 1 < P; ++i) {
+                a[i] = (rest + (P - 1 - i) - 1) / (P - 1 - i);
+                rest -= a[i];
+            }
+        }
+        if (const char* e2 = getenv("TF_NTT_SPLIT2")) {  // experiment: a0 for two-pass plans
+            const int x0 = atoi(e2);
+            if (P == 2 && x0 >= 5 && x0 <= 10 && log_n - x0 >= 5 && log_n - x0 <= 10) a[0] = x0, a[1] = log_n - x0;
+        }
+        if (const char* e = getenv("TF_NTT_SPLIT3")) {  // experiment: "a0,a1" for three-pass plans
+            int x0 = 0, x1 = 0;
+            if (P == 3 && sscanf(e, "%d,%d", &x0, &x1) == 2 && x0 >= 5 && x0 <= 10 && x1 >= 5 && x1 <= 10 && log_n - x0 - x1 >= 5 &&
+                log_n - x0 - x1 <= 10) {
+                a[0] = x0, a[1] = x1, a[2] = log_n - x0 - x1;
+            }
         }
     }
     const u64* inner[4] = {nullptr, nullptr, nullptr, nullptr};
