@@ -206,11 +206,22 @@ __global__ void __launch_bounds__(512, TF_NTT_WAVES) ntt_pass_kernel(const NttPa
     const int col0 = (int)i2 * A.nc;
     const int ncv = min(A.nc, A.col_limit - col0);
 
-    const int g = A.nc == 1 ? t : (int)__umulhi((u32)t, A.nc_magic);  // t / nc
-    const int c = t - g * A.nc;                        // t % nc
+    // LAST1024 always runs 512 threads in 16 column slots (slot 15 idles for XFE tiles of 15 word-columns)
+    const int g = LAST1024 ? (t >> 4) : (A.nc == 1 ? t : (int)__umulhi((u32)t, A.nc_magic));  // t / nc
+    const int c = LAST1024 ? (t & 15) : (t - g * A.nc);                                          // t % nc
     const bool act = c < ncv;
     const int ch = (int)div_by_L((u32)c, L), cl = c - ch * L;
     const long long bcol = (long long)div_by_L((u32)(col0 + c), L);
+    // LAST1024 reads rows of 1024 contiguous elements and writes 16 adjacent columns: the two sides want different
+    // lane orders, and the LDS exchange between them lets each have its own.  Loads and step 1 run with the lanes along the
+    // row: a wave reads 2 columns x 32 consecutive elements (four 128-byte lines) instead of 16 pieces of 32 bytes
+    // (measured -2.4 % on the 256 x 2^20 workload); the exchange hands the data to the column-major roles (g, c) for
+    // step 2.  Thread bit 3 selects the exchange round (column half) in BOTH roles, so a thread still writes its 32 old
+    // values and reads its 32 new ones in the same round: g_in = bits {0,1,2,4,5}, c_in = bits {6,7,8} + 8 * bit 3.
+    const int g_in = LAST1024 ? ((t & 7) | ((t >> 1) & 0x18)) : g;
+    const int c_in = LAST1024 ? (((t >> 6) & 7) | (t & 8)) : c;
+    const bool act_in = LAST1024 ? (c_in < ncv) : act;
+    const int ch_in = LAST1024 ? (int)div_by_L((u32)c_in, L) : ch, cl_in = LAST1024 ? (c_in - ch_in * L) : cl;
 
     // Addressing: every global access is  uniform 64-bit base (SGPRs, one per register slot q)  +  32-bit
     // per-thread offset (one VGPR for all 32 slots), so the load and store bursts cost (almost) no vector ALU
@@ -227,8 +238,8 @@ __global__ void __launch_bounds__(512, TF_NTT_WAVES) ntt_pass_kernel(const NttPa
     if constexpr (MODE == 1) {
 #pragma unroll
         for (int q = 0; q < 32; ++q) x[q] = (u64)(t * 32 + q) * 0x9e3779b97f4a7c15ULL >> 1;
-    } else if (act) {
-        const u32 toff = (u32)(((long long)ch * A.in_cs_hi + cl + (long long)g * A.in_rs) * 8);
+    } else if (act_in) {
+        const u32 toff = (u32)(((long long)ch_in * A.in_cs_hi + cl_in + (long long)g_in * A.in_rs) * 8);
         const char* base = reinterpret_cast<const char*>(in);
 #pragma unroll
         for (int q = 0; q < 32; ++q) {
@@ -262,7 +273,7 @@ __global__ void __launch_bounds__(512, TF_NTT_WAVES) ntt_pass_kernel(const NttPa
         dit_half<INV, 16>(x);
         dit_level<INV, 5>(x);
         if (A.inner_tw) {
-            const u64* tw = A.inner_tw + g * 32;
+            const u64* tw = A.inner_tw + g_in * 32;
 #pragma unroll
             for (int q = 0; q < 32; q += 2) gl::mont_mul2(x[q], tw[q], x[q + 1], tw[q + 1], x[q], x[q + 1]);
         }
@@ -271,7 +282,31 @@ __global__ void __launch_bounds__(512, TF_NTT_WAVES) ntt_pass_kernel(const NttPa
     // ------------------------------------------------------------------ LDS exchange, `nrounds` rounds of `cpr` columns
     // Element (k1, g) of a column goes from the thread that owns row group g to the thread that owns k1 mod P2.
     // A thread writes its 32 values and reads its 32 new values in the SAME round, so only 32 are ever live.
-    {
+    if constexpr (LAST1024) {
+        // Writers are in the row-major roles (g_in, c_in), readers in the column-major roles (g, c); 8 columns per round.
+        // Element (k1, g, cc) lives at k1 * 289 + cc * 36 + g: the 16 lanes of a writing half-wave that are active in a
+        // round (16 consecutive g, one column) cover 16 consecutive words; the 16 active lanes of a reading half-wave
+        // (8 columns x two consecutive k1, same g) fall on 16 different 8-byte bank pairs because 36 = 4 and 289 = 1
+        // (mod 32).  All 64 offsets are immediates on both sides.  (kLast1024LdsBytes in tf_hip.hip sizes the buffer.)
+        constexpr int S1 = 289, CS = 36;
+        const int wround = c_in >> 3, wcc = c_in & 7, rround = c >> 3, rcc = c & 7;
+        u64* wr = lds + wcc * CS + g_in;
+        const u64* rd = lds + g * S1 + rcc * CS;
+        const int nr = (A.nc + 7) >> 3;
+#pragma unroll 1
+        for (int r = 0; r < nr; ++r) {
+            if (r) __syncthreads();
+            if (wround == r) {
+#pragma unroll
+                for (int q = 0; q < 32; ++q) wr[q * S1] = x[q];
+            }
+            __syncthreads();
+            if (rround == r) {
+#pragma unroll
+                for (int q = 0; q < 32; ++q) x[q] = rd[brev5(q)];
+            }
+        }
+    } else {
         const int myround = c / A.cpr;
         const int cc = c - myround * A.cpr;
         u64* wr = lds + g * A.s2 + cc;

@@ -587,6 +587,8 @@ int launch_pass_t(const Launch& l, hipStream_t stream) {
 unsigned long long* g_dbg_buf = nullptr;  // TF_NTT_ABLATE=3: per-wave phase stamps of the last launch (tf_debug_stamps)
 int g_ablate = -1;  // measurement only (TF_NTT_ABLATE=1|2 selects an ablated forward kernel; results are then garbage)
 
+constexpr size_t kLast1024LdsBytes = size_t(32) * 289 * sizeof(u64);
+
 int launch_pass(const Launch& l, bool inverse, hipStream_t stream) {
     if (l.tiles == 0) return TF_OK;
     if (g_ablate < 0) {
@@ -600,6 +602,12 @@ int launch_pass(const Launch& l, bool inverse, hipStream_t stream) {
     const bool last1024 = l.a.p2 == 5 && !l.a.post_tw && g_ablate == 0 && !no_last1024;
     static const bool no_r1024 = getenv("TF_NTT_NO_R1024") != nullptr;  // A/B switch
     const bool r1024 = l.a.p2 == 5 && l.a.post_tw && g_ablate == 0 && !no_r1024;  // column pass with R = 1024
+    if (last1024) {  // this instantiation lays its exchange buffer out itself (32 x 289 words, ntt_kernels.h)
+        Launch l2 = l;
+        l2.lds_bytes = std::max(l.lds_bytes, kLast1024LdsBytes);
+        l2.threads = 512;  // 16 column slots x 32, also for tiles of 15 word-columns (XFE)
+        return inverse ? launch_pass_t<true, 0, 0, true>(l2, stream) : launch_pass_t<false, 0, 0, true>(l2, stream);
+    }
     if (inverse) {
         if (last1024) return launch_pass_t<true, 0, 0, true>(l, stream);
         return r1024 ? launch_pass_t<true, 0, 0, false, true>(l, stream) : launch_pass_t<true, 0, 0>(l, stream);
