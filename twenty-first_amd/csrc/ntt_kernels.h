@@ -306,7 +306,7 @@ __global__ void __launch_bounds__(512, TF_NTT_WAVES) ntt_pass_kernel(const NttPa
                 for (int q = 0; q < 32; ++q) x[q] = rd[brev5(q)];
             }
         }
-    } else {
+    } else if (p2 != 0) {  // R = 32: step 1 is the whole transform and every element stays with its thread
         const int myround = c / A.cpr;
         const int cc = c - myround * A.cpr;
         u64* wr = lds + g * A.s2 + cc;
