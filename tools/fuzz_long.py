@@ -1,0 +1,83 @@
+#!/usr/bin/env python3
+"""One-off extended randomised parity run (the pytest fuzz tests are the short form): every entry point against the oracle."""
+import os, random, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import twenty_first_amd as tf
+from oracle import tfo as oracle
+P = 0xFFFFFFFF00000001
+seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+budget = float(sys.argv[2]) if len(sys.argv) > 2 else 150.0
+rng = random.Random(seed)
+counts = {}
+t_end = time.time() + budget
+def bump(k): counts[k] = counts.get(k, 0) + 1
+while time.time() < t_end:
+    kind = rng.choice(["ntt", "ntt", "coset", "coset", "interp", "mul", "merkle", "varlen", "eval", "extrap"])
+    width = rng.choice([1, 3])
+    if kind == "ntt":
+        log_n = rng.randint(0, 23)
+        n = 1 << log_n
+        batch = rng.randint(1, max(1, min(67, (1 << 23) // (n * width))))
+        inverse = rng.random() < 0.5
+        x = oracle.fill_random(n * width * batch, rng.getrandbits(40))
+        got = x.copy(); tf.ntt(got, width=width, batch=batch, _inverse=inverse)
+        assert np.array_equal(got, oracle.ntt(x, width=width, inverse=inverse, batch=batch, threads=16)), (kind, log_n, width, batch, inverse)
+    elif kind == "coset":
+        log_order = rng.randint(0, 22)
+        order = 1 << log_order
+        n_coeffs = rng.choice([rng.randint(0, order), order >> rng.randint(0, 4), (order >> rng.randint(1, 3)) + rng.randint(0, 3)])
+        n_coeffs = min(order, max(0, n_coeffs))
+        batch = rng.randint(1, 3) if order * width <= (1 << 21) else 1
+        off = oracle.bfe_new(rng.randrange(1, P))
+        c = oracle.fill_random(n_coeffs * width * batch, rng.getrandbits(40))
+        got = tf.fast_coset_evaluate(c, off, order, width=width, batch=batch)
+        for b in range(batch):
+            want = oracle.coset_evaluate(c[b * n_coeffs * width:(b + 1) * n_coeffs * width], off, order, width=width)
+            assert np.array_equal(got[b * order * width:(b + 1) * order * width], want), (kind, order, n_coeffs, width, batch, b)
+    elif kind == "interp":
+        log_n = rng.randint(0, 21)
+        n = 1 << log_n
+        off = oracle.bfe_new(rng.randrange(1, P))
+        v = oracle.fill_random(n * width, rng.getrandbits(40))
+        assert np.array_equal(tf.fast_coset_interpolate(v, off, width=width), oracle.coset_interpolate(v, off, width=width)), (kind, log_n, width)
+    elif kind == "mul":
+        na, nb = rng.randint(1, 3000), rng.randint(1, 3000)
+        a = oracle.fill_random(na * width, rng.getrandbits(40)); b = oracle.fill_random(nb * width, rng.getrandbits(40))
+        got = tf.fast_multiply(a, b, width=width)
+        assert np.array_equal(got, oracle.poly_mul(a, b, width=width)), (kind, na, nb, width)
+    elif kind == "merkle":
+        h = rng.randint(0, 18)
+        n = 1 << h
+        batch = rng.randint(1, 3) if h < 15 else 1
+        leaves = oracle.fill_random(5 * n * batch, rng.getrandbits(40))
+        got = tf.MerkleTree.build_batch(leaves, n)
+        for b in range(batch):
+            assert np.array_equal(got[b].reshape(-1), oracle.merkle_build(leaves[5 * n * b:5 * n * (b + 1)], threads=16)), (kind, h, batch)
+    elif kind == "varlen":
+        row_len, n_rows = rng.randint(0, 120), rng.choice([1, 2, 17, 500, 40000])
+        rows = oracle.fill_random(max(1, n_rows * row_len), rng.getrandbits(40))[: n_rows * row_len]
+        if row_len:
+            assert np.array_equal(tf.Tip5.hash_varlen_rows(rows, row_len), oracle.hash_varlen_rows(rows, row_len)), (kind, row_len, n_rows)
+    elif kind == "eval":
+        nc, m = rng.choice([0, 1, 5, 700, 1024, 5000]), rng.randint(1, 200)
+        c = oracle.fill_random(max(1, nc) * width, rng.getrandbits(40))[: nc * width]
+        pts = oracle.fill_random(m * width, rng.getrandbits(40))
+        poly = tf.Polynomial(c, width=width)
+        if poly.degree() >= 0:
+            got = poly.batch_evaluate(pts).reshape(m, width)
+            i = rng.randrange(m)
+            want = oracle.poly_eval(poly.coefficients, int(pts[i]))[:1] if width == 1 else oracle.poly_eval_xfe_point(poly.coefficients, pts[3 * i:3 * i + 3])
+            assert np.array_equal(got[i], want), (kind, nc, m, width)
+    elif kind == "extrap":
+        log_n, m, batch = rng.randint(0, 14), rng.randint(1, 20), rng.randint(1, 3)
+        n = 1 << log_n
+        off = oracle.bfe_new(rng.randrange(1, P))
+        cw = oracle.fill_random(batch * n * width, rng.getrandbits(40)); pts = oracle.fill_random(m * width, rng.getrandbits(40))
+        got = tf.Polynomial.batch_coset_extrapolate(off, n, cw, pts, width=width).reshape(batch, m, width)
+        b, i = rng.randrange(batch), rng.randrange(m)
+        co = oracle.coset_interpolate(cw[b * n * width:(b + 1) * n * width], off, width=width)
+        want = oracle.poly_eval(co, int(pts[i]))[:1] if width == 1 else oracle.poly_eval_xfe_point(co, pts[3 * i:3 * i + 3])
+        assert np.array_equal(got[b, i], want), (kind, log_n, m, batch, width)
+    bump(kind)
+print(f"seed {seed}: all matched the oracle: " + ", ".join(f"{k} {v}" for k, v in sorted(counts.items())), flush=True)
