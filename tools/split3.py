@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Sweep the radix split (a0, a1, a2) of three-pass transforms (TF_NTT_SPLIT3 experiment switch): median of 5 timings each."""
 import os, sys, statistics
+os.environ["TF_NTT_EXPERIMENT"] = "1"  # enables the TF_NTT_SPLIT2 / TF_NTT_SPLIT3 planner switches
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import twenty_first_amd as tf

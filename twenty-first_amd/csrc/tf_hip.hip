@@ -386,6 +386,7 @@ struct Launch {
     unsigned tiles;
     unsigned threads;
     size_t lds_bytes;
+    bool bad_geometry = false;  // planner self-check failed: launch_pass refuses the launch
 };
 
 int pad_to_residue(int base, int residue) {  // smallest s >= base with s == residue (mod 32)
@@ -429,7 +430,7 @@ void finish_geometry(Launch* l, int nc, int p2) {
     A.nc_magic = nc > 1 ? (u32)((u64(1) << 32) / (u64)nc + 1) : 0;  // umulhi(t, magic) == t / nc (nc == 1: kernel uses t)
     for (u32 t = 0; t < l->threads; ++t) {
         const u32 q = (u32)(((u64)t * A.nc_magic) >> 32);
-        if (nc != 1 && q != t / (u32)nc) abort();  // unreachable: exactness proven for the ranges used
+        if (nc != 1 && q != t / (u32)nc) l->bad_geometry = true;  // never observed: the magic is exact for t < 1024, nc <= 1024
     }
 }
 
@@ -591,6 +592,10 @@ constexpr size_t kLast1024LdsBytes = size_t(32) * 289 * sizeof(u64);
 
 int launch_pass(const Launch& l, bool inverse, hipStream_t stream) {
     if (l.tiles == 0) return TF_OK;
+    if (l.bad_geometry) {
+        t_last_error = "NTT planner self-check failed (thread-to-column division is not exact for this geometry)";
+        return TF_ERR_HIP;
+    }
     if (g_ablate < 0) {
         const char* e = getenv("TF_NTT_ABLATE");
         g_ablate = e ? atoi(e) : 0;
@@ -631,6 +636,13 @@ int check_len(size_t n) {
 }
 
 std::atomic<int> g_min_passes{0};  // tf_set_ntt_min_passes
+
+// Experiment switches for tools/split3.py: looked up on every call only when TF_NTT_EXPERIMENT is set at load time
+// (the sweep tool changes them while the process runs); otherwise the planner never touches the environment.
+const char* exp_env(const char* name) {
+    static const bool enabled = getenv("TF_NTT_EXPERIMENT") != nullptr;
+    return enabled ? getenv(name) : nullptr;
+}
 
 int pass_count(int log_n) {  // global passes of a transform with log_n > 10
     int P = log_n <= 20 ? 2 : (log_n <= 30 ? 3 : 4);
@@ -717,11 +729,11 @@ int run_ntt(DeviceCtx* ctx, const u64* in, u64* out, long long in_bs, long long 
                 rest -= a[i];
             }
         }
-        if (const char* e2 = getenv("TF_NTT_SPLIT2")) {  // experiment: a0 for two-pass plans
+        if (const char* e2 = exp_env("TF_NTT_SPLIT2")) {  // experiment: a0 for two-pass plans
             const int x0 = atoi(e2);
             if (P == 2 && x0 >= 5 && x0 <= 10 && log_n - x0 >= 5 && log_n - x0 <= 10) a[0] = x0, a[1] = log_n - x0;
         }
-        if (const char* e = getenv("TF_NTT_SPLIT3")) {  // experiment: "a0,a1" for three-pass plans
+        if (const char* e = exp_env("TF_NTT_SPLIT3")) {  // experiment: "a0,a1" for three-pass plans
             int x0 = 0, x1 = 0;
             if (P == 3 && sscanf(e, "%d,%d", &x0, &x1) == 2 && x0 >= 5 && x0 <= 10 && x1 >= 5 && x1 <= 10 && log_n - x0 - x1 >= 5 &&
                 log_n - x0 - x1 <= 10) {
