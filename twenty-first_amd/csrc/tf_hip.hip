@@ -714,13 +714,13 @@ int run_ntt(DeviceCtx* ctx, const u64* in, u64* out, long long in_bs, long long 
         // Measured against the even split (tools/split3.py, 2^28 words per call): 2^15 1.92 vs 2.62 ms, 2^18 2.20 vs 2.48,
         // 2^22 3.18 vs 3.49, 2^24 3.31 vs 4.15, 2^26 3.58 vs 3.99.
         // XFieldElement slices (L = 3) are the exception: a last pass with R = 1024 has only 5 rows (15 word-columns) per
-        // workgroup, and the sweep prefers R = 32 (170 rows per tile) for the smaller lengths and R = 512 above.
+        // workgroup, and the sweep prefers R = 32 (170 rows per tile) for the smaller lengths (n <= 2^15, 2^21 and 2^22) and R = 512 above.
         int last = std::min(10, log_n - 5 * (P - 1));
         if (L == 3 && P == 2 && log_n < 20) last = log_n <= 15 ? 5 : 9;
-        if (L == 3 && P == 3 && log_n < 30) last = log_n <= 25 ? 5 : 9;
+        if (L == 3 && P == 3 && log_n < 30) last = log_n <= 22 ? 5 : 9;
         a[P - 1] = last;
         int rest = log_n - last;
-        if (L == 3 && P == 3 && log_n <= 25) {  // (log_n - 15, 10, 5)
+        if (L == 3 && P == 3 && log_n <= 22) {  // (log_n - 15, 10, 5)
             a[1] = std::min(10, rest - 5);
             a[0] = rest - a[1];
         } else {
