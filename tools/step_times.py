@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-step durations of the bench workload (256 x 2^20 forward NTT), to see whether a slow run is uniformly slow or has outliers."""
-import os, sys, time
+import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import twenty_first_amd as tf
