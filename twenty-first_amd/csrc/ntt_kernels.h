@@ -54,7 +54,8 @@ struct NttPassArgs {
     int col_limit;                           // valid columns along i2: min(nc, col_limit - i2 * nc)
     int ps_col;
     int cpr, nrounds;                        // LDS exchange in `nrounds` rounds of `cpr` columns (bounds the LDS footprint)
-    int s1, s2;                              // LDS strides in u64: idx = k1*s1 + g*s2 + (c % cpr)
+    int s1, s2, s3;                          // LDS strides in u64: idx = k1*s1 + g*s2 + (c % cpr)*s3
+    int gfast;                               // 1: thread t is (g = t % P2, column t / P2) instead of (t / nc, t % nc)
     int xcd_order;                           // G > 0: XCD-aware tile order in groups of G adjacent column tiles (0: natural order)
     u32 nc_magic;                            // t / nc == umulhi(t, nc_magic) for every t < blockDim (checked by the planner)
     unsigned long long* dbg;                 // MODE 3 only: per-wave cycle stamps (6 per wave)
@@ -207,8 +208,9 @@ __global__ void __launch_bounds__(512, TF_NTT_WAVES) ntt_pass_kernel(const NttPa
     const int ncv = min(A.nc, A.col_limit - col0);
 
     // LAST1024 always runs 512 threads in 16 column slots (slot 15 idles for XFE tiles of 15 word-columns)
-    const int g = LAST1024 ? (t >> 4) : (A.nc == 1 ? t : (int)__umulhi((u32)t, A.nc_magic));  // t / nc
-    const int c = LAST1024 ? (t & 15) : (t - g * A.nc);                                          // t % nc
+    // gfast (single-pass transforms, whose "columns" are whole rows of contiguous elements): lanes along the row, g = t % P2
+    const int g = LAST1024 ? (t >> 4) : (A.gfast ? (t & (P2 - 1)) : (A.nc == 1 ? t : (int)__umulhi((u32)t, A.nc_magic)));  // t / nc
+    const int c = LAST1024 ? (t & 15) : (A.gfast ? (t >> p2) : (t - g * A.nc));                                              // t % nc
     const bool act = c < ncv;
     const int ch = (int)div_by_L((u32)c, L), cl = c - ch * L;
     const long long bcol = (long long)div_by_L((u32)(col0 + c), L);
@@ -309,8 +311,8 @@ __global__ void __launch_bounds__(512, TF_NTT_WAVES) ntt_pass_kernel(const NttPa
     } else if (p2 != 0) {  // R = 32: step 1 is the whole transform and every element stays with its thread
         const int myround = c / A.cpr;
         const int cc = c - myround * A.cpr;
-        u64* wr = lds + g * A.s2 + cc;
-        const u64* rd = lds + cc;
+        u64* wr = lds + g * A.s2 + cc * A.s3;
+        const u64* rd = lds + cc * A.s3;
 #pragma unroll 1
         for (int r = 0; r < A.nrounds; ++r) {
             if (r) __syncthreads();

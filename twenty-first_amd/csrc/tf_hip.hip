@@ -424,6 +424,7 @@ void finish_geometry(Launch* l, int nc, int p2) {
     A.cpr = std::max(1, std::min(nc, round_elems() / R));
     A.nrounds = (nc + A.cpr - 1) / A.cpr;
     A.s2 = A.cpr;
+    A.s3 = 1;
     A.s1 = pad_to_residue(P2 * A.cpr, A.cpr % 32);  // consecutive k1 rows land cpr banks apart: conflict-free reads
     l->threads = (unsigned)(nc * P2);
     l->lds_bytes = size_t(32) * A.s1 * sizeof(u64);
@@ -563,6 +564,17 @@ Launch plan_row_pass(const u64* in, u64* out, long long in_bs, long long out_bs,
     A.js_k = 1;  // single pass: output element index = k
     A.xcd_order = 0;
     finish_geometry(&l, nc, p2);
+    static const bool no_gfast = getenv("TF_NTT_NO_GFAST") != nullptr;  // A/B switch
+    if (p2 >= 1 && !no_gfast) {
+        // rows are contiguous: put the lanes along the row (8 * P2-byte pieces become P2 times longer).  Exchange layout
+        // idx = k1 * s1 + cc * P2 + g with s1 = 1 (mod 32): a half-wave writes 32 consecutive words and reads
+        // g' * s1 + cc * P2 = g' + cc * P2 (mod 32), all different.
+        A.gfast = 1;
+        A.s2 = 1;
+        A.s3 = P2;
+        A.s1 = pad_to_residue(P2 * A.cpr, 1);
+        l.lds_bytes = size_t(32) * A.s1 * sizeof(u64);
+    }
     l.tiles = A.d2;
     return l;
 }
