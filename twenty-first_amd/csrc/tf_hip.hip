@@ -616,7 +616,8 @@ int launch_pass(const Launch& l, bool inverse, hipStream_t stream) {
     if (l.a.post_scale) return launch_pass_t<true, 2, 0>(l, stream);   // coset interpolation: inverse, scale on store
     // last pass of a plain transform with R = 1024: specialised kernel (constant P2, stores fused with level 5)
     static const bool no_last1024 = getenv("TF_NTT_NO_LAST1024") != nullptr;  // A/B switch
-    const bool last1024 = l.a.p2 == 5 && !l.a.post_tw && g_ablate == 0 && !no_last1024;
+    // (not for single-pass transforms: their stores run along the row as well, which only the gfast roles give -- 1.05 vs 1.20 ms)
+    const bool last1024 = l.a.p2 == 5 && !l.a.post_tw && g_ablate == 0 && !no_last1024 && !l.a.gfast;
     static const bool no_r1024 = getenv("TF_NTT_NO_R1024") != nullptr;  // A/B switch
     const bool r1024 = l.a.p2 == 5 && l.a.post_tw && g_ablate == 0 && !no_r1024;  // column pass with R = 1024
     if (last1024) {  // this instantiation lays its exchange buffer out itself (32 x 289 words, ntt_kernels.h)
