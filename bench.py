@@ -203,6 +203,17 @@ def main():
         "avg_launch_ms": round(avg_launch_ms, 5),
         "launches_per_step": launches_per_step,
     }
+    if log_n == 20:
+        # Informational second roofline: what actually bounds the kernel is integer VALU issue.  Static
+        # instruction counts of the two pass kernels (tools/isa_count.py on the committed build: 4114 + 3454 VALU
+        # instructions per thread = 32 elements per pass) against the measured issue rate of the 64-bit integer building
+        # blocks, 0.55 G wave-instructions/s per SIMD x 1024 SIMDs (profiles/microbench_r01_*.txt).
+        valu_instr_per_element = (4114 + 3454) / 32.0
+        wave_instr = batch * n * valu_instr_per_element / 64.0
+        floor_ms = wave_instr / (1024 * 0.55e9) * 1e3
+        roofline["valu_bound"] = {"valu_instr_per_element": round(valu_instr_per_element, 1), "floor_ms_per_step": round(floor_ms, 3),
+                                  "frac": round(floor_ms / (ev_ms / args.steps), 3),
+                                  "note": "integer VALU issue is the binding resource, not HBM"}
 
     out = {
         "metric": "goldilocks_ntt_gfelts_per_s",
