@@ -13,7 +13,7 @@ counts = {}
 t_end = time.time() + budget
 def bump(k): counts[k] = counts.get(k, 0) + 1
 while time.time() < t_end:
-    kind = rng.choice(["ntt", "ntt", "coset", "coset", "interp", "mul", "merkle", "varlen", "eval", "extrap"])
+    kind = rng.choice(["ntt", "ntt", "coset", "coset", "interp", "mul", "merkle", "varlen", "eval", "extrap", "lde", "auth", "square"])
     width = rng.choice([1, 3])
     if kind == "ntt":
         log_n = rng.randint(0, 23)
@@ -79,5 +79,37 @@ while time.time() < t_end:
         co = oracle.coset_interpolate(cw[b * n * width:(b + 1) * n * width], off, width=width)
         want = oracle.poly_eval(co, int(pts[i]))[:1] if width == 1 else oracle.poly_eval_xfe_point(co, pts[3 * i:3 * i + 3])
         assert np.array_equal(got[b, i], want), (kind, log_n, m, batch, width)
+    elif kind == "lde":
+        import torch
+        log_n, blow = rng.randint(0, 19), rng.randint(0, 3)
+        n, m = 1 << log_n, 1 << (log_n + blow)
+        batch = rng.randint(1, 3) if m * width <= (1 << 20) else 1
+        o_in, o_out = oracle.bfe_new(rng.randrange(1, P)), oracle.bfe_new(rng.randrange(1, P))
+        v = oracle.fill_random(batch * n * width, rng.getrandbits(40))
+        dv = torch.from_numpy(v.view(np.int64)).cuda()
+        ext = torch.empty(batch * m * width, dtype=torch.int64, device="cuda")
+        tf.device.lde(dv, n, o_in, ext, m, o_out, batch=batch, width=width)
+        torch.cuda.synchronize()
+        got = ext.cpu().numpy().view(np.uint64)
+        for b in range(batch):
+            co = oracle.coset_interpolate(v[b * n * width:(b + 1) * n * width], o_in, width=width)
+            assert np.array_equal(got[b * m * width:(b + 1) * m * width], oracle.coset_evaluate(co, o_out, m, width=width)), (kind, log_n, blow, width, batch)
+    elif kind == "auth":
+        import torch
+        h = rng.randint(0, 14)
+        n = 1 << h
+        leaves = oracle.fill_random(5 * n, rng.getrandbits(40))
+        dn = torch.empty(10 * n, dtype=torch.int64, device="cuda")
+        tf.device.merkle_build(torch.from_numpy(leaves.view(np.int64)).cuda(), n, dn)
+        torch.cuda.synchronize()
+        idx = [rng.randrange(n) for _ in range(rng.randint(0, 40))]
+        want_idx = oracle.auth_structure_indices(n, idx)
+        nodes = oracle.merkle_build(leaves).reshape(2 * n, 5)
+        got = tf.device.authentication_structure(dn, n, idx)
+        assert np.array_equal(got, nodes[np.asarray(want_idx, dtype=np.int64)].reshape(-1, 5)), (kind, h, len(idx))
+    elif kind == "square":
+        na = rng.randint(1, 4000)
+        a = oracle.fill_random(na * width, rng.getrandbits(40))
+        assert np.array_equal(tf.fast_square(a, width=width), oracle.poly_mul(a, a, width=width)), (kind, na, width)
     bump(kind)
 print(f"seed {seed}: all matched the oracle: " + ", ".join(f"{k} {v}" for k, v in sorted(counts.items())), flush=True)
