@@ -172,6 +172,7 @@ int tf_coset_extrapolate_bfe_dev(uint64_t offset_raw, const uint64_t *d_codeword
 int tf_coset_extrapolate_xfe_dev(uint64_t offset_raw, const uint64_t *d_codewords, size_t n, size_t batch, const uint64_t *d_points, size_t n_points, uint64_t *d_out, void *stream);
 int tf_merkle_from_rows(const uint64_t *rows, size_t row_len, size_t n_rows, uint64_t *nodes_out, size_t batch);
 int tf_merkle_from_rows_dev(const uint64_t *d_rows, size_t row_len, size_t n_rows, uint64_t *d_nodes_out, size_t batch, void *stream);
+/* Copies at most `capacity` node indices; *out_count always receives the full count (capacity 0 = sizing call). */
 int tf_merkle_auth_structure_indices(size_t num_leafs, const uint64_t *leaf_indices, size_t k, uint64_t *out_indices, size_t capacity, size_t *out_count);
 int tf_merkle_authentication_structure_dev(const uint64_t *d_nodes, size_t num_leafs, const uint64_t *leaf_indices, size_t k,
                                            uint64_t *out_digests, size_t capacity_digests, size_t *out_count, void *stream);

@@ -526,3 +526,52 @@ def test_config5_one_rank_of_eight(tf, oracle):
     got_roots = _to_host(roots).reshape(trees, 5)
     all_nodes = nodes.view(trees, 2 * n, 5)
     assert np.array_equal(got_roots, _to_host(all_nodes[:, 1, :].contiguous().view(-1)).reshape(trees, 5))  # frugal root == node 1
+
+
+def test_every_entry_point_validates_its_arguments(tf):
+    """Raw C-ABI calls: null pointers come back as TF_ERR_NULL_POINTER (7), bad lengths as the reference's panics, and
+    zero-sized work is a successful no-op -- never a crash (the reference panics or returns Err in the same places)."""
+    import ctypes as C
+
+    lib = tf._lib.lib()
+    buf = (C.c_uint64 * 4096)()
+    out = (C.c_uint64 * 16384)()
+    NULL = None
+    # ntt / intt
+    assert lib.tf_ntt_bfe(NULL, 8, 1, 0) == 7 and lib.tf_ntt_xfe(NULL, 8, 1, 1) == 7
+    assert lib.tf_ntt_bfe(buf, 12, 1, 0) == 4 and lib.tf_ntt_bfe(buf, 0, 5, 0) == 0 and lib.tf_ntt_bfe(buf, 8, 0, 0) == 0
+    assert lib.tf_ntt_bfe_dev(NULL, 8, 1, 0, None) == 7
+    # coset evaluation / interpolation / extrapolation
+    assert lib.tf_coset_eval_bfe(buf, 9, 7, out, 8, 1) == 6       # order <= degree  (polynomial.rs:1388)
+    assert lib.tf_coset_eval_bfe(buf, 4, 7, out, 12, 1) == 4
+    assert lib.tf_coset_eval_bfe(NULL, 4, 7, out, 8, 1) == 7 and lib.tf_coset_eval_xfe(buf, 4, 7, NULL, 8, 1) == 7
+    assert lib.tf_coset_eval_bfe(NULL, 0, 7, out, 8, 1) == 0      # the zero polynomial needs no coefficient pointer
+    assert lib.tf_coset_interpolate_bfe(buf, 12, 7, out, 1) == 4 and lib.tf_coset_interpolate_bfe(buf, 8, 0, out, 1) == 12
+    assert lib.tf_coset_interpolate_xfe(NULL, 8, 7, out, 1) == 7
+    assert lib.tf_coset_extrapolate_bfe(7, buf, 0, 1, buf, 2, out) == 4 and lib.tf_coset_extrapolate_bfe(7, buf, 24, 1, buf, 2, out) == 4
+    assert lib.tf_coset_extrapolate_bfe(0, buf, 8, 1, buf, 2, out) == 12 and lib.tf_coset_extrapolate_xfe(7, NULL, 8, 1, buf, 2, out) == 7
+    assert lib.tf_coset_extrapolate_bfe(7, buf, 8, 1, buf, 0, out) == 0
+    # products / evaluation
+    assert lib.tf_poly_mul_bfe(NULL, 3, buf, 3, out, 1) == 7 and lib.tf_poly_mul_xfe(buf, 3, buf, 3, NULL, 1) == 7
+    assert lib.tf_poly_square_bfe(NULL, 3, out, 1) == 7
+    assert lib.tf_poly_batch_evaluate_bfe(NULL, 3, buf, 2, out) == 7 and lib.tf_poly_batch_evaluate_xfe(buf, 3, buf, 2, NULL) == 7
+    assert lib.tf_poly_batch_evaluate_bfe(NULL, 0, buf, 2, out) == 0 and lib.tf_poly_batch_evaluate_bfe(buf, 3, NULL, 0, out) == 0
+    # Tip5 / Merkle
+    assert lib.tf_tip5_permute(NULL, 1) == 7 and lib.tf_tip5_permute(NULL, 0) == 0
+    assert lib.tf_tip5_hash_pairs(NULL, out, 1) == 7 and lib.tf_tip5_hash_pairs(buf, NULL, 1) == 7
+    assert lib.tf_tip5_hash_varlen_rows(NULL, 3, 2, out) == 7 and lib.tf_tip5_hash_varlen_rows(NULL, 0, 2, out) == 0
+    assert lib.tf_merkle_build(buf, 0, out, 1) == 1 and lib.tf_merkle_build(buf, 6, out, 1) == 2 and lib.tf_merkle_build(NULL, 8, out, 1) == 7
+    assert lib.tf_merkle_root(buf, 6, out, 1) == 2 and lib.tf_merkle_root(buf, 8, NULL, 1) == 7
+    assert lib.tf_merkle_from_rows(NULL, 3, 8, out, 1) == 7 and lib.tf_merkle_from_rows(buf, 3, 6, out, 1) == 2
+    cnt = C.c_size_t(0)
+    idx = (C.c_uint64 * 2)(0, 9)
+    assert lib.tf_merkle_auth_structure_indices(8, idx, 2, out, 64, C.byref(cnt)) == 11   # leaf 9 of 8
+    assert lib.tf_merkle_auth_structure_indices(12, idx, 1, out, 64, C.byref(cnt)) == 2
+    assert lib.tf_merkle_auth_structure_indices(8, idx, 1, out, 0, C.byref(cnt)) == 0 and cnt.value == 3   # sizing call: count only
+    assert lib.tf_status_string(7) == b"TF_ERR_NULL_POINTER" and lib.tf_status_string(13) == b"TF_ERR_BUFFER_TOO_SMALL"
+    # after all that the device still works
+    x = np.arange(8, dtype=np.uint64)
+    y = x.copy()
+    tf.ntt(y)
+    tf.intt(y)
+    assert np.array_equal(x, y)
