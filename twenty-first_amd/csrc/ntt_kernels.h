@@ -57,6 +57,7 @@ struct NttPassArgs {
     int s1, s2, s3;                          // LDS strides in u64: idx = k1*s1 + g*s2 + (c % cpr)*s3
     int gfast;                               // 1: thread t is (g = t % P2, column t / P2) instead of (t / nc, t % nc)
     int xcd_order;                           // G > 0: XCD-aware tile order in groups of G adjacent column tiles (0: natural order)
+    int xcd_colfast;                         // with xcd_order: walk the XCD's column groups fastest (their table slices fit its L2)
     u32 nc_magic;                            // t / nc == umulhi(t, nc_magic) for every t < blockDim (checked by the planner)
     unsigned long long* dbg;                 // MODE 3 only: per-wave cycle stamps (6 per wave)
 };
@@ -190,7 +191,12 @@ __global__ void __launch_bounds__(512, TF_NTT_WAVES) ntt_pass_kernel(const NttPa
         // halves of every 128-byte line are requested back to back from the same XCD (second one hits its L2).
         const u32 G = (u32)A.xcd_order;
         const u32 xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
-        const u32 grp = slot / (G * A.d01), within = slot % (G * A.d01);
+        // Order inside an XCD: column groups fastest when the inter-pass table slices of ALL its column tiles fit its L2
+        // together (the planner decides: xcd_colfast) -- neighbouring workgroups then stream from different DRAM pages
+        // instead of the same column of different batch entries (-1.1 % on 256 x 2^20); batch entries fastest otherwise.
+        const u32 ngrp = A.d2 / (8u * G);
+        const u32 grp = A.xcd_colfast ? slot % ngrp : slot / (G * A.d01);
+        const u32 within = A.xcd_colfast ? slot / ngrp : slot % (G * A.d01);
         i2 = ((grp << 3) | xcd) * G + within % G;
         const u32 rest = within / G;
         i1 = rest % A.d1;

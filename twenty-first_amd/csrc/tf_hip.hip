@@ -467,6 +467,8 @@ Launch plan_column_pass(const u64* in, u64* out, long long in_bs, long long out_
     {
         const int G = (nc * (int)sizeof(u64) < 128) ? 2 : 1;  // pair tiles narrower than a 128-byte line
         A.xcd_order = (A.d2 % (8 * G) == 0) ? G : ((A.d2 % 8 == 0) ? 1 : 0);
+        // table slice of one column tile = R rows x nc words; an XCD owns d2 / 8 column tiles and has a 4 MiB L2
+        if (A.xcd_order) A.xcd_colfast = (size_t(A.d2 / 8) * size_t(R) * nc * sizeof(u64) <= (size_t(2) << 20)) ? 1 : 0;
     }
     finish_geometry(&l, nc, p2);
     l.tiles = (unsigned)(batch * outer * A.d2);
