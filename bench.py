@@ -131,21 +131,26 @@ def main():
 
     launches_per_step = tf.lib().tf_ntt_launch_count(n, batch, 1)
 
-    # settle: untimed passes until the step time is stable (twiddle tables built, scratch pool grown, clocks ramped --
-    # on a cold GPU the first ~10 passes run 4.2 -> 2.3 ms, tools/step_times.py), at most 40; then the W warmup steps
+    # settle: untimed passes until the GPU is in steady state.  A cold GPU runs the first passes at 4.2 -> 2.3 ms and only
+    # reaches its steady 2.2 ms after ~50 (tools/step_times.py); some boxes have been seen to sit at ~1/4 speed (8.4 ms per
+    # pass, every pass of a process) -- the shader clock measured here tells such a run from a slow kernel.  Run windows
+    # of 25 passes until two consecutive windows agree within 2 % (at least 4 windows, at most 40), then the W warmup steps.
     settle = 0
+    sclk_before = tf.lib().tf_debug_sclk_mhz()
     if not args.no_settle:
-        hist = []
-        while settle < 40:
+        prev = None
+        for w in range(40):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            tf.device.ntt_(x, n, batch=batch)
+            for _ in range(25):
+                tf.device.ntt_(x, n, batch=batch)
             e1.record()
             torch.cuda.synchronize()
-            hist.append(e0.elapsed_time(e1))
-            settle += 1
-            if len(hist) >= 6 and max(hist[-5:]) <= 1.03 * min(hist[-5:]):
+            cur = e0.elapsed_time(e1) / 25
+            settle += 25
+            if w >= 3 and prev is not None and abs(cur - prev) <= 0.02 * prev:
                 break
+            prev = cur
     for _ in range(args.warmup):
         tf.device.ntt_(x, n, batch=batch)
     barrier()
@@ -155,18 +160,26 @@ def main():
     tf.device.ntt_(sample_gpu, n, batch=2)
     torch.cuda.synchronize()
 
-    evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     barrier()
     t0 = time.perf_counter()
-    evs[0].record()
-    for i in range(args.steps):
+    ev0.record()
+    for _ in range(args.steps):
         tf.device.ntt_(x, n, batch=batch)
-        evs[i + 1].record()
+    ev1.record()
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     elapsed = t1 - t0
-    ev_ms = evs[0].elapsed_time(evs[-1])
-    step_ms = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps))
+    ev_ms = ev0.elapsed_time(ev1)
+    # per-step spread, measured AFTER the timed region (an event per step costs ~2 % when it sits inside it)
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(11)]
+    evs[0].record()
+    for i in range(10):
+        tf.device.ntt_(x, n, batch=batch)
+        evs[i + 1].record()
+    torch.cuda.synchronize()
+    step_ms = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(10))
+    sclk_after = tf.lib().tf_debug_sclk_mhz()
     barrier()
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -235,8 +248,10 @@ def main():
             "parallelism": f"batch-sharded x{world}, no data-path collective",
         },
         "roofline": roofline,
-        "step_ms": {"min": round(step_ms[0], 4), "median": round(step_ms[len(step_ms) // 2], 4), "max": round(step_ms[-1], 4)},
+        "step_ms_after": {"min": round(step_ms[0], 4), "median": round(step_ms[len(step_ms) // 2], 4), "max": round(step_ms[-1], 4),
+                          "note": "10 extra steps with an event each, after the timed region"},
         "settle_steps": settle,
+        "sclk_mhz": {"before_settle": round(sclk_before, 0), "after_timed_region": round(sclk_after, 0)},
     }
 
     if rank == 0:

@@ -192,6 +192,8 @@ void tf_set_ntt_min_passes(int passes);
 int tf_ntt_launch_count(size_t n, size_t batch, int width);
 /* Measurement helper for tools/phase_timeline.py (TF_NTT_ABLATE=3): per-wave phase cycle stamps of the NTT pass kernel. */
 int tf_debug_stamps(unsigned long long *host_out, size_t words);
+/* Measurement helper: the shader clock (MHz) the current device is running at right now (one-wave ~0.5 ms spin; < 0 on failure). */
+double tf_debug_sclk_mhz(void);
 size_t tf_get_ntt_tile_bytes(void);
 
 #ifdef __cplusplus

@@ -640,6 +640,18 @@ __global__ void __launch_bounds__(256) batch_evaluate_split_kernel(const u64* co
     if (t < L) out[((long long)blockIdx.y * n_points + i) * L + t] = part[t];
 }
 
+// out[0] = shader cycles, out[1] = wall-clock ticks spent in a fixed spin (tf_debug_sclk_mhz)
+__global__ void sclk_probe_kernel(unsigned long long* out) {
+    const unsigned long long w0 = wall_clock64(), c0 = clock64();
+    unsigned v = threadIdx.x;
+    for (int i = 0; i < 200000; ++i) v = v * 1664525u + 1013904223u;
+    const unsigned long long c1 = clock64(), w1 = wall_clock64();
+    if (threadIdx.x == 0) {
+        out[0] = c1 - c0 + (v == 0xdeadbeefu);
+        out[1] = w1 - w0;
+    }
+}
+
 // out[k] = nodes[idx[k]] for digests (5 words): authentication structures from a device-resident tree
 __global__ void __launch_bounds__(256) gather_digests_kernel(const u64* nodes, const unsigned long long* idx, long long count, u64* out) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;

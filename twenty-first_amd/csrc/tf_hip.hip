@@ -1476,6 +1476,23 @@ size_t tf_get_ntt_tile_bytes(void) {
     return g_tile_bytes;
 }
 
+// measurement helper (not part of the drop-in boundary): the shader clock the GPU is running at right now, from the ratio of
+// the shader-cycle counter to the constant-rate wall clock over a ~0.5 ms spin of one wave.  bench.py records it next to its
+// timings so that a run taken while the GPU sits in a low power state can be told from a slow kernel.
+double tf_debug_sclk_mhz(void) {
+    int dev = 0, wall_khz = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return -1.0;
+    if (hipDeviceGetAttribute(&wall_khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || wall_khz <= 0) wall_khz = 100000;
+    unsigned long long* d = nullptr;
+    if (hipMalloc(reinterpret_cast<void**>(&d), 2 * sizeof(unsigned long long)) != hipSuccess) return -1.0;
+    hipLaunchKernelGGL(tfk::sclk_probe_kernel, dim3(1), dim3(64), 0, hipStream_t(0), d);
+    unsigned long long h[2] = {0, 0};
+    const hipError_t e = hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess || h[1] == 0) return -1.0;
+    return (double)h[0] / (double)h[1] * (double)wall_khz / 1000.0;
+}
+
 // measurement helper (not part of the drop-in boundary): allocate / fetch the MODE-3 stamp buffer
 int tf_debug_stamps(unsigned long long* host_out, size_t words) {
     if (!g_dbg_buf) {
