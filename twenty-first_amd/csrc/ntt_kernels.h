@@ -255,13 +255,32 @@ __global__ void __launch_bounds__(512, TF_NTT_WAVES) ntt_pass_kernel(const NttPa
             const u64* ptr = reinterpret_cast<const u64*>(base + ur * A.in_rs * 8 + toff);
             if constexpr (SCALE == 1) {
                 const long long j = (ur + g) * A.ps_rs + (A.ps_col ? bcol : 0);
-                if (j < A.n_coeffs) x[q] = gl::mont_mul(*ptr, A.pre_scale[j + (long long)i1 * A.ps_i1]);
+                if (j < A.n_coeffs) x[q] = *ptr;  // rows beyond the coefficients read as zero; scaled below
             } else {
 #ifdef TF_NT
                 x[q] = __builtin_nontemporal_load(ptr);
 #else
                 x[q] = *ptr;
 #endif
+            }
+        }
+    }
+    if constexpr (SCALE == 1) {
+        // coefficient j times offset^j: the 32 data loads above went out as one burst; the scale words follow eight at a
+        // time and the products are taken in hand-scheduled pairs (zero rows stay zero: their scale index is clamped)
+        if (act_in) {
+            const u64* ps = A.pre_scale + (long long)i1 * A.ps_i1;
+#pragma unroll
+            for (int q0 = 0; q0 < 32; q0 += 8) {
+                u64 w[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const long long ur = (long long)(brev5(q0 + i) << p2);
+                    const long long j = (ur + g) * A.ps_rs + (A.ps_col ? bcol : 0);
+                    w[i] = ps[j < A.n_coeffs ? j : 0];
+                }
+#pragma unroll
+                for (int i = 0; i < 8; i += 2) gl::mont_mul2(x[q0 + i], w[i], x[q0 + i + 1], w[i + 1], x[q0 + i], x[q0 + i + 1]);
             }
         }
     }

@@ -614,7 +614,11 @@ int launch_pass(const Launch& l, bool inverse, hipStream_t stream) {
         const char* e = getenv("TF_NTT_ABLATE");
         g_ablate = e ? atoi(e) : 0;
     }
-    if (l.a.pre_scale) return launch_pass_t<false, 1, 0>(l, stream);   // coset evaluation: forward, scale on load
+    if (l.a.pre_scale) {  // coset evaluation: forward, scale on load (constant-P2 variant for a first pass with R = 1024)
+        static const bool no_r1024_scale = getenv("TF_NTT_NO_R1024") != nullptr;
+        if (l.a.p2 == 5 && l.a.post_tw && !no_r1024_scale) return launch_pass_t<false, 1, 0, false, true>(l, stream);
+        return launch_pass_t<false, 1, 0>(l, stream);
+    }
     if (l.a.post_scale) return launch_pass_t<true, 2, 0>(l, stream);   // coset interpolation: inverse, scale on store
     // last pass of a plain transform with R = 1024: specialised kernel (constant P2, stores fused with level 5)
     static const bool no_last1024 = getenv("TF_NTT_NO_LAST1024") != nullptr;  // A/B switch
