@@ -37,6 +37,7 @@ struct NttPassArgs {
     const u64* inner_tw;   // [P2][32] Montgomery words: w_R^(+-g*k1) (times n^-1 for the last inverse pass); may be null
     const u64* post_tw;    // inter-pass twiddles T[k * tw_rs + b] (Montgomery words) or null
     const u64* pre_scale;  // coset powers S[j] (Montgomery words) or null        (polynomial.rs:760-773)
+    const u64* in2;        // SCALE = 1 only: second operand with the layout of `in`, multiplied in on load (or null)
     const u64* post_scale; // interpolation powers offset^-j applied to output element j, or null (polynomial.rs:1907-1918)
     long long js_i0, js_i1, js_i2, js_c, js_k;  // output element index j = i0*js_i0 + i1*js_i1 + i2*js_i2 + (c/L)*js_c + k*js_k (last pass only)
     long long n_coeffs;    // elements present per input polynomial; rows beyond are zero (polynomial.rs:1395); <0: no padding
@@ -255,7 +256,7 @@ __global__ void __launch_bounds__(512, TF_NTT_WAVES) ntt_pass_kernel(const NttPa
             const u64* ptr = reinterpret_cast<const u64*>(base + ur * A.in_rs * 8 + toff);
             if constexpr (SCALE == 1) {
                 const long long j = (ur + g) * A.ps_rs + (A.ps_col ? bcol : 0);
-                if (j < A.n_coeffs) x[q] = *ptr;  // rows beyond the coefficients read as zero; scaled below
+                if (A.n_coeffs < 0 || j < A.n_coeffs) x[q] = *ptr;  // rows beyond the coefficients read as zero; scaled below
             } else {
 #ifdef TF_NT
                 x[q] = __builtin_nontemporal_load(ptr);
@@ -267,8 +268,25 @@ __global__ void __launch_bounds__(512, TF_NTT_WAVES) ntt_pass_kernel(const NttPa
     }
     if constexpr (SCALE == 1) {
         // coefficient j times offset^j: the 32 data loads above went out as one burst; the scale words follow eight at a
-        // time and the products are taken in hand-scheduled pairs (zero rows stay zero: their scale index is clamped)
-        if (act_in) {
+        // time and the products are taken in hand-scheduled pairs (zero rows stay zero: their scale index is clamped).
+        // pre_scale == null with n_coeffs >= 0 is plain zero padding (fast_multiply); in2 != null multiplies by a second
+        // operand laid out like the input (the pointwise product of fast_multiply, fused into the inverse transform's load).
+        if (act_in && A.in2) {
+            const char* base2 = reinterpret_cast<const char*>(in + (A.in2 - A.in));
+            const u32 toff2 = (u32)(((long long)ch_in * A.in_cs_hi + cl_in + (long long)g_in * A.in_rs) * 8);
+#pragma unroll
+            for (int q0 = 0; q0 < 32; q0 += 8) {
+                u64 w[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const long long ur = (long long)(brev5(q0 + i) << p2);
+                    w[i] = *reinterpret_cast<const u64*>(base2 + ur * A.in_rs * 8 + toff2);
+                }
+#pragma unroll
+                for (int i = 0; i < 8; i += 2) gl::mont_mul2(x[q0 + i], w[i], x[q0 + i + 1], w[i + 1], x[q0 + i], x[q0 + i + 1]);
+            }
+        }
+        if (act_in && A.pre_scale) {
             const u64* ps = A.pre_scale + (long long)i1 * A.ps_i1;
 #pragma unroll
             for (int q0 = 0; q0 < 32; q0 += 8) {

@@ -614,8 +614,11 @@ int launch_pass(const Launch& l, bool inverse, hipStream_t stream) {
         const char* e = getenv("TF_NTT_ABLATE");
         g_ablate = e ? atoi(e) : 0;
     }
-    if (l.a.pre_scale) {  // coset evaluation: forward, scale on load (constant-P2 variant for a first pass with R = 1024)
+    if (l.a.pre_scale || l.a.n_coeffs >= 0 || l.a.in2) {
+        // work on load: coset scaling, zero padding, or the pointwise product with a second operand (forward or inverse;
+        // constant-P2 variant for a forward first pass with R = 1024)
         static const bool no_r1024_scale = getenv("TF_NTT_NO_R1024") != nullptr;
+        if (inverse) return launch_pass_t<true, 1, 0>(l, stream);
         if (l.a.p2 == 5 && l.a.post_tw && !no_r1024_scale) return launch_pass_t<false, 1, 0, false, true>(l, stream);
         return launch_pass_t<false, 1, 0>(l, stream);
     }
@@ -678,7 +681,7 @@ int pass_count(int log_n) {  // global passes of a transform with log_n > 10
 // reads the coefficients once per c and writes rows (k_1, c); from there on it is the ordinary plan with N_1 * C rows.
 int run_ntt(DeviceCtx* ctx, const u64* in, u64* out, long long in_bs, long long out_bs, size_t n, size_t batch, int L,
             bool inverse, const u64* pre_scale, long long n_coeffs, hipStream_t stream, const u64* post_scale = nullptr,
-            size_t cosets = 1) {
+            size_t cosets = 1, const u64* in2 = nullptr) {
     if (n == 0 || batch == 0) return TF_OK;
     const int log_n = ilog2(n);
     int rc;
@@ -717,6 +720,7 @@ int run_ntt(DeviceCtx* ctx, const u64* in, u64* out, long long in_bs, long long 
             l.a.pre_scale = pre_scale;
             l.a.post_scale = post_scale;
             l.a.n_coeffs = n_coeffs;
+            l.a.in2 = in2 ? in2 + b0 * in_bs : nullptr;
             rc = launch_pass(l, inverse, stream);
             if (rc) return rc;
         }
@@ -817,6 +821,7 @@ int run_ntt(DeviceCtx* ctx, const u64* in, u64* out, long long in_bs, long long 
             if (i == 0) {
                 p.a.pre_scale = pre_scale;
                 p.a.n_coeffs = n_coeffs;
+                p.a.in2 = in2 ? in2 + (long long)b0 * in_bs : nullptr;
                 if (cosets > 1) {  // "outer" index = coset c: same input for every c, output row (k_1, c), scale table c
                     p.a.ib1 = 0;
                     p.a.ob1 = B * L;
@@ -1180,11 +1185,25 @@ int poly_mul_dev(const u64* a, size_t na, const u64* b, size_t nb, u64* out, siz
     const size_t half = batch * order * size_t(L);
     hipError_t e = hipMallocAsync(reinterpret_cast<void**>(&tmp), 2 * half * sizeof(u64), s);
     if (e != hipSuccess) return hip_fail(e, "hipMallocAsync(poly_mul)", __FILE__, __LINE__);
-    rc = pad_copy(a, tmp, (long long)na * L, (long long)order * L, (long long)batch, s);
-    if (!rc) rc = pad_copy(b, tmp + half, (long long)nb * L, (long long)order * L, (long long)batch, s);
-    if (!rc) rc = run_ntt(ctx, tmp, tmp, (long long)order * L, (long long)order * L, order, 2 * batch, L, false, nullptr, -1, s);
-    if (!rc) rc = hadamard_dev(tmp, tmp + half, tmp, batch * order, L, s);
-    if (!rc) rc = run_ntt(ctx, tmp, tmp, (long long)order * L, (long long)order * L, order, batch, L, true, nullptr, -1, s);
+    static const bool no_fuse = getenv("TF_POLY_MUL_NO_FUSE") != nullptr;  // A/B switch
+    if (order > 16 && !no_fuse) {
+        // zero padding happens in the first pass of each forward transform (rows beyond the coefficients read as zero);
+        // over BFieldElement the pointwise product rides on the inverse transform's first load
+        rc = run_ntt(ctx, a, tmp, (long long)na * L, (long long)order * L, order, batch, L, false, nullptr, (long long)na, s);
+        if (!rc) rc = run_ntt(ctx, b, tmp + half, (long long)nb * L, (long long)order * L, order, batch, L, false, nullptr, (long long)nb, s);
+        if (!rc && L == 1) {
+            rc = run_ntt(ctx, tmp, tmp, (long long)order, (long long)order, order, batch, 1, true, nullptr, -1, s, nullptr, 1, tmp + half);
+        } else if (!rc) {
+            rc = hadamard_dev(tmp, tmp + half, tmp, batch * order, L, s);
+            if (!rc) rc = run_ntt(ctx, tmp, tmp, (long long)order * L, (long long)order * L, order, batch, L, true, nullptr, -1, s);
+        }
+    } else {
+        rc = pad_copy(a, tmp, (long long)na * L, (long long)order * L, (long long)batch, s);
+        if (!rc) rc = pad_copy(b, tmp + half, (long long)nb * L, (long long)order * L, (long long)batch, s);
+        if (!rc) rc = run_ntt(ctx, tmp, tmp, (long long)order * L, (long long)order * L, order, 2 * batch, L, false, nullptr, -1, s);
+        if (!rc) rc = hadamard_dev(tmp, tmp + half, tmp, batch * order, L, s);
+        if (!rc) rc = run_ntt(ctx, tmp, tmp, (long long)order * L, (long long)order * L, order, batch, L, true, nullptr, -1, s);
+    }
     if (!rc) rc = pad_copy(tmp, out, (long long)order * L, (long long)n_out * L, (long long)batch, s);
     hipError_t e2 = hipFreeAsync(tmp, s);
     if (rc) return rc;
@@ -1209,10 +1228,21 @@ int poly_square_dev(const u64* a, size_t na, u64* out, size_t batch, int L, void
     const size_t words = batch * order * size_t(L);
     hipError_t e = hipMallocAsync(reinterpret_cast<void**>(&tmp), words * sizeof(u64), s);
     if (e != hipSuccess) return hip_fail(e, "hipMallocAsync(poly_square)", __FILE__, __LINE__);
-    rc = pad_copy(a, tmp, (long long)na * L, (long long)order * L, (long long)batch, s);
-    if (!rc) rc = run_ntt(ctx, tmp, tmp, (long long)order * L, (long long)order * L, order, batch, L, false, nullptr, -1, s);
-    if (!rc) rc = hadamard_dev(tmp, tmp, tmp, batch * order, L, s);
-    if (!rc) rc = run_ntt(ctx, tmp, tmp, (long long)order * L, (long long)order * L, order, batch, L, true, nullptr, -1, s);
+    static const bool no_fuse = getenv("TF_POLY_MUL_NO_FUSE") != nullptr;  // A/B switch
+    if (order > 16 && !no_fuse) {
+        rc = run_ntt(ctx, a, tmp, (long long)na * L, (long long)order * L, order, batch, L, false, nullptr, (long long)na, s);
+        if (!rc && L == 1) {
+            rc = run_ntt(ctx, tmp, tmp, (long long)order, (long long)order, order, batch, 1, true, nullptr, -1, s, nullptr, 1, tmp);
+        } else if (!rc) {
+            rc = hadamard_dev(tmp, tmp, tmp, batch * order, L, s);
+            if (!rc) rc = run_ntt(ctx, tmp, tmp, (long long)order * L, (long long)order * L, order, batch, L, true, nullptr, -1, s);
+        }
+    } else {
+        rc = pad_copy(a, tmp, (long long)na * L, (long long)order * L, (long long)batch, s);
+        if (!rc) rc = run_ntt(ctx, tmp, tmp, (long long)order * L, (long long)order * L, order, batch, L, false, nullptr, -1, s);
+        if (!rc) rc = hadamard_dev(tmp, tmp, tmp, batch * order, L, s);
+        if (!rc) rc = run_ntt(ctx, tmp, tmp, (long long)order * L, (long long)order * L, order, batch, L, true, nullptr, -1, s);
+    }
     if (!rc) rc = pad_copy(tmp, out, (long long)order * L, (long long)n_out * L, (long long)batch, s);
     hipError_t e2 = hipFreeAsync(tmp, s);
     if (rc) return rc;
