@@ -261,3 +261,18 @@ def test_blown_up_coset_evaluation(tf, oracle, width, n_coeffs, order, batch, fo
     for b in range(batch):
         want = oracle.coset_evaluate(c[b * n_coeffs * width:(b + 1) * n_coeffs * width], off, order, width=width)
         assert np.array_equal(got[b * order * width:(b + 1) * order * width], want)
+
+
+@pytest.mark.parametrize("count,shift", [(1, 0), (2, 0), (7, 0), (1025, 0), (1024, 1), (4097, 1)])
+def test_hadamard_bfe_alignment_and_odd_counts(tf, oracle, count, shift):
+    """pointwise BFE product (math/polynomial.rs:920-925): the 16-byte path, its odd tail, and 8-byte-aligned operands"""
+    import torch
+
+    a = oracle.fill_random(count + shift, 50 + count)
+    b = oracle.fill_random(count + shift, 51 + count)
+    da = torch.from_numpy(a.view(np.int64)).cuda()[shift:]
+    db = torch.from_numpy(b.view(np.int64)).cuda()[shift:]
+    out = torch.empty(count + shift, dtype=torch.int64, device="cuda")[shift:]
+    tf.device.hadamard(da, db, out)
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy().view(np.uint64), oracle.hadamard(a[shift:], b[shift:]))

@@ -556,6 +556,25 @@ __global__ void __launch_bounds__(256) build_pow_table_kernel(u64* out, const u6
 __global__ void __launch_bounds__(256) hadamard_bfe_kernel(const u64* a, const u64* b, u64* out, long long count) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long stride = (long long)gridDim.x * blockDim.x;
+    // two elements per lane and access (16-byte loads/stores) when the three arrays are 16-byte aligned
+    if ((((unsigned long long)a | (unsigned long long)b | (unsigned long long)out) & 15) == 0) {
+        typedef unsigned long long ull2 __attribute__((ext_vector_type(2)));
+        const long long pairs = count >> 1;
+        const ull2* a2 = reinterpret_cast<const ull2*>(a);
+        const ull2* b2 = reinterpret_cast<const ull2*>(b);
+        ull2* o2 = reinterpret_cast<ull2*>(out);
+        for (long long k = i; k < pairs; k += stride) {
+            const ull2 x = a2[k], y = b2[k];
+            u64 r0, r1;
+            gl::mont_mul2(x.x, y.x, x.y, y.y, r0, r1);
+            ull2 r;
+            r.x = r0;
+            r.y = r1;
+            o2[k] = r;
+        }
+        if ((count & 1) && i == 0) out[count - 1] = gl::mont_mul(a[count - 1], b[count - 1]);
+        return;
+    }
     for (; i < count; i += stride) out[i] = gl::mont_mul(a[i], b[i]);
 }
 
