@@ -170,6 +170,17 @@ int tf_coset_extrapolate_bfe(uint64_t offset_raw, const uint64_t *codewords, siz
 int tf_coset_extrapolate_xfe(uint64_t offset_raw, const uint64_t *codewords, size_t n, size_t batch, const uint64_t *points, size_t n_points, uint64_t *out);
 int tf_coset_extrapolate_bfe_dev(uint64_t offset_raw, const uint64_t *d_codewords, size_t n, size_t batch, const uint64_t *d_points, size_t n_points, uint64_t *d_out, void *stream);
 int tf_coset_extrapolate_xfe_dev(uint64_t offset_raw, const uint64_t *d_codewords, size_t n, size_t batch, const uint64_t *d_points, size_t n_points, uint64_t *d_out, void *stream);
+/* Rows of a COLUMN-major table (the layout a batch of coset evaluations leaves behind: one codeword per column).
+ * table: `batch` tables of n_cols columns; column j = n_rows elements of `width` words (1 = BFieldElement, 3 = XFieldElement
+ * flattened as math/x_field_element.rs:217-231) at table + j * col_stride (col_stride >= n_rows * width, in words; tables are
+ * n_cols * col_stride words apart).  Row i = the concatenation over the columns of element i.
+ *   tf_tip5_hash_table_rows : digests[(t * n_rows + i) * 5 ..] = Tip5::hash_varlen(row i of table t)   tip5/mod.rs:617-623
+ *   tf_merkle_from_columns  : those digests as the leaves of one tree per table (nodes: batch x 2 n_rows digests), errors as
+ *                             tf_merkle_build. */
+int tf_tip5_hash_table_rows(const uint64_t *table, size_t n_rows, size_t n_cols, int width, size_t col_stride, uint64_t *digests, size_t batch);
+int tf_tip5_hash_table_rows_dev(const uint64_t *d_table, size_t n_rows, size_t n_cols, int width, size_t col_stride, uint64_t *d_digests, size_t batch, void *stream);
+int tf_merkle_from_columns(const uint64_t *table, size_t n_rows, size_t n_cols, int width, size_t col_stride, uint64_t *nodes_out, size_t batch);
+int tf_merkle_from_columns_dev(const uint64_t *d_table, size_t n_rows, size_t n_cols, int width, size_t col_stride, uint64_t *d_nodes_out, size_t batch, void *stream);
 int tf_merkle_from_rows(const uint64_t *rows, size_t row_len, size_t n_rows, uint64_t *nodes_out, size_t batch);
 int tf_merkle_from_rows_dev(const uint64_t *d_rows, size_t row_len, size_t n_rows, uint64_t *d_nodes_out, size_t batch, void *stream);
 /* Copies at most `capacity` node indices; *out_count always receives the full count (capacity 0 = sizing call). */

@@ -276,3 +276,42 @@ def test_hadamard_bfe_alignment_and_odd_counts(tf, oracle, count, shift):
     tf.device.hadamard(da, db, out)
     torch.cuda.synchronize()
     assert np.array_equal(out.cpu().numpy().view(np.uint64), oracle.hadamard(a[shift:], b[shift:]))
+
+
+@pytest.mark.parametrize("width", [1, 3])
+@pytest.mark.parametrize("n_rows,n_cols", [(1, 1), (8, 0), (8, 3), (64, 10), (256, 7), (1 << 12, 11), (1 << 16, 4)])
+def test_rows_of_column_major_tables(tf, oracle, width, n_rows, n_cols):
+    """hash_varlen (tip5/mod.rs:617-623) of the rows of a column-major table (XFE rows flattened as
+    x_field_element.rs:217-231) and the tree over them; both kernel shapes (16 lanes per row up to 2^15 rows)"""
+    cols = oracle.fill_random(max(1, n_cols * n_rows * width), 60 + n_rows + n_cols)[: n_cols * n_rows * width]
+    # the same table row-major on the host: row i = [col_0[i], col_1[i], ...]
+    rows = cols.reshape(n_cols, n_rows, width).transpose(1, 0, 2).reshape(-1) if n_cols else np.zeros(0, dtype=np.uint64)
+    row_len = n_cols * width
+    want = oracle.hash_varlen_rows(rows, row_len) if row_len else np.concatenate([oracle.hash_varlen(np.zeros(0, np.uint64))] * n_rows)
+    got = tf.Tip5.hash_table_rows(cols, n_rows, width=width) if n_cols else None
+    if n_cols:
+        assert np.array_equal(got, want)
+        tree = tf.MerkleTree.from_columns(cols, n_rows, width=width)
+        assert np.array_equal(tree.nodes.reshape(-1), oracle.merkle_build(want))
+
+
+def test_column_major_tables_on_device_with_stride_and_batch(tf, oracle):
+    """two tables of 5 XFE columns x 2^10 rows with padded columns (col_stride > n_rows * width), device-resident"""
+    import torch
+
+    n_rows, n_cols, width, pad, batch = 1 << 10, 5, 3, 16, 2
+    cs = n_rows * width + pad
+    raw = oracle.fill_random(batch * n_cols * cs, 71)
+    dt = torch.from_numpy(raw.view(np.int64)).cuda()
+    nodes = torch.empty(batch * 10 * n_rows, dtype=torch.int64, device="cuda")
+    digs = torch.empty(batch * 5 * n_rows, dtype=torch.int64, device="cuda")
+    tf.device.hash_table_rows(dt, n_rows, n_cols, digs, width=width, col_stride=cs, batch=batch)
+    tf.device.merkle_from_columns(dt, n_rows, n_cols, nodes, width=width, col_stride=cs, batch=batch)
+    torch.cuda.synchronize()
+    gd, gn = digs.cpu().numpy().view(np.uint64), nodes.cpu().numpy().view(np.uint64)
+    for b in range(batch):
+        t = raw[b * n_cols * cs:(b + 1) * n_cols * cs].reshape(n_cols, cs)[:, : n_rows * width].reshape(n_cols, n_rows, width)
+        rows = t.transpose(1, 0, 2).reshape(-1)
+        want = oracle.hash_varlen_rows(rows, n_cols * width)
+        assert np.array_equal(gd[b * 5 * n_rows:(b + 1) * 5 * n_rows], want)
+        assert np.array_equal(gn[b * 10 * n_rows:(b + 1) * 10 * n_rows], oracle.merkle_build(want))

@@ -322,6 +322,17 @@ class Tip5:
         return out
 
     @staticmethod
+    def hash_table_rows(columns: np.ndarray, n_rows: int, width: int = 1) -> np.ndarray:
+        """hash_varlen of every row of a column-major table (columns back to back, n_rows elements of `width` words each):
+        n_rows x 5 words."""
+        t = _words(np.ascontiguousarray(columns, dtype=np.uint64).reshape(-1), "columns")
+        col_words = n_rows * width
+        n_cols = t.size // col_words if col_words else 0
+        out = np.empty(n_rows * 5, dtype=np.uint64)
+        _check(lib().tf_tip5_hash_table_rows(_ptr(t), n_rows, n_cols, width, col_words, _ptr(out), 1), "Tip5::hash_varlen")
+        return out
+
+    @staticmethod
     def hash_varlen(inp) -> np.ndarray:
         """tip5/mod.rs:617-623.  (One row; the empty input is one row of length 0.)"""
         a = np.ascontiguousarray(inp, dtype=np.uint64).reshape(-1)
@@ -442,6 +453,17 @@ class MerkleTree:
         nodes = np.empty(max(10 * n, 1), dtype=np.uint64)
         _check(lib().tf_merkle_from_rows(_ptr(rows), row_len, n, _ptr(nodes), 1), "MerkleTree::par_new")
         return cls(nodes[: 10 * n].reshape(2 * n, 5))
+
+    @classmethod
+    def from_columns(cls, columns: np.ndarray, n_rows: int, width: int = 1) -> "MerkleTree":
+        """Leaves = Tip5::hash_varlen of every ROW of a column-major table (one codeword per column, n_rows elements of
+        `width` words each, columns back to back) -- the layout a batch of coset evaluations produces."""
+        t = _words(np.ascontiguousarray(columns, dtype=np.uint64).reshape(-1), "columns")
+        col_words = n_rows * width
+        n_cols = t.size // col_words if col_words else 0
+        nodes = np.empty(max(10 * n_rows, 1), dtype=np.uint64)
+        _check(lib().tf_merkle_from_columns(_ptr(t), n_rows, n_cols, width, col_words, _ptr(nodes), 1), "MerkleTree::par_new")
+        return cls(nodes[: 10 * n_rows].reshape(2 * n_rows, 5))
 
     @staticmethod
     def authentication_structure_node_indices(num_leafs: int, leaf_indices) -> np.ndarray:

@@ -65,6 +65,10 @@ SIGNATURES = {
     "tf_coset_extrapolate_xfe": (C.c_int, [C.c_uint64, _vp, _sz, _sz, _vp, _sz, _vp]),
     "tf_coset_extrapolate_bfe_dev": (C.c_int, [C.c_uint64, _vp, _sz, _sz, _vp, _sz, _vp, _vp]),
     "tf_coset_extrapolate_xfe_dev": (C.c_int, [C.c_uint64, _vp, _sz, _sz, _vp, _sz, _vp, _vp]),
+    "tf_tip5_hash_table_rows": (C.c_int, [_vp, _sz, _sz, C.c_int, _sz, _vp, _sz]),
+    "tf_tip5_hash_table_rows_dev": (C.c_int, [_vp, _sz, _sz, C.c_int, _sz, _vp, _sz, _vp]),
+    "tf_merkle_from_columns": (C.c_int, [_vp, _sz, _sz, C.c_int, _sz, _vp, _sz]),
+    "tf_merkle_from_columns_dev": (C.c_int, [_vp, _sz, _sz, C.c_int, _sz, _vp, _sz, _vp]),
     "tf_merkle_from_rows": (C.c_int, [_vp, _sz, _sz, _vp, _sz]),
     "tf_merkle_from_rows_dev": (C.c_int, [_vp, _sz, _sz, _vp, _sz, _vp]),
     "tf_merkle_auth_structure_indices": (C.c_int, [_sz, _vp, _sz, _vp, _sz, C.POINTER(C.c_size_t)]),

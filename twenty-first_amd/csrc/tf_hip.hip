@@ -1017,6 +1017,61 @@ int merkle_levels_in_place(u64* d_nodes, long long N, size_t batch, hipStream_t 
     return TF_OK;
 }
 
+// hash_varlen of the rows of `batch` column-major tables (one codeword per column): digests to out + t * out_ts + 5 * i
+int launch_hash_table_rows(const u64* table, long long n_rows, long long n_cols, int width, long long col_stride, long long table_stride,
+                           long long batch, u64* out, long long out_ts, hipStream_t s) {
+    const long long total = n_rows * batch;
+    if (total == 0) return TF_OK;
+    if (total <= kCoopMaxCount) {
+        hipLaunchKernelGGL(tfk::tip5_hash_table_rows_coop_kernel, dim3((unsigned)((total + 15) / 16)), dim3(256), 0, s, table, n_rows, n_cols,
+                           width, col_stride, table_stride, total, out, out_ts);
+    } else {
+        hipLaunchKernelGGL(tfk::tip5_hash_table_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, table, n_rows, n_cols,
+                           width, col_stride, table_stride, total, out, out_ts);
+    }
+    HIPCHK(hipGetLastError());
+    return TF_OK;
+}
+
+// Rows of a COLUMN-major table ("hash_varlen over rows of a column-major table, the producer of leaves")
+// -> leaf digests -> Merkle tree.  table: batch x n_cols columns of n_rows elements of `width` words, col_stride words apart.
+int hash_table_rows_dev(const u64* d_table, size_t n_rows, size_t n_cols, int width, size_t col_stride, u64* d_digests, size_t batch,
+                        void* stream) {
+    if (width != 1 && width != 3) return TF_ERR_NULL_POINTER;
+    if (n_rows == 0 || batch == 0) return TF_OK;
+    if (!d_digests || (n_cols && !d_table)) return TF_ERR_NULL_POINTER;
+    if (n_cols * size_t(width) >= (size_t(1) << 31) || col_stride < n_rows * size_t(width)) return TF_ERR_LEN_TOO_LARGE;
+    DeviceCtx* ctx = nullptr;
+    int rc = current_ctx(&ctx);
+    if (rc) return rc;
+    rc = ensure_tip5(ctx);
+    if (rc) return rc;
+    return launch_hash_table_rows(d_table, (long long)n_rows, (long long)n_cols, width, (long long)col_stride,
+                                  (long long)(n_cols * col_stride), (long long)batch, d_digests, 5ll * (long long)n_rows,
+                                  static_cast<hipStream_t>(stream));
+}
+
+int merkle_from_columns_dev(const u64* d_table, size_t n_rows, size_t n_cols, int width, size_t col_stride, u64* d_nodes, size_t batch,
+                            void* stream) {
+    if (width != 1 && width != 3) return TF_ERR_NULL_POINTER;
+    int rc = check_leaves(n_rows);
+    if (rc) return rc;
+    if (batch == 0) return TF_OK;
+    if (!d_nodes || (n_cols && !d_table)) return TF_ERR_NULL_POINTER;
+    if (n_cols * size_t(width) >= (size_t(1) << 31) || col_stride < n_rows * size_t(width)) return TF_ERR_LEN_TOO_LARGE;
+    DeviceCtx* ctx = nullptr;
+    rc = current_ctx(&ctx);
+    if (rc) return rc;
+    rc = ensure_tip5(ctx);
+    if (rc) return rc;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const long long N = (long long)n_rows;
+    rc = launch_hash_table_rows(d_table, N, (long long)n_cols, width, (long long)col_stride, (long long)(n_cols * col_stride),
+                                (long long)batch, d_nodes + 5 * N, 10 * N, s);
+    if (rc) return rc;
+    return merkle_levels_in_place(d_nodes, N, batch, s);
+}
+
 // Rows of a row-major table -> leaf digests (hash_varlen per row, tip5/mod.rs:617-623) -> Merkle tree, without the
 // leaves ever leaving HBM.  rows: batch x n_rows x row_len words.
 int merkle_from_rows_dev(const u64* d_rows, size_t row_len, size_t n_rows, u64* d_nodes, size_t batch, void* stream) {
@@ -1712,6 +1767,14 @@ int tf_coset_extrapolate_xfe_dev(uint64_t offset, const uint64_t* cw, size_t n, 
                                  uint64_t* out, void* stream) {
     return coset_extrapolate_dev(offset, cw, n, batch, pts, np, out, 3, stream);
 }
+int tf_tip5_hash_table_rows_dev(const uint64_t* d_table, size_t n_rows, size_t n_cols, int width, size_t col_stride, uint64_t* d_digests,
+                                size_t batch, void* stream) {
+    return hash_table_rows_dev(d_table, n_rows, n_cols, width, col_stride, d_digests, batch, stream);
+}
+int tf_merkle_from_columns_dev(const uint64_t* d_table, size_t n_rows, size_t n_cols, int width, size_t col_stride, uint64_t* d_nodes,
+                               size_t batch, void* stream) {
+    return merkle_from_columns_dev(d_table, n_rows, n_cols, width, col_stride, d_nodes, batch, stream);
+}
 int tf_merkle_from_rows_dev(const uint64_t* d_rows, size_t row_len, size_t n_rows, uint64_t* d_nodes, size_t batch, void* stream) {
     return merkle_from_rows_dev(d_rows, row_len, n_rows, d_nodes, batch, stream);
 }
@@ -1785,6 +1848,24 @@ int tf_coset_extrapolate_bfe(uint64_t offset, const uint64_t* cw, size_t n, size
 }
 int tf_coset_extrapolate_xfe(uint64_t offset, const uint64_t* cw, size_t n, size_t batch, const uint64_t* pts, size_t np, uint64_t* out) {
     return coset_extrapolate_host(offset, cw, n, batch, pts, np, out, 3);
+}
+int tf_tip5_hash_table_rows(const uint64_t* table, size_t n_rows, size_t n_cols, int width, size_t col_stride, uint64_t* digests,
+                            size_t batch) {
+    if (width != 1 && width != 3) return TF_ERR_NULL_POINTER;
+    if (n_rows == 0 || batch == 0) return TF_OK;
+    if (!digests || (n_cols && !table)) return TF_ERR_NULL_POINTER;
+    return host_roundtrip(table, batch * n_cols * col_stride, nullptr, 0, digests, batch * n_rows * 5,
+                          [&](u64* dt, u64*, u64* o, hipStream_t s) { return hash_table_rows_dev(dt, n_rows, n_cols, width, col_stride, o, batch, s); });
+}
+int tf_merkle_from_columns(const uint64_t* table, size_t n_rows, size_t n_cols, int width, size_t col_stride, uint64_t* nodes_out,
+                           size_t batch) {
+    if (width != 1 && width != 3) return TF_ERR_NULL_POINTER;
+    int rc = check_leaves(n_rows);
+    if (rc) return rc;
+    if (batch == 0) return TF_OK;
+    if (!nodes_out || (n_cols && !table)) return TF_ERR_NULL_POINTER;
+    return host_roundtrip(table, batch * n_cols * col_stride, nullptr, 0, nodes_out, batch * n_rows * 10,
+                          [&](u64* dt, u64*, u64* o, hipStream_t s) { return merkle_from_columns_dev(dt, n_rows, n_cols, width, col_stride, o, batch, s); });
 }
 int tf_merkle_from_rows(const uint64_t* rows, size_t row_len, size_t n_rows, uint64_t* nodes_out, size_t batch) {
     TRY(check_leaves(n_rows));

@@ -174,6 +174,45 @@ __global__ void __launch_bounds__(256) tip5_hash_varlen_rows_kernel(const u64* r
     for (int k = 0; k < 5; ++k) o[k] = s[k];
 }
 
+// hash_varlen of every ROW of a COLUMN-MAJOR table: column j is n_rows contiguous elements of `width` words (1 =
+// BFieldElement, 3 = XFieldElement, flattened as x_field_element.rs:217-231) starting at table + j * col_stride; row i is
+// the concatenation over the columns of element i's words.  This is the layout a batch of coset evaluations leaves in HBM
+// (one codeword per column), and the lanes -- one row each -- read every column coalesced.
+// Word w of a row is word (w % width) of the element in column w / width.
+__device__ __forceinline__ u64 table_word(const u64* table, long long i, long long w, int width, long long col_stride) {
+    const long long j = width == 1 ? w : (long long)(((unsigned long long)w * 0xAAAAAAABull) >> 33);  // w / 3 for w < 2^31
+    const long long k = w - j * width;
+    return table[j * col_stride + i * width + k];
+}
+
+__global__ void __launch_bounds__(256) tip5_hash_table_rows_kernel(const u64* table, long long n_rows, long long n_cols, int width,
+                                                                   long long col_stride, long long table_stride, long long total,
+                                                                   u64* out, long long out_ts) {
+    __shared__ __attribute__((aligned(16))) unsigned char lut[256];
+    stage_lut(lut);
+    const long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= total) return;
+    const long long tree = id / n_rows, i = id - tree * n_rows;
+    const u64* tb = table + tree * table_stride;
+    const long long row_len = n_cols * width;
+    u64 s[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s[k] = 0;  // Domain::VariableLength
+    const long long full = row_len / 10;
+    for (long long c = 0; c < full; ++c) {
+#pragma unroll
+        for (int k = 0; k < 10; ++k) s[k] = table_word(tb, i, c * 10 + k, width, col_stride);  // overwrite-mode absorb, mod.rs:684-691
+        tip5_permutation(s, lut);
+    }
+    const int rem = (int)(row_len - full * 10);
+#pragma unroll
+    for (int k = 0; k < 10; ++k) s[k] = (k < rem) ? table_word(tb, i, full * 10 + k, width, col_stride) : ((k == rem) ? gl::ONE : 0);
+    tip5_permutation(s, lut);
+    u64* o = out + tree * out_ts + i * 5;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) o[k] = s[k];
+}
+
 // ---- cooperative form: the 16 lanes of a DPP row hold the 16 state words of ONE permutation ------------------
 // The lane-per-permutation kernels above are throughput-optimal but one permutation is a dependent chain of ~8 200
 // instructions (~19 us), which is what every level of a Merkle tree with fewer nodes than the GPU has lanes costs.
@@ -262,6 +301,30 @@ __global__ void __launch_bounds__(256) tip5_hash_varlen_rows_coop_kernel(const u
     tip5_permutation_coop(s, j, lut);
     const long long tree = i / per_tree;
     if (j < 5) out[tree * out_ts + (i - tree * per_tree) * 5 + j] = s;
+}
+
+// the same for few rows: 16 lanes per row
+__global__ void __launch_bounds__(256) tip5_hash_table_rows_coop_kernel(const u64* table, long long n_rows, long long n_cols, int width,
+                                                                        long long col_stride, long long table_stride, long long total,
+                                                                        u64* out, long long out_ts) {
+    __shared__ __attribute__((aligned(16))) unsigned char lut[256];
+    stage_lut(lut);
+    const int j = threadIdx.x & 15;
+    const long long id = (long long)blockIdx.x * 16 + (threadIdx.x >> 4);
+    if (id >= total) return;
+    const long long tree = id / n_rows, i = id - tree * n_rows;
+    const u64* tb = table + tree * table_stride;
+    const long long row_len = n_cols * width;
+    u64 s = 0;
+    const long long full = row_len / 10;
+    for (long long c = 0; c < full; ++c) {
+        if (j < 10) s = table_word(tb, i, c * 10 + j, width, col_stride);
+        tip5_permutation_coop(s, j, lut);
+    }
+    const int rem = (int)(row_len - full * 10);
+    if (j < 10) s = (j < rem) ? table_word(tb, i, full * 10 + j, width, col_stride) : ((j == rem) ? gl::ONE : 0);
+    tip5_permutation_coop(s, j, lut);
+    if (j < 5) out[tree * out_ts + i * 5 + j] = s;
 }
 
 // Tip5::permutation of state i by row-group i

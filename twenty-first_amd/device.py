@@ -155,3 +155,17 @@ def coset_extrapolate(offset_raw: int, codewords, n: int, points, out, batch: in
         raise ValueError("buffer sizes do not match n/batch/points/width")
     fn = _lib.lib().tf_coset_extrapolate_bfe_dev if width == 1 else _lib.lib().tf_coset_extrapolate_xfe_dev
     _chk(fn(C.c_uint64(offset_raw), _p(codewords), n, batch, _p(points), n_points, _p(out), _stream(stream)), "batch_coset_extrapolate")
+
+
+def hash_table_rows(table, n_rows: int, n_cols: int, out, width: int = 1, col_stride=None, batch: int = 1, stream=None) -> None:
+    """hash_varlen of every row of `batch` column-major tables resident in HBM (column j at table + j * col_stride words)."""
+    table, out = _t(table, "table"), _t(out, "out")
+    cs = n_rows * width if col_stride is None else col_stride
+    _chk(_lib.lib().tf_tip5_hash_table_rows_dev(_p(table), n_rows, n_cols, width, cs, _p(out), batch, _stream(stream)), "Tip5::hash_varlen")
+
+
+def merkle_from_columns(table, n_rows: int, n_cols: int, nodes_out, width: int = 1, col_stride=None, batch: int = 1, stream=None) -> None:
+    """Rows of column-major tables -> leaves -> trees (nodes_out: batch x 2 n_rows digests), all in HBM."""
+    table, nodes_out = _t(table, "table"), _t(nodes_out, "nodes_out")
+    cs = n_rows * width if col_stride is None else col_stride
+    _chk(_lib.lib().tf_merkle_from_columns_dev(_p(table), n_rows, n_cols, width, cs, _p(nodes_out), batch, _stream(stream)), "MerkleTree::par_new")

@@ -159,6 +159,9 @@ int main() {
         for (uint64_t i = 0; i < 8 * 3; ++i) rows.push_back(BFieldElement::new_(i));
         MerkleTree tree = MerkleTree::from_rows(rows, 3);
         for (size_t i = 0; i < 8; ++i) EXPECT(*tree.leaf(i) == Tip5::hash_varlen(std::vector<BFieldElement>(rows.begin() + 3 * i, rows.begin() + 3 * i + 3)));
+        std::vector<BFieldElement> cols(rows.size());  // the same table column-major: column j = (rows[i * 3 + j])_i
+        for (size_t i = 0; i < 8; ++i) for (size_t j = 0; j < 3; ++j) cols[j * 8 + i] = rows[i * 3 + j];
+        EXPECT(MerkleTree::from_columns(cols, 8).nodes == tree.nodes);
         auto auth = tree.authentication_structure({0, 5});
         // needed: siblings 9, 12 and uncles 5, 7 minus computable ones -> {12, 9, 7, 5} descending (merkle_tree.rs:493-503)
         EXPECT(auth.size() == 4 && auth[0] == tree.nodes[12] && auth[1] == tree.nodes[9] && auth[2] == tree.nodes[7] && auth[3] == tree.nodes[5]);

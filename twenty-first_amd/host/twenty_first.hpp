@@ -266,6 +266,17 @@ struct MerkleTree {
         check(tf_merkle_from_rows(reinterpret_cast<const uint64_t*>(rows.data()), row_len, n_rows, reinterpret_cast<uint64_t*>(t.nodes.data()), 1), "MerkleTree::par_new");
         return t;
     }
+    // rows taken across a column-major table: `columns` = n_cols columns of n_rows elements back to back (one codeword each)
+    template <class FF>
+    static MerkleTree from_columns(const std::vector<FF>& columns, size_t n_rows) {
+        constexpr int width = sizeof(FF) / 8;
+        const size_t n_cols = n_rows ? columns.size() / n_rows : 0;
+        MerkleTree t;
+        t.nodes.resize(2 * n_rows + (n_rows ? 0 : 1));
+        check(tf_merkle_from_columns(reinterpret_cast<const uint64_t*>(columns.data()), n_rows, n_cols, width, n_rows * width,
+                                     reinterpret_cast<uint64_t*>(t.nodes.data()), 1), "MerkleTree::par_new");
+        return t;
+    }
     // authentication_structure (:614-622) over authentication_structure_node_indices (:449-504)
     std::vector<Digest> authentication_structure(const std::vector<size_t>& leaf_indices) const {
         std::vector<uint64_t> li(leaf_indices.begin(), leaf_indices.end()), idx(leaf_indices.size() * 64 + 1);
