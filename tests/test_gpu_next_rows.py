@@ -315,3 +315,34 @@ def test_column_major_tables_on_device_with_stride_and_batch(tf, oracle):
         want = oracle.hash_varlen_rows(rows, n_cols * width)
         assert np.array_equal(gd[b * 5 * n_rows:(b + 1) * 5 * n_rows], want)
         assert np.array_equal(gn[b * 10 * n_rows:(b + 1) * 10 * n_rows], oracle.merkle_build(want))
+
+
+@pytest.mark.parametrize("width", [1, 3])
+def test_device_resident_commitment_pipeline(tf, oracle, width):
+    """The callers on either side of the path chained in HBM: 6 columns of 2^10 values on the coset
+    1 * <w> -> low-degree extension to 2^12 points on 7 * <w'> (one codeword per column) -> hash_varlen of every row of that
+    column-major table -> Merkle tree -> authentication structure; every stage against the oracle."""
+    import torch
+
+    n, m, n_cols = 1 << 10, 1 << 12, 6
+    one, seven = oracle.bfe_new(1), oracle.bfe_new(7)
+    vals = oracle.fill_random(n_cols * n * width, 88 + width)
+    d_vals = torch.from_numpy(vals.view(np.int64)).cuda()
+    ext = torch.empty(n_cols * m * width, dtype=torch.int64, device="cuda")
+    nodes = torch.empty(10 * m, dtype=torch.int64, device="cuda")
+    tf.device.lde(d_vals, n, one, ext, m, seven, batch=n_cols, width=width)
+    tf.device.merkle_from_columns(ext, m, n_cols, nodes, width=width)
+    torch.cuda.synchronize()
+    want_cols = []
+    for j in range(n_cols):
+        co = oracle.coset_interpolate(vals[j * n * width:(j + 1) * n * width], one, width=width)
+        want_cols.append(oracle.coset_evaluate(co, seven, m, width=width))
+    want_ext = np.concatenate(want_cols)
+    assert np.array_equal(ext.cpu().numpy().view(np.uint64), want_ext)
+    rows = want_ext.reshape(n_cols, m, width).transpose(1, 0, 2).reshape(-1)
+    want_nodes = oracle.merkle_build(oracle.hash_varlen_rows(rows, n_cols * width))
+    assert np.array_equal(nodes.cpu().numpy().view(np.uint64), want_nodes)
+    idx = [5, 77, 4095, 2048]
+    got_auth = tf.device.authentication_structure(nodes, m, idx)
+    want_idx = oracle.auth_structure_indices(m, idx)
+    assert np.array_equal(got_auth, want_nodes.reshape(2 * m, 5)[np.asarray(want_idx, dtype=np.int64)])
