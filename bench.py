@@ -312,6 +312,33 @@ def side_measurements(tf, torch, dev):
         extra["xfe_coset_eval_16x2p22"] = {"ms": round(ms, 3), "gfelts_per_s": round(n * b / ms / 1e6, 3),
                                           "hbm_frac_at_48B_per_point": round(48.0 * n * b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
         del c, o
+        # the callers on either side of the path, device-resident
+        def _timed(fn, reps=8):
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(reps):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / reps
+
+        nh = 1 << 19
+        pa, pb = synth_words(256 * nh, dev, 6), synth_words(256 * nh, dev, 7)
+        po = torch.empty(256 * (2 * nh - 1), dtype=torch.int64, device=dev)
+        ms = _timed(lambda: tf.device.poly_mul(pa, nh, pb, nh, po, batch=256))
+        extra["fast_multiply_256x_2p19_by_2p19"] = {"ms": round(ms, 3), "output_coefficients_per_s": round(256 * (2 * nh - 1) / ms * 1e3, 1)}
+        del pa, pb, po
+        lv = synth_words(128 * (1 << 18), dev, 8)
+        lo = torch.empty(128 * (1 << 21), dtype=torch.int64, device=dev)
+        ms = _timed(lambda: tf.device.lde(lv, 1 << 18, tf.BFieldElement.new(1), lo, 1 << 21, off, batch=128))
+        extra["lde_128x_2p18_to_2p21"] = {"ms": round(ms, 3), "g_points_per_s": round(128 * (1 << 21) / ms / 1e6, 3)}
+        # the 128 codewords are now a column-major table of 2^21 rows: hash every row, build the tree
+        tn = torch.empty(10 * (1 << 21), dtype=torch.int64, device=dev)
+        ms = _timed(lambda: tf.device.merkle_from_columns(lo, 1 << 21, 128, tn))
+        extra["merkle_from_columns_2p21_rows_x128"] = {"ms": round(ms, 3), "rows_per_s": round((1 << 21) / ms * 1e3, 1)}
+        del lv, lo, tn
         # PCIe-inclusive figure of the host-pointer entry point (pageable numpy buffers, 32 x 2^20 BFE = 256 MiB each way)
         import time as _t
 
