@@ -346,3 +346,14 @@ def test_device_resident_commitment_pipeline(tf, oracle, width):
     got_auth = tf.device.authentication_structure(nodes, m, idx)
     want_idx = oracle.auth_structure_indices(m, idx)
     assert np.array_equal(got_auth, want_nodes.reshape(2 * m, 5)[np.asarray(want_idx, dtype=np.int64)])
+
+
+@pytest.mark.parametrize("width,na,nb", [(1, 20000, 12769), (1, 40000, 50000), (1, (1 << 20) + 5, 1 << 20), (3, 300000, 290001), (3, 9000, 9000)])
+def test_fast_multiply_large_products(tf, oracle, width, na, nb):
+    """products whose transform length is >= 2^15: zero padding in the first pass, (BFE) the pointwise product on the
+    inverse's first load, and the truncation to na + nb - 1 coefficients inside its last pass"""
+    a = oracle.fill_random(na * width, 3 + na)
+    b = oracle.fill_random(nb * width, 4 + nb)
+    assert np.array_equal(tf.fast_multiply(a, b, width=width), oracle.poly_mul(a, b, width=width))
+    if na <= 50000:
+        assert np.array_equal(tf.fast_square(a, width=width), oracle.poly_mul(a, a, width=width))

@@ -37,6 +37,7 @@ struct NttPassArgs {
     const u64* inner_tw;   // [P2][32] Montgomery words: w_R^(+-g*k1) (times n^-1 for the last inverse pass); may be null
     const u64* post_tw;    // inter-pass twiddles T[k * tw_rs + b] (Montgomery words) or null
     const u64* pre_scale;  // coset powers S[j] (Montgomery words) or null        (polynomial.rs:760-773)
+    long long n_out;       // LAST1024 only: >= 0 = store only output elements j < n_out (truncated product); < 0: all
     const u64* in2;        // SCALE = 1 only: second operand with the layout of `in`, multiplied in on load (or null)
     const u64* post_scale; // interpolation powers offset^-j applied to output element j, or null (polynomial.rs:1907-1918)
     long long js_i0, js_i1, js_i2, js_c, js_k;  // output element index j = i0*js_i0 + i1*js_i1 + i2*js_i2 + (c/L)*js_c + k*js_k (last pass only)
@@ -134,8 +135,9 @@ __device__ __forceinline__ void dit_half(u64 (&x)[32]) {
 }
 
 // Level 5 of the radix-32 network for the four butterflies (Q0+i, Q0+i+16), i < 4, followed by their eight stores.
-template <bool INV, int Q0>
-__device__ __forceinline__ void tail_p5(u64 (&x)[32], bool act, char* obase, u32 toff, long long out_rs_bytes) {
+// TRUNC: only the slots q < qlim are stored (output truncated to the first n_out elements, fast_multiply).
+template <bool INV, int Q0, bool TRUNC = false>
+__device__ __forceinline__ void tail_p5(u64 (&x)[32], bool act, char* obase, u32 toff, long long out_rs_bytes, int qlim = 32) {
     butterfly_pow2<TwExp<INV, 5, Q0 + 0>::value>(x[Q0 + 0], x[Q0 + 16]);
     butterfly_pow2<TwExp<INV, 5, Q0 + 1>::value>(x[Q0 + 1], x[Q0 + 17]);
     butterfly_pow2<TwExp<INV, 5, Q0 + 2>::value>(x[Q0 + 2], x[Q0 + 18]);
@@ -143,8 +145,9 @@ __device__ __forceinline__ void tail_p5(u64 (&x)[32], bool act, char* obase, u32
     if (act) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            *reinterpret_cast<u64*>(obase + (long long)(32 * (Q0 + i)) * out_rs_bytes + toff) = x[Q0 + i];
-            *reinterpret_cast<u64*>(obase + (long long)(32 * (Q0 + i + 16)) * out_rs_bytes + toff) = x[Q0 + i + 16];
+            if (!TRUNC || Q0 + i < qlim) *reinterpret_cast<u64*>(obase + (long long)(32 * (Q0 + i)) * out_rs_bytes + toff) = x[Q0 + i];
+            if (!TRUNC || Q0 + i + 16 < qlim)
+                *reinterpret_cast<u64*>(obase + (long long)(32 * (Q0 + i + 16)) * out_rs_bytes + toff) = x[Q0 + i + 16];
         }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -386,6 +389,19 @@ __global__ void __launch_bounds__(512, TF_NTT_WAVES) ntt_pass_kernel(const NttPa
         dit_half<INV, 16>(x);
         const u32 toff = (u32)(((long long)ch * A.out_cs_hi + cl + (long long)g * A.out_rs) * 8);
         char* base = reinterpret_cast<char*>(out);
+        if (A.n_out >= 0) {
+            // truncated output (fast_multiply keeps the first n_out coefficients): slot q holds output element
+            // j0 + 32 q js_k; the thread stores the slots below its own limit
+            const long long j0 = (long long)i0 * A.js_i0 + (long long)i1 * A.js_i1 + (long long)i2 * A.js_i2 + (long long)ch * A.js_c +
+                                 (long long)g * A.js_k;
+            const long long rem = A.n_out - j0, step = 32 * A.js_k;
+            const int qlim = rem <= 0 ? 0 : (int)min(32ll, (rem + step - 1) / step);
+            tail_p5<INV, 0, true>(x, act, base, toff, A.out_rs * 8, qlim);
+            tail_p5<INV, 4, true>(x, act, base, toff, A.out_rs * 8, qlim);
+            tail_p5<INV, 8, true>(x, act, base, toff, A.out_rs * 8, qlim);
+            tail_p5<INV, 12, true>(x, act, base, toff, A.out_rs * 8, qlim);
+            return;
+        }
         tail_p5<INV, 0>(x, act, base, toff, A.out_rs * 8);
         tail_p5<INV, 4>(x, act, base, toff, A.out_rs * 8);
         tail_p5<INV, 8>(x, act, base, toff, A.out_rs * 8);

@@ -464,6 +464,7 @@ Launch plan_column_pass(const u64* in, u64* out, long long in_bs, long long out_
     A.ps_col = 1;
     A.col_limit = (int)Bw;
     A.n_coeffs = -1;
+    A.n_out = -1;
     {
         const int G = (nc * (int)sizeof(u64) < 128) ? 2 : 1;  // pair tiles narrower than a 128-byte line
         A.xcd_order = (A.d2 % (8 * G) == 0) ? G : ((A.d2 % 8 == 0) ? 1 : 0);
@@ -520,6 +521,7 @@ Launch plan_transpose_pass(const u64* in, u64* out, long long in_bs, long long o
     A.out_rs = N1 * Q * L;
     A.col_limit = (int)(N1 * L);
     A.n_coeffs = -1;
+    A.n_out = -1;
     A.js_i1 = N1;
     A.js_i2 = T;
     A.js_c = 1;
@@ -563,6 +565,7 @@ Launch plan_row_pass(const u64* in, u64* out, long long in_bs, long long out_bs,
     A.ps_rs = 1;
     A.ps_col = 0;
     A.n_coeffs = -1;
+    A.n_out = -1;
     A.js_k = 1;  // single pass: output element index = k
     A.xcd_order = 0;
     finish_geometry(&l, nc, p2);
@@ -673,6 +676,53 @@ int pass_count(int log_n) {  // global passes of a transform with log_n > 10
     return P;
 }
 
+// Radix split of a multi-pass plan: a[0..P-1], sum = log_n, every a[i] in [5, 10].
+void choose_split(int log_n, int P, int L, int (&a)[4]) {
+    {
+        // The last pass gets the largest radix it can (R = 1024 whenever possible: the specialised kernel with constant P2
+        // and stores fused into level 5, 128-byte output segments); the column passes share the rest evenly, larger first.
+        // Measured against the even split (tools/split3.py, 2^28 words per call): 2^15 1.92 vs 2.62 ms, 2^18 2.20 vs 2.48,
+        // 2^22 3.18 vs 3.49, 2^24 3.31 vs 4.15, 2^26 3.58 vs 3.99.
+        // XFieldElement slices (L = 3) are the exception: a last pass with R = 1024 has only 5 rows (15 word-columns) per
+        // workgroup, and the sweep prefers R = 32 (170 rows per tile) for the smaller lengths (n <= 2^15, 2^21 and 2^22) and R = 512 above.
+        int last = std::min(10, log_n - 5 * (P - 1));
+        if (L == 3 && P == 2 && log_n < 20) last = log_n <= 15 ? 5 : 9;
+        if (L == 3 && P == 3 && log_n < 30) last = log_n <= 22 ? 5 : 9;
+        a[P - 1] = last;
+        int rest = log_n - last;
+        if (L == 3 && P == 3 && log_n <= 22) {  // (log_n - 15, 10, 5)
+            a[1] = std::min(10, rest - 5);
+            a[0] = rest - a[1];
+        } else {
+            for (int i = 0; i + 1 < P; ++i) {
+                a[i] = (rest + (P - 1 - i) - 1) / (P - 1 - i);
+                rest -= a[i];
+            }
+        }
+        if (const char* e2 = exp_env("TF_NTT_SPLIT2")) {  // experiment: a0 for two-pass plans
+            const int x0 = atoi(e2);
+            if (P == 2 && x0 >= 5 && x0 <= 10 && log_n - x0 >= 5 && log_n - x0 <= 10) a[0] = x0, a[1] = log_n - x0;
+        }
+        if (const char* e = exp_env("TF_NTT_SPLIT3")) {  // experiment: "a0,a1" for three-pass plans
+            int x0 = 0, x1 = 0;
+            if (P == 3 && sscanf(e, "%d,%d", &x0, &x1) == 2 && x0 >= 5 && x0 <= 10 && x1 >= 5 && x1 <= 10 && log_n - x0 - x1 >= 5 &&
+                log_n - x0 - x1 <= 10) {
+                a[0] = x0, a[1] = x1, a[2] = log_n - x0 - x1;
+            }
+        }
+    }
+}
+
+// Can the last pass of an n-point transform truncate its output (LAST1024 kernel: two or three passes, last radix 1024)?
+bool can_truncate(size_t n, int L) {
+    if (n <= 1024 || n > (size_t(1) << 30)) return false;
+    const int log_n = ilog2(n), P = pass_count(log_n);
+    int a[4] = {0, 0, 0, 0};
+    choose_split(log_n, P, L, a);
+    static const bool no_last1024 = getenv("TF_NTT_NO_LAST1024") != nullptr;
+    return P <= 3 && a[P - 1] == 10 && !no_last1024;
+}
+
 // The transform proper.  in/out are device pointers; in == out for ntt/intt, distinct for coset evaluation
 // (then pre_scale != null and rows >= n_coeffs read as zero).  in_bs/out_bs: words per polynomial.
 // cosets = C > 1 (forward coset evaluation only, n > 1024): the output has C * n points per polynomial,
@@ -681,7 +731,9 @@ int pass_count(int log_n) {  // global passes of a transform with log_n > 10
 // reads the coefficients once per c and writes rows (k_1, c); from there on it is the ordinary plan with N_1 * C rows.
 int run_ntt(DeviceCtx* ctx, const u64* in, u64* out, long long in_bs, long long out_bs, size_t n, size_t batch, int L,
             bool inverse, const u64* pre_scale, long long n_coeffs, hipStream_t stream, const u64* post_scale = nullptr,
-            size_t cosets = 1, const u64* in2 = nullptr) {
+            size_t cosets = 1, const u64* in2 = nullptr, long long n_out = -1) {
+    // n_out >= 0 (only with can_truncate(n, L)): the last pass stores output elements j < n_out only and out_bs may be
+    // n_out * L -- the truncation of fast_multiply without a copy; `in` is then used as work space and clobbered
     if (n == 0 || batch == 0) return TF_OK;
     const int log_n = ilog2(n);
     int rc;
@@ -731,39 +783,7 @@ int run_ntt(DeviceCtx* ctx, const u64* in, u64* out, long long in_bs, long long 
     // scatters output digit k_P to  k_1 + N_1 k_2 + ... + N_1..N_{P-1} k_P  (natural order).
     int a[4] = {0, 0, 0, 0};
     const int P = pass_count(log_n);
-    {
-        // The last pass gets the largest radix it can (R = 1024 whenever possible: the specialised kernel with constant P2
-        // and stores fused into level 5, 128-byte output segments); the column passes share the rest evenly, larger first.
-        // Measured against the even split (tools/split3.py, 2^28 words per call): 2^15 1.92 vs 2.62 ms, 2^18 2.20 vs 2.48,
-        // 2^22 3.18 vs 3.49, 2^24 3.31 vs 4.15, 2^26 3.58 vs 3.99.
-        // XFieldElement slices (L = 3) are the exception: a last pass with R = 1024 has only 5 rows (15 word-columns) per
-        // workgroup, and the sweep prefers R = 32 (170 rows per tile) for the smaller lengths (n <= 2^15, 2^21 and 2^22) and R = 512 above.
-        int last = std::min(10, log_n - 5 * (P - 1));
-        if (L == 3 && P == 2 && log_n < 20) last = log_n <= 15 ? 5 : 9;
-        if (L == 3 && P == 3 && log_n < 30) last = log_n <= 22 ? 5 : 9;
-        a[P - 1] = last;
-        int rest = log_n - last;
-        if (L == 3 && P == 3 && log_n <= 22) {  // (log_n - 15, 10, 5)
-            a[1] = std::min(10, rest - 5);
-            a[0] = rest - a[1];
-        } else {
-            for (int i = 0; i + 1 < P; ++i) {
-                a[i] = (rest + (P - 1 - i) - 1) / (P - 1 - i);
-                rest -= a[i];
-            }
-        }
-        if (const char* e2 = exp_env("TF_NTT_SPLIT2")) {  // experiment: a0 for two-pass plans
-            const int x0 = atoi(e2);
-            if (P == 2 && x0 >= 5 && x0 <= 10 && log_n - x0 >= 5 && log_n - x0 <= 10) a[0] = x0, a[1] = log_n - x0;
-        }
-        if (const char* e = exp_env("TF_NTT_SPLIT3")) {  // experiment: "a0,a1" for three-pass plans
-            int x0 = 0, x1 = 0;
-            if (P == 3 && sscanf(e, "%d,%d", &x0, &x1) == 2 && x0 >= 5 && x0 <= 10 && x1 >= 5 && x1 <= 10 && log_n - x0 - x1 >= 5 &&
-                log_n - x0 - x1 <= 10) {
-                a[0] = x0, a[1] = x1, a[2] = log_n - x0 - x1;
-            }
-        }
-    }
+    choose_split(log_n, P, L, a);
     const u64* inner[4] = {nullptr, nullptr, nullptr, nullptr};
     for (int i = 0; i < P; ++i) {
         rc = get_inner_table(ctx, a[i], inverse, (i == P - 1 && inverse) ? log_n : 0, &inner[i]);  // n^-1 rides on the last pass
@@ -813,8 +833,10 @@ int run_ntt(DeviceCtx* ctx, const u64* in, u64* out, long long in_bs, long long 
         for (int i = 0; i + 1 < P && rc == TF_OK; ++i) {
             B >>= a[i];
             const bool to_scratch = i == P - 2;
-            u64* dst = to_scratch ? scratch : tout;
-            const long long dst_bs = to_scratch ? sbs : out_bs;
+            // a truncated output (n_out >= 0) is smaller than the transform: the middle passes then work in place on the
+            // INPUT, which the caller gives up (fast_multiply's temporary)
+            u64* dst = to_scratch ? scratch : (n_out >= 0 ? const_cast<u64*>(tin) : tout);
+            const long long dst_bs = to_scratch ? sbs : (n_out >= 0 ? in_bs : out_bs);
             Launch p = plan_column_pass(src, dst, src_bs, dst_bs, nb, (i == 0) ? (long long)cosets : outer, a[i], B, L);
             p.a.inner_tw = inner[i];
             p.a.post_tw = post[i];
@@ -840,6 +862,7 @@ int run_ntt(DeviceCtx* ctx, const u64* in, u64* out, long long in_bs, long long 
             Launch pl = plan_transpose_pass(scratch, tout, sbs, out_bs, nb, a[P - 1], N[0] * (long long)cosets, P == 3 ? N[1] : 1, L);
             pl.a.inner_tw = inner[P - 1];
             pl.a.post_scale = post_scale;
+            pl.a.n_out = n_out;
             rc = launch_pass(pl, inverse, stream);
         } else {
             for (size_t b = 0; b < nb && rc == TF_OK; ++b) {
@@ -1241,17 +1264,24 @@ int poly_mul_dev(const u64* a, size_t na, const u64* b, size_t nb, u64* out, siz
     hipError_t e = hipMallocAsync(reinterpret_cast<void**>(&tmp), 2 * half * sizeof(u64), s);
     if (e != hipSuccess) return hip_fail(e, "hipMallocAsync(poly_mul)", __FILE__, __LINE__);
     static const bool no_fuse = getenv("TF_POLY_MUL_NO_FUSE") != nullptr;  // A/B switch
+    bool copied = false;
     if (order > 16 && !no_fuse) {
         // zero padding happens in the first pass of each forward transform (rows beyond the coefficients read as zero);
         // over BFieldElement the pointwise product rides on the inverse transform's first load
         rc = run_ntt(ctx, a, tmp, (long long)na * L, (long long)order * L, order, batch, L, false, nullptr, (long long)na, s);
         if (!rc) rc = run_ntt(ctx, b, tmp + half, (long long)nb * L, (long long)order * L, order, batch, L, false, nullptr, (long long)nb, s);
+        const bool trunc = can_truncate(order, L);  // the inverse's last pass writes the n_out coefficients straight to `out`
+        u64* dst = trunc ? out : tmp;
+        const long long dst_bs = trunc ? (long long)n_out * L : (long long)order * L;
         if (!rc && L == 1) {
-            rc = run_ntt(ctx, tmp, tmp, (long long)order, (long long)order, order, batch, 1, true, nullptr, -1, s, nullptr, 1, tmp + half);
+            rc = run_ntt(ctx, tmp, dst, (long long)order, dst_bs, order, batch, 1, true, nullptr, -1, s, nullptr, 1, tmp + half,
+                         trunc ? (long long)n_out : -1);
         } else if (!rc) {
             rc = hadamard_dev(tmp, tmp + half, tmp, batch * order, L, s);
-            if (!rc) rc = run_ntt(ctx, tmp, tmp, (long long)order * L, (long long)order * L, order, batch, L, true, nullptr, -1, s);
+            if (!rc) rc = run_ntt(ctx, tmp, dst, (long long)order * L, dst_bs, order, batch, L, true, nullptr, -1, s, nullptr, 1, nullptr,
+                                  trunc ? (long long)n_out : -1);
         }
+        copied = trunc;
     } else {
         rc = pad_copy(a, tmp, (long long)na * L, (long long)order * L, (long long)batch, s);
         if (!rc) rc = pad_copy(b, tmp + half, (long long)nb * L, (long long)order * L, (long long)batch, s);
@@ -1259,7 +1289,7 @@ int poly_mul_dev(const u64* a, size_t na, const u64* b, size_t nb, u64* out, siz
         if (!rc) rc = hadamard_dev(tmp, tmp + half, tmp, batch * order, L, s);
         if (!rc) rc = run_ntt(ctx, tmp, tmp, (long long)order * L, (long long)order * L, order, batch, L, true, nullptr, -1, s);
     }
-    if (!rc) rc = pad_copy(tmp, out, (long long)order * L, (long long)n_out * L, (long long)batch, s);
+    if (!rc && !copied) rc = pad_copy(tmp, out, (long long)order * L, (long long)n_out * L, (long long)batch, s);
     hipError_t e2 = hipFreeAsync(tmp, s);
     if (rc) return rc;
     if (e2 != hipSuccess) return hip_fail(e2, "hipFreeAsync", __FILE__, __LINE__);
@@ -1284,21 +1314,28 @@ int poly_square_dev(const u64* a, size_t na, u64* out, size_t batch, int L, void
     hipError_t e = hipMallocAsync(reinterpret_cast<void**>(&tmp), words * sizeof(u64), s);
     if (e != hipSuccess) return hip_fail(e, "hipMallocAsync(poly_square)", __FILE__, __LINE__);
     static const bool no_fuse = getenv("TF_POLY_MUL_NO_FUSE") != nullptr;  // A/B switch
+    bool copied = false;
     if (order > 16 && !no_fuse) {
         rc = run_ntt(ctx, a, tmp, (long long)na * L, (long long)order * L, order, batch, L, false, nullptr, (long long)na, s);
+        const bool trunc = can_truncate(order, L);
+        u64* dst = trunc ? out : tmp;
+        const long long dst_bs = trunc ? (long long)n_out * L : (long long)order * L;
         if (!rc && L == 1) {
-            rc = run_ntt(ctx, tmp, tmp, (long long)order, (long long)order, order, batch, 1, true, nullptr, -1, s, nullptr, 1, tmp);
+            rc = run_ntt(ctx, tmp, dst, (long long)order, dst_bs, order, batch, 1, true, nullptr, -1, s, nullptr, 1, tmp,
+                         trunc ? (long long)n_out : -1);
         } else if (!rc) {
             rc = hadamard_dev(tmp, tmp, tmp, batch * order, L, s);
-            if (!rc) rc = run_ntt(ctx, tmp, tmp, (long long)order * L, (long long)order * L, order, batch, L, true, nullptr, -1, s);
+            if (!rc) rc = run_ntt(ctx, tmp, dst, (long long)order * L, dst_bs, order, batch, L, true, nullptr, -1, s, nullptr, 1, nullptr,
+                                  trunc ? (long long)n_out : -1);
         }
+        copied = trunc;
     } else {
         rc = pad_copy(a, tmp, (long long)na * L, (long long)order * L, (long long)batch, s);
         if (!rc) rc = run_ntt(ctx, tmp, tmp, (long long)order * L, (long long)order * L, order, batch, L, false, nullptr, -1, s);
         if (!rc) rc = hadamard_dev(tmp, tmp, tmp, batch * order, L, s);
         if (!rc) rc = run_ntt(ctx, tmp, tmp, (long long)order * L, (long long)order * L, order, batch, L, true, nullptr, -1, s);
     }
-    if (!rc) rc = pad_copy(tmp, out, (long long)order * L, (long long)n_out * L, (long long)batch, s);
+    if (!rc && !copied) rc = pad_copy(tmp, out, (long long)order * L, (long long)n_out * L, (long long)batch, s);
     hipError_t e2 = hipFreeAsync(tmp, s);
     if (rc) return rc;
     if (e2 != hipSuccess) return hip_fail(e2, "hipFreeAsync", __FILE__, __LINE__);
