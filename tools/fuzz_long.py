@@ -42,7 +42,8 @@ while time.time() < t_end:
         v = oracle.fill_random(n * width, rng.getrandbits(40))
         assert np.array_equal(tf.fast_coset_interpolate(v, off, width=width), oracle.coset_interpolate(v, off, width=width)), (kind, log_n, width)
     elif kind == "mul":
-        na, nb = rng.randint(1, 3000), rng.randint(1, 3000)
+        big = rng.random() < 0.25
+        na, nb = (rng.randint(1, 70000), rng.randint(1, 70000)) if big else (rng.randint(1, 3000), rng.randint(1, 3000))
         a = oracle.fill_random(na * width, rng.getrandbits(40)); b = oracle.fill_random(nb * width, rng.getrandbits(40))
         got = tf.fast_multiply(a, b, width=width)
         assert np.array_equal(got, oracle.poly_mul(a, b, width=width)), (kind, na, nb, width)
@@ -108,7 +109,7 @@ while time.time() < t_end:
         got = tf.device.authentication_structure(dn, n, idx)
         assert np.array_equal(got, nodes[np.asarray(want_idx, dtype=np.int64)].reshape(-1, 5)), (kind, h, len(idx))
     elif kind == "square":
-        na = rng.randint(1, 4000)
+        na = rng.randint(1, 60000) if rng.random() < 0.25 else rng.randint(1, 4000)
         a = oracle.fill_random(na * width, rng.getrandbits(40))
         assert np.array_equal(tf.fast_square(a, width=width), oracle.poly_mul(a, a, width=width)), (kind, na, width)
     bump(kind)
