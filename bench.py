@@ -137,6 +137,21 @@ def main():
     # of 25 passes until two consecutive windows agree within 2 % (at least 4 windows, at most 40), then the W warmup steps.
     settle = 0
     sclk_before = tf.lib().tf_debug_sclk_mhz()
+
+    def copy_gbs():
+        """Platform sanity reference: a plain 2 GiB device copy (read + write), GB/s."""
+        y = torch.empty_like(x)
+        y.copy_(x)
+        torch.cuda.synchronize()
+        c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        c0.record()
+        for _ in range(3):
+            y.copy_(x)
+        c1.record()
+        torch.cuda.synchronize()
+        return 3 * 2 * x.numel() * 8 / (c0.elapsed_time(c1) * 1e-3) / 1e9
+
+    copy_before = copy_gbs()
     if not args.no_settle:
         prev = None
         for w in range(40):
@@ -180,6 +195,7 @@ def main():
     torch.cuda.synchronize()
     step_ms = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(10))
     sclk_after = tf.lib().tf_debug_sclk_mhz()
+    copy_after = copy_gbs()
     barrier()
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -252,6 +268,8 @@ def main():
                           "note": "10 extra steps with an event each, after the timed region"},
         "settle_steps": settle,
         "sclk_mhz": {"before_settle": round(sclk_before, 0), "after_timed_region": round(sclk_after, 0)},
+        "device_copy_gbs": {"before_settle": round(copy_before, 0), "after_timed_region": round(copy_after, 0),
+                            "note": "torch copy of the 2 GiB workload buffer, read + write: a platform reference (normally ~4500-5000)"},
     }
 
     if rank == 0:
