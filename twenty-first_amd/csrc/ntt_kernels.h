@@ -261,11 +261,7 @@ __global__ void __launch_bounds__(512, TF_NTT_WAVES) ntt_pass_kernel(const NttPa
                 const long long j = (ur + g) * A.ps_rs + (A.ps_col ? bcol : 0);
                 if (A.n_coeffs < 0 || j < A.n_coeffs) x[q] = *ptr;  // rows beyond the coefficients read as zero; scaled below
             } else {
-#ifdef TF_NT
-                x[q] = __builtin_nontemporal_load(ptr);
-#else
                 x[q] = *ptr;
-#endif
             }
         }
     }
@@ -476,11 +472,7 @@ __global__ void __launch_bounds__(512, TF_NTT_WAVES) ntt_pass_kernel(const NttPa
 #pragma unroll
             for (int q = 0; q < 32; ++q) {
                 const long long uk = (long long)(((q >> p2) << p2) + ((q & (P2 - 1)) << 5));
-#ifdef TF_NT
-                __builtin_nontemporal_store(x[q], reinterpret_cast<u64*>(base + uk * A.out_rs * 8 + toff));
-#else
                 *reinterpret_cast<u64*>(base + uk * A.out_rs * 8 + toff) = x[q];
-#endif
             }
         }
     }
