@@ -617,6 +617,15 @@ int launch_pass(const Launch& l, bool inverse, hipStream_t stream) {
         const char* e = getenv("TF_NTT_ABLATE");
         g_ablate = e ? atoi(e) : 0;
     }
+    if (l.a.n_out >= 0) {  // only the plain R = 1024 last-pass kernel truncates; anything else would overrun the caller's buffer
+        static const bool no_l1024 = getenv("TF_NTT_NO_LAST1024") != nullptr;
+        const bool ok = l.a.p2 == 5 && !l.a.post_tw && !l.a.gfast && !l.a.pre_scale && l.a.n_coeffs < 0 && !l.a.in2 && !l.a.post_scale &&
+                        g_ablate == 0 && !no_l1024;
+        if (!ok) {
+            t_last_error = "internal: truncated output requested from a pass that cannot truncate";
+            return TF_ERR_HIP;
+        }
+    }
     if (l.a.pre_scale || l.a.n_coeffs >= 0 || l.a.in2) {
         // work on load: coset scaling, zero padding, or the pointwise product with a second operand (forward or inverse;
         // constant-P2 variant for a forward first pass with R = 1024)
