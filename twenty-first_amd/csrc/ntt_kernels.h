@@ -485,6 +485,122 @@ __global__ void __launch_bounds__(512, TF_NTT_WAVES) ntt_pass_kernel(const NttPa
     }
 }
 
+// ---- 2^11 <= n <= 2^14, contiguous BFieldElement transforms: the WHOLE transform in one workgroup pass --------------
+// 16 384 elements are exactly one 512-thread tile, so n = 32 * 32 * P3 (P3 = 2 .. 16) runs as three register stages joined by
+// two LDS exchanges and touches HBM once instead of twice:
+//   stage A  thread (tr, rest = j2 P3 + j3): radix 32 over j1 (loads at stride n/32, lanes along `rest`: contiguous),
+//            times w_n^(k1 rest);
+//   exchange 1 (two rounds, by (tr, j3) pair);  stage B  thread (tr, j3, k1): radix 32 over j2, times w_{32 P3}^(k2 j3);
+//   exchange 2 (two rounds, by k1 half);        stage C  thread (tr, s, k1): radix P3 over j3 for its 32 / P3 values of k2;
+//   store X[k1 + 32 k2 + 1024 k3], lanes along k1: contiguous.
+// Both exchange layouts give every half-wave distinct 8-byte bank pairs (strides = 1 mod 32 between the lanes of a role).
+struct NttBlockArgs {
+    const u64* in;
+    u64* out;
+    const u64* tw1;   // [32][n / 32]: w_n^(k1 * rest)            (inverse: w^-1)
+    const u64* tw2;   // [32][P3]:     w_{32 P3}^(k2 * j3) (* n^-1 for the inverse)
+    long long total_transforms;
+};
+
+template <int LOGP3, bool INV>
+__global__ void __launch_bounds__(512, 4) ntt_block_kernel(const NttBlockArgs A) {
+    constexpr int P3 = 1 << LOGP3, N = 1024 << LOGP3, REST = 32 << LOGP3, T = 16 >> LOGP3;
+    constexpr int PS1 = 1056 + 32 / P3;      // exchange 1: pair slot stride (k1 * 33 + j2 inside a slot)
+    constexpr int KS2 = 32 * P3 + 1;         // exchange 2: stride between k1 (k2 * P3 + j3 inside)
+    extern __shared__ __attribute__((aligned(16))) u64 lds[];
+    const int t = threadIdx.x;
+    const long long tr0 = (long long)blockIdx.x * T;
+    const int nt = (int)min((long long)T, A.total_transforms - tr0);
+    u64 x[32];
+    // ---- stage A
+    const int trA = t / REST, rest = t - trA * REST;
+    const bool actA = trA < nt;
+    {
+        const u64* src = A.in + (tr0 + trA) * N + rest;
+#pragma unroll
+        for (int q = 0; q < 32; ++q) x[q] = actA ? src[(long long)brev5(q) * REST] : 0;
+    }
+    dit_half<INV, 0>(x);
+    dit_half<INV, 16>(x);
+    dit_level<INV, 5>(x);
+    {
+        const u64* tw = A.tw1 + rest;
+#pragma unroll
+        for (int q = 2; q < 32; q += 2) gl::mont_mul2(x[q], tw[q * REST], x[q + 1], tw[(q + 1) * REST], x[q], x[q + 1]);
+        x[1] = gl::mont_mul(x[1], tw[REST]);  // k1 = 0: factor 1
+    }
+    // ---- exchange 1: (k1 = q, j2, j3, tr) -> thread (tr, j3, k1) holding j2
+    const int j2A = rest >> LOGP3, j3A = rest & (P3 - 1);
+    const int pairA = trA * P3 + j3A;                       // 0 .. 15
+    // A thread writes its 32 old values and reads its 32 new ones in the SAME round (only 32 are ever live), so both roles
+    // must fall into the same round.  The round is pair >> 3: for P3 <= 8 that is a function of tr alone; for P3 = 16
+    // (one transform, 16 pairs = j3) the stage-B role is taken from the thread index with bits 3 and 8 swapped, which makes
+    // its j3 >> 3 equal to the stage-A role's.
+    const int tb = (LOGP3 == 4) ? ((t & ~0x108) | ((t & 8) << 5) | ((t >> 5) & 8)) : t;
+    const int trB = tb / REST, j3B = (tb >> 5) & (P3 - 1), k1B = tb & 31;
+    const int pairB = trB * P3 + j3B;
+#pragma unroll 1
+    for (int r = 0; r < 2; ++r) {
+        if (r) __syncthreads();
+        if ((pairA >> 3) == r) {
+            u64* wr = lds + (pairA & 7) * PS1 + j2A;
+#pragma unroll
+            for (int q = 0; q < 32; ++q) wr[q * 33] = x[q];
+        }
+        __syncthreads();
+        if ((pairB >> 3) == r) {
+            const u64* rd = lds + (pairB & 7) * PS1 + k1B * 33;
+#pragma unroll
+            for (int q = 0; q < 32; ++q) x[q] = rd[brev5(q)];
+        }
+    }
+    // ---- stage B
+    dit_half<INV, 0>(x);
+    dit_half<INV, 16>(x);
+    dit_level<INV, 5>(x);
+    {
+        const u64* tw = A.tw2 + j3B;
+#pragma unroll
+        for (int q = 0; q < 32; q += 2) gl::mont_mul2(x[q], tw[q * P3], x[q + 1], tw[(q + 1) * P3], x[q], x[q + 1]);
+    }
+    // ---- exchange 2: (k1, k2 = q, j3, tr) -> thread (tr, s, k1) holding k2 in [s * 32 / P3, ..) x all j3
+    const int trC = trB, sC = j3B, k1C = k1B;  // same thread index decomposition, s takes j3's bit positions
+    __syncthreads();
+#pragma unroll 1
+    for (int r = 0; r < 2; ++r) {
+        if (r) __syncthreads();
+        if ((k1B >> 4) == r) {
+            u64* wr = lds + (trB * 16 + (k1B & 15)) * KS2 + j3B;
+#pragma unroll
+            for (int q = 0; q < 32; ++q) wr[q * P3] = x[q];
+        }
+        __syncthreads();
+        if ((k1C >> 4) == r) {
+            const u64* rd = lds + (trC * 16 + (k1C & 15)) * KS2 + sC * (32 / P3) * P3;
+#pragma unroll
+            for (int q = 0; q < 32; ++q) {
+                const int grp = q >> LOGP3, rr = q & (P3 - 1);
+                const int j3 = (int)(__brev((unsigned)rr) >> (32 - LOGP3));
+                x[q] = rd[grp * P3 + j3];
+            }
+        }
+    }
+    // ---- stage C: radix P3 inside groups of P3 slots
+    if constexpr (LOGP3 >= 1) dit_level<INV, 1>(x);
+    if constexpr (LOGP3 >= 2) dit_level<INV, 2>(x);
+    if constexpr (LOGP3 >= 3) dit_level<INV, 3>(x);
+    if constexpr (LOGP3 >= 4) dit_level<INV, 4>(x);
+    if (trC < nt) {
+        u64* dst = A.out + (tr0 + trC) * N + k1C;
+#pragma unroll
+        for (int q = 0; q < 32; ++q) {
+            const int grp = q >> LOGP3, k3 = q & (P3 - 1);
+            const int k2 = sC * (32 / P3) + grp;
+            dst[32 * k2 + 1024 * k3] = x[q];
+        }
+    }
+}
+
 // ---- n <= 16: one thread per (transform, limb); reference-shaped radix-2 loop, tables in global memory.
 struct NttTinyArgs {
     const u64* in;

@@ -165,7 +165,7 @@ void split_powers(u64 base, int log_total, int* h_out, std::vector<u64>* hi, std
     *h_out = h;
 }
 
-enum : u64 { TAG_INNER = 1, TAG_POST = 2, TAG_TINY = 3 };
+enum : u64 { TAG_INNER = 1, TAG_POST = 2, TAG_TINY = 3, TAG_BLOCK1 = 4, TAG_BLOCK2 = 5 };
 u64 make_key(u64 tag, u64 a, u64 b, u64 c, u64 d) { return (tag << 56) | (a << 40) | (b << 24) | (c << 8) | d; }
 
 // inner[g*32 + k1] = w_R^(+-g*k1) * (scale_log_n ? n^-1 : 1),  R = 32 << p2
@@ -253,6 +253,53 @@ int get_post_table(DeviceCtx* ctx, int log_m, int a, bool inverse, hipStream_t s
     HIPCHK(hipFree(d_lo));
     if (!*temp) ctx->tables[key] = d;
     *out = d;
+    return TF_OK;
+}
+
+// tables of ntt_block_kernel (2^11 <= n <= 2^14): tw1[q * REST + rest] = w_n^(+-q * rest), tw2[k2 * P3 + j3] =
+// w_{32 P3}^(+-k2 * j3) (* n^-1 for the inverse)
+int get_block_tables(DeviceCtx* ctx, int log_n, bool inverse, const u64** tw1, const u64** tw2) {
+    const u64 key1 = make_key(TAG_BLOCK1, log_n, inverse, 0, 0), key2 = make_key(TAG_BLOCK2, log_n, inverse, 0, 0);
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    auto i1 = ctx->tables.find(key1), i2 = ctx->tables.find(key2);
+    if (i1 != ctx->tables.end() && i2 != ctx->tables.end()) {
+        *tw1 = i1->second;
+        *tw2 = i2->second;
+        return TF_OK;
+    }
+    const int n = 1 << log_n, rest_n = n / 32, p3 = n / 1024;
+    u64 w = root_of_unity_mont(log_n);
+    if (inverse) w = gl::mont_inverse(w);
+    std::vector<u64> t1((size_t)n), t2((size_t)32 * p3);
+    u64 wq = gl::ONE;  // w^q
+    for (int q = 0; q < 32; ++q) {
+        u64 acc = gl::ONE;
+        for (int r = 0; r < rest_n; ++r) {
+            t1[size_t(q) * rest_n + r] = acc;
+            acc = gl::mont_mul(acc, wq);
+        }
+        wq = gl::mont_mul(wq, w);
+    }
+    const u64 w32 = gl::mont_pow(w, 32);  // w_{n / 32} = w_{32 P3}
+    const u64 scale = inverse ? gl::mont_inverse(gl::to_mont(u64(n))) : gl::ONE;
+    u64 wk = gl::ONE;  // w32^k2
+    for (int k2 = 0; k2 < 32; ++k2) {
+        u64 acc = scale;
+        for (int j3 = 0; j3 < p3; ++j3) {
+            t2[size_t(k2) * p3 + j3] = acc;
+            acc = gl::mont_mul(acc, wk);
+        }
+        wk = gl::mont_mul(wk, w32);
+    }
+    u64 *d1 = nullptr, *d2 = nullptr;
+    int rc = upload_table(t1, &d1);
+    if (rc) return rc;
+    rc = upload_table(t2, &d2);
+    if (rc) return rc;
+    ctx->tables[key1] = d1;
+    ctx->tables[key2] = d2;
+    *tw1 = d1;
+    *tw2 = d2;
     return TF_OK;
 }
 
@@ -669,6 +716,46 @@ int check_len(size_t n) {
     return TF_OK;
 }
 
+// 2^11 <= n <= 2^14, contiguous BFieldElement transforms: whole transform per workgroup (ntt_block_kernel)
+template <int LOGP3, bool INV>
+int launch_block_t(const tfk::NttBlockArgs& a, unsigned grid, hipStream_t stream) {
+    static std::atomic<unsigned long long> done_mask{0};
+    int dev = 0;
+    HIPCHK(hipGetDevice(&dev));
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(done_mask.load(std::memory_order_acquire) & bit)) {
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&tfk::ntt_block_kernel<LOGP3, INV>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        done_mask.fetch_or(bit, std::memory_order_release);
+    }
+    constexpr int P3 = 1 << LOGP3;
+    const size_t lds_bytes = size_t(8) * (1056 + 32 / P3) * sizeof(u64);  // exchange 1 is the larger of the two layouts
+    hipLaunchKernelGGL((tfk::ntt_block_kernel<LOGP3, INV>), dim3(grid), dim3(512), lds_bytes, stream, a);
+    HIPCHK(hipGetLastError());
+    return TF_OK;
+}
+
+int launch_block(DeviceCtx* ctx, const u64* in, u64* out, int log_n, size_t batch, bool inverse, hipStream_t stream) {
+    tfk::NttBlockArgs a{};
+    int rc = get_block_tables(ctx, log_n, inverse, &a.tw1, &a.tw2);
+    if (rc) return rc;
+    a.in = in;
+    a.out = out;
+    a.total_transforms = (long long)batch;
+    const int lp3 = log_n - 10, T = 16 >> lp3;
+    const unsigned grid = (unsigned)((batch + T - 1) / T);
+    switch (lp3 * 2 + (inverse ? 1 : 0)) {
+        case 2: return launch_block_t<1, false>(a, grid, stream);
+        case 3: return launch_block_t<1, true>(a, grid, stream);
+        case 4: return launch_block_t<2, false>(a, grid, stream);
+        case 5: return launch_block_t<2, true>(a, grid, stream);
+        case 6: return launch_block_t<3, false>(a, grid, stream);
+        case 7: return launch_block_t<3, true>(a, grid, stream);
+        case 8: return launch_block_t<4, false>(a, grid, stream);
+        default: return launch_block_t<4, true>(a, grid, stream);
+    }
+}
+
 std::atomic<int> g_min_passes{0};  // tf_set_ntt_min_passes
 
 // Experiment switches for tools/split3.py: looked up on every call only when TF_NTT_EXPERIMENT is set at load time
@@ -786,6 +873,13 @@ int run_ntt(DeviceCtx* ctx, const u64* in, u64* out, long long in_bs, long long 
             if (rc) return rc;
         }
         return TF_OK;
+    }
+    {
+        static const bool no_block = getenv("TF_NTT_NO_BLOCK") != nullptr;  // A/B switch
+        if (!no_block && log_n >= 11 && log_n <= 14 && L == 1 && !pre_scale && !post_scale && n_coeffs < 0 && !in2 && n_out < 0 && cosets == 1 &&
+            in_bs == (long long)n && out_bs == (long long)n && g_min_passes.load(std::memory_order_relaxed) == 0 &&
+            batch < (size_t(1) << 31))
+            return launch_block(ctx, in, out, log_n, batch, inverse, stream);
     }
     // multi-pass: n = N_1 * ... * N_P, every N_i = 2^(a_i) <= 1024.  Passes 1 .. P-1 are column passes (DFT over digit i,
     // inter-pass twiddle, same position in and out); the last pass transforms the contiguous rows of N_P elements and
