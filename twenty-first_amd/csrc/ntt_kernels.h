@@ -499,10 +499,16 @@ struct NttBlockArgs {
     u64* out;
     const u64* tw1;   // [32][n / 32]: w_n^(k1 * rest)            (inverse: w^-1)
     const u64* tw2;   // [32][P3]:     w_{32 P3}^(k2 * j3) (* n^-1 for the inverse)
+    const u64* pre_scale;   // or null: coefficient j times pre_scale[j] on load (fast_coset_evaluate)
+    const u64* post_scale;  // or null: output element k times post_scale[k] on store (fast_coset_interpolate)
+    long long n_coeffs;     // < 0: none; else elements j >= n_coeffs read as zero
+    long long in_bs, out_bs;  // words between consecutive transforms
     long long total_transforms;
 };
 
-template <int LOGP3, bool INV>
+// SCALE: 0 plain, 1 padding / pre-scale on load (forward), 2 post-scale on store (inverse) -- separate instantiations so
+// that the plain transform keeps its register budget
+template <int LOGP3, bool INV, int SCALE = 0>
 __global__ void __launch_bounds__(512, 4) ntt_block_kernel(const NttBlockArgs A) {
     constexpr int P3 = 1 << LOGP3, N = 1024 << LOGP3, REST = 32 << LOGP3, T = 16 >> LOGP3;
     constexpr int PS1 = 1056 + 32 / P3;      // exchange 1: pair slot stride (k1 * 33 + j2 inside a slot)
@@ -516,9 +522,24 @@ __global__ void __launch_bounds__(512, 4) ntt_block_kernel(const NttBlockArgs A)
     const int trA = t / REST, rest = t - trA * REST;
     const bool actA = trA < nt;
     {
-        const u64* src = A.in + (tr0 + trA) * N + rest;
+        const u64* src = A.in + (tr0 + trA) * A.in_bs + rest;
+        const long long lim = (SCALE != 1 || A.n_coeffs < 0) ? (long long)N : A.n_coeffs;
 #pragma unroll
-        for (int q = 0; q < 32; ++q) x[q] = actA ? src[(long long)brev5(q) * REST] : 0;
+        for (int q = 0; q < 32; ++q) x[q] = (actA && (SCALE != 1 || brev5(q) * REST + rest < lim)) ? src[(long long)brev5(q) * REST] : 0;
+        if (SCALE == 1 && A.pre_scale) {
+            const u64* ps = A.pre_scale + rest;
+#pragma unroll
+            for (int q0 = 0; q0 < 32; q0 += 8) {
+                u64 w[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const long long j = brev5(q0 + i) * REST + rest;
+                    w[i] = ps[j < lim ? brev5(q0 + i) * REST : -rest];  // clamp to entry 0 beyond the coefficients (value unused: x is 0)
+                }
+#pragma unroll
+                for (int i = 0; i < 8; i += 2) gl::mont_mul2(x[q0 + i], w[i], x[q0 + i + 1], w[i + 1], x[q0 + i], x[q0 + i + 1]);
+            }
+        }
     }
     dit_half<INV, 0>(x);
     dit_half<INV, 16>(x);
@@ -591,12 +612,35 @@ __global__ void __launch_bounds__(512, 4) ntt_block_kernel(const NttBlockArgs A)
     if constexpr (LOGP3 >= 3) dit_level<INV, 3>(x);
     if constexpr (LOGP3 >= 4) dit_level<INV, 4>(x);
     if (trC < nt) {
-        u64* dst = A.out + (tr0 + trC) * N + k1C;
+        u64* dst = A.out + (tr0 + trC) * A.out_bs + k1C;
+        if (SCALE == 2 && A.post_scale) {
+            // scale and store eight outputs at a time (bounded register footprint)
+            const u64* ps = A.post_scale + k1C;
 #pragma unroll
-        for (int q = 0; q < 32; ++q) {
-            const int grp = q >> LOGP3, k3 = q & (P3 - 1);
-            const int k2 = sC * (32 / P3) + grp;
-            dst[32 * k2 + 1024 * k3] = x[q];
+            for (int q0 = 0; q0 < 32; q0 += 8) {
+                u64 w[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int q = q0 + i, grp = q >> LOGP3, k3 = q & (P3 - 1);
+                    w[i] = ps[32 * (sC * (32 / P3) + grp) + 1024 * k3];
+                }
+#pragma unroll
+                for (int i = 0; i < 8; i += 2) {
+                    const int qa = q0 + i, qb = q0 + i + 1;
+                    u64 r0, r1;
+                    gl::mont_mul2(x[qa], w[i], x[qb], w[i + 1], r0, r1);
+                    dst[32 * (sC * (32 / P3) + (qa >> LOGP3)) + 1024 * (qa & (P3 - 1))] = r0;
+                    dst[32 * (sC * (32 / P3) + (qb >> LOGP3)) + 1024 * (qb & (P3 - 1))] = r1;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 32; ++q) {
+                const int grp = q >> LOGP3, k3 = q & (P3 - 1);
+                const int k2 = sC * (32 / P3) + grp;
+                dst[32 * k2 + 1024 * k3] = x[q];
+            }
         }
     }
 }

@@ -717,42 +717,49 @@ int check_len(size_t n) {
 }
 
 // 2^11 <= n <= 2^14, contiguous BFieldElement transforms: whole transform per workgroup (ntt_block_kernel)
-template <int LOGP3, bool INV>
+template <int LOGP3, bool INV, int SCALE>
 int launch_block_t(const tfk::NttBlockArgs& a, unsigned grid, hipStream_t stream) {
     static std::atomic<unsigned long long> done_mask{0};
     int dev = 0;
     HIPCHK(hipGetDevice(&dev));
     const unsigned long long bit = 1ull << (dev & 63);
     if (!(done_mask.load(std::memory_order_acquire) & bit)) {
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&tfk::ntt_block_kernel<LOGP3, INV>),
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&tfk::ntt_block_kernel<LOGP3, INV, SCALE>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         done_mask.fetch_or(bit, std::memory_order_release);
     }
     constexpr int P3 = 1 << LOGP3;
     const size_t lds_bytes = size_t(8) * (1056 + 32 / P3) * sizeof(u64);  // exchange 1 is the larger of the two layouts
-    hipLaunchKernelGGL((tfk::ntt_block_kernel<LOGP3, INV>), dim3(grid), dim3(512), lds_bytes, stream, a);
+    hipLaunchKernelGGL((tfk::ntt_block_kernel<LOGP3, INV, SCALE>), dim3(grid), dim3(512), lds_bytes, stream, a);
     HIPCHK(hipGetLastError());
     return TF_OK;
 }
 
-int launch_block(DeviceCtx* ctx, const u64* in, u64* out, int log_n, size_t batch, bool inverse, hipStream_t stream) {
+int launch_block(DeviceCtx* ctx, const u64* in, u64* out, long long in_bs, long long out_bs, int log_n, size_t batch, bool inverse,
+                 const u64* pre_scale, long long n_coeffs, const u64* post_scale, hipStream_t stream) {
     tfk::NttBlockArgs a{};
     int rc = get_block_tables(ctx, log_n, inverse, &a.tw1, &a.tw2);
     if (rc) return rc;
     a.in = in;
     a.out = out;
+    a.pre_scale = pre_scale;
+    a.post_scale = post_scale;
+    a.n_coeffs = n_coeffs;
+    a.in_bs = in_bs;
+    a.out_bs = out_bs;
     a.total_transforms = (long long)batch;
     const int lp3 = log_n - 10, T = 16 >> lp3;
     const unsigned grid = (unsigned)((batch + T - 1) / T);
+    const bool scaled_load = pre_scale || n_coeffs >= 0, scaled_store = post_scale != nullptr;
     switch (lp3 * 2 + (inverse ? 1 : 0)) {
-        case 2: return launch_block_t<1, false>(a, grid, stream);
-        case 3: return launch_block_t<1, true>(a, grid, stream);
-        case 4: return launch_block_t<2, false>(a, grid, stream);
-        case 5: return launch_block_t<2, true>(a, grid, stream);
-        case 6: return launch_block_t<3, false>(a, grid, stream);
-        case 7: return launch_block_t<3, true>(a, grid, stream);
-        case 8: return launch_block_t<4, false>(a, grid, stream);
-        default: return launch_block_t<4, true>(a, grid, stream);
+        case 2: return scaled_load ? launch_block_t<1, false, 1>(a, grid, stream) : launch_block_t<1, false, 0>(a, grid, stream);
+        case 3: return scaled_store ? launch_block_t<1, true, 2>(a, grid, stream) : launch_block_t<1, true, 0>(a, grid, stream);
+        case 4: return scaled_load ? launch_block_t<2, false, 1>(a, grid, stream) : launch_block_t<2, false, 0>(a, grid, stream);
+        case 5: return scaled_store ? launch_block_t<2, true, 2>(a, grid, stream) : launch_block_t<2, true, 0>(a, grid, stream);
+        case 6: return scaled_load ? launch_block_t<3, false, 1>(a, grid, stream) : launch_block_t<3, false, 0>(a, grid, stream);
+        case 7: return scaled_store ? launch_block_t<3, true, 2>(a, grid, stream) : launch_block_t<3, true, 0>(a, grid, stream);
+        case 8: return scaled_load ? launch_block_t<4, false, 1>(a, grid, stream) : launch_block_t<4, false, 0>(a, grid, stream);
+        default: return scaled_store ? launch_block_t<4, true, 2>(a, grid, stream) : launch_block_t<4, true, 0>(a, grid, stream);
     }
 }
 
@@ -876,10 +883,9 @@ int run_ntt(DeviceCtx* ctx, const u64* in, u64* out, long long in_bs, long long 
     }
     {
         static const bool no_block = getenv("TF_NTT_NO_BLOCK") != nullptr;  // A/B switch
-        if (!no_block && log_n >= 11 && log_n <= 14 && L == 1 && !pre_scale && !post_scale && n_coeffs < 0 && !in2 && n_out < 0 && cosets == 1 &&
-            in_bs == (long long)n && out_bs == (long long)n && g_min_passes.load(std::memory_order_relaxed) == 0 &&
-            batch < (size_t(1) << 31))
-            return launch_block(ctx, in, out, log_n, batch, inverse, stream);
+        if (!no_block && log_n >= 11 && log_n <= 14 && L == 1 && !in2 && n_out < 0 && cosets == 1 && !((pre_scale || n_coeffs >= 0) && inverse) &&
+            !(post_scale && !inverse) && g_min_passes.load(std::memory_order_relaxed) == 0 && batch < (size_t(1) << 31))
+            return launch_block(ctx, in, out, in_bs, out_bs, log_n, batch, inverse, pre_scale, n_coeffs, post_scale, stream);
     }
     // multi-pass: n = N_1 * ... * N_P, every N_i = 2^(a_i) <= 1024.  Passes 1 .. P-1 are column passes (DFT over digit i,
     // inter-pass twiddle, same position in and out); the last pass transforms the contiguous rows of N_P elements and
