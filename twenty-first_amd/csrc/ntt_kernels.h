@@ -645,6 +645,90 @@ __global__ void __launch_bounds__(512, 4) ntt_block_kernel(const NttBlockArgs A)
     }
 }
 
+// ---- n = 32, contiguous transforms: one transform (one limb of it for XFE) per thread, staged through LDS ---------------
+// A thread's 32 elements are contiguous in memory, so direct loads are 8-byte pieces 256 bytes apart (1.94 ms per 2^28 words).
+// Here the workgroup streams its tile (512 BFE transforms or 170 XFE transforms = 510 limb-transforms) through LDS in two
+// halves: coalesced loads into rows of pitch 33, each thread picks up its row, transforms it in registers, puts it back, and
+// the tile leaves with coalesced stores.
+struct NttRows32Args {
+    const u64* in;
+    u64* out;
+    long long total_transforms;  // transforms (XFE counts as one)
+    u64 scale;                   // Montgomery 32^-1 for the inverse, 0 = none
+    int L;
+};
+
+template <bool INV>
+__global__ void __launch_bounds__(512, 4) ntt_rows32_kernel(const NttRows32Args A) {
+    extern __shared__ __attribute__((aligned(16))) u64 lds[];
+    const int t = threadIdx.x, L = A.L;
+    const int per_tile = L == 1 ? 512 : 170;                     // transforms per workgroup
+    const long long tr0 = (long long)blockIdx.x * per_tile;
+    const int ntr = (int)min((long long)per_tile, A.total_transforms - tr0);
+    const int nlt = ntr * L;                                     // limb-transforms (threads with work)
+    const int half_lt = L == 1 ? 256 : 255;                      // first half: limb-transforms [0, half_lt)
+    const u64* src = A.in + tr0 * 32 * L;
+    u64* dst = A.out + tr0 * 32 * L;
+    const int words = nlt * 32;
+    const int split = min(words, half_lt * 32);                  // words of the first half (whole transforms)
+    u64 x[32];
+#pragma unroll
+    for (int q = 0; q < 32; ++q) x[q] = 0;
+    const int myhalf = t >= half_lt ? 1 : 0;
+    const int row = t - myhalf * half_lt;
+#pragma unroll 1
+    for (int h = 0; h < 2; ++h) {
+        const int w0 = h ? split : 0, w1 = h ? words : split;
+        if (h) __syncthreads();
+        for (int w = w0 + t; w < w1; w += 512) {
+            int lt, e;
+            if (L == 1) {
+                lt = w >> 5;
+                e = w & 31;
+            } else {
+                const int el = (int)__umulhi((u32)w, 0x55555556u), limb = w - 3 * el;
+                lt = (el >> 5) * 3 + limb;
+                e = el & 31;
+            }
+            lds[(lt - h * half_lt) * 33 + e] = src[w];
+        }
+        __syncthreads();
+        if (myhalf == h && t < nlt) {
+#pragma unroll
+            for (int q = 0; q < 32; ++q) x[q] = lds[row * 33 + brev5(q)];
+        }
+    }
+    dit_half<INV, 0>(x);
+    dit_half<INV, 16>(x);
+    dit_level<INV, 5>(x);
+    if (INV) {
+#pragma unroll
+        for (int q = 0; q < 32; q += 2) gl::mont_mul2(x[q], A.scale, x[q + 1], A.scale, x[q], x[q + 1]);
+    }
+#pragma unroll 1
+    for (int h = 0; h < 2; ++h) {
+        const int w0 = h ? split : 0, w1 = h ? words : split;
+        __syncthreads();
+        if (myhalf == h && t < nlt) {
+#pragma unroll
+            for (int q = 0; q < 32; ++q) lds[row * 33 + q] = x[q];
+        }
+        __syncthreads();
+        for (int w = w0 + t; w < w1; w += 512) {
+            int lt, e;
+            if (L == 1) {
+                lt = w >> 5;
+                e = w & 31;
+            } else {
+                const int el = (int)__umulhi((u32)w, 0x55555556u), limb = w - 3 * el;
+                lt = (el >> 5) * 3 + limb;
+                e = el & 31;
+            }
+            dst[w] = lds[(lt - h * half_lt) * 33 + e];
+        }
+    }
+}
+
 // ---- n <= 16: one thread per (transform, limb); reference-shaped radix-2 loop, tables in global memory.
 struct NttTinyArgs {
     const u64* in;

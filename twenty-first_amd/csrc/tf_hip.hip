@@ -716,6 +716,41 @@ int check_len(size_t n) {
     return TF_OK;
 }
 
+// n = 32, contiguous transforms: LDS-staged rows (ntt_rows32_kernel)
+template <bool INV>
+int launch_rows32_t(const tfk::NttRows32Args& a, unsigned grid, hipStream_t stream) {
+    static std::atomic<unsigned long long> done_mask{0};
+    int dev = 0;
+    HIPCHK(hipGetDevice(&dev));
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(done_mask.load(std::memory_order_acquire) & bit)) {
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&tfk::ntt_rows32_kernel<INV>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   160 * 1024));
+        done_mask.fetch_or(bit, std::memory_order_release);
+    }
+    hipLaunchKernelGGL((tfk::ntt_rows32_kernel<INV>), dim3(grid), dim3(512), size_t(256) * 33 * sizeof(u64), stream, a);
+    HIPCHK(hipGetLastError());
+    return TF_OK;
+}
+
+int launch_rows32(const u64* in, u64* out, size_t batch, int L, bool inverse, hipStream_t stream) {
+    const size_t per_tile = L == 1 ? 512 : 170;
+    const size_t max_grid = size_t(1) << 30;
+    for (size_t b0 = 0; b0 < batch; b0 += max_grid * per_tile) {
+        const size_t nb = std::min(batch - b0, max_grid * per_tile);
+        tfk::NttRows32Args a{};
+        a.in = in + b0 * 32 * L;
+        a.out = out + b0 * 32 * L;
+        a.total_transforms = (long long)nb;
+        a.scale = inverse ? gl::mont_inverse(gl::to_mont(32)) : 0;
+        a.L = L;
+        const unsigned grid = (unsigned)((nb + per_tile - 1) / per_tile);
+        int rc = inverse ? launch_rows32_t<true>(a, grid, stream) : launch_rows32_t<false>(a, grid, stream);
+        if (rc) return rc;
+    }
+    return TF_OK;
+}
+
 // 2^11 <= n <= 2^14, contiguous BFieldElement transforms: whole transform per workgroup (ntt_block_kernel)
 template <int LOGP3, bool INV, int SCALE>
 int launch_block_t(const tfk::NttBlockArgs& a, unsigned grid, hipStream_t stream) {
@@ -861,6 +896,10 @@ int run_ntt(DeviceCtx* ctx, const u64* in, u64* out, long long in_bs, long long 
         hipLaunchKernelGGL(tfk::ntt_tiny_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, A);
         HIPCHK(hipGetLastError());
         return TF_OK;
+    }
+    if (log_n == 5 && L == 1 && !pre_scale && !post_scale && n_coeffs < 0 && !in2 && in_bs == 32 && out_bs == 32) {  // XFE: 0.98 vs 0.90 ms, not used
+        static const bool no_rows32 = getenv("TF_NTT_NO_ROWS32") != nullptr;  // A/B switch
+        if (!no_rows32) return launch_rows32(in, out, batch, L, inverse, stream);
     }
     if (log_n <= 10) {
         const u64* inner = nullptr;
