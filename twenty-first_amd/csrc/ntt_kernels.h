@@ -504,10 +504,13 @@ struct NttBlockArgs {
     long long n_coeffs;     // < 0: none; else elements j >= n_coeffs read as zero
     long long in_bs, out_bs;  // words between consecutive transforms
     long long total_transforms;
+    const u64* in2;         // SCALE 3: second operand laid out like `in`, multiplied in on load (fast_multiply)
+    long long n_out;        // SCALE 3: >= 0 = only output elements k < n_out are stored
 };
 
-// SCALE: 0 plain, 1 padding / pre-scale on load (forward), 2 post-scale on store (inverse) -- separate instantiations so
-// that the plain transform keeps its register budget
+// SCALE: 0 plain, 1 padding / pre-scale on load (forward), 2 post-scale on store (inverse), 3 pointwise product with a second
+// operand on load and truncated store (the inverse transform of fast_multiply) -- separate instantiations so that the plain
+// transform keeps its register budget
 template <int LOGP3, bool INV, int SCALE = 0>
 __global__ void __launch_bounds__(512, 4) ntt_block_kernel(const NttBlockArgs A) {
     constexpr int P3 = 1 << LOGP3, N = 1024 << LOGP3, REST = 32 << LOGP3, T = 16 >> LOGP3;
@@ -526,6 +529,17 @@ __global__ void __launch_bounds__(512, 4) ntt_block_kernel(const NttBlockArgs A)
         const long long lim = (SCALE != 1 || A.n_coeffs < 0) ? (long long)N : A.n_coeffs;
 #pragma unroll
         for (int q = 0; q < 32; ++q) x[q] = (actA && (SCALE != 1 || brev5(q) * REST + rest < lim)) ? src[(long long)brev5(q) * REST] : 0;
+        if (SCALE == 3) {
+            const u64* src2 = A.in2 + (tr0 + trA) * A.in_bs + rest;
+#pragma unroll
+            for (int q0 = 0; q0 < 32; q0 += 8) {
+                u64 w[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) w[i] = actA ? src2[(long long)brev5(q0 + i) * REST] : 0;
+#pragma unroll
+                for (int i = 0; i < 8; i += 2) gl::mont_mul2(x[q0 + i], w[i], x[q0 + i + 1], w[i + 1], x[q0 + i], x[q0 + i + 1]);
+            }
+        }
         if (SCALE == 1 && A.pre_scale) {
             const u64* ps = A.pre_scale + rest;
 #pragma unroll
@@ -635,11 +649,12 @@ __global__ void __launch_bounds__(512, 4) ntt_block_kernel(const NttBlockArgs A)
                 __builtin_amdgcn_sched_barrier(0);
             }
         } else {
+            const long long klim = (SCALE == 3 && A.n_out >= 0) ? A.n_out : (long long)N;
 #pragma unroll
             for (int q = 0; q < 32; ++q) {
                 const int grp = q >> LOGP3, k3 = q & (P3 - 1);
                 const int k2 = sC * (32 / P3) + grp;
-                dst[32 * k2 + 1024 * k3] = x[q];
+                if (SCALE != 3 || k1C + 32 * k2 + 1024 * k3 < klim) dst[32 * k2 + 1024 * k3] = x[q];
             }
         }
     }

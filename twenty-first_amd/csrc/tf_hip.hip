@@ -771,7 +771,8 @@ int launch_block_t(const tfk::NttBlockArgs& a, unsigned grid, hipStream_t stream
 }
 
 int launch_block(DeviceCtx* ctx, const u64* in, u64* out, long long in_bs, long long out_bs, int log_n, size_t batch, bool inverse,
-                 const u64* pre_scale, long long n_coeffs, const u64* post_scale, hipStream_t stream) {
+                 const u64* pre_scale, long long n_coeffs, const u64* post_scale, hipStream_t stream, const u64* in2 = nullptr,
+                 long long n_out = -1) {
     tfk::NttBlockArgs a{};
     int rc = get_block_tables(ctx, log_n, inverse, &a.tw1, &a.tw2);
     if (rc) return rc;
@@ -783,9 +784,19 @@ int launch_block(DeviceCtx* ctx, const u64* in, u64* out, long long in_bs, long 
     a.in_bs = in_bs;
     a.out_bs = out_bs;
     a.total_transforms = (long long)batch;
+    a.in2 = in2;
+    a.n_out = n_out;
     const int lp3 = log_n - 10, T = 16 >> lp3;
     const unsigned grid = (unsigned)((batch + T - 1) / T);
     const bool scaled_load = pre_scale || n_coeffs >= 0, scaled_store = post_scale != nullptr;
+    if (in2) {  // the inverse transform of a product: second operand on load, truncated store
+        switch (lp3) {
+            case 1: return launch_block_t<1, true, 3>(a, grid, stream);
+            case 2: return launch_block_t<2, true, 3>(a, grid, stream);
+            case 3: return launch_block_t<3, true, 3>(a, grid, stream);
+            default: return launch_block_t<4, true, 3>(a, grid, stream);
+        }
+    }
     switch (lp3 * 2 + (inverse ? 1 : 0)) {
         case 2: return scaled_load ? launch_block_t<1, false, 1>(a, grid, stream) : launch_block_t<1, false, 0>(a, grid, stream);
         case 3: return scaled_store ? launch_block_t<1, true, 2>(a, grid, stream) : launch_block_t<1, true, 0>(a, grid, stream);
@@ -854,6 +865,8 @@ void choose_split(int log_n, int P, int L, int (&a)[4]) {
 // Can the last pass of an n-point transform truncate its output (LAST1024 kernel: two or three passes, last radix 1024)?
 bool can_truncate(size_t n, int L) {
     if (n <= 1024 || n > (size_t(1) << 30)) return false;
+    static const bool no_block = getenv("TF_NTT_NO_BLOCK") != nullptr;
+    if (n <= (size_t(1) << 14)) return L == 1 && !no_block && g_min_passes.load(std::memory_order_relaxed) == 0;  // the block kernel truncates (BFE product inverse)
     const int log_n = ilog2(n), P = pass_count(log_n);
     int a[4] = {0, 0, 0, 0};
     choose_split(log_n, P, L, a);
@@ -922,9 +935,14 @@ int run_ntt(DeviceCtx* ctx, const u64* in, u64* out, long long in_bs, long long 
     }
     {
         static const bool no_block = getenv("TF_NTT_NO_BLOCK") != nullptr;  // A/B switch
-        if (!no_block && log_n >= 11 && log_n <= 14 && L == 1 && !in2 && n_out < 0 && cosets == 1 && !((pre_scale || n_coeffs >= 0) && inverse) &&
-            !(post_scale && !inverse) && g_min_passes.load(std::memory_order_relaxed) == 0 && batch < (size_t(1) << 31))
-            return launch_block(ctx, in, out, in_bs, out_bs, log_n, batch, inverse, pre_scale, n_coeffs, post_scale, stream);
+        const bool product_inverse = in2 && inverse && !pre_scale && !post_scale && n_coeffs < 0;
+        if (!no_block && log_n >= 11 && log_n <= 14 && L == 1 && cosets == 1 && g_min_passes.load(std::memory_order_relaxed) == 0 &&
+            batch < (size_t(1) << 31)) {
+            if (product_inverse)
+                return launch_block(ctx, in, out, in_bs, out_bs, log_n, batch, true, nullptr, -1, nullptr, stream, in2, n_out);
+            if (!in2 && n_out < 0 && !((pre_scale || n_coeffs >= 0) && inverse) && !(post_scale && !inverse))
+                return launch_block(ctx, in, out, in_bs, out_bs, log_n, batch, inverse, pre_scale, n_coeffs, post_scale, stream);
+        }
     }
     // multi-pass: n = N_1 * ... * N_P, every N_i = 2^(a_i) <= 1024.  Passes 1 .. P-1 are column passes (DFT over digit i,
     // inter-pass twiddle, same position in and out); the last pass transforms the contiguous rows of N_P elements and
