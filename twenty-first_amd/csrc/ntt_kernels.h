@@ -22,6 +22,16 @@
 //
 // XFE slices ([c0,c1,c2] per element, x_field_element.rs:56-59) are three interleaved BFE columns
 // with the same twiddles (ntt.rs:203-207, x_field_element.rs:540-548): L = 3 words per element.
+//
+// Kernels in this file and the lengths they serve (planner: run_ntt in tf_hip.hip):
+//   ntt_tiny_kernel    n <= 16                the reference's radix-2 sweeps, one transform per thread
+//   ntt_rows32_kernel  n == 32, BFE           tiles of 512 transforms staged through LDS, one per thread, no exchange
+//   ntt_pass_kernel    32 <= n <= 1024        one pass, rows of T whole transforms per workgroup
+//                      n > 2^14 (and XFE > 1024): 2-4 passes as described above; the R = 1024 instantiations
+//                      (LAST1024: row-major load roles / column-major store roles, stores fused with the last radix-2
+//                      level; R1024: constant P2) are the two kernels of the 2^20-point headline transform
+//   ntt_block_kernel   2^11 <= n <= 2^14, BFE one workgroup owns a whole transform: radix 32 x 32 x P3 with two LDS
+//                      exchanges, so these lengths cost one HBM pass instead of two
 #pragma once
 
 #include "gl64.h"

@@ -85,8 +85,8 @@ struct DeviceCtx {
     std::mutex mu;
     std::map<u64, u64*> tables;           // twiddle tables, never freed while the process lives
     std::map<std::pair<u64, u64>, u64*> pow_tables;  // (offset_raw, n) -> offset^j table
-    bool tip5_ready = false;
-    bool pool_ready = false;
+    bool tip5_ready = false;               // guarded by mu
+    std::atomic<bool> pool_ready{false};  // double-checked under mu
 };
 
 constexpr int kMaxDevices = 64;
@@ -104,18 +104,18 @@ int current_ctx(DeviceCtx** out) {
     HIPCHK(hipGetDevice(&dev));
     if (dev < 0 || dev >= kMaxDevices) return TF_ERR_NO_DEVICE;
     *out = &g_ctx[dev];
-    if (!g_ctx[dev].pool_ready) {
+    if (!g_ctx[dev].pool_ready.load(std::memory_order_acquire)) {
         // Keep freed stream-ordered allocations cached in the device's default pool (default threshold 0 hands
         // the memory back to the OS at every synchronisation, which makes the per-call scratch expensive).
         std::lock_guard<std::mutex> lk(g_ctx[dev].mu);
-        if (!g_ctx[dev].pool_ready) {
+        if (!g_ctx[dev].pool_ready.load(std::memory_order_relaxed)) {
             hipMemPool_t pool = nullptr;
             if (hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess && pool) {
                 uint64_t thr = UINT64_MAX;
                 (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &thr);
             }
             (void)hipGetLastError();
-            g_ctx[dev].pool_ready = true;
+            g_ctx[dev].pool_ready.store(true, std::memory_order_release);
         }
     }
     return TF_OK;
@@ -230,7 +230,10 @@ int get_post_table(DeviceCtx* ctx, int log_m, int a, bool inverse, hipStream_t s
     int rc = upload_table(hi, &d_hi);
     if (rc) return rc;
     rc = upload_table(lo, &d_lo);
-    if (rc) return rc;
+    if (rc) {
+        (void)hipFree(d_hi);
+        return rc;
+    }
     const long long M = 1ll << log_m, R = 1ll << a, B = M / R;
     if (*temp) {
         lk.unlock();
@@ -241,16 +244,25 @@ int get_post_table(DeviceCtx* ctx, int log_m, int a, bool inverse, hipStream_t s
             return hip_fail(e, "hipMallocAsync(twiddle table)", __FILE__, __LINE__);
         }
     } else {
-        HIPCHK(hipMalloc(&d, size_t(M) * sizeof(u64)));
+        hipError_t e = hipMalloc(&d, size_t(M) * sizeof(u64));
+        if (e != hipSuccess) {
+            (void)hipFree(d_hi);
+            (void)hipFree(d_lo);
+            return hip_fail(e, "hipMalloc(twiddle table)", __FILE__, __LINE__);
+        }
     }
     const int threads = 256;
     const long long blocks = (M + threads - 1) / threads;
     hipStream_t bs = *temp ? stream : hipStream_t(0);
     hipLaunchKernelGGL(tfk::build_post_tw_kernel, dim3((unsigned)blocks), dim3(threads), 0, bs, d, d_hi, d_lo, h, R, B);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(bs));
-    HIPCHK(hipFree(d_hi));
-    HIPCHK(hipFree(d_lo));
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(bs);
+    (void)hipFree(d_hi);
+    (void)hipFree(d_lo);
+    if (e != hipSuccess) {
+        if (*temp) (void)hipFreeAsync(d, stream); else (void)hipFree(d);
+        return hip_fail(e, "build_post_tw_kernel", __FILE__, __LINE__);
+    }
     if (!*temp) ctx->tables[key] = d;
     *out = d;
     return TF_OK;
@@ -355,12 +367,13 @@ int build_pow_table(u64 offset_raw, size_t n, u64* d, hipStream_t s, bool sync_a
     if (n) {
         hipLaunchKernelGGL(tfk::build_pow_table_kernel, dim3((unsigned)blocks), dim3(threads), 0, s, d, d_hi, d_lo, h,
                            (long long)n);
-        HIPCHK(hipGetLastError());
     }
     (void)sync_after;
-    HIPCHK(hipStreamSynchronize(s));  // hi/lo are freed below; the build kernel is microseconds
-    HIPCHK(hipFree(d_hi));
-    HIPCHK(hipFree(d_lo));
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(s);  // hi/lo are freed below; the build kernel is microseconds
+    (void)hipFree(d_hi);
+    (void)hipFree(d_lo);
+    if (e != hipSuccess) return hip_fail(e, "build_pow_table_kernel", __FILE__, __LINE__);
     return TF_OK;
 }
 
@@ -392,7 +405,10 @@ int get_pow_table(DeviceCtx* ctx, u64 offset_raw, size_t n, hipStream_t stream, 
     if (cacheable) {
         HIPCHK(hipMalloc(&d, words * sizeof(u64)));
         int rc = build_all(0);
-        if (rc) return rc;
+        if (rc) {
+            (void)hipFree(d);
+            return rc;
+        }
         ctx->pow_tables[key] = d;
         *out = d;
         return TF_OK;
@@ -444,22 +460,20 @@ int pad_to_residue(int base, int residue) {  // smallest s >= base with s == res
 // Workgroup geometry (tunable for A/B runs through TF_NTT_WG_THREADS = 256 | 512):
 //   512 threads: 16 columns per tile (128-byte segments), 64 KiB exchange rounds, 2 workgroups per CU;
 //   256 threads:  8 columns per tile (64-byte segments, adjacent tiles paired on one XCD), 32 KiB rounds, 4 per CU.
-int g_wg_threads = 0;
 int wg_threads() {
-    if (!g_wg_threads) {
+    static const int v = [] {
         const char* e = getenv("TF_NTT_WG_THREADS");
-        g_wg_threads = (e && atoi(e) == 512) ? 512 : ((e && atoi(e) == 256) ? 256 : 512);
-    }
-    return g_wg_threads;
+        return (e && atoi(e) == 256) ? 256 : 512;
+    }();
+    return v;
 }
-int g_round_elems = 0;
 int round_elems() {
-    if (!g_round_elems) {
+    static const int v = [] {
         const char* e = getenv("TF_NTT_ROUND_ELEMS");
-        g_round_elems = e ? atoi(e) : wg_threads() * 16;
-        if (g_round_elems < 1024) g_round_elems = wg_threads() * 16;
-    }
-    return g_round_elems;
+        const int r = e ? atoi(e) : 0;
+        return r >= 1024 ? r : wg_threads() * 16;
+    }();
+    return v;
 }
 
 // thread / LDS geometry shared by all pass types: nc columns, exchanged in rounds of cpr columns
@@ -650,7 +664,7 @@ int launch_pass_t(const Launch& l, hipStream_t stream) {
 }
 
 unsigned long long* g_dbg_buf = nullptr;  // TF_NTT_ABLATE=3: per-wave phase stamps of the last launch (tf_debug_stamps)
-int g_ablate = -1;  // measurement only (TF_NTT_ABLATE=1|2 selects an ablated forward kernel; results are then garbage)
+std::atomic<int> g_ablate_cfg{-1};  // measurement only (TF_NTT_ABLATE=1|2 selects an ablated forward kernel; results are then garbage)
 
 constexpr size_t kLast1024LdsBytes = size_t(32) * 289 * sizeof(u64);
 
@@ -660,9 +674,11 @@ int launch_pass(const Launch& l, bool inverse, hipStream_t stream) {
         t_last_error = "NTT planner self-check failed (thread-to-column division is not exact for this geometry)";
         return TF_ERR_HIP;
     }
+    int g_ablate = g_ablate_cfg.load(std::memory_order_relaxed);
     if (g_ablate < 0) {
         const char* e = getenv("TF_NTT_ABLATE");
         g_ablate = e ? atoi(e) : 0;
+        g_ablate_cfg.store(g_ablate, std::memory_order_relaxed);
     }
     if (l.a.n_out >= 0) {  // only the plain R = 1024 last-pass kernel truncates; anything else would overrun the caller's buffer
         static const bool no_l1024 = getenv("TF_NTT_NO_LAST1024") != nullptr;
@@ -694,11 +710,7 @@ int launch_pass(const Launch& l, bool inverse, hipStream_t stream) {
         l2.threads = 512;  // 16 column slots x 32, also for tiles of 15 word-columns (XFE)
         return inverse ? launch_pass_t<true, 0, 0, true>(l2, stream) : launch_pass_t<false, 0, 0, true>(l2, stream);
     }
-    if (inverse) {
-        if (last1024) return launch_pass_t<true, 0, 0, true>(l, stream);
-        return r1024 ? launch_pass_t<true, 0, 0, false, true>(l, stream) : launch_pass_t<true, 0, 0>(l, stream);
-    }
-    if (last1024) return launch_pass_t<false, 0, 0, true>(l, stream);
+    if (inverse) return r1024 ? launch_pass_t<true, 0, 0, false, true>(l, stream) : launch_pass_t<true, 0, 0>(l, stream);
     if (r1024) return launch_pass_t<false, 0, 0, false, true>(l, stream);
     if (g_ablate == 1) return launch_pass_t<false, 0, 1>(l, stream);
     if (g_ablate == 2) return launch_pass_t<false, 0, 2>(l, stream);
