@@ -70,6 +70,10 @@ struct NttPassArgs {
     int gfast;                               // 1: thread t is (g = t % P2, column t / P2) instead of (t / nc, t % nc)
     int xcd_order;                           // G > 0: XCD-aware tile order in groups of G adjacent column tiles (0: natural order)
     int xcd_colfast;                         // with xcd_order: walk the XCD's column groups fastest (their table slices fit its L2)
+    int col_shift0, col_shift_i0, col_wrap;  // LAST1024, L = 1: tile i2 of batch entry i0 covers columns [16 i2 - s, 16 i2 - s + 16) mod
+                                             // col_wrap (= N_1), s = (col_shift0 + i0 * col_shift_i0) mod 16, so its 128-byte output
+                                             // segments start on cache lines even when the output stride is not a multiple of 16 words
+                                             // (truncated products); tile 0 wraps around to the last s columns
     u32 nc_magic;                            // t / nc == umulhi(t, nc_magic) for every t < blockDim (checked by the planner)
     unsigned long long* dbg;                 // MODE 3 only: per-wave cycle stamps (6 per wave)
 };
@@ -224,7 +228,14 @@ __global__ void __launch_bounds__(512, TF_NTT_WAVES) ntt_pass_kernel(const NttPa
     }
     const u64* in = A.in + (long long)i0 * A.ib0 + (long long)i1 * A.ib1 + (long long)i2 * A.ib2;
     u64* out = A.out + (long long)i0 * A.ob0 + (long long)i1 * A.ob1 + (long long)i2 * A.ob2;
-    const int col0 = (int)i2 * A.nc;
+    // (LAST1024 with a column shift: the tile starts cshift columns early; tile 0 takes the last cshift columns instead of
+    // the non-existent columns below 0 -- cw_in / cw below)
+    const int cshift = LAST1024 ? (int)((A.col_shift0 + i0 * (u32)A.col_shift_i0) & 15u) : 0;
+    if constexpr (LAST1024) {
+        in -= (long long)cshift * A.in_cs_hi;
+        out -= (long long)cshift * A.out_cs_hi;
+    }
+    const int col0 = (int)i2 * A.nc - cshift;
     const int ncv = min(A.nc, A.col_limit - col0);
 
     // LAST1024 always runs 512 threads in 16 column slots (slot 15 idles for XFE tiles of 15 word-columns)
@@ -244,6 +255,7 @@ __global__ void __launch_bounds__(512, TF_NTT_WAVES) ntt_pass_kernel(const NttPa
     const int c_in = LAST1024 ? (((t >> 6) & 7) | (t & 8)) : c;
     const bool act_in = LAST1024 ? (c_in < ncv) : act;
     const int ch_in = LAST1024 ? (int)div_by_L((u32)c_in, L) : ch, cl_in = LAST1024 ? (c_in - ch_in * L) : cl;
+    const int cw_in = (LAST1024 && col0 + c_in < 0) ? A.col_wrap : 0, cw = (LAST1024 && col0 + c < 0) ? A.col_wrap : 0;
 
     // Addressing: every global access is  uniform 64-bit base (SGPRs, one per register slot q)  +  32-bit
     // per-thread offset (one VGPR for all 32 slots), so the load and store bursts cost (almost) no vector ALU
@@ -261,7 +273,7 @@ __global__ void __launch_bounds__(512, TF_NTT_WAVES) ntt_pass_kernel(const NttPa
 #pragma unroll
         for (int q = 0; q < 32; ++q) x[q] = (u64)(t * 32 + q) * 0x9e3779b97f4a7c15ULL >> 1;
     } else if (act_in) {
-        const u32 toff = (u32)(((long long)ch_in * A.in_cs_hi + cl_in + (long long)g_in * A.in_rs) * 8);
+        const u32 toff = (u32)(((long long)(ch_in + cw_in) * A.in_cs_hi + cl_in + (long long)g_in * A.in_rs) * 8);
         const char* base = reinterpret_cast<const char*>(in);
 #pragma unroll
         for (int q = 0; q < 32; ++q) {
@@ -393,13 +405,13 @@ __global__ void __launch_bounds__(512, TF_NTT_WAVES) ntt_pass_kernel(const NttPa
         // time, so the store burst overlaps the end of the arithmetic.  Slot q holds output row k = g + 32 q.
         dit_half<INV, 0>(x);
         dit_half<INV, 16>(x);
-        const u32 toff = (u32)(((long long)ch * A.out_cs_hi + cl + (long long)g * A.out_rs) * 8);
+        const u32 toff = (u32)(((long long)(ch + cw) * A.out_cs_hi + cl + (long long)g * A.out_rs) * 8);
         char* base = reinterpret_cast<char*>(out);
         if (A.n_out >= 0) {
             // truncated output (fast_multiply keeps the first n_out coefficients): slot q holds output element
             // j0 + 32 q js_k; the thread stores the slots below its own limit
-            const long long j0 = (long long)i0 * A.js_i0 + (long long)i1 * A.js_i1 + (long long)i2 * A.js_i2 + (long long)ch * A.js_c +
-                                 (long long)g * A.js_k;
+            const long long j0 = (long long)i0 * A.js_i0 + (long long)i1 * A.js_i1 + (long long)i2 * A.js_i2 +
+                                 (long long)(ch + cw - cshift) * A.js_c + (long long)g * A.js_k;
             const long long rem = A.n_out - j0, step = 32 * A.js_k;
             const int qlim = rem <= 0 ? 0 : (int)min(32ll, (rem + step - 1) / step);
             tail_p5<INV, 0, true>(x, act, base, toff, A.out_rs * 8, qlim);

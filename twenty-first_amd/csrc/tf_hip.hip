@@ -985,6 +985,7 @@ int run_ntt(DeviceCtx* ctx, const u64* in, u64* out, long long in_bs, long long 
         }
     }
     read_env();
+    static const bool no_col_shift = getenv("TF_NTT_NO_COL_SHIFT") != nullptr;  // A/B switch
     const size_t poly_bytes = n * cosets * size_t(L) * sizeof(u64);
     size_t tb = std::max<size_t>(1, g_tile_bytes / poly_bytes);
     tb = std::min(tb, batch);
@@ -1041,6 +1042,18 @@ int run_ntt(DeviceCtx* ctx, const u64* in, u64* out, long long in_bs, long long 
             pl.a.inner_tw = inner[P - 1];
             pl.a.post_scale = post_scale;
             pl.a.n_out = n_out;
+            if (L == 1 && a[P - 1] == 10 && pl.a.nc == 16 && !post_scale && !no_col_shift && log_n <= 28) {
+                // The R = 1024 last pass stores 128-byte segments of 16 adjacent output words.  When the output of batch entry
+                // b does not start on a cache line (a truncated product: stride n_out = na + nb - 1 words, or a caller's
+                // unaligned pointer) every segment would straddle two lines written by workgroups on different XCDs: shift
+                // the tile boundaries of entry b by s = (word address of its first output) mod 16 columns so that they fall
+                // on lines again; the first tile of a row wraps around to the row's last s columns.  (log_n <= 28: the
+                // wrapped lanes' 32-bit byte offset spans the whole transform.)  Measured, tools/trunc_align.py: 256 products
+                // of 2^19 x 2^19 7.29 -> 7.05 ms, 1024 of 2^17 x 2^17 7.19 -> 6.66, 64 of 2^21 x 2^21 10.25 -> 9.65.
+                pl.a.col_shift0 = (int)((reinterpret_cast<uintptr_t>(tout) / sizeof(u64)) & 15);
+                pl.a.col_shift_i0 = (int)(out_bs & 15);
+                pl.a.col_wrap = pl.a.col_limit;
+            }
             rc = launch_pass(pl, inverse, stream);
         } else {
             for (size_t b = 0; b < nb && rc == TF_OK; ++b) {
