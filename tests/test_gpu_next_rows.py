@@ -359,40 +359,46 @@ def test_fast_multiply_large_products(tf, oracle, width, na, nb):
         assert np.array_equal(tf.fast_square(a, width=width), oracle.poly_mul(a, a, width=width))
 
 
-@pytest.mark.parametrize("na,nb,batch,shift", [(20000, 12769, 5, 0), (33000, 33001, 4, 3), (70000, 61073, 3, 0), (1 << 19, (1 << 19) - 15, 3, 0),
-                                               (600000, 500003, 2, 7)])
-def test_fast_multiply_batched_products_with_unaligned_outputs(tf, oracle, na, nb, batch, shift):
-    """BFE products in a batch: entry b of the output starts at word b * (na + nb - 1) (+ an unaligned caller pointer), so the
-    R = 1024 last pass of the inverse transform shifts its tile boundaries per entry to keep its stores on cache lines"""
+@pytest.mark.parametrize("width,na,nb,batch,shift", [(1, 20000, 12769, 5, 0), (1, 33000, 33001, 4, 3), (1, 70000, 61073, 3, 0),
+                                                     (1, 1 << 19, (1 << 19) - 15, 3, 0), (1, 600000, 500003, 2, 7),
+                                                     (3, 20000, 12769, 5, 0), (3, 16001, 16000, 3, 5), (3, 1 << 19, (1 << 19) - 15, 2, 0),
+                                                     (3, 600000, 440001, 2, 1)])
+def test_fast_multiply_batched_products_with_unaligned_outputs(tf, oracle, width, na, nb, batch, shift):
+    """products in a batch: entry b of the output starts at word b * (na + nb - 1) * width (+ an unaligned caller pointer), so the
+    R = 1024 last pass of the inverse transform shifts its (word-granular) tile boundaries per entry to keep its stores on
+    cache lines; XFE orders 2^15 and 2^20 take that kernel too"""
     import torch
 
-    a = oracle.fill_random(na * batch, 7 + na)
-    b = oracle.fill_random(nb * batch, 8 + nb)
-    n_out = na + nb - 1
+    a = oracle.fill_random(na * batch * width, 7 + na)
+    b = oracle.fill_random(nb * batch * width, 8 + nb)
+    n_out = (na + nb - 1) * width
     da = torch.from_numpy(a.view(np.int64)).cuda()
     db = torch.from_numpy(b.view(np.int64)).cuda()
     out = torch.full((n_out * batch + shift + 64,), -1, dtype=torch.int64, device="cuda")
-    tf.device.poly_mul(da, na, db, nb, out[shift:shift + n_out * batch], batch=batch, width=1)
+    tf.device.poly_mul(da, na, db, nb, out[shift:shift + n_out * batch], batch=batch, width=width)
     torch.cuda.synchronize()
     got = out.cpu().numpy().view(np.uint64)
     assert np.all(got[:shift] == np.uint64(0xFFFFFFFFFFFFFFFF)) and np.all(got[shift + n_out * batch:] == np.uint64(0xFFFFFFFFFFFFFFFF))
     for k in range(batch):
-        want = oracle.poly_mul(a[k * na:(k + 1) * na], b[k * nb:(k + 1) * nb], width=1)
+        want = oracle.poly_mul(a[k * na * width:(k + 1) * na * width], b[k * nb * width:(k + 1) * nb * width], width=width)
         assert np.array_equal(got[shift + k * n_out:shift + (k + 1) * n_out], want), k
 
 
-@pytest.mark.parametrize("log_n,batch,shift", [(15, 3, 5), (17, 2, 1), (20, 2, 15), (21, 1, 9), (23, 1, 8)])
+@pytest.mark.parametrize("width,log_n,batch,shift", [(1, 15, 3, 5), (1, 17, 2, 1), (1, 20, 2, 15), (1, 21, 1, 9), (1, 23, 1, 8),
+                                                     (3, 15, 3, 5), (3, 13, 2, 1), (3, 20, 2, 7), (3, 23, 1, 2), (3, 24, 1, 0)])
 @pytest.mark.parametrize("inverse", [False, True])
-def test_ntt_on_unaligned_device_pointer(tf, oracle, log_n, batch, shift, inverse):
-    """ntt / intt (math/ntt.rs:67-125) in place on a device slice that does not start on a 128-byte line"""
+def test_ntt_on_unaligned_device_pointer(tf, oracle, width, log_n, batch, shift, inverse):
+    """ntt / intt (math/ntt.rs:67-125) in place on a device slice that does not start on a 128-byte line; the XFE lengths are
+    the ones whose last pass is the R = 1024 kernel with word-granular tiles (2^15, 2^20, >= 2^23) plus one that is not"""
     import torch
 
     n = 1 << log_n
-    x = oracle.fill_random(n * batch, 90 + log_n)
-    buf = torch.full((n * batch + shift + 32,), -1, dtype=torch.int64, device="cuda")
-    buf[shift:shift + n * batch] = torch.from_numpy(x.view(np.int64)).cuda()
-    tf.device.ntt_(buf[shift:shift + n * batch], n, batch=batch, width=1, inverse=inverse)
+    words = n * batch * width
+    x = oracle.fill_random(words, 90 + log_n)
+    buf = torch.full((words + shift + 32,), -1, dtype=torch.int64, device="cuda")
+    buf[shift:shift + words] = torch.from_numpy(x.view(np.int64)).cuda()
+    tf.device.ntt_(buf[shift:shift + words], n, batch=batch, width=width, inverse=inverse)
     torch.cuda.synchronize()
     got = buf.cpu().numpy().view(np.uint64)
-    assert np.all(got[:shift] == np.uint64(0xFFFFFFFFFFFFFFFF)) and np.all(got[shift + n * batch:] == np.uint64(0xFFFFFFFFFFFFFFFF))
-    assert np.array_equal(got[shift:shift + n * batch], oracle.ntt(x, inverse=inverse, batch=batch, threads=8))
+    assert np.all(got[:shift] == np.uint64(0xFFFFFFFFFFFFFFFF)) and np.all(got[shift + words:] == np.uint64(0xFFFFFFFFFFFFFFFF))
+    assert np.array_equal(got[shift:shift + words], oracle.ntt(x, width=width, inverse=inverse, batch=batch, threads=8))

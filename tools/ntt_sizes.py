@@ -7,8 +7,10 @@ import twenty_first_amd as tf
 dev = torch.device("cuda:0")
 g = torch.Generator(device=dev); g.manual_seed(1)
 buf = torch.randint(0, 2**62, (1 << 28,), dtype=torch.int64, device=dev, generator=g)
-for width in (1, 3):
-    for log_n in list(range(5, 27)) + [28]:
+widths = [int(w) for w in sys.argv[1].split(',')] if len(sys.argv) > 1 else [1, 3]
+lo, hi = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (5, 28)
+for width in widths:
+    for log_n in [l for l in list(range(5, 27)) + [28] if lo <= l <= hi]:
         n = 1 << log_n
         total = (1 << 28) if width == 1 else 3 * (1 << 26)
         batch = total // (n * width)

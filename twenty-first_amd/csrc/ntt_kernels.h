@@ -228,23 +228,34 @@ __global__ void __launch_bounds__(512, TF_NTT_WAVES) ntt_pass_kernel(const NttPa
     }
     const u64* in = A.in + (long long)i0 * A.ib0 + (long long)i1 * A.ib1 + (long long)i2 * A.ib2;
     u64* out = A.out + (long long)i0 * A.ob0 + (long long)i1 * A.ob1 + (long long)i2 * A.ob2;
-    // (LAST1024 with a column shift: the tile starts cshift columns early; tile 0 takes the last cshift columns instead of
-    // the non-existent columns below 0 -- cw_in / cw below)
+    // LAST1024 tiles are WORD-granular: tile i2 of batch entry i0 covers the word-columns [nc i2 - s, nc i2 - s + nc) of the
+    // N_1 * L words that are adjacent on the output side (nc = 16 = one 128-byte line for the transposing pass; an XFieldElement
+    // tile may start and end inside an element).  s = cshift is the word address of the entry's first output mod 16, so
+    // every 16-word store segment is one whole cache line; tile 0 takes the last s columns of the row instead of the
+    // columns below 0 (col_wrap).  Word-column w is limb w % L of element column w / L.
     const int cshift = LAST1024 ? (int)((A.col_shift0 + i0 * (u32)A.col_shift_i0) & 15u) : 0;
-    if constexpr (LAST1024) {
-        in -= (long long)cshift * A.in_cs_hi;
-        out -= (long long)cshift * A.out_cs_hi;
-    }
     const int col0 = (int)i2 * A.nc - cshift;
     const int ncv = min(A.nc, A.col_limit - col0);
+    const int ch0 = LAST1024 ? (int)div_by_L((u32)max(col0, 0), L) : 0;  // first element column of the tile (uniform)
+    if constexpr (LAST1024) {
+        in = A.in + (long long)i0 * A.ib0 + (long long)i1 * A.ib1 + (long long)ch0 * A.in_cs_hi;
+        out = A.out + (long long)i0 * A.ob0 + (long long)i1 * A.ob1 + (long long)ch0 * A.out_cs_hi;
+    }
 
-    // LAST1024 always runs 512 threads in 16 column slots (slot 15 idles for XFE tiles of 15 word-columns)
+    // LAST1024 always runs 512 threads in 16 column slots
     // gfast (single-pass transforms, whose "columns" are whole rows of contiguous elements): lanes along the row, g = t % P2
     const int g = LAST1024 ? (t >> 4) : (A.gfast ? (t & (P2 - 1)) : (A.nc == 1 ? t : (int)__umulhi((u32)t, A.nc_magic)));  // t / nc
     const int c = LAST1024 ? (t & 15) : (A.gfast ? (t >> p2) : (t - g * A.nc));                                              // t % nc
     const bool act = c < ncv;
-    const int ch = (int)div_by_L((u32)c, L), cl = c - ch * L;
-    const long long bcol = (long long)div_by_L((u32)(col0 + c), L);
+    int ch, cl;  // element column relative to the tile base, limb
+    if constexpr (LAST1024) {
+        const int w = col0 + c + (col0 + c < 0 ? A.col_wrap : 0);
+        const int e = (int)div_by_L((u32)w, L);
+        ch = e - ch0, cl = w - e * L;
+    } else {
+        ch = (int)div_by_L((u32)c, L), cl = c - ch * L;
+    }
+    const long long bcol = (long long)div_by_L((u32)max(col0 + c, 0), L);
     // LAST1024 reads rows of 1024 contiguous elements and writes 16 adjacent columns: the two sides want different
     // lane orders, and the LDS exchange between them lets each have its own.  Loads and step 1 run with the lanes along the
     // row: a wave reads 2 columns x 32 consecutive elements (four 128-byte lines) instead of 16 pieces of 32 bytes
@@ -254,8 +265,12 @@ __global__ void __launch_bounds__(512, TF_NTT_WAVES) ntt_pass_kernel(const NttPa
     const int g_in = LAST1024 ? ((t & 7) | ((t >> 1) & 0x18)) : g;
     const int c_in = LAST1024 ? (((t >> 6) & 7) | (t & 8)) : c;
     const bool act_in = LAST1024 ? (c_in < ncv) : act;
-    const int ch_in = LAST1024 ? (int)div_by_L((u32)c_in, L) : ch, cl_in = LAST1024 ? (c_in - ch_in * L) : cl;
-    const int cw_in = (LAST1024 && col0 + c_in < 0) ? A.col_wrap : 0, cw = (LAST1024 && col0 + c < 0) ? A.col_wrap : 0;
+    int ch_in = ch, cl_in = cl;
+    if constexpr (LAST1024) {
+        const int w = col0 + c_in + (col0 + c_in < 0 ? A.col_wrap : 0);
+        const int e = (int)div_by_L((u32)w, L);
+        ch_in = e - ch0, cl_in = w - e * L;
+    }
 
     // Addressing: every global access is  uniform 64-bit base (SGPRs, one per register slot q)  +  32-bit
     // per-thread offset (one VGPR for all 32 slots), so the load and store bursts cost (almost) no vector ALU
@@ -273,7 +288,7 @@ __global__ void __launch_bounds__(512, TF_NTT_WAVES) ntt_pass_kernel(const NttPa
 #pragma unroll
         for (int q = 0; q < 32; ++q) x[q] = (u64)(t * 32 + q) * 0x9e3779b97f4a7c15ULL >> 1;
     } else if (act_in) {
-        const u32 toff = (u32)(((long long)(ch_in + cw_in) * A.in_cs_hi + cl_in + (long long)g_in * A.in_rs) * 8);
+        const u32 toff = (u32)(((long long)ch_in * A.in_cs_hi + cl_in + (long long)g_in * A.in_rs) * 8);
         const char* base = reinterpret_cast<const char*>(in);
 #pragma unroll
         for (int q = 0; q < 32; ++q) {
@@ -405,13 +420,12 @@ __global__ void __launch_bounds__(512, TF_NTT_WAVES) ntt_pass_kernel(const NttPa
         // time, so the store burst overlaps the end of the arithmetic.  Slot q holds output row k = g + 32 q.
         dit_half<INV, 0>(x);
         dit_half<INV, 16>(x);
-        const u32 toff = (u32)(((long long)(ch + cw) * A.out_cs_hi + cl + (long long)g * A.out_rs) * 8);
+        const u32 toff = (u32)(((long long)ch * A.out_cs_hi + cl + (long long)g * A.out_rs) * 8);
         char* base = reinterpret_cast<char*>(out);
         if (A.n_out >= 0) {
             // truncated output (fast_multiply keeps the first n_out coefficients): slot q holds output element
             // j0 + 32 q js_k; the thread stores the slots below its own limit
-            const long long j0 = (long long)i0 * A.js_i0 + (long long)i1 * A.js_i1 + (long long)i2 * A.js_i2 +
-                                 (long long)(ch + cw - cshift) * A.js_c + (long long)g * A.js_k;
+            const long long j0 = (long long)i0 * A.js_i0 + (long long)i1 * A.js_i1 + (long long)(ch0 + ch) * A.js_c + (long long)g * A.js_k;
             const long long rem = A.n_out - j0, step = 32 * A.js_k;
             const int qlim = rem <= 0 ? 0 : (int)min(32ll, (rem + step - 1) / step);
             tail_p5<INV, 0, true>(x, act, base, toff, A.out_rs * 8, qlim);

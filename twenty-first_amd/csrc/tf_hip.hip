@@ -450,6 +450,7 @@ struct Launch {
     unsigned threads;
     size_t lds_bytes;
     bool bad_geometry = false;  // planner self-check failed: launch_pass refuses the launch
+    bool words16 = false;       // word-granular tiles of the R = 1024 last-pass kernel: only that kernel understands them
 };
 
 int pad_to_residue(int base, int residue) {  // smallest s >= base with s == residue (mod 32)
@@ -537,6 +538,22 @@ Launch plan_column_pass(const u64* in, u64* out, long long in_bs, long long out_
     return l;
 }
 
+std::atomic<int> g_ablate_cfg{-1};  // measurement only (TF_NTT_ABLATE=1|2 selects an ablated forward kernel; results are then garbage)
+int ablate_mode() {
+    int v = g_ablate_cfg.load(std::memory_order_relaxed);
+    if (v < 0) {
+        const char* e = getenv("TF_NTT_ABLATE");
+        v = e ? atoi(e) : 0;
+        g_ablate_cfg.store(v, std::memory_order_relaxed);
+    }
+    return v;
+}
+// the specialised R = 1024 last-pass kernel (LAST1024) is available unless an A/B switch or an ablation run disables it
+bool last1024_enabled() {
+    static const bool off = getenv("TF_NTT_NO_LAST1024") != nullptr;
+    return !off && ablate_mode() == 0;
+}
+
 // rows (independent DFTs) per tile for the passes whose columns are whole rows of elements
 int rows_per_tile(int P2, int L, long long limit) {
     int nc_max = std::max(1, wg_threads() / P2);
@@ -549,8 +566,10 @@ int rows_per_tile(int P2, int L, long long limit) {
 // A tile is T consecutive k1: its T*L word-columns are contiguous on the OUTPUT side.
 // split = N2 > 0 (four-pass transforms, one polynomial per launch): rho = k2 * (Q / N2) + k3 on the input side but
 // k2 + N2 * k3 on the output side; the kernel's batch index carries k2 and its rho index carries k3.
+// words16 (the R = 1024 last-pass kernel only): tiles are 16 adjacent output WORDS -- one 128-byte line -- instead of T whole
+// elements; for XFieldElement rows (24-byte elements) a tile then starts and ends inside an element, which that kernel handles.
 Launch plan_transpose_pass(const u64* in, u64* out, long long in_bs, long long out_bs, size_t batch, int a, long long N1,
-                           long long Q, int L, long long split = 0) {
+                           long long Q, int L, long long split = 0, bool words16 = false) {
     Launch l{};
     tfk::NttPassArgs& A = l.a;
     const int p2 = a - 5, P2 = 1 << p2;
@@ -562,17 +581,19 @@ Launch plan_transpose_pass(const u64* in, u64* out, long long in_bs, long long o
         const long long row_words = Q * R * L;
         const long long t_max = ((1ll << 29) - (1ll << 16)) / row_words;
         if (t_max < T) T = (int)std::max<long long>(1, t_max);
+        if (t_max < 17) words16 = false;  // a 16-word tile spans up to 16 (BFE) / 7 (XFE) rows
     }
-    const int nc = T * L;
+    const int nc = words16 ? 16 : T * L;
     A.in = in;
     A.out = out;
     A.L = L;
     A.d1 = (u32)Q;
-    A.d2 = (u32)((N1 + T - 1) / T);
+    A.d2 = words16 ? (u32)((N1 * L + 15) / 16) : (u32)((N1 + T - 1) / T);
+    l.words16 = words16;
     A.d01 = (u32)(batch * Q);
     A.ib0 = in_bs;
     A.ib1 = R * L;
-    A.ib2 = (long long)T * Q * R * L;
+    A.ib2 = (long long)T * Q * R * L;  // (ib2 / ob2 / js_i2 are not used by word-granular tiles)
     A.in_cs_hi = Q * R * L;
     A.in_rs = L;
     A.ob0 = out_bs;
@@ -664,8 +685,6 @@ int launch_pass_t(const Launch& l, hipStream_t stream) {
 }
 
 unsigned long long* g_dbg_buf = nullptr;  // TF_NTT_ABLATE=3: per-wave phase stamps of the last launch (tf_debug_stamps)
-std::atomic<int> g_ablate_cfg{-1};  // measurement only (TF_NTT_ABLATE=1|2 selects an ablated forward kernel; results are then garbage)
-
 constexpr size_t kLast1024LdsBytes = size_t(32) * 289 * sizeof(u64);
 
 int launch_pass(const Launch& l, bool inverse, hipStream_t stream) {
@@ -674,20 +693,13 @@ int launch_pass(const Launch& l, bool inverse, hipStream_t stream) {
         t_last_error = "NTT planner self-check failed (thread-to-column division is not exact for this geometry)";
         return TF_ERR_HIP;
     }
-    int g_ablate = g_ablate_cfg.load(std::memory_order_relaxed);
-    if (g_ablate < 0) {
-        const char* e = getenv("TF_NTT_ABLATE");
-        g_ablate = e ? atoi(e) : 0;
-        g_ablate_cfg.store(g_ablate, std::memory_order_relaxed);
-    }
-    if (l.a.n_out >= 0) {  // only the plain R = 1024 last-pass kernel truncates; anything else would overrun the caller's buffer
-        static const bool no_l1024 = getenv("TF_NTT_NO_LAST1024") != nullptr;
-        const bool ok = l.a.p2 == 5 && !l.a.post_tw && !l.a.gfast && !l.a.pre_scale && l.a.n_coeffs < 0 && !l.a.in2 && !l.a.post_scale &&
-                        g_ablate == 0 && !no_l1024;
-        if (!ok) {
-            t_last_error = "internal: truncated output requested from a pass that cannot truncate";
-            return TF_ERR_HIP;
-        }
+    const int g_ablate = ablate_mode();
+    // the plain R = 1024 last-pass kernel: the only one that truncates its output and that understands word-granular tiles
+    const bool plain_last1024 = l.a.p2 == 5 && !l.a.post_tw && !l.a.gfast && !l.a.pre_scale && l.a.n_coeffs < 0 && !l.a.in2 &&
+                                !l.a.post_scale && last1024_enabled();
+    if ((l.a.n_out >= 0 || l.words16) && !plain_last1024) {  // anything else would overrun the caller's buffer / misread the tiles
+        t_last_error = "internal: truncated output or word-granular tiles requested from a pass that does not support them";
+        return TF_ERR_HIP;
     }
     if (l.a.pre_scale || l.a.n_coeffs >= 0 || l.a.in2) {
         // work on load: coset scaling, zero padding, or the pointwise product with a second operand (forward or inverse;
@@ -699,9 +711,8 @@ int launch_pass(const Launch& l, bool inverse, hipStream_t stream) {
     }
     if (l.a.post_scale) return launch_pass_t<true, 2, 0>(l, stream);   // coset interpolation: inverse, scale on store
     // last pass of a plain transform with R = 1024: specialised kernel (constant P2, stores fused with level 5)
-    static const bool no_last1024 = getenv("TF_NTT_NO_LAST1024") != nullptr;  // A/B switch
     // (not for single-pass transforms: their stores run along the row as well, which only the gfast roles give -- 1.05 vs 1.20 ms)
-    const bool last1024 = l.a.p2 == 5 && !l.a.post_tw && g_ablate == 0 && !no_last1024 && !l.a.gfast;
+    const bool last1024 = l.a.p2 == 5 && !l.a.post_tw && last1024_enabled() && !l.a.gfast;
     static const bool no_r1024 = getenv("TF_NTT_NO_R1024") != nullptr;  // A/B switch
     const bool r1024 = l.a.p2 == 5 && l.a.post_tw && g_ablate == 0 && !no_r1024;  // column pass with R = 1024
     if (last1024) {  // this instantiation lays its exchange buffer out itself (32 x 289 words, ntt_kernels.h)
@@ -844,11 +855,12 @@ void choose_split(int log_n, int P, int L, int (&a)[4]) {
         // and stores fused into level 5, 128-byte output segments); the column passes share the rest evenly, larger first.
         // Measured against the even split (tools/split3.py, 2^28 words per call): 2^15 1.92 vs 2.62 ms, 2^18 2.20 vs 2.48,
         // 2^22 3.18 vs 3.49, 2^24 3.31 vs 4.15, 2^26 3.58 vs 3.99.
-        // XFieldElement slices (L = 3) are the exception: a last pass with R = 1024 has only 5 rows (15 word-columns) per
-        // workgroup, and the sweep prefers R = 32 (170 rows per tile) for the smaller lengths (n <= 2^15, 2^21 and 2^22) and R = 512 above.
+        // XFieldElement slices (L = 3) follow the same rule for n = 2^15, 2^20 and n >= 2^23 now that the R = 1024 kernel tiles
+        // their rows by whole 128-byte lines (tools/xfe_sweep.sh: 2^15 1.62 vs 1.83 ms, 2^23 2.62 vs 2.71, 2^25 2.71 vs 2.86 per
+        // 3 * 2^26 words); the sweep still prefers R = 32 (170 rows per tile) for n < 2^15, 2^21 and 2^22 and R = 512 for 2^16 .. 2^19.
         int last = std::min(10, log_n - 5 * (P - 1));
-        if (L == 3 && P == 2 && log_n < 20) last = log_n <= 15 ? 5 : 9;
-        if (L == 3 && P == 3 && log_n < 30) last = log_n <= 22 ? 5 : 9;
+        if (L == 3 && P == 2 && log_n < 20 && log_n != 15) last = log_n < 15 ? 5 : 9;
+        if (L == 3 && P == 3 && log_n <= 22) last = 5;
         a[P - 1] = last;
         int rest = log_n - last;
         if (L == 3 && P == 3 && log_n <= 22) {  // (log_n - 15, 10, 5)
@@ -882,8 +894,7 @@ bool can_truncate(size_t n, int L) {
     const int log_n = ilog2(n), P = pass_count(log_n);
     int a[4] = {0, 0, 0, 0};
     choose_split(log_n, P, L, a);
-    static const bool no_last1024 = getenv("TF_NTT_NO_LAST1024") != nullptr;
-    return P <= 3 && a[P - 1] == 10 && !no_last1024;
+    return P <= 3 && a[P - 1] == 10 && last1024_enabled();
 }
 
 // The transform proper.  in/out are device pointers; in == out for ntt/intt, distinct for coset evaluation
@@ -1038,16 +1049,20 @@ int run_ntt(DeviceCtx* ctx, const u64* in, u64* out, long long in_bs, long long 
         }
         if (rc) break;
         if (P < 4) {
-            Launch pl = plan_transpose_pass(scratch, tout, sbs, out_bs, nb, a[P - 1], N[0] * (long long)cosets, P == 3 ? N[1] : 1, L);
+            // XFieldElement rows through the R = 1024 kernel: word-granular tiles (whole 128-byte lines on the output side)
+            static const bool no_words16 = getenv("TF_NTT_NO_WORDS16") != nullptr;  // A/B switch
+            const bool plain1024 = a[P - 1] == 10 && !post_scale && last1024_enabled();
+            Launch pl = plan_transpose_pass(scratch, tout, sbs, out_bs, nb, a[P - 1], N[0] * (long long)cosets, P == 3 ? N[1] : 1, L, 0,
+                                            plain1024 && L == 3 && !no_words16);
             pl.a.inner_tw = inner[P - 1];
             pl.a.post_scale = post_scale;
             pl.a.n_out = n_out;
-            if (L == 1 && a[P - 1] == 10 && pl.a.nc == 16 && !post_scale && !no_col_shift && log_n <= 28) {
+            if (plain1024 && pl.a.nc == 16 && !no_col_shift && (unsigned long long)n * L * sizeof(u64) < (1ull << 32)) {
                 // The R = 1024 last pass stores 128-byte segments of 16 adjacent output words.  When the output of batch entry
                 // b does not start on a cache line (a truncated product: stride n_out = na + nb - 1 words, or a caller's
                 // unaligned pointer) every segment would straddle two lines written by workgroups on different XCDs: shift
                 // the tile boundaries of entry b by s = (word address of its first output) mod 16 columns so that they fall
-                // on lines again; the first tile of a row wraps around to the row's last s columns.  (log_n <= 28: the
+                // on lines again; the first tile of a row wraps around to the row's last s columns.  (n * L * 8 < 2^32: the
                 // wrapped lanes' 32-bit byte offset spans the whole transform.)  Measured, tools/trunc_align.py: 256 products
                 // of 2^19 x 2^19 7.29 -> 7.05 ms, 1024 of 2^17 x 2^17 7.19 -> 6.66, 64 of 2^21 x 2^21 10.25 -> 9.65.
                 pl.a.col_shift0 = (int)((reinterpret_cast<uintptr_t>(tout) / sizeof(u64)) & 15);
