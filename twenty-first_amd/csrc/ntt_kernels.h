@@ -70,7 +70,8 @@ struct NttPassArgs {
     int gfast;                               // 1: thread t is (g = t % P2, column t / P2) instead of (t / nc, t % nc)
     int xcd_order;                           // G > 0: XCD-aware tile order in groups of G adjacent column tiles (0: natural order)
     int xcd_colfast;                         // with xcd_order: walk the XCD's column groups fastest (their table slices fit its L2)
-    int col_shift0, col_shift_i0, col_wrap;  // LAST1024, L = 1: tile i2 of batch entry i0 covers columns [16 i2 - s, 16 i2 - s + 16) mod
+    int wtiles;                              // transposing passes: word-granular tiles (see the kernel); LAST1024 always works this way
+    int col_shift0, col_shift_i0, col_wrap;  // LAST1024: tile i2 of batch entry i0 covers columns [16 i2 - s, 16 i2 - s + 16) mod
                                              // col_wrap (= N_1), s = (col_shift0 + i0 * col_shift_i0) mod 16, so its 128-byte output
                                              // segments start on cache lines even when the output stride is not a multiple of 16 words
                                              // (truncated products); tile 0 wraps around to the last s columns
@@ -233,11 +234,14 @@ __global__ void __launch_bounds__(512, TF_NTT_WAVES) ntt_pass_kernel(const NttPa
     // tile may start and end inside an element).  s = cshift is the word address of the entry's first output mod 16, so
     // every 16-word store segment is one whole cache line; tile 0 takes the last s columns of the row instead of the
     // columns below 0 (col_wrap).  Word-column w is limb w % L of element column w / L.
+    // The other last-pass instantiations tile the same way when the planner asks (A.wtiles: XFE rows, so that their store
+    // segments are whole lines as well), without the shift.
+    const bool wt = LAST1024 || A.wtiles;
     const int cshift = LAST1024 ? (int)((A.col_shift0 + i0 * (u32)A.col_shift_i0) & 15u) : 0;
     const int col0 = (int)i2 * A.nc - cshift;
     const int ncv = min(A.nc, A.col_limit - col0);
-    const int ch0 = LAST1024 ? (int)div_by_L((u32)max(col0, 0), L) : 0;  // first element column of the tile (uniform)
-    if constexpr (LAST1024) {
+    const int ch0 = wt ? (int)div_by_L((u32)max(col0, 0), L) : 0;  // first element column of the tile (uniform)
+    if (wt) {
         in = A.in + (long long)i0 * A.ib0 + (long long)i1 * A.ib1 + (long long)ch0 * A.in_cs_hi;
         out = A.out + (long long)i0 * A.ob0 + (long long)i1 * A.ob1 + (long long)ch0 * A.out_cs_hi;
     }
@@ -248,8 +252,8 @@ __global__ void __launch_bounds__(512, TF_NTT_WAVES) ntt_pass_kernel(const NttPa
     const int c = LAST1024 ? (t & 15) : (A.gfast ? (t >> p2) : (t - g * A.nc));                                              // t % nc
     const bool act = c < ncv;
     int ch, cl;  // element column relative to the tile base, limb
-    if constexpr (LAST1024) {
-        const int w = col0 + c + (col0 + c < 0 ? A.col_wrap : 0);
+    if (wt) {
+        const int w = col0 + c + ((LAST1024 && col0 + c < 0) ? A.col_wrap : 0);
         const int e = (int)div_by_L((u32)w, L);
         ch = e - ch0, cl = w - e * L;
     } else {
@@ -481,7 +485,8 @@ __global__ void __launch_bounds__(512, TF_NTT_WAVES) ntt_pass_kernel(const NttPa
                 __builtin_amdgcn_sched_barrier(0);
             }
         } else if constexpr (SCALE == 2) {
-            const long long j0 = (long long)i0 * A.js_i0 + (long long)i1 * A.js_i1 + (long long)i2 * A.js_i2 + (long long)ch * A.js_c + (long long)g * A.js_k;
+            const long long j0 = (long long)i0 * A.js_i0 + (long long)i1 * A.js_i1 + (wt ? (long long)(ch0 + ch) * A.js_c : (long long)i2 * A.js_i2 + (long long)ch * A.js_c) +
+                                 (long long)g * A.js_k;
 #pragma unroll
             for (int q0 = 0; q0 < 32; q0 += 8) {
                 u64 w[8];

@@ -450,7 +450,6 @@ struct Launch {
     unsigned threads;
     size_t lds_bytes;
     bool bad_geometry = false;  // planner self-check failed: launch_pass refuses the launch
-    bool words16 = false;       // word-granular tiles of the R = 1024 last-pass kernel: only that kernel understands them
 };
 
 int pad_to_residue(int base, int residue) {  // smallest s >= base with s == residue (mod 32)
@@ -566,10 +565,10 @@ int rows_per_tile(int P2, int L, long long limit) {
 // A tile is T consecutive k1: its T*L word-columns are contiguous on the OUTPUT side.
 // split = N2 > 0 (four-pass transforms, one polynomial per launch): rho = k2 * (Q / N2) + k3 on the input side but
 // k2 + N2 * k3 on the output side; the kernel's batch index carries k2 and its rho index carries k3.
-// words16 (the R = 1024 last-pass kernel only): tiles are 16 adjacent output WORDS -- one 128-byte line -- instead of T whole
-// elements; for XFieldElement rows (24-byte elements) a tile then starts and ends inside an element, which that kernel handles.
+// words > 0: word-granular tiles of `words` adjacent output WORDS (whole 128-byte lines) instead of T whole elements; for
+// XFieldElement rows (24-byte elements) a tile then starts and ends inside an element (NttPassArgs::wtiles).
 Launch plan_transpose_pass(const u64* in, u64* out, long long in_bs, long long out_bs, size_t batch, int a, long long N1,
-                           long long Q, int L, long long split = 0, bool words16 = false) {
+                           long long Q, int L, long long split = 0, int words = 0) {
     Launch l{};
     tfk::NttPassArgs& A = l.a;
     const int p2 = a - 5, P2 = 1 << p2;
@@ -581,15 +580,15 @@ Launch plan_transpose_pass(const u64* in, u64* out, long long in_bs, long long o
         const long long row_words = Q * R * L;
         const long long t_max = ((1ll << 29) - (1ll << 16)) / row_words;
         if (t_max < T) T = (int)std::max<long long>(1, t_max);
-        if (t_max < 17) words16 = false;  // a 16-word tile spans up to 16 (BFE) / 7 (XFE) rows
+        if (t_max < words / L + 2) words = 0;  // rows a word-granular tile can span
     }
-    const int nc = words16 ? 16 : T * L;
+    const int nc = words ? words : T * L;
     A.in = in;
     A.out = out;
     A.L = L;
     A.d1 = (u32)Q;
-    A.d2 = words16 ? (u32)((N1 * L + 15) / 16) : (u32)((N1 + T - 1) / T);
-    l.words16 = words16;
+    A.d2 = words ? (u32)((N1 * L + words - 1) / words) : (u32)((N1 + T - 1) / T);
+    A.wtiles = words ? 1 : 0;
     A.d01 = (u32)(batch * Q);
     A.ib0 = in_bs;
     A.ib1 = R * L;
@@ -694,11 +693,11 @@ int launch_pass(const Launch& l, bool inverse, hipStream_t stream) {
         return TF_ERR_HIP;
     }
     const int g_ablate = ablate_mode();
-    // the plain R = 1024 last-pass kernel: the only one that truncates its output and that understands word-granular tiles
+    // the plain R = 1024 last-pass kernel: the only one that truncates its output and shifts its tiles
     const bool plain_last1024 = l.a.p2 == 5 && !l.a.post_tw && !l.a.gfast && !l.a.pre_scale && l.a.n_coeffs < 0 && !l.a.in2 &&
                                 !l.a.post_scale && last1024_enabled();
-    if ((l.a.n_out >= 0 || l.words16) && !plain_last1024) {  // anything else would overrun the caller's buffer / misread the tiles
-        t_last_error = "internal: truncated output or word-granular tiles requested from a pass that does not support them";
+    if ((l.a.n_out >= 0 || l.a.col_shift0 || l.a.col_shift_i0) && !plain_last1024) {  // anything else would overrun the caller's buffer
+        t_last_error = "internal: truncated output or shifted tiles requested from a pass that does not support them";
         return TF_ERR_HIP;
     }
     if (l.a.pre_scale || l.a.n_coeffs >= 0 || l.a.in2) {
@@ -1052,8 +1051,19 @@ int run_ntt(DeviceCtx* ctx, const u64* in, u64* out, long long in_bs, long long 
             // XFieldElement rows through the R = 1024 kernel: word-granular tiles (whole 128-byte lines on the output side)
             static const bool no_words16 = getenv("TF_NTT_NO_WORDS16") != nullptr;  // A/B switch
             const bool plain1024 = a[P - 1] == 10 && !post_scale && last1024_enabled();
+            // (the other last-pass kernels too: all their thread slots as word-columns, e.g. 32 words = 256 bytes for R = 512)
+            int words = 0;
+            if (L == 3 && !no_words16) {
+                if (plain1024) {
+                    words = 16;
+                } else {  // share the N_1 * L words of a row evenly among the fewest tiles, in whole lines
+                    const long long tot = N[0] * (long long)cosets * L, wmax = std::max(16, wg_threads() >> (a[P - 1] - 5));
+                    const long long tiles_per_row = (tot + wmax - 1) / wmax;
+                    words = (int)((((tot + tiles_per_row - 1) / tiles_per_row) + 15) / 16 * 16);
+                }
+            }
             Launch pl = plan_transpose_pass(scratch, tout, sbs, out_bs, nb, a[P - 1], N[0] * (long long)cosets, P == 3 ? N[1] : 1, L, 0,
-                                            plain1024 && L == 3 && !no_words16);
+                                            words);
             pl.a.inner_tw = inner[P - 1];
             pl.a.post_scale = post_scale;
             pl.a.n_out = n_out;
