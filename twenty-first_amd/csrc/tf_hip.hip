@@ -856,15 +856,16 @@ void choose_split(int log_n, int P, int L, int (&a)[4]) {
         // 2^22 3.18 vs 3.49, 2^24 3.31 vs 4.15, 2^26 3.58 vs 3.99.
         // XFieldElement slices (L = 3) follow the same rule for n = 2^15, 2^20 and n >= 2^23 now that the R = 1024 kernel tiles
         // their rows by whole 128-byte lines (tools/xfe_sweep.sh: 2^15 1.62 vs 1.83 ms, 2^23 2.62 vs 2.71, 2^25 2.71 vs 2.86 per
-        // 3 * 2^26 words); the sweep still prefers R = 32 (170 rows per tile) for n < 2^15, 2^21 and 2^22 and R = 512 for 2^16 .. 2^19.
+        // 3 * 2^26 words); the sweep still prefers R = 32 for n < 2^15 and R = 512 for 2^16 .. 2^19 (all within 1 % of R = 1024).
         int last = std::min(10, log_n - 5 * (P - 1));
         if (L == 3 && P == 2 && log_n < 20 && log_n != 15) last = log_n < 15 ? 5 : 9;
-        if (L == 3 && P == 3 && log_n <= 22) last = 5;
         a[P - 1] = last;
         int rest = log_n - last;
-        if (L == 3 && P == 3 && log_n <= 22) {  // (log_n - 15, 10, 5)
-            a[1] = std::min(10, rest - 5);
-            a[0] = rest - a[1];
+        if (P == 3 && last == 10 && log_n <= (L == 3 ? 25 : 23)) {
+            // (log_n - 15, 5, 10): an exchange-free radix-32 pass in the middle (tools/split3.py: XFE 2^21 2.26 vs 2.33 ms,
+            // 2^23 2.34 vs 2.45, 2^25 2.49 vs 2.51 per 3 * 2^26 words; BFE 2^22 2.90 vs 3.04, 2^23 3.01 vs 3.09 per 2^28)
+            a[1] = 5;
+            a[0] = rest - 5;
         } else {
             for (int i = 0; i + 1 < P; ++i) {
                 a[i] = (rest + (P - 1 - i) - 1) / (P - 1 - i);
