@@ -151,13 +151,26 @@ __device__ __forceinline__ void dit_half(u64 (&x)[32]) {
 
 // Level 5 of the radix-32 network for the four butterflies (Q0+i, Q0+i+16), i < 4, followed by their eight stores.
 // TRUNC: only the slots q < qlim are stored (output truncated to the first n_out elements, fast_multiply).
-template <bool INV, int Q0, bool TRUNC = false>
-__device__ __forceinline__ void tail_p5(u64 (&x)[32], bool act, char* obase, u32 toff, long long out_rs_bytes, int qlim = 32) {
+// SCALED: every output is multiplied by its word of a table laid out like the output (fast_coset_interpolate's offset^-j):
+//         sbase + 32 q s_rs_bytes + soff for slot q.
+template <bool INV, int Q0, bool TRUNC = false, bool SCALED = false>
+__device__ __forceinline__ void tail_p5(u64 (&x)[32], bool act, char* obase, u32 toff, long long out_rs_bytes, int qlim = 32,
+                                        const char* sbase = nullptr, u32 soff = 0, long long s_rs_bytes = 0) {
     butterfly_pow2<TwExp<INV, 5, Q0 + 0>::value>(x[Q0 + 0], x[Q0 + 16]);
     butterfly_pow2<TwExp<INV, 5, Q0 + 1>::value>(x[Q0 + 1], x[Q0 + 17]);
     butterfly_pow2<TwExp<INV, 5, Q0 + 2>::value>(x[Q0 + 2], x[Q0 + 18]);
     butterfly_pow2<TwExp<INV, 5, Q0 + 3>::value>(x[Q0 + 3], x[Q0 + 19]);
     if (act) {
+        if constexpr (SCALED) {
+            u64 w[8];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                w[i] = *reinterpret_cast<const u64*>(sbase + (long long)(32 * (Q0 + i)) * s_rs_bytes + soff);
+                w[4 + i] = *reinterpret_cast<const u64*>(sbase + (long long)(32 * (Q0 + i + 16)) * s_rs_bytes + soff);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) gl::mont_mul2(x[Q0 + i], w[i], x[Q0 + i + 16], w[4 + i], x[Q0 + i], x[Q0 + i + 16]);
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             if (!TRUNC || Q0 + i < qlim) *reinterpret_cast<u64*>(obase + (long long)(32 * (Q0 + i)) * out_rs_bytes + toff) = x[Q0 + i];
@@ -426,6 +439,17 @@ __global__ void __launch_bounds__(512, TF_NTT_WAVES) ntt_pass_kernel(const NttPa
         dit_half<INV, 16>(x);
         const u32 toff = (u32)(((long long)ch * A.out_cs_hi + cl + (long long)g * A.out_rs) * 8);
         char* base = reinterpret_cast<char*>(out);
+        if constexpr (SCALE == 2) {
+            // fast_coset_interpolate: output coefficient j times offset^-j; slot q holds element j0 + 32 q js_k (planner: n <= 2^28)
+            const long long j0 = (long long)i0 * A.js_i0 + (long long)i1 * A.js_i1 + (long long)(ch0 + ch) * A.js_c + (long long)g * A.js_k;
+            const char* sb = reinterpret_cast<const char*>(A.post_scale);
+            const u32 soff = (u32)(j0 * 8);
+            tail_p5<INV, 0, false, true>(x, act, base, toff, A.out_rs * 8, 32, sb, soff, A.js_k * 8);
+            tail_p5<INV, 4, false, true>(x, act, base, toff, A.out_rs * 8, 32, sb, soff, A.js_k * 8);
+            tail_p5<INV, 8, false, true>(x, act, base, toff, A.out_rs * 8, 32, sb, soff, A.js_k * 8);
+            tail_p5<INV, 12, false, true>(x, act, base, toff, A.out_rs * 8, 32, sb, soff, A.js_k * 8);
+            return;
+        }
         if (A.n_out >= 0) {
             // truncated output (fast_multiply keeps the first n_out coefficients): slot q holds output element
             // j0 + 32 q js_k; the thread stores the slots below its own limit

@@ -553,6 +553,12 @@ bool last1024_enabled() {
     return !off && ablate_mode() == 0;
 }
 
+// ... and its variant that multiplies on store (fast_coset_interpolate)
+bool scaled_last1024_enabled() {
+    static const bool off = getenv("TF_NTT_NO_SCALED_LAST1024") != nullptr;  // A/B switch
+    return !off;
+}
+
 // rows (independent DFTs) per tile for the passes whose columns are whole rows of elements
 int rows_per_tile(int P2, int L, long long limit) {
     int nc_max = std::max(1, wg_threads() / P2);
@@ -695,7 +701,7 @@ int launch_pass(const Launch& l, bool inverse, hipStream_t stream) {
     const int g_ablate = ablate_mode();
     // the plain R = 1024 last-pass kernel: the only one that truncates its output and shifts its tiles
     const bool plain_last1024 = l.a.p2 == 5 && !l.a.post_tw && !l.a.gfast && !l.a.pre_scale && l.a.n_coeffs < 0 && !l.a.in2 &&
-                                !l.a.post_scale && last1024_enabled();
+                                (!l.a.post_scale || (inverse && scaled_last1024_enabled())) && last1024_enabled();
     if ((l.a.n_out >= 0 || l.a.col_shift0 || l.a.col_shift_i0) && !plain_last1024) {  // anything else would overrun the caller's buffer
         t_last_error = "internal: truncated output or shifted tiles requested from a pass that does not support them";
         return TF_ERR_HIP;
@@ -708,7 +714,15 @@ int launch_pass(const Launch& l, bool inverse, hipStream_t stream) {
         if (l.a.p2 == 5 && l.a.post_tw && !no_r1024_scale) return launch_pass_t<false, 1, 0, false, true>(l, stream);
         return launch_pass_t<false, 1, 0>(l, stream);
     }
-    if (l.a.post_scale) return launch_pass_t<true, 2, 0>(l, stream);   // coset interpolation: inverse, scale on store
+    if (l.a.post_scale) {  // coset interpolation: inverse, scale on store
+        if (plain_last1024) {  // R = 1024 last pass: the specialised kernel with the multiplication in its fused tail
+            Launch l2 = l;
+            l2.lds_bytes = std::max(l.lds_bytes, kLast1024LdsBytes);
+            l2.threads = 512;
+            return launch_pass_t<true, 2, 0, true>(l2, stream);
+        }
+        return launch_pass_t<true, 2, 0>(l, stream);
+    }
     // last pass of a plain transform with R = 1024: specialised kernel (constant P2, stores fused with level 5)
     // (not for single-pass transforms: their stores run along the row as well, which only the gfast roles give -- 1.05 vs 1.20 ms)
     const bool last1024 = l.a.p2 == 5 && !l.a.post_tw && last1024_enabled() && !l.a.gfast;
@@ -1051,7 +1065,7 @@ int run_ntt(DeviceCtx* ctx, const u64* in, u64* out, long long in_bs, long long 
         if (P < 4) {
             // XFieldElement rows through the R = 1024 kernel: word-granular tiles (whole 128-byte lines on the output side)
             static const bool no_words16 = getenv("TF_NTT_NO_WORDS16") != nullptr;  // A/B switch
-            const bool plain1024 = a[P - 1] == 10 && !post_scale && last1024_enabled();
+            const bool plain1024 = a[P - 1] == 10 && last1024_enabled() && (!post_scale || (inverse && scaled_last1024_enabled() && log_n <= 28));
             // (the other last-pass kernels too: all their thread slots as word-columns, e.g. 32 words = 256 bytes for R = 512)
             int words = 0;
             if (L == 3 && !no_words16) {
