@@ -95,6 +95,7 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="transforms per GPU")
     ap.add_argument("--no-settle", action="store_true", help="skip the untimed stabilisation passes before the warmup")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true", help="initialise the RCCL process group even for one rank (exercises the N > 1 code path on a 1-GPU box)")
     ap.add_argument("--no-extra", action="store_true", help="skip the Merkle / coset-evaluation side measurements")
     args = ap.parse_args()
 
@@ -113,12 +114,14 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the product has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29517")
+        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -197,7 +200,7 @@ def main():
     sclk_after = tf.lib().tf_debug_sclk_mhz()
     copy_after = copy_gbs()
     barrier()
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -289,7 +292,7 @@ def main():
         if world == 1 and not args.no_extra:
             out["extra"] = side_measurements(tf, torch, dev)
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
