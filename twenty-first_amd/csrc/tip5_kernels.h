@@ -349,6 +349,7 @@ __global__ void __launch_bounds__(1024) merkle_top_kernel(const u64* level_in, l
                                                           long long leaves_ts) {
     __shared__ __attribute__((aligned(16))) unsigned char lut[256];
     __shared__ u64 buf[2][256 * 5];
+    (void)leaves_ts;  // leaves_to_copy != null only says that level_in IS the leaf level, to be copied into nodes[width..2 width)
     stage_lut(lut);
     const long long tree = blockIdx.x;
     const int t = threadIdx.x, j = t & 15, row = t >> 4;  // 64 rows of 16 lanes: one hash_pair per row at a time
