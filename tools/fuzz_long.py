@@ -9,11 +9,17 @@ P = 0xFFFFFFFF00000001
 seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 budget = float(sys.argv[2]) if len(sys.argv) > 2 else 150.0
 rng = random.Random(seed)
+KINDS = ["ntt", "ntt", "coset", "coset", "interp", "mul", "merkle", "varlen", "eval", "extrap", "lde", "auth", "square", "mulb", "nttu", "interpu"]
+if len(sys.argv) > 3:
+    KINDS = sys.argv[3].split(",")
+import torch
+def dev_words(a): return torch.from_numpy(a.view(np.int64)).cuda()
+FILL = np.uint64(0xFFFFFFFFFFFFFFFF)
 counts = {}
 t_end = time.time() + budget
 def bump(k): counts[k] = counts.get(k, 0) + 1
 while time.time() < t_end:
-    kind = rng.choice(["ntt", "ntt", "coset", "coset", "interp", "mul", "merkle", "varlen", "eval", "extrap", "lde", "auth", "square"])
+    kind = rng.choice(KINDS)
     width = rng.choice([1, 3])
     if kind == "ntt":
         log_n = rng.randint(0, 23)
@@ -47,6 +53,42 @@ while time.time() < t_end:
         a = oracle.fill_random(na * width, rng.getrandbits(40)); b = oracle.fill_random(nb * width, rng.getrandbits(40))
         got = tf.fast_multiply(a, b, width=width)
         assert np.array_equal(got, oracle.poly_mul(a, b, width=width)), (kind, na, nb, width)
+    elif kind == "mulb":  # packed batch of products on device, unaligned output pointer
+        log_hi = rng.choice([11, 13, 15, 16, 17, 18, 20])
+        na, nb = rng.randint(1, 1 << (log_hi - 1)), rng.randint(1, 1 << (log_hi - 1))
+        batch, shift = rng.randint(1, 5), rng.randint(0, 15)
+        a = oracle.fill_random(na * width * batch, rng.getrandbits(40)); b = oracle.fill_random(nb * width * batch, rng.getrandbits(40))
+        n_out = (na + nb - 1) * width
+        out = torch.full((n_out * batch + shift + 40,), -1, dtype=torch.int64, device="cuda")
+        tf.device.poly_mul(dev_words(a), na, dev_words(b), nb, out[shift:shift + n_out * batch], batch=batch, width=width)
+        torch.cuda.synchronize()
+        got = out.cpu().numpy().view(np.uint64)
+        assert np.all(got[:shift] == FILL) and np.all(got[shift + n_out * batch:] == FILL), (kind, "guard", na, nb, width, batch, shift)
+        for k in range(batch):
+            want = oracle.poly_mul(a[k * na * width:(k + 1) * na * width], b[k * nb * width:(k + 1) * nb * width], width=width)
+            assert np.array_equal(got[shift + k * n_out:shift + (k + 1) * n_out], want), (kind, na, nb, width, batch, shift, k)
+    elif kind in ("nttu", "interpu"):  # in place / out of place on unaligned device slices
+        log_n = rng.randint(5, 22)
+        n = 1 << log_n
+        batch = rng.randint(1, max(1, min(9, (1 << 22) // (n * width))))
+        shift, inverse = rng.randint(1, 15), rng.random() < 0.5
+        words = n * width * batch
+        x = oracle.fill_random(words, rng.getrandbits(40))
+        buf = torch.full((words + shift + 40,), -1, dtype=torch.int64, device="cuda")
+        buf[shift:shift + words] = dev_words(x)
+        if kind == "nttu":
+            tf.device.ntt_(buf[shift:shift + words], n, batch=batch, width=width, inverse=inverse)
+            want = oracle.ntt(x, width=width, inverse=inverse, batch=batch, threads=16)
+            res = buf
+        else:
+            off = oracle.bfe_new(rng.randrange(1, P))
+            res = torch.full((words + shift + 40,), -1, dtype=torch.int64, device="cuda")
+            tf.device.coset_interpolate(buf[shift:shift + words], n, off, res[shift:shift + words], batch=batch, width=width)
+            want = np.concatenate([oracle.coset_interpolate(x[k * n * width:(k + 1) * n * width], off, width=width) for k in range(batch)])
+        torch.cuda.synchronize()
+        got = res.cpu().numpy().view(np.uint64)
+        assert np.all(got[:shift] == FILL) and np.all(got[shift + words:] == FILL), (kind, "guard", log_n, width, batch, shift)
+        assert np.array_equal(got[shift:shift + words], want), (kind, log_n, width, batch, shift, inverse)
     elif kind == "merkle":
         h = rng.randint(0, 18)
         n = 1 << h
