@@ -201,6 +201,9 @@ void tf_set_ntt_min_passes(int passes);
 /* Number of ntt_pass_kernel launches one tf_ntt_*_dev call enqueues for this shape (diagnostic; used by
  * bench.py to turn a HIP-event interval into an average launch duration). */
 int tf_ntt_launch_count(size_t n, size_t batch, int width);
+/* Planner introspection (no device needed): number of global passes of one n-point transform (0 for lengths ntt rejects)
+ * and log2 of each pass's radix in log2_radix_out[0..3] (unused entries 0).  The radices multiply to n. */
+int tf_ntt_plan(size_t n, int width, int* log2_radix_out);
 /* Measurement helper for tools/phase_timeline.py (TF_NTT_ABLATE=3): per-wave phase cycle stamps of the NTT pass kernel. */
 int tf_debug_stamps(unsigned long long *host_out, size_t words);
 /* Measurement helper: the shader clock (MHz) the current device is running at right now (one-wave ~0.5 ms spin; < 0 on failure). */

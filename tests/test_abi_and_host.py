@@ -128,3 +128,33 @@ def test_length_checks_precede_any_device_work(tf):
     assert lib.tf_ntt_launch_count(1 << 31, 1, 1) == 4            # 2^31 is in range: three column passes + one last pass
     assert lib.tf_ntt_launch_count(1 << 20, 256, 1) == 2
     assert lib.tf_ntt_launch_count(1 << 32, 1, 1) == 0
+
+
+def test_planner_splits_are_valid_for_every_length(tf):
+    """Host logic, no device: for every length ntt accepts (math/ntt.rs:134-139) and both element widths the pass plan has
+    radices in [2^5, 2^10] that multiply to n (single-pass lengths: one radix = n), also with the deeper plans forced."""
+    import ctypes as C
+    lib = tf._lib.lib()
+    radix = (C.c_int * 4)()
+    assert lib.tf_ntt_plan(12, 1, radix) == 0 and lib.tf_ntt_plan(1 << 32, 1, radix) == 0 and lib.tf_ntt_plan(1, 1, radix) == 0
+    assert lib.tf_ntt_plan(1 << 20, 2, radix) == 0
+    for force in (0, 3, 4):
+        lib.tf_set_ntt_min_passes(force)
+        try:
+            for width in (1, 3):
+                for log_n in range(1, 32):
+                    passes = lib.tf_ntt_plan(1 << log_n, width, radix)
+                    r = list(radix)
+                    assert 1 <= passes <= 4 and sum(r[:passes]) == log_n and all(v == 0 for v in r[passes:]), (force, width, log_n, r)
+                    if passes > 1:
+                        assert all(5 <= v <= 10 for v in r[:passes]), (force, width, log_n, r)
+                        assert passes >= (2 if log_n <= 20 else 3 if log_n <= 30 else 4)
+                    else:
+                        assert log_n <= 10 or (width == 1 and log_n <= 14 and force == 0)
+                    if force and log_n >= 5 * force:
+                        assert passes >= force, (force, width, log_n, r)
+        finally:
+            lib.tf_set_ntt_min_passes(0)
+    # the headline transform: two passes of radix 1024; launches per call follow the plan
+    assert lib.tf_ntt_plan(1 << 20, 1, radix) == 2 and list(radix)[:2] == [10, 10]
+    assert lib.tf_ntt_launch_count(1 << 13, 1000, 1) == 1 and lib.tf_ntt_launch_count(1 << 13, 1000, 3) == 2

@@ -1864,10 +1864,29 @@ int tf_debug_stamps(unsigned long long* host_out, size_t words) {
 }
 
 void tf_set_ntt_min_passes(int passes) { g_min_passes.store(passes, std::memory_order_relaxed); }
+// The plan of one transform: number of global passes and log2 of each pass's radix (planner introspection for the CPU tests).
+int tf_ntt_plan(size_t n, int width, int* log2_radix_out) {
+    if (check_len(n) || n <= 1 || (width != 1 && width != 3) || !log2_radix_out) return 0;
+    const int log_n = ilog2(n);
+    for (int i = 0; i < 4; ++i) log2_radix_out[i] = 0;
+    static const bool no_block = getenv("TF_NTT_NO_BLOCK") != nullptr;
+    if (log_n <= 10 || (log_n <= 14 && width == 1 && !no_block && g_min_passes.load(std::memory_order_relaxed) == 0)) {
+        log2_radix_out[0] = log_n;
+        return 1;
+    }
+    const int P = pass_count(log_n);
+    int a[4] = {0, 0, 0, 0};
+    choose_split(log_n, P, width, a);
+    for (int i = 0; i < P; ++i) log2_radix_out[i] = a[i];
+    return P;
+}
+
 int tf_ntt_launch_count(size_t n, size_t batch, int width) {
     if (check_len(n) || n <= 1 || batch == 0 || (width != 1 && width != 3)) return 0;
     const int log_n = ilog2(n);
     if (log_n <= 10) return (int)((batch + (size_t(1) << 24) - 1) >> 24);
+    int radix[4];
+    if (tf_ntt_plan(n, width, radix) == 1) return 1;  // whole transform per workgroup (BFE 2^11 .. 2^14)
     read_env();
     const size_t poly_bytes = n * size_t(width) * sizeof(u64);
     size_t tb = std::min(std::max<size_t>(1, g_tile_bytes / poly_bytes), batch);
