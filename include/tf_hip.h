@@ -200,6 +200,9 @@ void tf_set_ntt_tile_bytes(size_t bytes);
 void tf_set_ntt_min_passes(int passes);
 /* Number of ntt_pass_kernel launches one tf_ntt_*_dev call enqueues for this shape (diagnostic; used by
  * bench.py to turn a HIP-event interval into an average launch duration). */
+/* Test hook: calls with little work (<= 2^21 words) are planned with narrower tiles; -1 = automatic (default),
+ * 0 = never, 1 = always -- so that both geometries can be checked at every size. */
+void tf_set_ntt_small_launch(int mode);
 int tf_ntt_launch_count(size_t n, size_t batch, int width);
 /* Planner introspection (no device needed): number of global passes of one n-point transform (0 for lengths ntt rejects)
  * and log2 of each pass's radix in log2_radix_out[0..3] (unused entries 0).  The radices multiply to n. */

@@ -402,3 +402,28 @@ def test_ntt_on_unaligned_device_pointer(tf, oracle, width, log_n, batch, shift,
     got = buf.cpu().numpy().view(np.uint64)
     assert np.all(got[:shift] == np.uint64(0xFFFFFFFFFFFFFFFF)) and np.all(got[shift + words:] == np.uint64(0xFFFFFFFFFFFFFFFF))
     assert np.array_equal(got[shift:shift + words], oracle.ntt(x, width=width, inverse=inverse, batch=batch, threads=8))
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("width,log_n,batch", [(1, 15, 3), (1, 16, 1), (1, 18, 2), (1, 20, 1), (1, 21, 1), (1, 22, 1),
+                                               (3, 11, 5), (3, 13, 2), (3, 15, 1), (3, 17, 3), (3, 20, 1), (3, 21, 1)])
+def test_both_launch_geometries_match_oracle(tf, oracle, mode, width, log_n, batch):
+    """Calls with little work are planned with 256-thread workgroups and the generic last pass, large ones with 512-thread
+    workgroups and the R = 1024 kernel (tf_set_ntt_small_launch: 0 = never, 1 = always): both are the same transform
+    (math/ntt.rs:67-125), as are the coset evaluation / interpolation built on them (polynomial.rs:1374-1399, :1907-1918)"""
+    lib = tf._lib.lib()
+    n = 1 << log_n
+    x = oracle.fill_random(n * width * batch, 1234 + log_n + width)
+    off = oracle.bfe_new(0x1234567 + log_n)
+    lib.tf_set_ntt_small_launch(mode)
+    try:
+        fwd = x.copy(); tf.ntt(fwd, width=width, batch=batch)
+        inv = x.copy(); tf.intt(inv, width=width, batch=batch)
+        ev = tf.fast_coset_evaluate(x[: (n // 2 + 3) * width], off, n, width=width)
+        ip = tf.fast_coset_interpolate(x[: n * width], off, width=width)
+    finally:
+        lib.tf_set_ntt_small_launch(-1)
+    assert np.array_equal(fwd, oracle.ntt(x, width=width, batch=batch, threads=8))
+    assert np.array_equal(inv, oracle.ntt(x, width=width, inverse=True, batch=batch, threads=8))
+    assert np.array_equal(ev, oracle.coset_evaluate(x[: (n // 2 + 3) * width], off, n, width=width))
+    assert np.array_equal(ip, oracle.coset_interpolate(x[: n * width], off, width=width))

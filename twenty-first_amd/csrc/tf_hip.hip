@@ -460,20 +460,30 @@ int pad_to_residue(int base, int residue) {  // smallest s >= base with s == res
 // Workgroup geometry (tunable for A/B runs through TF_NTT_WG_THREADS = 256 | 512):
 //   512 threads: 16 columns per tile (128-byte segments), 64 KiB exchange rounds, 2 workgroups per CU;
 //   256 threads:  8 columns per tile (64-byte segments, adjacent tiles paired on one XCD), 32 KiB rounds, 4 per CU.
-int wg_threads() {
+// A call with too little work to fill the chip with 512-thread tiles (a single slice of <= 2^20 points: 64 tiles for 256 CUs) is
+// planned with 256-thread workgroups and the generic last pass instead -- twice as many tiles of half the width: 2^16 44 -> 37 us,
+// 2^18 47.5 -> 39.7, 2^20 51.8 -> 43.8 us per call; from 2^22 words per call on the wide tiles win (tools/small_batch.py).
+// run_ntt sets the mode for the duration of one call (thread-local: the ABI is re-entrant).
+thread_local bool t_small_launch = false;
+std::atomic<int> g_small_launch_mode{-1};  // tf_set_ntt_small_launch: -1 automatic, 0 never, 1 always (tests)
+int wg_env() {
     static const int v = [] {
         const char* e = getenv("TF_NTT_WG_THREADS");
-        return (e && atoi(e) == 256) ? 256 : 512;
+        return (e && atoi(e) == 256) ? 256 : ((e && atoi(e) == 512) ? 512 : 0);
     }();
     return v;
+}
+int wg_threads() {
+    if (wg_env()) return wg_env();
+    return t_small_launch ? 256 : 512;
 }
 int round_elems() {
     static const int v = [] {
         const char* e = getenv("TF_NTT_ROUND_ELEMS");
         const int r = e ? atoi(e) : 0;
-        return r >= 1024 ? r : wg_threads() * 16;
+        return r >= 1024 ? r : 0;
     }();
-    return v;
+    return v ? v : wg_threads() * 16;
 }
 
 // thread / LDS geometry shared by all pass types: nc columns, exchanged in rounds of cpr columns
@@ -550,7 +560,7 @@ int ablate_mode() {
 // the specialised R = 1024 last-pass kernel (LAST1024) is available unless an A/B switch or an ablation run disables it
 bool last1024_enabled() {
     static const bool off = getenv("TF_NTT_NO_LAST1024") != nullptr;
-    return !off && ablate_mode() == 0;
+    return !off && ablate_mode() == 0 && !t_small_launch;
 }
 
 // ... and its variant that multiplies on store (fast_coset_interpolate)
@@ -984,6 +994,14 @@ int run_ntt(DeviceCtx* ctx, const u64* in, u64* out, long long in_bs, long long 
     // multi-pass: n = N_1 * ... * N_P, every N_i = 2^(a_i) <= 1024.  Passes 1 .. P-1 are column passes (DFT over digit i,
     // inter-pass twiddle, same position in and out); the last pass transforms the contiguous rows of N_P elements and
     // scatters output digit k_P to  k_1 + N_1 k_2 + ... + N_1..N_{P-1} k_P  (natural order).
+    struct SmallLaunchScope {  // see wg_threads(); a truncating call keeps the R = 1024 last pass its caller planned for
+        SmallLaunchScope(bool on) { t_small_launch = on; }
+        ~SmallLaunchScope() { t_small_launch = false; }
+    };
+    const int small_mode = g_small_launch_mode.load(std::memory_order_relaxed);
+    static const bool no_small = getenv("TF_NTT_NO_SMALL_LAUNCH") != nullptr;  // A/B switch
+    const bool small_call = (unsigned long long)n * cosets * batch * L <= (1ull << 21);
+    SmallLaunchScope small_scope(n_out < 0 && !wg_env() && (small_mode == 1 || (small_mode < 0 && small_call && !no_small)));
     int a[4] = {0, 0, 0, 0};
     const int P = pass_count(log_n);
     choose_split(log_n, P, L, a);
@@ -1864,6 +1882,7 @@ int tf_debug_stamps(unsigned long long* host_out, size_t words) {
 }
 
 void tf_set_ntt_min_passes(int passes) { g_min_passes.store(passes, std::memory_order_relaxed); }
+void tf_set_ntt_small_launch(int mode) { g_small_launch_mode.store(mode < 0 ? -1 : (mode ? 1 : 0), std::memory_order_relaxed); }
 // The plan of one transform: number of global passes and log2 of each pass's radix (planner introspection for the CPU tests).
 int tf_ntt_plan(size_t n, int width, int* log2_radix_out) {
     if (check_len(n) || n <= 1 || (width != 1 && width != 3) || !log2_radix_out) return 0;
