@@ -1,26 +1,40 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    python bench.py --gpus N --steps K --warmup W [--config 2|5]
 
-Workload = BASELINE.json configs[1]: a batch of 256 x 2^20-point BFieldElement forward NTTs per GPU,
-device-resident in and out, in place (math/ntt.rs:67-82 semantics, bit-exact).  One "step" = one pass of
-the hot path over the whole batch = one tf_ntt_bfe_dev call.  Independent transforms shard across ranks
-with no data-path collective, so N ranks run N x 256 transforms: weak scaling.
+N > 1 may be launched either by the driver (python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...) or simply as `python bench.py --gpus N`: with no
+WORLD_SIZE in the environment bench.py re-launches itself under torch.distributed.run, one rank per GPU.
+
+Default workload (--config 2) = BASELINE.json configs[1]: a batch of 256 x 2^20-point BFieldElement forward NTTs per
+GPU, device-resident in and out, in place (math/ntt.rs:67-82 semantics, bit-exact).  One "step" = one pass of the hot
+path over the whole batch = one tf_ntt_bfe_dev call.  Independent transforms shard across ranks with no data-path
+collective, so N ranks run N x 256 transforms: weak scaling.
 
 Prints ONE JSON line (rank 0).  `value` = (N * 256 * 2^20 * K elements) / (max-over-ranks time of the K steps).
-  roofline    : dominant kernel ntt_pass_kernel; achieved = algorithmic bytes per launch / average launch
-                duration from HIP events over the timed region.  A 2^20 transform is 2 launches of that
-                kernel (one per pass), and SURVEY.md 8(d) prices a transform at 16 B/element, so one
-                launch carries 8 B/element x (elements it touches).
-  cpu_baseline: the CPU oracle (C restatement of the reference algorithm, kind "port") timed on this box's
-                host cores on the same 256 x 2^20 workload, one transform per thread (what a rayon caller
-                of the single-threaded ntt() does).  Rank 0, N = 1 only.
+  roofline    : dominant kernel ntt_pass_kernel; achieved = algorithmic bytes per launch / average launch duration from
+                HIP events over the timed region.  A 2^20 transform is 2 launches of that kernel (one per pass), and
+                SURVEY.md 8(d) prices a transform at 16 B/element, so one launch carries 8 B/element x (elements it touches).
+  cpu_baseline: the CPU oracle (C restatement of the reference algorithm, kind "port") timed on this box's host cores on
+                the same 256 x 2^20 workload, one transform per thread (what a rayon caller of the single-threaded ntt()
+                does).  Rank 0, N = 1 only.
+  merkle      : the second half of BASELINE.json's metric -- Tip5 Merkle leaves/s on configs[2] (one 2^24-leaf tree per
+                GPU, full node array, root all-gathered over RCCL when N > 1), with its own integer-VALU roofline and the
+                oracle's par_new restatement (util_types/merkle_tree.rs:165-212) timed on the host cores in the same run;
+                the GPU root is compared with the oracle's.
+  coset_eval  : configs[3], 64 XFieldElement polynomials x 2^22 coefficients, fast_coset_evaluate (48 B/point roofline).
+  config5     : configs[4] run as a STRONG-scaling job: 4096 NTTs of 2^20 points + 256 trees of 2^20 leaves split over the
+                N ranks by sharding.shard_range, roots through sharding.gather_roots (RCCL all_gather).  `--config 5`
+                makes this job the timed headline (`value` = its NTT GFelts/s, "scaling": "strong").
+Inputs are the SplitMix64-seeded synthetic elements of SURVEY.md 8(d), generated on the device (tf_debug_fill_random_dev;
+the oracle's tfo.fill_random is the same counter-based sequence, so every parity sample is reproducible from its seed).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -30,30 +44,43 @@ if ROOT not in sys.path:
 
 P = 0xFFFFFFFF00000001
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+# Integer-VALU issue peak: 256 CUs x 4 SIMDs, one wave64 instruction of the 64-bit integer building blocks (v_mad_u64_u32,
+# carry adds, v_lshl_add_u64 ...) per 4 cycles per SIMD (SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU = 1.00 quad-cycles on the pass
+# and Tip5 kernels, profiles/) at the 2.4 GHz peak engine clock.
+VALU_PEAK_GWIPS = 256 * 4 * 2.4 / 4.0  # 614.4 G wave-instructions/s
+SEED_C2, SEED_C3, SEED_C4, SEED_C5 = 0x7F210002, 0x7F210003, 0x7F210004, 0x7F210005  # seed_c = 0x7F21_0000 + c
 
 
-def synth_words(numel, device, seed):
-    """Synthetic canonical field elements: uniform 64-bit words with the (2^-32 fraction of) words >= p
-    folded back into range."""
-    import torch
+def self_spawn(args):
+    """`python bench.py --gpus N` without torch.distributed.run: start the N ranks ourselves."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
 
-    g = torch.Generator(device=device)
-    g.manual_seed(seed)
-    x = torch.randint(-(2 ** 63), 2 ** 63 - 1, (numel,), dtype=torch.int64, device=device, generator=g)
-    bad = (x < 0) & (x >= -(2 ** 32 - 1))  # as u64: >= p
-    x = torch.where(bad, x + 2 ** 32, x)
-    return x
+
+def load_profile_json(name):
+    path = os.path.join(ROOT, "profiles", name)
+    if os.path.exists(path):
+        try:
+            return json.load(open(path))
+        except Exception:
+            return None
+    return None
 
 
-def cpu_baseline_ntt(log_n, batch, sample_host_words):
-    """Oracle leg: time the CPU restatement on the same workload shape; returns (dict, outputs of the sample)."""
-    import numpy as np
-
+def cpu_baseline_ntt(log_n, batch, seed):
+    """Oracle leg: time the CPU restatement on the same workload shape; returns (dict, first two transforms' outputs)."""
     from oracle import tfo
 
     n = 1 << log_n
     cores = os.cpu_count() or 1
-    x = tfo.fill_random(n * batch, 0x7F210002)
+    x = tfo.fill_random(n * batch, seed)
     tfo.ntt(x[:n].copy())  # build the oracle's twiddle cache outside the timed region (the reference caches too)
     t0 = time.perf_counter()
     tfo.ntt(x[: n * 4].copy(), batch=4, threads=1)
@@ -69,10 +96,8 @@ def cpu_baseline_ntt(log_n, batch, sample_host_words):
         tried[th] = batch * n / (t1 - t0) / 1e9
     threads = max(tried, key=tried.get)
     multi = tried[threads]
-    sample_out = None
-    if sample_host_words is not None:
-        k = sample_host_words.size // n
-        sample_out = tfo.ntt(sample_host_words, batch=k, threads=min(threads, k))
+    k = min(batch, 32)  # word-for-word parity sample: the first 32 transforms
+    sample_out = tfo.ntt(x[: k * n], batch=k, threads=min(threads, k))
     info = {
         "value": round(multi, 4),
         "unit": "GFelts/s",
@@ -86,18 +111,53 @@ def cpu_baseline_ntt(log_n, batch, sample_host_words):
     return info, sample_out
 
 
+def cpu_baseline_merkle(n_leaves, seed):
+    """Oracle leg of the Merkle metric: par_new restatement on the same leaves; returns (dict, root, a node sample)."""
+    from oracle import tfo
+
+    cores = os.cpu_count() or 1
+    leaves = tfo.fill_random(5 * n_leaves, seed)
+    ns = min(n_leaves, 1 << 20)  # single-thread figure on a bounded sample (sequential_new, ~1 s)
+    t0 = time.perf_counter()
+    tfo.merkle_build(leaves[: 5 * ns])
+    single = ns / (time.perf_counter() - t0)
+    tried, nodes = {}, None
+    for th in sorted(set(max(1, c) for c in (32, 64, cores))):
+        t0 = time.perf_counter()
+        nodes = tfo.merkle_build(leaves, threads=th)
+        tried[th] = n_leaves / (time.perf_counter() - t0)
+    threads = max(tried, key=tried.get)
+    info = {
+        "value": round(tried[threads], 1),
+        "unit": "leaves/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": f"the full 2^{n_leaves.bit_length() - 1}-leaf tree (MerkleTree::par_new restatement, util_types/merkle_tree.rs:165-212; bench shape "
+                  "benches/merkle_tree.rs:11-40); best of " + ", ".join(f"{k} threads: {v / 1e6:.2f} M" for k, v in tried.items())
+                  + f" leaves/s on {cores} host CPUs",
+        "single_thread_value": round(single, 1),
+    }
+    return info, nodes[5:10].copy(), nodes
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", type=int, default=2, choices=(2, 5), help="2: BASELINE configs[1] per GPU, weak scaling (default); 5: configs[4], strong scaling")
     ap.add_argument("--log-n", type=int, default=20)
-    ap.add_argument("--batch", type=int, default=256, help="transforms per GPU")
+    ap.add_argument("--batch", type=int, default=256, help="transforms per GPU (config 2)")
     ap.add_argument("--no-settle", action="store_true", help="skip the untimed stabilisation passes before the warmup")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="initialise the RCCL process group even for one rank (exercises the N > 1 code path on a 1-GPU box)")
-    ap.add_argument("--no-extra", action="store_true", help="skip the Merkle / coset-evaluation side measurements")
+    ap.add_argument("--no-extra", action="store_true", help="headline NTT leg only (no Merkle / coset-evaluation / config-5 legs)")
+    ap.add_argument("--c5-ntts", type=int, default=4096, help="config 5: transforms of 2^20 points in the whole job")
+    ap.add_argument("--c5-trees", type=int, default=256, help="config 5: trees of 2^20 leaves in the whole job")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_spawn(args))
 
     import numpy as np
     import torch
@@ -108,10 +168,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with nproc-per-node {args.gpus} (WORLD_SIZE={world})")
+    if world != max(1, args.gpus):
+        raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE={world}")
     if not torch.cuda.is_available() or tf.lib().tf_device_count() <= 0:
         raise SystemExit("bench.py needs an MI355X: the product has no CPU fallback")
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"rank {rank}: only {torch.cuda.device_count()} GPU(s) visible, --gpus {args.gpus} needs one per rank")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or args.force_dist
@@ -125,17 +187,61 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def max_over_ranks(seconds):
+        if not use_dist:
+            return seconds
+        t = torch.tensor([seconds], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    ctx = dict(tf=tf, torch=torch, dist=dist, np=np, dev=dev, world=world, rank=rank, use_dist=use_dist, barrier=barrier,
+               max_over_ranks=max_over_ranks, args=args)
+
+    if args.config == 5:
+        out = config5_leg(ctx, steps=args.steps, warmup=args.warmup, headline=True)
+    else:
+        out = ntt_headline(ctx)
+
+    if not args.no_extra:
+        # the other legs run on every rank (they contain collectives); rank 0 reports
+        try:
+            out["merkle"] = merkle_leg(ctx)
+        except Exception as e:  # a side leg never invalidates the headline line
+            out["merkle"] = {"error": repr(e)}
+        if world == 1:
+            try:
+                out["coset_eval"] = coset_leg(ctx)
+            except Exception as e:
+                out["coset_eval"] = {"error": repr(e)}
+        if args.config != 5:
+            try:
+                out["config5"] = config5_leg(ctx, steps=3, warmup=1, headline=False)
+            except Exception as e:
+                out["config5"] = {"error": repr(e)}
+        if world == 1:
+            out["extra"] = side_measurements(tf, torch, dev)
+    if rank == 0:
+        print(json.dumps(out))
+    if use_dist:
+        dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------------------------------------ headline: configs[1]
+def ntt_headline(ctx):
+    tf, torch, np, dev, args = ctx["tf"], ctx["torch"], ctx["np"], ctx["dev"], ctx["args"]
+    world, rank, barrier = ctx["world"], ctx["rank"], ctx["barrier"]
     log_n, batch = args.log_n, args.batch
     n = 1 << log_n
-    x = synth_words(n * batch, dev, 0x7F210002 + rank)
-
-    # in-run parity sample: first 2 transforms of this rank's batch
-    sample_in = x[: 2 * n].clone()
+    x = torch.empty(n * batch, dtype=torch.int64, device=dev)
+    # the whole job is ONE counter-based sequence: rank r holds elements [r * batch * n, (r + 1) * batch * n)
+    tf.device.fill_random(x, SEED_C2, first_index=rank * batch * n)
+    k_par = min(batch, 32)
+    sample_in = x[: k_par * n].clone()  # in-run parity sample: the first 32 transforms of this rank's batch
 
     launches_per_step = tf.lib().tf_ntt_launch_count(n, batch, 1)
 
     # settle: untimed passes until the GPU is in steady state.  A cold GPU runs the first passes at 4.2 -> 2.3 ms and only
-    # reaches its steady 2.2 ms after ~50 (tools/step_times.py); some boxes have been seen to sit at ~1/4 speed (8.4 ms per
+    # reaches its steady state after ~50 (tools/step_times.py); some boxes have been seen to sit at ~1/4 speed (8.4 ms per
     # pass, every pass of a process) -- the shader clock measured here tells such a run from a slow kernel.  Run windows
     # of 25 passes until two consecutive windows agree within 2 % (at least 4 windows, at most 40), then the W warmup steps.
     settle = 0
@@ -173,9 +279,9 @@ def main():
         tf.device.ntt_(x, n, batch=batch)
     barrier()
 
-    # parity of the first warmup step is checked on a fresh run of the sample (x has been transformed W times)
+    # parity is checked on a fresh run of the sample (x has been transformed many times by now)
     sample_gpu = sample_in.clone()
-    tf.device.ntt_(sample_gpu, n, batch=2)
+    tf.device.ntt_(sample_gpu, n, batch=k_par)
     torch.cuda.synchronize()
 
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -200,10 +306,7 @@ def main():
     sclk_after = tf.lib().tf_debug_sclk_mhz()
     copy_after = copy_gbs()
     barrier()
-    if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = ctx["max_over_ranks"](elapsed)
 
     total_elems = world * batch * n * args.steps
     value = total_elems / elapsed / 1e9
@@ -215,17 +318,12 @@ def main():
     alg_bytes_per_launch = 16.0 * batch * n / launches_per_step  # 16 B/element per transform, spread over its launches
     achieved = alg_bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9
     traffic = None
-    tpath = os.path.join(ROOT, "profiles", "hbm_traffic_ntt.json")
-    if os.path.exists(tpath):
-        try:
-            tj = json.load(open(tpath))
-            if tj.get("log_n") == log_n and tj.get("batch") == batch and tj.get("launches_per_step") == launches_per_step:
-                traffic = tj.get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
+    tj = load_profile_json("hbm_traffic_ntt.json")
+    if tj and tj.get("log_n") == log_n and tj.get("batch") == batch and tj.get("launches_per_step") == launches_per_step:
+        traffic = tj.get("hbm_bytes_per_launch")
     roofline = {
         "bound": "hbm",
-        "kernel": "tfk::ntt_pass_kernel<false, 0, 0, false, true> (pass 1) and <false, 0, 0, true, false> (pass 2), one launch of each per step",
+        "kernel": "tfk::ntt_pass_kernel (column pass + transposing pass; one launch of each per batch tile)",
         "achieved": round(achieved, 1),
         "peak": HBM_PEAK_GBS,
         "unit": "GB/s",
@@ -234,18 +332,18 @@ def main():
         "algorithmic_bytes_per_launch": alg_bytes_per_launch,
         "avg_launch_ms": round(avg_launch_ms, 5),
         "launches_per_step": launches_per_step,
+        "tile_bytes": int(tf.lib().tf_get_ntt_tile_bytes()),
+        "tile_streams": int(tf.lib().tf_get_ntt_pipe()),
     }
-    if log_n == 20:
-        # Informational second roofline: what actually bounds the kernel is integer VALU issue.  Static
-        # instruction counts of the two pass kernels (tools/isa_count.py on the committed build: 4114 + 3454 VALU
-        # instructions per thread = 32 elements per pass) against the measured issue rate of the 64-bit integer building
-        # blocks, 0.55 G wave-instructions/s per SIMD x 1024 SIMDs (profiles/microbench_r01_*.txt).
-        valu_instr_per_element = (4114 + 3454) / 32.0
-        wave_instr = batch * n * valu_instr_per_element / 64.0
-        floor_ms = wave_instr / (1024 * 0.55e9) * 1e3
-        roofline["valu_bound"] = {"valu_instr_per_element": round(valu_instr_per_element, 1), "floor_ms_per_step": round(floor_ms, 3),
-                                  "frac": round(floor_ms / (ev_ms / args.steps), 3),
-                                  "note": "integer VALU issue is the binding resource, not HBM"}
+    vc = load_profile_json("valu_counts.json")
+    if vc and log_n == 20 and vc.get("ntt_valu_wave_instr_per_transform_2p20"):
+        # Informational second roofline: integer VALU issue.  The instruction count is the DYNAMIC one,
+        # SQ_INSTS_VALU of the two pass kernels under rocprofv3 --pmc (profiles/valu_counts.json, tools/pmc_r02.sh).
+        wi = vc["ntt_valu_wave_instr_per_transform_2p20"] * batch
+        gw = wi / (ev_ms / args.steps * 1e-3) / 1e9
+        roofline["valu_bound"] = {"wave_instr_per_step": wi, "valu_instr_per_element": round(wi * 64.0 / (batch * n), 1),
+                                  "achieved": round(gw, 1), "peak": VALU_PEAK_GWIPS, "unit": "G wave-instr/s",
+                                  "frac": round(gw / VALU_PEAK_GWIPS, 3), "clock_under_load_mhz": vc.get("ntt_clock_under_load_mhz")}
 
     out = {
         "metric": "goldilocks_ntt_gfelts_per_s",
@@ -265,75 +363,243 @@ def main():
             "batch_per_gpu": batch,
             "n": n,
             "parallelism": f"batch-sharded x{world}, no data-path collective",
+            "inputs": f"SplitMix64, seed 0x{SEED_C2:X} (SURVEY.md 8(d)), generated on the device",
         },
         "roofline": roofline,
         "step_ms_after": {"min": round(step_ms[0], 4), "median": round(step_ms[len(step_ms) // 2], 4), "max": round(step_ms[-1], 4),
                           "note": "10 extra steps with an event each, after the timed region"},
         "settle_steps": settle,
-        "sclk_mhz": {"before_settle": round(sclk_before, 0), "after_timed_region": round(sclk_after, 0)},
+        "sclk_mhz": {"before_settle": round(sclk_before, 0), "after_timed_region": round(sclk_after, 0),
+                     "note": "one-wave idle probe; the clock under load is in roofline.valu_bound (from GRBM_GUI_ACTIVE)"},
         "device_copy_gbs": {"before_settle": round(copy_before, 0), "after_timed_region": round(copy_after, 0),
                             "note": "torch copy of the 2 GiB workload buffer, read + write: a platform reference (normally ~4500-5000)"},
     }
+    del x
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        info, sample_out = cpu_baseline_ntt(log_n, batch, SEED_C2)
+        out["cpu_baseline"] = info
+        got = sample_gpu.cpu().numpy().view(np.uint64)
+        ok = np.array_equal(got, sample_out)
+        out["parity"] = f"bit-exact vs oracle on {k_par} transforms (word for word)" if ok else "MISMATCH"
+        if not ok:
+            print(json.dumps(out))
+            raise SystemExit("GPU output differs from the oracle")
+    elif world == 1:
+        out["cpu_baseline"] = None
+    return out
 
-    if rank == 0:
-        # ---- cpu baseline + in-run parity (oracle = checker only)
-        if world == 1 and not args.no_cpu_baseline:
-            sample_host = sample_in.cpu().numpy().view(np.uint64)
-            info, sample_out = cpu_baseline_ntt(log_n, batch, sample_host)
-            out["cpu_baseline"] = info
-            got = sample_gpu.cpu().numpy().view(np.uint64)
-            out["parity"] = "bit-exact vs oracle on 2 transforms" if np.array_equal(got, sample_out) else "MISMATCH"
-            if out["parity"] == "MISMATCH":
-                print(json.dumps(out))
-                raise SystemExit("GPU output differs from the oracle")
-        elif world == 1:
-            out["cpu_baseline"] = None
-        # ---- side measurements (not part of `value`): Merkle leaves/s and XFE coset evaluation
-        if world == 1 and not args.no_extra:
-            out["extra"] = side_measurements(tf, torch, dev)
-        print(json.dumps(out))
-    if use_dist:
-        dist.destroy_process_group()
+
+# ------------------------------------------------------------------------------------------------ configs[2]: Merkle leg
+def merkle_leg(ctx):
+    """One 2^24-leaf tree per GPU (full node array); with N > 1 the N roots are all-gathered inside the timed region."""
+    tf, torch, np, dev, args = ctx["tf"], ctx["torch"], ctx["np"], ctx["dev"], ctx["args"]
+    world, rank, barrier, use_dist = ctx["world"], ctx["rank"], ctx["barrier"], ctx["use_dist"]
+    from twenty_first_amd import sharding
+
+    nl = 1 << 24
+    leaves = torch.empty(5 * nl, dtype=torch.int64, device=dev)
+    tf.device.fill_random(leaves, SEED_C3, first_index=rank * 5 * nl)
+    nodes = torch.empty(10 * nl, dtype=torch.int64, device=dev)
+
+    def step():
+        tf.device.merkle_build(leaves, nl, nodes)
+        if use_dist:
+            return sharding.gather_roots(nodes[5:10].reshape(1, 5), world)
+        return nodes[5:10].reshape(1, 5)
+
+    for _ in range(6):  # the GPU may have been idle during a CPU baseline: let the clocks come back
+        step()
+    iters = 10
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    barrier()
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(iters):
+        roots = step()
+    e1.record()
+    torch.cuda.synchronize()
+    elapsed = ctx["max_over_ranks"](time.perf_counter() - t0)
+    ms = elapsed / iters * 1e3
+    res = {
+        "metric": "tip5_merkle_leaves_per_s",
+        "value": round(world * nl / (elapsed / iters), 1),
+        "unit": "leaves/s",
+        "n_gpus": world,
+        "scaling": "weak",
+        "ms_per_step": round(ms, 4),
+        "device_ms_per_tree": round(e0.elapsed_time(e1) / iters, 4),
+        "config": {"workload": "one 2^24-leaf Tip5 Merkle tree per GPU: hash_pair ladder to the full 2^25-node array (BASELINE configs[2])"
+                               + ("; roots all-gathered over RCCL inside the timed region" if use_dist else ""),
+                   "inputs": f"SplitMix64, seed 0x{SEED_C3:X}"},
+        "hbm_frac_at_120B_per_leaf": round(120.0 * nl / (e0.elapsed_time(e1) / iters * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+    }
+    vc = load_profile_json("valu_counts.json")
+    if vc and vc.get("merkle_valu_wave_instr_per_tree_2p24"):
+        wi = vc["merkle_valu_wave_instr_per_tree_2p24"]
+        gw = wi / (e0.elapsed_time(e1) / iters * 1e-3) / 1e9
+        res["roofline"] = {"bound": "valu", "kernel": "tfk::tip5_hash_pairs_kernel (level sweep) + merkle_top_kernel",
+                           "achieved": round(gw, 1), "peak": VALU_PEAK_GWIPS, "unit": "G wave-instr/s", "frac": round(gw / VALU_PEAK_GWIPS, 3),
+                           "wave_instr_per_tree": wi, "valu_instr_per_hash_pair": round(wi * 64.0 / (nl - 1), 1),
+                           "source": "SQ_INSTS_VALU under rocprofv3 --pmc (profiles/valu_counts.json); peak = 1024 SIMDs x 2.4 GHz / 4 cycles"}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        info, want_root, want_nodes = cpu_baseline_merkle(nl, SEED_C3)
+        res["cpu_baseline"] = info
+        got_root = roots[0].cpu().numpy().view(np.uint64)
+        idx = np.unique(np.concatenate([np.arange(1, 4096), np.random.default_rng(3).integers(1, 2 * nl, 1 << 16)]))
+        got_nodes = nodes.view(-1, 5)[torch.from_numpy(idx).to(dev)].cpu().numpy().view(np.uint64)
+        ok = np.array_equal(got_root, want_root) and np.array_equal(got_nodes, want_nodes.reshape(-1, 5)[idx])
+        res["parity"] = "root and 69k sampled nodes match the oracle's par_new" if ok else "MISMATCH"
+        res["root"] = tf.Digest.to_hex(got_root)
+        if not ok:
+            raise SystemExit("GPU Merkle tree differs from the oracle")
+    del leaves, nodes
+    return res
+
+
+# ------------------------------------------------------------------------------------------------ configs[3]: XFE coset evaluation
+def coset_leg(ctx):
+    tf, torch, np, dev, args = ctx["tf"], ctx["torch"], ctx["np"], ctx["dev"], ctx["args"]
+    n, b = 1 << 22, 64
+    c = torch.empty(3 * n * b, dtype=torch.int64, device=dev)
+    tf.device.fill_random(c, SEED_C4)
+    o = torch.empty(3 * n * b, dtype=torch.int64, device=dev)
+    off = tf.BFieldElement.new(7)
+    for _ in range(4):
+        tf.device.coset_evaluate(c, n, off, o, n, batch=b, width=3)
+    torch.cuda.synchronize()
+    iters = 10
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        tf.device.coset_evaluate(c, n, off, o, n, batch=b, width=3)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    gbs = 48.0 * n * b / (ms * 1e-3) / 1e9
+    res = {
+        "metric": "xfe_coset_evaluate_gpoints_per_s",
+        "value": round(n * b / ms / 1e6, 3),
+        "unit": "G points/s",
+        "ms_per_step": round(ms, 4),
+        "config": {"workload": "64 XFieldElement polynomials x 2^22 coefficients, fast_coset_evaluate(offset = 7, order = 2^22) (BASELINE configs[3])",
+                   "inputs": f"SplitMix64, seed 0x{SEED_C4:X}"},
+        "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                     "algorithmic_bytes_per_point": 48, "launches_per_step": int(tf.lib().tf_ntt_launch_count(n, b, 3))},
+    }
+    if not args.no_cpu_baseline:
+        from oracle import tfo
+
+        c0 = tfo.fill_random(3 * n, SEED_C4)  # polynomial 0 of the batch
+        t0 = time.perf_counter()
+        want = tfo.coset_evaluate(c0, off, n, width=3)
+        dt = time.perf_counter() - t0
+        res["cpu_baseline"] = {"value": round(n / dt / 1e9, 5), "unit": "G points/s", "cores": 1, "kind": "port",
+                               "sample": "1 of the 64 polynomials (2^22 XFE coefficients), single thread: scale + ntt restatement of math/polynomial.rs:760-773,1374-1399"}
+        ok = np.array_equal(o[: 3 * n].cpu().numpy().view(np.uint64), want)
+        res["parity"] = "polynomial 0 bit-exact vs oracle (all 3 * 2^22 words)" if ok else "MISMATCH"
+        if not ok:
+            raise SystemExit("GPU coset evaluation differs from the oracle")
+    del c, o
+    return res
+
+
+# ------------------------------------------------------------------------------------------------ configs[4]: the sharded job
+def config5_leg(ctx, steps, warmup, headline):
+    """4096 x 2^20 NTTs + 256 trees of 2^20 leaves, split contiguously over the ranks (sharding.shard_range); the roots of
+    all trees are all-gathered with sharding.gather_roots (RCCL).  Strong scaling: the job is fixed, N varies."""
+    tf, torch, np, dev, args = ctx["tf"], ctx["torch"], ctx["np"], ctx["dev"], ctx["args"]
+    world, rank, barrier, use_dist = ctx["world"], ctx["rank"], ctx["barrier"], ctx["use_dist"]
+    from twenty_first_amd import sharding
+
+    n = nl = 1 << 20
+    t_lo, t_hi = sharding.shard_range(args.c5_ntts, world, rank)
+    m_lo, m_hi = sharding.shard_range(args.c5_trees, world, rank)
+    nt, nm = t_hi - t_lo, m_hi - m_lo
+    x = torch.empty(max(nt, 1) * n, dtype=torch.int64, device=dev)
+    tf.device.fill_random(x[: nt * n], SEED_C5, first_index=t_lo * n)
+    leaves = torch.empty(max(nm, 1) * 5 * nl, dtype=torch.int64, device=dev)
+    tf.device.fill_random(leaves[: nm * 5 * nl], SEED_C5 ^ (1 << 40), first_index=m_lo * 5 * nl)
+    nodes = torch.empty(max(nm, 1) * 10 * nl, dtype=torch.int64, device=dev)
+    roots_local = torch.empty(nm * 5, dtype=torch.int64, device=dev)
+
+    def ntt_phase():
+        if nt:
+            tf.device.ntt_(x[: nt * n], n, batch=nt)
+
+    def tree_phase():
+        if nm:
+            tf.device.merkle_build(leaves[: nm * 5 * nl], nl, nodes[: nm * 10 * nl], batch=nm)
+            roots_local.copy_(nodes[: nm * 10 * nl].view(nm, 2 * nl, 5)[:, 1, :].reshape(-1))
+        if use_dist:
+            return sharding.gather_roots(roots_local.view(-1, 5), args.c5_trees)
+        return roots_local.view(-1, 5)
+
+    for _ in range(warmup):
+        ntt_phase()
+        roots = tree_phase()
+    barrier()
+    t_ntt = t_tree = 0.0
+    for _ in range(steps):
+        barrier()
+        t0 = time.perf_counter()
+        ntt_phase()
+        barrier()
+        t1 = time.perf_counter()
+        roots = tree_phase()
+        barrier()
+        t2 = time.perf_counter()
+        t_ntt += t1 - t0
+        t_tree += t2 - t1
+    t_ntt, t_tree = ctx["max_over_ranks"](t_ntt), ctx["max_over_ranks"](t_tree)
+    ntt_val = args.c5_ntts * n * steps / t_ntt / 1e9
+    tree_val = args.c5_trees * nl * steps / t_tree
+    # integrity of the collective: every rank ends with all roots, in batch order; rank 0's own slice sits where it belongs
+    assert roots.shape == (args.c5_trees, 5)
+    assert torch.equal(roots[m_lo:m_hi].reshape(-1), roots_local)
+    res = {
+        "metric": "goldilocks_ntt_gfelts_per_s",
+        "value": round(ntt_val, 3),
+        "unit": "GFelts/s",
+        "n_gpus": world,
+        "steps": steps,
+        "warmup": warmup,
+        "ms_per_step": round((t_ntt + t_tree) / steps * 1e3, 4),
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "u64",
+        "data": "synthetic",
+        "config": {"workload": f"{args.c5_ntts} x 2^20-point BFE NTTs + {args.c5_trees} x 2^20-leaf Tip5 Merkle trees, the whole job split contiguously over "
+                               f"{world} GPU(s), roots all-gathered (BASELINE configs[4])",
+                   "ntts_this_rank": nt, "trees_this_rank": nm,
+                   "parallelism": f"contiguous batch split x{world} (sharding.shard_range); one RCCL all_gather of 40-byte roots per step",
+                   "inputs": f"SplitMix64, seed 0x{SEED_C5:X}"},
+        "ntt_ms_per_step": round(t_ntt / steps * 1e3, 4),
+        "merkle": {"metric": "tip5_merkle_leaves_per_s", "value": round(tree_val, 1), "unit": "leaves/s",
+                   "ms_per_step": round(t_tree / steps * 1e3, 4), "includes": "tree builds + root gather"},
+        "root_of_tree_0": tf.Digest.to_hex(roots[0].cpu().numpy().view(np.uint64)),
+    }
+    if headline:
+        alg = 16.0 * nt * n
+        gbs = alg * steps / t_ntt / 1e9
+        res["roofline"] = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                           "traffic": None, "note": "this rank's NTT phase: 16 B/element over the max-over-ranks time"}
+    del x, leaves, nodes
+    return res
 
 
 def side_measurements(tf, torch, dev):
-    """BASELINE configs[2] and [3] shapes, a few iterations each (reported, not the headline value)."""
+    """The callers on either side of the path, device-resident; reported, not part of any headline value."""
     extra = {}
     try:
-        nl = 1 << 24
-        leaves = synth_words(5 * nl, dev, 3)
-        nodes = torch.empty(10 * nl, dtype=torch.int64, device=dev)
-        for _ in range(6):  # the GPU has been idle during the CPU baseline: let the clocks come back
-            tf.device.merkle_build(leaves, nl, nodes)
-        torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        iters = 10
-        e0.record()
-        for _ in range(iters):
-            tf.device.merkle_build(leaves, nl, nodes)
-        e1.record()
-        torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / iters
-        extra["merkle_2p24"] = {"ms": round(ms, 3), "leaves_per_s": round(nl / ms * 1e3, 1),
-                                "hbm_frac_at_120B_per_leaf": round(120.0 * nl / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
-        del leaves, nodes
-        n, b = 1 << 22, 16
-        c = synth_words(3 * n * b, dev, 4)
-        o = torch.empty(3 * n * b, dtype=torch.int64, device=dev)
         off = tf.BFieldElement.new(7)
-        for _ in range(4):
-            tf.device.coset_evaluate(c, n, off, o, n, batch=b, width=3)
-        torch.cuda.synchronize()
-        e0.record()
-        for _ in range(iters):
-            tf.device.coset_evaluate(c, n, off, o, n, batch=b, width=3)
-        e1.record()
-        torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / iters
-        extra["xfe_coset_eval_16x2p22"] = {"ms": round(ms, 3), "gfelts_per_s": round(n * b / ms / 1e6, 3),
-                                          "hbm_frac_at_48B_per_point": round(48.0 * n * b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
-        del c, o
-        # the callers on either side of the path (SURVEY 8(f)), device-resident
+
+        def rnd(numel, seed):
+            t = torch.empty(numel, dtype=torch.int64, device=dev)
+            tf.device.fill_random(t, seed)
+            return t
+
         def _timed(fn, reps=8):
             for _ in range(3):
                 fn()
@@ -346,12 +612,12 @@ def side_measurements(tf, torch, dev):
             return e0.elapsed_time(e1) / reps
 
         nh = 1 << 19
-        pa, pb = synth_words(256 * nh, dev, 6), synth_words(256 * nh, dev, 7)
+        pa, pb = rnd(256 * nh, 6), rnd(256 * nh, 7)
         po = torch.empty(256 * (2 * nh - 1), dtype=torch.int64, device=dev)
         ms = _timed(lambda: tf.device.poly_mul(pa, nh, pb, nh, po, batch=256))
         extra["fast_multiply_256x_2p19_by_2p19"] = {"ms": round(ms, 3), "output_coefficients_per_s": round(256 * (2 * nh - 1) / ms * 1e3, 1)}
         del pa, pb, po
-        lv = synth_words(128 * (1 << 18), dev, 8)
+        lv = rnd(128 * (1 << 18), 8)
         lo = torch.empty(128 * (1 << 21), dtype=torch.int64, device=dev)
         ms = _timed(lambda: tf.device.lde(lv, 1 << 18, tf.BFieldElement.new(1), lo, 1 << 21, off, batch=128))
         extra["lde_128x_2p18_to_2p21"] = {"ms": round(ms, 3), "g_points_per_s": round(128 * (1 << 21) / ms / 1e6, 3)}
@@ -361,16 +627,14 @@ def side_measurements(tf, torch, dev):
         extra["merkle_from_columns_2p21_rows_x128"] = {"ms": round(ms, 3), "rows_per_s": round((1 << 21) / ms * 1e3, 1)}
         del lv, lo, tn
         # PCIe-inclusive figure of the host-pointer entry point (pageable numpy buffers, 32 x 2^20 BFE = 256 MiB each way)
-        import time as _t
-
         import numpy as _np
 
         hb = 32
         hx = _np.random.default_rng(5).integers(0, 2 ** 63, size=hb * (1 << 20), dtype=_np.uint64)
         tf.ntt(hx, batch=hb)
-        t0 = _t.perf_counter()
+        t0 = time.perf_counter()
         tf.ntt(hx, batch=hb)
-        dt = _t.perf_counter() - t0
+        dt = time.perf_counter() - t0
         extra["host_pointer_ntt_32x2p20"] = {"ms": round(dt * 1e3, 2), "gfelts_per_s": round(hb * (1 << 20) / dt / 1e9, 3),
                                              "note": "tf_ntt_bfe on pageable host memory: H2D + 2 passes + D2H, synchronous"}
     except Exception as e:  # side measurements never invalidate the headline line

@@ -183,7 +183,8 @@ int tf_merkle_from_columns(const uint64_t *table, size_t n_rows, size_t n_cols, 
 int tf_merkle_from_columns_dev(const uint64_t *d_table, size_t n_rows, size_t n_cols, int width, size_t col_stride, uint64_t *d_nodes_out, size_t batch, void *stream);
 int tf_merkle_from_rows(const uint64_t *rows, size_t row_len, size_t n_rows, uint64_t *nodes_out, size_t batch);
 int tf_merkle_from_rows_dev(const uint64_t *d_rows, size_t row_len, size_t n_rows, uint64_t *d_nodes_out, size_t batch, void *stream);
-/* Copies at most `capacity` node indices; *out_count always receives the full count (capacity 0 = sizing call). */
+/* *out_count always receives the full count.  out_indices == NULL or capacity == 0 is the sizing call (returns TF_OK);
+ * otherwise capacity < count -> TF_ERR_BUFFER_TOO_SMALL and nothing is written (same rule as the _dev sibling below). */
 int tf_merkle_auth_structure_indices(size_t num_leafs, const uint64_t *leaf_indices, size_t k, uint64_t *out_indices, size_t capacity, size_t *out_count);
 int tf_merkle_authentication_structure_dev(const uint64_t *d_nodes, size_t num_leafs, const uint64_t *leaf_indices, size_t k,
                                            uint64_t *out_digests, size_t capacity_digests, size_t *out_count, void *stream);
@@ -195,6 +196,14 @@ int tf_merkle_authentication_structure_dev(const uint64_t *d_nodes, size_t num_l
  *                       launches overlap better than Infinity-Cache-sized ones).
  */
 void tf_set_ntt_tile_bytes(size_t bytes);
+/*   TF_NTT_PIPE       : K = 1..4 side streams the batch tiles of a multi-pass NTT are dealt to round-robin (each with its own
+ *                       scratch tile), so the column pass of tile t + 1 overlaps the transposing pass of tile t and a tile
+ *                       sized for the Infinity Cache is re-read out of it; the caller's stream forks/joins with events. */
+void tf_set_ntt_pipe(int streams);
+int tf_get_ntt_pipe(void);
+/*   TF_NTT_NT         : bit 0 = non-temporal loads of the caller's input in the first pass, bit 1 = non-temporal stores of the
+ *                       result in the last pass of a plain multi-pass transform (keeps the Infinity Cache for the scratch tile). */
+void tf_set_ntt_nt(int mask);
 /* Test hook: plan at least `passes` (2..4) global passes whenever n >= 32^passes, so the three- and four-pass paths
  * (normally n > 2^20 and n = 2^31) can be checked against the oracle at small sizes.  0 restores the automatic plan. */
 void tf_set_ntt_min_passes(int passes);
@@ -212,6 +221,9 @@ int tf_debug_stamps(unsigned long long *host_out, size_t words);
 /* Measurement helper: the shader clock (MHz) the current device is running at right now (one-wave ~0.5 ms spin; < 0 on failure). */
 double tf_debug_sclk_mhz(void);
 size_t tf_get_ntt_tile_bytes(void);
+/* Synthetic inputs for benches/tests: d_out[i] = BFieldElement::new(splitmix64(seed ^ (first_index + i)) mod p),
+ * raw Montgomery words, generated on the device (the oracle's tfo_fill_random is the same counter-based sequence). */
+int tf_debug_fill_random_dev(uint64_t *d_out, size_t count, uint64_t seed, uint64_t first_index, void *stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Profiling target: the three BASELINE workloads and nothing else (no parity launches, no CPU legs), so that every
+dispatch of a kernel under rocprofv3 is a full-size one.  tools/prof_r02.sh runs it under --kernel-trace --stats and the
+separate --pmc passes.
+
+    python tools/prof_target.py [--ntt 12] [--merkle 3] [--coset 2] [--tile-mib M] [--pipe K]
+"""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--ntt", type=int, default=12)
+    ap.add_argument("--merkle", type=int, default=3)
+    ap.add_argument("--coset", type=int, default=2)
+    ap.add_argument("--tile-mib", type=int, default=0)
+    ap.add_argument("--pipe", type=int, default=0)
+    a = ap.parse_args()
+    import torch
+
+    import twenty_first_amd as tf
+
+    if a.tile_mib:
+        tf.lib().tf_set_ntt_tile_bytes(a.tile_mib << 20)
+    if a.pipe:
+        tf.lib().tf_set_ntt_pipe(a.pipe)
+    dev = torch.device("cuda", 0)
+    if a.ntt:
+        n, batch = 1 << 20, 256
+        x = torch.empty(n * batch, dtype=torch.int64, device=dev)
+        tf.device.fill_random(x, 0x7F210002)
+        for _ in range(a.ntt):
+            tf.device.ntt_(x, n, batch=batch)
+        torch.cuda.synchronize()
+        del x
+    if a.merkle:
+        nl = 1 << 24
+        leaves = torch.empty(5 * nl, dtype=torch.int64, device=dev)
+        tf.device.fill_random(leaves, 0x7F210003)
+        nodes = torch.empty(10 * nl, dtype=torch.int64, device=dev)
+        for _ in range(a.merkle):
+            tf.device.merkle_build(leaves, nl, nodes)
+        torch.cuda.synchronize()
+        del leaves, nodes
+    if a.coset:
+        n, b = 1 << 22, 64
+        c = torch.empty(3 * n * b, dtype=torch.int64, device=dev)
+        tf.device.fill_random(c, 0x7F210004)
+        o = torch.empty(3 * n * b, dtype=torch.int64, device=dev)
+        for _ in range(a.coset):
+            tf.device.coset_evaluate(c, n, tf.BFieldElement.new(7), o, n, batch=b, width=3)
+        torch.cuda.synchronize()
+
+
+if __name__ == "__main__":
+    main()

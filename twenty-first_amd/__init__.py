@@ -45,7 +45,7 @@ class TwentyFirstError(RuntimeError):
         name = lib().tf_status_string(code).decode()
         detail = lib().tf_last_error().decode()
         msg = f"{where}: {name}" if where else name
-        if detail and code >= 8:
+        if detail and 8 <= code <= 10:  # tf_last_error() is the text of a HIP failure; codes 11+ carry none
             msg += f" ({detail})"
         super().__init__(msg)
         self.code = code
@@ -137,11 +137,20 @@ def intt(x: np.ndarray, width: int = 1, batch: int = 1) -> None:
 
 
 def fast_coset_evaluate(coeffs: np.ndarray, offset_raw: int, order: int, width: int = 1, batch: int = 1) -> np.ndarray:
-    """`batch` polynomials of equal length -> `batch` x `order` evaluations (math/polynomial.rs:1374-1399)."""
+    """`batch` polynomials of equal length -> `batch` x `order` evaluations (math/polynomial.rs:1374-1399).
+    The reference compares `order` with the DEGREE (:1388): high-order zero coefficients common to the whole batch are
+    trimmed here before the length reaches the C ABI, as Polynomial::degree() does for one polynomial."""
     coeffs = _words(coeffs, "coeffs")
     if batch and coeffs.size % (batch * width):
         raise ValueError("coeffs size is not batch * n_coeffs * width")
     n_coeffs = coeffs.size // (batch * width) if batch else 0
+    if batch and n_coeffs > order:
+        c3 = coeffs.reshape(batch, n_coeffs, width)
+        live = np.nonzero(c3.any(axis=(0, 2)))[0]
+        keep = int(live[-1]) + 1 if live.size else 0
+        if keep < n_coeffs:
+            coeffs = np.ascontiguousarray(c3[:, :keep, :]).reshape(-1)
+            n_coeffs = keep
     out = np.empty(batch * order * width, dtype=np.uint64)
     fn = lib().tf_coset_eval_bfe if width == 1 else lib().tf_coset_eval_xfe
     _check(fn(_ptr(coeffs), n_coeffs, C.c_uint64(offset_raw), _ptr(out), order, batch), "fast_coset_evaluate")
@@ -164,6 +173,8 @@ def fast_multiply(a: np.ndarray, b: np.ndarray, width: int = 1, batch: int = 1) 
     """Coefficient arrays of `batch` polynomial pairs -> `batch` x (na + nb - 1) product coefficients
     (math/polynomial.rs:900-932, untrimmed)."""
     a, b = _words(a, "a"), _words(b, "b")
+    if batch and (a.size % (batch * width) or b.size % (batch * width)):
+        raise ValueError("operand size is not batch * n_coeffs * width")
     na = a.size // (batch * width) if batch else 0
     nb = b.size // (batch * width) if batch else 0
     if na == 0 or nb == 0:
@@ -178,6 +189,8 @@ def fast_square(a: np.ndarray, width: int = 1, batch: int = 1) -> np.ndarray:
     """`batch` polynomials of na coefficients -> `batch` x (2 na - 1) coefficients of their squares
     (math/polynomial.rs:780-798, untrimmed)."""
     a = _words(a, "a")
+    if batch and a.size % (batch * width):
+        raise ValueError("operand size is not batch * n_coeffs * width")
     na = a.size // (batch * width) if batch else 0
     if na == 0:
         return np.zeros(0, dtype=np.uint64)

@@ -85,6 +85,97 @@ __device__ __forceinline__ void add_sub(u64 a, u64 v, u64& sum, u64& diff) {
 }
 #endif
 
+#if defined(__HIPCC__)
+// ---- lazy (non-canonical) butterflies ------------------------------------------------------------------------------------
+// Between the reductions of a radix-32 network a value may be ANY u64 congruent to the element (only the word
+// that is finally stored has to be the canonical representative).  With  a  arbitrary and  v <= p:
+//   s = a + v:  a 64-bit carry c means the true sum is s + 2^64 = s + EPS (mod p); s + EPS cannot carry again because
+//               a + v - 2^64 < p (v <= p, a < 2^64), so s + EPS < p + EPS = 2^64.          s -= c; s_hi += c & ~borrow
+//   d = a - v:  a borrow b means the true difference is d - 2^64 = d - EPS (mod p); d = a - v + 2^64 >= 2^64 - p = EPS because
+//               v <= p, so d - EPS does not borrow again.                                  d_lo += b; d_hi -= b & ~carry
+// Eight VALU instructions per butterfly instead of ten (no  n = p - v,  no canonical outputs).  TWO butterflies per block:
+// their four carry chains are issued round-robin, so every carry mask is read at least three instructions after it was
+// written and the block needs no wait-state s_nop (gfx950 wants two wait states between a VALU writing a carry mask and a VALU
+// reading it).
+__device__ __forceinline__ void add_sub_lazy2(u64 a, u64 v, u64 c, u64 w, u64& sum0, u64& diff0, u64& sum1, u64& diff1) {
+    const u32 a0 = (u32)a, a1 = (u32)(a >> 32), v0 = (u32)v, v1 = (u32)(v >> 32);
+    const u32 c0 = (u32)c, c1 = (u32)(c >> 32), w0 = (u32)w, w1 = (u32)(w >> 32);
+    u32 p0, p1, q0, q1, r0, r1, t0, t1;
+    u64 mp, mq, mr, mt, np, nq, nr;  // m*: carry / borrow of the 64-bit operation, n*: of the correction's low word (chain t: vcc)
+    asm("v_add_co_u32_e64 %[p0], %[mp], %[a0], %[v0]\n\t"               //  1 P1  p0 = a0 + v0
+        "v_sub_co_u32_e64 %[q0], %[mq], %[a0], %[v0]\n\t"               //  2 Q1  q0 = a0 - v0
+        "v_add_co_u32_e64 %[r0], %[mr], %[c0], %[w0]\n\t"               //  3 R1
+        "v_sub_co_u32_e64 %[t0], %[mt], %[c0], %[w0]\n\t"               //  4 T1
+        "v_addc_co_u32_e64 %[p1], %[mp], %[a1], %[v1], %[mp]\n\t"       //  5 P2  p1 = a1 + v1 + carry     -> mp = carry of a + v
+        "v_subb_co_u32_e64 %[q1], %[mq], %[a1], %[v1], %[mq]\n\t"       //  6 Q2  q1 = a1 - v1 - borrow    -> mq = (a < v)
+        "v_addc_co_u32_e64 %[r1], %[mr], %[c1], %[w1], %[mr]\n\t"       //  7 R2
+        "v_subb_co_u32_e64 %[t1], %[mt], %[c1], %[w1], %[mt]\n\t"       //  8 T2
+        "v_subbrev_co_u32_e64 %[p0], %[np], 0, %[p0], %[mp]\n\t"        //  9 P3  p0 -= carry              -> np = borrow
+        "v_addc_co_u32_e64 %[q0], %[nq], 0, %[q0], %[mq]\n\t"           // 10 Q3  q0 += borrow             -> nq = carry
+        "v_subbrev_co_u32_e64 %[r0], %[nr], 0, %[r0], %[mr]\n\t"        // 11 R3
+        "v_addc_co_u32_e64 %[t0], vcc, 0, %[t0], %[mt]\n\t"             // 12 T3                           -> vcc = carry
+        "s_andn2_b64 %[mp], %[mp], %[np]\n\t"
+        "s_andn2_b64 %[mq], %[mq], %[nq]\n\t"
+        "s_andn2_b64 %[mr], %[mr], %[nr]\n\t"
+        "s_andn2_b64 %[mt], %[mt], vcc\n\t"
+        "v_addc_co_u32_e64 %[p1], %[np], 0, %[p1], %[mp]\n\t"           // 13 P4  p1 += carry & ~borrow
+        "v_subbrev_co_u32_e64 %[q1], %[nq], 0, %[q1], %[mq]\n\t"        // 14 Q4  q1 -= borrow & ~carry
+        "v_addc_co_u32_e64 %[r1], %[nr], 0, %[r1], %[mr]\n\t"           // 15 R4
+        "v_subbrev_co_u32_e64 %[t1], vcc, 0, %[t1], %[mt]"                // 16 T4
+        : [p0] "=&v"(p0), [p1] "=&v"(p1), [q0] "=&v"(q0), [q1] "=&v"(q1), [r0] "=&v"(r0), [r1] "=&v"(r1), [t0] "=&v"(t0), [t1] "=&v"(t1),
+          [mp] "=&s"(mp), [mq] "=&s"(mq), [mr] "=&s"(mr), [mt] "=&s"(mt), [np] "=&s"(np), [nq] "=&s"(nq), [nr] "=&s"(nr)
+        : [a0] "v"(a0), [a1] "v"(a1), [v0] "v"(v0), [v1] "v"(v1), [c0] "v"(c0), [c1] "v"(c1), [w0] "v"(w0), [w1] "v"(w1)
+        : "vcc", "scc");
+    sum0 = ((u64)p1 << 32) | p0;
+    diff0 = ((u64)q1 << 32) | q0;
+    sum1 = ((u64)r1 << 32) | r0;
+    diff1 = ((u64)t1 << 32) | t0;
+}
+
+// The canonical butterfly of add_sub for TWO butterflies at once: canonical inputs and outputs, ten VALU instructions each
+// as in add_sub, but the six carry chains (n = p - v, a - n, a - v, twice) are issued round-robin, so every carry mask is read
+// at least three instructions after it was written and no wait-state s_nop is needed (add_sub spends three per butterfly).
+__device__ __forceinline__ void add_sub2(u64 a, u64 v, u64 c, u64 w, u64& sum0, u64& diff0, u64& sum1, u64& diff1) {
+    const u32 a0 = (u32)a, a1 = (u32)(a >> 32), v0 = (u32)v, v1 = (u32)(v >> 32);
+    const u32 c0 = (u32)c, c1 = (u32)(c >> 32), w0 = (u32)w, w1 = (u32)(w >> 32);
+    u32 p0, p1, q0, q1, r0, r1, t0, t1, n0, n1, o0, o1;
+    u64 mA, mA2, mB, mB2, mK, mK2;
+    asm("v_sub_co_u32_e64 %[n0], %[mA], 1, %[v0]\n\t"                   //  1 N1   n0 = 1 - v0
+        "v_sub_co_u32_e64 %[o0], %[mA2], 1, %[w0]\n\t"                  //  2 N'1
+        "v_sub_co_u32_e64 %[q0], %[mB], %[a0], %[v0]\n\t"               //  3 D1   q0 = a0 - v0
+        "v_sub_co_u32_e64 %[t0], %[mB2], %[c0], %[w0]\n\t"              //  4 D'1
+        "v_subb_co_u32_e64 %[n1], %[mA], -1, %[v1], %[mA]\n\t"          //  5 N2   n1 = 0xffffffff - v1 - borrow
+        "v_subb_co_u32_e64 %[o1], %[mA2], -1, %[w1], %[mA2]\n\t"        //  6 N'2
+        "v_subb_co_u32_e64 %[q1], %[mB], %[a1], %[v1], %[mB]\n\t"       //  7 D2   q1 = a1 - v1 - borrow   -> mB = (a < v)
+        "v_subb_co_u32_e64 %[t1], %[mB2], %[c1], %[w1], %[mB2]\n\t"     //  8 D'2
+        "v_sub_co_u32_e64 %[p0], %[mA], %[a0], %[n0]\n\t"               //  9 S1   p0 = a0 - n0
+        "v_sub_co_u32_e64 %[r0], %[mA2], %[c0], %[o0]\n\t"              // 10 S'1
+        "v_addc_co_u32_e64 %[q0], %[mK], 0, %[q0], %[mB]\n\t"           // 11 D3   q0 += borrow           -> carry mK
+        "v_addc_co_u32_e64 %[t0], %[mK2], 0, %[t0], %[mB2]\n\t"         // 12 D'3
+        "v_subb_co_u32_e64 %[p1], %[mA], %[a1], %[n1], %[mA]\n\t"       // 13 S2   p1 = a1 - n1 - borrow   -> mA = (a < n)
+        "v_subb_co_u32_e64 %[r1], %[mA2], %[c1], %[o1], %[mA2]\n\t"     // 14 S'2
+        "s_andn2_b64 %[mB], %[mB], %[mK]\n\t"
+        "s_andn2_b64 %[mB2], %[mB2], %[mK2]\n\t"
+        "v_addc_co_u32_e64 %[p0], %[mK], 0, %[p0], %[mA]\n\t"           // 15 S3   p0 += borrow           -> carry mK
+        "v_addc_co_u32_e64 %[r0], %[mK2], 0, %[r0], %[mA2]\n\t"         // 16 S'3
+        "v_subbrev_co_u32_e64 %[q1], vcc, 0, %[q1], %[mB]\n\t"          // 17 D4   q1 -= borrow & ~carry
+        "v_subbrev_co_u32_e64 %[t1], vcc, 0, %[t1], %[mB2]\n\t"         // 18 D'4
+        "s_andn2_b64 %[mA], %[mA], %[mK]\n\t"
+        "s_andn2_b64 %[mA2], %[mA2], %[mK2]\n\t"
+        "v_subbrev_co_u32_e64 %[p1], vcc, 0, %[p1], %[mA]\n\t"          // 19 S4
+        "v_subbrev_co_u32_e64 %[r1], vcc, 0, %[r1], %[mA2]"               // 20 S'4
+        : [p0] "=&v"(p0), [p1] "=&v"(p1), [q0] "=&v"(q0), [q1] "=&v"(q1), [r0] "=&v"(r0), [r1] "=&v"(r1), [t0] "=&v"(t0), [t1] "=&v"(t1),
+          [n0] "=&v"(n0), [n1] "=&v"(n1), [o0] "=&v"(o0), [o1] "=&v"(o1), [mA] "=&s"(mA), [mA2] "=&s"(mA2), [mB] "=&s"(mB),
+          [mB2] "=&s"(mB2), [mK] "=&s"(mK), [mK2] "=&s"(mK2)
+        : [a0] "v"(a0), [a1] "v"(a1), [v0] "v"(v0), [v1] "v"(v1), [c0] "v"(c0), [c1] "v"(c1), [w0] "v"(w0), [w1] "v"(w1)
+        : "vcc", "scc");
+    sum0 = ((u64)p1 << 32) | p0;
+    diff0 = ((u64)q1 << 32) | q0;
+    sum1 = ((u64)r1 << 32) | r0;
+    diff1 = ((u64)t1 << 32) | t0;
+}
+#endif
+
 GL_HD u64 mulhi64(u64 a, u64 b) {
 #if defined(__HIP_DEVICE_COMPILE__)
     return __umul64hi(a, b);

@@ -76,6 +76,9 @@ struct NttPassArgs {
                                              // segments start on cache lines even when the output stride is not a multiple of 16 words
                                              // (truncated products); tile 0 wraps around to the last s columns
     u32 nc_magic;                            // t / nc == umulhi(t, nc_magic) for every t < blockDim (checked by the planner)
+    int nt;                                  // bit 0: non-temporal loads of the input, bit 1: non-temporal stores of the output (plain
+                                             // transforms only): streams that are touched once stay out of the Infinity Cache, which is
+                                             // then left to the scratch tile between the passes (TF_NTT_NT, planner)
     unsigned long long* dbg;                 // MODE 3 only: per-wave cycle stamps (6 per wave)
 };
 
@@ -90,10 +93,57 @@ struct TwExp {
 #ifndef TF_ASM_BFLY
 #define TF_ASM_BFLY 1  // 0: the compiler's compare-and-select add/sub (12 VALU per butterfly instead of 10)
 #endif
+#ifndef TF_LAZY
+#define TF_LAZY 1  // 0: every network canonical (A/B build); 1: lazy butterflies in the networks that are followed by a Montgomery product
+#endif
+
+// Butterfly I (0 .. 15) of level LVL over 32 register slots: groups of 2^LVL consecutive slots, butterfly j of a group pairs
+// slots (base + j, base + j + 2^(LVL-1)) with the twiddle w_{2^LVL}^j (inputs of a group in bit-reversed order, outputs natural).
+template <bool INV, int LVL, int I>
+struct Bf {
+    static constexpr int H = 1 << (LVL - 1);
+    static constexpr int j = I % H;
+    static constexpr int ia = (I / H) * 2 * H + j;
+    static constexpr int ib = ia + H;
+    static constexpr int E = TwExp<INV, LVL, j>::value;
+    static constexpr bool neg = gl::Pow2Mul<E>::negate;  // the power-of-two product comes back negated: swap the outputs
+};
+
+// x * 2^E up to the sign Bf::neg, as a CANONICAL word whatever 64-bit word x is (shl_fold / shl_monty reduce fully).
+// E = 0 passes x through: canonical in a canonical network; in a lazy network only level 1 meets that case with canonical inputs
+// (loaded words or Montgomery products), the levels above canonicalise the operand first (LAZY_IN).
+template <int E, bool LAZY_IN>
+__device__ __forceinline__ u64 tw_operand(u64 b) {
+    if constexpr (E % 192 == 0) {
+        if constexpr (LAZY_IN) return gl::add(b, 0);  // b >= p ? b - p : b   (4 VALU)
+        return b;
+    } else {
+        return gl::Pow2Mul<E>::apply(b);
+    }
+}
+
+// Two butterflies (I, I + 1) of one level in one block of interleaved carry chains (gl::add_sub2 / gl::add_sub_lazy2).
+//   LAZY = false: canonical inputs and outputs (ten VALU per butterfly).
+//   LAZY = true:  the first operand of a butterfly may be any 64-bit word congruent to the element, the outputs are such words
+//                 (eight VALU per butterfly); the twiddled operand is always canonical (tw_operand).
+template <bool INV, int LVL, int I, bool LAZY>
+__device__ __forceinline__ void butterfly_pair(u64 (&x)[32]) {
+    using B0 = Bf<INV, LVL, I>;
+    using B1 = Bf<INV, LVL, I + 1>;
+    const u64 v0 = tw_operand<B0::E, LAZY && (LVL > 1)>(x[B0::ib]);
+    const u64 v1 = tw_operand<B1::E, LAZY && (LVL > 1)>(x[B1::ib]);
+    u64 s0, d0, s1, d1;
+    if constexpr (LAZY) gl::add_sub_lazy2(x[B0::ia], v0, x[B1::ia], v1, s0, d0, s1, d1);
+    else gl::add_sub2(x[B0::ia], v0, x[B1::ia], v1, s0, d0, s1, d1);
+    x[B0::ia] = B0::neg ? d0 : s0;
+    x[B0::ib] = B0::neg ? s0 : d0;
+    x[B1::ia] = B1::neg ? d1 : s1;
+    x[B1::ib] = B1::neg ? s1 : d1;
+}
 
 template <int E>
 __device__ __forceinline__ void butterfly_pow2(u64& a, u64& b) {
-    // (a, b) -> (a + b * 2^E, a - b * 2^E); the sign of the power-of-two product is folded into add/sub
+    // (a, b) -> (a + b * 2^E, a - b * 2^E), canonical in and out; the sign of the power-of-two product is folded into add/sub
     const u64 v = gl::Pow2Mul<E>::apply(b);
 #if TF_ASM_BFLY
     if constexpr (!gl::Pow2Mul<E>::negate) gl::add_sub(a, v, a, b);
@@ -111,42 +161,30 @@ __device__ __forceinline__ void butterfly_pow2(u64& a, u64& b) {
     }
 }
 
-template <bool INV, int LVL, int BASE, int J>
-struct DitInner {
+// butterflies [I, END) of level LVL, two at a time
+template <bool INV, int LVL, int I, int END, bool LAZY>
+struct DitRange {
     static __device__ __forceinline__ void run(u64 (&x)[32]) {
-        constexpr int H = 1 << (LVL - 1);
-        butterfly_pow2<TwExp<INV, LVL, J>::value>(x[BASE + J], x[BASE + J + H]);
-        if constexpr (J + 1 < H) DitInner<INV, LVL, BASE, J + 1>::run(x);
+#if TF_ASM_BFLY
+        butterfly_pair<INV, LVL, I, LAZY>(x);
+#else
+        butterfly_pow2<Bf<INV, LVL, I>::E>(x[Bf<INV, LVL, I>::ia], x[Bf<INV, LVL, I>::ib]);
+        butterfly_pow2<Bf<INV, LVL, I + 1>::E>(x[Bf<INV, LVL, I + 1>::ia], x[Bf<INV, LVL, I + 1>::ib]);
+#endif
+        if constexpr (I + 2 < END) DitRange<INV, LVL, I + 2, END, LAZY>::run(x);
     }
 };
-template <bool INV, int LVL, int BASE>
-struct DitGroups {
-    static __device__ __forceinline__ void run(u64 (&x)[32]) {
-        constexpr int H = 1 << (LVL - 1);
-        DitInner<INV, LVL, BASE, 0>::run(x);
-        if constexpr (BASE + 2 * H < 32) DitGroups<INV, LVL, BASE + 2 * H>::run(x);
-    }
-};
-// Level LVL of a DIT network over all 32 registers (groups of 2^LVL consecutive slots; inputs of a
-// group in bit-reversed order, outputs natural).
-template <bool INV, int LVL>
-__device__ __forceinline__ void dit_level(u64 (&x)[32]) { DitGroups<INV, LVL, 0>::run(x); }
+// Level LVL of a DIT network over all 32 registers.
+template <bool INV, int LVL, bool LAZY = false>
+__device__ __forceinline__ void dit_level(u64 (&x)[32]) { DitRange<INV, LVL, 0, 16, LAZY && TF_LAZY>::run(x); }
 
-// levels 1..4 restricted to the 16 register slots starting at FIRST (0 or 16)
-template <bool INV, int LVL, int BASE, int END>
-struct DitGroupsRange {
-    static __device__ __forceinline__ void run(u64 (&x)[32]) {
-        constexpr int H = 1 << (LVL - 1);
-        DitInner<INV, LVL, BASE, 0>::run(x);
-        if constexpr (BASE + 2 * H < END) DitGroupsRange<INV, LVL, BASE + 2 * H, END>::run(x);
-    }
-};
-template <bool INV, int FIRST>
+// levels 1..4 restricted to the 16 register slots starting at FIRST (0 or 16): butterflies FIRST/2 .. FIRST/2 + 7 of each level
+template <bool INV, int FIRST, bool LAZY = false>
 __device__ __forceinline__ void dit_half(u64 (&x)[32]) {
-    DitGroupsRange<INV, 1, FIRST, FIRST + 16>::run(x);
-    DitGroupsRange<INV, 2, FIRST, FIRST + 16>::run(x);
-    DitGroupsRange<INV, 3, FIRST, FIRST + 16>::run(x);
-    DitGroupsRange<INV, 4, FIRST, FIRST + 16>::run(x);
+    DitRange<INV, 1, FIRST / 2, FIRST / 2 + 8, LAZY && TF_LAZY>::run(x);
+    DitRange<INV, 2, FIRST / 2, FIRST / 2 + 8, LAZY && TF_LAZY>::run(x);
+    DitRange<INV, 3, FIRST / 2, FIRST / 2 + 8, LAZY && TF_LAZY>::run(x);
+    DitRange<INV, 4, FIRST / 2, FIRST / 2 + 8, LAZY && TF_LAZY>::run(x);
 }
 
 // Level 5 of the radix-32 network for the four butterflies (Q0+i, Q0+i+16), i < 4, followed by their eight stores.
@@ -155,11 +193,8 @@ __device__ __forceinline__ void dit_half(u64 (&x)[32]) {
 //         sbase + 32 q s_rs_bytes + soff for slot q.
 template <bool INV, int Q0, bool TRUNC = false, bool SCALED = false>
 __device__ __forceinline__ void tail_p5(u64 (&x)[32], bool act, char* obase, u32 toff, long long out_rs_bytes, int qlim = 32,
-                                        const char* sbase = nullptr, u32 soff = 0, long long s_rs_bytes = 0) {
-    butterfly_pow2<TwExp<INV, 5, Q0 + 0>::value>(x[Q0 + 0], x[Q0 + 16]);
-    butterfly_pow2<TwExp<INV, 5, Q0 + 1>::value>(x[Q0 + 1], x[Q0 + 17]);
-    butterfly_pow2<TwExp<INV, 5, Q0 + 2>::value>(x[Q0 + 2], x[Q0 + 18]);
-    butterfly_pow2<TwExp<INV, 5, Q0 + 3>::value>(x[Q0 + 3], x[Q0 + 19]);
+                                        const char* sbase = nullptr, u32 soff = 0, long long s_rs_bytes = 0, bool nt = false) {
+    DitRange<INV, 5, Q0, Q0 + 4, false>::run(x);  // canonical: these words are stored
     if (act) {
         if constexpr (SCALED) {
             u64 w[8];
@@ -171,11 +206,19 @@ __device__ __forceinline__ void tail_p5(u64 (&x)[32], bool act, char* obase, u32
 #pragma unroll
             for (int i = 0; i < 4; ++i) gl::mont_mul2(x[Q0 + i], w[i], x[Q0 + i + 16], w[4 + i], x[Q0 + i], x[Q0 + i + 16]);
         }
+        if (!TRUNC && !SCALED && nt) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            if (!TRUNC || Q0 + i < qlim) *reinterpret_cast<u64*>(obase + (long long)(32 * (Q0 + i)) * out_rs_bytes + toff) = x[Q0 + i];
-            if (!TRUNC || Q0 + i + 16 < qlim)
-                *reinterpret_cast<u64*>(obase + (long long)(32 * (Q0 + i + 16)) * out_rs_bytes + toff) = x[Q0 + i + 16];
+            for (int i = 0; i < 4; ++i) {
+                __builtin_nontemporal_store(x[Q0 + i], reinterpret_cast<u64*>(obase + (long long)(32 * (Q0 + i)) * out_rs_bytes + toff));
+                __builtin_nontemporal_store(x[Q0 + i + 16], reinterpret_cast<u64*>(obase + (long long)(32 * (Q0 + i + 16)) * out_rs_bytes + toff));
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (!TRUNC || Q0 + i < qlim) *reinterpret_cast<u64*>(obase + (long long)(32 * (Q0 + i)) * out_rs_bytes + toff) = x[Q0 + i];
+                if (!TRUNC || Q0 + i + 16 < qlim)
+                    *reinterpret_cast<u64*>(obase + (long long)(32 * (Q0 + i + 16)) * out_rs_bytes + toff) = x[Q0 + i + 16];
+            }
         }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -212,6 +255,11 @@ __global__ void __launch_bounds__(512, TF_NTT_WAVES) ntt_pass_kernel(const NttPa
     // tail (a column pass of a 2^20-point transform): the constant P2 folds the slot index arithmetic at compile time.
     const int p2 = (LAST1024 || R1024) ? 5 : A.p2;
     const int P2 = 1 << p2;
+    // Lazy networks (TF_LAZY): step 1 of the R = 1024 instantiations is always followed by the inner-twiddle Montgomery product,
+    // step 2 of the column pass by the inter-pass one; a Montgomery product takes any 64-bit representative and returns the
+    // canonical word, so these networks run on non-canonical words (8 VALU per butterfly).  Everything else stays canonical.
+    constexpr bool LAZY1 = (LAST1024 || R1024) && MODE != 2;
+    constexpr bool LAZY2 = R1024 && MODE == 0;
     const int L = A.L;
 
     u32 i0, i1, i2;
@@ -315,7 +363,7 @@ __global__ void __launch_bounds__(512, TF_NTT_WAVES) ntt_pass_kernel(const NttPa
                 const long long j = (ur + g) * A.ps_rs + (A.ps_col ? bcol : 0);
                 if (A.n_coeffs < 0 || j < A.n_coeffs) x[q] = *ptr;  // rows beyond the coefficients read as zero; scaled below
             } else {
-                x[q] = *ptr;
+                x[q] = (A.nt & 1) ? __builtin_nontemporal_load(ptr) : *ptr;  // uniform: the compiler emits the burst twice
             }
         }
     }
@@ -359,7 +407,7 @@ __global__ void __launch_bounds__(512, TF_NTT_WAVES) ntt_pass_kernel(const NttPa
     if constexpr (MODE != 2) {
         // Levels 1-4 of the first 16 slots need only the first 16 loads: start on them while the second half of the
         // burst is still in flight (the levels below 5 never mix the two halves).  Measured: 2.56 -> 2.44 ms.
-        dit_half<INV, 0>(x);
+        dit_half<INV, 0, LAZY1>(x);
         __builtin_amdgcn_sched_barrier(0);
     }
     if constexpr (MODE == 3) {
@@ -368,9 +416,9 @@ __global__ void __launch_bounds__(512, TF_NTT_WAVES) ntt_pass_kernel(const NttPa
         stamp[2] = __builtin_readcyclecounter();
     }
     if constexpr (MODE != 2) {
-        dit_half<INV, 16>(x);
-        dit_level<INV, 5>(x);
-        if (A.inner_tw) {
+        dit_half<INV, 16, LAZY1>(x);
+        dit_level<INV, 5, LAZY1>(x);
+        if (LAZY1 || A.inner_tw) {  // (the R = 1024 instantiations always have an inner table: launch_pass checks)
             const u64* tw = A.inner_tw + g_in * 32;
 #pragma unroll
             for (int q = 0; q < 32; q += 2) gl::mont_mul2(x[q], tw[q], x[q + 1], tw[q + 1], x[q], x[q + 1]);
@@ -462,18 +510,19 @@ __global__ void __launch_bounds__(512, TF_NTT_WAVES) ntt_pass_kernel(const NttPa
             tail_p5<INV, 12, true>(x, act, base, toff, A.out_rs * 8, qlim);
             return;
         }
-        tail_p5<INV, 0>(x, act, base, toff, A.out_rs * 8);
-        tail_p5<INV, 4>(x, act, base, toff, A.out_rs * 8);
-        tail_p5<INV, 8>(x, act, base, toff, A.out_rs * 8);
-        tail_p5<INV, 12>(x, act, base, toff, A.out_rs * 8);
+        const bool nts = (A.nt & 2) != 0;
+        tail_p5<INV, 0>(x, act, base, toff, A.out_rs * 8, 32, nullptr, 0, 0, nts);
+        tail_p5<INV, 4>(x, act, base, toff, A.out_rs * 8, 32, nullptr, 0, 0, nts);
+        tail_p5<INV, 8>(x, act, base, toff, A.out_rs * 8, 32, nullptr, 0, 0, nts);
+        tail_p5<INV, 12>(x, act, base, toff, A.out_rs * 8, 32, nullptr, 0, 0, nts);
         return;
     }
     if constexpr (MODE != 2) {
-        if (p2 >= 1) dit_level<INV, 1>(x);
-        if (p2 >= 2) dit_level<INV, 2>(x);
-        if (p2 >= 3) dit_level<INV, 3>(x);
-        if (p2 >= 4) dit_level<INV, 4>(x);
-        if (p2 >= 5) dit_level<INV, 5>(x);
+        if (p2 >= 1) dit_level<INV, 1, LAZY2>(x);
+        if (p2 >= 2) dit_level<INV, 2, LAZY2>(x);
+        if (p2 >= 3) dit_level<INV, 3, LAZY2>(x);
+        if (p2 >= 4) dit_level<INV, 4, LAZY2>(x);
+        if (p2 >= 5) dit_level<INV, 5, LAZY2>(x);
     }
     if constexpr (MODE == 1) {
         u64 acc = 0;
@@ -620,14 +669,17 @@ __global__ void __launch_bounds__(512, 4) ntt_block_kernel(const NttBlockArgs A)
             }
         }
     }
-    dit_half<INV, 0>(x);
-    dit_half<INV, 16>(x);
-    dit_level<INV, 5>(x);
+    dit_half<INV, 0, true>(x);   // lazy networks in stages A and B: a Montgomery product follows (see ntt_pass_kernel)
+    dit_half<INV, 16, true>(x);
+    dit_level<INV, 5, true>(x);
     {
         const u64* tw = A.tw1 + rest;
 #pragma unroll
         for (int q = 2; q < 32; q += 2) gl::mont_mul2(x[q], tw[q * REST], x[q + 1], tw[(q + 1) * REST], x[q], x[q + 1]);
         x[1] = gl::mont_mul(x[1], tw[REST]);  // k1 = 0: factor 1
+#if TF_LAZY
+        x[0] = gl::add(x[0], 0);              // ... so the word is only made canonical
+#endif
     }
     // ---- exchange 1: (k1 = q, j2, j3, tr) -> thread (tr, j3, k1) holding j2
     const int j2A = rest >> LOGP3, j3A = rest & (P3 - 1);
@@ -655,9 +707,9 @@ __global__ void __launch_bounds__(512, 4) ntt_block_kernel(const NttBlockArgs A)
         }
     }
     // ---- stage B
-    dit_half<INV, 0>(x);
-    dit_half<INV, 16>(x);
-    dit_level<INV, 5>(x);
+    dit_half<INV, 0, true>(x);
+    dit_half<INV, 16, true>(x);
+    dit_level<INV, 5, true>(x);
     {
         const u64* tw = A.tw2 + j3B;
 #pragma unroll
@@ -778,9 +830,9 @@ __global__ void __launch_bounds__(512, 4) ntt_rows32_kernel(const NttRows32Args 
             for (int q = 0; q < 32; ++q) x[q] = lds[row * 33 + brev5(q)];
         }
     }
-    dit_half<INV, 0>(x);
-    dit_half<INV, 16>(x);
-    dit_level<INV, 5>(x);
+    dit_half<INV, 0, INV>(x);   // the inverse multiplies every word by 32^-1 afterwards: lazy network
+    dit_half<INV, 16, INV>(x);
+    dit_level<INV, 5, INV>(x);
     if (INV) {
 #pragma unroll
         for (int q = 0; q < 32; q += 2) gl::mont_mul2(x[q], A.scale, x[q + 1], A.scale, x[q], x[q + 1]);
@@ -876,11 +928,13 @@ __global__ void __launch_bounds__(256) build_post_tw_kernel(u64* out, const u64*
     out[id] = gl::mont_mul(hi[e >> h], lo[e & ((1ull << h) - 1)]);
 }
 
-// out[j] = HI[j >> h] * LO[j & (2^h - 1)]   (offset^j)
-__global__ void __launch_bounds__(256) build_pow_table_kernel(u64* out, const u64* hi, const u64* lo, int h, long long n) {
+// out[c * n + j] = HI_c[j >> h] * LO_c[j & (2^h - 1)]   (base_c^j; grid.y = c; tabs = [c][nhi + nlo] split tables)
+__global__ void __launch_bounds__(256) build_pow_tables_kernel(u64* out, const u64* tabs, int h, long long n, long long nhi, long long nlo) {
     long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= n) return;
-    out[id] = gl::mont_mul(hi[id >> h], lo[id & ((1ll << h) - 1)]);
+    const u64* hi = tabs + (long long)blockIdx.y * (nhi + nlo);
+    const u64* lo = hi + nhi;
+    out[(long long)blockIdx.y * n + id] = gl::mont_mul(hi[id >> h], lo[id & ((1ll << h) - 1)]);
 }
 
 // ---- pointwise products (Hadamard) ---------------------------------------------------------------
@@ -1037,6 +1091,20 @@ __global__ void sclk_probe_kernel(unsigned long long* out) {
     if (threadIdx.x == 0) {
         out[0] = c1 - c0 + (v == 0xdeadbeefu);
         out[1] = w1 - w0;
+    }
+}
+
+// Synthetic inputs for benches and tests: element i = BFieldElement::new(splitmix64(seed ^ i) mod p), raw
+// Montgomery word -- counter-based, so any slice can be regenerated; the oracle's tfo_fill_random is the same sequence.
+__global__ void __launch_bounds__(256) fill_random_kernel(u64* out, unsigned long long count, u64 seed, unsigned long long first) {
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
+        u64 z = (seed ^ (first + i)) + 0x9e3779b97f4a7c15ULL;
+        z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL;
+        z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL;
+        z ^= z >> 31;
+        if (z >= gl::P) z -= gl::P;          // z mod p (z < 2^64 < 2p)
+        out[i] = gl::mont_mul(z, gl::R2);    // BFieldElement::new (b_field_element.rs:235-237)
     }
 }
 

@@ -87,7 +87,14 @@ struct DeviceCtx {
     std::map<std::pair<u64, u64>, u64*> pow_tables;  // (offset_raw, n) -> offset^j table
     bool tip5_ready = false;               // guarded by mu
     std::atomic<bool> pool_ready{false};  // double-checked under mu
+    hipStream_t side[4] = {nullptr, nullptr, nullptr, nullptr};  // pipelined tiles (run_ntt); created on first use under mu
+    size_t cached_post_bytes = 0;          // inter-pass twiddle tables kept for the life of the process (guarded by mu)
+    size_t cached_pow_bytes = 0;           // coset power tables kept for the life of the process (guarded by mu)
 };
+// What the caches may pin for the life of the process; a table that does not fit becomes a stream-ordered temporary
+// that is rebuilt per call and released after the pass that reads it.
+constexpr size_t kPostCacheBudget = size_t(4) << 30;   // inter-pass twiddles (2^20: 8 MiB, 2^28: 2 GiB)
+constexpr size_t kPowCacheBudget = size_t(1) << 30;    // offset^j tables (n_coeffs words each)
 
 constexpr int kMaxDevices = 64;
 DeviceCtx g_ctx[kMaxDevices];
@@ -122,6 +129,12 @@ int current_ctx(DeviceCtx** out) {
 }
 
 size_t g_tile_bytes = 0;
+// Pipelined tiles: with g_pipe = K > 1 the batch tiles of a multi-pass transform are dealt round-robin to K side streams,
+// each with its own scratch tile, so that the column pass of tile t + 1 runs beside the transposing pass of tile t: the
+// launches' tails fill each other and a tile sized for the 256 MiB Infinity Cache is re-read out of it.  1 = one stream.
+std::atomic<int> g_pipe{0};
+constexpr int kMaxPipe = 4;
+std::atomic<int> g_nt{-1};  // TF_NTT_NT / tf_set_ntt_nt: bit 0 non-temporal input loads (first pass), bit 1 non-temporal output stores (last pass)
 std::once_flag g_env_once;
 void read_env() {
     std::call_once(g_env_once, [] {
@@ -129,6 +142,15 @@ void read_env() {
             const char* s = getenv("TF_NTT_TILE_BYTES");
             g_tile_bytes = s ? strtoull(s, nullptr, 10) : (size_t(2048) << 20);
             if (g_tile_bytes == 0) g_tile_bytes = size_t(2048) << 20;
+        }
+        if (g_pipe.load() == 0) {
+            const char* s = getenv("TF_NTT_PIPE");
+            const int k = s ? atoi(s) : 1;
+            g_pipe.store(std::min(std::max(k, 1), kMaxPipe));
+        }
+        if (g_nt.load() < 0) {
+            const char* s = getenv("TF_NTT_NT");
+            g_nt.store(s ? (atoi(s) & 3) : 0);
         }
     });
 }
@@ -220,6 +242,7 @@ int get_post_table(DeviceCtx* ctx, int log_m, int a, bool inverse, hipStream_t s
             *out = it->second;
             return TF_OK;
         }
+        if (ctx->cached_post_bytes + (sizeof(u64) << log_m) > kPostCacheBudget) *temp = true;  // over budget: temporary
     }
     u64 w = root_of_unity_mont(log_m);
     if (inverse) w = gl::mont_inverse(w);
@@ -263,7 +286,10 @@ int get_post_table(DeviceCtx* ctx, int log_m, int a, bool inverse, hipStream_t s
         if (*temp) (void)hipFreeAsync(d, stream); else (void)hipFree(d);
         return hip_fail(e, "build_post_tw_kernel", __FILE__, __LINE__);
     }
-    if (!*temp) ctx->tables[key] = d;
+    if (!*temp) {
+        ctx->tables[key] = d;
+        ctx->cached_post_bytes += size_t(M) * sizeof(u64);
+    }
     *out = d;
     return TF_OK;
 }
@@ -307,7 +333,10 @@ int get_block_tables(DeviceCtx* ctx, int log_n, bool inverse, const u64** tw1, c
     int rc = upload_table(t1, &d1);
     if (rc) return rc;
     rc = upload_table(t2, &d2);
-    if (rc) return rc;
+    if (rc) {
+        (void)hipFree(d1);
+        return rc;
+    }
     ctx->tables[key1] = d1;
     ctx->tables[key2] = d2;
     *tw1 = d1;
@@ -349,36 +378,42 @@ int get_tiny_table(DeviceCtx* ctx, int log_n, bool inverse, const u64** out) {
 // Up to 16 tables per device are cached for the life of the process; beyond that a table is built into a
 // stream-ordered temporary (*temp = true) that the caller releases with hipFreeAsync after its launches, so no
 // table another thread may still be using is ever freed.
-int build_pow_table(u64 offset_raw, size_t n, u64* d, hipStream_t s, bool sync_after) {
+int build_pow_tables(u64 offset_raw, u64 w, size_t cosets, size_t n, u64* d, hipStream_t s) {
+    // table c (c < cosets) = powers of base_c = offset * w^c: out[c * n + j] = base_c^j = HI_c[j >> h] * LO_c[j & (2^h - 1)].
+    // The split tables of ALL cosets go up in one allocation and ONE kernel fills every table (grid.y = coset).
     const int log_total = std::max(1, ilog2(n));
     int h = 0;
-    std::vector<u64> hi, lo;
-    split_powers(offset_raw, log_total, &h, &hi, &lo);
-    u64 *d_hi = nullptr, *d_lo = nullptr;
-    int rc = upload_table(hi, &d_hi);
-    if (rc) return rc;
-    rc = upload_table(lo, &d_lo);
-    if (rc) {
-        (void)hipFree(d_hi);
-        return rc;
+    std::vector<u64> hi, lo, all;
+    size_t nhi = 0, nlo = 0;
+    u64 base = offset_raw;
+    for (size_t c = 0; c < cosets; ++c) {
+        split_powers(base, log_total, &h, &hi, &lo);
+        nhi = hi.size(), nlo = lo.size();
+        if (c == 0) all.reserve(cosets * (nhi + nlo));
+        all.insert(all.end(), hi.begin(), hi.end());
+        all.insert(all.end(), lo.begin(), lo.end());
+        base = gl::mont_mul(base, w);
     }
+    u64* d_all = nullptr;
+    int rc = upload_table(all, &d_all);
+    if (rc) return rc;
     const int threads = 256;
     const long long blocks = ((long long)n + threads - 1) / threads;
     if (n) {
-        hipLaunchKernelGGL(tfk::build_pow_table_kernel, dim3((unsigned)blocks), dim3(threads), 0, s, d, d_hi, d_lo, h,
-                           (long long)n);
+        hipLaunchKernelGGL(tfk::build_pow_tables_kernel, dim3((unsigned)blocks, (unsigned)cosets), dim3(threads), 0, s, d, d_all, h,
+                           (long long)n, (long long)nhi, (long long)nlo);
     }
-    (void)sync_after;
     hipError_t e = hipGetLastError();
-    if (e == hipSuccess) e = hipStreamSynchronize(s);  // hi/lo are freed below; the build kernel is microseconds
-    (void)hipFree(d_hi);
-    (void)hipFree(d_lo);
-    if (e != hipSuccess) return hip_fail(e, "build_pow_table_kernel", __FILE__, __LINE__);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);  // the split tables are freed below; the build kernel is microseconds
+    (void)hipFree(d_all);
+    if (e != hipSuccess) return hip_fail(e, "build_pow_tables_kernel", __FILE__, __LINE__);
     return TF_OK;
 }
 
-// cosets = 1: out[j] = offset^j, j < n.  cosets = C > 1 (blown-up coset evaluation, see run_ntt): C tables back to back,
-// out[c * n + j] = (offset * w_{C * len}^c)^j with len the power-of-two transform length the n coefficients are padded to.
+// cosets = 1: out[j] = offset^j, j < n.  cosets = C > 1 (blown-up coset evaluation, see run_ntt; C <= kMaxCosetSplit): C tables
+// back to back, out[c * n + j] = (offset * w_{C * len}^c)^j with len the power-of-two transform length the n coefficients are
+// padded to.  At most 16 tables / kPowCacheBudget bytes stay cached; anything beyond is a stream-ordered temporary (*temp).
+constexpr size_t kMaxCosetSplit = 64;
 int get_pow_table(DeviceCtx* ctx, u64 offset_raw, size_t n, hipStream_t stream, const u64** out, bool* temp, size_t cosets = 1,
                   int log_order = 0) {
     *temp = false;
@@ -389,34 +424,26 @@ int get_pow_table(DeviceCtx* ctx, u64 offset_raw, size_t n, hipStream_t stream, 
         *out = it->second;
         return TF_OK;
     }
-    const bool cacheable = ctx->pow_tables.size() < 16;
     const size_t words = std::max<size_t>(n * cosets, 1);
+    const bool cacheable = ctx->pow_tables.size() < 16 && ctx->cached_pow_bytes + words * sizeof(u64) <= kPowCacheBudget;
     const u64 w = cosets > 1 ? root_of_unity_mont(log_order) : gl::ONE;
     u64* d = nullptr;
-    auto build_all = [&](hipStream_t s) -> int {
-        u64 base = offset_raw;
-        for (size_t c = 0; c < cosets; ++c) {
-            int rc = build_pow_table(base, n, d + c * n, s, true);
-            if (rc) return rc;
-            base = gl::mont_mul(base, w);
-        }
-        return TF_OK;
-    };
     if (cacheable) {
         HIPCHK(hipMalloc(&d, words * sizeof(u64)));
-        int rc = build_all(0);
+        int rc = build_pow_tables(offset_raw, w, cosets, n, d, 0);
         if (rc) {
             (void)hipFree(d);
             return rc;
         }
         ctx->pow_tables[key] = d;
+        ctx->cached_pow_bytes += words * sizeof(u64);
         *out = d;
         return TF_OK;
     }
-    lk.unlock();
+    lk.unlock();  // a temporary is private to this call: build it without holding the device context
     hipError_t e = hipMallocAsync(reinterpret_cast<void**>(&d), words * sizeof(u64), stream);
     if (e != hipSuccess) return hip_fail(e, "hipMallocAsync(pow table)", __FILE__, __LINE__);
-    int rc = build_all(stream);
+    int rc = build_pow_tables(offset_raw, w, cosets, n, d, stream);
     if (rc) {
         (void)hipFreeAsync(d, stream);
         return rc;
@@ -709,6 +736,10 @@ int launch_pass(const Launch& l, bool inverse, hipStream_t stream) {
         return TF_ERR_HIP;
     }
     const int g_ablate = ablate_mode();
+    if (l.a.p2 == 5 && !l.a.inner_tw) {  // the R = 1024 instantiations run lazy networks and rely on the product that follows
+        t_last_error = "internal: R = 1024 pass without its inner twiddle table";
+        return TF_ERR_HIP;
+    }
     // the plain R = 1024 last-pass kernel: the only one that truncates its output and shifts its tiles
     const bool plain_last1024 = l.a.p2 == 5 && !l.a.post_tw && !l.a.gfast && !l.a.pre_scale && l.a.n_coeffs < 0 && !l.a.in2 &&
                                 (!l.a.post_scale || (inverse && scaled_last1024_enabled())) && last1024_enabled();
@@ -1032,19 +1063,59 @@ int run_ntt(DeviceCtx* ctx, const u64* in, u64* out, long long in_bs, long long 
     const size_t poly_bytes = n * cosets * size_t(L) * sizeof(u64);
     size_t tb = std::max<size_t>(1, g_tile_bytes / poly_bytes);
     tb = std::min(tb, batch);
+    // pipelined tiles (g_pipe): tile t runs on side stream t % K with scratch tile t % K; the caller's stream forks into
+    // the side streams before the first tile and joins them after the last (event edges only, no host synchronisation)
+    const size_t ntiles = (batch + tb - 1) / tb;
+    int K = (P < 4) ? (int)std::min<size_t>((size_t)g_pipe.load(std::memory_order_relaxed), ntiles) : 1;
+    hipStream_t side[kMaxPipe] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[kMaxPipe] = {nullptr, nullptr, nullptr, nullptr};
+    if (K > 1) {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        for (int i = 0; i < K; ++i) {
+            if (!ctx->side[i] && hipStreamCreateWithFlags(&ctx->side[i], hipStreamNonBlocking) != hipSuccess) {
+                (void)hipGetLastError();
+                ctx->side[i] = nullptr;
+                K = 1;  // no side streams: the plain one-stream plan
+                break;
+            }
+            side[i] = ctx->side[i];
+        }
+    }
     u64* scratch = nullptr;
     {
-        hipError_t e = hipMallocAsync(reinterpret_cast<void**>(&scratch), tb * poly_bytes, stream);
+        hipError_t e = hipMallocAsync(reinterpret_cast<void**>(&scratch), size_t(K) * tb * poly_bytes, stream);
         if (e != hipSuccess) {
             release_tables();
             return hip_fail(e, "hipMallocAsync(ntt scratch)", __FILE__, __LINE__);
         }
     }
+    if (K > 1) {
+        hipError_t e = hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming);
+        for (int i = 0; i < K && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&ev_join[i], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventRecord(ev_fork, stream);
+        for (int i = 0; i < K && e == hipSuccess; ++i) e = hipStreamWaitEvent(side[i], ev_fork, 0);
+        if (e != hipSuccess) {
+            // nothing has been enqueued on the side streams that touches the scratch: release and report
+            if (ev_fork) (void)hipEventDestroy(ev_fork);
+            for (int i = 0; i < K; ++i)
+                if (ev_join[i]) (void)hipEventDestroy(ev_join[i]);
+            (void)hipFreeAsync(scratch, stream);
+            release_tables();
+            return hip_fail(e, "fork into the tile streams", __FILE__, __LINE__);
+        }
+    }
+    hipStream_t const caller_stream = stream;
+    u64* const scratch_base = scratch;
     const long long sbs = (long long)(n * cosets) * L;  // scratch batch stride
     long long N[4];
     for (int i = 0; i < 4; ++i) N[i] = 1ll << a[i];
-    for (size_t b0 = 0; b0 < batch && rc == TF_OK; b0 += tb) {
+    size_t tile_no = 0;
+    for (size_t b0 = 0; b0 < batch && rc == TF_OK; b0 += tb, ++tile_no) {
         const size_t nb = std::min(tb, batch - b0);
+        if (K > 1) {
+            stream = side[tile_no % K];
+            scratch = scratch_base + (tile_no % K) * tb * (size_t)sbs;
+        }
         const u64* tin = in + (long long)b0 * in_bs;
         u64* tout = out + (long long)b0 * out_bs;
         // column passes: the first reads the caller's input, the last writes the scratch tile, the ones between work
@@ -1062,6 +1133,7 @@ int run_ntt(DeviceCtx* ctx, const u64* in, u64* out, long long in_bs, long long 
             Launch p = plan_column_pass(src, dst, src_bs, dst_bs, nb, (i == 0) ? (long long)cosets : outer, a[i], B, L);
             p.a.inner_tw = inner[i];
             p.a.post_tw = post[i];
+            if (i == 0 && src != dst) p.a.nt = g_nt.load(std::memory_order_relaxed) & 1;  // the caller's input is read once
             if (i == 0) {
                 p.a.pre_scale = pre_scale;
                 p.a.n_coeffs = n_coeffs;
@@ -1100,6 +1172,7 @@ int run_ntt(DeviceCtx* ctx, const u64* in, u64* out, long long in_bs, long long 
             pl.a.inner_tw = inner[P - 1];
             pl.a.post_scale = post_scale;
             pl.a.n_out = n_out;
+            pl.a.nt = g_nt.load(std::memory_order_relaxed) & 2;  // the result is written once
             if (plain1024 && pl.a.nc == 16 && !no_col_shift && (unsigned long long)n * L * sizeof(u64) < (1ull << 32)) {
                 // The R = 1024 last pass stores 128-byte segments of 16 adjacent output words.  When the output of batch entry
                 // b does not start on a cache line (a truncated product: stride n_out = na + nb - 1 words, or a caller's
@@ -1121,6 +1194,24 @@ int run_ntt(DeviceCtx* ctx, const u64* in, u64* out, long long in_bs, long long 
                 pl.a.post_scale = post_scale;
                 rc = launch_pass(pl, inverse, stream);
             }
+        }
+    }
+    stream = caller_stream;
+    scratch = scratch_base;
+    if (K > 1) {  // join: whatever was enqueued (also after a failed launch) finishes before the caller's stream goes on
+        hipError_t je = hipSuccess;
+        for (int i = 0; i < K; ++i) {
+            hipError_t e1 = hipEventRecord(ev_join[i], side[i]);
+            if (e1 == hipSuccess) e1 = hipStreamWaitEvent(stream, ev_join[i], 0);
+            if (e1 != hipSuccess) je = e1;
+        }
+        (void)hipEventDestroy(ev_fork);
+        for (int i = 0; i < K; ++i) (void)hipEventDestroy(ev_join[i]);
+        if (je != hipSuccess) {
+            (void)hipDeviceSynchronize();  // cannot order the free after the side streams any other way
+            (void)hipFreeAsync(scratch, stream);
+            release_tables();
+            return hip_fail(je, "join of the tile streams", __FILE__, __LINE__);
         }
     }
     hipError_t e = hipFreeAsync(scratch, stream);
@@ -1167,7 +1258,9 @@ int coset_eval_dev(const u64* d_coeffs, size_t n_coeffs, u64 offset_raw, u64* d_
     size_t len = 1;
     while (len < n_coeffs) len <<= 1;
     static const bool no_split = getenv("TF_COSET_EVAL_NO_SPLIT") != nullptr;  // A/B switch
-    if (!no_split && len > 1024 && len < order && order <= (size_t(1) << 30) && pass_count(ilog2(len)) < pass_count(ilog2(order))) {
+    // (at most kMaxCosetSplit cosets: one scale table of n_coeffs words per coset is built and, while it fits the budget, cached)
+    if (!no_split && len > 1024 && len < order && order / len <= kMaxCosetSplit && order <= (size_t(1) << 30) &&
+        pass_count(ilog2(len)) < pass_count(ilog2(order))) {
         const size_t cosets = order / len;
         rc = get_pow_table(ctx, offset_raw, n_coeffs, s, &pw, &temp, cosets, ilog2(order));
         if (rc) return rc;
@@ -1850,6 +1943,18 @@ size_t tf_get_ntt_tile_bytes(void) {
     read_env();
     return g_tile_bytes;
 }
+void tf_set_ntt_nt(int mask) {
+    read_env();
+    g_nt.store(mask & 3, std::memory_order_relaxed);
+}
+void tf_set_ntt_pipe(int streams) {
+    read_env();
+    g_pipe.store(std::min(std::max(streams, 1), kMaxPipe), std::memory_order_relaxed);
+}
+int tf_get_ntt_pipe(void) {
+    read_env();
+    return g_pipe.load(std::memory_order_relaxed);
+}
 
 // measurement helper (not part of the drop-in boundary): the shader clock the GPU is running at right now, from the ratio of
 // the shader-cycle counter to the constant-rate wall clock over a ~0.5 ms spin of one wave.  bench.py records it next to its
@@ -1866,6 +1971,20 @@ double tf_debug_sclk_mhz(void) {
     (void)hipFree(d);
     if (e != hipSuccess || h[1] == 0) return -1.0;
     return (double)h[0] / (double)h[1] * (double)wall_khz / 1000.0;
+}
+
+// synthetic-input helper (not part of the drop-in boundary): d_out[i] = new(splitmix64(seed ^ (first_index + i)) mod p)
+int tf_debug_fill_random_dev(uint64_t* d_out, size_t count, uint64_t seed, uint64_t first_index, void* stream) {
+    if (count == 0) return TF_OK;
+    if (!d_out) return TF_ERR_NULL_POINTER;
+    DeviceCtx* ctx = nullptr;
+    int rc = current_ctx(&ctx);
+    if (rc) return rc;
+    const unsigned blocks = (unsigned)std::min<size_t>((count + 255) / 256, size_t(1) << 20);
+    hipLaunchKernelGGL(tfk::fill_random_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), d_out,
+                       (unsigned long long)count, (u64)seed, (unsigned long long)first_index);
+    HIPCHK(hipGetLastError());
+    return TF_OK;
 }
 
 // measurement helper (not part of the drop-in boundary): allocate / fetch the MODE-3 stamp buffer
@@ -2187,8 +2306,9 @@ int tf_merkle_auth_structure_indices(size_t num_leafs, const uint64_t* leaf_indi
     std::vector<unsigned long long> idx;
     TRY(auth_structure_indices(num_leafs, leaf_indices, k, &idx));
     *out_count = idx.size();
-    if (out_indices)
-        for (size_t i = 0; i < idx.size() && i < capacity; ++i) out_indices[i] = idx[i];
+    if (!out_indices || capacity == 0) return TF_OK;  // sizing call: only the count
+    if (capacity < idx.size()) return TF_ERR_BUFFER_TOO_SMALL;  // nothing is written; *out_count says what is needed
+    for (size_t i = 0; i < idx.size(); ++i) out_indices[i] = idx[i];
     return TF_OK;
 }
 

@@ -36,9 +36,30 @@ def _p(t):
     return C.c_void_p(t.data_ptr())
 
 
+def _need(cond: bool, what: str) -> None:
+    """Every wrapper checks its tensors against (n, batch, width) BEFORE the C ABI sees a raw pointer: a wrong size is a
+    ValueError here, never an out-of-bounds HBM access there."""
+    if not cond:
+        raise ValueError(what)
+
+
+def _width(width: int) -> int:
+    _need(width in (1, 3), "width must be 1 (BFieldElement) or 3 (XFieldElement)")
+    return width
+
+
+def fill_random(out, seed: int, first_index: int = 0, stream=None) -> None:
+    """Synthetic inputs (SURVEY.md 8(d)): out[i] = BFieldElement::new(splitmix64(seed ^ (first_index + i)) mod p), generated on
+    the device; the oracle's tfo.fill_random(count, seed) is the same sequence."""
+    out = _t(out, "out")
+    _chk(_lib.lib().tf_debug_fill_random_dev(_p(out), out.numel(), C.c_uint64(seed & (2 ** 64 - 1)), C.c_uint64(first_index),
+                                             _stream(stream)), "fill_random")
+
+
 def ntt_(x, n: int, batch: int = 1, width: int = 1, inverse: bool = False, stream=None) -> None:
     """In place on device: `batch` slices of n elements (math/ntt.rs:67-82, :109-125)."""
     x = _t(x, "x")
+    _width(width)
     if x.numel() != n * batch * width:
         raise ValueError("tensor size is not batch * n * width")
     fn = _lib.lib().tf_ntt_bfe_dev if width == 1 else _lib.lib().tf_ntt_xfe_dev
@@ -48,6 +69,7 @@ def ntt_(x, n: int, batch: int = 1, width: int = 1, inverse: bool = False, strea
 def coset_evaluate(coeffs, n_coeffs: int, offset_raw: int, out, order: int, batch: int = 1, width: int = 1, stream=None) -> None:
     """math/polynomial.rs:1374-1399 on device buffers (out: batch * order * width words)."""
     coeffs, out = _t(coeffs, "coeffs"), _t(out, "out")
+    _width(width)
     if coeffs.numel() != n_coeffs * batch * width or out.numel() != order * batch * width:
         raise ValueError("buffer sizes do not match n_coeffs/order/batch/width")
     fn = _lib.lib().tf_coset_eval_bfe_dev if width == 1 else _lib.lib().tf_coset_eval_xfe_dev
@@ -56,11 +78,13 @@ def coset_evaluate(coeffs, n_coeffs: int, offset_raw: int, out, order: int, batc
 
 def tip5_permute_(states, stream=None) -> None:
     states = _t(states, "states")
+    _need(states.numel() % 16 == 0, "states must hold 16 words per Tip5 state")
     _chk(_lib.lib().tf_tip5_permute_dev(_p(states), states.numel() // 16, _stream(stream)), "Tip5::permutation")
 
 
 def tip5_hash_pairs(inp, out, stream=None) -> None:
     inp, out = _t(inp, "in"), _t(out, "out")
+    _need(inp.numel() % 10 == 0, "in must hold 10 words per pair of digests")
     count = inp.numel() // 10
     if out.numel() != count * 5:
         raise ValueError("out must hold 5 words per input pair")
@@ -69,7 +93,9 @@ def tip5_hash_pairs(inp, out, stream=None) -> None:
 
 def tip5_hash_varlen_rows(rows, row_len: int, out, stream=None) -> None:
     rows, out = _t(rows, "rows"), _t(out, "out")
+    _need(out.numel() % 5 == 0, "out must hold 5 words per row")
     n_rows = out.numel() // 5
+    _need(row_len >= 0 and rows.numel() == n_rows * row_len, "rows must hold n_rows * row_len words (n_rows = out.numel() / 5)")
     _chk(_lib.lib().tf_tip5_hash_varlen_rows_dev(_p(rows), row_len, n_rows, _p(out), _stream(stream)), "Tip5::hash_varlen")
 
 
@@ -83,6 +109,7 @@ def merkle_build(leaves, n_leaves: int, nodes_out, batch: int = 1, stream=None) 
 
 def merkle_root(leaves, n_leaves: int, root_out, batch: int = 1, stream=None) -> None:
     leaves, root_out = _t(leaves, "leaves"), _t(root_out, "root_out")
+    _need(leaves.numel() == batch * n_leaves * 5 and root_out.numel() == batch * 5, "buffer sizes do not match n_leaves/batch")
     _chk(_lib.lib().tf_merkle_root_dev(_p(leaves), n_leaves, _p(root_out), batch, _stream(stream)), "MerkleTree::par_frugal_root")
 
 
@@ -91,6 +118,8 @@ def merkle_root(leaves, n_leaves: int, root_out, batch: int = 1, stream=None) ->
 def coset_interpolate(values, n: int, offset_raw: int, out, batch: int = 1, width: int = 1, stream=None) -> None:
     """math/polynomial.rs:1907-1918 on device buffers (out: batch * n * width words; may alias values)."""
     values, out = _t(values, "values"), _t(out, "out")
+    _width(width)
+    _need(values.numel() == n * batch * width and out.numel() == n * batch * width, "buffer sizes do not match n/batch/width")
     fn = _lib.lib().tf_coset_interpolate_bfe_dev if width == 1 else _lib.lib().tf_coset_interpolate_xfe_dev
     _chk(fn(_p(values), n, C.c_uint64(offset_raw), _p(out), batch, _stream(stream)), "fast_coset_interpolate")
 
@@ -98,6 +127,8 @@ def coset_interpolate(values, n: int, offset_raw: int, out, batch: int = 1, widt
 def hadamard(a, b, out, width: int = 1, stream=None) -> None:
     """Pointwise field product (math/polynomial.rs:920-925); out may alias a or b."""
     a, b, out = _t(a, "a"), _t(b, "b"), _t(out, "out")
+    _width(width)
+    _need(a.numel() % width == 0 and b.numel() == a.numel() and out.numel() == a.numel(), "a, b and out must hold the same number of elements")
     fn = _lib.lib().tf_hadamard_bfe_dev if width == 1 else _lib.lib().tf_hadamard_xfe_dev
     _chk(fn(_p(a), _p(b), _p(out), a.numel() // width, _stream(stream)), "hadamard")
 
@@ -105,6 +136,9 @@ def hadamard(a, b, out, width: int = 1, stream=None) -> None:
 def poly_mul(a, na: int, b, nb: int, out, batch: int = 1, width: int = 1, stream=None) -> None:
     """Polynomial::fast_multiply on device (math/polynomial.rs:900-932): out = batch x (na + nb - 1) coefficients."""
     a, b, out = _t(a, "a"), _t(b, "b"), _t(out, "out")
+    _width(width)
+    _need(a.numel() == na * batch * width and b.numel() == nb * batch * width, "operand sizes do not match na/nb/batch/width")
+    _need(not (na and nb) or out.numel() == (na + nb - 1) * batch * width, "out must hold batch * (na + nb - 1) coefficients")
     fn = _lib.lib().tf_poly_mul_bfe_dev if width == 1 else _lib.lib().tf_poly_mul_xfe_dev
     _chk(fn(_p(a), na, _p(b), nb, _p(out), batch, _stream(stream)), "fast_multiply")
 
@@ -112,6 +146,8 @@ def poly_mul(a, na: int, b, nb: int, out, batch: int = 1, width: int = 1, stream
 def lde(values, n: int, offset_in_raw: int, out, m: int, offset_out_raw: int, batch: int = 1, width: int = 1, stream=None) -> None:
     """Low-degree extension: interpolate on {offset_in w_n^i}, evaluate on {offset_out w_m^i}; coefficients stay in HBM."""
     values, out = _t(values, "values"), _t(out, "out")
+    _width(width)
+    _need(values.numel() == n * batch * width and out.numel() == m * batch * width, "buffer sizes do not match n/m/batch/width")
     fn = _lib.lib().tf_lde_bfe_dev if width == 1 else _lib.lib().tf_lde_xfe_dev
     _chk(fn(_p(values), n, C.c_uint64(offset_in_raw), _p(out), m, C.c_uint64(offset_out_raw), batch, _stream(stream)), "lde")
 
@@ -119,6 +155,7 @@ def lde(values, n: int, offset_in_raw: int, out, m: int, offset_out_raw: int, ba
 def merkle_from_rows(rows, row_len: int, n_rows: int, nodes_out, batch: int = 1, stream=None) -> None:
     """hash_varlen of every row -> leaf level -> tree, without the leaves leaving HBM."""
     rows, nodes_out = _t(rows, "rows"), _t(nodes_out, "nodes_out")
+    _need(rows.numel() == batch * n_rows * row_len and nodes_out.numel() == batch * n_rows * 10, "buffer sizes do not match row_len/n_rows/batch")
     _chk(_lib.lib().tf_merkle_from_rows_dev(_p(rows), row_len, n_rows, _p(nodes_out), batch, _stream(stream)), "MerkleTree::par_new")
 
 
@@ -127,6 +164,7 @@ def authentication_structure(nodes, num_leafs: int, leaf_indices):
     import numpy as np
 
     nodes = _t(nodes, "nodes")
+    _need(nodes.numel() == num_leafs * 10, "nodes must hold 2 * num_leafs digests")
     li = np.ascontiguousarray(leaf_indices, dtype=np.uint64).reshape(-1)
     cap = max(1, li.size * 66)
     out = np.empty(cap * 5, dtype=np.uint64)
@@ -160,12 +198,20 @@ def coset_extrapolate(offset_raw: int, codewords, n: int, points, out, batch: in
 def hash_table_rows(table, n_rows: int, n_cols: int, out, width: int = 1, col_stride=None, batch: int = 1, stream=None) -> None:
     """hash_varlen of every row of `batch` column-major tables resident in HBM (column j at table + j * col_stride words)."""
     table, out = _t(table, "table"), _t(out, "out")
+    _width(width)
     cs = n_rows * width if col_stride is None else col_stride
+    _need(cs >= n_rows * width, "col_stride must be at least n_rows * width words")
+    _need(table.numel() >= ((batch * n_cols - 1) * cs + n_rows * width if batch * n_cols else 0), "table is smaller than batch * n_cols columns")
+    _need(out.numel() == batch * n_rows * 5, "out must hold 5 words per row and table")
     _chk(_lib.lib().tf_tip5_hash_table_rows_dev(_p(table), n_rows, n_cols, width, cs, _p(out), batch, _stream(stream)), "Tip5::hash_varlen")
 
 
 def merkle_from_columns(table, n_rows: int, n_cols: int, nodes_out, width: int = 1, col_stride=None, batch: int = 1, stream=None) -> None:
     """Rows of column-major tables -> leaves -> trees (nodes_out: batch x 2 n_rows digests), all in HBM."""
     table, nodes_out = _t(table, "table"), _t(nodes_out, "nodes_out")
+    _width(width)
     cs = n_rows * width if col_stride is None else col_stride
+    _need(cs >= n_rows * width, "col_stride must be at least n_rows * width words")
+    _need(table.numel() >= ((batch * n_cols - 1) * cs + n_rows * width if batch * n_cols else 0), "table is smaller than batch * n_cols columns")
+    _need(nodes_out.numel() == batch * n_rows * 10, "nodes_out must hold batch x 2 n_rows digests")
     _chk(_lib.lib().tf_merkle_from_columns_dev(_p(table), n_rows, n_cols, width, cs, _p(nodes_out), batch, _stream(stream)), "MerkleTree::par_new")

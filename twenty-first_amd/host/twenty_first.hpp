@@ -80,7 +80,9 @@ static_assert(sizeof(Digest) == 40, "layout contract of the C ABI");
 struct BackendError : std::runtime_error {
     int code;
     BackendError(int c, const std::string& where)
-        : std::runtime_error(where + ": " + tf_status_string(c) + (c >= TF_ERR_NO_DEVICE ? std::string(" (") + tf_last_error() + ")" : "")), code(c) {}
+        : std::runtime_error(where + ": " + tf_status_string(c) +
+                             ((c >= TF_ERR_NO_DEVICE && c <= TF_ERR_OUT_OF_MEMORY) ? std::string(" (") + tf_last_error() + ")" : "")),
+          code(c) {}  // tf_last_error() belongs to the HIP failures (codes 8..10) only
 };
 // where the reference panics (math/ntt.rs:135-140, math/polynomial.rs:1388-1392)
 struct NttPanic : BackendError {
@@ -88,14 +90,14 @@ struct NttPanic : BackendError {
 };
 // util_types/merkle_tree.rs:933-965
 struct MerkleTreeError : BackendError {
-    enum Variant { TooFewLeafs = 1, IncorrectNumberOfLeafs = 2, TreeTooHigh = 3 } variant;
+    enum Variant { TooFewLeafs = 1, IncorrectNumberOfLeafs = 2, TreeTooHigh = 3, LeafIndexInvalid = 11 } variant;
     MerkleTreeError(int c, const std::string& where) : BackendError(c, where), variant((Variant)c) {}
 };
 
 inline void check(int rc, const char* where) {
     if (rc == TF_OK) return;
-    if (rc >= 1 && rc <= 3) throw MerkleTreeError(rc, where);
-    if (rc >= 4 && rc <= 6) throw NttPanic(rc, where);
+    if ((rc >= 1 && rc <= 3) || rc == TF_ERR_LEAF_INDEX_INVALID) throw MerkleTreeError(rc, where);  // merkle_tree.rs:933-965
+    if ((rc >= 4 && rc <= 6) || rc == TF_ERR_INVERSE_OF_ZERO) throw NttPanic(rc, where);            // the reference panics here
     throw BackendError(rc, where);
 }
 
