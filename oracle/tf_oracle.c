@@ -461,25 +461,150 @@ static inline void sbox_layer(u64 s[STATE_SIZE]) {
     }
 }
 
-/* :210-253.  The reference splits every raw word into 32-bit halves, runs
- * `generated_function` (:256-506) on each half-vector -- which computes exactly
- * 16 * sum_c M[(r-c) mod 16] * v[c] without wrapping (the true sum is < 2^52) -- and
- * recombines s = (lo >> 4) + (hi << 28) as u128.  That s is the plain integer
- * sum_c M[(r-c) mod 16] * raw[c]; we form it directly and then follow :244-252 literally,
- * including the possibly-degenerate (>= p) result. */
-static inline void mds(u64 s[STATE_SIZE]) {
+/* ---- the MDS layer, three ways ---------------------------------------------------------------------------------------
+ * (0) mds_plain:     the integer circulant sum  s_r = sum_c M[(r - c) mod 16] * raw[c]  formed directly in 128 bits, then the
+ *                    reduction of :244-252 (the round-1 form; it is also the shortcut the GPU kernel takes).
+ * (1) mds_cyclomul:  restatement of the reference's own second method, Tip5::mds_cyclomul + fast_cyclomul16/8/4/2,
+ *                    complex_negacyclomul8/4/2, complex_karatsuba4/2 (tip5/mod.rs:753-1019): cyclic convolution of the 32-bit
+ *                    halves with the MDS column over Z by the CRT split x^n - 1 = (x^(n/2) - 1)(x^(n/2) + 1), the negacyclic
+ *                    half as a product in Z[i][x] by Karatsuba; recombination and reduction as :766-777.
+ * (2) mds_generated: the shape of Tip5::mds_generated + generated_function (:210-506) -- the same CRT/Karatsuba graph with the
+ *                    MDS column as the constant operand, every halving deferred (so the graph returns 16 x the convolution),
+ *                    all arithmetic WRAPPING on u64 exactly as the reference's wrapping_add / wrapping_sub / wrapping_mul,
+ *                    recombined as s = (lo >> 4) + (hi << 28) and reduced as :244-252 (including the possibly degenerate
+ *                    result >= p that the round-constant addition repairs).  The reference's 250-line node list is that graph
+ *                    unrolled with its constants folded; the constants it hard-codes for the fully split components,
+ *                    524757 = sum M_i and 52427 = sum (-1)^i M_i (node_64 / node_67, :283-284), are asserted in
+ *                    tests/test_oracle_kat.py against the graph below.
+ * tfo_tip5_permutation runs (2); tests/test_oracle_kat.py restates the reference's differential
+ * test_mds_matrix_mul_methods_agree (:1509-1523) over all three on random and on degenerate (>= p) words. */
+typedef int64_t i64;
+
+static inline void mds_reduce_store(u128 acc, u64 *out) { /* :244-252 */
+    u64 s_hi = (u64)(acc >> 64);
+    u64 s_lo = (u64)acc;
+    u64 add = s_hi * 0xffffffffULL;
+    u64 res = s_lo + add;
+    int over = res < s_lo;
+    *out = over ? res + 0xffffffffULL : res;
+}
+
+static inline void mds_plain(u64 s[STATE_SIZE]) {
     u64 out[STATE_SIZE];
     for (int r = 0; r < STATE_SIZE; r++) {
         u128 acc = 0;
         for (int c = 0; c < STATE_SIZE; c++) acc += (u128)MDS_MATRIX_FIRST_COLUMN[(STATE_SIZE + r - c) % STATE_SIZE] * s[c];
-        u64 s_hi = (u64)(acc >> 64);
-        u64 s_lo = (u64)acc;
-        u64 add = s_hi * 0xffffffffULL;
-        u64 res = s_lo + add;
-        int over = res < s_lo;
-        out[r] = over ? res + 0xffffffffULL : res;
+        mds_reduce_store(acc, &out[r]);
     }
     memcpy(s, out, sizeof(out));
+}
+
+/* Z[i] pairs (re, im); generic over the word type so that (1) runs on i64 and (2) on wrapping u64 */
+#define CYCLO_IMPL(T, SUF)                                                                                                  \
+    static void complex_karatsuba_##SUF(int n, const T (*f)[2], const T (*g)[2], T (*out)[2]) { /* :941-997; out: 2n-1 */   \
+        if (n == 1) { /* complex_product :999-1002 */                                                                      \
+            out[0][0] = f[0][0] * g[0][0] - f[0][1] * g[0][1];                                                              \
+            out[0][1] = f[0][0] * g[0][1] + f[0][1] * g[0][0];                                                              \
+            return;                                                                                                         \
+        }                                                                                                                   \
+        const int h = n / 2;                                                                                                \
+        T ff[4][2], gg[4][2], lo[7][2], hi[7][2], mid[7][2];                                                                \
+        for (int i = 0; i < h; i++)                                                                                         \
+            for (int k = 0; k < 2; k++) ff[i][k] = f[i][k] + f[h + i][k], gg[i][k] = g[i][k] + g[h + i][k];                 \
+        complex_karatsuba_##SUF(h, f, g, lo);                                                                               \
+        complex_karatsuba_##SUF(h, f + h, g + h, hi);                                                                       \
+        complex_karatsuba_##SUF(h, ff, gg, mid);                                                                            \
+        for (int i = 0; i < 2 * n - 1; i++) out[i][0] = out[i][1] = 0;                                                      \
+        for (int i = 0; i < 2 * h - 1; i++)                                                                                 \
+            for (int k = 0; k < 2; k++) {                                                                                   \
+                out[i][k] += lo[i][k];                                                                                      \
+                out[h + i][k] += mid[i][k] - (lo[i][k] + hi[i][k]);                                                         \
+                out[2 * h + i][k] += hi[i][k];                                                                              \
+            }                                                                                                               \
+    }                                                                                                                       \
+    /* f * g mod x^n + 1 (n = 2N): x^N acts as i on the pairs (f_j, -f_{N+j}) :871-939 */                                  \
+    static void complex_negacyclomul_##SUF(int n, const T *f, const T *g, T *out) {                                        \
+        const int N = n / 2;                                                                                                \
+        T f0[4][2], g0[4][2], h0[7][2], h[12];                                                                              \
+        for (int i = 0; i < N; i++) f0[i][0] = f[i], f0[i][1] = (T)0 - f[N + i], g0[i][0] = g[i], g0[i][1] = (T)0 - g[N + i]; \
+        complex_karatsuba_##SUF(N, f0, g0, h0);                                                                             \
+        for (int i = 0; i < 3 * N; i++) h[i] = 0;                                                                           \
+        for (int i = 0; i < 2 * N - 1; i++) h[i] += h0[i][0], h[i + N] -= h0[i][1];                                         \
+        for (int i = 0; i < 2 * N; i++) out[i] = h[i];                                                                      \
+        for (int i = 2 * N; i < 3 * N - 1; i++) out[i - 2 * N] -= h[i];                                                     \
+    }                                                                                                                       \
+    /* f * g mod x^n - 1 :780-869.  halve: the reference's ">> 1" after every recombination (exact: the sums are even).     \
+     * !halve: every halving deferred -- the hi branch is scaled by n/2 instead, the result is n x the convolution. */      \
+    static void fast_cyclomul_##SUF(int n, const T *f, const T *g, T *out, int halve) {                                     \
+        if (n == 1) {                                                                                                       \
+            out[0] = f[0] * g[0];                                                                                           \
+            return;                                                                                                         \
+        }                                                                                                                   \
+        const int N = n / 2;                                                                                                \
+        T ff_lo[8], gg_lo[8], ff_hi[8], gg_hi[8], hh_lo[8], hh_hi[8];                                                       \
+        for (int i = 0; i < N; i++) {                                                                                       \
+            ff_lo[i] = f[i] + f[i + N], ff_hi[i] = f[i] - f[i + N];                                                         \
+            gg_lo[i] = g[i] + g[i + N], gg_hi[i] = g[i] - g[i + N];                                                         \
+        }                                                                                                                   \
+        fast_cyclomul_##SUF(N, ff_lo, gg_lo, hh_lo, halve);                                                                 \
+        if (N == 1) hh_hi[0] = ff_hi[0] * gg_hi[0]; /* fast_cyclomul2 :855-869 */                                          \
+        else complex_negacyclomul_##SUF(N, ff_hi, gg_hi, hh_hi);                                                            \
+        for (int i = 0; i < N; i++) {                                                                                       \
+            if (halve) {                                                                                                    \
+                out[i] = (T)((i64)(hh_lo[i] + hh_hi[i]) >> 1);                                                              \
+                out[i + N] = (T)((i64)(hh_lo[i] - hh_hi[i]) >> 1);                                                          \
+            } else {                                                                                                        \
+                out[i] = hh_lo[i] + (T)N * hh_hi[i];                                                                        \
+                out[i + N] = hh_lo[i] - (T)N * hh_hi[i];                                                                    \
+            }                                                                                                               \
+        }                                                                                                                   \
+    }
+CYCLO_IMPL(i64, s)
+CYCLO_IMPL(u64, w)
+
+static inline void mds_cyclomul(u64 s[STATE_SIZE]) { /* :753-778 */
+    i64 lo[STATE_SIZE], hi[STATE_SIZE], m[STATE_SIZE], rl[STATE_SIZE], rh[STATE_SIZE];
+    for (int i = 0; i < STATE_SIZE; i++) hi[i] = (i64)(s[i] >> 32), lo[i] = (i64)(s[i] & 0xffffffffULL), m[i] = MDS_MATRIX_FIRST_COLUMN[i];
+    fast_cyclomul_s(STATE_SIZE, lo, m, rl, 1);
+    fast_cyclomul_s(STATE_SIZE, hi, m, rh, 1);
+    for (int r = 0; r < STATE_SIZE; r++) {
+        u128 acc = (u128)(u64)rl[r] + ((u128)(u64)rh[r] << 32);
+        u64 s_hi = (u64)(acc >> 64), s_lo = (u64)acc;
+        u64 z = (s_hi << 32) - s_hi;
+        u64 res = s_lo + z;
+        int over = res < s_lo;
+        s[r] = res + (u64)(uint32_t)(0u - (uint32_t)over);
+    }
+}
+
+static inline void mds_generated(u64 s[STATE_SIZE]) { /* :210-253 over the graph of :256-506 */
+    u64 lo[STATE_SIZE], hi[STATE_SIZE], m[STATE_SIZE], rl[STATE_SIZE], rh[STATE_SIZE];
+    for (int i = 0; i < STATE_SIZE; i++) hi[i] = s[i] >> 32, lo[i] = s[i] & 0xffffffffULL, m[i] = (u64)MDS_MATRIX_FIRST_COLUMN[i];
+    fast_cyclomul_w(STATE_SIZE, lo, m, rl, 0);  /* = 16 x the convolution, wrapping u64 */
+    fast_cyclomul_w(STATE_SIZE, hi, m, rh, 0);
+    for (int r = 0; r < STATE_SIZE; r++) mds_reduce_store((u128)(rl[r] >> 4) + ((u128)rh[r] << 28), &s[r]);
+}
+
+static inline void mds(u64 s[STATE_SIZE]) { mds_generated(s); }
+
+/* test entry: one MDS layer by method 0 / 1 / 2 (see above) */
+void tfo_tip5_mds(uint64_t s[16], int method) {
+    if (method == 0) mds_plain(s);
+    else if (method == 1) mds_cyclomul(s);
+    else mds_generated(s);
+}
+
+/* test entry: the graph's fully split constants: out[0] = multiplier of (sum of the inputs) in output 0 of the deferred graph,
+ * out[1] = that of the alternating sum -- the reference's node_64 / node_67 literals 524757 and 52427 (:283-284) */
+void tfo_tip5_mds_graph_constants(uint64_t out[2]) {
+    u64 f[STATE_SIZE], m[STATE_SIZE], r[STATE_SIZE];
+    for (int i = 0; i < STATE_SIZE; i++) m[i] = (u64)MDS_MATRIX_FIRST_COLUMN[i];
+    for (int i = 0; i < STATE_SIZE; i++) f[i] = 1;  /* only the x - 1 component is non-zero: every output = sum f * sum M */
+    fast_cyclomul_w(STATE_SIZE, f, m, r, 0);
+    out[0] = r[0] / STATE_SIZE;  /* 16 x (16 * sum M) / 16 ... the graph returns 16 x convolution = 16 * 16 * sum M / 16 */
+    for (int i = 0; i < STATE_SIZE; i++) f[i] = (i & 1) ? (u64)0 - 1 : 1;  /* only the x + 1 component */
+    fast_cyclomul_w(STATE_SIZE, f, m, r, 0);
+    out[1] = r[0] / STATE_SIZE;
 }
 
 /* :175-181 */

@@ -65,6 +65,8 @@ def lib() -> C.CDLL:
             "tfo_poly_eval": (None, [pu, sz, i32, u64, pu]),
             "tfo_tip5_permutation": (None, [pu]),
             "tfo_tip5_permutation_naive": (None, [pu]),
+            "tfo_tip5_mds": (None, [pu, i32]),
+            "tfo_tip5_mds_graph_constants": (None, [pu]),
             "tfo_tip5_hash_10": (None, [pu, pu]),
             "tfo_tip5_hash_pair": (None, [pu, pu, pu]),
             "tfo_tip5_hash_varlen": (None, [pu, sz, pu]),
@@ -245,6 +247,20 @@ def tip5_permutation(state, naive: bool = False) -> np.ndarray:
     s = _arr(state, 16).copy()
     (lib().tfo_tip5_permutation_naive if naive else lib().tfo_tip5_permutation)(_p(s))
     return s
+
+
+def tip5_mds(state, method: int) -> np.ndarray:
+    """One MDS layer on 16 raw words.  method 0: plain circulant sum; 1: Tip5::mds_cyclomul restatement (tip5/mod.rs:753-1019);
+    2: the shape of mds_generated / generated_function (:210-506) -- what tfo_tip5_permutation runs."""
+    s = _arr(state, 16).copy()
+    lib().tfo_tip5_mds(_p(s), method)
+    return s
+
+
+def tip5_mds_graph_constants():
+    out = np.zeros(2, dtype=np.uint64)
+    lib().tfo_tip5_mds_graph_constants(_p(out))
+    return int(out[0]), int(out[1])
 
 
 def hash_10(inp) -> np.ndarray:

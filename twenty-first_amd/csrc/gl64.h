@@ -240,7 +240,15 @@ GL_HD u64 mont_mul(u64 a, u64 b) {
 //   Montgomery reduction of (h1:h0:l1:p0l) as in montyred, the final "+ p" done as  r0 += c, r1 -= c & ~carry.
 // The two carry chains are interleaved (one on vcc, one on an SGPR pair) so that, with one s_nop per step, every
 // carry is read at least two wait states after it was written.
+#ifndef TF_MONT_CC
+#define TF_MONT_CC 0  // 1 (A/B build): the compiler's 18-instruction product instead of the hand-scheduled pair
+#endif
 __device__ __forceinline__ void mont_mul2(u64 a, u64 b, u64 c, u64 d, u64& ab, u64& cd) {
+#if TF_MONT_CC
+    ab = mont_mul(a, b);
+    cd = mont_mul(c, d);
+    return;
+#endif
     const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
     const u32 c0 = (u32)c, c1 = (u32)(c >> 32), d0 = (u32)d, d1 = (u32)(d >> 32);
     const u64 xp = (u64)a0 * b0, xq = (u64)a1 * b0, xh = (u64)a1 * b1;

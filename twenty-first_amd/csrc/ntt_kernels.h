@@ -82,6 +82,28 @@ struct NttPassArgs {
     unsigned long long* dbg;                 // MODE 3 only: per-wave cycle stamps (6 per wave)
 };
 
+// ---- buffer addressing for the R = 1024 instantiations --------------------------------------------------------------------
+// A global_load/store takes ONE 64-bit address per lane; with 32 row slots per thread the compiler keeps 32 uniform bases and
+// forms every address with a 64-bit VALU add (v_lshl_add_u64 / v_mad_u64_u32: ~100 VALU instructions per burst, 7 % of a pass).
+// A buffer instruction adds  resource base (4 SGPRs, per workgroup) + 32-bit per-lane offset (ONE VGPR for all slots) + 32-bit
+// uniform offset (one SGPR per slot)  in the address unit: no VALU work at all.  The planner only selects these instantiations
+// when every slot offset plus thread offset fits 32 bits (fits_buffer_offsets in tf_hip.hip); larger transforms take the
+// generic kernel with plain pointers.
+typedef unsigned int tf_v2u __attribute__((__vector_size__(2 * sizeof(unsigned int))));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t buf_rsrc(const void* p) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, -1, 0x00020000);  // raw buffer, 4 GiB window, no swizzle
+}
+__device__ __forceinline__ u64 buf_load(__amdgpu_buffer_rsrc_t r, u32 voff, u32 soff) {
+    const tf_v2u v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+    return ((u64)v[1] << 32) | v[0];
+}
+__device__ __forceinline__ void buf_store(__amdgpu_buffer_rsrc_t r, u32 voff, u32 soff, u64 x) {
+    tf_v2u v;
+    v[0] = (u32)x;
+    v[1] = (u32)(x >> 32);
+    __builtin_amdgcn_raw_buffer_store_b64(v, r, voff, soff, 0);
+}
+
 // ---- radix-2^k DIT network with power-of-two twiddles --------------------------------------
 // w_{2^l} = 2^(39 * 2^(6-l))  (b_field_element.rs:46-51: w_64 = 2^39, ..., w_2 = 2^96 = -1), order 192.
 template <bool INV, int LVL, int J>
@@ -93,6 +115,18 @@ struct TwExp {
 #ifndef TF_ASM_BFLY
 #define TF_ASM_BFLY 1  // 0: the compiler's compare-and-select add/sub (12 VALU per butterfly instead of 10)
 #endif
+#ifndef TF_LDS_TW
+#define TF_LDS_TW 1  // the R = 1024 instantiations stage their [32][32] inner twiddle table in LDS (0: per-thread global loads, A/B build)
+#endif
+// The inner table w_R^(g k1) is read by row g: 32 words = 256 contiguous bytes per THREAD, i.e. a wave-load touches up to 64
+// different cache lines.  Through global memory those 16 dwordx4 loads per thread compete with the data stream for the
+// texture-addresser / L1 path (measured: 2.148 -> 2.081 ms per 256 x 2^20 with the column pass alone reading it from LDS,
+// profiles/r02b_ab_variants.txt); staged once per workgroup behind the exchange buffer, rows padded to 34 words (272 bytes:
+// 16-byte aligned for ds_read_b128, consecutive rows 4 banks apart), the reads are conflict-free LDS traffic.
+constexpr int kLdsTwStride = 34;
+// LAST1024 exchange layout: element (k1, g, cc) at k1 * kL1024S1 + cc * kL1024CS + g  (see the kernel)
+constexpr int kL1024S1 = 273, kL1024CS = 34;
+constexpr int kL1024ExchangeWords = ((31 * kL1024S1 + 7 * kL1024CS + 32 + 1) / 2) * 2;  // 16-byte aligned end
 #ifndef TF_LAZY
 #define TF_LAZY 1  // 0: every network canonical (A/B build); 1: lazy butterflies in the networks that are followed by a Montgomery product
 #endif
@@ -196,6 +230,7 @@ __device__ __forceinline__ void tail_p5(u64 (&x)[32], bool act, char* obase, u32
                                         const char* sbase = nullptr, u32 soff = 0, long long s_rs_bytes = 0, bool nt = false) {
     DitRange<INV, 5, Q0, Q0 + 4, false>::run(x);  // canonical: these words are stored
     if (act) {
+        const __amdgpu_buffer_rsrc_t ro = buf_rsrc(obase);  // LAST1024 only: the planner checked that the offsets fit (see buf_load)
         if constexpr (SCALED) {
             u64 w[8];
 #pragma unroll
@@ -206,19 +241,11 @@ __device__ __forceinline__ void tail_p5(u64 (&x)[32], bool act, char* obase, u32
 #pragma unroll
             for (int i = 0; i < 4; ++i) gl::mont_mul2(x[Q0 + i], w[i], x[Q0 + i + 16], w[4 + i], x[Q0 + i], x[Q0 + i + 16]);
         }
-        if (!TRUNC && !SCALED && nt) {
+        (void)nt;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                __builtin_nontemporal_store(x[Q0 + i], reinterpret_cast<u64*>(obase + (long long)(32 * (Q0 + i)) * out_rs_bytes + toff));
-                __builtin_nontemporal_store(x[Q0 + i + 16], reinterpret_cast<u64*>(obase + (long long)(32 * (Q0 + i + 16)) * out_rs_bytes + toff));
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                if (!TRUNC || Q0 + i < qlim) *reinterpret_cast<u64*>(obase + (long long)(32 * (Q0 + i)) * out_rs_bytes + toff) = x[Q0 + i];
-                if (!TRUNC || Q0 + i + 16 < qlim)
-                    *reinterpret_cast<u64*>(obase + (long long)(32 * (Q0 + i + 16)) * out_rs_bytes + toff) = x[Q0 + i + 16];
-            }
+        for (int i = 0; i < 4; ++i) {
+            if (!TRUNC || Q0 + i < qlim) buf_store(ro, toff, (u32)((long long)(32 * (Q0 + i)) * out_rs_bytes), x[Q0 + i]);
+            if (!TRUNC || Q0 + i + 16 < qlim) buf_store(ro, toff, (u32)((long long)(32 * (Q0 + i + 16)) * out_rs_bytes), x[Q0 + i + 16]);
         }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -347,6 +374,12 @@ __global__ void __launch_bounds__(512, TF_NTT_WAVES) ntt_pass_kernel(const NttPa
     u64 x[32];
 #pragma unroll
     for (int q = 0; q < 32; ++q) x[q] = 0;
+    constexpr bool LDS_TW = TF_LDS_TW && (R1024 || LAST1024) && MODE == 0;
+    u64* const ltw = lds + (LAST1024 ? kL1024ExchangeWords : 32 * A.s1);  // the staged inner table, behind the exchange buffer
+    if constexpr (LDS_TW) {
+        for (int i = t; i < 1024; i += blockDim.x) ltw[(i >> 5) * kLdsTwStride + (i & 31)] = A.inner_tw[i];
+        __syncthreads();
+    }
     // ------------------------------------------------------------------ load + step 1 (radix 32 over i, rows g + P2*i)
     __builtin_amdgcn_s_setprio(TF_PRIO_LOAD);
     if constexpr (MODE == 1) {
@@ -355,6 +388,11 @@ __global__ void __launch_bounds__(512, TF_NTT_WAVES) ntt_pass_kernel(const NttPa
     } else if (act_in) {
         const u32 toff = (u32)(((long long)ch_in * A.in_cs_hi + cl_in + (long long)g_in * A.in_rs) * 8);
         const char* base = reinterpret_cast<const char*>(in);
+        if constexpr ((LAST1024 || R1024) && SCALE != 1) {
+            const __amdgpu_buffer_rsrc_t ri = buf_rsrc(in);
+#pragma unroll
+            for (int q = 0; q < 32; ++q) x[q] = buf_load(ri, toff, (u32)((long long)(brev5(q) << 5) * A.in_rs * 8));
+        } else
 #pragma unroll
         for (int q = 0; q < 32; ++q) {
             const long long ur = (long long)(brev5(q) << p2);  // uniform part of the row index
@@ -419,7 +457,7 @@ __global__ void __launch_bounds__(512, TF_NTT_WAVES) ntt_pass_kernel(const NttPa
         dit_half<INV, 16, LAZY1>(x);
         dit_level<INV, 5, LAZY1>(x);
         if (LAZY1 || A.inner_tw) {  // (the R = 1024 instantiations always have an inner table: launch_pass checks)
-            const u64* tw = A.inner_tw + g_in * 32;
+            const u64* tw = LDS_TW ? ltw + g_in * kLdsTwStride : A.inner_tw + g_in * 32;
 #pragma unroll
             for (int q = 0; q < 32; q += 2) gl::mont_mul2(x[q], tw[q], x[q + 1], tw[q + 1], x[q], x[q + 1]);
         }
@@ -430,11 +468,13 @@ __global__ void __launch_bounds__(512, TF_NTT_WAVES) ntt_pass_kernel(const NttPa
     // A thread writes its 32 values and reads its 32 new values in the SAME round, so only 32 are ever live.
     if constexpr (LAST1024) {
         // Writers are in the row-major roles (g_in, c_in), readers in the column-major roles (g, c); 8 columns per round.
-        // Element (k1, g, cc) lives at k1 * 289 + cc * 36 + g: the 16 lanes of a writing half-wave that are active in a
-        // round (16 consecutive g, one column) cover 16 consecutive words; the 16 active lanes of a reading half-wave
-        // (8 columns x two consecutive k1, same g) fall on 16 different 8-byte bank pairs because 36 = 4 and 289 = 1
-        // (mod 32).  All 64 offsets are immediates on both sides.  (kLast1024LdsBytes in tf_hip.hip sizes the buffer.)
-        constexpr int S1 = 289, CS = 36;
+        // Element (k1, g, cc) lives at k1 * 273 + cc * 34 + g: the active lanes of a writing lane group (consecutive g, one
+        // column) cover consecutive words; the active lanes of a reading group (8 columns, same k1 -- and for the 32-lane
+        // groups of ds_read_b64 two consecutive k1) fall on different 8-byte bank pairs because 34 = 2 and 273 = 17 (mod 32):
+        // cc * 2 + 17 * (k1 & 1) takes 16 different values.  All 64 offsets are immediates on both sides.  (Round 1 used 36 /
+        // 289; the tighter pitch leaves room for the staged twiddle table with two workgroups per CU.  kLast1024LdsBytes in
+        // tf_hip.hip sizes the buffer.)
+        constexpr int S1 = kL1024S1, CS = kL1024CS;
         const int wround = c_in >> 3, wcc = c_in & 7, rround = c >> 3, rcc = c & 7;
         u64* wr = lds + wcc * CS + g_in;
         const u64* rd = lds + g * S1 + rcc * CS;
@@ -532,10 +572,11 @@ __global__ void __launch_bounds__(512, TF_NTT_WAVES) ntt_pass_kernel(const NttPa
     } else if (act) {
         const u32 toff = (u32)(((long long)ch * A.out_cs_hi + cl + (long long)g * A.out_rs) * 8);
         char* base = reinterpret_cast<char*>(out);
-        if (MODE != 2 && A.post_tw) {
+        if ((R1024 && MODE == 0) || (MODE != 2 && A.post_tw)) {  // (R1024 is only launched with an inter-pass table)
             // inter-pass twiddle: 8 table words at a time (bounded register footprint), multiply, store
             const u32 twoff = (u32)(((long long)g * A.tw_rs + bcol) * 8);
             const char* tbase = reinterpret_cast<const char*>(A.post_tw);
+            const __amdgpu_buffer_rsrc_t rt = buf_rsrc(A.post_tw), ro = buf_rsrc(out);  // used by the R1024 instantiation only
 #pragma unroll
             for (int q0 = 0; q0 < 32; q0 += 8) {
                 u64 w[8];
@@ -543,7 +584,8 @@ __global__ void __launch_bounds__(512, TF_NTT_WAVES) ntt_pass_kernel(const NttPa
                 for (int i = 0; i < 8; ++i) {
                     const int q = q0 + i;
                     const long long uk = (long long)(((q >> p2) << p2) + ((q & (P2 - 1)) << 5));  // uniform part of k
-                    w[i] = *reinterpret_cast<const u64*>(tbase + uk * A.tw_rs * 8 + twoff);
+                    if constexpr (R1024) w[i] = buf_load(rt, twoff, (u32)(uk * A.tw_rs * 8));
+                    else w[i] = *reinterpret_cast<const u64*>(tbase + uk * A.tw_rs * 8 + twoff);
                 }
 #pragma unroll
                 for (int i = 0; i < 8; i += 2) {
@@ -552,8 +594,13 @@ __global__ void __launch_bounds__(512, TF_NTT_WAVES) ntt_pass_kernel(const NttPa
                     const long long uk1 = (long long)((((q + 1) >> p2) << p2) + (((q + 1) & (P2 - 1)) << 5));
                     u64 r0, r1;
                     gl::mont_mul2(x[q], w[i], x[q + 1], w[i + 1], r0, r1);
-                    *reinterpret_cast<u64*>(base + uk0 * A.out_rs * 8 + toff) = r0;
-                    *reinterpret_cast<u64*>(base + uk1 * A.out_rs * 8 + toff) = r1;
+                    if constexpr (R1024) {
+                        buf_store(ro, toff, (u32)(uk0 * A.out_rs * 8), r0);
+                        buf_store(ro, toff, (u32)(uk1 * A.out_rs * 8), r1);
+                    } else {
+                        *reinterpret_cast<u64*>(base + uk0 * A.out_rs * 8 + toff) = r0;
+                        *reinterpret_cast<u64*>(base + uk1 * A.out_rs * 8 + toff) = r1;
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }

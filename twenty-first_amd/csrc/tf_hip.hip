@@ -584,6 +584,19 @@ int ablate_mode() {
     }
     return v;
 }
+// The R = 1024 instantiations address memory through buffer resources: resource base + 32-bit per-thread offset + 32-bit
+// per-slot offset (ntt_kernels.h, buf_load).  A thread's row offset is at most 31 rows, a slot's at most 992 rows: with
+// row strides of rs words everything stays below 2^32 bytes when 1024 * rs * 8 (+ the tile's column span) does.
+bool fits_buffer_offsets(const Launch& l) {
+    const unsigned long long lim = 1ull << 32;
+    const unsigned long long col_span = (unsigned long long)std::max(l.a.nc, 16) * 8ull * 3ull;  // columns of a tile, any limb
+    const auto ok = [&](long long rs_words, long long cs_hi_words) {
+        const unsigned long long cols = (unsigned long long)(cs_hi_words < 0 ? 0 : cs_hi_words) * 8ull * 16ull;  // ch < 16 columns of a tile
+        return 1024ull * (unsigned long long)rs_words * 8ull + cols + col_span < lim;
+    };
+    return ok(l.a.in_rs, l.a.in_cs_hi) && ok(l.a.out_rs, l.a.out_cs_hi) && ok(l.a.tw_rs, 0);
+}
+
 // the specialised R = 1024 last-pass kernel (LAST1024) is available unless an A/B switch or an ablation run disables it
 bool last1024_enabled() {
     static const bool off = getenv("TF_NTT_NO_LAST1024") != nullptr;
@@ -720,14 +733,17 @@ int launch_pass_t(const Launch& l, hipStream_t stream) {
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         done_mask.fetch_or(bit, std::memory_order_release);
     }
-    hipLaunchKernelGGL((tfk::ntt_pass_kernel<INV, SCALE, MODE, LAST1024, R1024>), dim3(l.tiles), dim3(l.threads), l.lds_bytes, stream,
+    // the R = 1024 column-pass instantiation stages its inner twiddle table behind the exchange buffer (LAST1024: part of
+    // kLast1024LdsBytes already)
+    const size_t lds_bytes = l.lds_bytes + ((TF_LDS_TW && R1024 && MODE == 0) ? size_t(32) * tfk::kLdsTwStride * sizeof(u64) : 0);
+    hipLaunchKernelGGL((tfk::ntt_pass_kernel<INV, SCALE, MODE, LAST1024, R1024>), dim3(l.tiles), dim3(l.threads), lds_bytes, stream,
                        l.a);
     HIPCHK(hipGetLastError());
     return TF_OK;
 }
 
 unsigned long long* g_dbg_buf = nullptr;  // TF_NTT_ABLATE=3: per-wave phase stamps of the last launch (tf_debug_stamps)
-constexpr size_t kLast1024LdsBytes = size_t(32) * 289 * sizeof(u64);
+constexpr size_t kLast1024LdsBytes = (size_t(tfk::kL1024ExchangeWords) + (TF_LDS_TW ? 32 * tfk::kLdsTwStride : 0)) * sizeof(u64);
 
 int launch_pass(const Launch& l, bool inverse, hipStream_t stream) {
     if (l.tiles == 0) return TF_OK;
@@ -741,8 +757,9 @@ int launch_pass(const Launch& l, bool inverse, hipStream_t stream) {
         return TF_ERR_HIP;
     }
     // the plain R = 1024 last-pass kernel: the only one that truncates its output and shifts its tiles
+    const bool fits = fits_buffer_offsets(l);
     const bool plain_last1024 = l.a.p2 == 5 && !l.a.post_tw && !l.a.gfast && !l.a.pre_scale && l.a.n_coeffs < 0 && !l.a.in2 &&
-                                (!l.a.post_scale || (inverse && scaled_last1024_enabled())) && last1024_enabled();
+                                (!l.a.post_scale || (inverse && scaled_last1024_enabled())) && last1024_enabled() && fits;
     if ((l.a.n_out >= 0 || l.a.col_shift0 || l.a.col_shift_i0) && !plain_last1024) {  // anything else would overrun the caller's buffer
         t_last_error = "internal: truncated output or shifted tiles requested from a pass that does not support them";
         return TF_ERR_HIP;
@@ -752,7 +769,7 @@ int launch_pass(const Launch& l, bool inverse, hipStream_t stream) {
         // constant-P2 variant for a forward first pass with R = 1024)
         static const bool no_r1024_scale = getenv("TF_NTT_NO_R1024") != nullptr;
         if (inverse) return launch_pass_t<true, 1, 0>(l, stream);
-        if (l.a.p2 == 5 && l.a.post_tw && !no_r1024_scale) return launch_pass_t<false, 1, 0, false, true>(l, stream);
+        if (l.a.p2 == 5 && l.a.post_tw && !no_r1024_scale && fits) return launch_pass_t<false, 1, 0, false, true>(l, stream);
         return launch_pass_t<false, 1, 0>(l, stream);
     }
     if (l.a.post_scale) {  // coset interpolation: inverse, scale on store
@@ -766,9 +783,9 @@ int launch_pass(const Launch& l, bool inverse, hipStream_t stream) {
     }
     // last pass of a plain transform with R = 1024: specialised kernel (constant P2, stores fused with level 5)
     // (not for single-pass transforms: their stores run along the row as well, which only the gfast roles give -- 1.05 vs 1.20 ms)
-    const bool last1024 = l.a.p2 == 5 && !l.a.post_tw && last1024_enabled() && !l.a.gfast;
+    const bool last1024 = l.a.p2 == 5 && !l.a.post_tw && last1024_enabled() && !l.a.gfast && fits;
     static const bool no_r1024 = getenv("TF_NTT_NO_R1024") != nullptr;  // A/B switch
-    const bool r1024 = l.a.p2 == 5 && l.a.post_tw && g_ablate == 0 && !no_r1024;  // column pass with R = 1024
+    const bool r1024 = l.a.p2 == 5 && l.a.post_tw && g_ablate == 0 && !no_r1024 && fits;  // column pass with R = 1024
     if (last1024) {  // this instantiation lays its exchange buffer out itself (32 x 289 words, ntt_kernels.h)
         Launch l2 = l;
         l2.lds_bytes = std::max(l.lds_bytes, kLast1024LdsBytes);
@@ -949,7 +966,8 @@ bool can_truncate(size_t n, int L) {
     const int log_n = ilog2(n), P = pass_count(log_n);
     int a[4] = {0, 0, 0, 0};
     choose_split(log_n, P, L, a);
-    return P <= 3 && a[P - 1] == 10 && last1024_enabled();
+    // ... and that kernel addresses its stores through a buffer resource: 1024 * (n L / 1024) * 8 bytes must fit 32 bits (fits_buffer_offsets)
+    return P <= 3 && a[P - 1] == 10 && last1024_enabled() && (unsigned long long)n * L * 8 + (1ull << 20) < (1ull << 32);
 }
 
 // The transform proper.  in/out are device pointers; in == out for ntt/intt, distinct for coset evaluation
