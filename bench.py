@@ -262,7 +262,7 @@ def ntt_headline(ctx):
 
     copy_before = copy_gbs()
     if not args.no_settle:
-        prev = None
+        prev, best = None, None
         for w in range(40):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -272,17 +272,14 @@ def ntt_headline(ctx):
             torch.cuda.synchronize()
             cur = e0.elapsed_time(e1) / 25
             settle += 25
-            if w >= 3 and prev is not None and abs(cur - prev) <= 0.02 * prev:
+            best = cur if best is None else min(best, cur)
+            # steady = two consecutive windows agree within 2 % AND sit within 5 % of the best window seen so far
+            if w >= 3 and prev is not None and abs(cur - prev) <= 0.02 * prev and cur <= 1.05 * best:
                 break
             prev = cur
     for _ in range(args.warmup):
         tf.device.ntt_(x, n, batch=batch)
     barrier()
-
-    # parity is checked on a fresh run of the sample (x has been transformed many times by now)
-    sample_gpu = sample_in.clone()
-    tf.device.ntt_(sample_gpu, n, batch=k_par)
-    torch.cuda.synchronize()
 
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     barrier()
@@ -305,6 +302,11 @@ def ntt_headline(ctx):
     step_ms = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(10))
     sclk_after = tf.lib().tf_debug_sclk_mhz()
     copy_after = copy_gbs()
+    # parity is checked on a fresh run of the sample, AFTER the timed region (x has been transformed many times by now; nothing
+    # of another shape runs between the warmup and the timed steps)
+    sample_gpu = sample_in.clone()
+    tf.device.ntt_(sample_gpu, n, batch=k_par)
+    torch.cuda.synchronize()
     barrier()
     elapsed = ctx["max_over_ranks"](elapsed)
 

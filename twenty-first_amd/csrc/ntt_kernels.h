@@ -93,7 +93,17 @@ typedef unsigned int tf_v2u __attribute__((__vector_size__(2 * sizeof(unsigned i
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t buf_rsrc(const void* p) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, -1, 0x00020000);  // raw buffer, 4 GiB window, no swizzle
 }
+#ifndef TF_LOAD_AUX
+#define TF_LOAD_AUX 2  // cache-policy bits of the data stream's buffer loads / stores: 2 = nt (streamed once; 0 for an A/B build).  Measured on 256 x 2^20: 1.919 -> 1.845 ms with both (loads alone 1.889, stores alone 1.890, profiles/r02f)
+#endif
+#ifndef TF_STORE_AUX
+#define TF_STORE_AUX 2
+#endif
 __device__ __forceinline__ u64 buf_load(__amdgpu_buffer_rsrc_t r, u32 voff, u32 soff) {
+    const tf_v2u v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, TF_LOAD_AUX);
+    return ((u64)v[1] << 32) | v[0];
+}
+__device__ __forceinline__ u64 buf_load_tab(__amdgpu_buffer_rsrc_t r, u32 voff, u32 soff) {  // twiddle tables: default policy (they are re-read)
     const tf_v2u v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
     return ((u64)v[1] << 32) | v[0];
 }
@@ -101,7 +111,7 @@ __device__ __forceinline__ void buf_store(__amdgpu_buffer_rsrc_t r, u32 voff, u3
     tf_v2u v;
     v[0] = (u32)x;
     v[1] = (u32)(x >> 32);
-    __builtin_amdgcn_raw_buffer_store_b64(v, r, voff, soff, 0);
+    __builtin_amdgcn_raw_buffer_store_b64(v, r, voff, soff, TF_STORE_AUX);
 }
 
 // ---- radix-2^k DIT network with power-of-two twiddles --------------------------------------
@@ -374,11 +384,13 @@ __global__ void __launch_bounds__(512, TF_NTT_WAVES) ntt_pass_kernel(const NttPa
     u64 x[32];
 #pragma unroll
     for (int q = 0; q < 32; ++q) x[q] = 0;
-    constexpr bool LDS_TW = TF_LDS_TW && (R1024 || LAST1024) && MODE == 0;
-    u64* const ltw = lds + (LAST1024 ? kL1024ExchangeWords : 32 * A.s1);  // the staged inner table, behind the exchange buffer
+    constexpr bool LDS_TW = TF_LDS_TW && MODE == 0;
+    u64* const ltw = lds + (LAST1024 ? kL1024ExchangeWords : 32 * A.s1);  // the staged inner table [P2][32], behind the exchange buffer
     if constexpr (LDS_TW) {
-        for (int i = t; i < 1024; i += blockDim.x) ltw[(i >> 5) * kLdsTwStride + (i & 31)] = A.inner_tw[i];
-        __syncthreads();
+        if ((LAST1024 || R1024) || A.inner_tw) {  // uniform
+            for (int i = t; i < 32 * P2; i += blockDim.x) ltw[(i >> 5) * kLdsTwStride + (i & 31)] = A.inner_tw[i];
+            __syncthreads();
+        }
     }
     // ------------------------------------------------------------------ load + step 1 (radix 32 over i, rows g + P2*i)
     __builtin_amdgcn_s_setprio(TF_PRIO_LOAD);
@@ -584,7 +596,7 @@ __global__ void __launch_bounds__(512, TF_NTT_WAVES) ntt_pass_kernel(const NttPa
                 for (int i = 0; i < 8; ++i) {
                     const int q = q0 + i;
                     const long long uk = (long long)(((q >> p2) << p2) + ((q & (P2 - 1)) << 5));  // uniform part of k
-                    if constexpr (R1024) w[i] = buf_load(rt, twoff, (u32)(uk * A.tw_rs * 8));
+                    if constexpr (R1024) w[i] = buf_load_tab(rt, twoff, (u32)(uk * A.tw_rs * 8));
                     else w[i] = *reinterpret_cast<const u64*>(tbase + uk * A.tw_rs * 8 + twoff);
                 }
 #pragma unroll

@@ -88,6 +88,13 @@ struct DeviceCtx {
     bool tip5_ready = false;               // guarded by mu
     std::atomic<bool> pool_ready{false};  // double-checked under mu
     hipStream_t side[4] = {nullptr, nullptr, nullptr, nullptr};  // pipelined tiles (run_ntt); created on first use under mu
+    struct ScratchBlock {
+        u64* p = nullptr;
+        size_t bytes = 0;
+        hipEvent_t ready = nullptr;  // recorded on the last user's stream when it gave the block back
+    };
+    std::vector<ScratchBlock> scratch_free;  // work space of the multi-pass transforms (guarded by mu), see scratch_acquire
+    size_t scratch_bytes = 0;                // bytes held by blocks in scratch_free
     size_t cached_post_bytes = 0;          // inter-pass twiddle tables kept for the life of the process (guarded by mu)
     size_t cached_pow_bytes = 0;           // coset power tables kept for the life of the process (guarded by mu)
 };
@@ -126,6 +133,84 @@ int current_ctx(DeviceCtx** out) {
         }
     }
     return TF_OK;
+}
+
+// Work space between the passes of a multi-pass transform.  Round 1 took it from the stream-ordered pool on every call; a
+// call of another size in between (bench.py's parity sample, a coset evaluation) splits the pooled block and the next full-size
+// call then pays a fresh 2 GiB device allocation inside its timed path (observed: +120 ms on one step).  Blocks are therefore
+// kept whole in a small per-device cache and handed from call to call with an event fence: release records an event on the
+// releasing stream, the next taker's stream waits for it -- no host synchronisation, any mix of streams and host threads.
+constexpr size_t kScratchCacheBytes = size_t(12) << 30;  // blocks beyond this are freed when they come back
+int scratch_acquire(DeviceCtx* ctx, size_t bytes, hipStream_t stream, DeviceCtx::ScratchBlock* out) {
+    {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        int best = -1;
+        for (int i = 0; i < (int)ctx->scratch_free.size(); ++i) {
+            const auto& b = ctx->scratch_free[i];
+            if (b.bytes >= bytes && (best < 0 || b.bytes < ctx->scratch_free[best].bytes)) best = i;
+        }
+        if (best >= 0 && ctx->scratch_free[best].bytes <= 4 * bytes + (size_t(64) << 20)) {  // do not pin a huge block under a small call
+            *out = ctx->scratch_free[best];
+            ctx->scratch_free.erase(ctx->scratch_free.begin() + best);
+            ctx->scratch_bytes -= out->bytes;
+        } else {
+            out->p = nullptr;
+        }
+    }
+    if (out->p) {
+        hipError_t e = hipStreamWaitEvent(stream, out->ready, 0);
+        if (e != hipSuccess) return hip_fail(e, "hipStreamWaitEvent(scratch)", __FILE__, __LINE__);
+        return TF_OK;
+    }
+    out->bytes = bytes;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&out->p), bytes);
+    if (e != hipSuccess) {
+        // make room: drop every cached block (after their last users) and retry once
+        std::vector<DeviceCtx::ScratchBlock> drop;
+        {
+            std::lock_guard<std::mutex> lk(ctx->mu);
+            drop.swap(ctx->scratch_free);
+            ctx->scratch_bytes = 0;
+        }
+        (void)hipGetLastError();
+        for (auto& b : drop) {
+            (void)hipEventSynchronize(b.ready);
+            (void)hipEventDestroy(b.ready);
+            (void)hipFree(b.p);
+        }
+        e = hipMalloc(reinterpret_cast<void**>(&out->p), bytes);
+        if (e != hipSuccess) return hip_fail(e, "hipMalloc(ntt scratch)", __FILE__, __LINE__);
+    }
+    e = hipEventCreateWithFlags(&out->ready, hipEventDisableTiming);
+    if (e != hipSuccess) {
+        (void)hipFree(out->p);
+        return hip_fail(e, "hipEventCreate(scratch)", __FILE__, __LINE__);
+    }
+    return TF_OK;
+}
+void scratch_release(DeviceCtx* ctx, DeviceCtx::ScratchBlock blk, hipStream_t stream) {
+    if (!blk.p) return;
+    if (hipEventRecord(blk.ready, stream) != hipSuccess) {  // cannot fence it: wait, then free
+        (void)hipGetLastError();
+        (void)hipStreamSynchronize(stream);
+        (void)hipEventDestroy(blk.ready);
+        (void)hipFree(blk.p);
+        return;
+    }
+    bool keep;
+    {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        keep = ctx->scratch_bytes + blk.bytes <= kScratchCacheBytes && ctx->scratch_free.size() < 16;
+        if (keep) {
+            ctx->scratch_free.push_back(blk);
+            ctx->scratch_bytes += blk.bytes;
+        }
+    }
+    if (!keep) {
+        (void)hipEventSynchronize(blk.ready);
+        (void)hipEventDestroy(blk.ready);
+        (void)hipFree(blk.p);
+    }
 }
 
 size_t g_tile_bytes = 0;
@@ -735,7 +820,7 @@ int launch_pass_t(const Launch& l, hipStream_t stream) {
     }
     // the R = 1024 column-pass instantiation stages its inner twiddle table behind the exchange buffer (LAST1024: part of
     // kLast1024LdsBytes already)
-    const size_t lds_bytes = l.lds_bytes + ((TF_LDS_TW && R1024 && MODE == 0) ? size_t(32) * tfk::kLdsTwStride * sizeof(u64) : 0);
+    const size_t lds_bytes = l.lds_bytes + ((TF_LDS_TW && !LAST1024 && MODE == 0 && l.a.inner_tw) ? (size_t(1) << l.a.p2) * tfk::kLdsTwStride * sizeof(u64) : 0);
     hipLaunchKernelGGL((tfk::ntt_pass_kernel<INV, SCALE, MODE, LAST1024, R1024>), dim3(l.tiles), dim3(l.threads), lds_bytes, stream,
                        l.a);
     HIPCHK(hipGetLastError());
@@ -1100,12 +1185,14 @@ int run_ntt(DeviceCtx* ctx, const u64* in, u64* out, long long in_bs, long long 
         }
     }
     u64* scratch = nullptr;
+    DeviceCtx::ScratchBlock sblk;
     {
-        hipError_t e = hipMallocAsync(reinterpret_cast<void**>(&scratch), size_t(K) * tb * poly_bytes, stream);
-        if (e != hipSuccess) {
+        rc = scratch_acquire(ctx, size_t(K) * tb * poly_bytes, stream, &sblk);
+        if (rc) {
             release_tables();
-            return hip_fail(e, "hipMallocAsync(ntt scratch)", __FILE__, __LINE__);
+            return rc;
         }
+        scratch = sblk.p;
     }
     if (K > 1) {
         hipError_t e = hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming);
@@ -1117,7 +1204,7 @@ int run_ntt(DeviceCtx* ctx, const u64* in, u64* out, long long in_bs, long long 
             if (ev_fork) (void)hipEventDestroy(ev_fork);
             for (int i = 0; i < K; ++i)
                 if (ev_join[i]) (void)hipEventDestroy(ev_join[i]);
-            (void)hipFreeAsync(scratch, stream);
+            scratch_release(ctx, sblk, stream);
             release_tables();
             return hip_fail(e, "fork into the tile streams", __FILE__, __LINE__);
         }
@@ -1226,16 +1313,15 @@ int run_ntt(DeviceCtx* ctx, const u64* in, u64* out, long long in_bs, long long 
         (void)hipEventDestroy(ev_fork);
         for (int i = 0; i < K; ++i) (void)hipEventDestroy(ev_join[i]);
         if (je != hipSuccess) {
-            (void)hipDeviceSynchronize();  // cannot order the free after the side streams any other way
-            (void)hipFreeAsync(scratch, stream);
+            (void)hipDeviceSynchronize();  // cannot order the release after the side streams any other way
+            scratch_release(ctx, sblk, stream);
             release_tables();
             return hip_fail(je, "join of the tile streams", __FILE__, __LINE__);
         }
     }
-    hipError_t e = hipFreeAsync(scratch, stream);
+    scratch_release(ctx, sblk, stream);
     release_tables();
     if (rc) return rc;
-    if (e != hipSuccess) return hip_fail(e, "hipFreeAsync(ntt scratch)", __FILE__, __LINE__);
     return TF_OK;
 }
 
