@@ -333,11 +333,13 @@ def test_config2_256x2pow20_roundtrip_and_samples(tf, oracle):
     orig = d.clone()
     tf.device.ntt_(d, n, batch=batch)
     torch.cuda.synchronize()
+    # 32 of the 256 transforms word for word (chunks 0 and 240 entirely: the oracle runs one transform per thread)
     for c0, h in host_chunks.items():
-        for b in (0, chunk - 1):
-            want = oracle.ntt(h[b * n:(b + 1) * n])
+        picks = range(chunk) if c0 in (0, 240) else (0, chunk - 1)
+        want = oracle.ntt(h, batch=chunk, threads=chunk)
+        for b in picks:
             got = _to_host(d[(c0 + b) * n:(c0 + b + 1) * n])
-            assert np.array_equal(got, want), (c0, b)
+            assert np.array_equal(got, want[b * n:(b + 1) * n]), (c0, b)
     tf.device.ntt_(d, n, batch=batch, inverse=True)
     torch.cuda.synchronize()
     assert torch.equal(d, orig)
@@ -568,6 +570,8 @@ def test_every_entry_point_validates_its_arguments(tf):
     assert lib.tf_merkle_auth_structure_indices(8, idx, 2, out, 64, C.byref(cnt)) == 11   # leaf 9 of 8
     assert lib.tf_merkle_auth_structure_indices(12, idx, 1, out, 64, C.byref(cnt)) == 2
     assert lib.tf_merkle_auth_structure_indices(8, idx, 1, out, 0, C.byref(cnt)) == 0 and cnt.value == 3   # sizing call: count only
+    assert lib.tf_merkle_auth_structure_indices(8, idx, 1, None, 64, C.byref(cnt)) == 0 and cnt.value == 3  # NULL buffer: sizing call too
+    assert lib.tf_merkle_auth_structure_indices(8, idx, 1, out, 2, C.byref(cnt)) == 13 and cnt.value == 3  # TF_ERR_BUFFER_TOO_SMALL, nothing written
     assert lib.tf_status_string(7) == b"TF_ERR_NULL_POINTER" and lib.tf_status_string(13) == b"TF_ERR_BUFFER_TOO_SMALL"
     # after all that the device still works
     x = np.arange(8, dtype=np.uint64)
@@ -575,3 +579,116 @@ def test_every_entry_point_validates_its_arguments(tf):
     tf.ntt(y)
     tf.intt(y)
     assert np.array_equal(x, y)
+
+
+@pytest.mark.parametrize("log_n,width", [(27, 1), (26, 3)])
+def test_huge_single_transforms_match_oracle(tf, oracle, log_n, width):
+    """The largest single transforms the suite can afford (tools/check_huge.py covers 2^28 .. 2^31 outside pytest): a 2^27-point
+    BFieldElement slice (1 GiB, three passes) and a 2^26-point XFieldElement slice (1.5 GiB), forward word for word against the
+    oracle (math/ntt.rs:67-82), then the inverse round trip."""
+    import torch
+
+    n = 1 << log_n
+    x = oracle.fill_random(n * width, 0xABC + log_n)
+    want = oracle.ntt(x, width=width)
+    d = _to_dev(x)
+    tf.device.ntt_(d, n, width=width)
+    torch.cuda.synchronize()
+    assert np.array_equal(_to_host(d), want)
+    del want
+    tf.device.ntt_(d, n, width=width, inverse=True)
+    torch.cuda.synchronize()
+    assert np.array_equal(_to_host(d), x)
+
+
+def test_device_fill_random_is_the_oracle_sequence(tf, oracle):
+    """tf_debug_fill_random_dev (bench.py's synthetic inputs) == tfo.fill_random, also from an offset"""
+    import torch
+
+    t = torch.empty(100_003, dtype=torch.int64, device="cuda")
+    tf.device.fill_random(t, 0x7F210002)
+    torch.cuda.synchronize()
+    want = oracle.fill_random(200_000, 0x7F210002)
+    assert np.array_equal(_to_host(t), want[:100_003])
+    tf.device.fill_random(t, 0x7F210002, first_index=77_777)
+    torch.cuda.synchronize()
+    assert np.array_equal(_to_host(t), want[77_777:77_777 + 100_003])
+    assert int(_to_host(t).max()) < P
+
+
+@pytest.mark.parametrize("tile_mib,pipe", [(8, 2), (16, 3), (8, 4), (64, 1)])
+def test_pipelined_batch_tiles_are_bit_exact(tf, oracle, tile_mib, pipe):
+    """TF_NTT_TILE_BYTES x TF_NTT_PIPE: the batch tiles of a multi-pass transform dealt to side streams (fork/join with events
+    on the caller's stream) give the same words as the one-stream plan, for in-place transforms and coset evaluations, and the
+    next call on the caller's stream sees the finished result."""
+    import torch
+
+    L = tf.lib()
+    n, batch = 1 << 16, 40  # 20 MiB per call: 3 .. 5 tiles of 8 MiB, a ragged last tile with 16 MiB
+    x = oracle.fill_random(n * batch, 31)
+    want = oracle.ntt(x, batch=batch, threads=8)
+    try:
+        L.tf_set_ntt_tile_bytes(tile_mib << 20)
+        L.tf_set_ntt_pipe(pipe)
+        s = torch.cuda.Stream()
+        with torch.cuda.stream(s):
+            d = _to_dev(x)
+            tf.device.ntt_(d, n, batch=batch)
+            e = d.clone()                       # enqueued behind the join on the same stream
+            tf.device.ntt_(d, n, batch=batch, inverse=True)
+        s.synchronize()
+        assert np.array_equal(_to_host(e), want)
+        assert np.array_equal(_to_host(d), x)
+        c = oracle.fill_random(3 * 1000 * 6, 32)
+        out = torch.empty(3 * 4096 * 6, dtype=torch.int64, device="cuda")
+        tf.device.coset_evaluate(_to_dev(c), 1000, oracle.bfe_new(7), out, 4096, batch=6, width=3)
+        torch.cuda.synchronize()
+        for b in range(6):
+            assert np.array_equal(_to_host(out[b * 3 * 4096:(b + 1) * 3 * 4096]), oracle.coset_evaluate(c[b * 3000:(b + 1) * 3000], oracle.bfe_new(7), 4096, width=3))
+    finally:
+        L.tf_set_ntt_tile_bytes(0)
+        L.tf_set_ntt_pipe(1)
+
+
+def test_wrapper_size_checks_raise_before_the_abi(tf):
+    """device.py validates every tensor against (n, batch, width): a wrong size is a ValueError, never an out-of-bounds access"""
+    import torch
+
+    z = lambda k: torch.zeros(k, dtype=torch.int64, device="cuda")
+    with pytest.raises(ValueError):
+        tf.device.tip5_hash_varlen_rows(z(99), 10, z(50))          # rows != n_rows * row_len
+    with pytest.raises(ValueError):
+        tf.device.merkle_root(z(5 * 8), 8, z(4))                   # root_out too small
+    with pytest.raises(ValueError):
+        tf.device.coset_interpolate(z(64), 64, 1, z(32))           # out too small
+    with pytest.raises(ValueError):
+        tf.device.hadamard(z(30), z(33), z(30), width=3)
+    with pytest.raises(ValueError):
+        tf.device.poly_mul(z(16), 8, z(16), 8, z(29), batch=2)     # out != batch * (na + nb - 1)
+    with pytest.raises(ValueError):
+        tf.device.lde(z(64), 64, 1, z(100), 128, 1)
+    with pytest.raises(ValueError):
+        tf.device.merkle_from_rows(z(70), 10, 8, z(80))
+    with pytest.raises(ValueError):
+        tf.device.hash_table_rows(z(100), 16, 4, z(80), col_stride=8)   # col_stride < n_rows * width
+    with pytest.raises(ValueError):
+        tf.device.merkle_from_columns(z(63), 16, 4, z(160))
+    with pytest.raises(ValueError):
+        tf.device.tip5_permute_(z(40))                              # not a multiple of 16 words
+    with pytest.raises(ValueError):
+        tf.device.ntt_(z(64), 64, width=2)
+
+
+def test_free_functions_validate_and_trim(tf, oracle):
+    """fast_multiply / fast_square reject sizes that are not batch * n * width; fast_coset_evaluate compares
+    `order` with the degree (math/polynomial.rs:1388): high-order zero coefficients do not count"""
+    with pytest.raises(ValueError):
+        tf.fast_multiply(np.zeros(7, np.uint64), np.zeros(8, np.uint64), batch=2)
+    with pytest.raises(ValueError):
+        tf.fast_square(np.zeros(7, np.uint64), width=3)
+    c = oracle.fill_random(3 * 40, 8)
+    padded = np.concatenate([c, np.zeros(3 * 30, np.uint64)])   # 70 coefficients, the top 30 zero: degree 39 < order 64
+    got = tf.fast_coset_evaluate(padded, oracle.bfe_new(7), 64, width=3)
+    assert np.array_equal(got, oracle.coset_evaluate(c, oracle.bfe_new(7), 64, width=3))
+    with pytest.raises(tf.NttPanic):
+        tf.fast_coset_evaluate(oracle.fill_random(3 * 70, 9), oracle.bfe_new(7), 64, width=3)   # degree 69 >= order

@@ -483,3 +483,65 @@ def test_merkle_root_goldens(oracle):
         leaves = tree_leaves(o, int(h))
         nodes = o.merkle_build(leaves).reshape(-1, 5)
         assert o.digest_hex(nodes[1]) == hexroot
+
+
+def test_mds_matrix_mul_methods_agree(oracle):
+    """tip5/mod.rs:1509-1523 (test_mds_matrix_mul_methods_agree): mds_cyclomul == mds_generated on arbitrary states -- restated
+    over the oracle's three MDS forms (plain circulant sum, the cyclomul recursion :753-1019, and the deferred-halving wrapping-u64
+    graph that generated_function :256-506 unrolls), on 10^5 random canonical states AND on degenerate words (>= p, all-ones,
+    0xffffffff halves): the raw output words must agree bit for bit, degenerate results included."""
+    o = oracle
+    rng = np.random.default_rng(20260928)
+    n = 100_000
+    states = rng.integers(0, P, size=(n, 16), dtype=np.uint64)
+    special = np.array([0, 1, 0xFFFFFFFF, 0x100000000, P - 1, P, P + 1, 2 ** 64 - 1, 0xFFFFFFFF00000000, 0xFFFFFFFEFFFFFFFF,
+                        0x00000000FFFFFFFF, 0x8000000080000000], dtype=np.uint64)
+    # degenerate rows: every word drawn from the special set / fully random 64-bit words (not canonical)
+    states[: n // 10] = special[rng.integers(0, special.size, size=(n // 10, 16))]
+    states[n // 10: n // 5] = rng.integers(0, 2 ** 64, size=(n // 10, 16), dtype=np.uint64)
+    for i in range(n):
+        a, b, c = o.tip5_mds(states[i], 0), o.tip5_mds(states[i], 1), o.tip5_mds(states[i], 2)
+        assert (a == b).all() and (a == c).all(), (i, states[i])
+    # the constants the reference's unrolled graph hard-codes for the fully split components (node_64 / node_67, :283-284)
+    assert o.tip5_mds_graph_constants() == (524757, 52427)
+
+
+def test_mds_degenerate_words_are_reproduced(oracle):
+    """tip5/mod.rs:217-242: the reduction at the end of mds_generated can leave a degenerate word (>= p) -- the reference's own
+    example is s_hi = 0, s_lo = P -- which only the round-constant addition repairs.  A state [x, 0, ..., 0] with
+    1108 * x in [p, 2^64) puts output 1 (= M[1] * x, an integer below 2^64, so s_hi = 0) exactly there: all three MDS forms must
+    hand back that degenerate word unchanged, and the full permutation must still agree with the naive field version."""
+    o = oracle
+    M = [61402, 1108, 28750, 33823, 7454, 43244, 53865, 12034, 56951, 27521, 41351, 40901, 12021, 59689, 26798, 17845]
+    x = -(-P // 1108)  # ceil(p / 1108)
+    for delta in (0, 1, 5):
+        st = np.zeros(16, dtype=np.uint64)
+        st[0] = x + delta
+        outs = [o.tip5_mds(st, m) for m in (0, 1, 2)]
+        assert (outs[0] == outs[1]).all() and (outs[0] == outs[2]).all()
+        assert int(outs[2][1]) == 1108 * (x + delta) and int(outs[2][1]) >= P   # degenerate, not reduced
+        for r in range(16):
+            assert int(outs[2][r]) % P == (M[r] * (x + delta)) % P
+    st = np.zeros(16, dtype=np.uint64)
+    st[0] = x
+    assert (o.tip5_permutation(st) == o.tip5_permutation(st, naive=True)).all()
+
+
+def test_mds_linearity_and_circulancy(oracle):
+    """tip5/mod.rs:1391-1455 (test_linearity_of_mds, test_mds_circulancy) on the MDS form the permutation runs: as field maps,
+    mds(a u + b v) = a mds(u) + b mds(v), and the image of the unit vector e_0 is the first column."""
+    o = oracle
+    rng = np.random.default_rng(5)
+    M = [61402, 1108, 28750, 33823, 7454, 43244, 53865, 12034, 56951, 27521, 41351, 40901, 12021, 59689, 26798, 17845]  # tip5/mod.rs:154-157
+    e0 = np.zeros(16, dtype=np.uint64)
+    e0[0] = o.bfe_new(1)
+    col = o.tip5_mds(e0, 2)
+    assert [o.bfe_value(int(v) % P) for v in col] == M
+    for _ in range(200):
+        u = rng.integers(0, P, size=16, dtype=np.uint64)
+        v = rng.integers(0, P, size=16, dtype=np.uint64)
+        a, b = int(rng.integers(0, P, dtype=np.uint64)), int(rng.integers(0, P, dtype=np.uint64))
+        w = np.array([o.bfe_add(o.bfe_mul(a, int(x)), o.bfe_mul(b, int(y))) for x, y in zip(u, v)], dtype=np.uint64)
+        mu, mv, mw = o.tip5_mds(u, 2), o.tip5_mds(v, 2), o.tip5_mds(w, 2)
+        for k in range(16):
+            assert int(mw[k]) % P == o.bfe_add(o.bfe_mul(a, int(mu[k]) % P), o.bfe_mul(b, int(mv[k]) % P))
