@@ -157,12 +157,17 @@ int tf_poly_square_bfe_dev(const uint64_t *d_a, size_t na, uint64_t *d_out, size
 int tf_poly_square_xfe_dev(const uint64_t *d_a, size_t na, uint64_t *d_out, size_t batch, void *stream);
 int tf_lde_bfe_dev(const uint64_t *d_values, size_t n, uint64_t offset_in_raw, uint64_t *d_out, size_t m, uint64_t offset_out_raw, size_t batch, void *stream);
 int tf_lde_xfe_dev(const uint64_t *d_values, size_t n, uint64_t offset_in_raw, uint64_t *d_out, size_t m, uint64_t offset_out_raw, size_t batch, void *stream);
-/* Polynomial::batch_evaluate / iterative_batch_evaluate  math/polynomial.rs:1840-1878: out[i] = f(points[i]),
- * points in the same field as the coefficients (bfe: 1 word per point, xfe: 3), Horner per point on the device. */
+/* Polynomial::batch_evaluate / iterative_batch_evaluate  math/polynomial.rs:1840-1894: out[i] = f(points[i]),
+ * points in the same field as the coefficients (bfe: 1 word per point, xfe: 3).  Few points / short polynomials: Horner per
+ * point; many points on a long polynomial: remaindering down a zerofier tree built from batched fast_multiply calls
+ * (O((n + m) log^2 m), the reference's divide_and_conquer_batch_evaluate :1882-1894 / math/zerofier_tree.rs). */
 int tf_poly_batch_evaluate_bfe(const uint64_t *coeffs, size_t n_coeffs, const uint64_t *points, size_t n_points, uint64_t *out);
 int tf_poly_batch_evaluate_xfe(const uint64_t *coeffs, size_t n_coeffs, const uint64_t *points, size_t n_points, uint64_t *out);
 int tf_poly_batch_evaluate_bfe_dev(const uint64_t *d_coeffs, size_t n_coeffs, const uint64_t *d_points, size_t n_points, uint64_t *d_out, void *stream);
 int tf_poly_batch_evaluate_xfe_dev(const uint64_t *d_coeffs, size_t n_coeffs, const uint64_t *d_points, size_t n_points, uint64_t *d_out, void *stream);
+/* Route of the batch evaluation (test / A-B hook): 0 = automatic (zerofier tree for many points on a long polynomial, Horner
+ * otherwise), 1 = always Horner, 2 = the zerofier tree whenever it applies (>= 512 points).  Same values either way. */
+void tf_set_batch_eval_route(int route);
 /* Polynomial::coset_extrapolate :2117-2128 / batch_coset_extrapolate :2196-2208 (and the par_ variant :2262): for each of
  * `batch` codewords of length n (a power of two, else TF_ERR_LEN_NOT_POWER_OF_TWO) given on {offset * w_n^i}, the values of
  * its interpolant at `points` (same field as the codeword): out[(b * n_points + i) * width]. */

@@ -427,3 +427,66 @@ def test_both_launch_geometries_match_oracle(tf, oracle, mode, width, log_n, bat
     assert np.array_equal(inv, oracle.ntt(x, width=width, inverse=True, batch=batch, threads=8))
     assert np.array_equal(ev, oracle.coset_evaluate(x[: (n // 2 + 3) * width], off, n, width=width))
     assert np.array_equal(ip, oracle.coset_interpolate(x[: n * width], off, width=width))
+
+
+@pytest.mark.parametrize("width,n,m", [(1, 3000, 2048), (1, 9000, 5000), (1, 20000, 4096), (1, 1 << 14, 1 << 13), (1, 700, 2100),
+                                       (3, 1000, 777), (3, 2048, 2048), (3, 300, 512), (3, 5000, 1100)])
+def test_zerofier_tree_batch_evaluate_matches_horner_and_oracle(tf, oracle, width, n, m):
+    """SURVEY 8(f4) at the reference's complexity (math/polynomial.rs:1840-1894, math/zerofier_tree.rs): the zerofier-tree route
+    of tf_poly_batch_evaluate_* -- leaves of 1024 (BFE) / 256 (XFE) points, remainders by power-series inverses, chunks when the polynomial is
+    longer than the padded point count -- returns the same words as the Horner route and as the oracle's Horner; point counts
+    that are not powers of two, polynomials shorter and longer than the point count, duplicate and zero points."""
+    import torch
+
+    L = tf.lib()
+    c = oracle.fill_random(n * width, 900 + n)
+    pts = oracle.fill_random(m * width, 901 + m)
+    pts[: width] = 0                      # the point 0
+    pts[width: 2 * width] = pts[2 * width: 3 * width]  # a duplicate
+    dc, dp = _to_dev(c), _to_dev(pts)
+    out_t = torch.empty(m * width, dtype=torch.int64, device="cuda")
+    out_h = torch.empty(m * width, dtype=torch.int64, device="cuda")
+    try:
+        L.tf_set_batch_eval_route(2)
+        tf.device.batch_evaluate(dc, n, dp, out_t, width=width)
+        L.tf_set_batch_eval_route(1)
+        tf.device.batch_evaluate(dc, n, dp, out_h, width=width)
+    finally:
+        L.tf_set_batch_eval_route(0)
+    torch.cuda.synchronize()
+    got_t, got_h = _to_host(out_t), _to_host(out_h)
+    assert np.array_equal(got_t, got_h)
+    for i in list(range(5)) + [m // 2, m - 1]:
+        if width == 1:
+            want = oracle.poly_eval(c, int(pts[i]))
+        else:
+            want = oracle.poly_eval_xfe_point(c, pts[3 * i: 3 * i + 3])
+        assert np.array_equal(got_t[i * width:(i + 1) * width], np.asarray(want).reshape(-1)), i
+
+
+def test_zerofier_tree_at_m_equals_n_2pow16(tf, oracle):
+    """parity of the tree route against Horner for m = n = 2^16 (BFieldElement), and the automatic
+    route picks the tree there; the two timings are recorded by tools/batch_eval_sweep.py."""
+    import torch
+
+    L = tf.lib()
+    n = m = 1 << 16
+    dc = torch.empty(n, dtype=torch.int64, device="cuda")
+    dp = torch.empty(m, dtype=torch.int64, device="cuda")
+    tf.device.fill_random(dc, 11)
+    tf.device.fill_random(dp, 12)
+    outs = []
+    try:
+        for route in (2, 1, 0):
+            o = torch.empty(m, dtype=torch.int64, device="cuda")
+            L.tf_set_batch_eval_route(route)
+            tf.device.batch_evaluate(dc, n, dp, o)
+            outs.append(o)
+    finally:
+        L.tf_set_batch_eval_route(0)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    c = _to_host(dc)
+    p = _to_host(dp)
+    for i in (0, 1, 12345, m - 1):
+        assert int(_to_host(outs[0])[i]) == int(np.asarray(oracle.poly_eval(c, int(p[i]))).reshape(-1)[0])

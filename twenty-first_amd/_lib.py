@@ -84,6 +84,7 @@ SIGNATURES = {
     "tf_set_ntt_pipe": (None, [C.c_int]),
     "tf_get_ntt_pipe": (C.c_int, []),
     "tf_set_ntt_nt": (None, [C.c_int]),
+    "tf_set_batch_eval_route": (None, [C.c_int]),
     "tf_debug_fill_random_dev": (C.c_int, [_vp, _sz, C.c_uint64, C.c_uint64, _vp]),
 }
 

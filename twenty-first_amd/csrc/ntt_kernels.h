@@ -1042,12 +1042,13 @@ __global__ void __launch_bounds__(256) hadamard_xfe_kernel(const u64* pa, const 
 }
 
 // dst[b][0..n_dst) = src[b][0..min(n_src, n_dst)) then zeros (resize(order, ZERO), polynomial.rs:913-914); words, not elements
-__global__ void __launch_bounds__(256) pad_copy_kernel(const u64* src, u64* dst, long long n_src, long long n_dst, long long batch) {
+__global__ void __launch_bounds__(256) pad_copy_kernel(const u64* src, u64* dst, long long n_src, long long n_dst, long long batch,
+                                                       long long src_stride) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long stride = (long long)gridDim.x * blockDim.x;
     for (; i < n_dst * batch; i += stride) {
         const long long b = i / n_dst, j = i - b * n_dst;
-        dst[i] = j < n_src ? src[b * n_src + j] : 0;
+        dst[i] = j < n_src ? src[b * src_stride + j] : 0;
     }
 }
 

@@ -20,6 +20,7 @@
 #include "gl64.h"
 #include "ntt_kernels.h"
 #include "tip5_kernels.h"
+#include "poly_kernels.h"
 
 using gl::u32;
 using gl::u64;
@@ -1682,10 +1683,12 @@ int hadamard_dev(const u64* a, const u64* b, u64* out, size_t count, int L, void
     return TF_OK;
 }
 
-int pad_copy(const u64* src, u64* dst, long long n_src_words, long long n_dst_words, long long batch, hipStream_t s) {
+int pad_copy(const u64* src, u64* dst, long long n_src_words, long long n_dst_words, long long batch, hipStream_t s,
+             long long src_stride_words = 0) {
     if (n_dst_words * batch == 0) return TF_OK;
     const long long blocks = std::min<long long>((n_dst_words * batch + 255) / 256, 256 * 32);
-    hipLaunchKernelGGL(tfk::pad_copy_kernel, dim3((unsigned)blocks), dim3(256), 0, s, src, dst, n_src_words, n_dst_words, batch);
+    hipLaunchKernelGGL(tfk::pad_copy_kernel, dim3((unsigned)blocks), dim3(256), 0, s, src, dst, n_src_words, n_dst_words, batch,
+                       src_stride_words ? src_stride_words : n_src_words);
     HIPCHK(hipGetLastError());
     return TF_OK;
 }
@@ -1693,8 +1696,13 @@ int pad_copy(const u64* src, u64* dst, long long n_src_words, long long n_dst_wo
 // Polynomial::fast_multiply (polynomial.rs:900-932): zero-pad both to order = next_power_of_two(deg a + deg b + 1),
 // ntt both, pointwise product, intt, truncate to na + nb - 1 coefficients.  (The reference then trims leading zero
 // coefficients in Polynomial::new; the caller does that -- the length here is data independent.)
-int poly_mul_dev(const u64* a, size_t na, const u64* b, size_t nb, u64* out, size_t batch, int L, void* stream) {
+// a_bs / b_bs: words between consecutive polynomials of the batch (0: packed, na * L / nb * L) -- the zerofier tree multiplies
+// the even-numbered nodes of a level by the odd-numbered ones in place.
+int poly_mul_dev(const u64* a, size_t na, const u64* b, size_t nb, u64* out, size_t batch, int L, void* stream, long long a_bs = 0,
+                 long long b_bs = 0) {
     if (batch == 0 || na == 0 || nb == 0) return TF_OK;  // a zero polynomial: empty product
+    if (!a_bs) a_bs = (long long)na * L;
+    if (!b_bs) b_bs = (long long)nb * L;
     if (!a || !b || !out) return TF_ERR_NULL_POINTER;
     const size_t n_out = na + nb - 1;
     size_t order = 1;
@@ -1714,8 +1722,8 @@ int poly_mul_dev(const u64* a, size_t na, const u64* b, size_t nb, u64* out, siz
     if (order > 16 && !no_fuse) {
         // zero padding happens in the first pass of each forward transform (rows beyond the coefficients read as zero);
         // over BFieldElement the pointwise product rides on the inverse transform's first load
-        rc = run_ntt(ctx, a, tmp, (long long)na * L, (long long)order * L, order, batch, L, false, nullptr, (long long)na, s);
-        if (!rc) rc = run_ntt(ctx, b, tmp + half, (long long)nb * L, (long long)order * L, order, batch, L, false, nullptr, (long long)nb, s);
+        rc = run_ntt(ctx, a, tmp, a_bs, (long long)order * L, order, batch, L, false, nullptr, (long long)na, s);
+        if (!rc) rc = run_ntt(ctx, b, tmp + half, b_bs, (long long)order * L, order, batch, L, false, nullptr, (long long)nb, s);
         const bool trunc = can_truncate(order, L);  // the inverse's last pass writes the n_out coefficients straight to `out`
         u64* dst = trunc ? out : tmp;
         const long long dst_bs = trunc ? (long long)n_out * L : (long long)order * L;
@@ -1729,8 +1737,8 @@ int poly_mul_dev(const u64* a, size_t na, const u64* b, size_t nb, u64* out, siz
         }
         copied = trunc;
     } else {
-        rc = pad_copy(a, tmp, (long long)na * L, (long long)order * L, (long long)batch, s);
-        if (!rc) rc = pad_copy(b, tmp + half, (long long)nb * L, (long long)order * L, (long long)batch, s);
+        rc = pad_copy(a, tmp, (long long)na * L, (long long)order * L, (long long)batch, s, a_bs);
+        if (!rc) rc = pad_copy(b, tmp + half, (long long)nb * L, (long long)order * L, (long long)batch, s, b_bs);
         if (!rc) rc = run_ntt(ctx, tmp, tmp, (long long)order * L, (long long)order * L, order, 2 * batch, L, false, nullptr, -1, s);
         if (!rc) rc = hadamard_dev(tmp, tmp + half, tmp, batch * order, L, s);
         if (!rc) rc = run_ntt(ctx, tmp, tmp, (long long)order * L, (long long)order * L, order, batch, L, true, nullptr, -1, s);
@@ -1813,6 +1821,173 @@ int lde_dev(const u64* values, size_t n, u64 offset_in, u64* out, size_t m, u64 
     return TF_OK;
 }
 
+
+// ---- zerofier-tree evaluation (poly_kernels.h has the scheme) --------------------------------------------------------------
+// Sub-quadratic counterpart of the Horner kernels for many points on a long polynomial: O((n + m) log^2 m) instead of O(n m).
+// `units` polynomials of `len` <= M coefficients each (packed, unit u at F + u * len * L) are evaluated at the n_points points;
+// vals[(u * M + i) * L] = unit_u(points[i]).  M = kTreeLeaf * 2^h >= n_points is the padded point count.
+// Leaf size: 1024 points over BFieldElement (= tfk::kLeafMax: the O(leaf^2) leaf work is cheap and two launch-bound tree levels
+// go away: 4.07 -> 3.85 ms at n = m = 2^16), 256 over XFieldElement (nine base-field products per step make the quadratic leaf
+// work expensive: 5.3 ms with 256 vs 8.4 ms with 1024), tools/batch_eval_sweep.py.
+constexpr int tree_leaf(int L) { return L == 1 ? 1024 : 256; }
+constexpr int tree_leaf_log(int L) { return L == 1 ? 10 : 8; }
+
+template <int L, class K, class... Args>
+int launch_1d(K kernel, long long threads, hipStream_t s, Args... args) {
+    if (threads <= 0) return TF_OK;
+    hipLaunchKernelGGL(kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, args...);
+    HIPCHK(hipGetLastError());
+    return TF_OK;
+}
+
+struct ZerofierTree {
+    int h = 0;                 // levels 0 .. h-1 hold zerofiers of degree leaf << level (the root, level h, is never needed)
+    long long M = 0;           // padded point count = leaf << h
+    std::vector<u64*> tails;   // [level]: (M / d) nodes x d elements
+    std::vector<u64*> inv;     // [level]: power-series inverses of the reversed zerofiers, precision d
+};
+
+template <int L>
+int zerofier_tree_build(const u64* points, long long n_points, ZerofierTree* T, u64* arena, hipStream_t s) {
+    // arena: 2 * h level arrays of M * L words, then work space of 8 * M * L words
+    const long long M = T->M;
+    const int h = T->h;
+    T->tails.resize(h);
+    T->inv.resize(h);
+    for (int l = 0; l < h; ++l) {
+        T->tails[l] = arena + (long long)(2 * l) * M * L;
+        T->inv[l] = arena + (long long)(2 * l + 1) * M * L;
+    }
+    u64* work = arena + (long long)(2 * h) * M * L;
+    if (h == 0) return TF_OK;
+    constexpr int kTreeLeaf = tree_leaf(L);
+    hipLaunchKernelGGL(tfk::leaf_zerofier_kernel<L>, dim3((unsigned)(M / kTreeLeaf)), dim3(kTreeLeaf), 0, s, points, n_points, kTreeLeaf,
+                       T->tails[0], T->inv[0]);
+    HIPCHK(hipGetLastError());
+    for (int l = 0; l + 1 < h; ++l) {
+        const long long d = (long long)kTreeLeaf << l, parents = M / (2 * d);
+        u64* P = work;                           // parents x (2d - 1)
+        u64* G = work + 2 * M * L;               // parents x d          (g_left g_right mod x^d)
+        u64* H = work + 3 * M * L;               // parents x 2d         (reversed parent zerofier)
+        u64* Tm = work + 4 * M * L;              // parents x (3d - 1)   (H G)
+        u64* E = work + 6 * M * L;               // parents x 2d         (2 - H G mod x^2d)
+        // tails of the parents
+        int rc = poly_mul_dev(T->tails[l], (size_t)d, T->tails[l] + d * L, (size_t)d, P, (size_t)parents, L, s, 2 * d * L, 2 * d * L);
+        if (rc) return rc;
+        rc = launch_1d<L>(tfk::zerofier_combine_kernel<L>, parents * 2 * d, s, (const u64*)P, (const u64*)T->tails[l], T->tails[l + 1], d, parents);
+        if (rc) return rc;
+        // inverses of the parents: g = g_left g_right mod x^d, then one Newton step g <- g (2 - rev(Z) g) mod x^2d
+        rc = poly_mul_dev(T->inv[l], (size_t)d, T->inv[l] + d * L, (size_t)d, P, (size_t)parents, L, s, 2 * d * L, 2 * d * L);
+        if (rc) return rc;
+        rc = launch_1d<L>(tfk::poly_truncate_kernel<L>, parents * d, s, (const u64*)P, 2 * d - 1, G, d, parents);
+        if (rc) return rc;
+        rc = launch_1d<L>(tfk::zerofier_reverse_kernel<L>, parents * 2 * d, s, (const u64*)T->tails[l + 1], H, 2 * d, parents);
+        if (rc) return rc;
+        rc = poly_mul_dev(H, (size_t)(2 * d), G, (size_t)d, Tm, (size_t)parents, L, s);
+        if (rc) return rc;
+        rc = launch_1d<L>(tfk::newton_two_minus_kernel<L>, parents * 2 * d, s, (const u64*)Tm, 3 * d - 1, E, 2 * d, parents);
+        if (rc) return rc;
+        rc = poly_mul_dev(G, (size_t)d, E, (size_t)(2 * d), Tm, (size_t)parents, L, s);
+        if (rc) return rc;
+        rc = launch_1d<L>(tfk::poly_truncate_kernel<L>, parents * 2 * d, s, (const u64*)Tm, 3 * d - 1, T->inv[l + 1], 2 * d, parents);
+        if (rc) return rc;
+    }
+    return TF_OK;
+}
+
+// F: one unit of exactly M coefficients (zero padded); vals: M values (the first n_points are meaningful)
+template <int L>
+int zerofier_tree_evaluate(const ZerofierTree& T, const u64* F, const u64* points, long long n_points, u64* vals, u64* work, hipStream_t s) {
+    constexpr int kTreeLeaf = tree_leaf(L);
+    const long long M = T.M;
+    const u64* cur = F;  // remainders of the level above: (M / 2d) polynomials of 2d coefficients
+    u64* ping = work;               // M
+    u64* pong = work + M * L;       // M
+    u64* fr = work + 2 * M * L;     // children x d
+    u64* prod = work + 3 * M * L;   // children x (2d - 1)  (< 2 M)
+    u64* q = work + 5 * M * L;      // children x d
+    for (int l = T.h - 1; l >= 0; --l) {
+        const long long d = (long long)kTreeLeaf << l, children = M / d;
+        int rc = launch_1d<L>(tfk::remainder_rev_high_kernel<L>, children * d, s, cur, fr, d, children);
+        if (rc) return rc;
+        rc = poly_mul_dev(fr, (size_t)d, T.inv[l], (size_t)d, prod, (size_t)children, L, s);
+        if (rc) return rc;
+        rc = launch_1d<L>(tfk::poly_reverse_kernel<L>, children * d, s, (const u64*)prod, 2 * d - 1, q, d, children);
+        if (rc) return rc;
+        rc = poly_mul_dev(q, (size_t)d, T.tails[l], (size_t)d, prod, (size_t)children, L, s);
+        if (rc) return rc;
+        u64* nxt = (cur == ping) ? pong : ping;
+        rc = launch_1d<L>(tfk::remainder_finish_kernel<L>, children * d, s, cur, (const u64*)prod, 2 * d - 1, nxt, d, children);
+        if (rc) return rc;
+        cur = nxt;
+    }
+    hipLaunchKernelGGL(tfk::leaf_evaluate_kernel<L>, dim3((unsigned)(M / kTreeLeaf)), dim3(kTreeLeaf), 0, s, cur, points, n_points, kTreeLeaf, vals);
+    HIPCHK(hipGetLastError());
+    return TF_OK;
+}
+
+// When the tree pays (measured, tools/batch_eval_sweep.py): many points AND a long polynomial.  TF_BATCH_EVAL = horner | tree
+// forces a route (A/B, tests).
+std::atomic<int> g_batch_eval_route{-1};  // tf_set_batch_eval_route: 0 automatic, 1 Horner, 2 zerofier tree (-1: read TF_BATCH_EVAL)
+bool tree_route(size_t n_coeffs, size_t n_points, size_t batch, int L) {
+    int route = g_batch_eval_route.load(std::memory_order_relaxed);
+    if (route < 0) {
+        const char* e = getenv("TF_BATCH_EVAL");
+        route = !e ? 0 : (!strcmp(e, "horner") ? 1 : (!strcmp(e, "tree") ? 2 : 0));
+        g_batch_eval_route.store(route, std::memory_order_relaxed);
+    }
+    const char* force = route == 1 ? "horner" : (route == 2 ? "tree" : nullptr);
+    if (force && !strcmp(force, "horner")) return false;
+    const size_t kTreeLeaf = (size_t)tree_leaf(L);
+    if (n_points < kTreeLeaf * 2 || n_coeffs < 2) return false;
+    size_t M = kTreeLeaf;
+    while (M < n_points) M <<= 1;
+    const size_t units = batch * ((n_coeffs + M - 1) / M);
+    if (units > 256) return false;  // one pass down the tree per unit: a very long polynomial on few points stays with Horner
+    if (force && !strcmp(force, "tree")) return true;
+    // Cost model fitted to tools/batch_eval_sweep.py on MI355X (profiles/r02_batch_eval_sweep.txt), milliseconds:
+    //   Horner  n m / 1.4e9            (x 7 over XFieldElement: nine base-field products per step)
+    //   tree    (1 + units) (1 + M / 2^16)   one build plus one pass per unit, launch-bound below 2^16 points   (x 3 over XFE)
+    const double horner_ms = (double)n_coeffs * (double)n_points / 1.4e9 * (L == 3 ? 7.0 : 1.0);
+    const double tree_ms = (1.0 + (double)units) * (0.75 + (double)M / 65536.0) * (L == 3 ? 1.35 : 1.0);
+    return tree_ms < 0.8 * horner_ms;
+}
+
+template <int L>
+int batch_evaluate_tree_t(const u64* coeffs, size_t n_coeffs, size_t poly_stride, size_t batch, const u64* points, size_t n_points,
+                          u64* out, hipStream_t s) {
+    constexpr int kTreeLeaf = tree_leaf(L);
+    ZerofierTree T;
+    long long M = kTreeLeaf;
+    int h = 0;
+    while (M < (long long)n_points) M <<= 1, ++h;
+    T.M = M;
+    T.h = h;
+    const size_t chunks = (n_coeffs + (size_t)M - 1) / (size_t)M;
+    // arena: tree (2 h M) + build / evaluate work (8 M) + one padded unit (M) + values of the chunks of one polynomial (chunks * M)
+    const size_t words = (size_t)(2 * h + 8 + 1 + chunks) * (size_t)M * L;
+    u64* arena = nullptr;
+    hipError_t e = hipMallocAsync(reinterpret_cast<void**>(&arena), words * sizeof(u64), s);
+    if (e != hipSuccess) return hip_fail(e, "hipMallocAsync(zerofier tree)", __FILE__, __LINE__);
+    u64* work = arena + (size_t)(2 * h) * M * L;
+    u64* unit = work + (size_t)8 * M * L;
+    u64* vals = unit + (size_t)M * L;
+    int rc = zerofier_tree_build<L>(points, (long long)n_points, &T, arena, s);
+    for (size_t b = 0; b < batch && !rc; ++b) {
+        for (size_t c = 0; c < chunks && !rc; ++c) {
+            const size_t len = std::min<size_t>((size_t)M, n_coeffs - c * (size_t)M);
+            rc = pad_copy(coeffs + b * poly_stride + c * (size_t)M * L, unit, (long long)(len * L), (long long)M * L, 1, s);
+            if (!rc) rc = zerofier_tree_evaluate<L>(T, unit, points, (long long)n_points, vals + c * (size_t)M * L, work, s);
+        }
+        if (!rc) rc = launch_1d<L>(tfk::chunk_combine_kernel<L>, (long long)n_points, s, (const u64*)vals, M, (int)chunks, points,
+                                   (long long)n_points, h + tree_leaf_log(L) /* log2 M */, out + b * n_points * L);
+    }
+    hipError_t e2 = hipFreeAsync(arena, s);
+    if (rc) return rc;
+    if (e2 != hipSuccess) return hip_fail(e2, "hipFreeAsync", __FILE__, __LINE__);
+    return TF_OK;
+}
+
 // ------------------------------------------------------------------------------------ batch evaluation
 // Polynomial::batch_evaluate / iterative_batch_evaluate (polynomial.rs:1840-1878): f at arbitrary points of the same
 // field.  Exact arithmetic makes every evaluation scheme return the reference's values, so the device uses Horner:
@@ -1827,6 +2002,10 @@ int batch_evaluate_dev(const u64* coeffs, size_t n_coeffs, size_t poly_stride, s
     int rc = current_ctx(&ctx);
     if (rc) return rc;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (tree_route(n_coeffs, n_points, batch, L)) {  // many points on a long polynomial: the zerofier tree (same values)
+        return L == 1 ? batch_evaluate_tree_t<1>(coeffs, n_coeffs, poly_stride, batch, points, n_points, out, s)
+                      : batch_evaluate_tree_t<3>(coeffs, n_coeffs, poly_stride, batch, points, n_points, out, s);
+    }
     const bool split = n_coeffs >= 1024 && n_points < (size_t(1) << 31);
     // grid.y is limited to 65535: walk the batch in slabs
     for (size_t b0 = 0; b0 < batch; b0 += 65535) {
@@ -2047,6 +2226,7 @@ size_t tf_get_ntt_tile_bytes(void) {
     read_env();
     return g_tile_bytes;
 }
+void tf_set_batch_eval_route(int route) { g_batch_eval_route.store(route == 1 || route == 2 ? route : 0, std::memory_order_relaxed); }
 void tf_set_ntt_nt(int mask) {
     read_env();
     g_nt.store(mask & 3, std::memory_order_relaxed);
