@@ -66,3 +66,51 @@ def test_two_rank_sharding_and_gather(tmp_path, total_trees):
         leaves = tfo.fill_random(5 * n_leaves, 0x7F210005 + (tree << 32))
         want = tfo.merkle_build(leaves)[5:10]
         assert np.array_equal(got[tree], want)
+
+
+def _tree_worker(rank, world, port, n_leaves, out_path):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+
+    from oracle import tfo
+    from twenty_first_amd.sharding import sharded_tree
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    leaves = tfo.fill_random(5 * n_leaves, 0x7F210003).view(np.int64).reshape(-1, 5)
+    per = n_leaves // world
+    local = torch.from_numpy(leaves[rank * per:(rank + 1) * per].copy())
+
+    def build(l):  # the oracle stands in for tf.device.merkle_build (this tests the split / gather / finish logic)
+        return torch.from_numpy(tfo.merkle_build(l.numpy().view(np.uint64).reshape(-1)).view(np.int64).reshape(-1, 5))
+
+    root, sub, top = sharded_tree(local, build, build)
+    np.save(f"{out_path}_{rank}.npy", np.concatenate([root.numpy().reshape(1, 5), top.numpy().reshape(-1, 5), sub.numpy().reshape(-1, 5)]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_single_tree_sharded_over_two_ranks_by_subtrees(tmp_path):
+    """SURVEY 8(e) 'optionally': one tree across G ranks by the reference's subtree split (merkle_tree.rs:247-275): every node
+    of the sharded tree equals the node of the unsharded one, found through sharding.global_node."""
+    import torch.multiprocessing as mp
+
+    from oracle import tfo
+    from twenty_first_amd.sharding import global_node
+
+    world, n_leaves = 2, 64
+    port = _free_port()
+    out = str(tmp_path / "tree")
+    mp.spawn(_tree_worker, args=(world, port, n_leaves, out), nprocs=world, join=True)
+    want = tfo.merkle_build(tfo.fill_random(5 * n_leaves, 0x7F210003)).reshape(-1, 5)
+    parts = [np.load(f"{out}_{r}.npy").view(np.uint64) for r in range(world)]
+    for r in range(world):
+        assert np.array_equal(parts[r][0], want[1])                      # every rank ends with the root
+    tops = [p[1:1 + 2 * world] for p in parts]
+    subs = [p[1 + 2 * world:] for p in parts]
+    for idx in range(1, 2 * n_leaves):
+        where = global_node(idx, n_leaves, world)
+        got = tops[0][where[1]] if where[0] == "top" else subs[where[1]][where[2]]
+        assert np.array_equal(got, want[idx]), (idx, where)

@@ -43,3 +43,45 @@ def gather_roots(local_roots, total_units: int):
     dist.all_gather(gathered, buf)
     parts = [gathered[r][: shards[r][1] - shards[r][0]] for r in range(world)]
     return torch.cat(parts, dim=0)
+
+
+def sharded_tree(local_leaves, build_subtree, finish_top):
+    """ONE Merkle tree across the ranks, by the reference's own subtree split (MerkleTree::par_new hands the num_threads
+    subtrees below the top log2(num_threads) layers to one worker each, util_types/merkle_tree.rs:165-212, :247-275): rank g of G
+    (a power of two) owns leaves [g * n / G, (g + 1) * n / G), builds that subtree on its GPU, the G subtree roots (40 bytes
+    each) are all-gathered, and every rank finishes the top log2(G) levels itself -- the only traffic is G x 40 bytes.
+
+    local_leaves      (n / G, 5) int64 tensor on this rank's device
+    build_subtree(l)  -> this rank's subtree as a (2 n / G, 5) node tensor in heap order (nodes[1] = subtree root), e.g.
+                         tf.device.merkle_build; the oracle in the CPU test
+    finish_top(r)     -> node array (2 G, 5) of the tree whose leaves are the G gathered subtree roots (same builder, G leaves)
+    Returns (root (5,), local_subtree_nodes, top_nodes).  global_node() below maps a heap index of the whole tree to its
+    place: the top G - 1 internal nodes are top_nodes[1 .. G), everything deeper sits in one rank's subtree."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    if world & (world - 1):
+        raise ValueError("a single tree shards over a power-of-two number of ranks (the reference's subtree split)")
+    sub = build_subtree(local_leaves)
+    sub_root = sub.reshape(-1, 5)[1:2].contiguous()
+    if world == 1:
+        return sub_root[0], sub, sub.reshape(-1, 5)[:2]
+    gathered = gather_roots(sub_root, world)          # (G, 5), rank order = leaf order
+    top = finish_top(gathered)
+    return top.reshape(-1, 5)[1], sub, top
+
+
+def global_node(index: int, num_leafs: int, world_size: int):
+    """Where node `index` (heap order, 1 = root) of a tree sharded by sharded_tree lives: ("top", i) for the top
+    log2(G) levels (index < G; i = index in the top tree), else ("rank", g, local) with `local` the heap index inside rank g's
+    subtree.  Mirrors the index arithmetic of subtrees_mut (util_types/merkle_tree.rs:247-275)."""
+    if index < 1 or index >= 2 * num_leafs:
+        raise IndexError(index)
+    if index < world_size:
+        return ("top", index)
+    depth = index.bit_length() - 1
+    g_depth = world_size.bit_length() - 1
+    rank = (index >> (depth - g_depth)) - world_size
+    local = (1 << (depth - g_depth)) | (index & ((1 << (depth - g_depth)) - 1))
+    return ("rank", rank, local)
