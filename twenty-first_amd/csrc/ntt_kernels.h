@@ -275,7 +275,7 @@ __device__ __forceinline__ u32 div_by_L(u32 v, int L) {  // v / L for L in {1, 3
 //            (polynomial.rs:1907-1918: intt, then scale by the inverse offset).
 // MODE: 0 = product kernel.  1 / 2 are measurement-only ablations (TF_NTT_ABLATE, never the default):
 //   1 = no global loads/stores (synthetic operands), 2 = no arithmetic (loads, LDS exchange, stores only).
-template <bool INV, int SCALE, int MODE = 0, bool LAST1024 = false, bool R1024 = false>
+template <bool INV, int SCALE, int MODE = 0, bool LAST1024 = false, bool R1024 = false, bool COL = false>
 #ifndef TF_PRIO_LOAD
 #define TF_PRIO_LOAD 3
 #endif
@@ -295,8 +295,11 @@ __global__ void __launch_bounds__(512, TF_NTT_WAVES) ntt_pass_kernel(const NttPa
     // Lazy networks (TF_LAZY): step 1 of the R = 1024 instantiations is always followed by the inner-twiddle Montgomery product,
     // step 2 of the column pass by the inter-pass one; a Montgomery product takes any 64-bit representative and returns the
     // canonical word, so these networks run on non-canonical words (8 VALU per butterfly).  Everything else stays canonical.
-    constexpr bool LAZY1 = (LAST1024 || R1024) && MODE != 2;
-    constexpr bool LAZY2 = R1024 && MODE == 0;
+    // COL: any column pass (inter-pass table present) of a plan whose offsets fit the buffer window -- the R1024 treatment
+    // (lazy networks, buffer addressing) with a run-time P2; R1024 is its constant-P2 special case.
+    constexpr bool COLP = R1024 || COL;
+    constexpr bool LAZY1 = (LAST1024 || COLP) && MODE != 2;
+    constexpr bool LAZY2 = COLP && MODE == 0;
     const int L = A.L;
 
     u32 i0, i1, i2;
@@ -400,10 +403,10 @@ __global__ void __launch_bounds__(512, TF_NTT_WAVES) ntt_pass_kernel(const NttPa
     } else if (act_in) {
         const u32 toff = (u32)(((long long)ch_in * A.in_cs_hi + cl_in + (long long)g_in * A.in_rs) * 8);
         const char* base = reinterpret_cast<const char*>(in);
-        if constexpr ((LAST1024 || R1024) && SCALE != 1) {
+        if constexpr ((LAST1024 || COLP) && SCALE != 1) {
             const __amdgpu_buffer_rsrc_t ri = buf_rsrc(in);
 #pragma unroll
-            for (int q = 0; q < 32; ++q) x[q] = buf_load(ri, toff, (u32)((long long)(brev5(q) << 5) * A.in_rs * 8));
+            for (int q = 0; q < 32; ++q) x[q] = buf_load(ri, toff, (u32)((long long)(brev5(q) << p2) * A.in_rs * 8));
         } else
 #pragma unroll
         for (int q = 0; q < 32; ++q) {
@@ -468,7 +471,8 @@ __global__ void __launch_bounds__(512, TF_NTT_WAVES) ntt_pass_kernel(const NttPa
     if constexpr (MODE != 2) {
         dit_half<INV, 16, LAZY1>(x);
         dit_level<INV, 5, LAZY1>(x);
-        if (LAZY1 || A.inner_tw) {  // (the R = 1024 instantiations always have an inner table: launch_pass checks)
+        if ((LAST1024 || R1024) || A.inner_tw) {  // (the R = 1024 instantiations always have an inner table: launch_pass checks;
+                                                  //  a lazy COL pass without one is R = 32: the inter-pass product follows directly)
             const u64* tw = LDS_TW ? ltw + g_in * kLdsTwStride : A.inner_tw + g_in * 32;
 #pragma unroll
             for (int q = 0; q < 32; q += 2) gl::mont_mul2(x[q], tw[q], x[q + 1], tw[q + 1], x[q], x[q + 1]);
@@ -584,11 +588,11 @@ __global__ void __launch_bounds__(512, TF_NTT_WAVES) ntt_pass_kernel(const NttPa
     } else if (act) {
         const u32 toff = (u32)(((long long)ch * A.out_cs_hi + cl + (long long)g * A.out_rs) * 8);
         char* base = reinterpret_cast<char*>(out);
-        if ((R1024 && MODE == 0) || (MODE != 2 && A.post_tw)) {  // (R1024 is only launched with an inter-pass table)
+        if ((COLP && MODE == 0) || (MODE != 2 && A.post_tw)) {  // (R1024 / COL are only launched with an inter-pass table)
             // inter-pass twiddle: 8 table words at a time (bounded register footprint), multiply, store
             const u32 twoff = (u32)(((long long)g * A.tw_rs + bcol) * 8);
             const char* tbase = reinterpret_cast<const char*>(A.post_tw);
-            const __amdgpu_buffer_rsrc_t rt = buf_rsrc(A.post_tw), ro = buf_rsrc(out);  // used by the R1024 instantiation only
+            const __amdgpu_buffer_rsrc_t rt = buf_rsrc(A.post_tw), ro = buf_rsrc(out);  // used by the R1024 / COL instantiations only
 #pragma unroll
             for (int q0 = 0; q0 < 32; q0 += 8) {
                 u64 w[8];
@@ -596,7 +600,7 @@ __global__ void __launch_bounds__(512, TF_NTT_WAVES) ntt_pass_kernel(const NttPa
                 for (int i = 0; i < 8; ++i) {
                     const int q = q0 + i;
                     const long long uk = (long long)(((q >> p2) << p2) + ((q & (P2 - 1)) << 5));  // uniform part of k
-                    if constexpr (R1024) w[i] = buf_load_tab(rt, twoff, (u32)(uk * A.tw_rs * 8));
+                    if constexpr (COLP) w[i] = buf_load_tab(rt, twoff, (u32)(uk * A.tw_rs * 8));
                     else w[i] = *reinterpret_cast<const u64*>(tbase + uk * A.tw_rs * 8 + twoff);
                 }
 #pragma unroll
@@ -606,7 +610,7 @@ __global__ void __launch_bounds__(512, TF_NTT_WAVES) ntt_pass_kernel(const NttPa
                     const long long uk1 = (long long)((((q + 1) >> p2) << p2) + (((q + 1) & (P2 - 1)) << 5));
                     u64 r0, r1;
                     gl::mont_mul2(x[q], w[i], x[q + 1], w[i + 1], r0, r1);
-                    if constexpr (R1024) {
+                    if constexpr (COLP) {
                         buf_store(ro, toff, (u32)(uk0 * A.out_rs * 8), r0);
                         buf_store(ro, toff, (u32)(uk1 * A.out_rs * 8), r1);
                     } else {

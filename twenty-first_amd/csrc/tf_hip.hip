@@ -689,6 +689,11 @@ bool last1024_enabled() {
     return !off && ablate_mode() == 0 && !t_small_launch;
 }
 
+bool col_enabled() {
+    static const bool off = getenv("TF_NTT_NO_COL") != nullptr;  // A/B switch
+    return !off;
+}
+
 // ... and its variant that multiplies on store (fast_coset_interpolate)
 bool scaled_last1024_enabled() {
     static const bool off = getenv("TF_NTT_NO_SCALED_LAST1024") != nullptr;  // A/B switch
@@ -807,7 +812,7 @@ Launch plan_row_pass(const u64* in, u64* out, long long in_bs, long long out_bs,
     return l;
 }
 
-template <bool INV, int SCALE, int MODE, bool LAST1024 = false, bool R1024 = false>
+template <bool INV, int SCALE, int MODE, bool LAST1024 = false, bool R1024 = false, bool COL = false>
 int launch_pass_t(const Launch& l, hipStream_t stream) {
     // one attribute call per (instantiation, device): the kernels use up to the full 160 KiB of dynamic LDS
     static std::atomic<unsigned long long> done_mask{0};
@@ -815,14 +820,14 @@ int launch_pass_t(const Launch& l, hipStream_t stream) {
     HIPCHK(hipGetDevice(&dev));
     const unsigned long long bit = 1ull << (dev & 63);
     if (!(done_mask.load(std::memory_order_acquire) & bit)) {
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&tfk::ntt_pass_kernel<INV, SCALE, MODE, LAST1024, R1024>),
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&tfk::ntt_pass_kernel<INV, SCALE, MODE, LAST1024, R1024, COL>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         done_mask.fetch_or(bit, std::memory_order_release);
     }
     // the R = 1024 column-pass instantiation stages its inner twiddle table behind the exchange buffer (LAST1024: part of
     // kLast1024LdsBytes already)
     const size_t lds_bytes = l.lds_bytes + ((TF_LDS_TW && !LAST1024 && MODE == 0 && l.a.inner_tw) ? (size_t(1) << l.a.p2) * tfk::kLdsTwStride * sizeof(u64) : 0);
-    hipLaunchKernelGGL((tfk::ntt_pass_kernel<INV, SCALE, MODE, LAST1024, R1024>), dim3(l.tiles), dim3(l.threads), lds_bytes, stream,
+    hipLaunchKernelGGL((tfk::ntt_pass_kernel<INV, SCALE, MODE, LAST1024, R1024, COL>), dim3(l.tiles), dim3(l.threads), lds_bytes, stream,
                        l.a);
     HIPCHK(hipGetLastError());
     return TF_OK;
@@ -856,6 +861,7 @@ int launch_pass(const Launch& l, bool inverse, hipStream_t stream) {
         static const bool no_r1024_scale = getenv("TF_NTT_NO_R1024") != nullptr;
         if (inverse) return launch_pass_t<true, 1, 0>(l, stream);
         if (l.a.p2 == 5 && l.a.post_tw && !no_r1024_scale && fits) return launch_pass_t<false, 1, 0, false, true>(l, stream);
+        if (l.a.post_tw && fits && !l.a.gfast && col_enabled()) return launch_pass_t<false, 1, 0, false, false, true>(l, stream);
         return launch_pass_t<false, 1, 0>(l, stream);
     }
     if (l.a.post_scale) {  // coset interpolation: inverse, scale on store
@@ -878,8 +884,12 @@ int launch_pass(const Launch& l, bool inverse, hipStream_t stream) {
         l2.threads = 512;  // 16 column slots x 32, also for tiles of 15 word-columns (XFE)
         return inverse ? launch_pass_t<true, 0, 0, true>(l2, stream) : launch_pass_t<false, 0, 0, true>(l2, stream);
     }
-    if (inverse) return r1024 ? launch_pass_t<true, 0, 0, false, true>(l, stream) : launch_pass_t<true, 0, 0>(l, stream);
+    // any other column pass whose offsets fit: the same treatment with a run-time P2 (COL)
+    const bool col = l.a.post_tw && !r1024 && fits && !l.a.gfast && g_ablate == 0 && col_enabled();
+    if (inverse) return r1024 ? launch_pass_t<true, 0, 0, false, true>(l, stream)
+                              : (col ? launch_pass_t<true, 0, 0, false, false, true>(l, stream) : launch_pass_t<true, 0, 0>(l, stream));
     if (r1024) return launch_pass_t<false, 0, 0, false, true>(l, stream);
+    if (col) return launch_pass_t<false, 0, 0, false, false, true>(l, stream);
     if (g_ablate == 1) return launch_pass_t<false, 0, 1>(l, stream);
     if (g_ablate == 2) return launch_pass_t<false, 0, 2>(l, stream);
     if (g_ablate == 3) {
@@ -1024,6 +1034,10 @@ void choose_split(int log_n, int P, int L, int (&a)[4]) {
             // 2^23 2.34 vs 2.45, 2^25 2.49 vs 2.51 per 3 * 2^26 words; BFE 2^22 2.90 vs 3.04, 2^23 3.01 vs 3.09 per 2^28)
             a[1] = 5;
             a[0] = rest - 5;
+            // BFieldElement 2^21 / 2^22: the radix-32 pass first, (5, log_n - 15, 10) -- since the column passes run lazy networks
+            // through buffer addressing (COL) the order matters only there: 2^21 2.49 vs 2.71 ms, 2^22 2.54 vs 2.59 ms per 2^28
+            // words; from 2^23 on and for XFieldElement slices both orders measure the same (tools/split3_ab.py)
+            if (L == 1 && log_n <= 22) a[0] = 5, a[1] = rest - 5;
         } else {
             for (int i = 0; i + 1 < P; ++i) {
                 a[i] = (rest + (P - 1 - i) - 1) / (P - 1 - i);
