@@ -29,6 +29,14 @@ __device__ __forceinline__ void step(u64 (&x)[NV]) {
     } else if constexpr (OP == 3) {  // mont_mul2
 #pragma unroll
         for (int i = 0; i < NV; i += 4) gl::mont_mul2(x[i], x[i + 1], x[i + 2], x[i + 3], x[i], x[i + 2]);
+    } else if constexpr (OP == 10) {  // mont_mul4: four products per block, no s_nop
+#pragma unroll
+        for (int i = 0; i < NV; i += 8) {
+            const u64 a4[4] = {x[i], x[i + 2], x[i + 4], x[i + 6]}, b4[4] = {x[i + 1], x[i + 3], x[i + 5], x[i + 7]};
+            u64 r4[4];
+            gl::mont_mul4(a4, b4, r4);
+            x[i] = r4[0], x[i + 2] = r4[1], x[i + 4] = r4[2], x[i + 6] = r4[3];
+        }
     } else if constexpr (OP == 4) {  // shl_fold<7> (compiler-scheduled)
 #pragma unroll
         for (int i = 0; i < NV; ++i) x[i] = gl::shl_fold<7>(x[i]);
@@ -98,6 +106,13 @@ __global__ void check(const u64* a, const u64* b, int n, int* bad) {
     const unsigned __int128 R = ((unsigned __int128)1 << 64) % gl::P;
     if (ref_mod((unsigned __int128)m0 * R) != ref_mod((unsigned __int128)(A % gl::P) * Bc) || m0 >= gl::P) e |= 16;
     if (ref_mod((unsigned __int128)m1 * R) != ref_mod((unsigned __int128)(B % gl::P) * Ac) || m1 >= gl::P) e |= 16;
+    {
+        const u64 a4[4] = {A, B, Ac, Bp}, b4[4] = {Bc, Ac, Bc, Ac};
+        u64 r4[4];
+        gl::mont_mul4(a4, b4, r4);
+        for (int i = 0; i < 4; ++i)
+            if (ref_mod((unsigned __int128)r4[i] * R) != ref_mod((unsigned __int128)(a4[i] % gl::P) * b4[i]) || r4[i] >= gl::P) e |= 32;
+    }
     if (e) atomicOr(bad, e);
 }
 
@@ -163,7 +178,7 @@ int main() {
     hipLaunchKernelGGL(check, dim3(n / 256), dim3(256), 0, 0, da, db, n, d_bad);
     int bad = 0;
     CK(hipMemcpy(&bad, d_bad, 4, hipMemcpyDeviceToHost));
-    printf("block check on %d operand pairs (edge x edge + random): %s (mask %d: 1 add_sub2, 2 add_sub_lazy2, 4 add_sub, 8 shl_fold, 16 mont_mul2 lazy operand)\n",
+    printf("block check on %d operand pairs (edge x edge + random): %s (mask %d: 1 add_sub2, 2 add_sub_lazy2, 4 add_sub, 8 shl_fold, 16 mont_mul2 lazy operand, 32 mont_mul4)\n",
            n, bad ? "MISMATCH" : "all bit-exact", bad);
     CK(hipMalloc(&d_out, (size_t)256 * 8 * 256 * 8 * 2));
     CK(hipMalloc(&d_cyc, (size_t)256 * 8 * 4 * 8 * 2));
@@ -172,6 +187,7 @@ int main() {
     run<2>("add_sub_lazy2", 8, NV / 2, d_out, d_cyc);
     run<6>("add+sub (cc)", 12, NV / 2, d_out, d_cyc);
     run<3>("mont_mul2", 15, NV / 2, d_out, d_cyc);
+    run<10>("mont_mul4", 15, NV / 2, d_out, d_cyc);
     run<7>("mont_mul (cc)", 18, NV / 2, d_out, d_cyc);
     run<4>("shl_fold<7>", 8, NV, d_out, d_cyc);
     run<5>("shl_monty<14>", 10, NV, d_out, d_cyc);

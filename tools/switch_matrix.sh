@@ -1,0 +1,38 @@
+#!/bin/bash
+# tools/switch_matrix.sh [outfile] -- the whole GPU suite under every A/B switch of the library in turn (each alternative path
+# must be bit-exact too), then the long randomised parity run on the default build.
+set -u
+REPO=$(cd "$(dirname "$0")/.." && pwd)
+OUT=${1:-$REPO/gpurun_out/switch_matrix.txt}
+mkdir -p "$(dirname "$OUT")"
+cd "$REPO"
+: > "$OUT"
+run() {  # <env assignment> <description>
+  local res
+  res=$(env $1 timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -n 1)
+  printf "%-34s %-100s %s\n" "$1" "($2)" "$res" | tee -a "$OUT"
+}
+run "TF_DEFAULT=1" "no switch: the shipped plan"
+run "TF_NTT_TILE_BYTES=33554432" "32 MiB scratch slabs: every batched multi-pass transform runs in many tiles"
+run "TF_NTT_TILE_BYTES=33554432 TF_NTT_PIPE=3" "... dealt to three side streams"
+run "TF_NTT_NO_LAST1024=1" "generic kernel instead of the R = 1024 last-pass specialisation"
+run "TF_NTT_NO_R1024=1" "run-time-P2 column pass (COL) instead of the constant-P2 one"
+run "TF_NTT_NO_COL=1" "generic kernel (canonical networks, plain pointers) for the column passes other than R = 1024"
+run "TF_NTT_NO_R1024=1 TF_NTT_NO_COL=1" "generic kernel for every column pass"
+run "TF_NTT_NO_GFAST=1" "single-pass transforms with the column-major thread order"
+run "TF_COSET_EVAL_NO_SPLIT=1" "blown-up coset evaluation by zero padding instead of interleaved cosets"
+run "TF_POLY_MUL_NO_FUSE=1" "fast_multiply with separate pad / Hadamard / truncate passes"
+run "TF_NTT_NO_BLOCK=1" "two-pass plans instead of the whole-transform-per-workgroup kernel, 2^11..2^14"
+run "TF_NTT_NO_ROWS32=1" "direct loads instead of LDS-staged rows for 32-point BFE transforms"
+run "TF_NTT_NO_WORDS16=1" "XFE rows through the last passes as tiles of whole elements, not whole cache lines"
+run "TF_NTT_NO_COL_SHIFT=1" "last-pass tile boundaries not shifted to the output's cache-line alignment"
+run "TF_NTT_NO_SCALED_LAST1024=1" "generic last pass for fast_coset_interpolate instead of the R = 1024 kernel's scaled tail"
+run "TF_NTT_NO_SMALL_LAUNCH=1" "512-thread tiles and the R = 1024 last pass for small calls too"
+run "TF_NTT_WG_THREADS=256" "256-thread workgroups everywhere"
+run "TF_NTT_NT=3" "non-temporal loads / stores in the generic kernels as well"
+run "TF_BATCH_EVAL=tree" "zerofier tree wherever it applies"
+run "TF_BATCH_EVAL=horner" "Horner everywhere"
+echo "--- long randomised parity run (tools/fuzz_long.py, 3 seeds x 120 s)" | tee -a "$OUT"
+for seed in 11 12 13; do
+  timeout 400 python tools/fuzz_long.py $seed 120 2>&1 | grep -v amdgpu.ids | tail -n 3 | tee -a "$OUT"
+done

@@ -134,6 +134,8 @@ struct TwExp {
 // profiles/r02b_ab_variants.txt); staged once per workgroup behind the exchange buffer, rows padded to 34 words (272 bytes:
 // 16-byte aligned for ds_read_b128, consecutive rows 4 banks apart), the reads are conflict-free LDS traffic.
 constexpr int kLdsTwStride = 34;
+// exchange geometry of the R1024 instantiation (= what finish_geometry computes for 512 threads and rounds of 8 192 elements)
+constexpr int kR1024Nc = 16, kR1024Cpr = 8, kR1024Rounds = 2, kR1024S1 = 264;
 // LAST1024 exchange layout: element (k1, g, cc) at k1 * kL1024S1 + cc * kL1024CS + g  (see the kernel)
 constexpr int kL1024S1 = 273, kL1024CS = 34;
 constexpr int kL1024ExchangeWords = ((31 * kL1024S1 + 7 * kL1024CS + 32 + 1) / 2) * 2;  // 16-byte aligned end
@@ -229,6 +231,14 @@ __device__ __forceinline__ void dit_half(u64 (&x)[32]) {
     DitRange<INV, 2, FIRST / 2, FIRST / 2 + 8, LAZY && TF_LAZY>::run(x);
     DitRange<INV, 3, FIRST / 2, FIRST / 2 + 8, LAZY && TF_LAZY>::run(x);
     DitRange<INV, 4, FIRST / 2, FIRST / 2 + 8, LAZY && TF_LAZY>::run(x);
+}
+
+// x[q0 .. q0+3] *= w[0 .. 3]  (four Montgomery products, no wait-state nops: gl::mont_mul4)
+__device__ __forceinline__ void mul4_inplace(u64 (&x)[32], int q0, u64 w0, u64 w1, u64 w2, u64 w3) {
+    const u64 a4[4] = {x[q0], x[q0 + 1], x[q0 + 2], x[q0 + 3]}, b4[4] = {w0, w1, w2, w3};
+    u64 r4[4];
+    gl::mont_mul4(a4, b4, r4);
+    x[q0] = r4[0], x[q0 + 1] = r4[1], x[q0 + 2] = r4[2], x[q0 + 3] = r4[3];
 }
 
 // Level 5 of the radix-32 network for the four butterflies (Q0+i, Q0+i+16), i < 4, followed by their eight stores.
@@ -339,8 +349,14 @@ __global__ void __launch_bounds__(512, TF_NTT_WAVES) ntt_pass_kernel(const NttPa
     // segments are whole lines as well), without the shift.
     const bool wt = LAST1024 || A.wtiles;
     const int cshift = LAST1024 ? (int)((A.col_shift0 + i0 * (u32)A.col_shift_i0) & 15u) : 0;
-    const int col0 = (int)i2 * A.nc - cshift;
-    const int ncv = min(A.nc, A.col_limit - col0);
+    // R1024: the planner launches this instantiation only with the standard geometry (512 threads, 16 columns, exchange rounds of
+    // 8 columns: kR1024* below), so the role arithmetic and every LDS offset of the exchange fold into immediates
+    constexpr bool GEO = R1024;
+    const int nc_ = GEO ? kR1024Nc : A.nc;
+    const int cpr_ = GEO ? kR1024Cpr : A.cpr, nrounds_ = GEO ? kR1024Rounds : A.nrounds;
+    const int s1_ = GEO ? kR1024S1 : A.s1, s2_ = GEO ? kR1024Cpr : A.s2, s3_ = GEO ? 1 : A.s3;
+    const int col0 = (int)i2 * nc_ - cshift;
+    const int ncv = min(nc_, A.col_limit - col0);
     const int ch0 = wt ? (int)div_by_L((u32)max(col0, 0), L) : 0;  // first element column of the tile (uniform)
     if (wt) {
         in = A.in + (long long)i0 * A.ib0 + (long long)i1 * A.ib1 + (long long)ch0 * A.in_cs_hi;
@@ -349,8 +365,8 @@ __global__ void __launch_bounds__(512, TF_NTT_WAVES) ntt_pass_kernel(const NttPa
 
     // LAST1024 always runs 512 threads in 16 column slots
     // gfast (single-pass transforms, whose "columns" are whole rows of contiguous elements): lanes along the row, g = t % P2
-    const int g = LAST1024 ? (t >> 4) : (A.gfast ? (t & (P2 - 1)) : (A.nc == 1 ? t : (int)__umulhi((u32)t, A.nc_magic)));  // t / nc
-    const int c = LAST1024 ? (t & 15) : (A.gfast ? (t >> p2) : (t - g * A.nc));                                              // t % nc
+    const int g = (LAST1024 || GEO) ? (t >> 4) : (A.gfast ? (t & (P2 - 1)) : (A.nc == 1 ? t : (int)__umulhi((u32)t, A.nc_magic)));  // t / nc
+    const int c = (LAST1024 || GEO) ? (t & 15) : (A.gfast ? (t >> p2) : (t - g * A.nc));                                              // t % nc
     const bool act = c < ncv;
     int ch, cl;  // element column relative to the tile base, limb
     if (wt) {
@@ -388,7 +404,7 @@ __global__ void __launch_bounds__(512, TF_NTT_WAVES) ntt_pass_kernel(const NttPa
 #pragma unroll
     for (int q = 0; q < 32; ++q) x[q] = 0;
     constexpr bool LDS_TW = TF_LDS_TW && MODE == 0;
-    u64* const ltw = lds + (LAST1024 ? kL1024ExchangeWords : 32 * A.s1);  // the staged inner table [P2][32], behind the exchange buffer
+    u64* const ltw = lds + (LAST1024 ? kL1024ExchangeWords : 32 * s1_);  // the staged inner table [P2][32], behind the exchange buffer
     if constexpr (LDS_TW) {
         if ((LAST1024 || R1024) || A.inner_tw) {  // uniform
             for (int i = t; i < 32 * P2; i += blockDim.x) ltw[(i >> 5) * kLdsTwStride + (i & 31)] = A.inner_tw[i];
@@ -437,7 +453,7 @@ __global__ void __launch_bounds__(512, TF_NTT_WAVES) ntt_pass_kernel(const NttPa
                     w[i] = *reinterpret_cast<const u64*>(base2 + ur * A.in_rs * 8 + toff2);
                 }
 #pragma unroll
-                for (int i = 0; i < 8; i += 2) gl::mont_mul2(x[q0 + i], w[i], x[q0 + i + 1], w[i + 1], x[q0 + i], x[q0 + i + 1]);
+                for (int i = 0; i < 8; i += 4) mul4_inplace(x, q0 + i, w[i], w[i + 1], w[i + 2], w[i + 3]);
             }
         }
         if (act_in && A.pre_scale) {
@@ -452,7 +468,7 @@ __global__ void __launch_bounds__(512, TF_NTT_WAVES) ntt_pass_kernel(const NttPa
                     w[i] = ps[j < A.n_coeffs ? j : 0];
                 }
 #pragma unroll
-                for (int i = 0; i < 8; i += 2) gl::mont_mul2(x[q0 + i], w[i], x[q0 + i + 1], w[i + 1], x[q0 + i], x[q0 + i + 1]);
+                for (int i = 0; i < 8; i += 4) mul4_inplace(x, q0 + i, w[i], w[i + 1], w[i + 2], w[i + 3]);
             }
         }
     }
@@ -475,7 +491,7 @@ __global__ void __launch_bounds__(512, TF_NTT_WAVES) ntt_pass_kernel(const NttPa
                                                   //  a lazy COL pass without one is R = 32: the inter-pass product follows directly)
             const u64* tw = LDS_TW ? ltw + g_in * kLdsTwStride : A.inner_tw + g_in * 32;
 #pragma unroll
-            for (int q = 0; q < 32; q += 2) gl::mont_mul2(x[q], tw[q], x[q + 1], tw[q + 1], x[q], x[q + 1]);
+            for (int q = 0; q < 32; q += 4) mul4_inplace(x, q, tw[q], tw[q + 1], tw[q + 2], tw[q + 3]);
         }
     }
     if constexpr (MODE == 3) { asm volatile("" :: "v"(x[0]), "v"(x[31])); stamp[3] = __builtin_readcyclecounter(); }
@@ -509,16 +525,16 @@ __global__ void __launch_bounds__(512, TF_NTT_WAVES) ntt_pass_kernel(const NttPa
             }
         }
     } else if (p2 != 0) {  // R = 32: step 1 is the whole transform and every element stays with its thread
-        const int myround = c / A.cpr;
-        const int cc = c - myround * A.cpr;
-        u64* wr = lds + g * A.s2 + cc * A.s3;
-        const u64* rd = lds + cc * A.s3;
+        const int myround = c / cpr_;
+        const int cc = c - myround * cpr_;
+        u64* wr = lds + g * s2_ + cc * s3_;
+        const u64* rd = lds + cc * s3_;
 #pragma unroll 1
-        for (int r = 0; r < A.nrounds; ++r) {
+        for (int r = 0; r < nrounds_; ++r) {
             if (r) __syncthreads();
             if (myround == r) {
 #pragma unroll
-                for (int q = 0; q < 32; ++q) wr[q * A.s1] = x[q];
+                for (int q = 0; q < 32; ++q) wr[q * s1_] = x[q];
             }
             __syncthreads();
             if (myround == r) {
@@ -528,7 +544,7 @@ __global__ void __launch_bounds__(512, TF_NTT_WAVES) ntt_pass_kernel(const NttPa
                     const int gbr = q & (P2 - 1);  // uniform
                     const int gg = p2 ? (int)(__brev((unsigned)gbr) >> (32 - p2)) : 0;
                     const int k1 = g + (s << p2);
-                    x[q] = rd[k1 * A.s1 + gg * A.s2];
+                    x[q] = rd[k1 * s1_ + gg * s2_];
                 }
             }
         }
@@ -604,18 +620,16 @@ __global__ void __launch_bounds__(512, TF_NTT_WAVES) ntt_pass_kernel(const NttPa
                     else w[i] = *reinterpret_cast<const u64*>(tbase + uk * A.tw_rs * 8 + twoff);
                 }
 #pragma unroll
-                for (int i = 0; i < 8; i += 2) {
+                for (int i = 0; i < 8; i += 4) {
                     const int q = q0 + i;
-                    const long long uk0 = (long long)(((q >> p2) << p2) + ((q & (P2 - 1)) << 5));  // uniform part of k
-                    const long long uk1 = (long long)((((q + 1) >> p2) << p2) + (((q + 1) & (P2 - 1)) << 5));
-                    u64 r0, r1;
-                    gl::mont_mul2(x[q], w[i], x[q + 1], w[i + 1], r0, r1);
-                    if constexpr (COLP) {
-                        buf_store(ro, toff, (u32)(uk0 * A.out_rs * 8), r0);
-                        buf_store(ro, toff, (u32)(uk1 * A.out_rs * 8), r1);
-                    } else {
-                        *reinterpret_cast<u64*>(base + uk0 * A.out_rs * 8 + toff) = r0;
-                        *reinterpret_cast<u64*>(base + uk1 * A.out_rs * 8 + toff) = r1;
+                    const u64 a4[4] = {x[q], x[q + 1], x[q + 2], x[q + 3]}, b4[4] = {w[i], w[i + 1], w[i + 2], w[i + 3]};
+                    u64 r4[4];
+                    gl::mont_mul4(a4, b4, r4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const long long uk = (long long)((((q + e) >> p2) << p2) + (((q + e) & (P2 - 1)) << 5));  // uniform part of k
+                        if constexpr (COLP) buf_store(ro, toff, (u32)(uk * A.out_rs * 8), r4[e]);
+                        else *reinterpret_cast<u64*>(base + uk * A.out_rs * 8 + toff) = r4[e];
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -714,7 +728,7 @@ __global__ void __launch_bounds__(512, 4) ntt_block_kernel(const NttBlockArgs A)
 #pragma unroll
                 for (int i = 0; i < 8; ++i) w[i] = actA ? src2[(long long)brev5(q0 + i) * REST] : 0;
 #pragma unroll
-                for (int i = 0; i < 8; i += 2) gl::mont_mul2(x[q0 + i], w[i], x[q0 + i + 1], w[i + 1], x[q0 + i], x[q0 + i + 1]);
+                for (int i = 0; i < 8; i += 4) mul4_inplace(x, q0 + i, w[i], w[i + 1], w[i + 2], w[i + 3]);
             }
         }
         if (SCALE == 1 && A.pre_scale) {
@@ -728,7 +742,7 @@ __global__ void __launch_bounds__(512, 4) ntt_block_kernel(const NttBlockArgs A)
                     w[i] = ps[j < lim ? brev5(q0 + i) * REST : -rest];  // clamp to entry 0 beyond the coefficients (value unused: x is 0)
                 }
 #pragma unroll
-                for (int i = 0; i < 8; i += 2) gl::mont_mul2(x[q0 + i], w[i], x[q0 + i + 1], w[i + 1], x[q0 + i], x[q0 + i + 1]);
+                for (int i = 0; i < 8; i += 4) mul4_inplace(x, q0 + i, w[i], w[i + 1], w[i + 2], w[i + 3]);
             }
         }
     }
@@ -738,7 +752,8 @@ __global__ void __launch_bounds__(512, 4) ntt_block_kernel(const NttBlockArgs A)
     {
         const u64* tw = A.tw1 + rest;
 #pragma unroll
-        for (int q = 2; q < 32; q += 2) gl::mont_mul2(x[q], tw[q * REST], x[q + 1], tw[(q + 1) * REST], x[q], x[q + 1]);
+        for (int q = 4; q < 32; q += 4) mul4_inplace(x, q, tw[q * REST], tw[(q + 1) * REST], tw[(q + 2) * REST], tw[(q + 3) * REST]);
+        gl::mont_mul2(x[2], tw[2 * REST], x[3], tw[3 * REST], x[2], x[3]);
         x[1] = gl::mont_mul(x[1], tw[REST]);  // k1 = 0: factor 1
 #if TF_LAZY
         x[0] = gl::add(x[0], 0);              // ... so the word is only made canonical
@@ -776,7 +791,7 @@ __global__ void __launch_bounds__(512, 4) ntt_block_kernel(const NttBlockArgs A)
     {
         const u64* tw = A.tw2 + j3B;
 #pragma unroll
-        for (int q = 0; q < 32; q += 2) gl::mont_mul2(x[q], tw[q * P3], x[q + 1], tw[(q + 1) * P3], x[q], x[q + 1]);
+        for (int q = 0; q < 32; q += 4) mul4_inplace(x, q, tw[q * P3], tw[(q + 1) * P3], tw[(q + 2) * P3], tw[(q + 3) * P3]);
     }
     // ---- exchange 2: (k1, k2 = q, j3, tr) -> thread (tr, s, k1) holding k2 in [s * 32 / P3, ..) x all j3
     const int trC = trB, sC = j3B, k1C = k1B;  // same thread index decomposition, s takes j3's bit positions
@@ -898,7 +913,7 @@ __global__ void __launch_bounds__(512, 4) ntt_rows32_kernel(const NttRows32Args 
     dit_level<INV, 5, INV>(x);
     if (INV) {
 #pragma unroll
-        for (int q = 0; q < 32; q += 2) gl::mont_mul2(x[q], A.scale, x[q + 1], A.scale, x[q], x[q + 1]);
+        for (int q = 0; q < 32; q += 4) mul4_inplace(x, q, A.scale, A.scale, A.scale, A.scale);
     }
 #pragma unroll 1
     for (int h = 0; h < 2; ++h) {

@@ -849,6 +849,9 @@ int launch_pass(const Launch& l, bool inverse, hipStream_t stream) {
     }
     // the plain R = 1024 last-pass kernel: the only one that truncates its output and shifts its tiles
     const bool fits = fits_buffer_offsets(l);
+    // the constant-geometry column pass (R1024) only with exactly the geometry its immediates assume; anything else is COL's
+    const bool std_geo = l.threads == 512 && l.a.nc == tfk::kR1024Nc && l.a.cpr == tfk::kR1024Cpr && l.a.nrounds == tfk::kR1024Rounds &&
+                         l.a.s1 == tfk::kR1024S1 && l.a.s2 == tfk::kR1024Cpr && l.a.s3 == 1 && !l.a.gfast;
     const bool plain_last1024 = l.a.p2 == 5 && !l.a.post_tw && !l.a.gfast && !l.a.pre_scale && l.a.n_coeffs < 0 && !l.a.in2 &&
                                 (!l.a.post_scale || (inverse && scaled_last1024_enabled())) && last1024_enabled() && fits;
     if ((l.a.n_out >= 0 || l.a.col_shift0 || l.a.col_shift_i0) && !plain_last1024) {  // anything else would overrun the caller's buffer
@@ -860,7 +863,7 @@ int launch_pass(const Launch& l, bool inverse, hipStream_t stream) {
         // constant-P2 variant for a forward first pass with R = 1024)
         static const bool no_r1024_scale = getenv("TF_NTT_NO_R1024") != nullptr;
         if (inverse) return launch_pass_t<true, 1, 0>(l, stream);
-        if (l.a.p2 == 5 && l.a.post_tw && !no_r1024_scale && fits) return launch_pass_t<false, 1, 0, false, true>(l, stream);
+        if (l.a.p2 == 5 && l.a.post_tw && !no_r1024_scale && fits && std_geo) return launch_pass_t<false, 1, 0, false, true>(l, stream);
         if (l.a.post_tw && fits && !l.a.gfast && col_enabled()) return launch_pass_t<false, 1, 0, false, false, true>(l, stream);
         return launch_pass_t<false, 1, 0>(l, stream);
     }
@@ -877,7 +880,7 @@ int launch_pass(const Launch& l, bool inverse, hipStream_t stream) {
     // (not for single-pass transforms: their stores run along the row as well, which only the gfast roles give -- 1.05 vs 1.20 ms)
     const bool last1024 = l.a.p2 == 5 && !l.a.post_tw && last1024_enabled() && !l.a.gfast && fits;
     static const bool no_r1024 = getenv("TF_NTT_NO_R1024") != nullptr;  // A/B switch
-    const bool r1024 = l.a.p2 == 5 && l.a.post_tw && g_ablate == 0 && !no_r1024 && fits;  // column pass with R = 1024
+    const bool r1024 = l.a.p2 == 5 && l.a.post_tw && g_ablate == 0 && !no_r1024 && fits && std_geo;  // column pass with R = 1024
     if (last1024) {  // this instantiation lays its exchange buffer out itself (32 x 289 words, ntt_kernels.h)
         Launch l2 = l;
         l2.lds_bytes = std::max(l.lds_bytes, kLast1024LdsBytes);
@@ -1712,8 +1715,15 @@ int pad_copy(const u64* src, u64* dst, long long n_src_words, long long n_dst_wo
 // coefficients in Polynomial::new; the caller does that -- the length here is data independent.)
 // a_bs / b_bs: words between consecutive polynomials of the batch (0: packed, na * L / nb * L) -- the zerofier tree multiplies
 // the even-numbered nodes of a level by the odd-numbered ones in place.
+// work: caller-provided space of poly_mul_work_words(na, nb, batch, L) words (the zerofier tree calls this ~100 times per
+// evaluation and hands every call the same block), nullptr = a stream-ordered temporary.
+size_t poly_mul_work_words(size_t na, size_t nb, size_t batch, int L) {
+    size_t order = 1;
+    while (order < na + nb - 1) order <<= 1;
+    return 2 * batch * order * size_t(L);
+}
 int poly_mul_dev(const u64* a, size_t na, const u64* b, size_t nb, u64* out, size_t batch, int L, void* stream, long long a_bs = 0,
-                 long long b_bs = 0) {
+                 long long b_bs = 0, u64* work = nullptr) {
     if (batch == 0 || na == 0 || nb == 0) return TF_OK;  // a zero polynomial: empty product
     if (!a_bs) a_bs = (long long)na * L;
     if (!b_bs) b_bs = (long long)nb * L;
@@ -1727,10 +1737,12 @@ int poly_mul_dev(const u64* a, size_t na, const u64* b, size_t nb, u64* out, siz
     rc = current_ctx(&ctx);
     if (rc) return rc;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    u64* tmp = nullptr;
+    u64* tmp = work;
     const size_t half = batch * order * size_t(L);
-    hipError_t e = hipMallocAsync(reinterpret_cast<void**>(&tmp), 2 * half * sizeof(u64), s);
-    if (e != hipSuccess) return hip_fail(e, "hipMallocAsync(poly_mul)", __FILE__, __LINE__);
+    if (!work) {
+        hipError_t e = hipMallocAsync(reinterpret_cast<void**>(&tmp), 2 * half * sizeof(u64), s);
+        if (e != hipSuccess) return hip_fail(e, "hipMallocAsync(poly_mul)", __FILE__, __LINE__);
+    }
     static const bool no_fuse = getenv("TF_POLY_MUL_NO_FUSE") != nullptr;  // A/B switch
     bool copied = false;
     if (order > 16 && !no_fuse) {
@@ -1758,7 +1770,7 @@ int poly_mul_dev(const u64* a, size_t na, const u64* b, size_t nb, u64* out, siz
         if (!rc) rc = run_ntt(ctx, tmp, tmp, (long long)order * L, (long long)order * L, order, batch, L, true, nullptr, -1, s);
     }
     if (!rc && !copied) rc = pad_copy(tmp, out, (long long)order * L, (long long)n_out * L, (long long)batch, s);
-    hipError_t e2 = hipFreeAsync(tmp, s);
+    hipError_t e2 = work ? hipSuccess : hipFreeAsync(tmp, s);
     if (rc) return rc;
     if (e2 != hipSuccess) return hip_fail(e2, "hipFreeAsync", __FILE__, __LINE__);
     return TF_OK;
@@ -1862,8 +1874,9 @@ struct ZerofierTree {
 };
 
 template <int L>
-int zerofier_tree_build(const u64* points, long long n_points, ZerofierTree* T, u64* arena, hipStream_t s) {
-    // arena: 2 * h level arrays of M * L words, then work space of 8 * M * L words
+int zerofier_tree_build(const u64* points, long long n_points, ZerofierTree* T, u64* arena, u64* pm_work, hipStream_t s) {
+    // arena: 2 * h level arrays of M * L words, then work space of 8 * M * L words; pm_work: 8 M L words for the products
+    // (the largest one is 2d x d over M / 2d parents: order 4d, 2 * (M / 2d) * 4d = 4 M elements)
     const long long M = T->M;
     const int h = T->h;
     T->tails.resize(h);
@@ -1886,22 +1899,22 @@ int zerofier_tree_build(const u64* points, long long n_points, ZerofierTree* T, 
         u64* Tm = work + 4 * M * L;              // parents x (3d - 1)   (H G)
         u64* E = work + 6 * M * L;               // parents x 2d         (2 - H G mod x^2d)
         // tails of the parents
-        int rc = poly_mul_dev(T->tails[l], (size_t)d, T->tails[l] + d * L, (size_t)d, P, (size_t)parents, L, s, 2 * d * L, 2 * d * L);
+        int rc = poly_mul_dev(T->tails[l], (size_t)d, T->tails[l] + d * L, (size_t)d, P, (size_t)parents, L, s, 2 * d * L, 2 * d * L, pm_work);
         if (rc) return rc;
         rc = launch_1d<L>(tfk::zerofier_combine_kernel<L>, parents * 2 * d, s, (const u64*)P, (const u64*)T->tails[l], T->tails[l + 1], d, parents);
         if (rc) return rc;
         // inverses of the parents: g = g_left g_right mod x^d, then one Newton step g <- g (2 - rev(Z) g) mod x^2d
-        rc = poly_mul_dev(T->inv[l], (size_t)d, T->inv[l] + d * L, (size_t)d, P, (size_t)parents, L, s, 2 * d * L, 2 * d * L);
+        rc = poly_mul_dev(T->inv[l], (size_t)d, T->inv[l] + d * L, (size_t)d, P, (size_t)parents, L, s, 2 * d * L, 2 * d * L, pm_work);
         if (rc) return rc;
         rc = launch_1d<L>(tfk::poly_truncate_kernel<L>, parents * d, s, (const u64*)P, 2 * d - 1, G, d, parents);
         if (rc) return rc;
         rc = launch_1d<L>(tfk::zerofier_reverse_kernel<L>, parents * 2 * d, s, (const u64*)T->tails[l + 1], H, 2 * d, parents);
         if (rc) return rc;
-        rc = poly_mul_dev(H, (size_t)(2 * d), G, (size_t)d, Tm, (size_t)parents, L, s);
+        rc = poly_mul_dev(H, (size_t)(2 * d), G, (size_t)d, Tm, (size_t)parents, L, s, 0, 0, pm_work);
         if (rc) return rc;
         rc = launch_1d<L>(tfk::newton_two_minus_kernel<L>, parents * 2 * d, s, (const u64*)Tm, 3 * d - 1, E, 2 * d, parents);
         if (rc) return rc;
-        rc = poly_mul_dev(G, (size_t)d, E, (size_t)(2 * d), Tm, (size_t)parents, L, s);
+        rc = poly_mul_dev(G, (size_t)d, E, (size_t)(2 * d), Tm, (size_t)parents, L, s, 0, 0, pm_work);
         if (rc) return rc;
         rc = launch_1d<L>(tfk::poly_truncate_kernel<L>, parents * 2 * d, s, (const u64*)Tm, 3 * d - 1, T->inv[l + 1], 2 * d, parents);
         if (rc) return rc;
@@ -1911,7 +1924,8 @@ int zerofier_tree_build(const u64* points, long long n_points, ZerofierTree* T, 
 
 // F: one unit of exactly M coefficients (zero padded); vals: M values (the first n_points are meaningful)
 template <int L>
-int zerofier_tree_evaluate(const ZerofierTree& T, const u64* F, const u64* points, long long n_points, u64* vals, u64* work, hipStream_t s) {
+int zerofier_tree_evaluate(const ZerofierTree& T, const u64* F, const u64* points, long long n_points, u64* vals, u64* work, u64* pm_work,
+                           hipStream_t s) {
     constexpr int kTreeLeaf = tree_leaf(L);
     const long long M = T.M;
     const u64* cur = F;  // remainders of the level above: (M / 2d) polynomials of 2d coefficients
@@ -1924,11 +1938,11 @@ int zerofier_tree_evaluate(const ZerofierTree& T, const u64* F, const u64* point
         const long long d = (long long)kTreeLeaf << l, children = M / d;
         int rc = launch_1d<L>(tfk::remainder_rev_high_kernel<L>, children * d, s, cur, fr, d, children);
         if (rc) return rc;
-        rc = poly_mul_dev(fr, (size_t)d, T.inv[l], (size_t)d, prod, (size_t)children, L, s);
+        rc = poly_mul_dev(fr, (size_t)d, T.inv[l], (size_t)d, prod, (size_t)children, L, s, 0, 0, pm_work);
         if (rc) return rc;
         rc = launch_1d<L>(tfk::poly_reverse_kernel<L>, children * d, s, (const u64*)prod, 2 * d - 1, q, d, children);
         if (rc) return rc;
-        rc = poly_mul_dev(q, (size_t)d, T.tails[l], (size_t)d, prod, (size_t)children, L, s);
+        rc = poly_mul_dev(q, (size_t)d, T.tails[l], (size_t)d, prod, (size_t)children, L, s, 0, 0, pm_work);
         if (rc) return rc;
         u64* nxt = (cur == ping) ? pong : ping;
         rc = launch_1d<L>(tfk::remainder_finish_kernel<L>, children * d, s, cur, (const u64*)prod, 2 * d - 1, nxt, d, children);
@@ -1978,20 +1992,22 @@ int batch_evaluate_tree_t(const u64* coeffs, size_t n_coeffs, size_t poly_stride
     T.M = M;
     T.h = h;
     const size_t chunks = (n_coeffs + (size_t)M - 1) / (size_t)M;
-    // arena: tree (2 h M) + build / evaluate work (8 M) + one padded unit (M) + values of the chunks of one polynomial (chunks * M)
-    const size_t words = (size_t)(2 * h + 8 + 1 + chunks) * (size_t)M * L;
+    // arena: tree (2 h M) + build / evaluate work (8 M) + product work (8 M) + one padded unit (M) + values of the chunks of one
+    // polynomial (chunks * M)
+    const size_t words = (size_t)(2 * h + 8 + 8 + 1 + chunks) * (size_t)M * L;
     u64* arena = nullptr;
     hipError_t e = hipMallocAsync(reinterpret_cast<void**>(&arena), words * sizeof(u64), s);
     if (e != hipSuccess) return hip_fail(e, "hipMallocAsync(zerofier tree)", __FILE__, __LINE__);
     u64* work = arena + (size_t)(2 * h) * M * L;
-    u64* unit = work + (size_t)8 * M * L;
+    u64* pm_work = work + (size_t)8 * M * L;
+    u64* unit = pm_work + (size_t)8 * M * L;
     u64* vals = unit + (size_t)M * L;
-    int rc = zerofier_tree_build<L>(points, (long long)n_points, &T, arena, s);
+    int rc = zerofier_tree_build<L>(points, (long long)n_points, &T, arena, pm_work, s);
     for (size_t b = 0; b < batch && !rc; ++b) {
         for (size_t c = 0; c < chunks && !rc; ++c) {
             const size_t len = std::min<size_t>((size_t)M, n_coeffs - c * (size_t)M);
             rc = pad_copy(coeffs + b * poly_stride + c * (size_t)M * L, unit, (long long)(len * L), (long long)M * L, 1, s);
-            if (!rc) rc = zerofier_tree_evaluate<L>(T, unit, points, (long long)n_points, vals + c * (size_t)M * L, work, s);
+            if (!rc) rc = zerofier_tree_evaluate<L>(T, unit, points, (long long)n_points, vals + c * (size_t)M * L, work, pm_work, s);
         }
         if (!rc) rc = launch_1d<L>(tfk::chunk_combine_kernel<L>, (long long)n_points, s, (const u64*)vals, M, (int)chunks, points,
                                    (long long)n_points, h + tree_leaf_log(L) /* log2 M */, out + b * n_points * L);

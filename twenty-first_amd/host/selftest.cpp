@@ -166,8 +166,16 @@ int main() {
         // needed: siblings 9, 12 and uncles 5, 7 minus computable ones -> {12, 9, 7, 5} descending (merkle_tree.rs:493-503)
         EXPECT(auth.size() == 4 && auth[0] == tree.nodes[12] && auth[1] == tree.nodes[9] && auth[2] == tree.nodes[7] && auth[3] == tree.nodes[5]);
         bool bad = false;
-        try { tree.authentication_structure({8}); } catch (const BackendError& e) { bad = e.code == TF_ERR_LEAF_INDEX_INVALID; }
+        // merkle_tree.rs:486-488: MerkleTreeError::LeafIndexInvalid -- the same type and variant as in the reference, and the
+        // message of a non-HIP failure carries no stale HIP error text
+        try { tree.authentication_structure({8}); } catch (const MerkleTreeError& e) {
+            bad = e.code == TF_ERR_LEAF_INDEX_INVALID && e.variant == MerkleTreeError::LeafIndexInvalid && std::string(e.what()).find('(') == std::string::npos;
+        }
         EXPECT(bad);
+        // b_field_element.rs:264-268: the inverse of a zero offset panics in fast_coset_interpolate
+        bool panicked = false;
+        try { Polynomial<BFieldElement>::fast_coset_interpolate(BFieldElement::new_(0), bfe_vec({1, 2, 3, 4})); } catch (const NttPanic& e) { panicked = e.code == TF_ERR_INVERSE_OF_ZERO; }
+        EXPECT(panicked);
     }
     if (failures) {
         fprintf(stderr, "%d failure(s)\n", failures);
