@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Turn a tools/prof_r02.sh output directory into the two records bench.py reads: profiles/valu_counts.json (dynamic VALU
+wave-instructions per transform / per tree, clock under load) and profiles/hbm_traffic_ntt.json (HBM-side bytes per launch).
+usage: make_profile_records.py gpurun_out/prof_<tag> <tag>"""
+import collections, csv, glob, json, os, sys
+
+src, tag = sys.argv[1], sys.argv[2]
+root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+summ = json.load(open(os.path.join(src, "summary.json")))
+ntt, clocks, per, tot, n = 0.0, [], {}, 0.0, 0
+for k, e in summ["kernels"].items():
+    if "ntt_pass_kernel" in k and e.get("duration", {}).get("grid") == 8388608:  # the 256 x 2^20 BFE dispatches
+        c, d = e["counters"], e["derived"]
+        ntt += c["SQ_INSTS_VALU"]
+        clocks.append(d["clock_under_load_mhz"])
+        per["void tfk::" + k + "(tfk::NttPassArgs)"] = {"FETCH_SIZE_KB": c["FETCH_SIZE"], "WRITE_SIZE_KB": c["WRITE_SIZE"], "hbm_bytes": d["hbm_side_bytes_per_dispatch"],
+                                                        "dispatches": e["duration"]["dispatches"], "avg_us_under_pmc_profiler": e["duration"]["avg_us"],
+                                                        "valu_instr_per_wave": d["valu_instr_per_wave"], "valu_busy_frac_at_4_cycles": d["valu_busy_frac_at_4_cycles"]}
+        tot += d["hbm_side_bytes_per_dispatch"]
+        n += 1
+# Merkle: every dispatch of the Tip5 / Merkle kernels of the trees built by tools/prof_target.py
+mer, trees = collections.defaultdict(float), 0
+for f in glob.glob(os.path.join(src, "pmc_sq/**/*counter_collection.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] == "SQ_INSTS_VALU" and ("tip5" in r["Kernel_Name"] or "merkle" in r["Kernel_Name"]):
+            mer[r["Kernel_Name"]] += float(r["Counter_Value"])
+            if "merkle_top_kernel" in r["Kernel_Name"]:
+                trees += 1
+rec = {"source": f"rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_VALU ... (tools/prof_r02.sh {tag} -> profiles/{tag}_rocprof_summary.json): SQ_INSTS_VALU summed over the dispatches of one step / one tree",
+       "ntt_valu_wave_instr_per_transform_2p20": ntt / 256, "ntt_valu_instr_per_element": ntt * 64 / 2 ** 28,
+       "ntt_clock_under_load_mhz": round(sum(clocks) / len(clocks), 1) if clocks else None,
+       "valu_peak_note": "peak = 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction = 614.4 G wave-instr/s (SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU = 1.00 quad-cycles on every kernel measured)"}
+old = {}
+try:
+    old = json.load(open(os.path.join(root, "profiles", "valu_counts.json")))
+except Exception:
+    pass
+if trees:
+    m = sum(mer.values()) / trees
+    rec["merkle_valu_wave_instr_per_tree_2p24"] = m
+    rec["merkle_valu_instr_per_hash_pair"] = m * 64 / (2 ** 24 - 1)
+else:  # NTT-only profile: keep the Merkle figures of the last record
+    for k in ("merkle_valu_wave_instr_per_tree_2p24", "merkle_valu_instr_per_hash_pair"):
+        if k in old:
+            rec[k] = old[k]
+json.dump(rec, open(os.path.join(root, "profiles", "valu_counts.json"), "w"), indent=1)
+json.dump({"log_n": 20, "batch": 256, "launches_per_step": 2,
+           "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes (tools/prof_r02.sh {tag} -> profiles/{tag}_rocprof_summary.json), tools/prof_target.py: every dispatch is a full-size one",
+           "per_kernel": per,
+           "correction": "FETCH_SIZE doubled: on gfx950 it tallies the 128-byte requests of a fully coalesced stream at 64 B (MI355X_MICROARCH.md, HBM section); WRITE_SIZE taken as is (it equals the 2^31 bytes each pass must write)",
+           "hbm_bytes_per_launch": tot / n, "algorithmic_bytes_per_launch": 2147483648,
+           "note": "each pass reads and writes every element exactly once (2 x the algorithmic 16 B/element per transform is the two-pass design); the inter-pass table stays in L2 since the data stream is non-temporal. These counters sit on the L2's memory side: reads served by the Infinity Cache are counted as well, so Infinity-Cache residency cannot be read off them."},
+          open(os.path.join(root, "profiles", "hbm_traffic_ntt.json"), "w"), indent=1)
+print(json.dumps(rec, indent=1))

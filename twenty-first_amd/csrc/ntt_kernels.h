@@ -383,8 +383,37 @@ __global__ void __launch_bounds__(512, TF_NTT_WAVES) ntt_pass_kernel(const NttPa
     // (measured -2.4 % on the 256 x 2^20 workload); the exchange hands the data to the column-major roles (g, c) for
     // step 2.  Thread bit 3 selects the exchange round (column half) in BOTH roles, so a thread still writes its 32 old
     // values and reads its 32 new ones in the same round: g_in = bits {0,1,2,4,5}, c_in = bits {6,7,8} + 8 * bit 3.
-    const int g_in = LAST1024 ? ((t & 7) | ((t >> 1) & 0x18)) : g;
-    const int c_in = LAST1024 ? (((t >> 6) & 7) | (t & 8)) : c;
+    int g_in = LAST1024 ? ((t & 7) | ((t >> 1) & 0x18)) : g;
+    int c_in = LAST1024 ? (((t >> 6) & 7) | (t & 8)) : c;
+#ifndef TF_XFE_ROLES
+#define TF_XFE_ROLES 1
+#endif
+    if constexpr (LAST1024 && TF_XFE_ROLES) {
+        // XFieldElement rows: consecutive elements of one limb are 24 bytes apart, so the assignment above makes a wave-load
+        // touch 768 bytes for 256 it uses (measured: 1.53 x the bytes of the pass fetched on the L2's memory side).  Here the
+        // 256 (column, g) pairs of an exchange round are dealt to the round's 256 threads in ADDRESS order instead -- within a
+        // row the words (g, limb) are contiguous -- so the 32 lanes of a wave that share a round read 256 contiguous bytes.
+        // The round is still thread bit 3, as the exchange needs.  (Not for the wrapped first tile of a shifted row.)
+        if (L == 3 && col0 >= 0) {  // uniform
+            const int r = (t >> 3) & 1;
+            const int v = (t & 7) | ((t >> 4) << 3);  // rank of the thread among the 256 of its round
+            const int wc0 = col0 + 8 * r;
+            int nk = 3 - (wc0 - 3 * (int)div_by_L((u32)wc0, 3));  // limbs of the first (possibly partial) row in this round
+            int start = 0, colbase = 0;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {  // at most four row segments: (1 | 2 | 3), 3, 3, rest
+                if (v >= start + 32 * nk) {
+                    start += 32 * nk;
+                    colbase += nk;
+                    nk = min(3, 8 - colbase);
+                }
+            }
+            const int local = v - start;
+            const int gq = nk == 1 ? local : (nk == 2 ? (local >> 1) : (int)__umulhi((u32)local, 0x55555556u));
+            g_in = gq;
+            c_in = 8 * r + colbase + (local - gq * nk);
+        }
+    }
     const bool act_in = LAST1024 ? (c_in < ncv) : act;
     int ch_in = ch, cl_in = cl;
     if constexpr (LAST1024) {
