@@ -150,7 +150,7 @@ def test_planner_splits_are_valid_for_every_length(tf):
                         assert all(5 <= v <= 10 for v in r[:passes]), (force, width, log_n, r)
                         assert passes >= (2 if log_n <= 20 else 3 if log_n <= 30 else 4)
                     else:
-                        assert log_n <= 10 or (width == 1 and log_n <= 14 and force == 0)
+                        assert log_n <= 10 or (log_n <= (14 if width == 1 else 12) and force == 0)  # whole transform per workgroup
                     if force and log_n >= 5 * force:
                         assert passes >= force, (force, width, log_n, r)
         finally:

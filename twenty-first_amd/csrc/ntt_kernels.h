@@ -726,6 +726,9 @@ struct NttBlockArgs {
     long long total_transforms;
     const u64* in2;         // SCALE 3: second operand laid out like `in`, multiplied in on load (fast_multiply)
     long long n_out;        // SCALE 3: >= 0 = only output elements k < n_out are stored
+    int L;                  // words per element.  L = 3 (XFieldElement): the three limbs of an element are three independent
+                            // transforms with element stride 3 (ntt.rs:203-207); total_transforms then counts LIMB transforms
+                            // (3 per XFieldElement slice) and workgroup slots take them in order.  SCALE 3 is L = 1 only.
 };
 
 // SCALE: 0 plain, 1 padding / pre-scale on load (forward), 2 post-scale on store (inverse), 3 pointwise product with a second
@@ -744,13 +747,15 @@ __global__ void __launch_bounds__(512, 4) ntt_block_kernel(const NttBlockArgs A)
     // ---- stage A
     const int trA = t / REST, rest = t - trA * REST;
     const bool actA = trA < nt;
+    const int es = A.L;  // element stride in words
     {
-        const u64* src = A.in + (tr0 + trA) * A.in_bs + rest;
+        const long long ltA = tr0 + trA, slA = ltA / es;  // limb transform -> (slice, limb)
+        const u64* src = A.in + slA * A.in_bs + (ltA - slA * es) + (long long)rest * es;
         const long long lim = (SCALE != 1 || A.n_coeffs < 0) ? (long long)N : A.n_coeffs;
 #pragma unroll
-        for (int q = 0; q < 32; ++q) x[q] = (actA && (SCALE != 1 || brev5(q) * REST + rest < lim)) ? src[(long long)brev5(q) * REST] : 0;
+        for (int q = 0; q < 32; ++q) x[q] = (actA && (SCALE != 1 || brev5(q) * REST + rest < lim)) ? src[(long long)brev5(q) * REST * es] : 0;
         if (SCALE == 3) {
-            const u64* src2 = A.in2 + (tr0 + trA) * A.in_bs + rest;
+            const u64* src2 = A.in2 + (tr0 + trA) * A.in_bs + rest;  // (SCALE 3 runs with L = 1)
 #pragma unroll
             for (int q0 = 0; q0 < 32; q0 += 8) {
                 u64 w[8];
@@ -850,7 +855,8 @@ __global__ void __launch_bounds__(512, 4) ntt_block_kernel(const NttBlockArgs A)
     if constexpr (LOGP3 >= 3) dit_level<INV, 3>(x);
     if constexpr (LOGP3 >= 4) dit_level<INV, 4>(x);
     if (trC < nt) {
-        u64* dst = A.out + (tr0 + trC) * A.out_bs + k1C;
+        const long long ltC = tr0 + trC, slC = ltC / es;
+        u64* dst = A.out + slC * A.out_bs + (ltC - slC * es) + (long long)k1C * es;
         if (SCALE == 2 && A.post_scale) {
             // scale and store eight outputs at a time (bounded register footprint)
             const u64* ps = A.post_scale + k1C;
@@ -867,8 +873,8 @@ __global__ void __launch_bounds__(512, 4) ntt_block_kernel(const NttBlockArgs A)
                     const int qa = q0 + i, qb = q0 + i + 1;
                     u64 r0, r1;
                     gl::mont_mul2(x[qa], w[i], x[qb], w[i + 1], r0, r1);
-                    dst[32 * (sC * (32 / P3) + (qa >> LOGP3)) + 1024 * (qa & (P3 - 1))] = r0;
-                    dst[32 * (sC * (32 / P3) + (qb >> LOGP3)) + 1024 * (qb & (P3 - 1))] = r1;
+                    dst[(long long)(32 * (sC * (32 / P3) + (qa >> LOGP3)) + 1024 * (qa & (P3 - 1))) * es] = r0;
+                    dst[(long long)(32 * (sC * (32 / P3) + (qb >> LOGP3)) + 1024 * (qb & (P3 - 1))) * es] = r1;
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -878,7 +884,7 @@ __global__ void __launch_bounds__(512, 4) ntt_block_kernel(const NttBlockArgs A)
             for (int q = 0; q < 32; ++q) {
                 const int grp = q >> LOGP3, k3 = q & (P3 - 1);
                 const int k2 = sC * (32 / P3) + grp;
-                if (SCALE != 3 || k1C + 32 * k2 + 1024 * k3 < klim) dst[32 * k2 + 1024 * k3] = x[q];
+                if (SCALE != 3 || k1C + 32 * k2 + 1024 * k3 < klim) dst[(long long)(32 * k2 + 1024 * k3) * es] = x[q];
             }
         }
     }

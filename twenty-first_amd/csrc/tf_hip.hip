@@ -965,7 +965,7 @@ int launch_block_t(const tfk::NttBlockArgs& a, unsigned grid, hipStream_t stream
 
 int launch_block(DeviceCtx* ctx, const u64* in, u64* out, long long in_bs, long long out_bs, int log_n, size_t batch, bool inverse,
                  const u64* pre_scale, long long n_coeffs, const u64* post_scale, hipStream_t stream, const u64* in2 = nullptr,
-                 long long n_out = -1) {
+                 long long n_out = -1, int L = 1) {
     tfk::NttBlockArgs a{};
     int rc = get_block_tables(ctx, log_n, inverse, &a.tw1, &a.tw2);
     if (rc) return rc;
@@ -976,11 +976,12 @@ int launch_block(DeviceCtx* ctx, const u64* in, u64* out, long long in_bs, long 
     a.n_coeffs = n_coeffs;
     a.in_bs = in_bs;
     a.out_bs = out_bs;
-    a.total_transforms = (long long)batch;
+    a.total_transforms = (long long)batch * L;  // limb transforms (ntt_kernels.h)
     a.in2 = in2;
     a.n_out = n_out;
+    a.L = L;
     const int lp3 = log_n - 10, T = 16 >> lp3;
-    const unsigned grid = (unsigned)((batch + T - 1) / T);
+    const unsigned grid = (unsigned)((batch * (size_t)L + T - 1) / T);
     const bool scaled_load = pre_scale || n_coeffs >= 0, scaled_store = post_scale != nullptr;
     if (in2) {  // the inverse transform of a product: second operand on load, truncated store
         switch (lp3) {
@@ -1135,12 +1136,17 @@ int run_ntt(DeviceCtx* ctx, const u64* in, u64* out, long long in_bs, long long 
     {
         static const bool no_block = getenv("TF_NTT_NO_BLOCK") != nullptr;  // A/B switch
         const bool product_inverse = in2 && inverse && !pre_scale && !post_scale && n_coeffs < 0;
-        if (!no_block && log_n >= 11 && log_n <= 14 && L == 1 && cosets == 1 && g_min_passes.load(std::memory_order_relaxed) == 0 &&
-            batch < (size_t(1) << 31)) {
-            if (product_inverse)
+        // XFieldElement slices take the same kernel as three limb transforms per slice with element stride 3 (round 2;
+        // TF_NTT_NO_XFE_BLOCK restores the two-pass plan for an A/B run): one HBM pass instead of two
+        static const bool no_xfe_block = getenv("TF_NTT_NO_XFE_BLOCK") != nullptr;
+        // (2^11 and 2^12 only: 1.09 vs 1.46 and 1.33 vs 1.42 ms per 3 * 2^26 words; at 2^13 / 2^14 the limbs of a slice sit in
+        // different workgroups and the 24-byte element stride costs more than the second pass saves: 1.52 vs 1.42, 1.78 vs 1.33)
+        if (!no_block && log_n >= 11 && log_n <= (L == 1 ? 14 : 12) && (L == 1 || (L == 3 && !no_xfe_block)) && cosets == 1 &&
+            g_min_passes.load(std::memory_order_relaxed) == 0 && batch < (size_t(1) << 29)) {
+            if (product_inverse && L == 1)
                 return launch_block(ctx, in, out, in_bs, out_bs, log_n, batch, true, nullptr, -1, nullptr, stream, in2, n_out);
             if (!in2 && n_out < 0 && !((pre_scale || n_coeffs >= 0) && inverse) && !(post_scale && !inverse))
-                return launch_block(ctx, in, out, in_bs, out_bs, log_n, batch, inverse, pre_scale, n_coeffs, post_scale, stream);
+                return launch_block(ctx, in, out, in_bs, out_bs, log_n, batch, inverse, pre_scale, n_coeffs, post_scale, stream, nullptr, -1, L);
         }
     }
     // multi-pass: n = N_1 * ... * N_P, every N_i = 2^(a_i) <= 1024.  Passes 1 .. P-1 are column passes (DFT over digit i,
@@ -2322,7 +2328,8 @@ int tf_ntt_plan(size_t n, int width, int* log2_radix_out) {
     const int log_n = ilog2(n);
     for (int i = 0; i < 4; ++i) log2_radix_out[i] = 0;
     static const bool no_block = getenv("TF_NTT_NO_BLOCK") != nullptr;
-    if (log_n <= 10 || (log_n <= 14 && width == 1 && !no_block && g_min_passes.load(std::memory_order_relaxed) == 0)) {
+    static const bool no_xfe_block = getenv("TF_NTT_NO_XFE_BLOCK") != nullptr;
+    if (log_n <= 10 || (log_n <= (width == 1 ? 14 : (no_xfe_block ? 10 : 12)) && !no_block && g_min_passes.load(std::memory_order_relaxed) == 0)) {
         log2_radix_out[0] = log_n;
         return 1;
     }
