@@ -99,19 +99,28 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t buf_rsrc(const void* p) {
 #ifndef TF_STORE_AUX
 #define TF_STORE_AUX 2
 #endif
+// per-role overrides for A/B builds: the scratch tile between the passes (stores of a column pass, loads of the last pass)
+#ifndef TF_AUX_COL_STORE
+#define TF_AUX_COL_STORE TF_STORE_AUX
+#endif
+#ifndef TF_AUX_LAST_LOAD
+#define TF_AUX_LAST_LOAD TF_LOAD_AUX
+#endif
+template <int AUX = TF_LOAD_AUX>
 __device__ __forceinline__ u64 buf_load(__amdgpu_buffer_rsrc_t r, u32 voff, u32 soff) {
-    const tf_v2u v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, TF_LOAD_AUX);
+    const tf_v2u v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, AUX);
     return ((u64)v[1] << 32) | v[0];
 }
 __device__ __forceinline__ u64 buf_load_tab(__amdgpu_buffer_rsrc_t r, u32 voff, u32 soff) {  // twiddle tables: default policy (they are re-read)
     const tf_v2u v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
     return ((u64)v[1] << 32) | v[0];
 }
+template <int AUX = TF_STORE_AUX>
 __device__ __forceinline__ void buf_store(__amdgpu_buffer_rsrc_t r, u32 voff, u32 soff, u64 x) {
     tf_v2u v;
     v[0] = (u32)x;
     v[1] = (u32)(x >> 32);
-    __builtin_amdgcn_raw_buffer_store_b64(v, r, voff, soff, TF_STORE_AUX);
+    __builtin_amdgcn_raw_buffer_store_b64(v, r, voff, soff, AUX);
 }
 
 // ---- radix-2^k DIT network with power-of-two twiddles --------------------------------------
@@ -451,7 +460,7 @@ __global__ void __launch_bounds__(512, TF_NTT_WAVES) ntt_pass_kernel(const NttPa
         if constexpr ((LAST1024 || COLP) && SCALE != 1) {
             const __amdgpu_buffer_rsrc_t ri = buf_rsrc(in);
 #pragma unroll
-            for (int q = 0; q < 32; ++q) x[q] = buf_load(ri, toff, (u32)((long long)(brev5(q) << p2) * A.in_rs * 8));
+            for (int q = 0; q < 32; ++q) x[q] = buf_load<LAST1024 ? TF_AUX_LAST_LOAD : TF_LOAD_AUX>(ri, toff, (u32)((long long)(brev5(q) << p2) * A.in_rs * 8));
         } else
 #pragma unroll
         for (int q = 0; q < 32; ++q) {
@@ -657,7 +666,7 @@ __global__ void __launch_bounds__(512, TF_NTT_WAVES) ntt_pass_kernel(const NttPa
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const long long uk = (long long)((((q + e) >> p2) << p2) + (((q + e) & (P2 - 1)) << 5));  // uniform part of k
-                        if constexpr (COLP) buf_store(ro, toff, (u32)(uk * A.out_rs * 8), r4[e]);
+                        if constexpr (COLP) buf_store<TF_AUX_COL_STORE>(ro, toff, (u32)(uk * A.out_rs * 8), r4[e]);
                         else *reinterpret_cast<u64*>(base + uk * A.out_rs * 8 + toff) = r4[e];
                     }
                 }

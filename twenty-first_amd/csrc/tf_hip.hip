@@ -1978,6 +1978,12 @@ bool tree_route(size_t n_coeffs, size_t n_points, size_t batch, int L) {
     while (M < n_points) M <<= 1;
     const size_t units = batch * ((n_coeffs + M - 1) / M);
     if (units > 256) return false;  // one pass down the tree per unit: a very long polynomial on few points stays with Horner
+    {
+        int h = 0;
+        for (size_t v = kTreeLeaf; v < M; v <<= 1) ++h;
+        const size_t arena_words = (size_t)(2 * h + 17 + (n_coeffs + M - 1) / M) * M * (size_t)L;  // batch_evaluate_tree_t's arena
+        if (arena_words * sizeof(u64) > (size_t(8) << 30)) return false;  // the tree's levels would not fit a sane work space
+    }
     if (force && !strcmp(force, "tree")) return true;
     // Cost model fitted to tools/batch_eval_sweep.py on MI355X (profiles/r02_batch_eval_sweep.txt), milliseconds:
     //   Horner  n m / 1.4e9            (x 7 over XFieldElement: nine base-field products per step)
