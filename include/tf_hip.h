@@ -51,7 +51,8 @@ enum tf_status {
     TF_ERR_OUT_OF_MEMORY = 10,
     TF_ERR_LEAF_INDEX_INVALID = 11,        /* MerkleTreeError::LeafIndexInvalid  merkle_tree.rs:486-488 */
     TF_ERR_INVERSE_OF_ZERO = 12,           /* offset.inverse() of zero panics    b_field_element.rs:264-268 */
-    TF_ERR_BUFFER_TOO_SMALL = 13
+    TF_ERR_BUFFER_TOO_SMALL = 13,
+    TF_ERR_EMPTY_DOMAIN = 14               /* interpolate panic: "interpolation must happen through more than zero points"  math/polynomial.rs:1503-1506 */
 };
 
 /* Human-readable name of a status code. */
@@ -165,6 +166,25 @@ int tf_poly_batch_evaluate_bfe(const uint64_t *coeffs, size_t n_coeffs, const ui
 int tf_poly_batch_evaluate_xfe(const uint64_t *coeffs, size_t n_coeffs, const uint64_t *points, size_t n_points, uint64_t *out);
 int tf_poly_batch_evaluate_bfe_dev(const uint64_t *d_coeffs, size_t n_coeffs, const uint64_t *d_points, size_t n_points, uint64_t *d_out, void *stream);
 int tf_poly_batch_evaluate_xfe_dev(const uint64_t *d_coeffs, size_t n_coeffs, const uint64_t *d_points, size_t n_points, uint64_t *d_out, void *stream);
+/* Polynomial::zerofier / par_zerofier  math/polynomial.rs:1435-1485 (smart_zerofier :1462, fast_zerofier :1478): the monic
+ * prod_i (x - roots[i]); out receives n_roots + 1 coefficients, low to high (out[n_roots] = 1; n_roots = 0 gives the constant 1).
+ * Repeated roots are allowed.  On the device: the root of the zerofier tree of the batch evaluation above. */
+int tf_poly_zerofier_bfe(const uint64_t *roots, size_t n_roots, uint64_t *out);
+int tf_poly_zerofier_xfe(const uint64_t *roots, size_t n_roots, uint64_t *out);
+int tf_poly_zerofier_bfe_dev(const uint64_t *d_roots, size_t n_roots, uint64_t *d_out, void *stream);
+int tf_poly_zerofier_xfe_dev(const uint64_t *d_roots, size_t n_roots, uint64_t *d_out, void *stream);
+/* Polynomial::interpolate / par_interpolate / lagrange_interpolate / fast_interpolate  math/polynomial.rs:1502-1701, and
+ * batch_fast_interpolate :1703-1838 (`rows` value rows over one domain, the tree and the inverse weights shared as the reference
+ * memoises them): out[row * n_points + j] = coefficient j of the unique polynomial of degree < n_points through
+ * (domain[i], values[row * n_points + i]).  Always n_points coefficients per row: the reference trims leading zero coefficients
+ * in Polynomial::new, the caller does that -- the length here is data independent.
+ * Errors: n_points == 0 -> TF_ERR_EMPTY_DOMAIN (:1503-1506); a repeated domain point -> TF_ERR_INVERSE_OF_ZERO (the reference
+ * panics dividing by zero: traits.rs:106 / b_field_element.rs:264-268).  The _dev calls synchronise the stream once (the
+ * repeated-point check). */
+int tf_poly_interpolate_bfe(const uint64_t *domain, const uint64_t *values, size_t n_points, size_t rows, uint64_t *out);
+int tf_poly_interpolate_xfe(const uint64_t *domain, const uint64_t *values, size_t n_points, size_t rows, uint64_t *out);
+int tf_poly_interpolate_bfe_dev(const uint64_t *d_domain, const uint64_t *d_values, size_t n_points, size_t rows, uint64_t *d_out, void *stream);
+int tf_poly_interpolate_xfe_dev(const uint64_t *d_domain, const uint64_t *d_values, size_t n_points, size_t rows, uint64_t *d_out, void *stream);
 /* Route of the batch evaluation (test / A-B hook): 0 = automatic (zerofier tree for many points on a long polynomial, Horner
  * otherwise), 1 = always Horner, 2 = the zerofier tree whenever it applies (>= 512 points).  Same values either way. */
 void tf_set_batch_eval_route(int route);

@@ -892,6 +892,117 @@ void tfo_poly_eval_xfe_point(const uint64_t *c, size_t n_coeffs, const uint64_t 
     memcpy(out, acc, sizeof(acc));
 }
 
+/* ------------------------------------------------------------------ zerofier / interpolation (math/polynomial.rs) */
+
+static void fe_mul_w(const u64 *a, const u64 *b, u64 *out, int w) {
+    if (w == 1) out[0] = bfe_mul(a[0], b[0]);
+    else tfo_xfe_mul(a, b, out);
+}
+static void fe_add_w(const u64 *a, const u64 *b, u64 *out, int w) {
+    for (int k = 0; k < w; k++) out[k] = bfe_add(a[k], b[k]);
+}
+static void fe_sub_w(const u64 *a, const u64 *b, u64 *out, int w) {
+    for (int k = 0; k < w; k++) out[k] = bfe_sub(a[k], b[k]);
+}
+
+/* XFieldElement::inverse (x_field_element.rs:371-379) runs xgcd(self, x^3 - x + 1) over Polynomial<BFieldElement>; the inverse
+ * is unique, and here it is found as the solution b of the linear system (a * x^j)_j b = 1: the columns come from the
+ * reference's own product (tfo_xfe_mul), the system is solved by Gauss-Jordan elimination over BFieldElement.
+ * Returns 1 for a = 0 ("Cannot invert the zero element in the extension field."). */
+int tfo_xfe_inverse(const u64 a[3], u64 out[3]) {
+    u64 m[3][4];
+    for (int j = 0; j < 3; j++) {
+        u64 e[3] = {0, 0, 0}, col[3];
+        e[j] = bfe_new(1);
+        tfo_xfe_mul(a, e, col);
+        for (int r = 0; r < 3; r++) m[r][j] = col[r];
+    }
+    m[0][3] = bfe_new(1);
+    m[1][3] = 0;
+    m[2][3] = 0;
+    for (int c = 0; c < 3; c++) {
+        int piv = -1;
+        for (int r = c; r < 3; r++)
+            if (m[r][c]) { piv = r; break; }
+        if (piv < 0) return 1;
+        for (int k = 0; k < 4; k++) { u64 t = m[c][k]; m[c][k] = m[piv][k]; m[piv][k] = t; }
+        u64 inv = bfe_inverse(m[c][c]);
+        for (int k = 0; k < 4; k++) m[c][k] = bfe_mul(m[c][k], inv);
+        for (int r = 0; r < 3; r++) {
+            if (r == c || !m[r][c]) continue;
+            u64 f = m[r][c];
+            for (int k = 0; k < 4; k++) m[r][k] = bfe_sub(m[r][k], bfe_mul(f, m[c][k]));
+        }
+    }
+    for (int r = 0; r < 3; r++) out[r] = m[r][3];
+    return 0;
+}
+
+/* Polynomial::smart_zerofier (polynomial.rs:1462-1475): prod (x - root), n + 1 coefficients, one root at a time */
+void tfo_poly_zerofier(const uint64_t *roots, size_t n, int width, uint64_t *out) {
+    const size_t w = (size_t)width;
+    memset(out, 0, (n + 1) * w * sizeof(u64));
+    out[0] = bfe_new(1);
+    size_t num_coeffs = 1;
+    for (size_t i = 0; i < n; i++) {
+        const u64 *root = roots + i * w;
+        for (size_t k = num_coeffs; k >= 1; k--) { /* zerofier[k] = zerofier[k - 1] - root * zerofier[k] */
+            u64 t[3];
+            fe_mul_w(root, out + k * w, t, width);
+            fe_sub_w(out + (k - 1) * w, t, out + k * w, width);
+        }
+        u64 t[3], z[3] = {0, 0, 0};
+        fe_mul_w(root, out, t, width); /* zerofier[0] = -root * zerofier[0] */
+        fe_sub_w(z, t, out, width);
+        num_coeffs++;
+    }
+}
+
+/* Polynomial::lagrange_interpolate (polynomial.rs:1565-1606): n coefficients; returns 1 where the reference panics dividing by
+ * a zero summand_eval (a repeated domain point), 2 for an empty domain */
+int tfo_poly_lagrange_interpolate(const uint64_t *domain, const uint64_t *values, size_t n, int width, uint64_t *out) {
+    if (n == 0) return 2;
+    const size_t w = (size_t)width;
+    u64 *zerofier = (u64 *)malloc((n + 1) * w * sizeof(u64));
+    u64 *summand = (u64 *)malloc(n * w * sizeof(u64));
+    tfo_poly_zerofier(domain, n, width, zerofier);
+    memset(out, 0, n * w * sizeof(u64));
+    int rc = 0;
+    for (size_t i = 0; i < n && !rc; i++) {
+        const u64 *x = domain + i * w;
+        u64 lead[3], supp[3], eval[3] = {0, 0, 0}, t[3];
+        memcpy(lead, zerofier + n * w, w * sizeof(u64));
+        memcpy(supp, zerofier + (n - 1) * w, w * sizeof(u64));
+        for (size_t j = n - 1; j >= 1; j--) {
+            memcpy(summand + j * w, lead, w * sizeof(u64));
+            fe_mul_w(eval, x, t, width);
+            fe_add_w(t, lead, eval, width);
+            fe_mul_w(lead, x, t, width);
+            fe_add_w(supp, t, lead, width);
+            memcpy(supp, zerofier + (j - 1) * w, w * sizeof(u64));
+        }
+        memcpy(summand, lead, w * sizeof(u64));
+        fe_mul_w(eval, x, t, width);
+        fe_add_w(t, lead, eval, width);
+        u64 inv[3] = {0, 0, 0}, corrected[3];
+        if (width == 1) {
+            if (!eval[0]) rc = 1;
+            else inv[0] = bfe_inverse(eval[0]);
+        } else if (tfo_xfe_inverse(eval, inv)) {
+            rc = 1;
+        }
+        if (rc) break;
+        fe_mul_w(values + i * w, inv, corrected, width);
+        for (size_t j = 0; j < n; j++) {
+            fe_mul_w(corrected, summand + j * w, t, width);
+            fe_add_w(out + j * w, t, out + j * w, width);
+        }
+    }
+    free(zerofier);
+    free(summand);
+    return rc;
+}
+
 /* ------------------------------------------------------------------ helpers */
 
 uint64_t tfo_splitmix64(uint64_t *state) {

@@ -80,6 +80,9 @@ def lib() -> C.CDLL:
             "tfo_poly_mul_fast": (i32, [pu, sz, pu, sz, i32, pu]),
             "tfo_auth_structure_indices": (i32, [sz, pu, sz, pu, sz, C.POINTER(C.c_size_t)]),
             "tfo_poly_eval_xfe_point": (None, [pu, sz, pu, pu]),
+            "tfo_xfe_inverse": (i32, [pu, pu]),
+            "tfo_poly_zerofier": (None, [pu, sz, i32, pu]),
+            "tfo_poly_lagrange_interpolate": (i32, [pu, pu, sz, i32, pu]),
             "tfo_fill_random": (None, [pu, sz, u64]),
             "tfo_digest_to_hex": (None, [pu, C.c_char_p]),
         }
@@ -380,6 +383,35 @@ def poly_eval_xfe_point(coeffs, point) -> np.ndarray:
     buf = c if c.size else np.zeros(3, dtype=np.uint64)
     lib().tfo_poly_eval_xfe_point(_p(buf), c.size // 3, _p(pt), _p(out))
     return out
+
+
+def xfe_inverse(a) -> np.ndarray:
+    out = np.zeros(3, dtype=np.uint64)
+    if lib().tfo_xfe_inverse(_p(_arr(a, 3)), _p(out)):
+        raise OraclePanic(12)
+    return out
+
+
+def zerofier(roots, width: int = 1) -> np.ndarray:
+    """Polynomial::smart_zerofier (math/polynomial.rs:1462-1475): n + 1 coefficients."""
+    r = _arr(roots).reshape(-1)
+    n = r.size // width
+    out = np.zeros((n + 1) * width, dtype=np.uint64)
+    buf = r if r.size else np.zeros(width, dtype=np.uint64)
+    lib().tfo_poly_zerofier(_p(buf), n, width, _p(out))
+    return out
+
+
+def lagrange_interpolate(domain, values, width: int = 1) -> np.ndarray:
+    """Polynomial::lagrange_interpolate (math/polynomial.rs:1565-1606): n coefficients, untrimmed."""
+    d, v = _arr(domain).reshape(-1), _arr(values).reshape(-1)
+    assert d.size == v.size
+    n = d.size // width
+    out = np.zeros(max(n, 1) * width, dtype=np.uint64)
+    rc = lib().tfo_poly_lagrange_interpolate(_p(d if d.size else out), _p(v if v.size else out), n, width, _p(out))
+    if rc:
+        raise OraclePanic(12 if rc == 1 else 14)
+    return out[: n * width]
 
 
 def merkle_from_rows(rows, row_len: int) -> np.ndarray:

@@ -490,3 +490,130 @@ def test_zerofier_tree_at_m_equals_n_2pow16(tf, oracle):
     p = _to_host(dp)
     for i in (0, 1, 12345, m - 1):
         assert int(_to_host(outs[0])[i]) == int(np.asarray(oracle.poly_eval(c, int(p[i]))).reshape(-1)[0])
+
+
+# ---- zerofier and interpolation through the zerofier tree (math/polynomial.rs:1435-1838) ---------------------------------------
+def _distinct_points(oracle, n, width, seed):
+    pts = oracle.fill_random(n * width, seed)
+    if n > 1:
+        pts[width: 2 * width] = 0  # the point 0 is a legal domain point
+    return pts
+
+
+@pytest.mark.parametrize("width", [1, 3])
+@pytest.mark.parametrize("n", [0, 1, 2, 3, 17, 255, 256, 257, 1023, 1024, 1025, 2049, 3000, 5000])
+def test_zerofier_matches_oracle(tf, oracle, width, n):
+    """Polynomial::zerofier (polynomial.rs:1435-1441): the root of the device's padded tree against the oracle's smart_zerofier
+    (:1462-1475), word for word -- sizes around the leaf sizes (1024 BFE / 256 XFE) and the padded tree sizes, repeated and
+    zero roots; monic (:3485-3488)."""
+    r = oracle.fill_random(n * width, 1300 + n)
+    if n > 3:
+        r[: width] = 0
+        r[width: 2 * width] = r[2 * width: 3 * width]  # a repeated root is allowed
+    z = np.empty((n + 1) * width, dtype=np.uint64)
+    fn = tf.lib().tf_poly_zerofier_bfe if width == 1 else tf.lib().tf_poly_zerofier_xfe
+    import ctypes as C
+
+    assert fn(C.c_void_p(r.ctypes.data) if n else C.c_void_p(0), n, C.c_void_p(z.ctypes.data)) == 0
+    assert np.array_equal(z, oracle.zerofier(r, width))
+    assert int(z[n * width]) == oracle.bfe_new(1) and not z[n * width + 1:].any()
+    assert tf.Polynomial.zerofier(r, width=width).degree() == n
+
+
+@pytest.mark.parametrize("width", [1, 3])
+@pytest.mark.parametrize("n", [1, 2, 4, 17, 255, 256, 257, 1024, 1025, 2051, 3000])
+def test_interpolate_matches_lagrange_oracle(tf, oracle, width, n):
+    """Polynomial::interpolate / fast_interpolate (polynomial.rs:1502-1654) against the oracle's lagrange_interpolate (:1565-1606),
+    the identity the reference tests at :3572-3582; the interpolant evaluates back to the values (:3602-3612)."""
+    d = _distinct_points(oracle, n, width, 1400 + n)
+    v = oracle.fill_random(n * width, 1401 + n)
+    got = np.empty(n * width, dtype=np.uint64)
+    fn = tf.lib().tf_poly_interpolate_bfe if width == 1 else tf.lib().tf_poly_interpolate_xfe
+    import ctypes as C
+
+    assert fn(C.c_void_p(d.ctypes.data), C.c_void_p(v.ctypes.data), n, 1, C.c_void_p(got.ctypes.data)) == 0
+    assert np.array_equal(got, oracle.lagrange_interpolate(d, v, width))
+    assert np.array_equal(tf.Polynomial(got, width=width).batch_evaluate(d), v)
+
+
+def test_interpolate_doc_examples_and_panics(tf, oracle):
+    """polynomial.rs:1490-1497 (doc example), :3522-3570 (no points, unequal lengths, repeated points, one point)."""
+    P_ = tf.Polynomial
+    f = P_.interpolate(oracle.to_raw([0, 1, 2, 3]), oracle.to_raw([1, 3, 5, 7]))
+    assert f.degree() == 1 and np.array_equal(f.coefficients, oracle.to_raw([1, 2]))
+    assert np.array_equal(f.batch_evaluate(oracle.to_raw([4])), oracle.to_raw([9]))
+    z = P_.zerofier(oracle.to_raw([2, 4, 6]))
+    assert z.degree() == 3 and not z.batch_evaluate(oracle.to_raw([2, 4, 6])).any()
+    assert z.batch_evaluate(oracle.to_raw([0, 1, 3, 5])).all()
+    assert np.array_equal(P_.zerofier(np.zeros(0, dtype=np.uint64)).coefficients, oracle.to_raw([1]))
+    assert np.array_equal(P_.interpolate(oracle.to_raw([5]), oracle.to_raw([42])).coefficients, oracle.to_raw([42]))
+    with pytest.raises(tf.NttPanic) as e:
+        P_.interpolate(np.zeros(0, dtype=np.uint64), np.zeros(0, dtype=np.uint64))
+    assert e.value.code == 14
+    with pytest.raises(tf.NttPanic):
+        P_.interpolate(oracle.to_raw([1, 2]), oracle.to_raw([1]))
+    for n in (2, 300, 1500, 5000):  # a repeated domain point: inside one leaf and across leaves
+        d = oracle.fill_random(n, 77)
+        d[n - 1] = d[n // 3]
+        with pytest.raises(tf.NttPanic) as e:
+            P_.interpolate(d, oracle.fill_random(n, 78))
+        assert e.value.code == 12
+    dx = oracle.fill_random(3 * 700, 79)
+    dx[3 * 699: 3 * 700] = dx[0:3]
+    with pytest.raises(tf.NttPanic) as e:
+        P_.interpolate(dx, oracle.fill_random(3 * 700, 80), width=3)
+    assert e.value.code == 12
+    import ctypes as C
+
+    assert tf.lib().tf_poly_interpolate_bfe(C.c_void_p(0), C.c_void_p(0), 0, 1, C.c_void_p(0)) == 14
+    assert tf.lib().tf_status_string(14) == b"TF_ERR_EMPTY_DOMAIN"
+
+
+@pytest.mark.parametrize("width,n,rows", [(1, 700, 3), (1, 2500, 4), (3, 300, 2), (3, 1100, 3)])
+def test_batch_fast_interpolate_rows_share_the_domain(tf, oracle, width, n, rows):
+    """batch_fast_interpolate (polynomial.rs:1703-1838) equals interpolate row by row (:3614-3663)."""
+    d = _distinct_points(oracle, n, width, 1500 + n)
+    vals = [oracle.fill_random(n * width, 1501 + n + r) for r in range(rows)]
+    polys = tf.Polynomial.batch_fast_interpolate(d, vals, width=width)
+    assert len(polys) == rows
+    for r in range(rows):
+        want = oracle.lagrange_interpolate(d, vals[r], width)
+        assert np.array_equal(polys[r].coefficients, tf.Polynomial(want, width=width).coefficients)
+        assert np.array_equal(polys[r].coefficients, tf.Polynomial.interpolate(d, vals[r], width=width).coefficients)
+
+
+@pytest.mark.parametrize("width,log_n", [(1, 10), (1, 13), (1, 16), (3, 9), (3, 14)])
+def test_interpolation_on_a_coset_equals_fast_coset_interpolate(tf, oracle, width, log_n):
+    """polynomial.rs:3665-3680: interpolating through the points of a coset gives fast_coset_interpolate's polynomial -- here the
+    tree interpolation against the NTT path of the same library, at sizes the O(n^2) oracle does not reach; and the interpolant
+    of f's values on arbitrary points is f (deg f < n)."""
+    import torch
+
+    n = 1 << log_n
+    off = oracle.bfe_new(7)
+    w = tf.BFieldElement.primitive_root_of_unity(n)
+    pts = np.zeros(n * width, dtype=np.uint64)
+    x = off
+    for i in range(n):
+        pts[i * width] = x
+        x = oracle.bfe_mul(x, w)
+    v = oracle.fill_random(n * width, 1600 + log_n)
+    want = tf.fast_coset_interpolate(v, off, width=width)
+    got = tf.Polynomial.interpolate(pts, v, width=width)
+    assert np.array_equal(got.coefficients, tf.Polynomial(want, width=width).coefficients)
+    # device-resident round trip on random points: evaluate f, interpolate the values, get f back (untrimmed coefficients)
+    f = _to_dev(oracle.fill_random(n * width, 1601 + log_n))
+    dom = torch.empty(n * width, dtype=torch.int64, device="cuda")
+    tf.device.fill_random(dom, 1602 + log_n)
+    vals = torch.empty_like(dom)
+    back = torch.empty_like(dom)
+    tf.device.batch_evaluate(f, n, dom, vals, width=width)
+    tf.device.interpolate(dom, vals, back, rows=1, width=width)
+    torch.cuda.synchronize()
+    assert torch.equal(back, f)
+    z = torch.empty((n + 1) * width, dtype=torch.int64, device="cuda")
+    tf.device.zerofier(dom, z, width=width)
+    zv = torch.empty_like(dom)
+    tf.device.batch_evaluate(z, n + 1, dom, zv, width=width)
+    torch.cuda.synchronize()
+    assert not zv.any().item()

@@ -545,3 +545,53 @@ def test_mds_linearity_and_circulancy(oracle):
         mu, mv, mw = o.tip5_mds(u, 2), o.tip5_mds(v, 2), o.tip5_mds(w, 2)
         for k in range(16):
             assert int(mw[k]) % P == o.bfe_add(o.bfe_mul(a, int(mu[k]) % P), o.bfe_mul(b, int(mv[k]) % P))
+
+
+def test_zerofier_and_interpolation_doc_examples(oracle):
+    """Polynomial::zerofier doc example (math/polynomial.rs:1426-1434) and Polynomial::interpolate doc example (:1490-1497)
+    through the oracle's smart_zerofier (:1462-1475) / lagrange_interpolate (:1565-1606); interpolation then evaluation is the
+    identity (:3602-3612), one point gives the constant (:3562-3570), repeated points panic (:3554-3560)."""
+    tfo = oracle
+    P = 0xFFFFFFFF00000001
+    z = tfo.zerofier(tfo.to_raw([2, 4, 6]))
+    assert [int(v) for v in tfo.to_values(z)] == [(-48) % P, 44, (-12) % P, 1]
+    for root in (2, 4, 6):
+        assert int(tfo.poly_eval(z, tfo.bfe_new(root))[0]) == 0
+    for other in (0, 1, 3, 5):
+        assert int(tfo.poly_eval(z, tfo.bfe_new(other))[0]) != 0
+    assert [int(v) for v in tfo.to_values(tfo.zerofier(np.zeros(0, dtype=np.uint64)))] == [1]
+    f = tfo.lagrange_interpolate(tfo.to_raw([0, 1, 2, 3]), tfo.to_raw([1, 3, 5, 7]))
+    assert [int(v) for v in tfo.to_values(f)] == [1, 2, 0, 0]
+    assert int(tfo.to_values(tfo.poly_eval(f, tfo.bfe_new(4)))[0]) == 9
+    assert [int(v) for v in tfo.to_values(tfo.lagrange_interpolate(tfo.to_raw([5]), tfo.to_raw([42])))] == [42]
+    with pytest.raises(tfo.OraclePanic):
+        tfo.lagrange_interpolate(tfo.to_raw([1, 1]), tfo.to_raw([1, 2]))
+    for width in (1, 3):
+        n = 23
+        d, v = tfo.fill_random(n * width, 5), tfo.fill_random(n * width, 6)
+        c = tfo.lagrange_interpolate(d, v, width)
+        zz = tfo.zerofier(d, width)
+        for i in range(n):
+            if width == 1:
+                assert int(tfo.poly_eval(c, int(d[i]))[0]) == int(v[i])
+                assert int(tfo.poly_eval(zz, int(d[i]))[0]) == 0
+            else:
+                assert np.array_equal(tfo.poly_eval_xfe_point(c, d[3 * i: 3 * i + 3]), v[3 * i: 3 * i + 3])
+                assert not tfo.poly_eval_xfe_point(zz, d[3 * i: 3 * i + 3]).any()
+
+
+def test_xfe_inverse_is_the_inverse(oracle):
+    """XFieldElement::inverse (x_field_element.rs:371-379): a * a^-1 = 1 (tests :1294-1300), lifted base-field elements invert
+    like BFieldElement::inverse, zero panics."""
+    tfo = oracle
+    one = np.array([tfo.bfe_new(1), 0, 0], dtype=np.uint64)
+    for seed in range(20):
+        a = tfo.fill_random(3, 900 + seed)
+        assert np.array_equal(tfo.xfe_mul(a, tfo.xfe_inverse(a)), one)
+    b = np.array([tfo.bfe_new(12345), 0, 0], dtype=np.uint64)
+    assert int(tfo.xfe_inverse(b)[0]) == tfo.bfe_inverse(tfo.bfe_new(12345)) and not tfo.xfe_inverse(b)[1:].any()
+    for sparse in ([0, 1, 0], [0, 0, 1], [1, 0, 1]):
+        a = tfo.to_raw(sparse)
+        assert np.array_equal(tfo.xfe_mul(a, tfo.xfe_inverse(a)), one)
+    with pytest.raises(tfo.OraclePanic):
+        tfo.xfe_inverse(np.zeros(3, dtype=np.uint64))

@@ -23,6 +23,7 @@ run "TF_NTT_NO_GFAST=1" "single-pass transforms with the column-major thread ord
 run "TF_COSET_EVAL_NO_SPLIT=1" "blown-up coset evaluation by zero padding instead of interleaved cosets"
 run "TF_POLY_MUL_NO_FUSE=1" "fast_multiply with separate pad / Hadamard / truncate passes"
 run "TF_NTT_NO_BLOCK=1" "two-pass plans instead of the whole-transform-per-workgroup kernel, 2^11..2^14"
+run "TF_NTT_NO_XFE_BLOCK=1" "XFE slices of 2^11 / 2^12 points through two-pass plans instead of the block kernel's limb transforms"
 run "TF_NTT_NO_ROWS32=1" "direct loads instead of LDS-staged rows for 32-point BFE transforms"
 run "TF_NTT_NO_WORDS16=1" "XFE rows through the last passes as tiles of whole elements, not whole cache lines"
 run "TF_NTT_NO_COL_SHIFT=1" "last-pass tile boundaries not shifted to the output's cache-line alignment"

@@ -70,7 +70,7 @@ def _check(rc: int, where: str):
         return
     if rc in (1, 2, 3, 11):
         raise MerkleTreeError(rc, where)
-    if rc in (4, 5, 6, 12):
+    if rc in (4, 5, 6, 12, 14):
         raise NttPanic(rc, where)
     raise TwentyFirstError(rc, where)
 
@@ -234,6 +234,46 @@ class Polynomial:
         fn = lib().tf_poly_batch_evaluate_bfe if self.width == 1 else lib().tf_poly_batch_evaluate_xfe
         _check(fn(_ptr(self.coefficients), self.coefficients.size // self.width, _ptr(pts), n_points, _ptr(out)), "batch_evaluate")
         return out
+
+    @classmethod
+    def zerofier(cls, roots: np.ndarray, width: int = 1) -> "Polynomial":
+        """math/polynomial.rs:1435-1441 (and par_zerofier :1444-1459): the monic polynomial with exactly these roots."""
+        r = _words(np.ascontiguousarray(roots, dtype=np.uint64).reshape(-1), "roots")
+        if r.size % width:
+            raise ValueError("roots size is not n * width")
+        n = r.size // width
+        out = np.empty((n + 1) * width, dtype=np.uint64)
+        fn = lib().tf_poly_zerofier_bfe if width == 1 else lib().tf_poly_zerofier_xfe
+        _check(fn(_ptr(r), n, _ptr(out)), "zerofier")
+        return cls(out, width=width)
+
+    @classmethod
+    def interpolate(cls, domain: np.ndarray, values: np.ndarray, width: int = 1) -> "Polynomial":
+        """math/polynomial.rs:1502-1520 (and par_interpolate :1525-1545, fast_interpolate :1611-1654): the lowest-degree
+        polynomial through (domain[i], values[i]).  Panics (NttPanic) on an empty domain, on unequal lengths and on repeated
+        domain points."""
+        return cls.batch_fast_interpolate(domain, [values], width=width)[0]
+
+    @classmethod
+    def batch_fast_interpolate(cls, domain: np.ndarray, values_matrix, width: int = 1) -> list:
+        """math/polynomial.rs:1703-1731: one interpolant per row of `values_matrix` over the same domain."""
+        d = _words(np.ascontiguousarray(domain, dtype=np.uint64).reshape(-1), "domain")
+        if d.size % width:
+            raise ValueError("domain size is not n * width")
+        n = d.size // width
+        if n == 0:
+            raise NttPanic(14, "interpolate")  # "interpolation must happen through more than zero points" (:1503-1506)
+        rows = [np.ascontiguousarray(v, dtype=np.uint64).reshape(-1) for v in values_matrix]
+        for v in rows:
+            if v.size != n * width:
+                raise NttPanic(14, "interpolate: the domain and values lists have to be of equal length")  # :1507-1511
+        if not rows:
+            return []
+        vals = np.ascontiguousarray(np.concatenate(rows))
+        out = np.empty(len(rows) * n * width, dtype=np.uint64)
+        fn = lib().tf_poly_interpolate_bfe if width == 1 else lib().tf_poly_interpolate_xfe
+        _check(fn(_ptr(d), _ptr(vals), n, len(rows), _ptr(out)), "interpolate")
+        return [cls(out[i * n * width:(i + 1) * n * width], width=width) for i in range(len(rows))]
 
     @staticmethod
     def batch_coset_extrapolate(domain_offset_raw: int, codeword_length: int, codewords: np.ndarray, points: np.ndarray,

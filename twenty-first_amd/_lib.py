@@ -61,6 +61,14 @@ SIGNATURES = {
     "tf_poly_batch_evaluate_xfe": (C.c_int, [_vp, _sz, _vp, _sz, _vp]),
     "tf_poly_batch_evaluate_bfe_dev": (C.c_int, [_vp, _sz, _vp, _sz, _vp, _vp]),
     "tf_poly_batch_evaluate_xfe_dev": (C.c_int, [_vp, _sz, _vp, _sz, _vp, _vp]),
+    "tf_poly_zerofier_bfe": (C.c_int, [_vp, _sz, _vp]),
+    "tf_poly_zerofier_xfe": (C.c_int, [_vp, _sz, _vp]),
+    "tf_poly_zerofier_bfe_dev": (C.c_int, [_vp, _sz, _vp, _vp]),
+    "tf_poly_zerofier_xfe_dev": (C.c_int, [_vp, _sz, _vp, _vp]),
+    "tf_poly_interpolate_bfe": (C.c_int, [_vp, _vp, _sz, _sz, _vp]),
+    "tf_poly_interpolate_xfe": (C.c_int, [_vp, _vp, _sz, _sz, _vp]),
+    "tf_poly_interpolate_bfe_dev": (C.c_int, [_vp, _vp, _sz, _sz, _vp, _vp]),
+    "tf_poly_interpolate_xfe_dev": (C.c_int, [_vp, _vp, _sz, _sz, _vp, _vp]),
     "tf_coset_extrapolate_bfe": (C.c_int, [C.c_uint64, _vp, _sz, _sz, _vp, _sz, _vp]),
     "tf_coset_extrapolate_xfe": (C.c_int, [C.c_uint64, _vp, _sz, _sz, _vp, _sz, _vp]),
     "tf_coset_extrapolate_bfe_dev": (C.c_int, [C.c_uint64, _vp, _sz, _sz, _vp, _sz, _vp, _vp]),

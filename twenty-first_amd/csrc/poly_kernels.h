@@ -249,4 +249,182 @@ __global__ void __launch_bounds__(256) chunk_combine_kernel(const u64* vals, lon
     fe_store<L>(out + i * L, acc);
 }
 
+// ---- zerofier and interpolation through the same tree ----------------------------------------------------------------------
+// Polynomial::zerofier (polynomial.rs:1435-1485) is the root of the tree; Polynomial::interpolate / fast_interpolate /
+// batch_fast_interpolate (:1502-1838) is the tree walked upwards:
+//   f = sum_i w_i Z(x) / (x - x_i),  w_i = v_i / Z'(x_i)              (the interpolant is unique: any scheme returns the reference's
+//   N_node = sum_{i in node} w_i Z_node / (x - x_i)  ->  N_parent = N_left Z_right + N_right Z_left       coefficients exactly)
+// The tree is padded with zero points up to M = leaf << h; with zero weights on the padding every padded quantity is the true
+// one times x^(number of padded points below the node), so the zerofier and the interpolant come out of the root shifted up by
+// M - n coefficients and are copied out from there.
+
+// D = Z' of the TRUE zerofier Z = (x^M + root_tail) / x^(M - n):  D[j] = (j + 1) Z_{j + 1} for j < n, zero up to M.
+template <int L>
+__global__ void __launch_bounds__(256) zerofier_derivative_kernel(const u64* root_tail, long long M, long long n, u64* D) {
+    const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= M) return;
+    u64 v[L];
+#pragma unroll
+    for (int q = 0; q < L; ++q) v[q] = 0;
+    if (j < n) {
+        const long long idx = j + 1 + (M - n);
+        const u64 k = gl::to_mont((u64)(j + 1));
+#pragma unroll
+        for (int q = 0; q < L; ++q) v[q] = gl::mont_mul(k, idx < M ? root_tail[idx * L + q] : (q ? 0 : gl::ONE));
+    }
+    fe_store<L>(D + j * L, v);
+}
+
+// out[j] = Z_j, j <= n: the true zerofier's n + 1 coefficients from the padded root
+template <int L>
+__global__ void __launch_bounds__(256) zerofier_unpad_kernel(const u64* root_tail, long long M, long long n, u64* out) {
+    const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j > n) return;
+    const long long idx = j + (M - n);
+#pragma unroll
+    for (int q = 0; q < L; ++q) out[j * L + q] = idx < M ? root_tail[idx * L + q] : (q ? 0 : gl::ONE);
+}
+
+// Multiplicative inverse in F_p[x] / (x^3 - x + 1): multiplication by a is the matrix
+//   [ a0   -a2      -a1    ]
+//   [ a1   a0 + a2  a1 - a2]     (x_field_element.rs:512-536 read as a linear map of the other operand)
+//   [ a2   a1       a0 + a2]
+// and a^-1 is the solution of M b = (1, 0, 0): the cofactors of the first row over the determinant.
+__device__ __forceinline__ bool xfe_inverse(const u64 (&a)[3], u64 (&r)[3]) {
+    const u64 s = gl::add(a[0], a[2]), dd = gl::sub(a[1], a[2]);
+    const u64 c0 = gl::sub(gl::mont_mul(s, s), gl::mont_mul(dd, a[1]));
+    const u64 c1 = gl::sub(gl::mont_mul(dd, a[2]), gl::mont_mul(a[1], s));
+    const u64 c2 = gl::sub(gl::mont_mul(a[1], a[1]), gl::mont_mul(s, a[2]));
+    const u64 det = gl::sub(gl::sub(gl::mont_mul(a[0], c0), gl::mont_mul(a[2], c1)), gl::mont_mul(a[1], c2));
+    const u64 di = gl::mont_inverse(det);
+    r[0] = gl::mont_mul(c0, di);
+    r[1] = gl::mont_mul(c1, di);
+    r[2] = gl::mont_mul(c2, di);
+    return det != 0;
+}
+
+// w[i] = 1 / x[i], i < n; *flag is raised when some x[i] is zero (a repeated domain point: the reference panics in
+// batch_inversion, traits.rs:106)
+template <int L>
+__global__ void __launch_bounds__(256) fe_inverse_kernel(const u64* x, long long n, u64* w, int* flag) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u64 a[L], r[L];
+    fe_load<L>(x + i * L, a);
+    bool ok;
+    if constexpr (L == 1) {
+        r[0] = gl::mont_inverse(a[0]);
+        ok = a[0] != 0;
+    } else {
+        ok = xfe_inverse(a, r);
+    }
+    if (!ok) atomicOr(flag, 1);
+    fe_store<L>(w + i * L, r);
+}
+
+// targets[row][i] = values[row][i] * w[i] for i < n, zero for n <= i < M   (grid.y = rows; values rows n elements apart)
+template <int L>
+__global__ void __launch_bounds__(256) interpolation_targets_kernel(const u64* values, const u64* w, long long n, long long M, u64* targets) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M) return;
+    const long long row = blockIdx.y;
+    u64 r[L];
+#pragma unroll
+    for (int q = 0; q < L; ++q) r[q] = 0;
+    if (i < n) {
+        u64 v[L], wi[L];
+        fe_load<L>(values + (row * n + i) * L, v);
+        fe_load<L>(w + i * L, wi);
+        fe_mul<L>(v, wi, r);
+    }
+    fe_store<L>(targets + (row * M + i) * L, r);
+}
+
+// Leaves of the interpolant: N = sum_i w_i prod_{k != i} (x - p_k) over the leaf's d points, built with the zerofier one point at
+// a time:  N <- N (x - p) + w Z,  Z <- Z (x - p).   grid = (leaves, rows), block = d threads (thread t owns coefficient t).
+template <int L>
+__global__ void __launch_bounds__(kLeafMax) leaf_interpolant_kernel(const u64* points, const u64* targets, long long n_points, int d,
+                                                                    long long M, u64* N) {
+    __shared__ u64 c[kLeafMax * L];   // Z, coefficients 0 .. d - 1 (its leading 1 is still inside while it is needed)
+    __shared__ u64 nn[kLeafMax * L];  // N
+    const int t = threadIdx.x;
+    const long long leaf = blockIdx.x, row = blockIdx.y;
+#pragma unroll
+    for (int k = 0; k < L; ++k) {
+        c[t * L + k] = (t == 0 && k == 0) ? gl::ONE : 0;
+        nn[t * L + k] = 0;
+    }
+    __syncthreads();
+    for (int i = 0; i < d; ++i) {
+        const long long pi = leaf * d + i;
+        u64 p[L], w[L], cur[L], prev[L], ncur[L], nprev[L];
+#pragma unroll
+        for (int k = 0; k < L; ++k) {
+            p[k] = pi < n_points ? points[pi * L + k] : 0;
+            w[k] = pi < n_points ? targets[(row * M + pi) * L + k] : 0;
+        }
+        fe_load<L>(&c[t * L], cur);
+        fe_load<L>(&nn[t * L], ncur);
+#pragma unroll
+        for (int k = 0; k < L; ++k) {
+            prev[k] = t > 0 ? c[(t - 1) * L + k] : 0;
+            nprev[k] = t > 0 ? nn[(t - 1) * L + k] : 0;
+        }
+        __syncthreads();
+        u64 pc[L], pn[L], wz[L], a[L], b[L], zc[L];
+        fe_mul<L>(p, cur, pc);
+        fe_mul<L>(p, ncur, pn);
+        fe_mul<L>(w, cur, wz);
+        fe_sub<L>(nprev, pn, a);
+        fe_add<L>(a, wz, b);
+        fe_sub<L>(prev, pc, zc);
+        fe_store<L>(&nn[t * L], b);
+        fe_store<L>(&c[t * L], zc);
+        __syncthreads();
+    }
+    u64 v[L];
+    fe_load<L>(&nn[t * L], v);
+    fe_store<L>(N + (row * M + leaf * d + t) * L, v);
+}
+
+// N_parent = N_left Z_right + N_right Z_left in the transform domain of order 2d (deg N_parent < 2d: no wrap-around).
+//   Nh: forward transforms of the children's interpolants, [rows * children][2d]   (d coefficients each, zero padded)
+//   Th: forward transforms of the children's zerofier TAILS, [children][2d], shared by the rows; the leading x^d of a zerofier
+//       transforms to w_2d^(d k) = (-1)^k, added here
+//   out[(row * parents + node) * 2d + k] = Nh_left[k] (Th_right[k] + (-1)^k) + Nh_right[k] (Th_left[k] + (-1)^k)
+// The inverse transform of `out`, in place, IS the next level's [rows][M] array.
+template <int L>
+__global__ void __launch_bounds__(256) interpolant_pointwise_kernel(const u64* Nh, const u64* Th, u64* out, long long d, long long parents,
+                                                                    long long rows) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * parents * 2 * d) return;
+    const long long k = i % (2 * d), gnode = i / (2 * d), node = gnode % parents;
+    u64 nl[L], nr[L], zl[L], zr[L], a[L], b[L], r[L];
+    fe_load<L>(Nh + ((2 * gnode) * 2 * d + k) * L, nl);
+    fe_load<L>(Nh + ((2 * gnode + 1) * 2 * d + k) * L, nr);
+    fe_load<L>(Th + ((2 * node) * 2 * d + k) * L, zl);
+    fe_load<L>(Th + ((2 * node + 1) * 2 * d + k) * L, zr);
+    if (k & 1) {
+        zl[0] = gl::sub(zl[0], gl::ONE);
+        zr[0] = gl::sub(zr[0], gl::ONE);
+    } else {
+        zl[0] = gl::add(zl[0], gl::ONE);
+        zr[0] = gl::add(zr[0], gl::ONE);
+    }
+    fe_mul<L>(nl, zr, a);
+    fe_mul<L>(nr, zl, b);
+    fe_add<L>(a, b, r);
+    fe_store<L>(out + i * L, r);
+}
+
+// out[row][j] = Nroot[row][j + M - n], j < n: the interpolant's n coefficients from the padded root
+template <int L>
+__global__ void __launch_bounds__(256) interpolant_unpad_kernel(const u64* Nroot, long long M, long long n, u64* out) {
+    const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const long long row = blockIdx.y;
+#pragma unroll
+    for (int q = 0; q < L; ++q) out[(row * n + j) * L + q] = Nroot[(row * M + j + (M - n)) * L + q];
+}
+
 }  // namespace tfk

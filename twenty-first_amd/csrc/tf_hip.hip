@@ -2072,6 +2072,161 @@ int batch_evaluate_dev(const u64* coeffs, size_t n_coeffs, size_t poly_stride, s
     return TF_OK;
 }
 
+// ---------------------------------------------------------------- zerofier and interpolation through the zerofier tree
+// Polynomial::zerofier / par_zerofier (polynomial.rs:1435-1485) and Polynomial::interpolate / par_interpolate / fast_interpolate /
+// batch_fast_interpolate (:1502-1838), poly_kernels.h has the scheme.  The tree of the padded point set is built once; the
+// zerofier is its root, the interpolants of `rows` value rows share the tree and the inverse weights 1 / Z'(x_i) (what the
+// reference's batch_fast_interpolate memoises in its two dictionaries, :1723-1731).
+struct PaddedTree {
+    ZerofierTree T;
+    u64* arena = nullptr;     // tree levels + work + product work
+    u64* work = nullptr;      // 8 M L words
+    u64* pm_work = nullptr;   // 8 M L words
+    u64* root_tail = nullptr; // M L words: x^M + root_tail = prod (x - p_i) * x^(M - n)
+    u64* extra = nullptr;     // caller's space behind the tree
+};
+
+template <int L>
+int padded_tree_build(const u64* points, size_t n_points, size_t extra_words, PaddedTree* pt, hipStream_t s) {
+    constexpr int kTreeLeaf = tree_leaf(L);
+    long long M = kTreeLeaf;
+    int h = 0;
+    while (M < (long long)n_points) M <<= 1, ++h;
+    pt->T.M = M;
+    pt->T.h = h;
+    // tree (2 h M) + work (8 M) + product work (8 M) + root tail (M) + a scratch inverse for a single leaf (M) + caller's
+    const size_t words = (size_t)(2 * h + 8 + 8 + 2) * (size_t)M * L + extra_words;
+    if (words * sizeof(u64) > (size_t(64) << 30)) return TF_ERR_OUT_OF_MEMORY;
+    hipError_t e = hipMallocAsync(reinterpret_cast<void**>(&pt->arena), words * sizeof(u64), s);
+    if (e != hipSuccess) return hip_fail(e, "hipMallocAsync(zerofier tree)", __FILE__, __LINE__);
+    pt->work = pt->arena + (size_t)(2 * h) * M * L;
+    pt->pm_work = pt->work + (size_t)8 * M * L;
+    pt->root_tail = pt->pm_work + (size_t)8 * M * L;
+    u64* leaf_inv = pt->root_tail + (size_t)M * L;
+    pt->extra = leaf_inv + (size_t)M * L;
+    if (h == 0) {  // one leaf: it is the root
+        hipLaunchKernelGGL(tfk::leaf_zerofier_kernel<L>, dim3(1), dim3(kTreeLeaf), 0, s, points, (long long)n_points, kTreeLeaf,
+                           pt->root_tail, leaf_inv);
+        HIPCHK(hipGetLastError());
+        return TF_OK;
+    }
+    int rc = zerofier_tree_build<L>(points, (long long)n_points, &pt->T, pt->arena, pt->pm_work, s);
+    if (rc) return rc;
+    const long long d = M / 2;  // the two nodes of level h - 1
+    u64* P = pt->work;
+    rc = poly_mul_dev(pt->T.tails[h - 1], (size_t)d, pt->T.tails[h - 1] + d * L, (size_t)d, P, 1, L, s, 0, 0, pt->pm_work);
+    if (rc) return rc;
+    return launch_1d<L>(tfk::zerofier_combine_kernel<L>, 2 * d, s, (const u64*)P, (const u64*)pt->T.tails[h - 1], pt->root_tail, d, (long long)1);
+}
+
+int padded_tree_free(PaddedTree* pt, hipStream_t s, int rc) {
+    hipError_t e = pt->arena ? hipFreeAsync(pt->arena, s) : hipSuccess;
+    if (rc) return rc;
+    if (e != hipSuccess) return hip_fail(e, "hipFreeAsync", __FILE__, __LINE__);
+    return TF_OK;
+}
+
+template <int L>
+int zerofier_dev_t(const u64* roots, size_t n_roots, u64* out, hipStream_t s) {
+    PaddedTree pt;
+    int rc = padded_tree_build<L>(roots, n_roots, 0, &pt, s);
+    if (!rc) rc = launch_1d<L>(tfk::zerofier_unpad_kernel<L>, (long long)n_roots + 1, s, (const u64*)pt.root_tail, pt.T.M, (long long)n_roots, out);
+    return padded_tree_free(&pt, s, rc);
+}
+
+int zerofier_dev(const u64* roots, size_t n_roots, u64* out, int L, void* stream) {
+    if (!out || (n_roots && !roots)) return TF_ERR_NULL_POINTER;
+    if (n_roots > (size_t(1) << 30)) return TF_ERR_LEN_TOO_LARGE;
+    DeviceCtx* ctx = nullptr;
+    int rc = current_ctx(&ctx);
+    if (rc) return rc;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    return L == 1 ? zerofier_dev_t<1>(roots, n_roots, out, s) : zerofier_dev_t<3>(roots, n_roots, out, s);
+}
+
+template <int L>
+int interpolate_dev_t(const u64* domain, const u64* values, size_t n, size_t rows, u64* out, hipStream_t s) {
+    constexpr int kTreeLeaf = tree_leaf(L);
+    long long M = kTreeLeaf;
+    while (M < (long long)n) M <<= 1;
+    const size_t ML = (size_t)M * L;
+    // rows go up the tree in slabs: targets, two interpolant levels and the children's transforms (2 M) per row
+    const size_t slab = std::max<size_t>(1, std::min<size_t>(std::min<size_t>(rows, 32768), (size_t(1) << 26) / ML));
+    // behind the tree: derivative (M), its values (M), inverse weights (M), transforms of a level's tails (2 M),
+    // slab x (targets, N ping, N pong, transforms 2 M), flag
+    const size_t extra = (5 + 5 * slab) * ML + 2;
+    PaddedTree pt;
+    int rc = padded_tree_build<L>(domain, n, extra, &pt, s);
+    if (rc) return padded_tree_free(&pt, s, rc);
+    DeviceCtx* ctx = nullptr;
+    rc = current_ctx(&ctx);
+    if (rc) return padded_tree_free(&pt, s, rc);
+    u64* deriv = pt.extra;
+    u64* dz = deriv + ML;
+    u64* winv = dz + ML;
+    u64* Th = winv + ML;
+    u64* targets = Th + 2 * ML;
+    u64* na = targets + slab * ML;
+    u64* nb = na + slab * ML;
+    u64* Nh = nb + slab * ML;
+    int* flag = reinterpret_cast<int*>(Nh + 2 * slab * ML);
+    const int h = pt.T.h;
+    if (!rc) rc = launch_1d<L>(tfk::zerofier_derivative_kernel<L>, M, s, (const u64*)pt.root_tail, M, (long long)n, deriv);
+    if (!rc) rc = zerofier_tree_evaluate<L>(pt.T, deriv, domain, (long long)n, dz, pt.work, pt.pm_work, s);
+    if (!rc) {
+        hipError_t e = hipMemsetAsync(flag, 0, sizeof(int), s);
+        if (e != hipSuccess) rc = hip_fail(e, "hipMemsetAsync", __FILE__, __LINE__);
+    }
+    if (!rc) rc = launch_1d<L>(tfk::fe_inverse_kernel<L>, (long long)n, s, (const u64*)dz, (long long)n, winv, flag);
+    if (!rc) {
+        int host_flag = 0;
+        hipError_t e = hipMemcpyAsync(&host_flag, flag, sizeof(int), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e != hipSuccess) rc = hip_fail(e, "interpolate: weight check", __FILE__, __LINE__);
+        else if (host_flag) rc = TF_ERR_INVERSE_OF_ZERO;  // Z'(x_i) = 0: a repeated domain point
+    }
+    for (size_t r0 = 0; r0 < rows && !rc; r0 += slab) {
+        const size_t nr = std::min(slab, rows - r0);
+        hipLaunchKernelGGL(tfk::interpolation_targets_kernel<L>, dim3((unsigned)((M + 255) / 256), (unsigned)nr), dim3(256), 0, s,
+                           values + r0 * n * L, (const u64*)winv, (long long)n, M, targets);
+        hipLaunchKernelGGL(tfk::leaf_interpolant_kernel<L>, dim3((unsigned)(M / kTreeLeaf), (unsigned)nr), dim3(kTreeLeaf), 0, s, domain,
+                           (const u64*)targets, (long long)n, kTreeLeaf, M, na);
+        HIPCHK(hipGetLastError());
+        u64* cur = na;
+        u64* nxt = nb;
+        for (int l = 0; l < h && !rc; ++l) {
+            // one level for all rows of the slab: transforms of order 2d of every child's tail (shared) and interpolant, the
+            // combination N_left Z_right + N_right Z_left pointwise, one inverse transform -- which lands in the next level's layout
+            const long long d = (long long)kTreeLeaf << l, children = M / d, parents = children / 2;
+            rc = run_ntt(ctx, pt.T.tails[l], Th, d * L, 2 * d * L, (size_t)(2 * d), (size_t)children, L, false, nullptr, d, s);
+            if (!rc) rc = run_ntt(ctx, cur, Nh, d * L, 2 * d * L, (size_t)(2 * d), (size_t)(children * (long long)nr), L, false, nullptr, d, s);
+            if (!rc) rc = launch_1d<L>(tfk::interpolant_pointwise_kernel<L>, (long long)nr * parents * 2 * d, s, (const u64*)Nh, (const u64*)Th, nxt, d,
+                                       parents, (long long)nr);
+            if (!rc) rc = run_ntt(ctx, nxt, nxt, 2 * d * L, 2 * d * L, (size_t)(2 * d), (size_t)(parents * (long long)nr), L, true, nullptr, -1, s);
+            std::swap(cur, nxt);
+        }
+        if (!rc) {
+            hipLaunchKernelGGL(tfk::interpolant_unpad_kernel<L>, dim3((unsigned)((n + 255) / 256), (unsigned)nr), dim3(256), 0, s,
+                               (const u64*)cur, M, (long long)n, out + r0 * n * L);
+            HIPCHK(hipGetLastError());
+        }
+    }
+    return padded_tree_free(&pt, s, rc);
+}
+
+// `rows` value rows of n elements over one domain of n distinct points -> rows x n coefficients (low to high).
+int interpolate_dev(const u64* domain, const u64* values, size_t n, size_t rows, u64* out, int L, void* stream) {
+    if (n == 0) return TF_ERR_EMPTY_DOMAIN;  // "interpolation must happen through more than zero points" (:1503-1506)
+    if (rows == 0) return TF_OK;
+    if (!domain || !values || !out) return TF_ERR_NULL_POINTER;
+    if (n > (size_t(1) << 30)) return TF_ERR_LEN_TOO_LARGE;
+    DeviceCtx* ctx = nullptr;
+    int rc = current_ctx(&ctx);
+    if (rc) return rc;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    return L == 1 ? interpolate_dev_t<1>(domain, values, n, rows, out, s) : interpolate_dev_t<3>(domain, values, n, rows, out, s);
+}
+
 // Polynomial::{coset_extrapolate, batch_coset_extrapolate} (polynomial.rs:2117-2331): the values, at `points`, of the
 // degree-< n interpolants of `batch` codewords given on the coset {offset * w_n^i}.  Both of the reference's routes
 // (naive :2145-2156, fast :2158-2170) compute exactly interpolant(point), which is what this does:
@@ -2244,6 +2399,7 @@ const char* tf_status_string(int status) {
         case TF_ERR_LEAF_INDEX_INVALID: return "TF_ERR_LEAF_INDEX_INVALID";
         case TF_ERR_INVERSE_OF_ZERO: return "TF_ERR_INVERSE_OF_ZERO";
         case TF_ERR_BUFFER_TOO_SMALL: return "TF_ERR_BUFFER_TOO_SMALL";
+        case TF_ERR_EMPTY_DOMAIN: return "TF_ERR_EMPTY_DOMAIN";
         default: return "TF_ERR_UNKNOWN";
     }
 }
@@ -2583,6 +2739,29 @@ int tf_poly_batch_evaluate_xfe(const uint64_t* c, size_t nc, const uint64_t* pts
     return host_roundtrip(c, 3 * nc, pts, 3 * np, out, 3 * np,
                           [&](u64* dc, u64* dp, u64* o, hipStream_t s) { return batch_evaluate_dev(dc, nc, 3 * nc, 1, dp, np, o, 3, s); });
 }
+int tf_poly_zerofier_bfe_dev(const uint64_t* r, size_t n, uint64_t* out, void* stream) { return zerofier_dev(r, n, out, 1, stream); }
+int tf_poly_zerofier_xfe_dev(const uint64_t* r, size_t n, uint64_t* out, void* stream) { return zerofier_dev(r, n, out, 3, stream); }
+static int zerofier_host(const uint64_t* r, size_t n, uint64_t* out, int L) {
+    if (!out || (n && !r)) return TF_ERR_NULL_POINTER;
+    return host_roundtrip(r, n * L, nullptr, 0, out, (n + 1) * L, [&](u64* dr, u64*, u64* o, hipStream_t s) { return zerofier_dev(dr, n, o, L, s); });
+}
+int tf_poly_zerofier_bfe(const uint64_t* r, size_t n, uint64_t* out) { return zerofier_host(r, n, out, 1); }
+int tf_poly_zerofier_xfe(const uint64_t* r, size_t n, uint64_t* out) { return zerofier_host(r, n, out, 3); }
+int tf_poly_interpolate_bfe_dev(const uint64_t* d, const uint64_t* v, size_t n, size_t rows, uint64_t* out, void* stream) {
+    return interpolate_dev(d, v, n, rows, out, 1, stream);
+}
+int tf_poly_interpolate_xfe_dev(const uint64_t* d, const uint64_t* v, size_t n, size_t rows, uint64_t* out, void* stream) {
+    return interpolate_dev(d, v, n, rows, out, 3, stream);
+}
+static int interpolate_host(const uint64_t* d, const uint64_t* v, size_t n, size_t rows, uint64_t* out, int L) {
+    if (n == 0) return TF_ERR_EMPTY_DOMAIN;
+    if (rows == 0) return TF_OK;
+    if (!d || !v || !out) return TF_ERR_NULL_POINTER;
+    return host_roundtrip(d, n * L, v, rows * n * L, out, rows * n * L,
+                          [&](u64* dd, u64* dv, u64* o, hipStream_t s) { return interpolate_dev(dd, dv, n, rows, o, L, s); });
+}
+int tf_poly_interpolate_bfe(const uint64_t* d, const uint64_t* v, size_t n, size_t rows, uint64_t* out) { return interpolate_host(d, v, n, rows, out, 1); }
+int tf_poly_interpolate_xfe(const uint64_t* d, const uint64_t* v, size_t n, size_t rows, uint64_t* out) { return interpolate_host(d, v, n, rows, out, 3); }
 static int coset_extrapolate_host(uint64_t offset, const uint64_t* cw, size_t n, size_t batch, const uint64_t* pts, size_t np,
                                   uint64_t* out, int L) {
     if (n == 0) return TF_ERR_LEN_NOT_POWER_OF_TWO;

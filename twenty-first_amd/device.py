@@ -184,6 +184,27 @@ def batch_evaluate(coeffs, n_coeffs: int, points, out, width: int = 1, stream=No
     _chk(fn(_p(coeffs), n_coeffs, _p(points), points.numel() // width, _p(out), _stream(stream)), "batch_evaluate")
 
 
+def zerofier(roots, out, width: int = 1, stream=None) -> None:
+    """Polynomial::zerofier (math/polynomial.rs:1435-1441) on device buffers: out = the n + 1 coefficients of prod (x - roots[i])."""
+    roots, out = _t(roots, "roots"), _t(out, "out")
+    _need(roots.numel() % width == 0, "roots must hold whole elements")
+    n = roots.numel() // width
+    _need(out.numel() == (n + 1) * width, "out must hold n_roots + 1 coefficients")
+    fn = _lib.lib().tf_poly_zerofier_bfe_dev if width == 1 else _lib.lib().tf_poly_zerofier_xfe_dev
+    _chk(fn(_p(roots), n, _p(out), _stream(stream)), "zerofier")
+
+
+def interpolate(domain, values, out, rows: int = 1, width: int = 1, stream=None) -> None:
+    """Polynomial::interpolate / batch_fast_interpolate (math/polynomial.rs:1502-1838) on device buffers: `rows` value rows over
+    one domain -> rows x n coefficients (untrimmed)."""
+    domain, values, out = _t(domain, "domain"), _t(values, "values"), _t(out, "out")
+    _need(domain.numel() % width == 0, "domain must hold whole elements")
+    n = domain.numel() // width
+    _need(values.numel() == rows * n * width and out.numel() == rows * n * width, "values / out must hold rows * n elements")
+    fn = _lib.lib().tf_poly_interpolate_bfe_dev if width == 1 else _lib.lib().tf_poly_interpolate_xfe_dev
+    _chk(fn(_p(domain), _p(values), n, rows, _p(out), _stream(stream)), "interpolate")
+
+
 def coset_extrapolate(offset_raw: int, codewords, n: int, points, out, batch: int = 1, width: int = 1, stream=None) -> None:
     """Polynomial::batch_coset_extrapolate (math/polynomial.rs:2196-2208) on device buffers:
     out[(b * n_points + i) * width] = interpolant_b(points[i])."""

@@ -131,6 +131,27 @@ int main() {
         // batch_evaluate: 1 + 2x + 3x^2 at 0, 1, 2, 10
         EXPECT(a.batch_evaluate(bfe_vec({0, 1, 2, 10})) == bfe_vec({1, 6, 17, 321}));
     }
+    {  // zerofier doc example (polynomial.rs:1426-1434): roots 2, 4, 6 -> degree 3, zero exactly there; interpolate doc example
+       // (:1490-1497): through (0,1) (1,3) (2,5) (3,7) -> 1 + 2x (degree 1, value 9 at 4)
+        using Poly = Polynomial<BFieldElement>;
+        auto roots = bfe_vec({2, 4, 6});
+        Poly z = Poly::zerofier(roots);
+        EXPECT(z.degree() == 3 && z.coefficients.back() == BFieldElement::new_(1));
+        EXPECT(z.batch_evaluate(roots) == bfe_vec({0, 0, 0}));
+        for (auto& v : z.batch_evaluate(bfe_vec({0, 1, 3, 5}))) EXPECT(!(v == BFieldElement{}));
+        EXPECT(Poly::zerofier({}).coefficients == bfe_vec({1}));
+        Poly f = Poly::interpolate(bfe_vec({0, 1, 2, 3}), bfe_vec({1, 3, 5, 7}));
+        EXPECT(f.coefficients == bfe_vec({1, 2}));
+        EXPECT(f.batch_evaluate(bfe_vec({4})) == bfe_vec({9}));
+        EXPECT(Poly::interpolate(bfe_vec({5}), bfe_vec({42})).coefficients == bfe_vec({42}));  // one point: the constant (:3562-3570)
+        auto both = Poly::batch_fast_interpolate(bfe_vec({0, 1, 2, 3}), {bfe_vec({1, 3, 5, 7}), bfe_vec({0, 1, 4, 9})});
+        EXPECT(both.size() == 2 && both[0].coefficients == bfe_vec({1, 2}) && both[1].coefficients == bfe_vec({0, 0, 1}));
+        bool p1 = false, p2 = false, p3 = false;
+        try { Poly::interpolate({}, {}); } catch (const NttPanic& e) { p1 = e.code == TF_ERR_EMPTY_DOMAIN; }          // :3522-3526
+        try { Poly::interpolate(bfe_vec({1, 2}), bfe_vec({1})); } catch (const NttPanic&) { p2 = true; }              // :3546-3552
+        try { Poly::interpolate(bfe_vec({1, 1}), bfe_vec({1, 2})); } catch (const NttPanic& e) { p3 = e.code == TF_ERR_INVERSE_OF_ZERO; }  // :3554-3560
+        EXPECT(p1 && p2 && p3);
+    }
     {  // batch_coset_extrapolate doc example, polynomial.rs:2183-2195: constant codewords extrapolate to the constant
         const size_t n = 32;
         std::vector<BFieldElement> codewords;

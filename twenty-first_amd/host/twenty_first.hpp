@@ -97,7 +97,7 @@ struct MerkleTreeError : BackendError {
 inline void check(int rc, const char* where) {
     if (rc == TF_OK) return;
     if ((rc >= 1 && rc <= 3) || rc == TF_ERR_LEAF_INDEX_INVALID) throw MerkleTreeError(rc, where);  // merkle_tree.rs:933-965
-    if ((rc >= 4 && rc <= 6) || rc == TF_ERR_INVERSE_OF_ZERO) throw NttPanic(rc, where);            // the reference panics here
+    if ((rc >= 4 && rc <= 6) || rc == TF_ERR_INVERSE_OF_ZERO || rc == TF_ERR_EMPTY_DOMAIN) throw NttPanic(rc, where);  // the reference panics here
     throw BackendError(rc, where);
 }
 
@@ -167,6 +167,39 @@ struct Polynomial {
         else
             check(tf_poly_batch_evaluate_xfe(c, coefficients.size(), d, domain.size(), o), "batch_evaluate");
         return out;
+    }
+    // zerofier (polynomial.rs:1435-1441, par_zerofier :1444-1459): the monic polynomial with exactly these roots
+    static Polynomial zerofier(const std::vector<FF>& roots) {
+        std::vector<FF> out(roots.size() + 1);
+        const uint64_t* r = reinterpret_cast<const uint64_t*>(roots.data());
+        uint64_t* o = reinterpret_cast<uint64_t*>(out.data());
+        if constexpr (sizeof(FF) == 8) check(tf_poly_zerofier_bfe(r, roots.size(), o), "zerofier");
+        else check(tf_poly_zerofier_xfe(r, roots.size(), o), "zerofier");
+        return Polynomial(std::move(out));
+    }
+    // batch_fast_interpolate (polynomial.rs:1703-1731): one interpolant per value row over the same domain
+    static std::vector<Polynomial> batch_fast_interpolate(const std::vector<FF>& domain, const std::vector<std::vector<FF>>& values_matrix) {
+        if (domain.empty()) throw NttPanic(TF_ERR_EMPTY_DOMAIN, "interpolate");  // :1503-1506
+        std::vector<FF> flat;
+        flat.reserve(values_matrix.size() * domain.size());
+        for (auto& row : values_matrix) {
+            if (row.size() != domain.size()) throw NttPanic(TF_ERR_EMPTY_DOMAIN, "interpolate: the domain and values lists have to be of equal length");  // :1507-1511
+            flat.insert(flat.end(), row.begin(), row.end());
+        }
+        std::vector<FF> out(flat.size());
+        const uint64_t* d = reinterpret_cast<const uint64_t*>(domain.data());
+        const uint64_t* v = reinterpret_cast<const uint64_t*>(flat.data());
+        uint64_t* o = reinterpret_cast<uint64_t*>(out.data());
+        if constexpr (sizeof(FF) == 8) check(tf_poly_interpolate_bfe(d, v, domain.size(), values_matrix.size(), o), "interpolate");
+        else check(tf_poly_interpolate_xfe(d, v, domain.size(), values_matrix.size(), o), "interpolate");
+        std::vector<Polynomial> polys;
+        for (size_t r = 0; r < values_matrix.size(); ++r)
+            polys.emplace_back(std::vector<FF>(out.begin() + r * domain.size(), out.begin() + (r + 1) * domain.size()));
+        return polys;
+    }
+    // interpolate (polynomial.rs:1502-1520; par_interpolate :1525-1545): panics on an empty domain, unequal lengths, repeated points
+    static Polynomial interpolate(const std::vector<FF>& domain, const std::vector<FF>& values) {
+        return batch_fast_interpolate(domain, {values})[0];
     }
     // batch_coset_extrapolate (polynomial.rs:2196-2208, par_ :2262): codeword-major values of every interpolant at
     // every point; panics unless codeword_length is a power of two
