@@ -52,7 +52,9 @@ enum tf_status {
     TF_ERR_LEAF_INDEX_INVALID = 11,        /* MerkleTreeError::LeafIndexInvalid  merkle_tree.rs:486-488 */
     TF_ERR_INVERSE_OF_ZERO = 12,           /* offset.inverse() of zero panics    b_field_element.rs:264-268 */
     TF_ERR_BUFFER_TOO_SMALL = 13,
-    TF_ERR_EMPTY_DOMAIN = 14               /* interpolate panic: "interpolation must happen through more than zero points"  math/polynomial.rs:1503-1506 */
+    TF_ERR_EMPTY_DOMAIN = 14,              /* interpolate panic: "interpolation must happen through more than zero points"  math/polynomial.rs:1503-1506 */
+    TF_ERR_DIVISION_BY_ZERO = 15,          /* naive_divide panic: "divisor should be non-zero"  math/polynomial.rs:556-559 */
+    TF_ERR_DIVISION_NOT_CLEAN = 16         /* clean_divide panic: the quotient does not come back to the base field  math/polynomial.rs:2374, :2410 */
 };
 
 /* Human-readable name of a status code. */
@@ -185,6 +187,16 @@ int tf_poly_interpolate_bfe(const uint64_t *domain, const uint64_t *values, size
 int tf_poly_interpolate_xfe(const uint64_t *domain, const uint64_t *values, size_t n_points, size_t rows, uint64_t *out);
 int tf_poly_interpolate_bfe_dev(const uint64_t *d_domain, const uint64_t *d_values, size_t n_points, size_t rows, uint64_t *d_out, void *stream);
 int tf_poly_interpolate_xfe_dev(const uint64_t *d_domain, const uint64_t *d_values, size_t n_points, size_t rows, uint64_t *d_out, void *stream);
+/* Polynomial::<BFieldElement>::clean_divide  math/polynomial.rs:2358-2411: the quotient a / b of a division KNOWN to be clean
+ * (b | a), by pointwise division on a coset of the extension field: two forward XFE transforms of order
+ * next_power_of_two(na), one inverse.  a, b: normalised coefficient arrays (na, nb count up to the non-zero leading coefficient,
+ * as Polynomial::degree does); out receives na - nb + 1 coefficients.
+ * Errors (where the reference panics): nb == 0 -> TF_ERR_DIVISION_BY_ZERO; the division is not clean (including
+ * 0 < na < nb) -> TF_ERR_DIVISION_NOT_CLEAN (the reference: "might panic or produce a wrong result"; here it is always
+ * detected); a divisor with a root on the coset (an irreducible cubic factor of a special form) -> TF_ERR_INVERSE_OF_ZERO as in the
+ * reference's batch_inversion.  na == 0 (zero dividend): TF_OK, nothing written.  The _dev call synchronises its stream once. */
+int tf_poly_clean_divide_bfe(const uint64_t *a, size_t na, const uint64_t *b, size_t nb, uint64_t *out);
+int tf_poly_clean_divide_bfe_dev(const uint64_t *d_a, size_t na, const uint64_t *d_b, size_t nb, uint64_t *d_out, void *stream);
 /* Route of the batch evaluation (test / A-B hook): 0 = automatic (zerofier tree for many points on a long polynomial, Horner
  * otherwise), 1 = always Horner, 2 = the zerofier tree whenever it applies (>= 512 points).  Same values either way. */
 void tf_set_batch_eval_route(int route);

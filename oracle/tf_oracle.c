@@ -1003,6 +1003,92 @@ int tfo_poly_lagrange_interpolate(const uint64_t *domain, const uint64_t *values
     return rc;
 }
 
+/* ------------------------------------------------------------------ division (math/polynomial.rs) */
+
+/* Polynomial::naive_divide (polynomial.rs:552-600) over BFieldElement: quotient (max(na - nb + 1, 0) coefficients, untrimmed) and
+ * remainder (na coefficients, the top ones zeroed as the long division consumes them).  na / nb count NORMALISED coefficients
+ * (non-zero leading coefficient), as Polynomial::degree sees them.  Returns 1 for a zero divisor ("divisor should be non-zero"). */
+int tfo_poly_naive_divide_bfe(const uint64_t *a, size_t na, const uint64_t *b, size_t nb, uint64_t *quot, uint64_t *rem) {
+    if (nb == 0) return 1;
+    memcpy(rem, a, na * sizeof(u64));
+    if (na < nb) return 0;
+    const u64 lc_inv = bfe_inverse(b[nb - 1]);
+    const size_t qdeg = na - nb;
+    size_t len = na; /* remainder_coefficients.len() */
+    for (size_t step = 0; step <= qdeg; step++) {
+        const u64 lc = rem[len - 1];
+        rem[len - 1] = 0;
+        len--; /* pop */
+        const u64 qc = bfe_mul(lc, lc_inv);
+        quot[qdeg - step] = qc;
+        if (!qc) continue;
+        const size_t rdeg = len ? len - 1 : 0;
+        for (size_t i = 0; i + 1 < nb; i++) /* divisor back to front, leading coefficient skipped */
+            rem[rdeg - i] = bfe_sub(rem[rdeg - i], bfe_mul(qc, b[nb - 2 - i]));
+    }
+    return 0;
+}
+
+/* Polynomial::<BFieldElement>::clean_divide (polynomial.rs:2358-2411).  cutoff = CLEAN_DIVIDE_CUTOFF_THRESHOLD (:2339: 1 << 9,
+ * 0 under cfg(test)): divisors of lower degree go through naive_divide.  na / nb count normalised coefficients.
+ * out receives na - nb + 1 coefficients.  Returns 0, or the reference's panics: 1 zero divisor (naive_divide :556-559),
+ * 2 a zero among the divisor's values on the coset (batch_inversion, traits.rs:106), 3 division not clean (:2374
+ * assert / :2410 unlift().unwrap(); also a quotient of higher degree than deg a - deg b, which the reference would return as a
+ * wrong result), 4 dividend of lower degree than the divisor and not zero. */
+int tfo_poly_clean_divide_bfe(const uint64_t *a, size_t na, const uint64_t *b, size_t nb, size_t cutoff, uint64_t *out) {
+    if (nb == 0) return 1;
+    if (na < nb) return na ? 4 : 0;
+    if (nb - 1 < cutoff) { /* divisor.degree() < threshold */
+        u64 *rem = (u64 *)malloc((na ? na : 1) * sizeof(u64));
+        int rc = tfo_poly_naive_divide_bfe(a, na, b, nb, out, rem);
+        free(rem); /* debug_assert!(remainder.is_zero()) only */
+        return rc;
+    }
+    /* :2368-2378 one factor x off both when the divisor's constant term is zero */
+    if (b[0] == 0) {
+        if (a[0] != 0) return 3;
+        a++, b++, na--, nb--;
+    }
+    const u64 X[3] = {0, bfe_new(1), 0};            /* offset = XFieldElement::from([0, 1, 0]) :2383 */
+    size_t order = 1;
+    while (order < na) order <<= 1;                 /* (dividend.degree() + 1).next_power_of_two() :2388-2389 */
+    u64 *da = (u64 *)calloc(3 * order, sizeof(u64)), *db = (u64 *)calloc(3 * order, sizeof(u64));
+    u64 pw[3] = {bfe_new(1), 0, 0}, t[3];
+    for (size_t i = 0; i < order; i++) {            /* scale(offset) :2384-2385: c_i * offset^i */
+        if (i < na) tfo_xfe_mul_bfe(pw, a[i], da + 3 * i);
+        if (i < nb) tfo_xfe_mul_bfe(pw, b[i], db + 3 * i);
+        tfo_xfe_mul(pw, X, t);
+        memcpy(pw, t, sizeof(t));
+    }
+    int rc = 0;
+    ntt_any(da, order, 3, 0);
+    ntt_any(db, order, 3, 0);
+    for (size_t i = 0; i < order && !rc; i++) {     /* batch_inversion + pointwise product :2397-2402 */
+        u64 inv[3];
+        if (tfo_xfe_inverse(db + 3 * i, inv)) { rc = 2; break; }
+        tfo_xfe_mul(da + 3 * i, inv, t);
+        memcpy(da + 3 * i, t, sizeof(t));
+    }
+    if (!rc) {
+        ntt_any(da, order, 3, 1);
+        u64 Xinv[3];
+        tfo_xfe_inverse(X, Xinv);
+        u64 q[3] = {bfe_new(1), 0, 0};
+        const size_t nq = na - nb + 1;
+        for (size_t i = 0; i < order; i++) {        /* scale(offset.inverse()) and unlift :2408-2410 */
+            tfo_xfe_mul(da + 3 * i, q, t);
+            if (t[1] || t[2] || (i >= nq && t[0])) { rc = 3; break; }
+            if (i < nq) out[i] = t[0];
+            u64 n2[3];
+            tfo_xfe_mul(q, Xinv, n2);
+            memcpy(q, n2, sizeof(n2));
+        }
+    }
+    free(da);
+    free(db);
+    return rc;
+}
+
 /* ------------------------------------------------------------------ helpers */
 
 uint64_t tfo_splitmix64(uint64_t *state) {

@@ -83,6 +83,8 @@ def lib() -> C.CDLL:
             "tfo_xfe_inverse": (i32, [pu, pu]),
             "tfo_poly_zerofier": (None, [pu, sz, i32, pu]),
             "tfo_poly_lagrange_interpolate": (i32, [pu, pu, sz, i32, pu]),
+            "tfo_poly_naive_divide_bfe": (i32, [pu, sz, pu, sz, pu, pu]),
+            "tfo_poly_clean_divide_bfe": (i32, [pu, sz, pu, sz, sz, pu]),
             "tfo_fill_random": (None, [pu, sz, u64]),
             "tfo_digest_to_hex": (None, [pu, C.c_char_p]),
         }
@@ -412,6 +414,37 @@ def lagrange_interpolate(domain, values, width: int = 1) -> np.ndarray:
     if rc:
         raise OraclePanic(12 if rc == 1 else 14)
     return out[: n * width]
+
+
+def _trim(c: np.ndarray) -> np.ndarray:
+    n = c.size
+    while n and not c[n - 1]:
+        n -= 1
+    return c[:n]
+
+
+def naive_divide(a, b):
+    """Polynomial::naive_divide (math/polynomial.rs:552-600) over BFieldElement: (quotient, remainder), trimmed."""
+    a, b = _trim(_arr(a).reshape(-1)), _trim(_arr(b).reshape(-1))
+    quot = np.zeros(max(a.size - b.size + 1, 1), dtype=np.uint64)
+    rem = np.zeros(max(a.size, 1), dtype=np.uint64)
+    pad = np.zeros(1, dtype=np.uint64)
+    rc = lib().tfo_poly_naive_divide_bfe(_p(a if a.size else pad), a.size, _p(b if b.size else pad), b.size, _p(quot), _p(rem))
+    if rc:
+        raise OraclePanic(15)
+    return _trim(quot[: max(a.size - b.size + 1, 0)]), _trim(rem[: a.size])
+
+
+def clean_divide(a, b, cutoff: int = 1 << 9) -> np.ndarray:
+    """Polynomial::<BFieldElement>::clean_divide (math/polynomial.rs:2358-2411); `cutoff` is CLEAN_DIVIDE_CUTOFF_THRESHOLD
+    (0 = the cfg(test) value: always the coset route).  Trimmed quotient."""
+    a, b = _trim(_arr(a).reshape(-1)), _trim(_arr(b).reshape(-1))
+    out = np.zeros(max(a.size - b.size + 1, 1), dtype=np.uint64)
+    pad = np.zeros(1, dtype=np.uint64)
+    rc = lib().tfo_poly_clean_divide_bfe(_p(a if a.size else pad), a.size, _p(b if b.size else pad), b.size, cutoff, _p(out))
+    if rc:
+        raise OraclePanic({1: 15, 2: 12, 3: 16, 4: 16}[rc])
+    return _trim(out[: max(a.size - b.size + 1, 0)])
 
 
 def merkle_from_rows(rows, row_len: int) -> np.ndarray:

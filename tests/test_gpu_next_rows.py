@@ -617,3 +617,89 @@ def test_interpolation_on_a_coset_equals_fast_coset_interpolate(tf, oracle, widt
     tf.device.batch_evaluate(z, n + 1, dom, zv, width=width)
     torch.cuda.synchronize()
     assert not zv.any().item()
+
+
+# ---- clean division (math/polynomial.rs:2358-2411) ------------------------------------------------------------------------------
+@pytest.mark.parametrize("nq,nb", [(1, 1), (5, 3), (3, 5), (100, 40), (700, 600), (513, 513), (1500, 520), (3, 1000), (5000, 4097),
+                                   (1 << 15, (1 << 15) + 1), ((1 << 18) + 3, 1 << 17)])
+def test_clean_divide_matches_oracle(tf, oracle, nq, nb):
+    """Polynomial::clean_divide against the oracle's restatement of it (both of the reference's routes: naive_divide below
+    divisor degree 512 and the extension-field coset above, :2360-2364) -- the property test :3707-3719 with a = q * b."""
+    q, b = oracle.fill_random(nq, 1700 + nq), oracle.fill_random(nb, 1701 + nb)
+    a = oracle.poly_mul(q, b)
+    got = tf.Polynomial(a).clean_divide(tf.Polynomial(b))
+    assert np.array_equal(got.coefficients, q)
+    if nq * nb <= 1 << 22:
+        assert np.array_equal(oracle.clean_divide(a, b, 0), q) and np.array_equal(oracle.clean_divide(a, b), q)
+        assert np.array_equal(oracle.naive_divide(a, b)[0], q)
+
+
+def test_clean_divide_roots_at_zero_and_panics(tf, oracle):
+    """polynomial.rs:3722-3787 (divisor with 0 as a single / multiple / only root, roots 0..9), :4433 (monomials), and the panics:
+    zero divisor, unclean division, dividend of lower degree."""
+    P_ = tf.Polynomial
+    one = oracle.bfe_new(1)
+    for k in (1, 2, 7):  # divisor x^k
+        q = oracle.fill_random(40, 50 + k)
+        xk = np.zeros(k + 1, dtype=np.uint64)
+        xk[k] = one
+        a = np.concatenate([np.zeros(k, dtype=np.uint64), q])
+        assert np.array_equal(P_(a).clean_divide(P_(xk)).coefficients, q)
+    b = oracle.fill_random(600, 60)
+    b[0] = 0
+    b[1] = 0
+    q = oracle.fill_random(700, 61)
+    a = oracle.poly_mul(q, b)
+    assert np.array_equal(P_(a).clean_divide(P_(b)).coefficients, q)
+    assert np.array_equal(oracle.clean_divide(a, b, 0), q)
+    z = P_.zerofier(oracle.to_raw(list(range(10))))  # roots 0 through 9
+    q = oracle.fill_random(33, 62)
+    a = oracle.poly_mul(q, z.coefficients)
+    assert np.array_equal(P_(a).clean_divide(z).coefficients, q)
+    # monomial / smaller monomial (:4433-4450)
+    hi = np.zeros(10, dtype=np.uint64)
+    hi[9] = oracle.bfe_new(6)
+    lo = np.zeros(4, dtype=np.uint64)
+    lo[3] = oracle.bfe_new(3)
+    got = P_(hi).clean_divide(P_(lo)).coefficients
+    assert got.size == 7 and int(got[6]) == oracle.bfe_new(2) and not got[:6].any()
+    # zero dividend: zero quotient
+    assert P_(np.zeros(0, dtype=np.uint64)).clean_divide(P_(b)).degree() == -1
+    with pytest.raises(tf.NttPanic) as e:
+        P_(a).clean_divide(P_(np.zeros(3, dtype=np.uint64)))
+    assert e.value.code == 15
+    for na_, nb_ in ((900, 600), (40, 7)):  # unclean: one coefficient of a clean product perturbed; x does not divide 1 + ...
+        bb, qq = oracle.fill_random(nb_, 63), oracle.fill_random(na_ - nb_ + 1, 64)
+        aa = oracle.poly_mul(qq, bb)
+        aa[na_ // 2] ^= np.uint64(1)
+        with pytest.raises(tf.NttPanic) as e:
+            P_(aa).clean_divide(P_(bb))
+        assert e.value.code == 16
+        with pytest.raises(oracle.OraclePanic):
+            oracle.clean_divide(aa, bb, 0)
+    with pytest.raises(tf.NttPanic) as e:
+        P_(oracle.fill_random(5, 65)).clean_divide(P_(oracle.fill_random(9, 66)))
+    assert e.value.code == 16
+    bz = oracle.fill_random(30, 67)
+    bz[0] = 0
+    with pytest.raises(tf.NttPanic) as e:  # :2374 assert!(dividend_coefficients[0].is_zero())
+        P_(oracle.fill_random(60, 68)).clean_divide(P_(bz))
+    assert e.value.code == 16
+    assert tf.lib().tf_status_string(15) == b"TF_ERR_DIVISION_BY_ZERO" and tf.lib().tf_status_string(16) == b"TF_ERR_DIVISION_NOT_CLEAN"
+
+
+def test_clean_divide_device_resident_large(tf, oracle):
+    """2^20-coefficient quotient times a 2^20-coefficient divisor, all in HBM: fast_multiply then clean_divide gives the factor back."""
+    import torch
+
+    nq = nb = 1 << 20
+    q = torch.empty(nq, dtype=torch.int64, device="cuda")
+    b = torch.empty(nb, dtype=torch.int64, device="cuda")
+    tf.device.fill_random(q, 71)
+    tf.device.fill_random(b, 72)
+    a = torch.empty(nq + nb - 1, dtype=torch.int64, device="cuda")
+    tf.device.poly_mul(q, nq, b, nb, a)
+    out = torch.empty(nq, dtype=torch.int64, device="cuda")
+    tf.device.clean_divide(a, b, out)
+    torch.cuda.synchronize()
+    assert torch.equal(out, q)

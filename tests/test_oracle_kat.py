@@ -595,3 +595,33 @@ def test_xfe_inverse_is_the_inverse(oracle):
         assert np.array_equal(tfo.xfe_mul(a, tfo.xfe_inverse(a)), one)
     with pytest.raises(tfo.OraclePanic):
         tfo.xfe_inverse(np.zeros(3, dtype=np.uint64))
+
+
+def test_division_restatements(oracle):
+    """Polynomial::naive_divide (math/polynomial.rs:552-600) and clean_divide (:2358-2411) in the oracle: a = q b + r with
+    deg r < deg b (:3789-3803 style), clean_divide == divide's quotient on clean divisions through both of its routes (:3707-3719),
+    divisors with zero as a (multiple) root (:3722-3772), and the panics."""
+    tfo = oracle
+    for na, nb in ((100, 13), (13, 100), (64, 64), (1, 1), (300, 299)):
+        a, b = tfo.fill_random(na, 10 + na), tfo.fill_random(nb, 11 + nb)
+        q, r = tfo.naive_divide(a, b)
+        assert r.size < nb
+        back = tfo.poly_mul(q, b) if q.size else np.zeros(0, dtype=np.uint64)
+        back = np.concatenate([back, np.zeros(max(na - back.size, 0), dtype=np.uint64)])
+        for i in range(r.size):
+            back[i] = tfo.bfe_add(int(back[i]), int(r[i]))
+        assert np.array_equal(back[:na], a) and not back[na:].any()
+    # (x + 1)(x + 2)(x + 3) / (x + 2) = x^2 + 4 x + 3
+    prod = tfo.poly_mul(tfo.poly_mul(tfo.to_raw([1, 1]), tfo.to_raw([2, 1])), tfo.to_raw([3, 1]))
+    for cutoff in (0, 1 << 9):
+        assert [int(v) for v in tfo.to_values(tfo.clean_divide(prod, tfo.to_raw([2, 1]), cutoff))] == [3, 4, 1]
+    for nq, nb in ((5, 3), (100, 40), (700, 600), (3, 1000)):
+        q, b = tfo.fill_random(nq, 20 + nq), tfo.fill_random(nb, 21 + nb)
+        b[0] = 0 if nb > 3 else b[0]
+        a = tfo.poly_mul(q, b)
+        assert np.array_equal(tfo.clean_divide(a, b, 0), q) and np.array_equal(tfo.clean_divide(a, b), q)
+        assert np.array_equal(tfo.naive_divide(a, b)[0], q) and tfo.naive_divide(a, b)[1].size == 0
+    with pytest.raises(tfo.OraclePanic):
+        tfo.clean_divide(prod, np.zeros(2, dtype=np.uint64))
+    with pytest.raises(tfo.OraclePanic):
+        tfo.clean_divide(tfo.to_raw([1, 0, 1]), tfo.to_raw([1, 1]), 0)  # x^2 + 1 is not a multiple of x + 1

@@ -70,7 +70,7 @@ def _check(rc: int, where: str):
         return
     if rc in (1, 2, 3, 11):
         raise MerkleTreeError(rc, where)
-    if rc in (4, 5, 6, 12, 14):
+    if rc in (4, 5, 6, 12, 14, 15, 16):
         raise NttPanic(rc, where)
     raise TwentyFirstError(rc, where)
 
@@ -234,6 +234,16 @@ class Polynomial:
         fn = lib().tf_poly_batch_evaluate_bfe if self.width == 1 else lib().tf_poly_batch_evaluate_xfe
         _check(fn(_ptr(self.coefficients), self.coefficients.size // self.width, _ptr(pts), n_points, _ptr(out)), "batch_evaluate")
         return out
+
+    def clean_divide(self, divisor: "Polynomial") -> "Polynomial":
+        """math/polynomial.rs:2358-2411 (BFieldElement only): self / divisor for a division known to be clean.  Panics (NttPanic)
+        on a zero divisor and on an unclean division."""
+        if self.width != 1 or divisor.width != 1:
+            raise TypeError("clean_divide is defined for Polynomial<BFieldElement> (polynomial.rs:2333)")
+        na, nb = self.coefficients.size, divisor.coefficients.size
+        out = np.zeros(max(na - nb + 1, 0), dtype=np.uint64)
+        _check(lib().tf_poly_clean_divide_bfe(_ptr(self.coefficients), na, _ptr(divisor.coefficients), nb, _ptr(out)), "clean_divide")
+        return Polynomial(out)
 
     @classmethod
     def zerofier(cls, roots: np.ndarray, width: int = 1) -> "Polynomial":

@@ -61,6 +61,8 @@ SIGNATURES = {
     "tf_poly_batch_evaluate_xfe": (C.c_int, [_vp, _sz, _vp, _sz, _vp]),
     "tf_poly_batch_evaluate_bfe_dev": (C.c_int, [_vp, _sz, _vp, _sz, _vp, _vp]),
     "tf_poly_batch_evaluate_xfe_dev": (C.c_int, [_vp, _sz, _vp, _sz, _vp, _vp]),
+    "tf_poly_clean_divide_bfe": (C.c_int, [_vp, _sz, _vp, _sz, _vp]),
+    "tf_poly_clean_divide_bfe_dev": (C.c_int, [_vp, _sz, _vp, _sz, _vp, _vp]),
     "tf_poly_zerofier_bfe": (C.c_int, [_vp, _sz, _vp]),
     "tf_poly_zerofier_xfe": (C.c_int, [_vp, _sz, _vp]),
     "tf_poly_zerofier_bfe_dev": (C.c_int, [_vp, _sz, _vp, _vp]),

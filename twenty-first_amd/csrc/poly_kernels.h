@@ -427,4 +427,73 @@ __global__ void __launch_bounds__(256) interpolant_unpad_kernel(const u64* Nroot
     for (int q = 0; q < L; ++q) out[(row * n + j) * L + q] = Nroot[(row * M + j + (M - n)) * L + q];
 }
 
+// ---- clean division over BFieldElement (Polynomial::clean_divide, polynomial.rs:2358-2411) ----------------------------------
+// The reference moves dividend and divisor to the coset X * <w> of the EXTENSION field (X = the element x of
+// F_p[x]/(x^3 - x + 1): a polynomial over the base field has no roots there unless it has an irreducible cubic factor),
+// divides pointwise and interpolates.  Same steps here, every one a device pass.
+
+// base^e by square-and-multiply (e < 2^32)
+__device__ __forceinline__ void xfe_pow(const u64 (&base)[3], unsigned long long e, u64 (&r)[3]) {
+    u64 sq[3] = {base[0], base[1], base[2]}, t[3];
+    r[0] = gl::ONE;
+    r[1] = 0;
+    r[2] = 0;
+    while (e) {
+        if (e & 1) {
+            xfe_mul(r, sq, t);
+            r[0] = t[0], r[1] = t[1], r[2] = t[2];
+        }
+        e >>= 1;
+        if (e) {
+            xfe_mul(sq, sq, t);
+            sq[0] = t[0], sq[1] = t[1], sq[2] = t[2];
+        }
+    }
+}
+
+// out[i] = c[i] * base^i (an XFieldElement) for i < n_c, zero up to order: Polynomial::scale with an extension-field offset
+// (polynomial.rs:760-773) followed by the zero padding of :2391-2392
+__global__ void __launch_bounds__(256) lift_scale_kernel(const u64* c, long long n_c, long long order, u64* out, u64 b0, u64 b1, u64 b2) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= order) return;
+    u64 r[3] = {0, 0, 0};
+    if (i < n_c) {
+        const u64 base[3] = {b0, b1, b2};
+        u64 pw[3];
+        xfe_pow(base, (unsigned long long)i, pw);
+        const u64 ci = c[i];
+        r[0] = gl::mont_mul(pw[0], ci);
+        r[1] = gl::mont_mul(pw[1], ci);
+        r[2] = gl::mont_mul(pw[2], ci);
+    }
+    fe_store<3>(out + 3 * i, r);
+}
+
+// out[i] = a[i] / b[i]; flag bit 0 when some b[i] is zero (batch_inversion panics, traits.rs:106)
+__global__ void __launch_bounds__(256) xfe_divide_pointwise_kernel(const u64* a, const u64* b, u64* out, long long count, int* flag) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    u64 x[3], y[3], inv[3], r[3];
+    fe_load<3>(a + 3 * i, x);
+    fe_load<3>(b + 3 * i, y);
+    if (!xfe_inverse(y, inv)) atomicOr(flag, 1);
+    xfe_mul(x, inv, r);
+    fe_store<3>(out + 3 * i, r);
+}
+
+// out[i] = unlift(q[i] * base_inv^i) for i < n_q; flag bit 1 when a coefficient does not come back to the base field
+// (unlift().unwrap() panics, :2410) or a coefficient beyond the quotient's degree is not zero (the division was not clean)
+__global__ void __launch_bounds__(256) unscale_unlift_kernel(const u64* q, long long order, long long n_q, u64* out, u64 b0, u64 b1, u64 b2,
+                                                            int* flag) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= order) return;
+    const u64 base[3] = {b0, b1, b2};
+    u64 pw[3], v[3], r[3];
+    xfe_pow(base, (unsigned long long)i, pw);
+    fe_load<3>(q + 3 * i, v);
+    xfe_mul(v, pw, r);
+    if (r[1] | r[2] | (i >= n_q ? r[0] : 0)) atomicOr(flag, 2);
+    if (i < n_q) out[i] = r[0];
+}
+
 }  // namespace tfk

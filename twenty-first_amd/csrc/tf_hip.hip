@@ -2227,6 +2227,63 @@ int interpolate_dev(const u64* domain, const u64* values, size_t n, size_t rows,
     return L == 1 ? interpolate_dev_t<1>(domain, values, n, rows, out, s) : interpolate_dev_t<3>(domain, values, n, rows, out, s);
 }
 
+// Polynomial::<BFieldElement>::clean_divide (polynomial.rs:2358-2411): a / b for b | a, by pointwise division on the coset
+// X * <w_order> of the extension field (poly_kernels.h).  a, b: normalised coefficient arrays (non-zero leading coefficient),
+// out: na - nb + 1 coefficients.  The reference's factor-x workaround (:2368-2378) changes nothing on this coset (X w^i != 0) and
+// is not needed; the naive route it takes for divisors below degree 512 (:2360-2364) returns the same quotient.
+int clean_divide_dev(const u64* a, size_t na, const u64* b, size_t nb, u64* out, void* stream) {
+    if (nb == 0) return TF_ERR_DIVISION_BY_ZERO;                      // naive_divide :556-559 "divisor should be non-zero"
+    if (na < nb) return na ? TF_ERR_DIVISION_NOT_CLEAN : TF_OK;       // a non-zero dividend of lower degree: the remainder is the dividend
+    if (!a || !b || !out) return TF_ERR_NULL_POINTER;
+    size_t order = 1;
+    while (order < na) order <<= 1;                                   // (dividend.degree() + 1).next_power_of_two() :2388-2389
+    int rc = check_len(order);
+    if (rc) return rc;
+    DeviceCtx* ctx = nullptr;
+    rc = current_ctx(&ctx);
+    if (rc) return rc;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    u64* tmp = nullptr;
+    const size_t half = order * 3;
+    hipError_t e = hipMallocAsync(reinterpret_cast<void**>(&tmp), (2 * half + 2) * sizeof(u64), s);
+    if (e != hipSuccess) return hip_fail(e, "hipMallocAsync(clean_divide)", __FILE__, __LINE__);
+    int* flag = reinterpret_cast<int*>(tmp + 2 * half);
+    const u64 X[3] = {0, gl::ONE, 0};                                 // XFieldElement::from([0, 1, 0]) :2383
+    const u64 Xinv[3] = {gl::ONE, 0, gl::neg(gl::ONE)};               // x (x^2 - 1) = -1  ->  x^-1 = 1 - x^2
+    const unsigned blocks = (unsigned)((order + 255) / 256);
+    e = hipMemsetAsync(flag, 0, sizeof(int), s);
+    if (e != hipSuccess) rc = hip_fail(e, "hipMemsetAsync", __FILE__, __LINE__);
+    if (!rc) {
+        hipLaunchKernelGGL(tfk::lift_scale_kernel, dim3(blocks), dim3(256), 0, s, a, (long long)na, (long long)order, tmp, X[0], X[1], X[2]);
+        hipLaunchKernelGGL(tfk::lift_scale_kernel, dim3(blocks), dim3(256), 0, s, b, (long long)nb, (long long)order, tmp + half, X[0], X[1], X[2]);
+        if (hipGetLastError() != hipSuccess) rc = TF_ERR_HIP;
+    }
+    if (!rc) rc = run_ntt(ctx, tmp, tmp, (long long)half, (long long)half, order, 2, 3, false, nullptr, -1, s);
+    if (!rc) {
+        hipLaunchKernelGGL(tfk::xfe_divide_pointwise_kernel, dim3(blocks), dim3(256), 0, s, (const u64*)tmp, (const u64*)(tmp + half), tmp,
+                           (long long)order, flag);
+        if (hipGetLastError() != hipSuccess) rc = TF_ERR_HIP;
+    }
+    if (!rc) rc = run_ntt(ctx, tmp, tmp, (long long)half, (long long)half, order, 1, 3, true, nullptr, -1, s);
+    if (!rc) {
+        hipLaunchKernelGGL(tfk::unscale_unlift_kernel, dim3(blocks), dim3(256), 0, s, (const u64*)tmp, (long long)order, (long long)(na - nb + 1),
+                           out, Xinv[0], Xinv[1], Xinv[2], flag);
+        if (hipGetLastError() != hipSuccess) rc = TF_ERR_HIP;
+    }
+    if (!rc) {
+        int host_flag = 0;
+        e = hipMemcpyAsync(&host_flag, flag, sizeof(int), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e != hipSuccess) rc = hip_fail(e, "clean_divide: flag", __FILE__, __LINE__);
+        else if (host_flag & 1) rc = TF_ERR_INVERSE_OF_ZERO;     // a zero of the divisor on the coset: batch_inversion panics
+        else if (host_flag & 2) rc = TF_ERR_DIVISION_NOT_CLEAN;  // unlift().unwrap() :2410
+    }
+    hipError_t e2 = hipFreeAsync(tmp, s);
+    if (rc) return rc;
+    if (e2 != hipSuccess) return hip_fail(e2, "hipFreeAsync", __FILE__, __LINE__);
+    return TF_OK;
+}
+
 // Polynomial::{coset_extrapolate, batch_coset_extrapolate} (polynomial.rs:2117-2331): the values, at `points`, of the
 // degree-< n interpolants of `batch` codewords given on the coset {offset * w_n^i}.  Both of the reference's routes
 // (naive :2145-2156, fast :2158-2170) compute exactly interpolant(point), which is what this does:
@@ -2400,6 +2457,8 @@ const char* tf_status_string(int status) {
         case TF_ERR_INVERSE_OF_ZERO: return "TF_ERR_INVERSE_OF_ZERO";
         case TF_ERR_BUFFER_TOO_SMALL: return "TF_ERR_BUFFER_TOO_SMALL";
         case TF_ERR_EMPTY_DOMAIN: return "TF_ERR_EMPTY_DOMAIN";
+        case TF_ERR_DIVISION_BY_ZERO: return "TF_ERR_DIVISION_BY_ZERO";
+        case TF_ERR_DIVISION_NOT_CLEAN: return "TF_ERR_DIVISION_NOT_CLEAN";
         default: return "TF_ERR_UNKNOWN";
     }
 }
@@ -2762,6 +2821,15 @@ static int interpolate_host(const uint64_t* d, const uint64_t* v, size_t n, size
 }
 int tf_poly_interpolate_bfe(const uint64_t* d, const uint64_t* v, size_t n, size_t rows, uint64_t* out) { return interpolate_host(d, v, n, rows, out, 1); }
 int tf_poly_interpolate_xfe(const uint64_t* d, const uint64_t* v, size_t n, size_t rows, uint64_t* out) { return interpolate_host(d, v, n, rows, out, 3); }
+int tf_poly_clean_divide_bfe_dev(const uint64_t* a, size_t na, const uint64_t* b, size_t nb, uint64_t* out, void* stream) {
+    return clean_divide_dev(a, na, b, nb, out, stream);
+}
+int tf_poly_clean_divide_bfe(const uint64_t* a, size_t na, const uint64_t* b, size_t nb, uint64_t* out) {
+    if (nb == 0) return TF_ERR_DIVISION_BY_ZERO;
+    if (na < nb) return na ? TF_ERR_DIVISION_NOT_CLEAN : TF_OK;
+    if (!a || !b || !out) return TF_ERR_NULL_POINTER;
+    return host_roundtrip(a, na, b, nb, out, na - nb + 1, [&](u64* da, u64* db, u64* o, hipStream_t s) { return clean_divide_dev(da, na, db, nb, o, s); });
+}
 static int coset_extrapolate_host(uint64_t offset, const uint64_t* cw, size_t n, size_t batch, const uint64_t* pts, size_t np,
                                   uint64_t* out, int L) {
     if (n == 0) return TF_ERR_LEN_NOT_POWER_OF_TWO;

@@ -184,6 +184,14 @@ def batch_evaluate(coeffs, n_coeffs: int, points, out, width: int = 1, stream=No
     _chk(fn(_p(coeffs), n_coeffs, _p(points), points.numel() // width, _p(out), _stream(stream)), "batch_evaluate")
 
 
+def clean_divide(a, b, out, stream=None) -> None:
+    """Polynomial::<BFieldElement>::clean_divide (math/polynomial.rs:2358-2411) on device buffers: a, b normalised coefficient
+    arrays, out = the na - nb + 1 quotient coefficients."""
+    a, b, out = _t(a, "a"), _t(b, "b"), _t(out, "out")
+    _need(a.numel() >= b.numel() and out.numel() == a.numel() - b.numel() + 1, "out must hold na - nb + 1 coefficients")
+    _chk(_lib.lib().tf_poly_clean_divide_bfe_dev(_p(a), a.numel(), _p(b), b.numel(), _p(out), _stream(stream)), "clean_divide")
+
+
 def zerofier(roots, out, width: int = 1, stream=None) -> None:
     """Polynomial::zerofier (math/polynomial.rs:1435-1441) on device buffers: out = the n + 1 coefficients of prod (x - roots[i])."""
     roots, out = _t(roots, "roots"), _t(out, "out")

@@ -152,6 +152,17 @@ int main() {
         try { Poly::interpolate(bfe_vec({1, 1}), bfe_vec({1, 2})); } catch (const NttPanic& e) { p3 = e.code == TF_ERR_INVERSE_OF_ZERO; }  // :3554-3560
         EXPECT(p1 && p2 && p3);
     }
+    {  // clean_divide (polynomial.rs:2358-2411): (x + 1)(x + 2)(x + 3) / (x + 2), x^9 * 6 / (x^3 * 3), and the panics
+        using Poly = Polynomial<BFieldElement>;
+        Poly prod = Poly(bfe_vec({1, 1})).fast_multiply(Poly(bfe_vec({2, 1}))).fast_multiply(Poly(bfe_vec({3, 1})));
+        EXPECT(prod.clean_divide(Poly(bfe_vec({2, 1}))).coefficients == bfe_vec({3, 4, 1}));
+        EXPECT(Poly(bfe_vec({0, 0, 0, 0, 0, 0, 0, 0, 0, 6})).clean_divide(Poly(bfe_vec({0, 0, 0, 3}))).coefficients == bfe_vec({0, 0, 0, 0, 0, 0, 2}));
+        EXPECT(Poly({}).clean_divide(Poly(bfe_vec({2, 1}))).degree() == -1);
+        bool z = false, u = false;
+        try { prod.clean_divide(Poly({})); } catch (const NttPanic& e) { z = e.code == TF_ERR_DIVISION_BY_ZERO; }
+        try { Poly(bfe_vec({1, 0, 1})).clean_divide(Poly(bfe_vec({1, 1}))); } catch (const NttPanic& e) { u = e.code == TF_ERR_DIVISION_NOT_CLEAN; }
+        EXPECT(z && u);
+    }
     {  // batch_coset_extrapolate doc example, polynomial.rs:2183-2195: constant codewords extrapolate to the constant
         const size_t n = 32;
         std::vector<BFieldElement> codewords;

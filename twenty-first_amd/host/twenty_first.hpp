@@ -97,7 +97,7 @@ struct MerkleTreeError : BackendError {
 inline void check(int rc, const char* where) {
     if (rc == TF_OK) return;
     if ((rc >= 1 && rc <= 3) || rc == TF_ERR_LEAF_INDEX_INVALID) throw MerkleTreeError(rc, where);  // merkle_tree.rs:933-965
-    if ((rc >= 4 && rc <= 6) || rc == TF_ERR_INVERSE_OF_ZERO || rc == TF_ERR_EMPTY_DOMAIN) throw NttPanic(rc, where);  // the reference panics here
+    if ((rc >= 4 && rc <= 6) || rc == TF_ERR_INVERSE_OF_ZERO || rc >= TF_ERR_EMPTY_DOMAIN) throw NttPanic(rc, where);  // the reference panics here
     throw BackendError(rc, where);
 }
 
@@ -167,6 +167,18 @@ struct Polynomial {
         else
             check(tf_poly_batch_evaluate_xfe(c, coefficients.size(), d, domain.size(), o), "batch_evaluate");
         return out;
+    }
+    // clean_divide (polynomial.rs:2358-2411, BFieldElement only): self / divisor for a division known to be clean; panics on a
+    // zero divisor and on an unclean division
+    Polynomial clean_divide(const Polynomial& divisor) const {
+        static_assert(sizeof(FF) == 8, "clean_divide is defined for Polynomial<BFieldElement> (polynomial.rs:2333)");
+        const size_t na = coefficients.size(), nb = divisor.coefficients.size();
+        std::vector<FF> out(na >= nb ? na - nb + 1 : 0);
+        check(tf_poly_clean_divide_bfe(reinterpret_cast<const uint64_t*>(coefficients.data()), na,
+                                       reinterpret_cast<const uint64_t*>(divisor.coefficients.data()), nb, reinterpret_cast<uint64_t*>(out.data())),
+              "clean_divide");
+        if (na < nb) out.clear();
+        return Polynomial(std::move(out));
     }
     // zerofier (polynomial.rs:1435-1441, par_zerofier :1444-1459): the monic polynomial with exactly these roots
     static Polynomial zerofier(const std::vector<FF>& roots) {
