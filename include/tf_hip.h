@@ -187,6 +187,15 @@ int tf_poly_interpolate_bfe(const uint64_t *domain, const uint64_t *values, size
 int tf_poly_interpolate_xfe(const uint64_t *domain, const uint64_t *values, size_t n_points, size_t rows, uint64_t *out);
 int tf_poly_interpolate_bfe_dev(const uint64_t *d_domain, const uint64_t *d_values, size_t n_points, size_t rows, uint64_t *d_out, void *stream);
 int tf_poly_interpolate_xfe_dev(const uint64_t *d_domain, const uint64_t *d_values, size_t n_points, size_t rows, uint64_t *d_out, void *stream);
+/* fast_coset_evaluate / fast_coset_interpolate of XFieldElement polynomials with an XFieldElement OFFSET (S = XFieldElement in
+ * math/polynomial.rs:1374-1378 and :1907-1911; offset = 3 raw words).  Same arguments, errors and layout as tf_coset_eval_xfe /
+ * tf_coset_interpolate_xfe; a zero offset -> TF_ERR_INVERSE_OF_ZERO in the interpolation (x_field_element.rs:371-375).  The
+ * scaling by offset^i is a separate device pass here (the reference's docs recommend a base-field offset, :1366-1368, which is
+ * the fused fast path). */
+int tf_coset_eval_xfe_xoffset(const uint64_t *coeffs, size_t n_coeffs, const uint64_t offset[3], uint64_t *out, size_t order, size_t batch);
+int tf_coset_interpolate_xfe_xoffset(const uint64_t *values, size_t n, const uint64_t offset[3], uint64_t *out, size_t batch);
+int tf_coset_eval_xfe_xoffset_dev(const uint64_t *d_coeffs, size_t n_coeffs, const uint64_t offset[3], uint64_t *d_out, size_t order, size_t batch, void *stream);
+int tf_coset_interpolate_xfe_xoffset_dev(const uint64_t *d_values, size_t n, const uint64_t offset[3], uint64_t *d_out, size_t batch, void *stream);
 /* Polynomial::<BFieldElement>::clean_divide  math/polynomial.rs:2358-2411: the quotient a / b of a division KNOWN to be clean
  * (b | a), by pointwise division on a coset of the extension field: two forward XFE transforms of order
  * next_power_of_two(na), one inverse.  a, b: normalised coefficient arrays (na, nb count up to the non-zero leading coefficient,

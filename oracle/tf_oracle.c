@@ -1003,6 +1003,18 @@ int tfo_poly_lagrange_interpolate(const uint64_t *domain, const uint64_t *values
     return rc;
 }
 
+/* Polynomial::scale with an XFieldElement alpha on XFieldElement coefficients (polynomial.rs:760-773): c_i <- c_i * alpha^i,
+ * the power chain carried sequentially as the reference does */
+void tfo_poly_scale_xfe(uint64_t *c, size_t n_coeffs, const uint64_t alpha[3]) {
+    u64 pw[3] = {bfe_new(1), 0, 0}, t[3];
+    for (size_t i = 0; i < n_coeffs; i++) {
+        tfo_xfe_mul(c + 3 * i, pw, t);
+        memcpy(c + 3 * i, t, sizeof(t));
+        tfo_xfe_mul(pw, alpha, t);
+        memcpy(pw, t, sizeof(t));
+    }
+}
+
 /* ------------------------------------------------------------------ division (math/polynomial.rs) */
 
 /* Polynomial::naive_divide (polynomial.rs:552-600) over BFieldElement: quotient (max(na - nb + 1, 0) coefficients, untrimmed) and

@@ -84,6 +84,7 @@ def lib() -> C.CDLL:
             "tfo_poly_zerofier": (None, [pu, sz, i32, pu]),
             "tfo_poly_lagrange_interpolate": (i32, [pu, pu, sz, i32, pu]),
             "tfo_poly_naive_divide_bfe": (i32, [pu, sz, pu, sz, pu, pu]),
+            "tfo_poly_scale_xfe": (None, [pu, sz, pu]),
             "tfo_poly_clean_divide_bfe": (i32, [pu, sz, pu, sz, sz, pu]),
             "tfo_fill_random": (None, [pu, sz, u64]),
             "tfo_digest_to_hex": (None, [pu, C.c_char_p]),
@@ -445,6 +446,24 @@ def clean_divide(a, b, cutoff: int = 1 << 9) -> np.ndarray:
     if rc:
         raise OraclePanic({1: 15, 2: 12, 3: 16, 4: 16}[rc])
     return _trim(out[: max(a.size - b.size + 1, 0)])
+
+
+def coset_evaluate_xfe_offset(coeffs, offset, order: int) -> np.ndarray:
+    """fast_coset_evaluate with S = XFieldElement (math/polynomial.rs:1374-1399): scale by the offset, zero-pad, ntt."""
+    c = _arr(coeffs).reshape(-1)
+    if c.size // 3 > order:
+        raise OraclePanic(6)
+    buf = np.zeros(3 * order, dtype=np.uint64)
+    buf[: c.size] = c
+    lib().tfo_poly_scale_xfe(_p(buf), c.size // 3, _p(_arr(offset, 3)))
+    return ntt(buf, width=3)
+
+
+def coset_interpolate_xfe_offset(values, offset) -> np.ndarray:
+    """fast_coset_interpolate with S = XFieldElement (math/polynomial.rs:1907-1918): intt, scale by the inverse offset."""
+    v = intt(_arr(values).reshape(-1), width=3)
+    lib().tfo_poly_scale_xfe(_p(v), v.size // 3, _p(xfe_inverse(offset)))
+    return v
 
 
 def merkle_from_rows(rows, row_len: int) -> np.ndarray:

@@ -703,3 +703,40 @@ def test_clean_divide_device_resident_large(tf, oracle):
     tf.device.clean_divide(a, b, out)
     torch.cuda.synchronize()
     assert torch.equal(out, q)
+
+
+@pytest.mark.parametrize("n_coeffs,order,batch", [(1, 1, 1), (3, 8, 2), (100, 128, 3), (1024, 1024, 1), (3000, 4096, 2), (1 << 15, 1 << 16, 1)])
+def test_coset_evaluation_with_an_extension_field_offset(tf, oracle, n_coeffs, order, batch):
+    """fast_coset_evaluate / fast_coset_interpolate with S = XFieldElement (math/polynomial.rs:1374-1378, :1907-1911; the
+    reference tests the scaling with offsets of either field at :2921-2944): bit-exact against the oracle's sequential power
+    chain, and interpolate inverts evaluate."""
+    off = oracle.fill_random(3, 1800 + n_coeffs)
+    c = oracle.fill_random(3 * n_coeffs * batch, 1801 + n_coeffs)
+    got = tf.fast_coset_evaluate(c, off, order, width=3, batch=batch).reshape(batch, -1)
+    for b in range(batch):
+        want = oracle.coset_evaluate_xfe_offset(c[3 * n_coeffs * b: 3 * n_coeffs * (b + 1)], off, order)
+        assert np.array_equal(got[b], want)
+    back = tf.fast_coset_interpolate(got.reshape(-1), off, width=3, batch=batch).reshape(batch, -1)
+    for b in range(batch):
+        assert np.array_equal(back[b, : 3 * n_coeffs], c[3 * n_coeffs * b: 3 * n_coeffs * (b + 1)]) and not back[b, 3 * n_coeffs:].any()
+        assert np.array_equal(back[b], oracle.coset_interpolate_xfe_offset(got[b], off))
+    # an offset in the base field, given as an XFieldElement, gives the base-field path's values
+    lifted = np.array([oracle.bfe_new(7), 0, 0], dtype=np.uint64)
+    assert np.array_equal(tf.fast_coset_evaluate(c, lifted, order, width=3, batch=batch),
+                          tf.fast_coset_evaluate(c, oracle.bfe_new(7), order, width=3, batch=batch))
+
+
+def test_extension_field_offset_panics(tf, oracle):
+    c = oracle.fill_random(3 * 16, 5)
+    off = oracle.fill_random(3, 6)
+    with pytest.raises(tf.NttPanic) as e:
+        tf.fast_coset_evaluate(c, off, 8, width=3)      # order <= degree (:1388-1392)
+    assert e.value.code == 6
+    with pytest.raises(tf.NttPanic) as e:
+        tf.fast_coset_evaluate(c[: 3 * 5], off, 12, width=3)  # order not a power of two
+    assert e.value.code == 4
+    with pytest.raises(tf.NttPanic) as e:
+        tf.fast_coset_interpolate(c, np.zeros(3, dtype=np.uint64), width=3)  # the zero offset has no inverse
+    assert e.value.code == 12
+    with pytest.raises(TypeError):
+        tf.fast_coset_evaluate(oracle.fill_random(16, 7), off, 16, width=1)  # BFieldElement * XFieldElement is not a BFieldElement

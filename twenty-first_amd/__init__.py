@@ -136,7 +136,20 @@ def intt(x: np.ndarray, width: int = 1, batch: int = 1) -> None:
     ntt(x, width=width, batch=batch, _inverse=True)
 
 
-def fast_coset_evaluate(coeffs: np.ndarray, offset_raw: int, order: int, width: int = 1, batch: int = 1) -> np.ndarray:
+def _xfe_offset(offset, width: int):
+    """None for a BFieldElement offset (one raw word), the 3 raw words for an XFieldElement offset (XFE polynomials only:
+    FF: Mul<S, Output = FF>, math/polynomial.rs:1376)."""
+    if isinstance(offset, (int, np.integer)):
+        return None
+    off = np.ascontiguousarray(offset, dtype=np.uint64).reshape(-1)
+    if off.size == 1:
+        return None
+    if off.size != 3 or width != 3:
+        raise TypeError("an XFieldElement offset (3 raw words) needs XFieldElement coefficients")
+    return off
+
+
+def fast_coset_evaluate(coeffs: np.ndarray, offset_raw, order: int, width: int = 1, batch: int = 1) -> np.ndarray:
     """`batch` polynomials of equal length -> `batch` x `order` evaluations (math/polynomial.rs:1374-1399).
     The reference compares `order` with the DEGREE (:1388): high-order zero coefficients common to the whole batch are
     trimmed here before the length reaches the C ABI, as Polynomial::degree() does for one polynomial."""
@@ -152,18 +165,28 @@ def fast_coset_evaluate(coeffs: np.ndarray, offset_raw: int, order: int, width: 
             coeffs = np.ascontiguousarray(c3[:, :keep, :]).reshape(-1)
             n_coeffs = keep
     out = np.empty(batch * order * width, dtype=np.uint64)
+    xoff = _xfe_offset(offset_raw, width)
+    if xoff is not None:  # S = XFieldElement (:1374-1378)
+        _check(lib().tf_coset_eval_xfe_xoffset(_ptr(coeffs), n_coeffs, _ptr(xoff), _ptr(out), order, batch), "fast_coset_evaluate")
+        return out
+    offset_raw = int(np.asarray(offset_raw).reshape(-1)[0])
     fn = lib().tf_coset_eval_bfe if width == 1 else lib().tf_coset_eval_xfe
     _check(fn(_ptr(coeffs), n_coeffs, C.c_uint64(offset_raw), _ptr(out), order, batch), "fast_coset_evaluate")
     return out
 
 
-def fast_coset_interpolate(values: np.ndarray, offset_raw: int, width: int = 1, batch: int = 1) -> np.ndarray:
+def fast_coset_interpolate(values: np.ndarray, offset_raw, width: int = 1, batch: int = 1) -> np.ndarray:
     """`batch` x n evaluations on {offset * w^i} -> `batch` x n coefficients (math/polynomial.rs:1907-1918)."""
     values = _words(values, "values")
     if batch and values.size % (batch * width):
         raise ValueError("values size is not batch * n * width")
     n = values.size // (batch * width) if batch else 0
     out = np.empty_like(values)
+    xoff = _xfe_offset(offset_raw, width)
+    if xoff is not None:  # S = XFieldElement (:1907-1911)
+        _check(lib().tf_coset_interpolate_xfe_xoffset(_ptr(values), n, _ptr(xoff), _ptr(out), batch), "fast_coset_interpolate")
+        return out
+    offset_raw = int(np.asarray(offset_raw).reshape(-1)[0])
     fn = lib().tf_coset_interpolate_bfe if width == 1 else lib().tf_coset_interpolate_xfe
     _check(fn(_ptr(values), n, C.c_uint64(offset_raw), _ptr(out), batch), "fast_coset_interpolate")
     return out

@@ -496,4 +496,23 @@ __global__ void __launch_bounds__(256) unscale_unlift_kernel(const u64* q, long 
     if (i < n_q) out[i] = r[0];
 }
 
+// out[b][i] = in[b][i] * base^i (XFieldElement coefficients and base) for i < n_in, zero for n_in <= i < n_out:
+// Polynomial::scale with an extension-field offset (polynomial.rs:760-773) plus the zero padding of fast_coset_evaluate (:1396).
+// In place when in == out and the geometry matches (every thread owns its element).
+__global__ void __launch_bounds__(256) xfe_scale_kernel(const u64* in, long long n_in, long long in_stride, u64* out, long long n_out,
+                                                        long long batch, u64 b0, u64 b1, u64 b2) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_out * batch) return;
+    const long long b = t / n_out, i = t - b * n_out;
+    u64 r[3] = {0, 0, 0};
+    if (i < n_in) {
+        const u64 base[3] = {b0, b1, b2};
+        u64 pw[3], v[3];
+        xfe_pow(base, (unsigned long long)i, pw);
+        fe_load<3>(in + b * in_stride + 3 * i, v);
+        xfe_mul(v, pw, r);
+    }
+    fe_store<3>(out + 3 * t, r);
+}
+
 }  // namespace tfk

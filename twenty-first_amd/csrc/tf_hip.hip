@@ -2227,6 +2227,61 @@ int interpolate_dev(const u64* domain, const u64* values, size_t n, size_t rows,
     return L == 1 ? interpolate_dev_t<1>(domain, values, n, rows, out, s) : interpolate_dev_t<3>(domain, values, n, rows, out, s);
 }
 
+// fast_coset_evaluate / fast_coset_interpolate with an XFieldElement OFFSET (polynomial.rs:1374-1399, :1907-1918 with
+// S = XFieldElement; the docs recommend a BFieldElement offset, :1366-1368, and the fused pre/post-scale tables of the main path
+// are base-field): the scaling is its own pass here -- c_i * offset^i by square-and-multiply per coefficient -- around the plain
+// XFE transform.
+static bool xfe_inverse_host(const u64 (&a)[3], u64 (&r)[3]) {  // the cofactor formula of poly_kernels.h on the host
+    const u64 sm = gl::add(a[0], a[2]), dd = gl::sub(a[1], a[2]);
+    const u64 c0 = gl::sub(gl::mont_mul(sm, sm), gl::mont_mul(dd, a[1]));
+    const u64 c1 = gl::sub(gl::mont_mul(dd, a[2]), gl::mont_mul(a[1], sm));
+    const u64 c2 = gl::sub(gl::mont_mul(a[1], a[1]), gl::mont_mul(sm, a[2]));
+    const u64 det = gl::sub(gl::sub(gl::mont_mul(a[0], c0), gl::mont_mul(a[2], c1)), gl::mont_mul(a[1], c2));
+    const u64 di = gl::mont_inverse(det);
+    r[0] = gl::mont_mul(c0, di);
+    r[1] = gl::mont_mul(c1, di);
+    r[2] = gl::mont_mul(c2, di);
+    return det != 0;
+}
+
+int coset_eval_xoffset_dev(const u64* d_coeffs, size_t n_coeffs, const u64 offset[3], u64* d_out, size_t order, size_t batch, void* stream) {
+    if (n_coeffs > order) return TF_ERR_ORDER_NOT_ABOVE_DEGREE;  // polynomial.rs:1388-1392
+    int rc = check_len(order);
+    if (rc) return rc;
+    if (order == 0 || batch == 0) return TF_OK;
+    if (!d_out || !offset || (n_coeffs && !d_coeffs)) return TF_ERR_NULL_POINTER;
+    DeviceCtx* ctx = nullptr;
+    rc = current_ctx(&ctx);
+    if (rc) return rc;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const long long total = (long long)order * (long long)batch;
+    hipLaunchKernelGGL(tfk::xfe_scale_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, d_coeffs, (long long)n_coeffs,
+                       (long long)n_coeffs * 3, d_out, (long long)order, (long long)batch, offset[0], offset[1], offset[2]);
+    HIPCHK(hipGetLastError());
+    return run_ntt(ctx, d_out, d_out, (long long)order * 3, (long long)order * 3, order, batch, 3, false, nullptr, -1, s);
+}
+
+int coset_interp_xoffset_dev(const u64* d_values, size_t n, const u64 offset[3], u64* d_out, size_t batch, void* stream) {
+    int rc = check_len(n);
+    if (rc) return rc;
+    if (n == 0 || batch == 0) return TF_OK;
+    if (!d_values || !d_out || !offset) return TF_ERR_NULL_POINTER;
+    const u64 off[3] = {offset[0], offset[1], offset[2]};
+    u64 inv[3];
+    if (!xfe_inverse_host(off, inv)) return TF_ERR_INVERSE_OF_ZERO;  // offset.inverse() panics on zero (x_field_element.rs:371-375)
+    DeviceCtx* ctx = nullptr;
+    rc = current_ctx(&ctx);
+    if (rc) return rc;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    rc = run_ntt(ctx, d_values, d_out, (long long)n * 3, (long long)n * 3, n, batch, 3, true, nullptr, -1, s);
+    if (rc) return rc;
+    const long long total = (long long)n * (long long)batch;
+    hipLaunchKernelGGL(tfk::xfe_scale_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const u64*)d_out, (long long)n,
+                       (long long)n * 3, d_out, (long long)n, (long long)batch, inv[0], inv[1], inv[2]);
+    HIPCHK(hipGetLastError());
+    return TF_OK;
+}
+
 // Polynomial::<BFieldElement>::clean_divide (polynomial.rs:2358-2411): a / b for b | a, by pointwise division on the coset
 // X * <w_order> of the extension field (poly_kernels.h).  a, b: normalised coefficient arrays (non-zero leading coefficient),
 // out: na - nb + 1 coefficients.  The reference's factor-x workaround (:2368-2378) changes nothing on this coset (X w^i != 0) and
@@ -2821,6 +2876,29 @@ static int interpolate_host(const uint64_t* d, const uint64_t* v, size_t n, size
 }
 int tf_poly_interpolate_bfe(const uint64_t* d, const uint64_t* v, size_t n, size_t rows, uint64_t* out) { return interpolate_host(d, v, n, rows, out, 1); }
 int tf_poly_interpolate_xfe(const uint64_t* d, const uint64_t* v, size_t n, size_t rows, uint64_t* out) { return interpolate_host(d, v, n, rows, out, 3); }
+int tf_coset_eval_xfe_xoffset_dev(const uint64_t* c, size_t nc, const uint64_t offset[3], uint64_t* out, size_t order, size_t batch, void* stream) {
+    return coset_eval_xoffset_dev(c, nc, offset, out, order, batch, stream);
+}
+int tf_coset_interpolate_xfe_xoffset_dev(const uint64_t* v, size_t n, const uint64_t offset[3], uint64_t* out, size_t batch, void* stream) {
+    return coset_interp_xoffset_dev(v, n, offset, out, batch, stream);
+}
+int tf_coset_eval_xfe_xoffset(const uint64_t* c, size_t nc, const uint64_t offset[3], uint64_t* out, size_t order, size_t batch) {
+    if (nc > order) return TF_ERR_ORDER_NOT_ABOVE_DEGREE;
+    int rc = check_len(order);
+    if (rc) return rc;
+    if (order == 0 || batch == 0) return TF_OK;
+    if (!out || !offset || (nc && !c)) return TF_ERR_NULL_POINTER;
+    return host_roundtrip(c, 3 * nc * batch, nullptr, 0, out, 3 * order * batch,
+                          [&](u64* dc, u64*, u64* o, hipStream_t s) { return coset_eval_xoffset_dev(dc, nc, offset, o, order, batch, s); });
+}
+int tf_coset_interpolate_xfe_xoffset(const uint64_t* v, size_t n, const uint64_t offset[3], uint64_t* out, size_t batch) {
+    int rc = check_len(n);
+    if (rc) return rc;
+    if (n == 0 || batch == 0) return TF_OK;
+    if (!v || !out || !offset) return TF_ERR_NULL_POINTER;
+    return host_roundtrip(v, 3 * n * batch, nullptr, 0, out, 3 * n * batch,
+                          [&](u64* dv, u64*, u64* o, hipStream_t s) { return coset_interp_xoffset_dev(dv, n, offset, o, batch, s); });
+}
 int tf_poly_clean_divide_bfe_dev(const uint64_t* a, size_t na, const uint64_t* b, size_t nb, uint64_t* out, void* stream) {
     return clean_divide_dev(a, na, b, nb, out, stream);
 }
