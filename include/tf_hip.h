@@ -207,7 +207,7 @@ int tf_coset_interpolate_xfe_xoffset_dev(const uint64_t *d_values, size_t n, con
 int tf_poly_clean_divide_bfe(const uint64_t *a, size_t na, const uint64_t *b, size_t nb, uint64_t *out);
 int tf_poly_clean_divide_bfe_dev(const uint64_t *d_a, size_t na, const uint64_t *d_b, size_t nb, uint64_t *d_out, void *stream);
 /* Route of the batch evaluation (test / A-B hook): 0 = automatic (zerofier tree for many points on a long polynomial, Horner
- * otherwise), 1 = always Horner, 2 = the zerofier tree whenever it applies (>= 512 points).  Same values either way. */
+ * otherwise), 1 = always Horner, 2 = the zerofier tree whenever it applies (at least two leaves: 512 points over BFE, 256 over XFE).  Same values either way. */
 void tf_set_batch_eval_route(int route);
 /* Polynomial::coset_extrapolate :2117-2128 / batch_coset_extrapolate :2196-2208 (and the par_ variant :2262): for each of
  * `batch` codewords of length n (a power of two, else TF_ERR_LEN_NOT_POWER_OF_TWO) given on {offset * w_n^i}, the values of

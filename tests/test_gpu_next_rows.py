@@ -501,7 +501,7 @@ def _distinct_points(oracle, n, width, seed):
 
 
 @pytest.mark.parametrize("width", [1, 3])
-@pytest.mark.parametrize("n", [0, 1, 2, 3, 17, 255, 256, 257, 1023, 1024, 1025, 2049, 3000, 5000])
+@pytest.mark.parametrize("n", [0, 1, 2, 3, 17, 127, 128, 129, 255, 256, 257, 511, 513, 1023, 1024, 1025, 2049, 3000, 5000])
 def test_zerofier_matches_oracle(tf, oracle, width, n):
     """Polynomial::zerofier (polynomial.rs:1435-1441): the root of the device's padded tree against the oracle's smart_zerofier
     (:1462-1475), word for word -- sizes around the leaf sizes (1024 BFE / 256 XFE) and the padded tree sizes, repeated and
@@ -521,7 +521,7 @@ def test_zerofier_matches_oracle(tf, oracle, width, n):
 
 
 @pytest.mark.parametrize("width", [1, 3])
-@pytest.mark.parametrize("n", [1, 2, 4, 17, 255, 256, 257, 1024, 1025, 2051, 3000])
+@pytest.mark.parametrize("n", [1, 2, 4, 17, 127, 128, 129, 255, 256, 257, 512, 513, 1024, 1025, 2051, 3000])
 def test_interpolate_matches_lagrange_oracle(tf, oracle, width, n):
     """Polynomial::interpolate / fast_interpolate (polynomial.rs:1502-1654) against the oracle's lagrange_interpolate (:1565-1606),
     the identity the reference tests at :3572-3582; the interpolant evaluates back to the values (:3602-3612)."""

@@ -4,9 +4,9 @@
 // :1882-1894 over math/zerofier_tree.rs): f at m arbitrary points by remaindering down a binary tree of zerofiers
 // Z_node(x) = prod (x - p_i), leaves evaluated directly.  Every scheme returns exactly f(p_i) (exact field arithmetic), so the
 // tree here is laid out for the device instead of mirrored node by node:
-//   * leaves of LEAF = 1024 points (one workgroup each: the O(LEAF^2) leaf work is 1/64 of a Horner pass at m = 2^16 and saves
-//     two tree levels of launch-bound small products); a level is ONE array [nodes][d] of monic zerofiers stored without their leading 1 ("tails"),
-//     so every product / remainder of a level is one batched fast_multiply (tf_hip.hip: zerofier_tree_*);
+//   * leaves of 256 (BFE) / 128 (XFE) points, one workgroup each (O(leaf^2) work in LDS); a level is ONE array [nodes][d] of
+//     monic zerofiers stored without their leading 1 ("tails") beside its forward transforms of order 2d, so every product /
+//     remainder of a level is a batched transform, a pointwise kernel and a batched inverse transform (tf_hip.hip: zerofier_tree_*);
 //   * a remainder f mod Z (deg f < 2d, deg Z = d) is taken with the power-series inverse g of rev(Z) mod x^d:
 //     rev(q) = rev(f_high) * g mod x^d,  r = f_low - (q * tail(Z))_low   (two products of size d x d);
 //     g of a parent = g_left * g_right (precision d) followed by one Newton step to precision 2d, so the inverses cost three
@@ -48,8 +48,9 @@ __device__ __forceinline__ void fe_store(u64* p, const u64 (&r)[L]) {
 constexpr int kLeafMax = 1024;  // threads per leaf workgroup = points per leaf
 template <int L>
 __global__ void __launch_bounds__(kLeafMax) leaf_zerofier_kernel(const u64* points, long long n_points, int d, u64* tails, u64* inv) {
-    __shared__ u64 c[kLeafMax * L];    // coefficients 0 .. d - 1 of the running product (the leading 1 leaves the array at the last point)
-    __shared__ u64 acc[kLeafMax * L];  // partial sums of the series inversion
+    extern __shared__ u64 leaf_lds[];  // 2 * d * L words (dynamic: a small leaf leaves the LDS to more workgroups)
+    u64* c = leaf_lds;                 // coefficients 0 .. d - 1 of the running product (the leading 1 leaves the array at the last point)
+    u64* acc = leaf_lds + d * L;       // partial sums of the series inversion
     const int t = threadIdx.x;
     const long long leaf = blockIdx.x;
     // product: c = 1; for every point p: c_new[j] = c[j - 1] - p * c[j]
@@ -196,11 +197,89 @@ __global__ void __launch_bounds__(256) remainder_finish_kernel(const u64* f, con
     fe_store<L>(r + i * L, v);
 }
 
+// ---- levels in the transform domain (round 2) -------------------------------------------------------------------------------
+// Every level keeps, beside the tails and the inverses, their forward transforms of order 2d ("That", "Ghat": [nodes][2d]); the
+// build produces them anyway for the parents, and the walk down (and the interpolation walk up) multiplies against them
+// without transforming the tree again.
+
+// Parents' tails from the children's transformed tails: the zerofier x^d + A transforms (order 2d) to That_A[k] + (-1)^k;
+// (x^d + A)(x^d + B) = x^2d + tail_parent, and x^2d wraps to 1 at order 2d:  out = (A^ + s_k)(B^ + s_k) - 1,  s_k = (-1)^k.
+// The inverse transform of `out` is the parents' [parents][2d] tail array.
+template <int L>
+__global__ void __launch_bounds__(256) zerofier_pointwise_kernel(const u64* That, u64* out, long long d, long long n_parents) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_parents * 2 * d) return;
+    const long long node = i / (2 * d), k = i - node * 2 * d;
+    u64 a[L], b[L], r[L];
+    fe_load<L>(That + ((2 * node) * 2 * d + k) * L, a);
+    fe_load<L>(That + ((2 * node + 1) * 2 * d + k) * L, b);
+    if (k & 1) {
+        a[0] = gl::sub(a[0], gl::ONE);
+        b[0] = gl::sub(b[0], gl::ONE);
+    } else {
+        a[0] = gl::add(a[0], gl::ONE);
+        b[0] = gl::add(b[0], gl::ONE);
+    }
+    fe_mul<L>(a, b, r);
+    r[0] = gl::sub(r[0], gl::ONE);
+    fe_store<L>(out + i * L, r);
+}
+
+// out[node][k] = X[2 node][k] * X[2 node + 1][k], k < n: the product of sibling transforms (XFieldElement; over BFieldElement
+// the product rides on the inverse transform's load)
+template <int L>
+__global__ void __launch_bounds__(256) pair_product_kernel(const u64* X, u64* out, long long n, long long n_parents) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_parents * n) return;
+    const long long node = i / n, k = i - node * n;
+    u64 a[L], b[L], r[L];
+    fe_load<L>(X + ((2 * node) * n + k) * L, a);
+    fe_load<L>(X + ((2 * node + 1) * n + k) * L, b);
+    fe_mul<L>(a, b, r);
+    fe_store<L>(out + i * L, r);
+}
+
+// Inputs of the Newton step, both 2d coefficients per parent, in ONE array so that one batched transform of order 4d takes them:
+//   B[node]           = G = (g_left g_right mod x^d), zero padded   (S1: [parents][2d], the product's low half is G)
+//   B[parents + node] = H = rev(Z_parent): H[0] = 1, H[k] = tail[2d - k]
+template <int L>
+__global__ void __launch_bounds__(256) newton_inputs_kernel(const u64* S1, const u64* parent_tails, u64* B, long long d, long long n_parents) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_parents * 2 * d) return;
+    const long long node = i / (2 * d), k = i - node * 2 * d;
+    u64 g[L], h[L];
+#pragma unroll
+    for (int q = 0; q < L; ++q) {
+        g[q] = k < d ? S1[i * L + q] : 0;
+        h[q] = k == 0 ? (q ? 0 : gl::ONE) : parent_tails[(node * 2 * d + (2 * d - k)) * L + q];
+    }
+    fe_store<L>(B + i * L, g);
+    fe_store<L>(B + (n_parents * 2 * d + i) * L, h);
+}
+
+// C: transforms of order n = 4d of B's rows.  In place on the G rows:  C[node] <- g^ (2 - h^ g^)   (deg g (2 - h g) < 4d: no wrap;
+// its low 2d coefficients are the parent's inverse to precision 2d)
+template <int L>
+__global__ void __launch_bounds__(256) newton_pointwise_kernel(u64* C, long long n, long long n_parents) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_parents * n) return;
+    u64 g[L], h[L], hg[L], e[L], r[L];
+    fe_load<L>(C + i * L, g);
+    fe_load<L>(C + (n_parents * n + i) * L, h);
+    fe_mul<L>(h, g, hg);
+#pragma unroll
+    for (int q = 0; q < L; ++q) e[q] = gl::neg(hg[q]);
+    e[0] = gl::add(e[0], gl::add(gl::ONE, gl::ONE));
+    fe_mul<L>(g, e, r);
+    fe_store<L>(C + i * L, r);
+}
+
 // Leaves: remainder of degree < d per leaf, evaluated at the leaf's d points by Horner (coefficients through LDS).
 // vals[leaf * d + t] = r_leaf(points[leaf * d + t]);  grid = leaves, block = d threads
 template <int L>
 __global__ void __launch_bounds__(kLeafMax) leaf_evaluate_kernel(const u64* rem, const u64* points, long long n_points, int d, u64* vals) {
-    __shared__ u64 c[kLeafMax * L];
+    extern __shared__ u64 leaf_lds[];  // d * L words
+    u64* c = leaf_lds;
     const int t = threadIdx.x;
     const long long leaf = blockIdx.x;
 #pragma unroll
@@ -345,8 +424,9 @@ __global__ void __launch_bounds__(256) interpolation_targets_kernel(const u64* v
 template <int L>
 __global__ void __launch_bounds__(kLeafMax) leaf_interpolant_kernel(const u64* points, const u64* targets, long long n_points, int d,
                                                                     long long M, u64* N) {
-    __shared__ u64 c[kLeafMax * L];   // Z, coefficients 0 .. d - 1 (its leading 1 is still inside while it is needed)
-    __shared__ u64 nn[kLeafMax * L];  // N
+    extern __shared__ u64 leaf_lds[];  // 2 * d * L words
+    u64* c = leaf_lds;                 // Z, coefficients 0 .. d - 1 (its leading 1 is still inside while it is needed)
+    u64* nn = leaf_lds + d * L;        // N
     const int t = threadIdx.x;
     const long long leaf = blockIdx.x, row = blockIdx.y;
 #pragma unroll

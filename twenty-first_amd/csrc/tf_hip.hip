@@ -1858,11 +1858,20 @@ int lde_dev(const u64* values, size_t n, u64 offset_in, u64* out, size_t m, u64 
 // Sub-quadratic counterpart of the Horner kernels for many points on a long polynomial: O((n + m) log^2 m) instead of O(n m).
 // `units` polynomials of `len` <= M coefficients each (packed, unit u at F + u * len * L) are evaluated at the n_points points;
 // vals[(u * M + i) * L] = unit_u(points[i]).  M = kTreeLeaf * 2^h >= n_points is the padded point count.
-// Leaf size: 1024 points over BFieldElement (= tfk::kLeafMax: the O(leaf^2) leaf work is cheap and two launch-bound tree levels
-// go away: 4.07 -> 3.85 ms at n = m = 2^16), 256 over XFieldElement (nine base-field products per step make the quadratic leaf
-// work expensive: 5.3 ms with 256 vs 8.4 ms with 1024), tools/batch_eval_sweep.py.
-constexpr int tree_leaf(int L) { return L == 1 ? 1024 : 256; }
-constexpr int tree_leaf_log(int L) { return L == 1 ? 10 : 8; }
+// Leaf size: 256 points over BFieldElement, 128 over XFieldElement (nine base-field products per step make the quadratic leaf
+// work expensive).  With the levels in the transform domain (10 launches per level to build, 7 to walk) a level costs less than
+// the O(leaf^2) work of a bigger leaf on the few workgroups a small tree has: n = m = 2^16 BFE 2.56 ms with 1024-point leaves,
+// 2.30 with 512, 2.33 with 256, 2.46 with 128; 2^20 x 2^20 6.7 / 5.7 / 5.4 / 5.5; XFE 2^20 x 2^20 24.1 / 17.0 / 14.0 / 13.6
+// (tools/leaf_ab.sh, profiles/r02_leaf_ab.txt).
+inline int tree_leaf_log(int L) {  // TF_TREE_LEAF_LOG = 6..10 overrides both fields (A/B: tools/batch_eval_sweep.py)
+    static const int forced = [] {
+        const char* e = getenv("TF_TREE_LEAF_LOG");
+        const int v = e ? atoi(e) : 0;
+        return (v >= 6 && v <= 10) ? v : 0;
+    }();
+    return forced ? forced : (L == 1 ? 8 : 7);
+}
+inline int tree_leaf(int L) { return 1 << tree_leaf_log(L); }
 
 template <int L, class K, class... Args>
 int launch_1d(K kernel, long long threads, hipStream_t s, Args... args) {
@@ -1877,52 +1886,72 @@ struct ZerofierTree {
     long long M = 0;           // padded point count = leaf << h
     std::vector<u64*> tails;   // [level]: (M / d) nodes x d elements
     std::vector<u64*> inv;     // [level]: power-series inverses of the reversed zerofiers, precision d
+    std::vector<u64*> That;    // [level]: forward transforms of order 2d of the tails   (M / d) x 2d
+    std::vector<u64*> Ghat;    // [level]: forward transforms of order 2d of the inverses
 };
+constexpr int kTreeLevelArrays = 6;  // M-element arrays per level: tails, inv, That (2), Ghat (2)
+constexpr int kTreeWorkArrays = 8;   // M-element arrays of work space shared by the build and the walks
+
+// inverse transform of the pointwise product a^ * b^ (batch entries in_bs words apart in both), L words per element.  Over
+// BFieldElement the product rides on the transform's first load; over XFieldElement it is a pass of its own into `out`.
+template <int L>
+int inverse_of_product(DeviceCtx* ctx, const u64* a_hat, const u64* b_hat, long long in_bs, u64* out, size_t order, size_t batch, bool pairs,
+                       hipStream_t s) {
+    if constexpr (L == 1) {
+        return run_ntt(ctx, a_hat, out, in_bs, (long long)order, order, batch, 1, true, nullptr, -1, s, nullptr, 1, b_hat, -1);
+    } else {
+        int rc;
+        if (pairs)  // a_hat / b_hat are the even / odd rows of one array
+            rc = launch_1d<L>(tfk::pair_product_kernel<L>, (long long)(batch * order), s, a_hat, out, (long long)order, (long long)batch);
+        else
+            rc = hadamard_dev(a_hat, b_hat, out, batch * order, L, s);
+        if (rc) return rc;
+        return run_ntt(ctx, out, out, (long long)order * L, (long long)order * L, order, batch, L, true, nullptr, -1, s);
+    }
+}
 
 template <int L>
-int zerofier_tree_build(const u64* points, long long n_points, ZerofierTree* T, u64* arena, u64* pm_work, hipStream_t s) {
-    // arena: 2 * h level arrays of M * L words, then work space of 8 * M * L words; pm_work: 8 M L words for the products
-    // (the largest one is 2d x d over M / 2d parents: order 4d, 2 * (M / 2d) * 4d = 4 M elements)
+int zerofier_tree_build(DeviceCtx* ctx, const u64* points, long long n_points, ZerofierTree* T, u64* arena, hipStream_t s) {
+    // arena: kTreeLevelArrays * h level arrays of M * L words, then kTreeWorkArrays * M * L words of work space
     const long long M = T->M;
     const int h = T->h;
     T->tails.resize(h);
     T->inv.resize(h);
+    T->That.resize(h);
+    T->Ghat.resize(h);
     for (int l = 0; l < h; ++l) {
-        T->tails[l] = arena + (long long)(2 * l) * M * L;
-        T->inv[l] = arena + (long long)(2 * l + 1) * M * L;
+        u64* base = arena + (long long)(kTreeLevelArrays * l) * M * L;
+        T->tails[l] = base;
+        T->inv[l] = base + M * L;
+        T->That[l] = base + 2 * M * L;
+        T->Ghat[l] = base + 4 * M * L;
     }
-    u64* work = arena + (long long)(2 * h) * M * L;
+    u64* work = arena + (long long)(kTreeLevelArrays * h) * M * L;
     if (h == 0) return TF_OK;
-    constexpr int kTreeLeaf = tree_leaf(L);
-    hipLaunchKernelGGL(tfk::leaf_zerofier_kernel<L>, dim3((unsigned)(M / kTreeLeaf)), dim3(kTreeLeaf), 0, s, points, n_points, kTreeLeaf,
-                       T->tails[0], T->inv[0]);
+    const int kTreeLeaf = tree_leaf(L);
+    hipLaunchKernelGGL(tfk::leaf_zerofier_kernel<L>, dim3((unsigned)(M / kTreeLeaf)), dim3(kTreeLeaf), 2 * kTreeLeaf * L * sizeof(u64), s, points,
+                       n_points, kTreeLeaf, T->tails[0], T->inv[0]);
     HIPCHK(hipGetLastError());
-    for (int l = 0; l + 1 < h; ++l) {
-        const long long d = (long long)kTreeLeaf << l, parents = M / (2 * d);
-        u64* P = work;                           // parents x (2d - 1)
-        u64* G = work + 2 * M * L;               // parents x d          (g_left g_right mod x^d)
-        u64* H = work + 3 * M * L;               // parents x 2d         (reversed parent zerofier)
-        u64* Tm = work + 4 * M * L;              // parents x (3d - 1)   (H G)
-        u64* E = work + 6 * M * L;               // parents x 2d         (2 - H G mod x^2d)
-        // tails of the parents
-        int rc = poly_mul_dev(T->tails[l], (size_t)d, T->tails[l] + d * L, (size_t)d, P, (size_t)parents, L, s, 2 * d * L, 2 * d * L, pm_work);
+    for (int l = 0; l < h; ++l) {
+        const long long d = (long long)kTreeLeaf << l, children = M / d, parents = children / 2;
+        // transforms of order 2d of this level's tails and inverses: kept for the walks, and the parents are built from them
+        int rc = run_ntt(ctx, T->tails[l], T->That[l], d * L, 2 * d * L, (size_t)(2 * d), (size_t)children, L, false, nullptr, d, s);
+        if (!rc) rc = run_ntt(ctx, T->inv[l], T->Ghat[l], d * L, 2 * d * L, (size_t)(2 * d), (size_t)children, L, false, nullptr, d, s);
         if (rc) return rc;
-        rc = launch_1d<L>(tfk::zerofier_combine_kernel<L>, parents * 2 * d, s, (const u64*)P, (const u64*)T->tails[l], T->tails[l + 1], d, parents);
-        if (rc) return rc;
-        // inverses of the parents: g = g_left g_right mod x^d, then one Newton step g <- g (2 - rev(Z) g) mod x^2d
-        rc = poly_mul_dev(T->inv[l], (size_t)d, T->inv[l] + d * L, (size_t)d, P, (size_t)parents, L, s, 2 * d * L, 2 * d * L, pm_work);
-        if (rc) return rc;
-        rc = launch_1d<L>(tfk::poly_truncate_kernel<L>, parents * d, s, (const u64*)P, 2 * d - 1, G, d, parents);
-        if (rc) return rc;
-        rc = launch_1d<L>(tfk::zerofier_reverse_kernel<L>, parents * 2 * d, s, (const u64*)T->tails[l + 1], H, 2 * d, parents);
-        if (rc) return rc;
-        rc = poly_mul_dev(H, (size_t)(2 * d), G, (size_t)d, Tm, (size_t)parents, L, s, 0, 0, pm_work);
-        if (rc) return rc;
-        rc = launch_1d<L>(tfk::newton_two_minus_kernel<L>, parents * 2 * d, s, (const u64*)Tm, 3 * d - 1, E, 2 * d, parents);
-        if (rc) return rc;
-        rc = poly_mul_dev(G, (size_t)d, E, (size_t)(2 * d), Tm, (size_t)parents, L, s, 0, 0, pm_work);
-        if (rc) return rc;
-        rc = launch_1d<L>(tfk::poly_truncate_kernel<L>, parents * 2 * d, s, (const u64*)Tm, 3 * d - 1, T->inv[l + 1], 2 * d, parents);
+        if (l + 1 == h) break;
+        u64* S1 = work;              // parents x 2d    g_left g_right (its low half is G)
+        u64* B = work + M * L;       // 2 parents x 2d  Newton inputs G | H
+        u64* C = work + 3 * M * L;   // 2 parents x 4d  their transforms; the G rows become g (2 - h g)
+        // tails of the parents: (A^ + s)(B^ + s) - 1 pointwise, one inverse transform straight into the level array
+        rc = launch_1d<L>(tfk::zerofier_pointwise_kernel<L>, parents * 2 * d, s, (const u64*)T->That[l], T->tails[l + 1], d, parents);
+        if (!rc) rc = run_ntt(ctx, T->tails[l + 1], T->tails[l + 1], 2 * d * L, 2 * d * L, (size_t)(2 * d), (size_t)parents, L, true, nullptr, -1, s);
+        // inverses of the parents: G = g_left g_right mod x^d, then one Newton step g <- G (2 - rev(Z) G) mod x^2d at order 4d
+        if (!rc) rc = inverse_of_product<L>(ctx, T->Ghat[l], T->Ghat[l] + 2 * d * L, 4 * d * L, S1, (size_t)(2 * d), (size_t)parents, true, s);
+        if (!rc) rc = launch_1d<L>(tfk::newton_inputs_kernel<L>, parents * 2 * d, s, (const u64*)S1, (const u64*)T->tails[l + 1], B, d, parents);
+        if (!rc) rc = run_ntt(ctx, B, C, 2 * d * L, 4 * d * L, (size_t)(4 * d), (size_t)(2 * parents), L, false, nullptr, 2 * d, s);
+        if (!rc) rc = launch_1d<L>(tfk::newton_pointwise_kernel<L>, parents * 4 * d, s, C, 4 * d, parents);
+        if (!rc) rc = run_ntt(ctx, C, C, 4 * d * L, 4 * d * L, (size_t)(4 * d), (size_t)parents, L, true, nullptr, -1, s);
+        if (!rc) rc = launch_1d<L>(tfk::poly_truncate_kernel<L>, parents * 2 * d, s, (const u64*)C, 4 * d, T->inv[l + 1], 2 * d, parents);
         if (rc) return rc;
     }
     return TF_OK;
@@ -1930,32 +1959,34 @@ int zerofier_tree_build(const u64* points, long long n_points, ZerofierTree* T, 
 
 // F: one unit of exactly M coefficients (zero padded); vals: M values (the first n_points are meaningful)
 template <int L>
-int zerofier_tree_evaluate(const ZerofierTree& T, const u64* F, const u64* points, long long n_points, u64* vals, u64* work, u64* pm_work,
+int zerofier_tree_evaluate(DeviceCtx* ctx, const ZerofierTree& T, const u64* F, const u64* points, long long n_points, u64* vals, u64* work,
                            hipStream_t s) {
-    constexpr int kTreeLeaf = tree_leaf(L);
+    const int kTreeLeaf = tree_leaf(L);
     const long long M = T.M;
     const u64* cur = F;  // remainders of the level above: (M / 2d) polynomials of 2d coefficients
     u64* ping = work;               // M
     u64* pong = work + M * L;       // M
-    u64* fr = work + 2 * M * L;     // children x d
-    u64* prod = work + 3 * M * L;   // children x (2d - 1)  (< 2 M)
-    u64* q = work + 5 * M * L;      // children x d
+    u64* fr = work + 2 * M * L;     // children x d      reversed upper halves, then the quotients
+    u64* Fh = work + 3 * M * L;     // children x 2d     their transforms
+    u64* prod = work + 5 * M * L;   // children x 2d     products back in the coefficient domain
     for (int l = T.h - 1; l >= 0; --l) {
         const long long d = (long long)kTreeLeaf << l, children = M / d;
+        // rev(q) = rev(f_high) g mod x^d
         int rc = launch_1d<L>(tfk::remainder_rev_high_kernel<L>, children * d, s, cur, fr, d, children);
-        if (rc) return rc;
-        rc = poly_mul_dev(fr, (size_t)d, T.inv[l], (size_t)d, prod, (size_t)children, L, s, 0, 0, pm_work);
-        if (rc) return rc;
-        rc = launch_1d<L>(tfk::poly_reverse_kernel<L>, children * d, s, (const u64*)prod, 2 * d - 1, q, d, children);
-        if (rc) return rc;
-        rc = poly_mul_dev(q, (size_t)d, T.tails[l], (size_t)d, prod, (size_t)children, L, s, 0, 0, pm_work);
+        if (!rc) rc = run_ntt(ctx, fr, Fh, d * L, 2 * d * L, (size_t)(2 * d), (size_t)children, L, false, nullptr, d, s);
+        if (!rc) rc = inverse_of_product<L>(ctx, Fh, T.Ghat[l], 2 * d * L, prod, (size_t)(2 * d), (size_t)children, false, s);
+        if (!rc) rc = launch_1d<L>(tfk::poly_reverse_kernel<L>, children * d, s, (const u64*)prod, 2 * d, fr, d, children);
+        // r = f_low - (q tail)_low
+        if (!rc) rc = run_ntt(ctx, fr, Fh, d * L, 2 * d * L, (size_t)(2 * d), (size_t)children, L, false, nullptr, d, s);
+        if (!rc) rc = inverse_of_product<L>(ctx, Fh, T.That[l], 2 * d * L, prod, (size_t)(2 * d), (size_t)children, false, s);
         if (rc) return rc;
         u64* nxt = (cur == ping) ? pong : ping;
-        rc = launch_1d<L>(tfk::remainder_finish_kernel<L>, children * d, s, cur, (const u64*)prod, 2 * d - 1, nxt, d, children);
+        rc = launch_1d<L>(tfk::remainder_finish_kernel<L>, children * d, s, cur, (const u64*)prod, 2 * d, nxt, d, children);
         if (rc) return rc;
         cur = nxt;
     }
-    hipLaunchKernelGGL(tfk::leaf_evaluate_kernel<L>, dim3((unsigned)(M / kTreeLeaf)), dim3(kTreeLeaf), 0, s, cur, points, n_points, kTreeLeaf, vals);
+    hipLaunchKernelGGL(tfk::leaf_evaluate_kernel<L>, dim3((unsigned)(M / kTreeLeaf)), dim3(kTreeLeaf), kTreeLeaf * L * sizeof(u64), s, cur, points,
+                       n_points, kTreeLeaf, vals);
     HIPCHK(hipGetLastError());
     return TF_OK;
 }
@@ -1981,22 +2012,27 @@ bool tree_route(size_t n_coeffs, size_t n_points, size_t batch, int L) {
     {
         int h = 0;
         for (size_t v = kTreeLeaf; v < M; v <<= 1) ++h;
-        const size_t arena_words = (size_t)(2 * h + 17 + (n_coeffs + M - 1) / M) * M * (size_t)L;  // batch_evaluate_tree_t's arena
+        const size_t arena_words = (size_t)(kTreeLevelArrays * h + kTreeWorkArrays + 1 + (n_coeffs + M - 1) / M) * M * (size_t)L;  // batch_evaluate_tree_t's arena
         if (arena_words * sizeof(u64) > (size_t(8) << 30)) return false;  // the tree's levels would not fit a sane work space
     }
     if (force && !strcmp(force, "tree")) return true;
     // Cost model fitted to tools/batch_eval_sweep.py on MI355X (profiles/r02_batch_eval_sweep.txt), milliseconds:
     //   Horner  n m / 1.4e9            (x 7 over XFieldElement: nine base-field products per step)
-    //   tree    (1 + units) (1 + M / 2^16)   one build plus one pass per unit, launch-bound below 2^16 points   (x 3 over XFE)
+    //   tree    walk (1.4 + units): one build (1.4 walks) plus one walk per unit; a walk is launch-bound per level
+    //           (7 launches, 0.115 ms) plus a term in the padded point count (0.06 ms per 2^16 points, 0.2 over XFE)
+    int levels = 0;
+    for (size_t v = kTreeLeaf; v < M; v <<= 1) ++levels;
     const double horner_ms = (double)n_coeffs * (double)n_points / 1.4e9 * (L == 3 ? 7.0 : 1.0);
-    const double tree_ms = (1.0 + (double)units) * (0.75 + (double)M / 65536.0) * (L == 3 ? 1.35 : 1.0);
-    return tree_ms < 0.8 * horner_ms;
+    const double latency = std::max(0.1, -0.10 + 0.115 * levels) * (L == 3 ? 1.3 : 1.0);
+    const double walk_ms = latency + (L == 3 ? 0.2 : 0.06) * (double)M / 65536.0;
+    const double tree_ms = walk_ms * (1.4 + (double)units);
+    return tree_ms < 0.9 * horner_ms;
 }
 
 template <int L>
 int batch_evaluate_tree_t(const u64* coeffs, size_t n_coeffs, size_t poly_stride, size_t batch, const u64* points, size_t n_points,
                           u64* out, hipStream_t s) {
-    constexpr int kTreeLeaf = tree_leaf(L);
+    const int kTreeLeaf = tree_leaf(L);
     ZerofierTree T;
     long long M = kTreeLeaf;
     int h = 0;
@@ -2004,22 +2040,23 @@ int batch_evaluate_tree_t(const u64* coeffs, size_t n_coeffs, size_t poly_stride
     T.M = M;
     T.h = h;
     const size_t chunks = (n_coeffs + (size_t)M - 1) / (size_t)M;
-    // arena: tree (2 h M) + build / evaluate work (8 M) + product work (8 M) + one padded unit (M) + values of the chunks of one
-    // polynomial (chunks * M)
-    const size_t words = (size_t)(2 * h + 8 + 8 + 1 + chunks) * (size_t)M * L;
+    // arena: tree (6 h M) + build / walk work (8 M) + one padded unit (M) + values of the chunks of one polynomial (chunks * M)
+    const size_t words = (size_t)(kTreeLevelArrays * h + kTreeWorkArrays + 1 + chunks) * (size_t)M * L;
     u64* arena = nullptr;
+    DeviceCtx* ctx = nullptr;
+    int rc = current_ctx(&ctx);
+    if (rc) return rc;
     hipError_t e = hipMallocAsync(reinterpret_cast<void**>(&arena), words * sizeof(u64), s);
     if (e != hipSuccess) return hip_fail(e, "hipMallocAsync(zerofier tree)", __FILE__, __LINE__);
-    u64* work = arena + (size_t)(2 * h) * M * L;
-    u64* pm_work = work + (size_t)8 * M * L;
-    u64* unit = pm_work + (size_t)8 * M * L;
+    u64* work = arena + (size_t)(kTreeLevelArrays * h) * M * L;
+    u64* unit = work + (size_t)kTreeWorkArrays * M * L;
     u64* vals = unit + (size_t)M * L;
-    int rc = zerofier_tree_build<L>(points, (long long)n_points, &T, arena, pm_work, s);
+    rc = zerofier_tree_build<L>(ctx, points, (long long)n_points, &T, arena, s);
     for (size_t b = 0; b < batch && !rc; ++b) {
         for (size_t c = 0; c < chunks && !rc; ++c) {
             const size_t len = std::min<size_t>((size_t)M, n_coeffs - c * (size_t)M);
             rc = pad_copy(coeffs + b * poly_stride + c * (size_t)M * L, unit, (long long)(len * L), (long long)M * L, 1, s);
-            if (!rc) rc = zerofier_tree_evaluate<L>(T, unit, points, (long long)n_points, vals + c * (size_t)M * L, work, pm_work, s);
+            if (!rc) rc = zerofier_tree_evaluate<L>(ctx, T, unit, points, (long long)n_points, vals + c * (size_t)M * L, work, s);
         }
         if (!rc) rc = launch_1d<L>(tfk::chunk_combine_kernel<L>, (long long)n_points, s, (const u64*)vals, M, (int)chunks, points,
                                    (long long)n_points, h + tree_leaf_log(L) /* log2 M */, out + b * n_points * L);
@@ -2079,44 +2116,45 @@ int batch_evaluate_dev(const u64* coeffs, size_t n_coeffs, size_t poly_stride, s
 // reference's batch_fast_interpolate memoises in its two dictionaries, :1723-1731).
 struct PaddedTree {
     ZerofierTree T;
-    u64* arena = nullptr;     // tree levels + work + product work
+    u64* arena = nullptr;     // tree levels + work
     u64* work = nullptr;      // 8 M L words
-    u64* pm_work = nullptr;   // 8 M L words
     u64* root_tail = nullptr; // M L words: x^M + root_tail = prod (x - p_i) * x^(M - n)
     u64* extra = nullptr;     // caller's space behind the tree
 };
 
 template <int L>
 int padded_tree_build(const u64* points, size_t n_points, size_t extra_words, PaddedTree* pt, hipStream_t s) {
-    constexpr int kTreeLeaf = tree_leaf(L);
+    const int kTreeLeaf = tree_leaf(L);
     long long M = kTreeLeaf;
     int h = 0;
     while (M < (long long)n_points) M <<= 1, ++h;
     pt->T.M = M;
     pt->T.h = h;
-    // tree (2 h M) + work (8 M) + product work (8 M) + root tail (M) + a scratch inverse for a single leaf (M) + caller's
-    const size_t words = (size_t)(2 * h + 8 + 8 + 2) * (size_t)M * L + extra_words;
+    // tree (6 h M) + work (8 M) + root tail (M) + a scratch inverse for a single leaf (M) + caller's
+    const size_t words = (size_t)(kTreeLevelArrays * h + kTreeWorkArrays + 2) * (size_t)M * L + extra_words;
     if (words * sizeof(u64) > (size_t(64) << 30)) return TF_ERR_OUT_OF_MEMORY;
     hipError_t e = hipMallocAsync(reinterpret_cast<void**>(&pt->arena), words * sizeof(u64), s);
     if (e != hipSuccess) return hip_fail(e, "hipMallocAsync(zerofier tree)", __FILE__, __LINE__);
-    pt->work = pt->arena + (size_t)(2 * h) * M * L;
-    pt->pm_work = pt->work + (size_t)8 * M * L;
-    pt->root_tail = pt->pm_work + (size_t)8 * M * L;
+    pt->work = pt->arena + (size_t)(kTreeLevelArrays * h) * M * L;
+    pt->root_tail = pt->work + (size_t)kTreeWorkArrays * M * L;
     u64* leaf_inv = pt->root_tail + (size_t)M * L;
     pt->extra = leaf_inv + (size_t)M * L;
     if (h == 0) {  // one leaf: it is the root
-        hipLaunchKernelGGL(tfk::leaf_zerofier_kernel<L>, dim3(1), dim3(kTreeLeaf), 0, s, points, (long long)n_points, kTreeLeaf,
-                           pt->root_tail, leaf_inv);
+        hipLaunchKernelGGL(tfk::leaf_zerofier_kernel<L>, dim3(1), dim3(kTreeLeaf), 2 * kTreeLeaf * L * sizeof(u64), s, points, (long long)n_points,
+                           kTreeLeaf, pt->root_tail, leaf_inv);
         HIPCHK(hipGetLastError());
         return TF_OK;
     }
-    int rc = zerofier_tree_build<L>(points, (long long)n_points, &pt->T, pt->arena, pt->pm_work, s);
+    DeviceCtx* ctx = nullptr;
+    int rc = current_ctx(&ctx);
     if (rc) return rc;
-    const long long d = M / 2;  // the two nodes of level h - 1
-    u64* P = pt->work;
-    rc = poly_mul_dev(pt->T.tails[h - 1], (size_t)d, pt->T.tails[h - 1] + d * L, (size_t)d, P, 1, L, s, 0, 0, pt->pm_work);
+    rc = zerofier_tree_build<L>(ctx, points, (long long)n_points, &pt->T, pt->arena, s);
     if (rc) return rc;
-    return launch_1d<L>(tfk::zerofier_combine_kernel<L>, 2 * d, s, (const u64*)P, (const u64*)pt->T.tails[h - 1], pt->root_tail, d, (long long)1);
+    // the root from the transforms of the two nodes of level h - 1 (d = M / 2, order M)
+    const long long d = M / 2;
+    rc = launch_1d<L>(tfk::zerofier_pointwise_kernel<L>, 2 * d, s, (const u64*)pt->T.That[h - 1], pt->root_tail, d, (long long)1);
+    if (!rc) rc = run_ntt(ctx, pt->root_tail, pt->root_tail, 2 * d * L, 2 * d * L, (size_t)(2 * d), 1, L, true, nullptr, -1, s);
+    return rc;
 }
 
 int padded_tree_free(PaddedTree* pt, hipStream_t s, int rc) {
@@ -2146,15 +2184,14 @@ int zerofier_dev(const u64* roots, size_t n_roots, u64* out, int L, void* stream
 
 template <int L>
 int interpolate_dev_t(const u64* domain, const u64* values, size_t n, size_t rows, u64* out, hipStream_t s) {
-    constexpr int kTreeLeaf = tree_leaf(L);
+    const int kTreeLeaf = tree_leaf(L);
     long long M = kTreeLeaf;
     while (M < (long long)n) M <<= 1;
     const size_t ML = (size_t)M * L;
     // rows go up the tree in slabs: targets, two interpolant levels and the children's transforms (2 M) per row
     const size_t slab = std::max<size_t>(1, std::min<size_t>(std::min<size_t>(rows, 32768), (size_t(1) << 26) / ML));
-    // behind the tree: derivative (M), its values (M), inverse weights (M), transforms of a level's tails (2 M),
-    // slab x (targets, N ping, N pong, transforms 2 M), flag
-    const size_t extra = (5 + 5 * slab) * ML + 2;
+    // behind the tree: derivative (M), its values (M), inverse weights (M), slab x (targets, N ping, N pong, transforms 2 M), flag
+    const size_t extra = (3 + 5 * slab) * ML + 2;
     PaddedTree pt;
     int rc = padded_tree_build<L>(domain, n, extra, &pt, s);
     if (rc) return padded_tree_free(&pt, s, rc);
@@ -2164,15 +2201,14 @@ int interpolate_dev_t(const u64* domain, const u64* values, size_t n, size_t row
     u64* deriv = pt.extra;
     u64* dz = deriv + ML;
     u64* winv = dz + ML;
-    u64* Th = winv + ML;
-    u64* targets = Th + 2 * ML;
+    u64* targets = winv + ML;
     u64* na = targets + slab * ML;
     u64* nb = na + slab * ML;
     u64* Nh = nb + slab * ML;
     int* flag = reinterpret_cast<int*>(Nh + 2 * slab * ML);
     const int h = pt.T.h;
     if (!rc) rc = launch_1d<L>(tfk::zerofier_derivative_kernel<L>, M, s, (const u64*)pt.root_tail, M, (long long)n, deriv);
-    if (!rc) rc = zerofier_tree_evaluate<L>(pt.T, deriv, domain, (long long)n, dz, pt.work, pt.pm_work, s);
+    if (!rc) rc = zerofier_tree_evaluate<L>(ctx, pt.T, deriv, domain, (long long)n, dz, pt.work, s);
     if (!rc) {
         hipError_t e = hipMemsetAsync(flag, 0, sizeof(int), s);
         if (e != hipSuccess) rc = hip_fail(e, "hipMemsetAsync", __FILE__, __LINE__);
@@ -2189,8 +2225,8 @@ int interpolate_dev_t(const u64* domain, const u64* values, size_t n, size_t row
         const size_t nr = std::min(slab, rows - r0);
         hipLaunchKernelGGL(tfk::interpolation_targets_kernel<L>, dim3((unsigned)((M + 255) / 256), (unsigned)nr), dim3(256), 0, s,
                            values + r0 * n * L, (const u64*)winv, (long long)n, M, targets);
-        hipLaunchKernelGGL(tfk::leaf_interpolant_kernel<L>, dim3((unsigned)(M / kTreeLeaf), (unsigned)nr), dim3(kTreeLeaf), 0, s, domain,
-                           (const u64*)targets, (long long)n, kTreeLeaf, M, na);
+        hipLaunchKernelGGL(tfk::leaf_interpolant_kernel<L>, dim3((unsigned)(M / kTreeLeaf), (unsigned)nr), dim3(kTreeLeaf),
+                           2 * kTreeLeaf * L * sizeof(u64), s, domain, (const u64*)targets, (long long)n, kTreeLeaf, M, na);
         HIPCHK(hipGetLastError());
         u64* cur = na;
         u64* nxt = nb;
@@ -2198,9 +2234,9 @@ int interpolate_dev_t(const u64* domain, const u64* values, size_t n, size_t row
             // one level for all rows of the slab: transforms of order 2d of every child's tail (shared) and interpolant, the
             // combination N_left Z_right + N_right Z_left pointwise, one inverse transform -- which lands in the next level's layout
             const long long d = (long long)kTreeLeaf << l, children = M / d, parents = children / 2;
-            rc = run_ntt(ctx, pt.T.tails[l], Th, d * L, 2 * d * L, (size_t)(2 * d), (size_t)children, L, false, nullptr, d, s);
-            if (!rc) rc = run_ntt(ctx, cur, Nh, d * L, 2 * d * L, (size_t)(2 * d), (size_t)(children * (long long)nr), L, false, nullptr, d, s);
-            if (!rc) rc = launch_1d<L>(tfk::interpolant_pointwise_kernel<L>, (long long)nr * parents * 2 * d, s, (const u64*)Nh, (const u64*)Th, nxt, d,
+            const u64* Th = pt.T.That[l];
+            rc = run_ntt(ctx, cur, Nh, d * L, 2 * d * L, (size_t)(2 * d), (size_t)(children * (long long)nr), L, false, nullptr, d, s);
+            if (!rc) rc = launch_1d<L>(tfk::interpolant_pointwise_kernel<L>, (long long)nr * parents * 2 * d, s, (const u64*)Nh, Th, nxt, d,
                                        parents, (long long)nr);
             if (!rc) rc = run_ntt(ctx, nxt, nxt, 2 * d * L, 2 * d * L, (size_t)(2 * d), (size_t)(parents * (long long)nr), L, true, nullptr, -1, s);
             std::swap(cur, nxt);
