@@ -433,7 +433,7 @@ def test_both_launch_geometries_match_oracle(tf, oracle, mode, width, log_n, bat
                                        (3, 1000, 777), (3, 2048, 2048), (3, 300, 512), (3, 5000, 1100)])
 def test_zerofier_tree_batch_evaluate_matches_horner_and_oracle(tf, oracle, width, n, m):
     """SURVEY 8(f4) at the reference's complexity (math/polynomial.rs:1840-1894, math/zerofier_tree.rs): the zerofier-tree route
-    of tf_poly_batch_evaluate_* -- leaves of 1024 (BFE) / 256 (XFE) points, remainders by power-series inverses, chunks when the polynomial is
+    of tf_poly_batch_evaluate_* -- leaves of 256 (BFE) / 128 (XFE) points, levels in the transform domain, remainders by power-series inverses, chunks when the polynomial is
     longer than the padded point count -- returns the same words as the Horner route and as the oracle's Horner; point counts
     that are not powers of two, polynomials shorter and longer than the point count, duplicate and zero points."""
     import torch
