@@ -206,6 +206,30 @@ int tf_coset_interpolate_xfe_xoffset_dev(const uint64_t *d_values, size_t n, con
  * reference's batch_inversion.  na == 0 (zero dividend): TF_OK, nothing written.  The _dev call synchronises its stream once. */
 int tf_poly_clean_divide_bfe(const uint64_t *a, size_t na, const uint64_t *b, size_t nb, uint64_t *out);
 int tf_poly_clean_divide_bfe_dev(const uint64_t *d_a, size_t na, const uint64_t *d_b, size_t nb, uint64_t *d_out, void *stream);
+/* ZerofierTree  math/zerofier_tree.rs (new_from_domain :66-87, zerofier :93-99) with Polynomial::divide_and_conquer_batch_evaluate
+ * math/polynomial.rs:1882-1894: the tree of a domain built ONCE and kept in HBM (levels, the cached level transforms, the root,
+ * the domain, and after the first interpolation the inverse weights), for callers that evaluate or interpolate on the same
+ * points many times -- the build is 1.4 walks, and an interpolation over a prepared tree is one walk up.  A handle belongs to the
+ * device that was current when it was made; every call brings its own stream-ordered work space, so one handle serves concurrent
+ * calls on different streams.  An empty domain gives the empty tree (zerofier 1, no values; :136-138).
+ * tf_zerofier_tree_new_*: domain of n points (host pointer; _dev: device pointer, the call synchronises `stream` before returning).
+ * tf_zerofier_tree_zerofier*: n + 1 coefficients.   tf_zerofier_tree_batch_evaluate*: `batch` polynomials of n_coeffs packed
+ * coefficients -> out[(b * n + i) * width] = f_b(domain[i]).   tf_zerofier_tree_interpolate*: `rows` value rows -> rows * n
+ * coefficients (errors as tf_poly_interpolate_*; the first call computes the weights and synchronises its stream once). */
+typedef struct tf_zerofier_tree tf_zerofier_tree;
+int tf_zerofier_tree_new_bfe(const uint64_t *domain, size_t n_points, tf_zerofier_tree **tree);
+int tf_zerofier_tree_new_xfe(const uint64_t *domain, size_t n_points, tf_zerofier_tree **tree);
+int tf_zerofier_tree_new_bfe_dev(const uint64_t *d_domain, size_t n_points, void *stream, tf_zerofier_tree **tree);
+int tf_zerofier_tree_new_xfe_dev(const uint64_t *d_domain, size_t n_points, void *stream, tf_zerofier_tree **tree);
+void tf_zerofier_tree_free(tf_zerofier_tree *tree);
+size_t tf_zerofier_tree_num_points(const tf_zerofier_tree *tree);
+int tf_zerofier_tree_width(const tf_zerofier_tree *tree);   /* 1 = BFieldElement, 3 = XFieldElement */
+int tf_zerofier_tree_zerofier(const tf_zerofier_tree *tree, uint64_t *out);
+int tf_zerofier_tree_batch_evaluate(const tf_zerofier_tree *tree, const uint64_t *coeffs, size_t n_coeffs, size_t batch, uint64_t *out);
+int tf_zerofier_tree_interpolate(tf_zerofier_tree *tree, const uint64_t *values, size_t rows, uint64_t *out);
+int tf_zerofier_tree_zerofier_dev(const tf_zerofier_tree *tree, uint64_t *d_out, void *stream);
+int tf_zerofier_tree_batch_evaluate_dev(const tf_zerofier_tree *tree, const uint64_t *d_coeffs, size_t n_coeffs, size_t batch, uint64_t *d_out, void *stream);
+int tf_zerofier_tree_interpolate_dev(tf_zerofier_tree *tree, const uint64_t *d_values, size_t rows, uint64_t *d_out, void *stream);
 /* Route of the batch evaluation (test / A-B hook): 0 = automatic (zerofier tree for many points on a long polynomial, Horner
  * otherwise), 1 = always Horner, 2 = the zerofier tree whenever it applies (at least two leaves: 512 points over BFE, 256 over XFE).  Same values either way. */
 void tf_set_batch_eval_route(int route);

@@ -740,3 +740,88 @@ def test_extension_field_offset_panics(tf, oracle):
     assert e.value.code == 12
     with pytest.raises(TypeError):
         tf.fast_coset_evaluate(oracle.fill_random(16, 7), off, 16, width=1)  # BFieldElement * XFieldElement is not a BFieldElement
+
+
+# ---- a zerofier tree kept across calls (math/zerofier_tree.rs) ----------------------------------------------------------------
+@pytest.mark.parametrize("width,n", [(1, 0), (1, 1), (1, 100), (1, 256), (1, 700), (1, 5000), (3, 1), (3, 128), (3, 300), (3, 2100)])
+def test_zerofier_tree_handle_matches_the_one_shot_calls(tf, oracle, width, n):
+    """ZerofierTree::new_from_domain + zerofier (zerofier_tree.rs:66-99) and divide_and_conquer_batch_evaluate
+    (polynomial.rs:1882-1894) over a tree kept in HBM: the same words as the one-shot entry points and as the oracle; the tree can be
+    empty (:136-138); interpolation over the prepared tree equals Polynomial::interpolate; repeated use gives the same result."""
+    d = _distinct_points(oracle, n, width, 1900 + n)
+    with tf.ZerofierTree.new_from_domain(d, width=width) as tree:
+        assert tree.num_points == n
+        z = tree.zerofier()
+        assert np.array_equal(z.coefficients, tf.Polynomial(oracle.zerofier(d, width), width=width).coefficients)
+        for n_coeffs in (0, 1, 5, max(n // 2, 1), n + 3, 3 * n + 1):
+            f = tf.Polynomial(oracle.fill_random(n_coeffs * width, 1901 + n_coeffs), width=width)
+            got = tree.batch_evaluate(f)
+            if n:
+                assert np.array_equal(got, f.batch_evaluate(d))
+                for i in (0, n // 2, n - 1):
+                    want = oracle.poly_eval(f.coefficients, int(d[i])) if width == 1 else oracle.poly_eval_xfe_point(f.coefficients, d[3 * i: 3 * i + 3])
+                    assert np.array_equal(got[i * width:(i + 1) * width], np.asarray(want).reshape(-1))
+            else:
+                assert got.size == 0
+        if n == 0:
+            with pytest.raises(tf.NttPanic) as e:
+                tree.interpolate([np.zeros(0, dtype=np.uint64)])
+            assert e.value.code == 14
+            return
+        vals = [oracle.fill_random(n * width, 1902 + r) for r in range(3)]
+        for attempt in range(2):  # the second pass reuses the cached weights
+            polys = tree.interpolate(vals)
+            for r in range(3):
+                assert np.array_equal(polys[r].coefficients, tf.Polynomial.interpolate(d, vals[r], width=width).coefficients)
+        if n <= 700:
+            assert np.array_equal(polys[0].coefficients, tf.Polynomial(oracle.lagrange_interpolate(d, vals[0], width), width=width).coefficients)
+
+
+def test_zerofier_tree_handle_on_device_buffers_and_errors(tf, oracle):
+    import ctypes as C
+
+    import torch
+
+    n, rows = 1 << 14, 4
+    dom = torch.empty(n, dtype=torch.int64, device="cuda")
+    tf.device.fill_random(dom, 31)
+    side = torch.cuda.Stream()
+    with tf.device.ZerofierTree(dom) as tree:
+        f = torch.empty(2 * n, dtype=torch.int64, device="cuda")       # two polynomials of n coefficients
+        tf.device.fill_random(f, 32)
+        vals = torch.empty(2 * n, dtype=torch.int64, device="cuda")
+        tree.batch_evaluate(f, n, vals, batch=2)
+        one = torch.empty(n, dtype=torch.int64, device="cuda")
+        tf.device.batch_evaluate(f[n:], n, dom, one)
+        torch.cuda.synchronize()
+        assert torch.equal(vals[n:], one)
+        back = torch.empty(2 * n, dtype=torch.int64, device="cuda")
+        with torch.cuda.stream(side):                                   # a second stream on the same handle
+            tree.interpolate(vals, back, rows=2, stream=side)
+        z = torch.empty(n + 1, dtype=torch.int64, device="cuda")
+        tree.zerofier(z)
+        torch.cuda.synchronize()
+        assert torch.equal(back, f)
+        zz = torch.empty(n + 1, dtype=torch.int64, device="cuda")
+        tf.device.zerofier(dom, zz)
+        torch.cuda.synchronize()
+        assert torch.equal(z, zz)
+        with pytest.raises(ValueError):
+            tree.batch_evaluate(f, n, vals[:n], batch=2)
+    # a repeated point: the tree builds (a zerofier may have repeated roots), the interpolation panics
+    d = oracle.fill_random(600, 33)
+    d[599] = d[7]
+    with tf.ZerofierTree(d) as tree:
+        assert tree.zerofier().degree() == 600
+        with pytest.raises(tf.NttPanic) as e:
+            tree.interpolate([oracle.fill_random(600, 34)])
+        assert e.value.code == 12
+    lib = tf.lib()
+    assert lib.tf_zerofier_tree_num_points(C.c_void_p(0)) == 0 and lib.tf_zerofier_tree_width(C.c_void_p(0)) == 0
+    assert lib.tf_zerofier_tree_zerofier(C.c_void_p(0), C.c_void_p(0)) == 7
+    lib.tf_zerofier_tree_free(C.c_void_p(0))  # freeing nothing is fine
+    closed = tf.ZerofierTree(oracle.fill_random(10, 35))
+    closed.close()
+    closed.close()
+    with pytest.raises(ValueError):
+        closed.zerofier()

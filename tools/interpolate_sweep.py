@@ -41,6 +41,11 @@ for log_n in range(8, max_log + 1, 2):
     t_z = timed(lambda: tf.device.zerofier(dom, z, width=width), reps)
     t_1 = timed(lambda: tf.device.interpolate(dom, vals[: n * width], one, rows=1, width=width), reps)
     t_8 = timed(lambda: tf.device.interpolate(dom, vals, many, rows=rows, width=width), reps)
+    with tf.device.ZerofierTree(dom, width=width) as tree:   # the tree kept across calls: evaluation and interpolation per use
+        ev = torch.empty(n * width, dtype=torch.int64, device=dev)
+        t_he = timed(lambda: tree.batch_evaluate(one, n, ev), reps)
+        t_h1 = timed(lambda: tree.interpolate(vals[: n * width], one, rows=1), reps)
+        t_h8 = timed(lambda: tree.interpolate(vals, many, rows=rows), reps)
     back = torch.empty(n * width, dtype=torch.int64, device=dev)
     tf.device.batch_evaluate(many[(rows - 1) * n * width:], n, dom, back, width=width)
     ok = torch.equal(back, vals[(rows - 1) * n * width:]) and torch.equal(many[: n * width], one)
@@ -51,4 +56,5 @@ for log_n in range(8, max_log + 1, 2):
         want = tfo.lagrange_interpolate(d_h, v_h, width)
         cpu = f"   host lagrange (1 thread) {1e3 * (time.perf_counter() - t0):9.1f} ms, {'same words' if np.array_equal(want, one.cpu().numpy().view(np.uint64)) else 'MISMATCH'}"
     print(f"width {width} n 2^{log_n}: zerofier {t_z:8.3f} ms   interpolate {t_1:8.3f} ms   8 rows {t_8:8.3f} ms   "
+          f"| prepared tree: evaluate {t_he:7.3f}  interpolate {t_h1:7.3f}  8 rows {t_h8:7.3f} ms   "
           f"{'round trip ok' if ok else 'ROUND TRIP MISMATCH'}{cpu}", flush=True)

@@ -26,7 +26,7 @@ import numpy as np
 from . import _lib
 
 __all__ = [
-    "P", "BFieldElement", "ntt", "intt", "Polynomial", "fast_coset_evaluate", "fast_coset_interpolate", "fast_multiply", "fast_square", "Tip5", "Tip5Sponge", "Digest", "MerkleTree",
+    "P", "BFieldElement", "ntt", "intt", "Polynomial", "ZerofierTree", "fast_coset_evaluate", "fast_coset_interpolate", "fast_multiply", "fast_square", "Tip5", "Tip5Sponge", "Digest", "MerkleTree",
     "MerkleTreeError", "TwentyFirstError", "NttPanic", "lib", "device",
 ]
 
@@ -342,6 +342,78 @@ class Polynomial:
         if self.degree() < 0 or other.degree() < 0:
             return Polynomial(np.zeros(0, dtype=np.uint64), width=self.width)
         return Polynomial(fast_multiply(self.coefficients, other.coefficients, width=self.width), width=self.width)
+
+
+class ZerofierTree:
+    """math/zerofier_tree.rs: the tree of vanishing polynomials of a domain, built once on the device and kept there
+    (`ZerofierTree::new_from_domain` :66-87), for `Polynomial::divide_and_conquer_batch_evaluate` (polynomial.rs:1882-1894) and for
+    interpolation over the same domain.  Holds device memory: use as a context manager or call close()."""
+
+    def __init__(self, domain: np.ndarray, width: int = 1):
+        d = _words(np.ascontiguousarray(domain, dtype=np.uint64).reshape(-1), "domain")
+        if width not in (1, 3) or d.size % width:
+            raise ValueError("domain size is not n * width")
+        self.width = width
+        self.num_points = d.size // width
+        self._h = C.c_void_p(0)
+        self._free = lib().tf_zerofier_tree_free
+        fn = lib().tf_zerofier_tree_new_bfe if width == 1 else lib().tf_zerofier_tree_new_xfe
+        _check(fn(_ptr(d), self.num_points, C.byref(self._h)), "ZerofierTree::new_from_domain")
+
+    @classmethod
+    def new_from_domain(cls, domain: np.ndarray, width: int = 1) -> "ZerofierTree":
+        return cls(domain, width)
+
+    def close(self) -> None:
+        h = getattr(self, "_h", None)
+        if h is not None and h.value:
+            self._free(h)  # bound at construction: still callable while the interpreter shuts down
+            h.value = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    @property
+    def handle(self):
+        if not self._h.value:
+            raise ValueError("the tree has been closed")
+        return self._h
+
+    def zerofier(self) -> "Polynomial":
+        """:93-99"""
+        out = np.empty((self.num_points + 1) * self.width, dtype=np.uint64)
+        _check(lib().tf_zerofier_tree_zerofier(self.handle, _ptr(out)), "ZerofierTree::zerofier")
+        return Polynomial(out, width=self.width)
+
+    def batch_evaluate(self, polynomial: "Polynomial") -> np.ndarray:
+        """polynomial.divide_and_conquer_batch_evaluate(&tree) (polynomial.rs:1882-1894): the values on the tree's domain."""
+        if polynomial.width != self.width:
+            raise TypeError("the polynomial and the tree are over different fields")
+        out = np.zeros(self.num_points * self.width, dtype=np.uint64)
+        c = polynomial.coefficients
+        _check(lib().tf_zerofier_tree_batch_evaluate(self.handle, _ptr(c), c.size // self.width, 1, _ptr(out)), "divide_and_conquer_batch_evaluate")
+        return out
+
+    def interpolate(self, values_matrix) -> list:
+        """One interpolant per value row over the tree's domain (the memoised form of batch_fast_interpolate, polynomial.rs:1703-1838)."""
+        n, w = self.num_points, self.width
+        if n == 0:
+            raise NttPanic(14, "interpolate")
+        rows = [np.ascontiguousarray(v, dtype=np.uint64).reshape(-1) for v in values_matrix]
+        for v in rows:
+            if v.size != n * w:
+                raise NttPanic(14, "interpolate: the domain and values lists have to be of equal length")
+        if not rows:
+            return []
+        vals = np.ascontiguousarray(np.concatenate(rows))
+        out = np.empty(len(rows) * n * w, dtype=np.uint64)
+        _check(lib().tf_zerofier_tree_interpolate(self.handle, _ptr(vals), len(rows), _ptr(out)), "interpolate")
+        return [Polynomial(out[i * n * w:(i + 1) * n * w], width=w) for i in range(len(rows))]
 
 
 # ----------------------------------------------------------------------------- Tip5

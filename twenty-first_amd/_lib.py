@@ -67,6 +67,19 @@ SIGNATURES = {
     "tf_coset_interpolate_xfe_xoffset_dev": (C.c_int, [_vp, _sz, _vp, _vp, _sz, _vp]),
     "tf_poly_clean_divide_bfe": (C.c_int, [_vp, _sz, _vp, _sz, _vp]),
     "tf_poly_clean_divide_bfe_dev": (C.c_int, [_vp, _sz, _vp, _sz, _vp, _vp]),
+    "tf_zerofier_tree_new_bfe": (C.c_int, [_vp, _sz, C.POINTER(C.c_void_p)]),
+    "tf_zerofier_tree_new_xfe": (C.c_int, [_vp, _sz, C.POINTER(C.c_void_p)]),
+    "tf_zerofier_tree_new_bfe_dev": (C.c_int, [_vp, _sz, _vp, C.POINTER(C.c_void_p)]),
+    "tf_zerofier_tree_new_xfe_dev": (C.c_int, [_vp, _sz, _vp, C.POINTER(C.c_void_p)]),
+    "tf_zerofier_tree_free": (None, [_vp]),
+    "tf_zerofier_tree_num_points": (_sz, [_vp]),
+    "tf_zerofier_tree_width": (C.c_int, [_vp]),
+    "tf_zerofier_tree_zerofier": (C.c_int, [_vp, _vp]),
+    "tf_zerofier_tree_batch_evaluate": (C.c_int, [_vp, _vp, _sz, _sz, _vp]),
+    "tf_zerofier_tree_interpolate": (C.c_int, [_vp, _vp, _sz, _vp]),
+    "tf_zerofier_tree_zerofier_dev": (C.c_int, [_vp, _vp, _vp]),
+    "tf_zerofier_tree_batch_evaluate_dev": (C.c_int, [_vp, _vp, _sz, _sz, _vp, _vp]),
+    "tf_zerofier_tree_interpolate_dev": (C.c_int, [_vp, _vp, _sz, _vp, _vp]),
     "tf_poly_zerofier_bfe": (C.c_int, [_vp, _sz, _vp]),
     "tf_poly_zerofier_xfe": (C.c_int, [_vp, _sz, _vp]),
     "tf_poly_zerofier_bfe_dev": (C.c_int, [_vp, _sz, _vp, _vp]),

@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <set>
 #include <string>
@@ -1911,8 +1912,8 @@ int inverse_of_product(DeviceCtx* ctx, const u64* a_hat, const u64* b_hat, long 
 }
 
 template <int L>
-int zerofier_tree_build(DeviceCtx* ctx, const u64* points, long long n_points, ZerofierTree* T, u64* arena, hipStream_t s) {
-    // arena: kTreeLevelArrays * h level arrays of M * L words, then kTreeWorkArrays * M * L words of work space
+int zerofier_tree_build(DeviceCtx* ctx, const u64* points, long long n_points, ZerofierTree* T, u64* arena, u64* work, hipStream_t s) {
+    // arena: kTreeLevelArrays * h level arrays of M * L words (they stay); work: kTreeWorkArrays * M * L words (only during the build)
     const long long M = T->M;
     const int h = T->h;
     T->tails.resize(h);
@@ -1926,7 +1927,6 @@ int zerofier_tree_build(DeviceCtx* ctx, const u64* points, long long n_points, Z
         T->That[l] = base + 2 * M * L;
         T->Ghat[l] = base + 4 * M * L;
     }
-    u64* work = arena + (long long)(kTreeLevelArrays * h) * M * L;
     if (h == 0) return TF_OK;
     const int kTreeLeaf = tree_leaf(L);
     hipLaunchKernelGGL(tfk::leaf_zerofier_kernel<L>, dim3((unsigned)(M / kTreeLeaf)), dim3(kTreeLeaf), 2 * kTreeLeaf * L * sizeof(u64), s, points,
@@ -2029,6 +2029,38 @@ bool tree_route(size_t n_coeffs, size_t n_points, size_t batch, int L) {
     return tree_ms < 0.9 * horner_ms;
 }
 
+// `batch` polynomials down an existing tree (levels >= 1): work space, one padded unit and the chunk values are this call's own
+// stream-ordered temporaries, so one tree serves concurrent calls.
+template <int L>
+int tree_batch_evaluate(DeviceCtx* ctx, const ZerofierTree& T, const u64* points, size_t n_points, const u64* coeffs, size_t n_coeffs,
+                        size_t poly_stride, size_t batch, u64* out, hipStream_t s) {
+    const long long M = T.M;
+    const size_t chunks = std::max<size_t>(1, (n_coeffs + (size_t)M - 1) / (size_t)M);
+    const size_t words = (size_t)(kTreeWorkArrays + 1 + chunks) * (size_t)M * L;
+    u64* tmp = nullptr;
+    hipError_t e = hipMallocAsync(reinterpret_cast<void**>(&tmp), words * sizeof(u64), s);
+    if (e != hipSuccess) return hip_fail(e, "hipMallocAsync(zerofier tree walk)", __FILE__, __LINE__);
+    u64* work = tmp;
+    u64* unit = work + (size_t)kTreeWorkArrays * M * L;
+    u64* vals = unit + (size_t)M * L;
+    int rc = TF_OK;
+    for (size_t b = 0; b < batch && !rc; ++b) {
+        for (size_t c = 0; c < chunks && !rc; ++c) {
+            const size_t len = n_coeffs > c * (size_t)M ? std::min<size_t>((size_t)M, n_coeffs - c * (size_t)M) : 0;
+            rc = pad_copy(coeffs + b * poly_stride + c * (size_t)M * L, unit, (long long)(len * L), (long long)M * L, 1, s);
+            if (!rc) rc = zerofier_tree_evaluate<L>(ctx, T, unit, points, (long long)n_points, vals + c * (size_t)M * L, work, s);
+        }
+        int log_m = 0;
+        while ((1ll << log_m) < M) ++log_m;
+        if (!rc) rc = launch_1d<L>(tfk::chunk_combine_kernel<L>, (long long)n_points, s, (const u64*)vals, M, (int)chunks, points,
+                                   (long long)n_points, log_m, out + b * n_points * L);
+    }
+    hipError_t e2 = hipFreeAsync(tmp, s);
+    if (rc) return rc;
+    if (e2 != hipSuccess) return hip_fail(e2, "hipFreeAsync", __FILE__, __LINE__);
+    return TF_OK;
+}
+
 template <int L>
 int batch_evaluate_tree_t(const u64* coeffs, size_t n_coeffs, size_t poly_stride, size_t batch, const u64* points, size_t n_points,
                           u64* out, hipStream_t s) {
@@ -2039,28 +2071,16 @@ int batch_evaluate_tree_t(const u64* coeffs, size_t n_coeffs, size_t poly_stride
     while (M < (long long)n_points) M <<= 1, ++h;
     T.M = M;
     T.h = h;
-    const size_t chunks = (n_coeffs + (size_t)M - 1) / (size_t)M;
-    // arena: tree (6 h M) + build / walk work (8 M) + one padded unit (M) + values of the chunks of one polynomial (chunks * M)
-    const size_t words = (size_t)(kTreeLevelArrays * h + kTreeWorkArrays + 1 + chunks) * (size_t)M * L;
+    // the tree (6 h M) and the build's work space (8 M); the walks bring their own
+    const size_t words = (size_t)(kTreeLevelArrays * h + kTreeWorkArrays) * (size_t)M * L;
     u64* arena = nullptr;
     DeviceCtx* ctx = nullptr;
     int rc = current_ctx(&ctx);
     if (rc) return rc;
     hipError_t e = hipMallocAsync(reinterpret_cast<void**>(&arena), words * sizeof(u64), s);
     if (e != hipSuccess) return hip_fail(e, "hipMallocAsync(zerofier tree)", __FILE__, __LINE__);
-    u64* work = arena + (size_t)(kTreeLevelArrays * h) * M * L;
-    u64* unit = work + (size_t)kTreeWorkArrays * M * L;
-    u64* vals = unit + (size_t)M * L;
-    rc = zerofier_tree_build<L>(ctx, points, (long long)n_points, &T, arena, s);
-    for (size_t b = 0; b < batch && !rc; ++b) {
-        for (size_t c = 0; c < chunks && !rc; ++c) {
-            const size_t len = std::min<size_t>((size_t)M, n_coeffs - c * (size_t)M);
-            rc = pad_copy(coeffs + b * poly_stride + c * (size_t)M * L, unit, (long long)(len * L), (long long)M * L, 1, s);
-            if (!rc) rc = zerofier_tree_evaluate<L>(ctx, T, unit, points, (long long)n_points, vals + c * (size_t)M * L, work, s);
-        }
-        if (!rc) rc = launch_1d<L>(tfk::chunk_combine_kernel<L>, (long long)n_points, s, (const u64*)vals, M, (int)chunks, points,
-                                   (long long)n_points, h + tree_leaf_log(L) /* log2 M */, out + b * n_points * L);
-    }
+    rc = zerofier_tree_build<L>(ctx, points, (long long)n_points, &T, arena, arena + (size_t)(kTreeLevelArrays * h) * M * L, s);
+    if (!rc) rc = tree_batch_evaluate<L>(ctx, T, points, n_points, coeffs, n_coeffs, poly_stride, batch, out, s);
     hipError_t e2 = hipFreeAsync(arena, s);
     if (rc) return rc;
     if (e2 != hipSuccess) return hip_fail(e2, "hipFreeAsync", __FILE__, __LINE__);
@@ -2073,6 +2093,8 @@ int batch_evaluate_tree_t(const u64* coeffs, size_t n_coeffs, size_t poly_stride
 // lane per point for short polynomials, workgroup per (point, polynomial) with a 256-way split of the coefficients
 // otherwise.  `batch` polynomials of n_coeffs coefficients (poly_stride words apart) share the points;
 // out[(b * n_points + i) * L ..] = f_b(points[i]).
+int batch_evaluate_horner(const u64* coeffs, size_t n_coeffs, size_t poly_stride, size_t batch, const u64* points, size_t n_points, u64* out,
+                          int L, void* stream);
 int batch_evaluate_dev(const u64* coeffs, size_t n_coeffs, size_t poly_stride, size_t batch, const u64* points, size_t n_points,
                        u64* out, int L, void* stream) {
     if (n_points == 0 || batch == 0) return TF_OK;
@@ -2085,6 +2107,13 @@ int batch_evaluate_dev(const u64* coeffs, size_t n_coeffs, size_t poly_stride, s
         return L == 1 ? batch_evaluate_tree_t<1>(coeffs, n_coeffs, poly_stride, batch, points, n_points, out, s)
                       : batch_evaluate_tree_t<3>(coeffs, n_coeffs, poly_stride, batch, points, n_points, out, s);
     }
+    return batch_evaluate_horner(coeffs, n_coeffs, poly_stride, batch, points, n_points, out, L, stream);
+}
+
+int batch_evaluate_horner(const u64* coeffs, size_t n_coeffs, size_t poly_stride, size_t batch, const u64* points, size_t n_points, u64* out,
+                          int L, void* stream) {
+    if (n_points == 0 || batch == 0) return TF_OK;
+    hipStream_t s = static_cast<hipStream_t>(stream);
     const bool split = n_coeffs >= 1024 && n_points < (size_t(1) << 31);
     // grid.y is limited to 65535: walk the batch in slabs
     for (size_t b0 = 0; b0 < batch; b0 += 65535) {
@@ -2116,27 +2145,36 @@ int batch_evaluate_dev(const u64* coeffs, size_t n_coeffs, size_t poly_stride, s
 // reference's batch_fast_interpolate memoises in its two dictionaries, :1723-1731).
 struct PaddedTree {
     ZerofierTree T;
-    u64* arena = nullptr;     // tree levels + work
-    u64* work = nullptr;      // 8 M L words
+    size_t n = 0;             // real points
+    bool persistent = false;  // hipMalloc'ed (a caller's handle) instead of a stream-ordered temporary
+    u64* arena = nullptr;     // tree levels, root tail, leaf scratch, caller's extra
     u64* root_tail = nullptr; // M L words: x^M + root_tail = prod (x - p_i) * x^(M - n)
     u64* extra = nullptr;     // caller's space behind the tree
 };
 
+// Builds the padded tree of `points` (levels, root).  The build's work space is a temporary of the build alone.
 template <int L>
-int padded_tree_build(const u64* points, size_t n_points, size_t extra_words, PaddedTree* pt, hipStream_t s) {
+int padded_tree_build(const u64* points, size_t n_points, size_t extra_words, PaddedTree* pt, hipStream_t s, bool persistent = false) {
     const int kTreeLeaf = tree_leaf(L);
     long long M = kTreeLeaf;
     int h = 0;
     while (M < (long long)n_points) M <<= 1, ++h;
     pt->T.M = M;
     pt->T.h = h;
-    // tree (6 h M) + work (8 M) + root tail (M) + a scratch inverse for a single leaf (M) + caller's
-    const size_t words = (size_t)(kTreeLevelArrays * h + kTreeWorkArrays + 2) * (size_t)M * L + extra_words;
-    if (words * sizeof(u64) > (size_t(64) << 30)) return TF_ERR_OUT_OF_MEMORY;
-    hipError_t e = hipMallocAsync(reinterpret_cast<void**>(&pt->arena), words * sizeof(u64), s);
-    if (e != hipSuccess) return hip_fail(e, "hipMallocAsync(zerofier tree)", __FILE__, __LINE__);
-    pt->work = pt->arena + (size_t)(kTreeLevelArrays * h) * M * L;
-    pt->root_tail = pt->work + (size_t)kTreeWorkArrays * M * L;
+    pt->n = n_points;
+    pt->persistent = persistent;
+    // tree (6 h M) + root tail (M) + a scratch inverse for a single leaf (M) + caller's
+    const size_t words = (size_t)(kTreeLevelArrays * h + 2) * (size_t)M * L + extra_words;
+    const size_t work_words = (size_t)kTreeWorkArrays * (size_t)M * L;
+    if ((words + work_words) * sizeof(u64) > (size_t(64) << 30)) return TF_ERR_OUT_OF_MEMORY;
+    hipError_t e = persistent ? hipMalloc(reinterpret_cast<void**>(&pt->arena), words * sizeof(u64))
+                              : hipMallocAsync(reinterpret_cast<void**>(&pt->arena), words * sizeof(u64), s);
+    if (e != hipSuccess) {
+        pt->arena = nullptr;
+        (void)hipGetLastError();
+        return e == hipErrorOutOfMemory ? TF_ERR_OUT_OF_MEMORY : hip_fail(e, "hipMalloc(zerofier tree)", __FILE__, __LINE__);
+    }
+    pt->root_tail = pt->arena + (size_t)(kTreeLevelArrays * h) * M * L;
     u64* leaf_inv = pt->root_tail + (size_t)M * L;
     pt->extra = leaf_inv + (size_t)M * L;
     if (h == 0) {  // one leaf: it is the root
@@ -2148,19 +2186,25 @@ int padded_tree_build(const u64* points, size_t n_points, size_t extra_words, Pa
     DeviceCtx* ctx = nullptr;
     int rc = current_ctx(&ctx);
     if (rc) return rc;
-    rc = zerofier_tree_build<L>(ctx, points, (long long)n_points, &pt->T, pt->arena, s);
-    if (rc) return rc;
+    u64* work = nullptr;
+    e = hipMallocAsync(reinterpret_cast<void**>(&work), work_words * sizeof(u64), s);
+    if (e != hipSuccess) return hip_fail(e, "hipMallocAsync(zerofier tree build)", __FILE__, __LINE__);
+    rc = zerofier_tree_build<L>(ctx, points, (long long)n_points, &pt->T, pt->arena, work, s);
     // the root from the transforms of the two nodes of level h - 1 (d = M / 2, order M)
     const long long d = M / 2;
-    rc = launch_1d<L>(tfk::zerofier_pointwise_kernel<L>, 2 * d, s, (const u64*)pt->T.That[h - 1], pt->root_tail, d, (long long)1);
+    if (!rc) rc = launch_1d<L>(tfk::zerofier_pointwise_kernel<L>, 2 * d, s, (const u64*)pt->T.That[h - 1], pt->root_tail, d, (long long)1);
     if (!rc) rc = run_ntt(ctx, pt->root_tail, pt->root_tail, 2 * d * L, 2 * d * L, (size_t)(2 * d), 1, L, true, nullptr, -1, s);
+    hipError_t e2 = hipFreeAsync(work, s);
+    if (!rc && e2 != hipSuccess) rc = hip_fail(e2, "hipFreeAsync", __FILE__, __LINE__);
     return rc;
 }
 
 int padded_tree_free(PaddedTree* pt, hipStream_t s, int rc) {
-    hipError_t e = pt->arena ? hipFreeAsync(pt->arena, s) : hipSuccess;
+    hipError_t e = hipSuccess;
+    if (pt->arena) e = pt->persistent ? hipFree(pt->arena) : hipFreeAsync(pt->arena, s);
+    pt->arena = nullptr;
     if (rc) return rc;
-    if (e != hipSuccess) return hip_fail(e, "hipFreeAsync", __FILE__, __LINE__);
+    if (e != hipSuccess) return hip_fail(e, "hipFree(zerofier tree)", __FILE__, __LINE__);
     return TF_OK;
 }
 
@@ -2182,71 +2226,98 @@ int zerofier_dev(const u64* roots, size_t n_roots, u64* out, int L, void* stream
     return L == 1 ? zerofier_dev_t<1>(roots, n_roots, out, s) : zerofier_dev_t<3>(roots, n_roots, out, s);
 }
 
+// winv[i] = 1 / Z'(x_i), i < n (M L words are written: zero beyond n is NOT guaranteed, the consumers stop at n).  Synchronises
+// the stream once: a zero Z'(x_i) is a repeated domain point, where the reference panics (TF_ERR_INVERSE_OF_ZERO).
 template <int L>
-int interpolate_dev_t(const u64* domain, const u64* values, size_t n, size_t rows, u64* out, hipStream_t s) {
-    const int kTreeLeaf = tree_leaf(L);
-    long long M = kTreeLeaf;
-    while (M < (long long)n) M <<= 1;
-    const size_t ML = (size_t)M * L;
-    // rows go up the tree in slabs: targets, two interpolant levels and the children's transforms (2 M) per row
-    const size_t slab = std::max<size_t>(1, std::min<size_t>(std::min<size_t>(rows, 32768), (size_t(1) << 26) / ML));
-    // behind the tree: derivative (M), its values (M), inverse weights (M), slab x (targets, N ping, N pong, transforms 2 M), flag
-    const size_t extra = (3 + 5 * slab) * ML + 2;
-    PaddedTree pt;
-    int rc = padded_tree_build<L>(domain, n, extra, &pt, s);
-    if (rc) return padded_tree_free(&pt, s, rc);
-    DeviceCtx* ctx = nullptr;
-    rc = current_ctx(&ctx);
-    if (rc) return padded_tree_free(&pt, s, rc);
-    u64* deriv = pt.extra;
+int tree_inverse_weights(DeviceCtx* ctx, const PaddedTree& pt, const u64* domain, u64* winv, hipStream_t s) {
+    const long long M = pt.T.M;
+    const size_t ML = (size_t)M * L, n = pt.n;
+    u64* tmp = nullptr;  // derivative (M), its values (M), walk work (8 M), flag
+    hipError_t e = hipMallocAsync(reinterpret_cast<void**>(&tmp), ((2 + kTreeWorkArrays) * ML + 2) * sizeof(u64), s);
+    if (e != hipSuccess) return hip_fail(e, "hipMallocAsync(interpolation weights)", __FILE__, __LINE__);
+    u64* deriv = tmp;
     u64* dz = deriv + ML;
-    u64* winv = dz + ML;
-    u64* targets = winv + ML;
-    u64* na = targets + slab * ML;
-    u64* nb = na + slab * ML;
-    u64* Nh = nb + slab * ML;
-    int* flag = reinterpret_cast<int*>(Nh + 2 * slab * ML);
-    const int h = pt.T.h;
-    if (!rc) rc = launch_1d<L>(tfk::zerofier_derivative_kernel<L>, M, s, (const u64*)pt.root_tail, M, (long long)n, deriv);
-    if (!rc) rc = zerofier_tree_evaluate<L>(ctx, pt.T, deriv, domain, (long long)n, dz, pt.work, s);
+    u64* work = dz + ML;
+    int* flag = reinterpret_cast<int*>(work + (size_t)kTreeWorkArrays * ML);
+    int rc = launch_1d<L>(tfk::zerofier_derivative_kernel<L>, M, s, (const u64*)pt.root_tail, M, (long long)n, deriv);
+    if (!rc) rc = zerofier_tree_evaluate<L>(ctx, pt.T, deriv, domain, (long long)n, dz, work, s);
     if (!rc) {
-        hipError_t e = hipMemsetAsync(flag, 0, sizeof(int), s);
+        e = hipMemsetAsync(flag, 0, sizeof(int), s);
         if (e != hipSuccess) rc = hip_fail(e, "hipMemsetAsync", __FILE__, __LINE__);
     }
     if (!rc) rc = launch_1d<L>(tfk::fe_inverse_kernel<L>, (long long)n, s, (const u64*)dz, (long long)n, winv, flag);
     if (!rc) {
         int host_flag = 0;
-        hipError_t e = hipMemcpyAsync(&host_flag, flag, sizeof(int), hipMemcpyDeviceToHost, s);
+        e = hipMemcpyAsync(&host_flag, flag, sizeof(int), hipMemcpyDeviceToHost, s);
         if (e == hipSuccess) e = hipStreamSynchronize(s);
         if (e != hipSuccess) rc = hip_fail(e, "interpolate: weight check", __FILE__, __LINE__);
         else if (host_flag) rc = TF_ERR_INVERSE_OF_ZERO;  // Z'(x_i) = 0: a repeated domain point
     }
+    hipError_t e2 = hipFreeAsync(tmp, s);
+    if (!rc && e2 != hipSuccess) rc = hip_fail(e2, "hipFreeAsync", __FILE__, __LINE__);
+    return rc;
+}
+
+// The walk up: `rows` value rows -> rows x n coefficients, given the tree and the inverse weights.
+template <int L>
+int tree_interpolate_rows(DeviceCtx* ctx, const PaddedTree& pt, const u64* domain, const u64* winv, const u64* values, size_t rows, u64* out,
+                          hipStream_t s) {
+    const int kTreeLeaf = tree_leaf(L);
+    const long long M = pt.T.M;
+    const size_t ML = (size_t)M * L, n = pt.n;
+    const int h = pt.T.h;
+    // rows go up the tree in slabs: targets, two interpolant levels and the children's transforms (2 M) per row
+    const size_t slab = std::max<size_t>(1, std::min<size_t>(std::min<size_t>(rows, 32768), (size_t(1) << 26) / ML));
+    u64* tmp = nullptr;
+    hipError_t e = hipMallocAsync(reinterpret_cast<void**>(&tmp), 5 * slab * ML * sizeof(u64), s);
+    if (e != hipSuccess) return hip_fail(e, "hipMallocAsync(interpolation rows)", __FILE__, __LINE__);
+    u64* targets = tmp;
+    u64* na = targets + slab * ML;
+    u64* nb = na + slab * ML;
+    u64* Nh = nb + slab * ML;
+    int rc = TF_OK;
     for (size_t r0 = 0; r0 < rows && !rc; r0 += slab) {
         const size_t nr = std::min(slab, rows - r0);
         hipLaunchKernelGGL(tfk::interpolation_targets_kernel<L>, dim3((unsigned)((M + 255) / 256), (unsigned)nr), dim3(256), 0, s,
-                           values + r0 * n * L, (const u64*)winv, (long long)n, M, targets);
+                           values + r0 * n * L, winv, (long long)n, M, targets);
         hipLaunchKernelGGL(tfk::leaf_interpolant_kernel<L>, dim3((unsigned)(M / kTreeLeaf), (unsigned)nr), dim3(kTreeLeaf),
                            2 * kTreeLeaf * L * sizeof(u64), s, domain, (const u64*)targets, (long long)n, kTreeLeaf, M, na);
-        HIPCHK(hipGetLastError());
+        if (hipGetLastError() != hipSuccess) rc = TF_ERR_HIP;
         u64* cur = na;
         u64* nxt = nb;
         for (int l = 0; l < h && !rc; ++l) {
-            // one level for all rows of the slab: transforms of order 2d of every child's tail (shared) and interpolant, the
-            // combination N_left Z_right + N_right Z_left pointwise, one inverse transform -- which lands in the next level's layout
+            // one level for all rows of the slab: transforms of order 2d of every child's interpolant against the level's cached
+            // tail transforms, the combination N_left Z_right + N_right Z_left pointwise, one inverse transform -- which lands
+            // in the next level's layout
             const long long d = (long long)kTreeLeaf << l, children = M / d, parents = children / 2;
-            const u64* Th = pt.T.That[l];
             rc = run_ntt(ctx, cur, Nh, d * L, 2 * d * L, (size_t)(2 * d), (size_t)(children * (long long)nr), L, false, nullptr, d, s);
-            if (!rc) rc = launch_1d<L>(tfk::interpolant_pointwise_kernel<L>, (long long)nr * parents * 2 * d, s, (const u64*)Nh, Th, nxt, d,
-                                       parents, (long long)nr);
+            if (!rc) rc = launch_1d<L>(tfk::interpolant_pointwise_kernel<L>, (long long)nr * parents * 2 * d, s, (const u64*)Nh,
+                                       (const u64*)pt.T.That[l], nxt, d, parents, (long long)nr);
             if (!rc) rc = run_ntt(ctx, nxt, nxt, 2 * d * L, 2 * d * L, (size_t)(2 * d), (size_t)(parents * (long long)nr), L, true, nullptr, -1, s);
             std::swap(cur, nxt);
         }
         if (!rc) {
             hipLaunchKernelGGL(tfk::interpolant_unpad_kernel<L>, dim3((unsigned)((n + 255) / 256), (unsigned)nr), dim3(256), 0, s,
                                (const u64*)cur, M, (long long)n, out + r0 * n * L);
-            HIPCHK(hipGetLastError());
+            if (hipGetLastError() != hipSuccess) rc = TF_ERR_HIP;
         }
     }
+    hipError_t e2 = hipFreeAsync(tmp, s);
+    if (!rc && e2 != hipSuccess) rc = hip_fail(e2, "hipFreeAsync", __FILE__, __LINE__);
+    return rc;
+}
+
+template <int L>
+int interpolate_dev_t(const u64* domain, const u64* values, size_t n, size_t rows, u64* out, hipStream_t s) {
+    const int kTreeLeaf = tree_leaf(L);
+    long long M = kTreeLeaf;
+    while (M < (long long)n) M <<= 1;
+    PaddedTree pt;
+    int rc = padded_tree_build<L>(domain, n, (size_t)M * L, &pt, s);  // extra: the inverse weights
+    DeviceCtx* ctx = nullptr;
+    if (!rc) rc = current_ctx(&ctx);
+    if (!rc) rc = tree_inverse_weights<L>(ctx, pt, domain, pt.extra, s);
+    if (!rc) rc = tree_interpolate_rows<L>(ctx, pt, domain, pt.extra, values, rows, out, s);
     return padded_tree_free(&pt, s, rc);
 }
 
@@ -2261,6 +2332,128 @@ int interpolate_dev(const u64* domain, const u64* values, size_t n, size_t rows,
     if (rc) return rc;
     hipStream_t s = static_cast<hipStream_t>(stream);
     return L == 1 ? interpolate_dev_t<1>(domain, values, n, rows, out, s) : interpolate_dev_t<3>(domain, values, n, rows, out, s);
+}
+
+// ---- a zerofier tree that outlives the call (math/zerofier_tree.rs: ZerofierTree::new_from_domain, used with
+// Polynomial::divide_and_conquer_batch_evaluate, polynomial.rs:1882-1894): levels, cached level transforms, root, the domain and
+// -- once an interpolation has asked for them -- the inverse weights stay in HBM; every call brings its own work space, so one
+// handle serves concurrent calls on different streams.
+struct TreeHandle {
+    int L = 1;
+    int device = 0;
+    PaddedTree pt;
+    u64* points = nullptr;  // the domain, M L words (pt.extra)
+    u64* winv = nullptr;    // 1 / Z'(x_i), M L words (pt.extra + M L)
+    std::mutex mu;
+    bool have_winv = false;
+};
+
+template <int L>
+int tree_handle_new_t(const u64* d_domain, size_t n, hipStream_t s, TreeHandle* H) {
+    const int kTreeLeaf = tree_leaf(L);
+    long long M = kTreeLeaf;
+    while (M < (long long)n) M <<= 1;
+    int rc = padded_tree_build<L>(d_domain, n, 2 * (size_t)M * L, &H->pt, s, true);
+    if (rc) return rc;
+    H->points = H->pt.extra;
+    H->winv = H->points + (size_t)M * L;
+    // the tree was built from the caller's array; the handle keeps its own copy for the leaf evaluations
+    hipError_t e = hipMemsetAsync(H->points, 0, (size_t)M * L * sizeof(u64), s);
+    if (e == hipSuccess && n) e = hipMemcpyAsync(H->points, d_domain, n * L * sizeof(u64), hipMemcpyDeviceToDevice, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);  // the handle may be used from any stream afterwards
+    if (e != hipSuccess) return hip_fail(e, "zerofier tree: domain copy", __FILE__, __LINE__);
+    return TF_OK;
+}
+
+int tree_handle_new(const u64* d_domain, size_t n, int L, void* stream, TreeHandle** out) {
+    if (!out) return TF_ERR_NULL_POINTER;
+    *out = nullptr;
+    if (n && !d_domain) return TF_ERR_NULL_POINTER;
+    if (n > (size_t(1) << 30)) return TF_ERR_LEN_TOO_LARGE;
+    DeviceCtx* ctx = nullptr;
+    int rc = current_ctx(&ctx);
+    if (rc) return rc;
+    std::unique_ptr<TreeHandle> H(new TreeHandle());
+    H->L = L;
+    if (hipGetDevice(&H->device) != hipSuccess) return TF_ERR_NO_DEVICE;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    rc = L == 1 ? tree_handle_new_t<1>(d_domain, n, s, H.get()) : tree_handle_new_t<3>(d_domain, n, s, H.get());
+    if (rc) {
+        (void)hipStreamSynchronize(s);
+        (void)padded_tree_free(&H->pt, s, rc);
+        return rc;
+    }
+    *out = H.release();
+    return TF_OK;
+}
+
+int tree_handle_check(const TreeHandle* H, DeviceCtx** ctx) {
+    if (!H) return TF_ERR_NULL_POINTER;
+    int rc = current_ctx(ctx);
+    if (rc) return rc;
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev != H->device) {
+        t_last_error = "zerofier tree used on a device other than the one it was built on";
+        return TF_ERR_HIP;
+    }
+    return TF_OK;
+}
+
+int tree_handle_zerofier(const TreeHandle* H, u64* d_out, void* stream) {
+    DeviceCtx* ctx = nullptr;
+    int rc = tree_handle_check(H, &ctx);
+    if (rc) return rc;
+    if (!d_out) return TF_ERR_NULL_POINTER;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const long long n = (long long)H->pt.n;
+    return H->L == 1 ? launch_1d<1>(tfk::zerofier_unpad_kernel<1>, n + 1, s, (const u64*)H->pt.root_tail, H->pt.T.M, n, d_out)
+                     : launch_1d<3>(tfk::zerofier_unpad_kernel<3>, n + 1, s, (const u64*)H->pt.root_tail, H->pt.T.M, n, d_out);
+}
+
+// out[(b * n + i) * L] = f_b(domain[i]); `batch` polynomials of n_coeffs coefficients, packed
+int tree_handle_batch_evaluate(const TreeHandle* H, const u64* d_coeffs, size_t n_coeffs, size_t batch, u64* d_out, void* stream) {
+    DeviceCtx* ctx = nullptr;
+    int rc = tree_handle_check(H, &ctx);
+    if (rc) return rc;
+    const size_t n = H->pt.n;
+    if (n == 0 || batch == 0) return TF_OK;
+    if (!d_out || (n_coeffs && !d_coeffs)) return TF_ERR_NULL_POINTER;
+    const int L = H->L;
+    if (H->pt.T.h == 0 || n_coeffs < 2)  // a single leaf (or a constant): Horner on the handle's copy of the domain
+        return batch_evaluate_horner(d_coeffs, n_coeffs, n_coeffs * L, batch, H->points, n, d_out, L, stream);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    return L == 1 ? tree_batch_evaluate<1>(ctx, H->pt.T, H->points, n, d_coeffs, n_coeffs, n_coeffs, batch, d_out, s)
+                  : tree_batch_evaluate<3>(ctx, H->pt.T, H->points, n, d_coeffs, n_coeffs, 3 * n_coeffs, batch, d_out, s);
+}
+
+int tree_handle_interpolate(TreeHandle* H, const u64* d_values, size_t rows, u64* d_out, void* stream) {
+    DeviceCtx* ctx = nullptr;
+    int rc = tree_handle_check(H, &ctx);
+    if (rc) return rc;
+    if (H->pt.n == 0) return TF_ERR_EMPTY_DOMAIN;
+    if (rows == 0) return TF_OK;
+    if (!d_values || !d_out) return TF_ERR_NULL_POINTER;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    {
+        std::lock_guard<std::mutex> lk(H->mu);  // the first interpolation computes the weights (and synchronises its stream)
+        if (!H->have_winv) {
+            rc = H->L == 1 ? tree_inverse_weights<1>(ctx, H->pt, H->points, H->winv, s) : tree_inverse_weights<3>(ctx, H->pt, H->points, H->winv, s);
+            if (rc) return rc;
+            H->have_winv = true;
+        }
+    }
+    return H->L == 1 ? tree_interpolate_rows<1>(ctx, H->pt, H->points, H->winv, d_values, rows, d_out, s)
+                     : tree_interpolate_rows<3>(ctx, H->pt, H->points, H->winv, d_values, rows, d_out, s);
+}
+
+void tree_handle_free(TreeHandle* H) {
+    if (!H) return;
+    int prev = -1;
+    const bool switched = hipGetDevice(&prev) == hipSuccess && prev != H->device && hipSetDevice(H->device) == hipSuccess;
+    (void)hipDeviceSynchronize();  // calls still in flight on any stream read the tree
+    (void)padded_tree_free(&H->pt, nullptr, TF_OK);
+    if (switched) (void)hipSetDevice(prev);
+    delete H;
 }
 
 // fast_coset_evaluate / fast_coset_interpolate with an XFieldElement OFFSET (polynomial.rs:1374-1399, :1907-1918 with
@@ -2912,6 +3105,71 @@ static int interpolate_host(const uint64_t* d, const uint64_t* v, size_t n, size
 }
 int tf_poly_interpolate_bfe(const uint64_t* d, const uint64_t* v, size_t n, size_t rows, uint64_t* out) { return interpolate_host(d, v, n, rows, out, 1); }
 int tf_poly_interpolate_xfe(const uint64_t* d, const uint64_t* v, size_t n, size_t rows, uint64_t* out) { return interpolate_host(d, v, n, rows, out, 3); }
+static int tree_new_any(const uint64_t* domain, size_t n, int L, bool on_device, void* stream, tf_zerofier_tree** tree) {
+    if (!tree) return TF_ERR_NULL_POINTER;
+    *tree = nullptr;
+    TreeHandle* H = nullptr;
+    int rc;
+    if (on_device) {
+        rc = tree_handle_new(domain, n, L, stream, &H);
+    } else {
+        if (n && !domain) return TF_ERR_NULL_POINTER;
+        DeviceCtx* ctx = nullptr;
+        rc = current_ctx(&ctx);
+        if (rc) return rc;
+        hipStream_t s = host_stream();
+        DevBuf d(s);
+        rc = d.alloc(n * L);
+        if (!rc) rc = h2d(d.p, domain, n * L, s);
+        if (!rc) rc = tree_handle_new(d.p, n, L, s, &H);
+        if (!rc) rc = sync(s);
+    }
+    if (rc) return rc;
+    *tree = reinterpret_cast<tf_zerofier_tree*>(H);
+    return TF_OK;
+}
+static TreeHandle* tree_of(const tf_zerofier_tree* t) { return const_cast<TreeHandle*>(reinterpret_cast<const TreeHandle*>(t)); }
+int tf_zerofier_tree_new_bfe(const uint64_t* domain, size_t n, tf_zerofier_tree** tree) { return tree_new_any(domain, n, 1, false, nullptr, tree); }
+int tf_zerofier_tree_new_xfe(const uint64_t* domain, size_t n, tf_zerofier_tree** tree) { return tree_new_any(domain, n, 3, false, nullptr, tree); }
+int tf_zerofier_tree_new_bfe_dev(const uint64_t* d_domain, size_t n, void* stream, tf_zerofier_tree** tree) {
+    return tree_new_any(d_domain, n, 1, true, stream, tree);
+}
+int tf_zerofier_tree_new_xfe_dev(const uint64_t* d_domain, size_t n, void* stream, tf_zerofier_tree** tree) {
+    return tree_new_any(d_domain, n, 3, true, stream, tree);
+}
+void tf_zerofier_tree_free(tf_zerofier_tree* tree) { tree_handle_free(tree_of(tree)); }
+size_t tf_zerofier_tree_num_points(const tf_zerofier_tree* tree) { return tree ? tree_of(tree)->pt.n : 0; }
+int tf_zerofier_tree_width(const tf_zerofier_tree* tree) { return tree ? tree_of(tree)->L : 0; }
+int tf_zerofier_tree_zerofier_dev(const tf_zerofier_tree* tree, uint64_t* d_out, void* stream) { return tree_handle_zerofier(tree_of(tree), d_out, stream); }
+int tf_zerofier_tree_batch_evaluate_dev(const tf_zerofier_tree* tree, const uint64_t* d_coeffs, size_t n_coeffs, size_t batch, uint64_t* d_out,
+                                        void* stream) {
+    return tree_handle_batch_evaluate(tree_of(tree), d_coeffs, n_coeffs, batch, d_out, stream);
+}
+int tf_zerofier_tree_interpolate_dev(tf_zerofier_tree* tree, const uint64_t* d_values, size_t rows, uint64_t* d_out, void* stream) {
+    return tree_handle_interpolate(tree_of(tree), d_values, rows, d_out, stream);
+}
+int tf_zerofier_tree_zerofier(const tf_zerofier_tree* tree, uint64_t* out) {
+    if (!tree || !out) return TF_ERR_NULL_POINTER;
+    TreeHandle* H = tree_of(tree);
+    return host_roundtrip(nullptr, 0, nullptr, 0, out, (H->pt.n + 1) * H->L, [&](u64*, u64*, u64* o, hipStream_t s) { return tree_handle_zerofier(H, o, s); });
+}
+int tf_zerofier_tree_batch_evaluate(const tf_zerofier_tree* tree, const uint64_t* coeffs, size_t n_coeffs, size_t batch, uint64_t* out) {
+    if (!tree) return TF_ERR_NULL_POINTER;
+    TreeHandle* H = tree_of(tree);
+    if (H->pt.n == 0 || batch == 0) return TF_OK;
+    if (!out || (n_coeffs && !coeffs)) return TF_ERR_NULL_POINTER;
+    return host_roundtrip(coeffs, batch * n_coeffs * H->L, nullptr, 0, out, batch * H->pt.n * H->L,
+                          [&](u64* dc, u64*, u64* o, hipStream_t s) { return tree_handle_batch_evaluate(H, dc, n_coeffs, batch, o, s); });
+}
+int tf_zerofier_tree_interpolate(tf_zerofier_tree* tree, const uint64_t* values, size_t rows, uint64_t* out) {
+    if (!tree) return TF_ERR_NULL_POINTER;
+    TreeHandle* H = tree_of(tree);
+    if (H->pt.n == 0) return TF_ERR_EMPTY_DOMAIN;
+    if (rows == 0) return TF_OK;
+    if (!values || !out) return TF_ERR_NULL_POINTER;
+    return host_roundtrip(values, rows * H->pt.n * H->L, nullptr, 0, out, rows * H->pt.n * H->L,
+                          [&](u64* dv, u64*, u64* o, hipStream_t s) { return tree_handle_interpolate(H, dv, rows, o, s); });
+}
 int tf_coset_eval_xfe_xoffset_dev(const uint64_t* c, size_t nc, const uint64_t offset[3], uint64_t* out, size_t order, size_t batch, void* stream) {
     return coset_eval_xoffset_dev(c, nc, offset, out, order, batch, stream);
 }

@@ -213,6 +213,52 @@ def interpolate(domain, values, out, rows: int = 1, width: int = 1, stream=None)
     _chk(fn(_p(domain), _p(values), n, rows, _p(out), _stream(stream)), "interpolate")
 
 
+class ZerofierTree:
+    """math/zerofier_tree.rs on device buffers: the tree of a device-resident domain, kept in HBM across calls
+    (tf_zerofier_tree_* of include/tf_hip.h).  close() (or the context manager) releases the device memory."""
+
+    def __init__(self, domain, width: int = 1, stream=None):
+        domain = _t(domain, "domain")
+        _need(domain.numel() % _width(width) == 0, "domain must hold whole elements")
+        self.width = width
+        self.num_points = domain.numel() // width
+        self._h = C.c_void_p(0)
+        self._free = _lib.lib().tf_zerofier_tree_free
+        fn = _lib.lib().tf_zerofier_tree_new_bfe_dev if width == 1 else _lib.lib().tf_zerofier_tree_new_xfe_dev
+        _chk(fn(_p(domain), self.num_points, _stream(stream), C.byref(self._h)), "ZerofierTree::new_from_domain")
+
+    def close(self) -> None:
+        h = getattr(self, "_h", None)
+        if h is not None and h.value:
+            self._free(h)  # bound at construction: still callable while the interpreter shuts down
+            h.value = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def zerofier(self, out, stream=None) -> None:
+        out = _t(out, "out")
+        _need(out.numel() == (self.num_points + 1) * self.width, "out must hold n + 1 coefficients")
+        _chk(_lib.lib().tf_zerofier_tree_zerofier_dev(self._h, _p(out), _stream(stream)), "ZerofierTree::zerofier")
+
+    def batch_evaluate(self, coeffs, n_coeffs: int, out, batch: int = 1, stream=None) -> None:
+        coeffs, out = _t(coeffs, "coeffs"), _t(out, "out")
+        _need(coeffs.numel() == batch * n_coeffs * self.width, "coeffs must hold batch * n_coeffs elements")
+        _need(out.numel() == batch * self.num_points * self.width, "out must hold batch * n_points elements")
+        _chk(_lib.lib().tf_zerofier_tree_batch_evaluate_dev(self._h, _p(coeffs), n_coeffs, batch, _p(out), _stream(stream)),
+             "divide_and_conquer_batch_evaluate")
+
+    def interpolate(self, values, out, rows: int = 1, stream=None) -> None:
+        values, out = _t(values, "values"), _t(out, "out")
+        _need(values.numel() == rows * self.num_points * self.width and out.numel() == values.numel(), "values / out must hold rows * n elements")
+        _chk(_lib.lib().tf_zerofier_tree_interpolate_dev(self._h, _p(values), rows, _p(out), _stream(stream)), "interpolate")
+
+
 def coset_extrapolate(offset_raw: int, codewords, n: int, points, out, batch: int = 1, width: int = 1, stream=None) -> None:
     """Polynomial::batch_coset_extrapolate (math/polynomial.rs:2196-2208) on device buffers:
     out[(b * n_points + i) * width] = interpolant_b(points[i])."""

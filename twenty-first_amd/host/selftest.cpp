@@ -152,6 +152,16 @@ int main() {
         try { Poly::interpolate(bfe_vec({1, 1}), bfe_vec({1, 2})); } catch (const NttPanic& e) { p3 = e.code == TF_ERR_INVERSE_OF_ZERO; }  // :3554-3560
         EXPECT(p1 && p2 && p3);
     }
+    {  // ZerofierTree (zerofier_tree.rs): built once, used for evaluation and interpolation; the empty tree's zerofier is 1
+        using Poly = Polynomial<BFieldElement>;
+        auto tree = ZerofierTree<BFieldElement>::new_from_domain(bfe_vec({0, 1, 2, 3}));
+        EXPECT(tree.zerofier().coefficients == Poly::zerofier(bfe_vec({0, 1, 2, 3})).coefficients);
+        EXPECT(tree.batch_evaluate(Poly(bfe_vec({1, 2}))) == bfe_vec({1, 3, 5, 7}));
+        EXPECT(tree.interpolate(bfe_vec({1, 3, 5, 7})).coefficients == bfe_vec({1, 2}));
+        EXPECT(tree.interpolate(bfe_vec({0, 1, 4, 9})).coefficients == bfe_vec({0, 0, 1}));
+        auto empty = ZerofierTree<BFieldElement>::new_from_domain({});
+        EXPECT(empty.zerofier().coefficients == bfe_vec({1}) && empty.batch_evaluate(Poly(bfe_vec({1, 2}))).empty());
+    }
     {  // clean_divide (polynomial.rs:2358-2411): (x + 1)(x + 2)(x + 3) / (x + 2), x^9 * 6 / (x^3 * 3), and the panics
         using Poly = Polynomial<BFieldElement>;
         Poly prod = Poly(bfe_vec({1, 1})).fast_multiply(Poly(bfe_vec({2, 1}))).fast_multiply(Poly(bfe_vec({3, 1})));

@@ -233,6 +233,46 @@ struct Polynomial {
     }
 };
 
+// ---- ZerofierTree (math/zerofier_tree.rs): the tree of a domain, built once and kept in HBM -----------------------------
+template <class FF>
+struct ZerofierTree {
+    tf_zerofier_tree* handle = nullptr;
+    size_t num_points = 0;
+    ZerofierTree() = default;
+    ZerofierTree(const ZerofierTree&) = delete;
+    ZerofierTree& operator=(const ZerofierTree&) = delete;
+    ZerofierTree(ZerofierTree&& o) noexcept : handle(o.handle), num_points(o.num_points) { o.handle = nullptr; }
+    ~ZerofierTree() { tf_zerofier_tree_free(handle); }
+    static ZerofierTree new_from_domain(const std::vector<FF>& domain) {  // :66-87
+        ZerofierTree t;
+        const uint64_t* d = reinterpret_cast<const uint64_t*>(domain.data());
+        if constexpr (sizeof(FF) == 8) check(tf_zerofier_tree_new_bfe(d, domain.size(), &t.handle), "ZerofierTree::new_from_domain");
+        else check(tf_zerofier_tree_new_xfe(d, domain.size(), &t.handle), "ZerofierTree::new_from_domain");
+        t.num_points = domain.size();
+        return t;
+    }
+    Polynomial<FF> zerofier() const {  // :93-99
+        std::vector<FF> out(num_points + 1);
+        check(tf_zerofier_tree_zerofier(handle, reinterpret_cast<uint64_t*>(out.data())), "ZerofierTree::zerofier");
+        return Polynomial<FF>(std::move(out));
+    }
+    // polynomial.divide_and_conquer_batch_evaluate(&tree) (polynomial.rs:1882-1894)
+    std::vector<FF> batch_evaluate(const Polynomial<FF>& f) const {
+        std::vector<FF> out(num_points);
+        check(tf_zerofier_tree_batch_evaluate(handle, reinterpret_cast<const uint64_t*>(f.coefficients.data()), f.coefficients.size(), 1,
+                                              reinterpret_cast<uint64_t*>(out.data())),
+              "divide_and_conquer_batch_evaluate");
+        return out;
+    }
+    // the interpolant of `values` over the tree's domain (weights cached after the first call)
+    Polynomial<FF> interpolate(const std::vector<FF>& values) {
+        if (values.size() != num_points || num_points == 0) throw NttPanic(TF_ERR_EMPTY_DOMAIN, "interpolate");
+        std::vector<FF> out(num_points);
+        check(tf_zerofier_tree_interpolate(handle, reinterpret_cast<const uint64_t*>(values.data()), 1, reinterpret_cast<uint64_t*>(out.data())), "interpolate");
+        return Polynomial<FF>(std::move(out));
+    }
+};
+
 // ---- Tip5 (tip5/mod.rs) ---------------------------------------------------------------------------
 struct Tip5 {
     std::array<BFieldElement, 16> state{};  // :159-165
