@@ -97,9 +97,13 @@ int tf_coset_eval_xfe_dev(const uint64_t *d_coeffs, size_t n_coeffs, uint64_t of
  * Tip5                  replaces  Tip5::permutation  tip5/mod.rs:529-533   (states: count x 16 words, in place)
  *                                 Tip5::hash_10 / hash_pair  :559-586       (in: count x 10 words, out: count x 5)
  *                                 Tip5::hash_varlen  :617-623 (+ sponge.rs:41-55)   one digest per row
+ *                                 Tip5::trace  :538-548   trace: count x 6 x 16 words (the state before the permutation and
+ *                                                          after each of the 5 rounds); states end permuted, as `&mut self` does
  * Batching is the only reason to cross the boundary; a single hash_pair belongs on the CPU.
  */
 int tf_tip5_permute(uint64_t *states, size_t count);
+int tf_tip5_trace(uint64_t *states, uint64_t *trace, size_t count);
+int tf_tip5_trace_dev(uint64_t *d_states, uint64_t *d_trace, size_t count, void *stream);
 int tf_tip5_hash_pairs(const uint64_t *in, uint64_t *out, size_t count);
 int tf_tip5_hash_varlen_rows(const uint64_t *rows, size_t row_len, size_t n_rows, uint64_t *out);
 int tf_tip5_permute_dev(uint64_t *d_states, size_t count, void *stream);

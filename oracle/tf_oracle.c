@@ -619,6 +619,15 @@ void tfo_tip5_permutation(uint64_t s[16]) { /* :529-533 */
     for (int r = 0; r < NUM_ROUNDS; r++) tip5_round(s, r);
 }
 
+/* Tip5::trace (tip5/mod.rs:538-548): the state before the permutation and after every round; s ends permuted */
+void tfo_tip5_trace(uint64_t s[16], uint64_t trace[96]) {
+    pthread_once(&g_tip5_once, tip5_init_tables);
+    memcpy(trace, s, 16 * sizeof(u64));
+    for (int i = 0; i < NUM_ROUNDS; i++) {
+        tip5_round(s, i);
+        memcpy(trace + 16 * (i + 1), s, 16 * sizeof(u64));
+    }
+}
 /* tip5/naive.rs:26-76 : x^7 by mod_pow, MDS as a field matrix product */
 void tfo_tip5_permutation_naive(uint64_t s[16]) {
     pthread_once(&g_tip5_once, tip5_init_tables);

@@ -65,6 +65,7 @@ def lib() -> C.CDLL:
             "tfo_poly_eval": (None, [pu, sz, i32, u64, pu]),
             "tfo_tip5_permutation": (None, [pu]),
             "tfo_tip5_permutation_naive": (None, [pu]),
+            "tfo_tip5_trace": (None, [pu, pu]),
             "tfo_tip5_mds": (None, [pu, i32]),
             "tfo_tip5_mds_graph_constants": (None, [pu]),
             "tfo_tip5_hash_10": (None, [pu, pu]),
@@ -253,6 +254,14 @@ def tip5_permutation(state, naive: bool = False) -> np.ndarray:
     s = _arr(state, 16).copy()
     (lib().tfo_tip5_permutation_naive if naive else lib().tfo_tip5_permutation)(_p(s))
     return s
+
+
+def tip5_trace(state):
+    """Tip5::trace (tip5/mod.rs:538-548): (6 x 16 trace, permuted state)."""
+    s = _arr(state, 16).copy()
+    t = np.zeros(96, dtype=np.uint64)
+    lib().tfo_tip5_trace(_p(s), _p(t))
+    return t.reshape(6, 16), s
 
 
 def tip5_mds(state, method: int) -> np.ndarray:

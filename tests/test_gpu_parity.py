@@ -692,3 +692,30 @@ def test_free_functions_validate_and_trim(tf, oracle):
     assert np.array_equal(got, oracle.coset_evaluate(c, oracle.bfe_new(7), 64, width=3))
     with pytest.raises(tf.NttPanic):
         tf.fast_coset_evaluate(oracle.fill_random(3 * 70, 9), oracle.bfe_new(7), 64, width=3)   # degree 69 >= order
+
+
+@pytest.mark.parametrize("count", [1, 3, 64, 1000, 1 << 14])
+def test_tip5_trace_matches_oracle(tf, oracle, count):
+    """Tip5::trace (tip5/mod.rs:538-548): count x 6 x 16 words, row 0 the input state, row 5 the permutation's output
+    (test :1557-1565), every row equal to the oracle's; the states end permuted like `&mut self`."""
+    import torch
+
+    s0 = oracle.fill_random(16 * count, 2100 + count)
+    s = s0.copy()
+    trace = tf.Tip5.trace_states(s)
+    assert trace.shape == (count, 6, 16)
+    assert np.array_equal(trace[:, 0, :].reshape(-1), s0)
+    assert np.array_equal(trace[:, 5, :].reshape(-1), s)
+    perm = s0.copy()
+    tf.Tip5.permute_states(perm)
+    assert np.array_equal(perm, s)
+    for i in sorted({0, count // 2, count - 1}):
+        want, _ = oracle.tip5_trace(s0[16 * i: 16 * i + 16])
+        assert np.array_equal(trace[i], want)
+    ds = torch.from_numpy(s0.view(np.int64).copy()).cuda()
+    dt = torch.empty(96 * count, dtype=torch.int64, device="cuda")
+    tf.device.tip5_trace_(ds, dt)
+    torch.cuda.synchronize()
+    assert np.array_equal(dt.cpu().numpy().view(np.uint64).reshape(count, 6, 16), trace)
+    with pytest.raises(ValueError):
+        tf.device.tip5_trace_(ds, dt[:-1])

@@ -625,3 +625,15 @@ def test_division_restatements(oracle):
         tfo.clean_divide(prod, np.zeros(2, dtype=np.uint64))
     with pytest.raises(tfo.OraclePanic):
         tfo.clean_divide(tfo.to_raw([1, 0, 1]), tfo.to_raw([1, 1]), 0)  # x^2 + 1 is not a multiple of x + 1
+
+
+def test_tip5_trace_starts_with_the_state_and_ends_with_the_permutation(oracle):
+    """tip5/mod.rs:1557-1565: trace()[0] is the initial state, trace()[5] the permuted one; every row is one round further
+    (checked against the naive permutation's end state, tip5/naive.rs, which shares no code with the round function)."""
+    for seed in range(5):
+        s = oracle.fill_random(16, 4000 + seed)
+        trace, end = oracle.tip5_trace(s)
+        assert np.array_equal(trace[0], s)
+        assert np.array_equal(trace[5], oracle.tip5_permutation(s)) and np.array_equal(end, trace[5])
+        assert np.array_equal(trace[5], oracle.tip5_permutation(s, naive=True))
+        assert len({trace[r].tobytes() for r in range(6)}) == 6

@@ -440,6 +440,18 @@ class Tip5:
         _check(lib().tf_tip5_permute(_ptr(states), states.size // 16), "Tip5::permutation")
 
     @staticmethod
+    def trace_states(states: np.ndarray) -> np.ndarray:
+        """Tip5::trace (tip5/mod.rs:538-548) for count x 16 raw words: returns count x 6 x 16 words (the state before the permutation
+        and after each round); `states` ends permuted, like `&mut self`."""
+        states = _words(states, "states")
+        if states.size % 16:
+            raise ValueError("states must hold a multiple of 16 words")
+        count = states.size // 16
+        trace = np.empty(count * 96, dtype=np.uint64)
+        _check(lib().tf_tip5_trace(_ptr(states), _ptr(trace), count), "Tip5::trace")
+        return trace.reshape(count, 6, 16)
+
+    @staticmethod
     def permutation(state: np.ndarray) -> np.ndarray:
         s = np.ascontiguousarray(state, dtype=np.uint64).copy()
         Tip5.permute_states(s)

@@ -32,6 +32,8 @@ SIGNATURES = {
     "tf_coset_eval_bfe_dev": (C.c_int, [_vp, _sz, C.c_uint64, _vp, _sz, _sz, _vp]),
     "tf_coset_eval_xfe_dev": (C.c_int, [_vp, _sz, C.c_uint64, _vp, _sz, _sz, _vp]),
     "tf_tip5_permute": (C.c_int, [_vp, _sz]),
+    "tf_tip5_trace": (C.c_int, [_vp, _vp, _sz]),
+    "tf_tip5_trace_dev": (C.c_int, [_vp, _vp, _sz, _vp]),
     "tf_tip5_hash_pairs": (C.c_int, [_vp, _vp, _sz]),
     "tf_tip5_hash_varlen_rows": (C.c_int, [_vp, _sz, _sz, _vp]),
     "tf_tip5_permute_dev": (C.c_int, [_vp, _sz, _vp]),

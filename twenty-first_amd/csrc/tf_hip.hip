@@ -1430,6 +1430,21 @@ int tip5_permute_dev(u64* d_states, size_t count, void* stream) {
     return TF_OK;
 }
 
+int tip5_trace_dev(u64* d_states, u64* d_trace, size_t count, void* stream) {
+    if (count == 0) return TF_OK;
+    if (!d_states || !d_trace) return TF_ERR_NULL_POINTER;
+    DeviceCtx* ctx = nullptr;
+    int rc = current_ctx(&ctx);
+    if (rc) return rc;
+    rc = ensure_tip5(ctx);
+    if (rc) return rc;
+    const long long blocks = ((long long)count + 255) / 256;
+    hipLaunchKernelGGL(tfk::tip5_trace_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), d_states, d_trace,
+                       (long long)count);
+    HIPCHK(hipGetLastError());
+    return TF_OK;
+}
+
 int launch_hash_pairs(const u64* in, u64* out, u64* leaf_copy, long long count, long long per_tree, long long in_ts,
                       long long out_ts, long long copy_ts, hipStream_t s) {
     if (count == 0) return TF_OK;
@@ -2898,6 +2913,22 @@ int tf_merkle_root_dev(const uint64_t* d_leaves, size_t n, uint64_t* d_root, siz
     return merkle_root_dev(d_leaves, n, d_root, batch, stream);
 }
 
+int tf_tip5_trace_dev(uint64_t* d_states, uint64_t* d_trace, size_t count, void* stream) { return tip5_trace_dev(d_states, d_trace, count, stream); }
+int tf_tip5_trace(uint64_t* states, uint64_t* trace, size_t count) {
+    if (count == 0) return TF_OK;
+    if (!states || !trace) return TF_ERR_NULL_POINTER;
+    DeviceCtx* ctx = nullptr;
+    TRY(current_ctx(&ctx));
+    hipStream_t s = host_stream();
+    DevBuf d(s), t(s);
+    TRY(d.alloc(count * 16));
+    TRY(t.alloc(count * 96));
+    TRY(h2d(d.p, states, count * 16, s));
+    TRY(tip5_trace_dev(d.p, t.p, count, s));
+    TRY(d2h(states, d.p, count * 16, s));
+    TRY(d2h(trace, t.p, count * 96, s));
+    return sync(s);
+}
 int tf_tip5_permute(uint64_t* states, size_t count) {
     if (count == 0) return TF_OK;
     if (!states) return TF_ERR_NULL_POINTER;

@@ -117,6 +117,31 @@ __global__ void __launch_bounds__(256) tip5_permute_kernel(u64* states, long lon
     for (int k = 0; k < 16; ++k) p[k] = s[k];
 }
 
+// Tip5::trace (mod.rs:538-548): trace[i][0] = the state before the permutation, trace[i][1 + r] = the state after round r;
+// states[i] ends as the permuted state.  6 x 16 words per permutation, the rows a hash-table arithmetisation is filled from.
+__global__ void __launch_bounds__(256) tip5_trace_kernel(u64* states, u64* trace, long long count) {
+    __shared__ __attribute__((aligned(16))) unsigned char lut[256];
+    stage_lut(lut);
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    u64 s[16];
+    u64* p = states + i * 16;
+    u64* t = trace + i * 96;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        s[k] = p[k];
+        t[k] = s[k];
+    }
+#pragma unroll 1
+    for (int r = 0; r < 5; ++r) {
+        tip5_round(s, r, lut);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t[16 * (r + 1) + k] = s[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) p[k] = s[k];
+}
+
 // out[i] = hash_10(in[10 i .. 10 i + 10)) = hash_pair(left, right)  (mod.rs:559-586).
 // If leaf_copy != null the 10 input words are also copied there (Merkle leaf level, merkle_tree.rs:426).
 // Addressing: item i belongs to tree i / per_tree; its input is in + tree * in_ts + 10 * (i % per_tree), etc.

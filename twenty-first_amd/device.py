@@ -82,6 +82,13 @@ def tip5_permute_(states, stream=None) -> None:
     _chk(_lib.lib().tf_tip5_permute_dev(_p(states), states.numel() // 16, _stream(stream)), "Tip5::permutation")
 
 
+def tip5_trace_(states, trace, stream=None) -> None:
+    """Tip5::trace (tip5/mod.rs:538-548) on device buffers: trace = count x 6 x 16 words, states permuted in place."""
+    states, trace = _t(states, "states"), _t(trace, "trace")
+    _need(states.numel() % 16 == 0 and trace.numel() == 6 * states.numel(), "trace must hold 6 x 16 words per Tip5 state")
+    _chk(_lib.lib().tf_tip5_trace_dev(_p(states), _p(trace), states.numel() // 16, _stream(stream)), "Tip5::trace")
+
+
 def tip5_hash_pairs(inp, out, stream=None) -> None:
     inp, out = _t(inp, "in"), _t(out, "out")
     _need(inp.numel() % 10 == 0, "in must hold 10 words per pair of digests")

@@ -152,6 +152,14 @@ int main() {
         try { Poly::interpolate(bfe_vec({1, 1}), bfe_vec({1, 2})); } catch (const NttPanic& e) { p3 = e.code == TF_ERR_INVERSE_OF_ZERO; }  // :3554-3560
         EXPECT(p1 && p2 && p3);
     }
+    {  // Tip5::trace (tip5/mod.rs:538-548, test :1557-1565): first row = the state, last row = the permutation's output
+        Tip5 a = Tip5::init(), b = Tip5::init();
+        for (int i = 0; i < 16; ++i) a.state[i] = b.state[i] = BFieldElement::new_(1000 + i);
+        auto before = a.state;
+        auto t = a.trace();
+        b.permutation();
+        EXPECT(t[0] == before && t[5] == b.state && a.state == b.state);
+    }
     {  // ZerofierTree (zerofier_tree.rs): built once, used for evaluation and interpolation; the empty tree's zerofier is 1
         using Poly = Polynomial<BFieldElement>;
         auto tree = ZerofierTree<BFieldElement>::new_from_domain(bfe_vec({0, 1, 2, 3}));

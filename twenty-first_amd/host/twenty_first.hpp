@@ -278,6 +278,11 @@ struct Tip5 {
     std::array<BFieldElement, 16> state{};  // :159-165
     static constexpr size_t RATE = 10;
     void permutation() { check(tf_tip5_permute(reinterpret_cast<uint64_t*>(state.data()), 1), "Tip5::permutation"); }  // :529-533
+    std::array<std::array<BFieldElement, 16>, 6> trace() {  // :538-548: the state before the permutation and after each round
+        std::array<std::array<BFieldElement, 16>, 6> t;
+        check(tf_tip5_trace(reinterpret_cast<uint64_t*>(state.data()), reinterpret_cast<uint64_t*>(t.data()), 1), "Tip5::trace");
+        return t;
+    }
     static std::array<BFieldElement, 5> hash_10(const std::array<BFieldElement, 10>& in) {  // :559-569
         std::array<BFieldElement, 5> out;
         check(tf_tip5_hash_pairs(reinterpret_cast<const uint64_t*>(in.data()), reinterpret_cast<uint64_t*>(out.data()), 1), "Tip5::hash_10");
