@@ -9,7 +9,8 @@ P = 0xFFFFFFFF00000001
 seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 budget = float(sys.argv[2]) if len(sys.argv) > 2 else 150.0
 rng = random.Random(seed)
-KINDS = ["ntt", "ntt", "coset", "coset", "interp", "mul", "merkle", "varlen", "eval", "extrap", "lde", "auth", "square", "mulb", "nttu", "interpu"]
+KINDS = ["ntt", "ntt", "coset", "coset", "interp", "mul", "merkle", "varlen", "eval", "extrap", "lde", "auth", "square", "mulb", "nttu", "interpu",
+         "zerofier", "lagrange", "treeeval", "cdiv", "xoff", "trace", "handle"]
 if len(sys.argv) > 3:
     KINDS = sys.argv[3].split(",")
 import torch
@@ -154,5 +155,70 @@ while time.time() < t_end:
         na = rng.randint(1, 60000) if rng.random() < 0.25 else rng.randint(1, 4000)
         a = oracle.fill_random(na * width, rng.getrandbits(40))
         assert np.array_equal(tf.fast_square(a, width=width), oracle.poly_mul(a, a, width=width)), (kind, na, width)
+    elif kind == "zerofier":
+        n = rng.choice([rng.randint(0, 40), rng.randint(100, 700), rng.randint(900, 3000)])
+        r = oracle.fill_random(max(1, n) * width, rng.getrandbits(40))[: n * width]
+        if n > 2 and rng.random() < 0.3:
+            r[width: 2 * width] = r[:width]
+        assert np.array_equal(tf.Polynomial.zerofier(r, width=width).coefficients, tf.Polynomial(oracle.zerofier(r, width), width=width).coefficients), (kind, n, width)
+    elif kind == "lagrange":
+        n = rng.choice([rng.randint(1, 40), rng.randint(100, 700), rng.randint(900, 2200)])
+        rows = rng.randint(1, 3)
+        d = oracle.fill_random(n * width, rng.getrandbits(40))
+        vals = [oracle.fill_random(n * width, rng.getrandbits(40)) for _ in range(rows)]
+        polys = tf.Polynomial.batch_fast_interpolate(d, vals, width=width)
+        k = rng.randrange(rows)
+        assert np.array_equal(polys[k].coefficients, tf.Polynomial(oracle.lagrange_interpolate(d, vals[k], width), width=width).coefficients), (kind, n, width, rows)
+    elif kind == "treeeval":  # the zerofier-tree route against Horner and the oracle
+        n, m = rng.randint(2, 20000), rng.randint(2 * (256 if width == 1 else 128), 9000)
+        c = oracle.fill_random(n * width, rng.getrandbits(40)); pts = oracle.fill_random(m * width, rng.getrandbits(40))
+        try:
+            tf.lib().tf_set_batch_eval_route(2)
+            got = tf.Polynomial(c, width=width).batch_evaluate(pts).reshape(m, width)
+        finally:
+            tf.lib().tf_set_batch_eval_route(0)
+        for i in (0, rng.randrange(m), m - 1):
+            want = oracle.poly_eval(c, int(pts[i]))[:1] if width == 1 else oracle.poly_eval_xfe_point(c, pts[3 * i:3 * i + 3])
+            assert np.array_equal(got[i], want), (kind, n, m, width, i)
+    elif kind == "cdiv":
+        nq, nb = rng.choice([(rng.randint(1, 50), rng.randint(1, 50)), (rng.randint(1, 3000), rng.randint(1, 3000)), (rng.randint(1, 40000), rng.randint(500, 40000))])
+        q, b = oracle.fill_random(nq, rng.getrandbits(40)), oracle.fill_random(nb, rng.getrandbits(40))
+        if rng.random() < 0.3:
+            b[0] = 0
+        if not q[-1] or not b[-1]:
+            continue
+        a = oracle.poly_mul(q, b)
+        assert np.array_equal(tf.Polynomial(a).clean_divide(tf.Polynomial(b)).coefficients, q), (kind, nq, nb)
+        if nq * nb < (1 << 21):
+            assert np.array_equal(oracle.clean_divide(a, b, 0), q), (kind, "oracle", nq, nb)
+    elif kind == "xoff":
+        log_order = rng.randint(0, 14)
+        order = 1 << log_order
+        n_coeffs = rng.randint(0, order)
+        off = oracle.fill_random(3, rng.getrandbits(40))
+        c = oracle.fill_random(max(1, n_coeffs) * 3, rng.getrandbits(40))[: 3 * n_coeffs]
+        got = tf.fast_coset_evaluate(c, off, order, width=3)
+        assert np.array_equal(got, oracle.coset_evaluate_xfe_offset(c, off, order)), (kind, order, n_coeffs)
+        assert np.array_equal(tf.fast_coset_interpolate(got, off, width=3), oracle.coset_interpolate_xfe_offset(got, off)), (kind, "interp", order)
+    elif kind == "trace":
+        count = rng.choice([1, 5, 300, 5000])
+        s0 = oracle.fill_random(16 * count, rng.getrandbits(40))
+        s = s0.copy()
+        tr = tf.Tip5.trace_states(s)
+        i = rng.randrange(count)
+        want, end = oracle.tip5_trace(s0[16 * i: 16 * i + 16])
+        assert np.array_equal(tr[i], want) and np.array_equal(s[16 * i: 16 * i + 16], end), (kind, count, i)
+    elif kind == "handle":
+        n = rng.choice([rng.randint(1, 300), rng.randint(300, 4000)])
+        d = oracle.fill_random(n * width, rng.getrandbits(40))
+        with tf.ZerofierTree(d, width=width) as tree:
+            f = tf.Polynomial(oracle.fill_random(rng.randint(1, 3 * n) * width, rng.getrandbits(40)), width=width)
+            vals = tree.batch_evaluate(f)
+            i = rng.randrange(n)
+            want = oracle.poly_eval(f.coefficients, int(d[i]))[:1] if width == 1 else oracle.poly_eval_xfe_point(f.coefficients, d[3 * i:3 * i + 3])
+            assert np.array_equal(vals[i * width:(i + 1) * width], want), (kind, n, width)
+            g = tf.Polynomial(oracle.fill_random(n * width, rng.getrandbits(40)), width=width)
+            back = tree.interpolate([tree.batch_evaluate(g)])[0]
+            assert np.array_equal(back.coefficients, g.coefficients), (kind, "round trip", n, width)
     bump(kind)
 print(f"seed {seed}: all matched the oracle: " + ", ".join(f"{k} {v}" for k, v in sorted(counts.items())), flush=True)
