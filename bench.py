@@ -669,6 +669,21 @@ def side_measurements(tf, torch, dev):
         ms = _timed(lambda: tf.device.merkle_from_columns(lo, 1 << 21, 128, tn))
         extra["merkle_from_columns_2p21_rows_x128"] = {"ms": round(ms, 3), "rows_per_s": round((1 << 21) / ms * 1e3, 1)}
         del lv, lo, tn
+        # the zerofier tree: batch evaluation at the reference's complexity, interpolation, and both over a prepared tree
+        for log_n in (16, 20):
+            n = 1 << log_n
+            dom, cf = rnd(n, 9), rnd(n, 10)
+            vals, back = torch.empty(n, dtype=torch.int64, device=dev), torch.empty(n, dtype=torch.int64, device=dev)
+            ms_e = _timed(lambda: tf.device.batch_evaluate(cf, n, dom, vals), reps=3)
+            ms_i = _timed(lambda: tf.device.interpolate(dom, vals, back), reps=3)
+            ok = bool(torch.equal(back, cf))
+            with tf.device.ZerofierTree(dom) as tree:
+                ms_te = _timed(lambda: tree.batch_evaluate(cf, n, vals), reps=3)
+                ms_ti = _timed(lambda: tree.interpolate(vals, back), reps=3)
+            extra[f"zerofier_tree_2p{log_n}_points"] = {"batch_evaluate_ms": round(ms_e, 3), "interpolate_ms": round(ms_i, 3),
+                                                       "prepared_tree_evaluate_ms": round(ms_te, 3), "prepared_tree_interpolate_ms": round(ms_ti, 3),
+                                                       "evaluate_then_interpolate_is_identity": ok}
+            del dom, cf, vals, back
         # PCIe-inclusive figure of the host-pointer entry point (pageable numpy buffers, 32 x 2^20 BFE = 256 MiB each way)
         import numpy as _np
 
