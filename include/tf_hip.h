@@ -200,6 +200,18 @@ int tf_coset_eval_xfe_xoffset(const uint64_t *coeffs, size_t n_coeffs, const uin
 int tf_coset_interpolate_xfe_xoffset(const uint64_t *values, size_t n, const uint64_t offset[3], uint64_t *out, size_t batch);
 int tf_coset_eval_xfe_xoffset_dev(const uint64_t *d_coeffs, size_t n_coeffs, const uint64_t offset[3], uint64_t *d_out, size_t order, size_t batch, void *stream);
 int tf_coset_interpolate_xfe_xoffset_dev(const uint64_t *d_values, size_t n, const uint64_t offset[3], uint64_t *d_out, size_t batch, void *stream);
+/* barycentric_evaluate  math/polynomial.rs:2609-2637: out[b] = the value at `indeterminate` of the interpolant of codeword b given
+ * on the subgroup of order n (natural order, no offset), for `batch` codewords of n elements at ONE indeterminate -- the
+ * out-of-domain evaluation of every column of a table.  indeterminate: 3 raw words (an XFieldElement; a BFieldElement x as
+ * [x, 0, 0]); _bfe / _xfe is the codewords' field; out: batch x 3 words (an XFieldElement each; limbs 1 and 2 are zero when
+ * codewords and indeterminate are in the base field, the reference's BFieldElement result being limb 0).  One pass over the
+ * codewords (8 / 24 bytes per element) against the shared weights d_i / (x - d_i).
+ * Errors where the reference panics: n not a power of two -> TF_ERR_LEN_NOT_POWER_OF_TWO (primitive_root_of_unity(..).unwrap(),
+ * :2620); the indeterminate inside the subgroup, or n == 0 -> TF_ERR_INVERSE_OF_ZERO (batch_inversion / inverse of zero). */
+int tf_barycentric_evaluate_bfe(const uint64_t *codewords, size_t n, size_t batch, const uint64_t indeterminate[3], uint64_t *out);
+int tf_barycentric_evaluate_xfe(const uint64_t *codewords, size_t n, size_t batch, const uint64_t indeterminate[3], uint64_t *out);
+int tf_barycentric_evaluate_bfe_dev(const uint64_t *d_codewords, size_t n, size_t batch, const uint64_t indeterminate[3], uint64_t *d_out, void *stream);
+int tf_barycentric_evaluate_xfe_dev(const uint64_t *d_codewords, size_t n, size_t batch, const uint64_t indeterminate[3], uint64_t *d_out, void *stream);
 /* Polynomial::<BFieldElement>::clean_divide  math/polynomial.rs:2358-2411: the quotient a / b of a division KNOWN to be clean
  * (b | a), by pointwise division on a coset of the extension field: two forward XFE transforms of order
  * next_power_of_two(na), one inverse.  a, b: normalised coefficient arrays (na, nb count up to the non-zero leading coefficient,

@@ -1024,6 +1024,36 @@ void tfo_poly_scale_xfe(uint64_t *c, size_t n_coeffs, const uint64_t alpha[3]) {
     }
 }
 
+/* barycentric_evaluate (polynomial.rs:2609-2637): the interpolant of `codeword` (on the subgroup of order n, natural order) at
+ * an indeterminate that is not in the subgroup:  sum_i c_i d_i / (x - d_i)  over  sum_i d_i / (x - d_i),  d_i = w_n^i.
+ * The indeterminate is given as an XFieldElement (a BFieldElement is its lift [x, 0, 0]: the arithmetic then never leaves the
+ * base field and limb 0 is the reference's BFieldElement result); width = 1 / 3 is the codeword's field.
+ * Returns 1 for a length that is not a power of two <= 2^32 (primitive_root_of_unity(..).unwrap() panics), 2 where
+ * batch_inversion / inverse panic on zero (the indeterminate is in the subgroup, or n = 0). */
+int tfo_barycentric_evaluate(const uint64_t *codeword, size_t n, int width, const uint64_t x[3], uint64_t out[3]) {
+    if (n & (n - 1)) return 1;
+    if (n == 0) return 2; /* denominator = 0: inverse() panics */
+    const u64 gen = tfo_bfe_primitive_root(n);
+    u64 d = bfe_new(1), den[3] = {0, 0, 0}, num[3] = {0, 0, 0};
+    for (size_t i = 0; i < n; i++) {
+        u64 shift[3] = {bfe_sub(x[0], d), x[1], x[2]}, inv[3], w[3], t[3];
+        if (tfo_xfe_inverse(shift, inv)) return 2;
+        tfo_xfe_mul_bfe(inv, d, w); /* domain_over_domain_shift */
+        tfo_xfe_add(den, w, t);
+        memcpy(den, t, sizeof(t));
+        if (width == 1) tfo_xfe_mul_bfe(w, codeword[i], t);
+        else tfo_xfe_mul(codeword + 3 * i, w, t);
+        u64 acc[3];
+        tfo_xfe_add(num, t, acc);
+        memcpy(num, acc, sizeof(acc));
+        d = bfe_mul(d, gen);
+    }
+    u64 dinv[3];
+    if (tfo_xfe_inverse(den, dinv)) return 2;
+    tfo_xfe_mul(num, dinv, out);
+    return 0;
+}
+
 /* ------------------------------------------------------------------ division (math/polynomial.rs) */
 
 /* Polynomial::naive_divide (polynomial.rs:552-600) over BFieldElement: quotient (max(na - nb + 1, 0) coefficients, untrimmed) and

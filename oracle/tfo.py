@@ -86,6 +86,7 @@ def lib() -> C.CDLL:
             "tfo_poly_lagrange_interpolate": (i32, [pu, pu, sz, i32, pu]),
             "tfo_poly_naive_divide_bfe": (i32, [pu, sz, pu, sz, pu, pu]),
             "tfo_poly_scale_xfe": (None, [pu, sz, pu]),
+            "tfo_barycentric_evaluate": (i32, [pu, sz, i32, pu, pu]),
             "tfo_poly_clean_divide_bfe": (i32, [pu, sz, pu, sz, sz, pu]),
             "tfo_fill_random": (None, [pu, sz, u64]),
             "tfo_digest_to_hex": (None, [pu, C.c_char_p]),
@@ -473,6 +474,20 @@ def coset_interpolate_xfe_offset(values, offset) -> np.ndarray:
     v = intt(_arr(values).reshape(-1), width=3)
     lib().tfo_poly_scale_xfe(_p(v), v.size // 3, _p(xfe_inverse(offset)))
     return v
+
+
+def barycentric_evaluate(codeword, indeterminate, width: int = 1) -> np.ndarray:
+    """barycentric_evaluate (math/polynomial.rs:2609-2637); the indeterminate as 1 (BFieldElement, lifted) or 3 raw words; the
+    result as an XFieldElement (limbs 1, 2 zero when everything is in the base field)."""
+    c = _arr(codeword).reshape(-1)
+    x = np.zeros(3, dtype=np.uint64)
+    xi = np.asarray(indeterminate, dtype=np.uint64).reshape(-1)
+    x[: xi.size] = xi
+    out = np.zeros(3, dtype=np.uint64)
+    rc = lib().tfo_barycentric_evaluate(_p(c if c.size else out), c.size // width, width, _p(x), _p(out))
+    if rc:
+        raise OraclePanic(4 if rc == 1 else 12)
+    return out
 
 
 def merkle_from_rows(rows, row_len: int) -> np.ndarray:

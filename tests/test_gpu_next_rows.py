@@ -825,3 +825,71 @@ def test_zerofier_tree_handle_on_device_buffers_and_errors(tf, oracle):
     closed.close()
     with pytest.raises(ValueError):
         closed.zerofier()
+
+
+# ---- barycentric evaluation (math/polynomial.rs:2609-2637) ---------------------------------------------------------------------
+@pytest.mark.parametrize("width", [1, 3])
+@pytest.mark.parametrize("log_n,batch", [(0, 1), (1, 2), (3, 3), (6, 5), (11, 4), (12, 1), (16, 3), (20, 1)])
+def test_barycentric_evaluate_matches_oracle_and_the_polynomial(tf, oracle, width, log_n, batch):
+    """barycentric_evaluate for a batch of codewords at one out-of-domain point, XFieldElement and BFieldElement indeterminates, against
+    the oracle's restatement (up to 2^12 points) and against the polynomial itself (the reference's property test :4593-4616:
+    codeword = the polynomial's values on the subgroup, barycentric value = polynomial.evaluate)."""
+    n = 1 << log_n
+    coeffs = oracle.fill_random(n * width * batch, 2200 + log_n)
+    cw = coeffs.copy()
+    tf.ntt(cw, width=width, batch=batch)  # values on <w_n>, natural order
+    for x in (oracle.fill_random(3, 2201 + log_n), np.array([oracle.bfe_new(987654321)], dtype=np.uint64)):
+        got = tf.barycentric_evaluate(cw, x, width=width, batch=batch)
+        base_field = width == 1 and x.size == 1
+        got = got.reshape(batch, 1 if base_field else 3)
+        x3 = np.zeros(3, dtype=np.uint64)
+        x3[: x.size] = x
+        for b in sorted({0, batch - 1}):
+            c_b = coeffs[b * n * width:(b + 1) * n * width]
+            if width == 1:
+                lifted = np.zeros(3 * n, dtype=np.uint64)
+                lifted[0::3] = c_b
+            else:
+                lifted = c_b
+            want = oracle.poly_eval_xfe_point(lifted, x3)
+            assert np.array_equal(got[b], want[:1] if base_field else want), (b, x.size)
+            if log_n <= 12:
+                o = oracle.barycentric_evaluate(cw[b * n * width:(b + 1) * n * width], x, width)
+                assert np.array_equal(got[b], o[:1] if base_field else o)
+                if base_field:
+                    assert not o[1:].any()
+
+
+def test_barycentric_evaluate_on_device_and_panics(tf, oracle):
+    import ctypes as C
+
+    import torch
+
+    n, batch = 1 << 14, 300
+    cw = torch.empty(n * batch, dtype=torch.int64, device="cuda")
+    tf.device.fill_random(cw, 41)
+    x = oracle.fill_random(3, 42)
+    out = torch.empty(3 * batch, dtype=torch.int64, device="cuda")
+    tf.device.barycentric_evaluate(cw, n, x, out, batch=batch)
+    # the same values through coset_extrapolate (offset 1: the subgroup itself) on lifted codewords' interpolants
+    ref = tf.Polynomial.batch_coset_extrapolate(oracle.bfe_new(1), n, _to_host(cw)[: 3 * n], np.array([oracle.bfe_new(5)], dtype=np.uint64))
+    b3 = tf.barycentric_evaluate(_to_host(cw)[: 3 * n], oracle.bfe_new(5), batch=3)
+    torch.cuda.synchronize()
+    assert np.array_equal(b3, ref)
+    got = _to_host(out).reshape(batch, 3)
+    for b in (0, 17, batch - 1):
+        assert np.array_equal(got[b], tf.barycentric_evaluate(_to_host(cw)[b * n:(b + 1) * n], x))
+    with pytest.raises(tf.NttPanic) as e:
+        tf.barycentric_evaluate(oracle.fill_random(12, 1), x)          # length not a power of two
+    assert e.value.code == 4
+    w = tf.BFieldElement.primitive_root_of_unity(16)
+    inside = oracle.bfe_mod_pow(w, 5)
+    with pytest.raises(tf.NttPanic) as e:
+        tf.barycentric_evaluate(oracle.fill_random(16, 2), inside)     # the indeterminate is a domain point
+    assert e.value.code == 12
+    assert tf.barycentric_evaluate(oracle.fill_random(16, 2), np.array([inside, 1, 0], dtype=np.uint64)).size == 3  # same limb 0, outside the base field
+    with pytest.raises(tf.NttPanic) as e:
+        tf.barycentric_evaluate(np.zeros(0, dtype=np.uint64), x)       # no points: the denominator is zero
+    assert e.value.code == 12
+    with pytest.raises(ValueError):
+        tf.device.barycentric_evaluate(cw, n, x, out[:-1], batch=batch)

@@ -637,3 +637,24 @@ def test_tip5_trace_starts_with_the_state_and_ends_with_the_permutation(oracle):
         assert np.array_equal(trace[5], oracle.tip5_permutation(s)) and np.array_equal(end, trace[5])
         assert np.array_equal(trace[5], oracle.tip5_permutation(s, naive=True))
         assert len({trace[r].tobytes() for r in range(6)}) == 6
+
+
+def test_barycentric_evaluation_equals_polynomial_evaluation(oracle):
+    """math/polynomial.rs:4593-4616 (polynomial_evaluation_and_barycentric_evaluation_are_equivalent) and :4630-4638 (all four
+    type combinations), through the oracle's restatement of barycentric_evaluate (:2609-2637)."""
+    tfo = oracle
+    for width in (1, 3):
+        for log_n in (0, 1, 4, 7):
+            n = 1 << log_n
+            c = tfo.fill_random(n * width, 60 + log_n)
+            cw = tfo.ntt(c, width=width)
+            for x in (tfo.fill_random(3, 61), np.array([tfo.bfe_new(424242), 0, 0], dtype=np.uint64)):
+                lifted = c
+                if width == 1:
+                    lifted = np.zeros(3 * n, dtype=np.uint64)
+                    lifted[0::3] = c
+                assert np.array_equal(tfo.barycentric_evaluate(cw, x, width), tfo.poly_eval_xfe_point(lifted, x))
+    with pytest.raises(tfo.OraclePanic):
+        tfo.barycentric_evaluate(tfo.fill_random(12, 1), tfo.fill_random(3, 2))      # not a power of two
+    with pytest.raises(tfo.OraclePanic):
+        tfo.barycentric_evaluate(tfo.fill_random(8, 1), np.array([tfo.bfe_new(1), 0, 0], dtype=np.uint64))  # 1 is in every subgroup

@@ -10,7 +10,7 @@ seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 budget = float(sys.argv[2]) if len(sys.argv) > 2 else 150.0
 rng = random.Random(seed)
 KINDS = ["ntt", "ntt", "coset", "coset", "interp", "mul", "merkle", "varlen", "eval", "extrap", "lde", "auth", "square", "mulb", "nttu", "interpu",
-         "zerofier", "lagrange", "treeeval", "cdiv", "xoff", "trace", "handle"]
+         "zerofier", "lagrange", "treeeval", "cdiv", "xoff", "trace", "handle", "bary"]
 if len(sys.argv) > 3:
     KINDS = sys.argv[3].split(",")
 import torch
@@ -208,6 +208,17 @@ while time.time() < t_end:
         i = rng.randrange(count)
         want, end = oracle.tip5_trace(s0[16 * i: 16 * i + 16])
         assert np.array_equal(tr[i], want) and np.array_equal(s[16 * i: 16 * i + 16], end), (kind, count, i)
+    elif kind == "bary":
+        log_n, batch = rng.randint(0, 12), rng.randint(1, 5)
+        n = 1 << log_n
+        cw = oracle.fill_random(n * width * batch, rng.getrandbits(40))
+        x = oracle.fill_random(3, rng.getrandbits(40)) if rng.random() < 0.7 else np.array([oracle.bfe_new(rng.randrange(2, P))], dtype=np.uint64)
+        if x.size == 1 and oracle.bfe_mod_pow(int(x[0]), n) == oracle.bfe_new(1):
+            continue
+        got = tf.barycentric_evaluate(cw, x, width=width, batch=batch).reshape(batch, -1)
+        b = rng.randrange(batch)
+        want = oracle.barycentric_evaluate(cw[b * n * width:(b + 1) * n * width], x, width)
+        assert np.array_equal(got[b], want[: got.shape[1]]), (kind, log_n, width, batch, x.size)
     elif kind == "handle":
         n = rng.choice([rng.randint(1, 300), rng.randint(300, 4000)])
         d = oracle.fill_random(n * width, rng.getrandbits(40))

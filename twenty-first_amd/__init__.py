@@ -26,7 +26,7 @@ import numpy as np
 from . import _lib
 
 __all__ = [
-    "P", "BFieldElement", "ntt", "intt", "Polynomial", "ZerofierTree", "fast_coset_evaluate", "fast_coset_interpolate", "fast_multiply", "fast_square", "Tip5", "Tip5Sponge", "Digest", "MerkleTree",
+    "P", "BFieldElement", "ntt", "intt", "Polynomial", "ZerofierTree", "barycentric_evaluate", "fast_coset_evaluate", "fast_coset_interpolate", "fast_multiply", "fast_square", "Tip5", "Tip5Sponge", "Digest", "MerkleTree",
     "MerkleTreeError", "TwentyFirstError", "NttPanic", "lib", "device",
 ]
 
@@ -342,6 +342,28 @@ class Polynomial:
         if self.degree() < 0 or other.degree() < 0:
             return Polynomial(np.zeros(0, dtype=np.uint64), width=self.width)
         return Polynomial(fast_multiply(self.coefficients, other.coefficients, width=self.width), width=self.width)
+
+
+def barycentric_evaluate(codewords: np.ndarray, indeterminate, width: int = 1, batch: int = 1) -> np.ndarray:
+    """math/polynomial.rs:2609-2637 for `batch` codewords of equal length at one indeterminate (an int / one raw word: BFieldElement;
+    three raw words: XFieldElement).  Returns batch x 3 raw words (XFieldElements), or batch words when codewords and indeterminate
+    are both in the base field (the reference's BFieldElement result).  Panics (NttPanic) unless the length is a power of two, and
+    when the indeterminate lies in the evaluation domain."""
+    cw = _words(np.ascontiguousarray(codewords, dtype=np.uint64).reshape(-1), "codewords")
+    if width not in (1, 3) or batch < 0 or (batch and cw.size % (batch * width)):
+        raise ValueError("codewords size is not batch * n * width")
+    n = cw.size // (batch * width) if batch else 0
+    xi = np.asarray([indeterminate] if isinstance(indeterminate, (int, np.integer)) else indeterminate, dtype=np.uint64).reshape(-1)
+    if xi.size not in (1, 3):
+        raise ValueError("the indeterminate is one raw word (BFieldElement) or three (XFieldElement)")
+    x = np.zeros(3, dtype=np.uint64)
+    x[: xi.size] = xi
+    out = np.zeros(3 * batch, dtype=np.uint64)
+    fn = lib().tf_barycentric_evaluate_bfe if width == 1 else lib().tf_barycentric_evaluate_xfe
+    _check(fn(_ptr(cw), n, batch, _ptr(x), _ptr(out)), "barycentric_evaluate")
+    if width == 1 and xi.size == 1:
+        return np.ascontiguousarray(out.reshape(batch, 3)[:, 0])
+    return out
 
 
 class ZerofierTree:

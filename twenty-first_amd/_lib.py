@@ -67,6 +67,10 @@ SIGNATURES = {
     "tf_coset_interpolate_xfe_xoffset": (C.c_int, [_vp, _sz, _vp, _vp, _sz]),
     "tf_coset_eval_xfe_xoffset_dev": (C.c_int, [_vp, _sz, _vp, _vp, _sz, _sz, _vp]),
     "tf_coset_interpolate_xfe_xoffset_dev": (C.c_int, [_vp, _sz, _vp, _vp, _sz, _vp]),
+    "tf_barycentric_evaluate_bfe": (C.c_int, [_vp, _sz, _sz, _vp, _vp]),
+    "tf_barycentric_evaluate_xfe": (C.c_int, [_vp, _sz, _sz, _vp, _vp]),
+    "tf_barycentric_evaluate_bfe_dev": (C.c_int, [_vp, _sz, _sz, _vp, _vp, _vp]),
+    "tf_barycentric_evaluate_xfe_dev": (C.c_int, [_vp, _sz, _sz, _vp, _vp, _vp]),
     "tf_poly_clean_divide_bfe": (C.c_int, [_vp, _sz, _vp, _sz, _vp]),
     "tf_poly_clean_divide_bfe_dev": (C.c_int, [_vp, _sz, _vp, _sz, _vp, _vp]),
     "tf_zerofier_tree_new_bfe": (C.c_int, [_vp, _sz, C.POINTER(C.c_void_p)]),

@@ -2526,6 +2526,56 @@ int coset_interp_xoffset_dev(const u64* d_values, size_t n, const u64 offset[3],
     return TF_OK;
 }
 
+// barycentric_evaluate (polynomial.rs:2609-2637) for `batch` codewords of length n (a power of two) at ONE indeterminate
+// (3 raw words; a BFieldElement as [x, 0, 0]): out[b] = interpolant_b(x) as an XFieldElement.  cw_width 1 / 3 = the codewords'
+// field.  Where the reference panics: n not a power of two (primitive_root_of_unity(..).unwrap()) -> TF_ERR_LEN_NOT_POWER_OF_TWO;
+// x inside the subgroup, or n = 0 (batch_inversion / inverse of zero) -> TF_ERR_INVERSE_OF_ZERO.
+int barycentric_dev(const u64* codewords, size_t n, size_t batch, int cw_width, const u64 x[3], u64* out, void* stream) {
+    int rc = check_len(n);
+    if (rc) return rc;
+    if (!x) return TF_ERR_NULL_POINTER;
+    if (n == 0) return TF_ERR_INVERSE_OF_ZERO;  // the empty sums: denominator.inverse() of zero
+    if (x[1] == 0 && x[2] == 0 && gl::mont_pow(x[0], (u64)n) == gl::ONE) return TF_ERR_INVERSE_OF_ZERO;  // x = w^i for some i
+    if (batch == 0) return TF_OK;
+    if (!codewords || !out) return TF_ERR_NULL_POINTER;
+    DeviceCtx* ctx = nullptr;
+    rc = current_ctx(&ctx);
+    if (rc) return rc;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const long long per_chunk = (long long)tfk::kBaryPerThread * 256, n_chunks = ((long long)n + per_chunk - 1) / per_chunk;
+    u64* tmp = nullptr;  // weights (3 n) + partial sums ((batch + 1) n_chunks 3)
+    const size_t words = 3 * n + 3 * (batch + 1) * (size_t)n_chunks;
+    hipError_t e = hipMallocAsync(reinterpret_cast<void**>(&tmp), words * sizeof(u64), s);
+    if (e != hipSuccess) return hip_fail(e, "hipMallocAsync(barycentric)", __FILE__, __LINE__);
+    u64* w = tmp;
+    u64* partial = tmp + 3 * n;
+    const int log_n = ilog2(n);
+    const u64 omega = root_of_unity_mont(log_n);
+    hipLaunchKernelGGL(tfk::barycentric_weights_kernel, dim3((unsigned)n_chunks), dim3(256), 0, s, (long long)n, log_n, omega, gl::mont_pow(omega, 256),
+                       x[0], x[1], x[2], w);
+    {
+        static const int rows_env = [] { const char* e = getenv("TF_BARY_ROWS"); const int v = e ? atoi(e) : 0; return (v >= 1 && v <= tfk::kBaryRows) ? v : 0; }();
+        const int rpb = rows_env ? rows_env : 2;  // rows per block (A/B: tools/barycentric_bench.py; 1 / 2 / 4 within 3 % of each other)
+        const long long row_groups = ((long long)batch + 1 + rpb - 1) / rpb;  // the denominator is row `batch`
+        if (row_groups > 65535) rc = TF_ERR_LEN_TOO_LARGE;  // more than 65 534 codewords in one call
+        else if (cw_width == 1)
+            hipLaunchKernelGGL(tfk::barycentric_partial_kernel<1>, dim3((unsigned)n_chunks, (unsigned)row_groups), dim3(256), 0, s, codewords,
+                               (const u64*)w, (long long)n, (long long)batch, partial, rpb);
+        else
+            hipLaunchKernelGGL(tfk::barycentric_partial_kernel<3>, dim3((unsigned)n_chunks, (unsigned)row_groups), dim3(256), 0, s, codewords,
+                               (const u64*)w, (long long)n, (long long)batch, partial, rpb);
+        if (!rc && hipGetLastError() != hipSuccess) rc = TF_ERR_HIP;
+    }
+    if (!rc) {
+        hipLaunchKernelGGL(tfk::barycentric_finish_kernel, dim3((unsigned)batch), dim3(64), 0, s, (const u64*)partial, n_chunks, (long long)batch, out);
+        if (hipGetLastError() != hipSuccess) rc = TF_ERR_HIP;
+    }
+    hipError_t e2 = hipFreeAsync(tmp, s);
+    if (rc) return rc;
+    if (e2 != hipSuccess) return hip_fail(e2, "hipFreeAsync", __FILE__, __LINE__);
+    return TF_OK;
+}
+
 // Polynomial::<BFieldElement>::clean_divide (polynomial.rs:2358-2411): a / b for b | a, by pointwise division on the coset
 // X * <w_order> of the extension field (poly_kernels.h).  a, b: normalised coefficient arrays (non-zero leading coefficient),
 // out: na - nb + 1 coefficients.  The reference's factor-x workaround (:2368-2378) changes nothing on this coset (X w^i != 0) and
@@ -3224,6 +3274,24 @@ int tf_coset_interpolate_xfe_xoffset(const uint64_t* v, size_t n, const uint64_t
     return host_roundtrip(v, 3 * n * batch, nullptr, 0, out, 3 * n * batch,
                           [&](u64* dv, u64*, u64* o, hipStream_t s) { return coset_interp_xoffset_dev(dv, n, offset, o, batch, s); });
 }
+int tf_barycentric_evaluate_bfe_dev(const uint64_t* cw, size_t n, size_t batch, const uint64_t x[3], uint64_t* out, void* stream) {
+    return barycentric_dev(cw, n, batch, 1, x, out, stream);
+}
+int tf_barycentric_evaluate_xfe_dev(const uint64_t* cw, size_t n, size_t batch, const uint64_t x[3], uint64_t* out, void* stream) {
+    return barycentric_dev(cw, n, batch, 3, x, out, stream);
+}
+static int barycentric_host(const uint64_t* cw, size_t n, size_t batch, int width, const uint64_t x[3], uint64_t* out) {
+    int rc = check_len(n);
+    if (rc) return rc;
+    if (!x) return TF_ERR_NULL_POINTER;
+    if (n == 0) return TF_ERR_INVERSE_OF_ZERO;
+    if (batch == 0) return barycentric_dev(nullptr, n, 0, width, x, nullptr, nullptr);  // the argument checks alone
+    if (!cw || !out) return TF_ERR_NULL_POINTER;
+    return host_roundtrip(cw, batch * n * width, nullptr, 0, out, 3 * batch,
+                          [&](u64* dc, u64*, u64* o, hipStream_t s) { return barycentric_dev(dc, n, batch, width, x, o, s); });
+}
+int tf_barycentric_evaluate_bfe(const uint64_t* cw, size_t n, size_t batch, const uint64_t x[3], uint64_t* out) { return barycentric_host(cw, n, batch, 1, x, out); }
+int tf_barycentric_evaluate_xfe(const uint64_t* cw, size_t n, size_t batch, const uint64_t x[3], uint64_t* out) { return barycentric_host(cw, n, batch, 3, x, out); }
 int tf_poly_clean_divide_bfe_dev(const uint64_t* a, size_t na, const uint64_t* b, size_t nb, uint64_t* out, void* stream) {
     return clean_divide_dev(a, na, b, nb, out, stream);
 }

@@ -220,6 +220,21 @@ def interpolate(domain, values, out, rows: int = 1, width: int = 1, stream=None)
     _chk(fn(_p(domain), _p(values), n, rows, _p(out), _stream(stream)), "interpolate")
 
 
+def barycentric_evaluate(codewords, n: int, indeterminate, out, batch: int = 1, width: int = 1, stream=None) -> None:
+    """barycentric_evaluate (math/polynomial.rs:2609-2637) on device buffers: `batch` codewords of n elements at one indeterminate
+    (3 raw words, host side) -> out = batch x 3 words."""
+    import numpy as np
+
+    codewords, out = _t(codewords, "codewords"), _t(out, "out")
+    _need(codewords.numel() == batch * n * _width(width) and out.numel() == 3 * batch, "codewords = batch * n elements, out = batch XFieldElements")
+    x = np.zeros(3, dtype=np.uint64)
+    xi = np.asarray(indeterminate, dtype=np.uint64).reshape(-1)
+    _need(xi.size in (1, 3), "the indeterminate is one raw word or three")
+    x[: xi.size] = xi
+    fn = _lib.lib().tf_barycentric_evaluate_bfe_dev if width == 1 else _lib.lib().tf_barycentric_evaluate_xfe_dev
+    _chk(fn(_p(codewords), n, batch, C.c_void_p(x.ctypes.data), _p(out), _stream(stream)), "barycentric_evaluate")
+
+
 class ZerofierTree:
     """math/zerofier_tree.rs on device buffers: the tree of a device-resident domain, kept in HBM across calls
     (tf_zerofier_tree_* of include/tf_hip.h).  close() (or the context manager) releases the device memory."""

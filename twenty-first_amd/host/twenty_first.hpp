@@ -233,6 +233,19 @@ struct Polynomial {
     }
 };
 
+// ---- barycentric_evaluate (math/polynomial.rs:2609-2637): every codeword of a batch at one indeterminate ------------------
+template <class Coeff>
+inline std::vector<XFieldElement> barycentric_evaluate(const std::vector<Coeff>& codewords, size_t codeword_length, XFieldElement indeterminate) {
+    const size_t batch = codeword_length ? codewords.size() / codeword_length : 0;
+    std::vector<XFieldElement> out(batch);
+    const uint64_t* c = reinterpret_cast<const uint64_t*>(codewords.data());
+    const uint64_t* x = reinterpret_cast<const uint64_t*>(&indeterminate);
+    uint64_t* o = reinterpret_cast<uint64_t*>(out.data());
+    if constexpr (sizeof(Coeff) == 8) check(tf_barycentric_evaluate_bfe(c, codeword_length, batch, x, o), "barycentric_evaluate");
+    else check(tf_barycentric_evaluate_xfe(c, codeword_length, batch, x, o), "barycentric_evaluate");
+    return out;
+}
+
 // ---- ZerofierTree (math/zerofier_tree.rs): the tree of a domain, built once and kept in HBM -----------------------------
 template <class FF>
 struct ZerofierTree {
