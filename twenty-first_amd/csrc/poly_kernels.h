@@ -184,9 +184,12 @@ __global__ void __launch_bounds__(256) poly_reverse_kernel(const u64* Qr, long l
     for (int k = 0; k < L; ++k) q[i * L + k] = Qr[(node * qr_stride + (d - 1 - j)) * L + k];
 }
 
-// r[child][j] = f[child / 2][j] - S[child][j], j < d  (S polynomials s_stride elements apart)
+// r[child][j] = f[child / 2][j] - S[child][j], j < d  (S polynomials s_stride elements apart).  When fr_next is given, the upper
+// half of r is also written reversed for BOTH grandchildren (the first step of the next level down, remainder_rev_high_kernel with
+// d / 2): fr_next[2 child + s][k] = r[child][d - 1 - k], k < d / 2 -- one launch per level less.
 template <int L>
-__global__ void __launch_bounds__(256) remainder_finish_kernel(const u64* f, const u64* S, long long s_stride, u64* r, long long d, long long children) {
+__global__ void __launch_bounds__(256) remainder_finish_kernel(const u64* f, const u64* S, long long s_stride, u64* r, long long d, long long children,
+                                                               u64* fr_next) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= children * d) return;
     const long long child = i / d, j = i - child * d;
@@ -195,6 +198,11 @@ __global__ void __launch_bounds__(256) remainder_finish_kernel(const u64* f, con
     fe_load<L>(S + (child * s_stride + j) * L, b);
     fe_sub<L>(a, b, v);
     fe_store<L>(r + i * L, v);
+    if (fr_next && j >= d / 2) {
+        const long long h = d / 2, k = d - 1 - j;
+        fe_store<L>(fr_next + ((2 * child) * h + k) * L, v);
+        fe_store<L>(fr_next + ((2 * child + 1) * h + k) * L, v);
+    }
 }
 
 // ---- levels in the transform domain (round 2) -------------------------------------------------------------------------------

@@ -1984,11 +1984,17 @@ int zerofier_tree_evaluate(DeviceCtx* ctx, const ZerofierTree& T, const u64* F, 
     u64* fr = work + 2 * M * L;     // children x d      reversed upper halves, then the quotients
     u64* Fh = work + 3 * M * L;     // children x 2d     their transforms
     u64* prod = work + 5 * M * L;   // children x 2d     products back in the coefficient domain
+    u64* frq = work + 7 * M * L;    // children x d      the next level's reversed upper halves, written by this level's last kernel
     for (int l = T.h - 1; l >= 0; --l) {
         const long long d = (long long)kTreeLeaf << l, children = M / d;
-        // rev(q) = rev(f_high) g mod x^d
-        int rc = launch_1d<L>(tfk::remainder_rev_high_kernel<L>, children * d, s, cur, fr, d, children);
-        if (!rc) rc = run_ntt(ctx, fr, Fh, d * L, 2 * d * L, (size_t)(2 * d), (size_t)children, L, false, nullptr, d, s);
+        // rev(q) = rev(f_high) g mod x^d   (below the top level the reversed upper halves come from the level above's last kernel)
+        int rc = TF_OK;
+        const u64* fr_in = frq;
+        if (l == T.h - 1) {
+            rc = launch_1d<L>(tfk::remainder_rev_high_kernel<L>, children * d, s, cur, fr, d, children);
+            fr_in = fr;
+        }
+        if (!rc) rc = run_ntt(ctx, fr_in, Fh, d * L, 2 * d * L, (size_t)(2 * d), (size_t)children, L, false, nullptr, d, s);
         if (!rc) rc = inverse_of_product<L>(ctx, Fh, T.Ghat[l], 2 * d * L, prod, (size_t)(2 * d), (size_t)children, false, s);
         if (!rc) rc = launch_1d<L>(tfk::poly_reverse_kernel<L>, children * d, s, (const u64*)prod, 2 * d, fr, d, children);
         // r = f_low - (q tail)_low
@@ -1996,7 +2002,7 @@ int zerofier_tree_evaluate(DeviceCtx* ctx, const ZerofierTree& T, const u64* F, 
         if (!rc) rc = inverse_of_product<L>(ctx, Fh, T.That[l], 2 * d * L, prod, (size_t)(2 * d), (size_t)children, false, s);
         if (rc) return rc;
         u64* nxt = (cur == ping) ? pong : ping;
-        rc = launch_1d<L>(tfk::remainder_finish_kernel<L>, children * d, s, cur, (const u64*)prod, 2 * d, nxt, d, children);
+        rc = launch_1d<L>(tfk::remainder_finish_kernel<L>, children * d, s, cur, (const u64*)prod, 2 * d, nxt, d, children, l > 0 ? frq : (u64*)nullptr);
         if (rc) return rc;
         cur = nxt;
     }
