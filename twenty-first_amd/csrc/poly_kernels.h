@@ -8,9 +8,9 @@
 //     monic zerofiers stored without their leading 1 ("tails") beside its forward transforms of order 2d, so every product /
 //     remainder of a level is a batched transform, a pointwise kernel and a batched inverse transform (tf_hip.hip: zerofier_tree_*);
 //   * a remainder f mod Z (deg f < 2d, deg Z = d) is taken with the power-series inverse g of rev(Z) mod x^d:
-//     rev(q) = rev(f_high) * g mod x^d,  r = f_low - (q * tail(Z))_low   (two products of size d x d);
-//     g of a parent = g_left * g_right (precision d) followed by one Newton step to precision 2d, so the inverses cost three
-//     products per level and no division is ever done from scratch;
+//     rev(q) = rev(f_high) * g mod x^d,  r = f_low - (q * tail(Z))_low   (two products of size d x d against cached transforms);
+//     g of a parent = g_left * g_right (precision d) followed by one Newton step to precision 2d at order 4d, so no division is
+//     ever done from scratch;
 //   * the reference's reduce_by_ntt_friendly_modulus (:1087-1142) serves the same purpose on the CPU (a cheap first reduction
 //     when deg f >> m); here a polynomial longer than the padded point count M is cut into chunks of M coefficients which go
 //     down the tree together and are recombined per point with powers of x^M.
@@ -108,38 +108,6 @@ __global__ void __launch_bounds__(kLeafMax) leaf_zerofier_kernel(const u64* poin
     }
 }
 
-// tails of the parents from the product P = tail_left * tail_right (2d - 1 coefficients, packed) and the children's tails:
-//   (x^d + A)(x^d + B) = x^2d + (A + B) x^d + A B   ->   out[j] = P[j] (j < 2d - 1) + (A + B)[j - d] (j >= d),  j < 2d
-template <int L>
-__global__ void __launch_bounds__(256) zerofier_combine_kernel(const u64* P, const u64* child_tails, u64* out, long long d, long long n_parents) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_parents * 2 * d) return;
-    const long long node = i / (2 * d), j = i - node * 2 * d;
-    u64 v[L];
-#pragma unroll
-    for (int k = 0; k < L; ++k) v[k] = j < 2 * d - 1 ? P[(node * (2 * d - 1) + j) * L + k] : 0;
-    if (j >= d) {
-        u64 a[L], b[L], s[L], r[L];
-        fe_load<L>(child_tails + ((2 * node) * d + (j - d)) * L, a);
-        fe_load<L>(child_tails + ((2 * node + 1) * d + (j - d)) * L, b);
-        fe_add<L>(a, b, s);
-        fe_add<L>(v, s, r);
-        fe_store<L>(out + i * L, r);
-    } else {
-        fe_store<L>(out + i * L, v);
-    }
-}
-
-// H = rev(Z) to precision len (= deg Z): H[0] = 1, H[k] = tail[len - k]
-template <int L>
-__global__ void __launch_bounds__(256) zerofier_reverse_kernel(const u64* tails, u64* H, long long len, long long nodes) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nodes * len) return;
-    const long long node = i / len, k = i - node * len;
-#pragma unroll
-    for (int q = 0; q < L; ++q) H[i * L + q] = k == 0 ? (q ? 0 : gl::ONE) : tails[(node * len + (len - k)) * L + q];
-}
-
 // dst[node][k] = src[node][k], k < len  (src polynomials src_stride elements apart): truncation mod x^len
 template <int L>
 __global__ void __launch_bounds__(256) poly_truncate_kernel(const u64* src, long long src_stride, u64* dst, long long len, long long nodes) {
@@ -148,20 +116,6 @@ __global__ void __launch_bounds__(256) poly_truncate_kernel(const u64* src, long
     const long long node = i / len, k = i - node * len;
 #pragma unroll
     for (int q = 0; q < L; ++q) dst[i * L + q] = src[(node * src_stride + k) * L + q];
-}
-
-// E = 2 - T mod x^len  (T polynomials t_stride elements apart): the Newton step g <- g (2 - h g)
-template <int L>
-__global__ void __launch_bounds__(256) newton_two_minus_kernel(const u64* T, long long t_stride, u64* E, long long len, long long nodes) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nodes * len) return;
-    const long long node = i / len, k = i - node * len;
-    u64 tv[L], z[L], r[L];
-    fe_load<L>(T + (node * t_stride + k) * L, tv);
-#pragma unroll
-    for (int q = 0; q < L; ++q) z[q] = (k == 0 && q == 0) ? gl::add(gl::ONE, gl::ONE) : 0;
-    fe_sub<L>(z, tv, r);
-    fe_store<L>(E + i * L, r);
 }
 
 // fr[child][k] = f[child / 2][2d - 1 - k], k < d: the reversed upper halves of the parents' remainders, once per child

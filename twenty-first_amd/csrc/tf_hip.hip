@@ -1735,17 +1735,9 @@ int pad_copy(const u64* src, u64* dst, long long n_src_words, long long n_dst_wo
 // Polynomial::fast_multiply (polynomial.rs:900-932): zero-pad both to order = next_power_of_two(deg a + deg b + 1),
 // ntt both, pointwise product, intt, truncate to na + nb - 1 coefficients.  (The reference then trims leading zero
 // coefficients in Polynomial::new; the caller does that -- the length here is data independent.)
-// a_bs / b_bs: words between consecutive polynomials of the batch (0: packed, na * L / nb * L) -- the zerofier tree multiplies
-// the even-numbered nodes of a level by the odd-numbered ones in place.
-// work: caller-provided space of poly_mul_work_words(na, nb, batch, L) words (the zerofier tree calls this ~100 times per
-// evaluation and hands every call the same block), nullptr = a stream-ordered temporary.
-size_t poly_mul_work_words(size_t na, size_t nb, size_t batch, int L) {
-    size_t order = 1;
-    while (order < na + nb - 1) order <<= 1;
-    return 2 * batch * order * size_t(L);
-}
+// a_bs / b_bs: words between consecutive polynomials of the batch (0: packed, na * L / nb * L).
 int poly_mul_dev(const u64* a, size_t na, const u64* b, size_t nb, u64* out, size_t batch, int L, void* stream, long long a_bs = 0,
-                 long long b_bs = 0, u64* work = nullptr) {
+                 long long b_bs = 0) {
     if (batch == 0 || na == 0 || nb == 0) return TF_OK;  // a zero polynomial: empty product
     if (!a_bs) a_bs = (long long)na * L;
     if (!b_bs) b_bs = (long long)nb * L;
@@ -1759,12 +1751,10 @@ int poly_mul_dev(const u64* a, size_t na, const u64* b, size_t nb, u64* out, siz
     rc = current_ctx(&ctx);
     if (rc) return rc;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    u64* tmp = work;
+    u64* tmp = nullptr;
     const size_t half = batch * order * size_t(L);
-    if (!work) {
-        hipError_t e = hipMallocAsync(reinterpret_cast<void**>(&tmp), 2 * half * sizeof(u64), s);
-        if (e != hipSuccess) return hip_fail(e, "hipMallocAsync(poly_mul)", __FILE__, __LINE__);
-    }
+    hipError_t e = hipMallocAsync(reinterpret_cast<void**>(&tmp), 2 * half * sizeof(u64), s);
+    if (e != hipSuccess) return hip_fail(e, "hipMallocAsync(poly_mul)", __FILE__, __LINE__);
     static const bool no_fuse = getenv("TF_POLY_MUL_NO_FUSE") != nullptr;  // A/B switch
     bool copied = false;
     if (order > 16 && !no_fuse) {
@@ -1792,7 +1782,7 @@ int poly_mul_dev(const u64* a, size_t na, const u64* b, size_t nb, u64* out, siz
         if (!rc) rc = run_ntt(ctx, tmp, tmp, (long long)order * L, (long long)order * L, order, batch, L, true, nullptr, -1, s);
     }
     if (!rc && !copied) rc = pad_copy(tmp, out, (long long)order * L, (long long)n_out * L, (long long)batch, s);
-    hipError_t e2 = work ? hipSuccess : hipFreeAsync(tmp, s);
+    hipError_t e2 = hipFreeAsync(tmp, s);
     if (rc) return rc;
     if (e2 != hipSuccess) return hip_fail(e2, "hipFreeAsync", __FILE__, __LINE__);
     return TF_OK;
