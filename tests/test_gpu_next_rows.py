@@ -893,3 +893,58 @@ def test_barycentric_evaluate_on_device_and_panics(tf, oracle):
     assert e.value.code == 12
     with pytest.raises(ValueError):
         tf.device.barycentric_evaluate(cw, n, x, out[:-1], batch=batch)
+
+
+@pytest.mark.parametrize("width,log_n", [(1, 22), (3, 21)])
+def test_tree_round_trips_at_millions_of_points(tf, oracle, width, log_n):
+    """Size-independent properties at sizes the O(n^2) oracle cannot reach: evaluate -> interpolate is the identity on 2^22 (BFE) /
+    2^21 (XFE) random points, and the zerofier of the points vanishes on all of them (polynomial.rs:3470-3483, :3602-3612)."""
+    import torch
+
+    n = 1 << log_n
+    dom = torch.empty(n * width, dtype=torch.int64, device="cuda")
+    f = torch.empty(n * width, dtype=torch.int64, device="cuda")
+    tf.device.fill_random(dom, 51)
+    tf.device.fill_random(f, 52)
+    vals, back = torch.empty_like(f), torch.empty_like(f)
+    tf.device.batch_evaluate(f, n, dom, vals, width=width)
+    tf.device.interpolate(dom, vals, back, width=width)
+    z = torch.empty((n + 1) * width, dtype=torch.int64, device="cuda")
+    tf.device.zerofier(dom, z, width=width)
+    zv = torch.empty_like(dom)
+    tf.device.batch_evaluate(z, n + 1, dom, zv, width=width)
+    torch.cuda.synchronize()
+    assert torch.equal(back, f)
+    assert not zv.any().item()
+    i = 12345
+    c, p = _to_host(f), _to_host(dom)
+    want = oracle.poly_eval(c, int(p[i])) if width == 1 else oracle.poly_eval_xfe_point(c, p[3 * i: 3 * i + 3])
+    assert np.array_equal(_to_host(vals)[i * width:(i + 1) * width], np.asarray(want).reshape(-1))
+
+
+def test_horner_route_with_more_points_than_one_launch_takes(tf, oracle):
+    """A short polynomial at 2^23 + 5 points stays on the Horner route, which walks the points in slabs of 2^22 (a launch is
+    limited to 2^32 - 1 threads); sampled points across the slab boundaries against the oracle, two polynomials in the batch."""
+    import torch
+
+    m = (1 << 23) + 5
+    pts = torch.empty(m, dtype=torch.int64, device="cuda")
+    tf.device.fill_random(pts, 61)
+    c = oracle.fill_random(2 * 1500, 62)   # two polynomials of 1500 coefficients: the workgroup-per-point kernel
+    dc = _to_dev(c)
+    out = torch.empty(2 * m, dtype=torch.int64, device="cuda")
+    lib = tf.lib()
+    lib.tf_set_batch_eval_route(1)
+    try:
+        short = torch.empty(m, dtype=torch.int64, device="cuda")
+        tf.device.batch_evaluate(dc[:7], 7, pts, short)   # lane-per-point kernel, 7 coefficients
+        for b in range(2):
+            tf.device.batch_evaluate(dc[b * 1500:(b + 1) * 1500], 1500, pts, out[b * m:(b + 1) * m])
+    finally:
+        lib.tf_set_batch_eval_route(0)
+    torch.cuda.synchronize()
+    hp = _to_host(pts)
+    for i in (0, (1 << 22) - 1, 1 << 22, (1 << 23) - 1, 1 << 23, m - 1):
+        assert int(_to_host(short[i:i + 1])[0]) == int(oracle.poly_eval(c[:7], int(hp[i]))[0])
+        for b in range(2):
+            assert int(_to_host(out[b * m + i: b * m + i + 1])[0]) == int(oracle.poly_eval(c[b * 1500:(b + 1) * 1500], int(hp[i]))[0])

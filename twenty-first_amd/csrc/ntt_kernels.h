@@ -1136,7 +1136,7 @@ __device__ __forceinline__ void fe_mul(const u64 (&a)[L], const u64 (&b)[L], u64
 // Lane per point: the right shape for short polynomials at many points.  grid = (ceil(m / 256), batch).
 template <int L>
 __global__ void __launch_bounds__(256) batch_evaluate_kernel(const u64* coeffs, long long n_coeffs, long long poly_stride,
-                                                            const u64* points, long long n_points, u64* out) {
+                                                            const u64* points, long long n_points, u64* out, long long out_stride) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_points) return;
     const u64* c = coeffs + (long long)blockIdx.y * poly_stride;
@@ -1149,7 +1149,7 @@ __global__ void __launch_bounds__(256) batch_evaluate_kernel(const u64* coeffs, 
 #pragma unroll
         for (int k = 0; k < L; ++k) acc[k] = gl::add(t[k], c[L * j + k]);
     }
-    u64* o = out + ((long long)blockIdx.y * n_points + i) * L;
+    u64* o = out + ((long long)blockIdx.y * out_stride + i) * L;  // out_stride: the points of the whole call (a launch may be a slab of them)
 #pragma unroll
     for (int k = 0; k < L; ++k) o[k] = acc[k];
 }
@@ -1159,7 +1159,7 @@ __global__ void __launch_bounds__(256) batch_evaluate_kernel(const u64* coeffs, 
 //   f(x) = sum_t x^t * sum_j c[t + 256 j] X^j.   grid = (m, batch).
 template <int L>
 __global__ void __launch_bounds__(256) batch_evaluate_split_kernel(const u64* coeffs, long long n_coeffs, long long poly_stride,
-                                                                  const u64* points, long long n_points, u64* out) {
+                                                                  const u64* points, long long n_points, u64* out, long long out_stride) {
     __shared__ u64 part[256 * L];
     const int t = threadIdx.x;
     const long long i = blockIdx.x;
@@ -1202,7 +1202,7 @@ __global__ void __launch_bounds__(256) batch_evaluate_split_kernel(const u64* co
         }
         __syncthreads();
     }
-    if (t < L) out[((long long)blockIdx.y * n_points + i) * L + t] = part[t];
+    if (t < L) out[((long long)blockIdx.y * out_stride + i) * L + t] = part[t];
 }
 
 // out[0] = shader cycles, out[1] = wall-clock ticks spent in a fixed spin (tf_debug_sclk_mhz)

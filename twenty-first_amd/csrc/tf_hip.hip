@@ -2024,7 +2024,7 @@ bool tree_route(size_t n_coeffs, size_t n_points, size_t batch, int L) {
         int h = 0;
         for (size_t v = kTreeLeaf; v < M; v <<= 1) ++h;
         const size_t arena_words = (size_t)(kTreeLevelArrays * h + kTreeWorkArrays + 1 + (n_coeffs + M - 1) / M) * M * (size_t)L;  // batch_evaluate_tree_t's arena
-        if (arena_words * sizeof(u64) > (size_t(8) << 30)) return false;  // the tree's levels would not fit a sane work space
+        if (arena_words * sizeof(u64) > (size_t(64) << 30)) return false;  // the tree's levels would not fit a sane work space (288 GB of HBM)
     }
     if (force && !strcmp(force, "tree")) return true;
     // Cost model fitted to tools/batch_eval_sweep.py on MI355X (profiles/r02_batch_eval_sweep.txt), milliseconds:
@@ -2125,26 +2125,32 @@ int batch_evaluate_horner(const u64* coeffs, size_t n_coeffs, size_t poly_stride
                           int L, void* stream) {
     if (n_points == 0 || batch == 0) return TF_OK;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const bool split = n_coeffs >= 1024 && n_points < (size_t(1) << 31);
-    // grid.y is limited to 65535: walk the batch in slabs
+    const bool split = n_coeffs >= 1024;
+    // grid.y is limited to 65535 and a launch to 2^32 - 1 threads: walk the batch and the points in slabs
+    const size_t point_slab = size_t(1) << 22;
     for (size_t b0 = 0; b0 < batch; b0 += 65535) {
         const unsigned nb = (unsigned)std::min<size_t>(65535, batch - b0);
-        const u64* c = coeffs + b0 * poly_stride;
-        u64* o = out + b0 * n_points * size_t(L);
-        const dim3 grid = split ? dim3((unsigned)n_points, nb) : dim3((unsigned)((n_points + 255) / 256), nb);
-        if (split && L == 1)
-            hipLaunchKernelGGL(tfk::batch_evaluate_split_kernel<1>, grid, dim3(256), 0, s, c, (long long)n_coeffs, (long long)poly_stride,
-                               points, (long long)n_points, o);
-        else if (split)
-            hipLaunchKernelGGL(tfk::batch_evaluate_split_kernel<3>, grid, dim3(256), 0, s, c, (long long)n_coeffs, (long long)poly_stride,
-                               points, (long long)n_points, o);
-        else if (L == 1)
-            hipLaunchKernelGGL(tfk::batch_evaluate_kernel<1>, grid, dim3(256), 0, s, c, (long long)n_coeffs, (long long)poly_stride,
-                               points, (long long)n_points, o);
-        else
-            hipLaunchKernelGGL(tfk::batch_evaluate_kernel<3>, grid, dim3(256), 0, s, c, (long long)n_coeffs, (long long)poly_stride,
-                               points, (long long)n_points, o);
-        HIPCHK(hipGetLastError());
+        for (size_t p0 = 0; p0 < n_points; p0 += point_slab) {
+            const size_t np = std::min(point_slab, n_points - p0);
+            const u64* c = coeffs + b0 * poly_stride;
+            const u64* pts = points + p0 * size_t(L);
+            u64* o = out + (b0 * n_points + p0) * size_t(L);
+            // the kernels index the output of polynomial b at o + b * out_stride: the full point count, not the slab's
+            const dim3 grid = split ? dim3((unsigned)np, nb) : dim3((unsigned)((np + 255) / 256), nb);
+            if (split && L == 1)
+                hipLaunchKernelGGL(tfk::batch_evaluate_split_kernel<1>, grid, dim3(256), 0, s, c, (long long)n_coeffs, (long long)poly_stride, pts,
+                                   (long long)np, o, (long long)n_points);
+            else if (split)
+                hipLaunchKernelGGL(tfk::batch_evaluate_split_kernel<3>, grid, dim3(256), 0, s, c, (long long)n_coeffs, (long long)poly_stride, pts,
+                                   (long long)np, o, (long long)n_points);
+            else if (L == 1)
+                hipLaunchKernelGGL(tfk::batch_evaluate_kernel<1>, grid, dim3(256), 0, s, c, (long long)n_coeffs, (long long)poly_stride, pts,
+                                   (long long)np, o, (long long)n_points);
+            else
+                hipLaunchKernelGGL(tfk::batch_evaluate_kernel<3>, grid, dim3(256), 0, s, c, (long long)n_coeffs, (long long)poly_stride, pts,
+                                   (long long)np, o, (long long)n_points);
+            HIPCHK(hipGetLastError());
+        }
     }
     return TF_OK;
 }
