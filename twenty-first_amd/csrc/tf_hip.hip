@@ -2500,10 +2500,14 @@ int coset_eval_xoffset_dev(const u64* d_coeffs, size_t n_coeffs, const u64 offse
     rc = current_ctx(&ctx);
     if (rc) return rc;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const long long total = (long long)order * (long long)batch;
-    hipLaunchKernelGGL(tfk::xfe_scale_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, d_coeffs, (long long)n_coeffs,
-                       (long long)n_coeffs * 3, d_out, (long long)order, (long long)batch, offset[0], offset[1], offset[2]);
-    HIPCHK(hipGetLastError());
+    // a launch takes at most 2^32 - 1 threads: walk the batch in slabs of at most 2^30 elements
+    const size_t slab = std::max<size_t>(1, (size_t(1) << 30) / order);
+    for (size_t b0 = 0; b0 < batch; b0 += slab) {
+        const long long nb = (long long)std::min(slab, batch - b0), total = (long long)order * nb;
+        hipLaunchKernelGGL(tfk::xfe_scale_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, d_coeffs + b0 * n_coeffs * 3, (long long)n_coeffs,
+                           (long long)n_coeffs * 3, d_out + b0 * order * 3, (long long)order, nb, offset[0], offset[1], offset[2]);
+        HIPCHK(hipGetLastError());
+    }
     return run_ntt(ctx, d_out, d_out, (long long)order * 3, (long long)order * 3, order, batch, 3, false, nullptr, -1, s);
 }
 
@@ -2521,10 +2525,14 @@ int coset_interp_xoffset_dev(const u64* d_values, size_t n, const u64 offset[3],
     hipStream_t s = static_cast<hipStream_t>(stream);
     rc = run_ntt(ctx, d_values, d_out, (long long)n * 3, (long long)n * 3, n, batch, 3, true, nullptr, -1, s);
     if (rc) return rc;
-    const long long total = (long long)n * (long long)batch;
-    hipLaunchKernelGGL(tfk::xfe_scale_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const u64*)d_out, (long long)n,
-                       (long long)n * 3, d_out, (long long)n, (long long)batch, inv[0], inv[1], inv[2]);
-    HIPCHK(hipGetLastError());
+    const size_t slab = std::max<size_t>(1, (size_t(1) << 30) / n);
+    for (size_t b0 = 0; b0 < batch; b0 += slab) {
+        const long long nb = (long long)std::min(slab, batch - b0), total = (long long)n * nb;
+        u64* o = d_out + b0 * n * 3;
+        hipLaunchKernelGGL(tfk::xfe_scale_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const u64*)o, (long long)n, (long long)n * 3, o,
+                           (long long)n, nb, inv[0], inv[1], inv[2]);
+        HIPCHK(hipGetLastError());
+    }
     return TF_OK;
 }
 
