@@ -948,3 +948,35 @@ def test_horner_route_with_more_points_than_one_launch_takes(tf, oracle):
         assert int(_to_host(short[i:i + 1])[0]) == int(oracle.poly_eval(c[:7], int(hp[i]))[0])
         for b in range(2):
             assert int(_to_host(out[b * m + i: b * m + i + 1])[0]) == int(oracle.poly_eval(c[b * 1500:(b + 1) * 1500], int(hp[i]))[0])
+
+
+def test_poly_goldens_reproduced_by_the_device(tf, oracle):
+    """tests/golden/poly_goldens.json through the HIP path: the committed vectors (canonical values) of zerofier, interpolate,
+    clean_divide, barycentric_evaluate, fast_coset_evaluate with an XFieldElement offset and Tip5::trace."""
+    import json
+    import os
+
+    cases = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "poly_goldens.json")))["cases"]
+    fr = oracle.fill_random
+
+    def pad(p, n_elems, width):  # the device API returns trimmed polynomials: pad back to the fixture's fixed length
+        c = p.coefficients
+        return np.concatenate([c, np.zeros(n_elems * width - c.size, dtype=np.uint64)])
+
+    for case in cases:
+        o, w = case["op"], case.get("width", 1)
+        if o == "zerofier":
+            got = pad(tf.Polynomial.zerofier(fr(case["n"] * w, case["seed"]), width=w), case["n"] + 1, w)
+        elif o == "interpolate":
+            got = pad(tf.Polynomial.interpolate(fr(case["n"] * w, case["domain_seed"]), fr(case["n"] * w, case["values_seed"]), width=w), case["n"], w)
+        elif o == "barycentric_evaluate":
+            got = tf.barycentric_evaluate(fr(case["n"] * w, case["codeword_seed"]), fr(3, case["indeterminate_seed"]), width=w)
+        elif o == "clean_divide":
+            got = pad(tf.Polynomial(oracle.to_raw(case["dividend"])).clean_divide(tf.Polynomial(fr(case["nb"], case["divisor_seed"]))), case["nq"], 1)
+        elif o == "coset_evaluate_xfe_offset":
+            got = tf.fast_coset_evaluate(fr(3 * case["n_coeffs"], case["coeffs_seed"]), fr(3, case["offset_seed"]), case["order"], width=3)
+        elif o == "tip5_trace":
+            got = tf.Tip5.trace_states(fr(16, case["state_seed"]).copy()).reshape(-1)
+        else:
+            raise AssertionError(o)
+        assert [int(v) for v in oracle.to_values(np.asarray(got, dtype=np.uint64).reshape(-1))] == case["out"], o

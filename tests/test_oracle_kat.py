@@ -658,3 +658,43 @@ def test_barycentric_evaluation_equals_polynomial_evaluation(oracle):
         tfo.barycentric_evaluate(tfo.fill_random(12, 1), tfo.fill_random(3, 2))      # not a power of two
     with pytest.raises(tfo.OraclePanic):
         tfo.barycentric_evaluate(tfo.fill_random(8, 1), np.array([tfo.bfe_new(1), 0, 0], dtype=np.uint64))  # 1 is in every subgroup
+
+
+def _poly_golden_cases():
+    return json.load(open(os.path.join(HERE, "golden", "poly_goldens.json")))["cases"]
+
+
+def _poly_golden_eval(case, ops):
+    """Runs one golden case through `ops` (the oracle here, the HIP path in tests/test_gpu_next_rows.py); returns raw words."""
+    o, fr = case["op"], oracle_fill
+    if o == "zerofier":
+        return ops["zerofier"](fr(case["n"] * case["width"], case["seed"]), case["width"])
+    if o == "interpolate":
+        return ops["interpolate"](fr(case["n"] * case["width"], case["domain_seed"]), fr(case["n"] * case["width"], case["values_seed"]), case["width"])
+    if o == "barycentric_evaluate":
+        return ops["barycentric"](fr(case["n"] * case["width"], case["codeword_seed"]), fr(3, case["indeterminate_seed"]), case["width"])
+    if o == "clean_divide":
+        return ops["clean_divide"](ops["to_raw"](case["dividend"]), fr(case["nb"], case["divisor_seed"]))
+    if o == "coset_evaluate_xfe_offset":
+        return ops["coset_xoff"](fr(3 * case["n_coeffs"], case["coeffs_seed"]), fr(3, case["offset_seed"]), case["order"])
+    if o == "tip5_trace":
+        return ops["trace"](fr(16, case["state_seed"]))
+    raise AssertionError(o)
+
+
+oracle_fill = None
+
+
+def test_poly_goldens_reproduced_by_the_oracle(oracle):
+    """tests/golden/poly_goldens.json (tests/golden/make_poly_goldens.py): the committed vectors of zerofier, interpolation, clean
+    division, barycentric evaluation, the extension-field offset and Tip5::trace -- a change of the oracle shows up here."""
+    global oracle_fill
+    oracle_fill = oracle.fill_random
+    ops = {"zerofier": oracle.zerofier, "interpolate": oracle.lagrange_interpolate, "barycentric": oracle.barycentric_evaluate,
+           "clean_divide": lambda a, b: oracle.clean_divide(a, b, 0), "coset_xoff": oracle.coset_evaluate_xfe_offset,
+           "trace": lambda s: oracle.tip5_trace(s)[0], "to_raw": oracle.to_raw}
+    cases = _poly_golden_cases()
+    assert len(cases) == 9
+    for case in cases:
+        got = np.asarray(_poly_golden_eval(case, ops), dtype=np.uint64).reshape(-1)
+        assert [int(v) for v in oracle.to_values(got)] == case["out"], case["op"]
