@@ -353,6 +353,11 @@ def ntt_headline(ctx):
         roofline["valu_bound"] = {"wave_instr_per_step": wi, "valu_instr_per_element": round(wi * 64.0 / (batch * n), 1),
                                   "achieved": round(gw, 1), "peak": VALU_PEAK_GWIPS, "unit": "G wave-instr/s",
                                   "frac": round(gw / VALU_PEAK_GWIPS, 3), "clock_under_load_mhz": vc.get("ntt_clock_under_load_mhz")}
+        clk = vc.get("ntt_clock_under_load_mhz")
+        if clk:  # the same issue rate priced at the clock the chip holds under this kernel (profiled, GRBM_GUI_ACTIVE / duration)
+            peak_at_clk = 1024 * clk * 1e6 / 4 / 1e9
+            roofline["valu_bound"]["peak_at_clock_under_load"] = round(peak_at_clk, 1)
+            roofline["valu_bound"]["frac_at_clock_under_load"] = round(gw / peak_at_clk, 3)
 
     out = {
         "metric": "goldilocks_ntt_gfelts_per_s",
