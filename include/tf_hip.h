@@ -246,6 +246,9 @@ int tf_zerofier_tree_interpolate(tf_zerofier_tree *tree, const uint64_t *values,
 int tf_zerofier_tree_zerofier_dev(const tf_zerofier_tree *tree, uint64_t *d_out, void *stream);
 int tf_zerofier_tree_batch_evaluate_dev(const tf_zerofier_tree *tree, const uint64_t *d_coeffs, size_t n_coeffs, size_t batch, uint64_t *d_out, void *stream);
 int tf_zerofier_tree_interpolate_dev(tf_zerofier_tree *tree, const uint64_t *d_values, size_t rows, uint64_t *d_out, void *stream);
+/* The route tf_poly_batch_evaluate_* takes for a shape: 1 = Horner, 2 = zerofier tree (0: width not 1 / 3).  Pure host logic (the
+ * fitted cost model of the router), checked by the CPU tests; honours tf_set_batch_eval_route / TF_BATCH_EVAL. */
+int tf_batch_eval_plan(size_t n_coeffs, size_t n_points, size_t batch, int width);
 /* Route of the batch evaluation (test / A-B hook): 0 = automatic (zerofier tree for many points on a long polynomial, Horner
  * otherwise), 1 = always Horner, 2 = the zerofier tree whenever it applies (at least two leaves: 512 points over BFE, 256 over XFE).  Same values either way. */
 void tf_set_batch_eval_route(int route);

@@ -158,3 +158,33 @@ def test_planner_splits_are_valid_for_every_length(tf):
     # the headline transform: two passes of radix 1024; launches per call follow the plan
     assert lib.tf_ntt_plan(1 << 20, 1, radix) == 2 and list(radix)[:2] == [10, 10]
     assert lib.tf_ntt_launch_count(1 << 13, 1000, 1) == 1 and lib.tf_ntt_launch_count(1 << 13, 1000, 3) == 2
+
+
+def test_batch_evaluation_router_is_host_logic_with_the_measured_crossovers(tf):
+    """tf_batch_eval_plan (host logic, no device): the router of tf_poly_batch_evaluate_* picks the zerofier tree where it measured
+    faster than Horner (profiles/r02_batch_eval_sweep.txt) and Horner elsewhere; the test hook forces either route; a tree never
+    applies below two leaves."""
+    lib = tf._lib.lib()
+    plan = lib.tf_batch_eval_plan
+    lib.tf_set_batch_eval_route(0)
+    try:
+        # (n_coeffs, n_points, batch, width) -> route; 1 = Horner, 2 = tree
+        measured = [((1 << 12, 1 << 12, 1, 1), 1), ((1 << 14, 1 << 14, 1, 1), 1), ((1 << 16, 1 << 14, 1, 1), 1), ((1 << 16, 1 << 16, 1, 1), 2),
+                    ((1 << 18, 1 << 16, 1, 1), 2), ((1 << 18, 1 << 18, 1, 1), 2), ((1 << 20, 1 << 20, 1, 1), 2), ((1 << 22, 1 << 16, 1, 1), 2),
+                    ((1 << 14, 1 << 14, 1, 3), 1), ((1 << 16, 1 << 14, 1, 3), 2), ((1 << 16, 1 << 16, 1, 3), 2), ((1 << 20, 1 << 20, 1, 3), 2)]
+        for shape, want in measured:
+            assert plan(*shape) == want, shape
+        assert plan(1 << 20, 100, 1, 1) == 1 and plan(5, 1 << 20, 1, 1) == 1 and plan(0, 1 << 20, 1, 1) == 1   # few points / a short polynomial
+        assert plan(1 << 26, 1 << 10, 1, 1) == 1                                                                 # too many chunks for the tree
+        assert plan(1 << 16, 1 << 16, 1, 2) == 0
+        prev = 1                                   # at n = m the decision is monotone in the size
+        for log in range(8, 24):
+            r = plan(1 << log, 1 << log, 1, 1)
+            assert r >= prev, log
+            prev = r
+        lib.tf_set_batch_eval_route(1)
+        assert plan(1 << 20, 1 << 20, 1, 1) == 1
+        lib.tf_set_batch_eval_route(2)
+        assert plan(1 << 12, 1 << 12, 1, 1) == 2 and plan(1 << 12, 511, 1, 1) == 1 and plan(1 << 12, 255, 1, 3) == 1
+    finally:
+        lib.tf_set_batch_eval_route(0)

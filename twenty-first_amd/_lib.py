@@ -108,6 +108,7 @@ SIGNATURES = {
     "tf_merkle_authentication_structure_dev": (C.c_int, [_vp, _sz, _vp, _sz, _vp, _sz, C.POINTER(C.c_size_t), _vp]),
     "tf_ntt_launch_count": (C.c_int, [_sz, _sz, C.c_int]),
     "tf_ntt_plan": (C.c_int, [_sz, C.c_int, C.POINTER(C.c_int)]),
+    "tf_batch_eval_plan": (C.c_int, [_sz, _sz, _sz, C.c_int]),
     "tf_set_ntt_small_launch": (None, [C.c_int]),
     "tf_debug_stamps": (C.c_int, [_vp, _sz]),
     "tf_debug_sclk_mhz": (C.c_double, []),

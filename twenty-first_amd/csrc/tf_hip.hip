@@ -2028,12 +2028,12 @@ bool tree_route(size_t n_coeffs, size_t n_points, size_t batch, int L) {
     }
     if (force && !strcmp(force, "tree")) return true;
     // Cost model fitted to tools/batch_eval_sweep.py on MI355X (profiles/r02_batch_eval_sweep.txt), milliseconds:
-    //   Horner  n m / 1.4e9            (x 7 over XFieldElement: nine base-field products per step)
+    //   Horner  n m / 1.4e9            (x 8 over XFieldElement: nine base-field products per step; measured 7 - 10)
     //   tree    walk (1.4 + units): one build (1.4 walks) plus one walk per unit; a walk is launch-bound per level
     //           (7 launches, 0.115 ms) plus a term in the padded point count (0.06 ms per 2^16 points, 0.2 over XFE)
     int levels = 0;
     for (size_t v = kTreeLeaf; v < M; v <<= 1) ++levels;
-    const double horner_ms = (double)n_coeffs * (double)n_points / 1.4e9 * (L == 3 ? 7.0 : 1.0);
+    const double horner_ms = (double)n_coeffs * (double)n_points / 1.4e9 * (L == 3 ? 8.0 : 1.0);
     const double latency = std::max(0.1, -0.10 + 0.115 * levels) * (L == 3 ? 1.3 : 1.0);
     const double walk_ms = latency + (L == 3 ? 0.2 : 0.06) * (double)M / 65536.0;
     const double tree_ms = walk_ms * (1.4 + (double)units);
@@ -2903,6 +2903,12 @@ int tf_debug_stamps(unsigned long long* host_out, size_t words) {
 void tf_set_ntt_min_passes(int passes) { g_min_passes.store(passes, std::memory_order_relaxed); }
 void tf_set_ntt_small_launch(int mode) { g_small_launch_mode.store(mode < 0 ? -1 : (mode ? 1 : 0), std::memory_order_relaxed); }
 // The plan of one transform: number of global passes and log2 of each pass's radix (planner introspection for the CPU tests).
+// The route tf_poly_batch_evaluate_* takes for this shape: 1 Horner, 2 zerofier tree; 0 for a width that is not 1 / 3.  Host logic
+// only (no device is touched), so the CPU tests pin the router.
+int tf_batch_eval_plan(size_t n_coeffs, size_t n_points, size_t batch, int width) {
+    if (width != 1 && width != 3) return 0;
+    return tree_route(n_coeffs, n_points, batch, width) ? 2 : 1;
+}
 int tf_ntt_plan(size_t n, int width, int* log2_radix_out) {
     if (check_len(n) || n <= 1 || (width != 1 && width != 3) || !log2_radix_out) return 0;
     const int log_n = ilog2(n);
