@@ -980,3 +980,48 @@ def test_poly_goldens_reproduced_by_the_device(tf, oracle):
         else:
             raise AssertionError(o)
         assert [int(v) for v in oracle.to_values(np.asarray(got, dtype=np.uint64).reshape(-1))] == case["out"], o
+
+
+def test_zerofier_tree_handle_serves_concurrent_host_threads(tf, oracle):
+    """One prepared tree, four host threads, each on its own stream, evaluating and interpolating at the same time (ctypes releases
+    the GIL during the calls; the first interpolation takes the handle's lock to compute the weights): every thread gets the
+    words the single-threaded calls give."""
+    import threading
+
+    import torch
+
+    n, rounds = 1 << 13, 6
+    dom = torch.empty(n, dtype=torch.int64, device="cuda")
+    tf.device.fill_random(dom, 71)
+    polys = [torch.empty(n, dtype=torch.int64, device="cuda") for _ in range(4)]
+    for k, p in enumerate(polys):
+        tf.device.fill_random(p, 72 + k)
+    want_vals = []
+    for p in polys:
+        v = torch.empty(n, dtype=torch.int64, device="cuda")
+        tf.device.batch_evaluate(p, n, dom, v)
+        want_vals.append(v)
+    torch.cuda.synchronize()
+    errors = []
+    with tf.device.ZerofierTree(dom) as tree:
+        def worker(k):
+            try:
+                st = torch.cuda.Stream()
+                with torch.cuda.stream(st):
+                    for _ in range(rounds):
+                        v = torch.empty(n, dtype=torch.int64, device="cuda")
+                        b = torch.empty(n, dtype=torch.int64, device="cuda")
+                        tree.batch_evaluate(polys[k], n, v, stream=st)
+                        tree.interpolate(v, b, stream=st)
+                        st.synchronize()
+                        if not torch.equal(v, want_vals[k]) or not torch.equal(b, polys[k]):
+                            errors.append(k)
+            except Exception as e:  # noqa: BLE001
+                errors.append(repr(e))
+
+        threads = [threading.Thread(target=worker, args=(k,)) for k in range(4)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+    assert not errors, errors
