@@ -84,6 +84,18 @@ def test_reentrant_from_many_host_threads(tf, oracle):
                 off = oracle.bfe_new(rng.randrange(1, P))  # > 16 distinct offsets overall: exercises the uncached path
                 if not np.array_equal(tf.fast_coset_evaluate(c, off, 512), oracle.coset_evaluate(c, off, 512)):
                     errors.append(("coset", k, it))
+                # the callers of the second half of round 2: interpolation through the tree, clean division, barycentric evaluation
+                m = rng.choice([40, 300, 700])
+                d, v = oracle.fill_random(m, rng.getrandbits(40)), oracle.fill_random(m, rng.getrandbits(40))
+                f = tf.Polynomial.interpolate(d, v)
+                if not np.array_equal(f.coefficients, tf.Polynomial(oracle.lagrange_interpolate(d, v)).coefficients):
+                    errors.append(("interpolate", k, it))
+                q, b = oracle.fill_random(rng.randint(1, 900), rng.getrandbits(40)), oracle.fill_random(rng.randint(1, 900), rng.getrandbits(40))
+                if q[-1] and b[-1] and not np.array_equal(tf.Polynomial(oracle.poly_mul(q, b)).clean_divide(tf.Polynomial(b)).coefficients, q):
+                    errors.append(("clean_divide", k, it))
+                cw, xp = oracle.fill_random(256, rng.getrandbits(40)), oracle.fill_random(3, rng.getrandbits(40))
+                if not np.array_equal(tf.barycentric_evaluate(cw, xp), oracle.barycentric_evaluate(cw, xp)):
+                    errors.append(("barycentric", k, it))
         except Exception as e:  # noqa: BLE001
             errors.append(("exception", k, repr(e)))
 
