@@ -200,6 +200,12 @@ int tf_coset_eval_xfe_xoffset(const uint64_t *coeffs, size_t n_coeffs, const uin
 int tf_coset_interpolate_xfe_xoffset(const uint64_t *values, size_t n, const uint64_t offset[3], uint64_t *out, size_t batch);
 int tf_coset_eval_xfe_xoffset_dev(const uint64_t *d_coeffs, size_t n_coeffs, const uint64_t offset[3], uint64_t *d_out, size_t order, size_t batch, void *stream);
 int tf_coset_interpolate_xfe_xoffset_dev(const uint64_t *d_values, size_t n, const uint64_t offset[3], uint64_t *d_out, size_t batch, void *stream);
+/* Polynomial<BFieldElement>::evaluate::<XFieldElement, XFieldElement>  math/polynomial.rs:309-320 (the generic evaluate with the
+ * indeterminate in the extension field), batched: `batch` base-field polynomials of n_coeffs packed coefficients at n_points
+ * XFieldElement points (3 words each) -> out[(b * n_points + i) * 3].  Horner; the coefficients are read as 8-byte words, not
+ * lifted. */
+int tf_poly_evaluate_bfe_at_xfe(const uint64_t *coeffs, size_t n_coeffs, size_t batch, const uint64_t *points, size_t n_points, uint64_t *out);
+int tf_poly_evaluate_bfe_at_xfe_dev(const uint64_t *d_coeffs, size_t n_coeffs, size_t batch, const uint64_t *d_points, size_t n_points, uint64_t *d_out, void *stream);
 /* barycentric_evaluate  math/polynomial.rs:2609-2637: out[b] = the value at `indeterminate` of the interpolant of codeword b given
  * on the subgroup of order n (natural order, no offset), for `batch` codewords of n elements at ONE indeterminate -- the
  * out-of-domain evaluation of every column of a table.  indeterminate: 3 raw words (an XFieldElement; a BFieldElement x as

@@ -1025,3 +1025,35 @@ def test_zerofier_tree_handle_serves_concurrent_host_threads(tf, oracle):
         for t in threads:
             t.join()
     assert not errors, errors
+
+
+@pytest.mark.parametrize("n_coeffs,n_points,batch", [(0, 3, 1), (1, 1, 1), (7, 5, 3), (1024, 2, 2), (5000, 9, 4), (1 << 16, 3, 2)])
+def test_base_field_polynomials_at_extension_field_points(tf, oracle, n_coeffs, n_points, batch):
+    """Polynomial<BFieldElement>::evaluate::<XFieldElement, XFieldElement> (math/polynomial.rs:309-320), batched over polynomials
+    and points: against the oracle's Horner on the lifted coefficients; a point in the base field gives the base-field value
+    lifted (the doc example :296-307)."""
+    import torch
+
+    c = oracle.fill_random(max(1, n_coeffs * batch), 2300 + n_coeffs)[: n_coeffs * batch]
+    pts = oracle.fill_random(3 * n_points, 2301 + n_points)
+    pts[1:3] = 0  # the first point is a lifted base-field element
+    dc = _to_dev(c) if c.size else torch.empty(0, dtype=torch.int64, device="cuda")
+    out = torch.empty(3 * batch * n_points, dtype=torch.int64, device="cuda")
+    tf.device.evaluate_bfe_at_xfe(dc, n_coeffs, _to_dev(pts), out, batch=batch)
+    torch.cuda.synchronize()
+    got = _to_host(out).reshape(batch, n_points, 3)
+    for b in range(batch):
+        cb = c[b * n_coeffs:(b + 1) * n_coeffs]
+        lifted = np.zeros(3 * n_coeffs, dtype=np.uint64)
+        lifted[0::3] = cb
+        for i in sorted({0, n_points // 2, n_points - 1}):
+            assert np.array_equal(got[b, i], oracle.poly_eval_xfe_point(lifted, pts[3 * i: 3 * i + 3])), (b, i)
+        if n_coeffs:
+            assert int(got[b, 0, 0]) == int(oracle.poly_eval(cb, int(pts[0]))[0]) and not got[b, 0, 1:].any()
+    if batch == 1 or n_coeffs == 7:
+        p = tf.Polynomial(c[:n_coeffs])
+        assert np.array_equal(p.evaluate_at_xfe_points(pts).reshape(n_points, 3), got[0])
+    # the doc example (:296-307): 2 + 5 x + 12 x^2 is 19 at 1 and, evaluated into the extension field at 2, xfe!(60)
+    ex = tf.Polynomial(oracle.to_raw([2, 5, 12]))
+    at = np.array([oracle.bfe_new(1), 0, 0, oracle.bfe_new(2), 0, 0], dtype=np.uint64)
+    assert [int(v) for v in oracle.to_values(ex.evaluate_at_xfe_points(at))] == [19, 0, 0, 60, 0, 0]

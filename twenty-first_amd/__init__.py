@@ -258,6 +258,18 @@ class Polynomial:
         _check(fn(_ptr(self.coefficients), self.coefficients.size // self.width, _ptr(pts), n_points, _ptr(out)), "batch_evaluate")
         return out
 
+    def evaluate_at_xfe_points(self, points: np.ndarray) -> np.ndarray:
+        """Polynomial<BFieldElement>::evaluate::<XFieldElement, XFieldElement> (math/polynomial.rs:309-320) at every point of
+        `points` (3 raw words each): n_points x 3 raw words."""
+        if self.width != 1:
+            return self.batch_evaluate(points)
+        pts = _words(np.ascontiguousarray(points, dtype=np.uint64).reshape(-1), "points")
+        if pts.size % 3:
+            raise ValueError("points must hold whole XFieldElements")
+        out = np.zeros(pts.size, dtype=np.uint64)
+        _check(lib().tf_poly_evaluate_bfe_at_xfe(_ptr(self.coefficients), self.coefficients.size, 1, _ptr(pts), pts.size // 3, _ptr(out)), "evaluate")
+        return out
+
     def clean_divide(self, divisor: "Polynomial") -> "Polynomial":
         """math/polynomial.rs:2358-2411 (BFieldElement only): self / divisor for a division known to be clean.  Panics (NttPanic)
         on a zero divisor and on an unclean division."""

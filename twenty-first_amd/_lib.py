@@ -67,6 +67,8 @@ SIGNATURES = {
     "tf_coset_interpolate_xfe_xoffset": (C.c_int, [_vp, _sz, _vp, _vp, _sz]),
     "tf_coset_eval_xfe_xoffset_dev": (C.c_int, [_vp, _sz, _vp, _vp, _sz, _sz, _vp]),
     "tf_coset_interpolate_xfe_xoffset_dev": (C.c_int, [_vp, _sz, _vp, _vp, _sz, _vp]),
+    "tf_poly_evaluate_bfe_at_xfe": (C.c_int, [_vp, _sz, _sz, _vp, _sz, _vp]),
+    "tf_poly_evaluate_bfe_at_xfe_dev": (C.c_int, [_vp, _sz, _sz, _vp, _sz, _vp, _vp]),
     "tf_barycentric_evaluate_bfe": (C.c_int, [_vp, _sz, _sz, _vp, _vp]),
     "tf_barycentric_evaluate_xfe": (C.c_int, [_vp, _sz, _sz, _vp, _vp]),
     "tf_barycentric_evaluate_bfe_dev": (C.c_int, [_vp, _sz, _sz, _vp, _vp, _vp]),

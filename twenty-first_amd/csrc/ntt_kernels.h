@@ -1134,7 +1134,9 @@ __device__ __forceinline__ void fe_mul(const u64 (&a)[L], const u64 (&b)[L], u64
 }
 
 // Lane per point: the right shape for short polynomials at many points.  grid = (ceil(m / 256), batch).
-template <int L>
+// CL = words per COEFFICIENT (L: same field as the points; 1 with L = 3: Polynomial<BFieldElement>::evaluate::<XFieldElement, _>,
+// polynomial.rs:309-320 -- the base-field coefficient is added to limb 0 of the extension-field accumulator).
+template <int L, int CL = L>
 __global__ void __launch_bounds__(256) batch_evaluate_kernel(const u64* coeffs, long long n_coeffs, long long poly_stride,
                                                             const u64* points, long long n_points, u64* out, long long out_stride) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1147,7 +1149,7 @@ __global__ void __launch_bounds__(256) batch_evaluate_kernel(const u64* coeffs, 
         u64 t[L];
         fe_mul<L>(acc, x, t);
 #pragma unroll
-        for (int k = 0; k < L; ++k) acc[k] = gl::add(t[k], c[L * j + k]);
+        for (int k = 0; k < L; ++k) acc[k] = k < CL ? gl::add(t[k], c[CL * j + k]) : t[k];
     }
     u64* o = out + ((long long)blockIdx.y * out_stride + i) * L;  // out_stride: the points of the whole call (a launch may be a slab of them)
 #pragma unroll
@@ -1157,7 +1159,7 @@ __global__ void __launch_bounds__(256) batch_evaluate_kernel(const u64* coeffs, 
 // Workgroup per (point, polynomial): thread t runs Horner in X = x^256 over coefficients t, t + 256, ... (coalesced
 // reads), scales by x^t, and the 256 partial values are summed through LDS:
 //   f(x) = sum_t x^t * sum_j c[t + 256 j] X^j.   grid = (m, batch).
-template <int L>
+template <int L, int CL = L>
 __global__ void __launch_bounds__(256) batch_evaluate_split_kernel(const u64* coeffs, long long n_coeffs, long long poly_stride,
                                                                   const u64* points, long long n_points, u64* out, long long out_stride) {
     __shared__ u64 part[256 * L];
@@ -1183,9 +1185,9 @@ __global__ void __launch_bounds__(256) batch_evaluate_split_kernel(const u64* co
     if (t < n_coeffs) {
         for (long long j = (n_coeffs - 1 - t) >> 8; j >= 0; --j) {
             fe_mul<L>(acc, X, tmp);
-            const u64* cj = c + (t + (j << 8)) * L;
+            const u64* cj = c + (t + (j << 8)) * CL;
 #pragma unroll
-            for (int k = 0; k < L; ++k) acc[k] = gl::add(tmp[k], cj[k]);
+            for (int k = 0; k < L; ++k) acc[k] = k < CL ? gl::add(tmp[k], cj[k]) : tmp[k];
         }
         fe_mul<L>(acc, pw, tmp);
 #pragma unroll

@@ -2105,7 +2105,7 @@ int batch_evaluate_tree_t(const u64* coeffs, size_t n_coeffs, size_t poly_stride
 // otherwise.  `batch` polynomials of n_coeffs coefficients (poly_stride words apart) share the points;
 // out[(b * n_points + i) * L ..] = f_b(points[i]).
 int batch_evaluate_horner(const u64* coeffs, size_t n_coeffs, size_t poly_stride, size_t batch, const u64* points, size_t n_points, u64* out,
-                          int L, void* stream);
+                          int L, void* stream, int CL = 0);
 int batch_evaluate_dev(const u64* coeffs, size_t n_coeffs, size_t poly_stride, size_t batch, const u64* points, size_t n_points,
                        u64* out, int L, void* stream) {
     if (n_points == 0 || batch == 0) return TF_OK;
@@ -2121,9 +2121,11 @@ int batch_evaluate_dev(const u64* coeffs, size_t n_coeffs, size_t poly_stride, s
     return batch_evaluate_horner(coeffs, n_coeffs, poly_stride, batch, points, n_points, out, L, stream);
 }
 
+// CL: words per coefficient (0 = L; 1 with L = 3: base-field coefficients at extension-field points)
 int batch_evaluate_horner(const u64* coeffs, size_t n_coeffs, size_t poly_stride, size_t batch, const u64* points, size_t n_points, u64* out,
-                          int L, void* stream) {
+                          int L, void* stream, int CL) {
     if (n_points == 0 || batch == 0) return TF_OK;
+    const bool mixed = L == 3 && CL == 1;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bool split = n_coeffs >= 1024;
     // grid.y is limited to 65535 and a launch to 2^32 - 1 threads: walk the batch and the points in slabs
@@ -2137,7 +2139,13 @@ int batch_evaluate_horner(const u64* coeffs, size_t n_coeffs, size_t poly_stride
             u64* o = out + (b0 * n_points + p0) * size_t(L);
             // the kernels index the output of polynomial b at o + b * out_stride: the full point count, not the slab's
             const dim3 grid = split ? dim3((unsigned)np, nb) : dim3((unsigned)((np + 255) / 256), nb);
-            if (split && L == 1)
+            if (mixed && split)
+                hipLaunchKernelGGL((tfk::batch_evaluate_split_kernel<3, 1>), grid, dim3(256), 0, s, c, (long long)n_coeffs, (long long)poly_stride, pts,
+                                   (long long)np, o, (long long)n_points);
+            else if (mixed)
+                hipLaunchKernelGGL((tfk::batch_evaluate_kernel<3, 1>), grid, dim3(256), 0, s, c, (long long)n_coeffs, (long long)poly_stride, pts,
+                                   (long long)np, o, (long long)n_points);
+            else if (split && L == 1)
                 hipLaunchKernelGGL(tfk::batch_evaluate_split_kernel<1>, grid, dim3(256), 0, s, c, (long long)n_coeffs, (long long)poly_stride, pts,
                                    (long long)np, o, (long long)n_points);
             else if (split)
@@ -3308,6 +3316,23 @@ static int barycentric_host(const uint64_t* cw, size_t n, size_t batch, int widt
 }
 int tf_barycentric_evaluate_bfe(const uint64_t* cw, size_t n, size_t batch, const uint64_t x[3], uint64_t* out) { return barycentric_host(cw, n, batch, 1, x, out); }
 int tf_barycentric_evaluate_xfe(const uint64_t* cw, size_t n, size_t batch, const uint64_t x[3], uint64_t* out) { return barycentric_host(cw, n, batch, 3, x, out); }
+// Polynomial<BFieldElement>::evaluate::<XFieldElement, XFieldElement> (polynomial.rs:309-320) for `batch` polynomials at n_points
+// extension-field points: out[(b * n_points + i) * 3] = f_b(points[i]).  Horner (the shape of the use: every column polynomial
+// of a table at a few out-of-domain points).
+int tf_poly_evaluate_bfe_at_xfe_dev(const uint64_t* c, size_t nc, size_t batch, const uint64_t* pts, size_t np, uint64_t* out, void* stream) {
+    if (np == 0 || batch == 0) return TF_OK;
+    if (!pts || !out || (nc && !c)) return TF_ERR_NULL_POINTER;
+    DeviceCtx* ctx = nullptr;
+    int rc = current_ctx(&ctx);
+    if (rc) return rc;
+    return batch_evaluate_horner(c, nc, nc, batch, pts, np, out, 3, stream, 1);
+}
+int tf_poly_evaluate_bfe_at_xfe(const uint64_t* c, size_t nc, size_t batch, const uint64_t* pts, size_t np, uint64_t* out) {
+    if (np == 0 || batch == 0) return TF_OK;
+    if (!pts || !out || (nc && !c)) return TF_ERR_NULL_POINTER;
+    return host_roundtrip(c, batch * nc, pts, 3 * np, out, 3 * batch * np,
+                          [&](u64* dc, u64* dp, u64* o, hipStream_t s) { return batch_evaluate_horner(dc, nc, nc, batch, dp, np, o, 3, s, 1); });
+}
 int tf_poly_clean_divide_bfe_dev(const uint64_t* a, size_t na, const uint64_t* b, size_t nb, uint64_t* out, void* stream) {
     return clean_divide_dev(a, na, b, nb, out, stream);
 }

@@ -191,6 +191,15 @@ def batch_evaluate(coeffs, n_coeffs: int, points, out, width: int = 1, stream=No
     _chk(fn(_p(coeffs), n_coeffs, _p(points), points.numel() // width, _p(out), _stream(stream)), "batch_evaluate")
 
 
+def evaluate_bfe_at_xfe(coeffs, n_coeffs: int, points, out, batch: int = 1, stream=None) -> None:
+    """Polynomial<BFieldElement>::evaluate with XFieldElement indeterminates (math/polynomial.rs:309-320) on device buffers: `batch`
+    base-field polynomials at the XFieldElement points -> out[(b * n_points + i) * 3]."""
+    coeffs, points, out = _t(coeffs, "coeffs"), _t(points, "points"), _t(out, "out")
+    _need(points.numel() % 3 == 0 and coeffs.numel() == batch * n_coeffs and out.numel() == batch * points.numel(),
+          "coeffs = batch * n_coeffs words, points = n_points XFieldElements, out = batch * n_points XFieldElements")
+    _chk(_lib.lib().tf_poly_evaluate_bfe_at_xfe_dev(_p(coeffs), n_coeffs, batch, _p(points), points.numel() // 3, _p(out), _stream(stream)), "evaluate")
+
+
 def clean_divide(a, b, out, stream=None) -> None:
     """Polynomial::<BFieldElement>::clean_divide (math/polynomial.rs:2358-2411) on device buffers: a, b normalised coefficient
     arrays, out = the na - nb + 1 quotient coefficients."""

@@ -152,6 +152,15 @@ int main() {
         try { Poly::interpolate(bfe_vec({1, 1}), bfe_vec({1, 2})); } catch (const NttPanic& e) { p3 = e.code == TF_ERR_INVERSE_OF_ZERO; }  // :3554-3560
         EXPECT(p1 && p2 && p3);
     }
+    {  // evaluate doc example (polynomial.rs:296-307): 2 + 5x + 12x^2 is 19 at 1 and xfe!(60) at 2, evaluated into the extension field
+        Polynomial<BFieldElement> p(bfe_vec({2, 5, 12}));
+        XFieldElement one{}, two{};
+        one.coefficients[0] = BFieldElement::new_(1);
+        two.coefficients[0] = BFieldElement::new_(2);
+        auto v = p.evaluate_at({one, two});
+        EXPECT(v[0].coefficients[0] == BFieldElement::new_(19) && v[1].coefficients[0] == BFieldElement::new_(60));
+        EXPECT(v[1].coefficients[1] == BFieldElement{} && v[1].coefficients[2] == BFieldElement{});
+    }
     {  // Tip5::trace (tip5/mod.rs:538-548, test :1557-1565): first row = the state, last row = the permutation's output
         Tip5 a = Tip5::init(), b = Tip5::init();
         for (int i = 0; i < 16; ++i) a.state[i] = b.state[i] = BFieldElement::new_(1000 + i);

@@ -213,6 +213,15 @@ struct Polynomial {
     static Polynomial interpolate(const std::vector<FF>& domain, const std::vector<FF>& values) {
         return batch_fast_interpolate(domain, {values})[0];
     }
+    // evaluate::<XFieldElement, XFieldElement> (polynomial.rs:309-320) of a base-field polynomial at extension-field points
+    std::vector<XFieldElement> evaluate_at(const std::vector<XFieldElement>& points) const {
+        static_assert(sizeof(FF) == 8, "the mixed-field evaluation is for Polynomial<BFieldElement>; use batch_evaluate otherwise");
+        std::vector<XFieldElement> out(points.size());
+        check(tf_poly_evaluate_bfe_at_xfe(reinterpret_cast<const uint64_t*>(coefficients.data()), coefficients.size(), 1,
+                                          reinterpret_cast<const uint64_t*>(points.data()), points.size(), reinterpret_cast<uint64_t*>(out.data())),
+              "evaluate");
+        return out;
+    }
     // batch_coset_extrapolate (polynomial.rs:2196-2208, par_ :2262): codeword-major values of every interpolant at
     // every point; panics unless codeword_length is a power of two
     static std::vector<FF> batch_coset_extrapolate(BFieldElement domain_offset, size_t codeword_length, const std::vector<FF>& codewords,
