@@ -169,13 +169,15 @@ def test_batch_evaluation_router_is_host_logic_with_the_measured_crossovers(tf):
     lib.tf_set_batch_eval_route(0)
     try:
         # (n_coeffs, n_points, batch, width) -> route; 1 = Horner, 2 = tree
-        measured = [((1 << 12, 1 << 12, 1, 1), 1), ((1 << 14, 1 << 14, 1, 1), 1), ((1 << 16, 1 << 14, 1, 1), 1), ((1 << 16, 1 << 16, 1, 1), 2),
-                    ((1 << 18, 1 << 16, 1, 1), 2), ((1 << 18, 1 << 18, 1, 1), 2), ((1 << 20, 1 << 20, 1, 1), 2), ((1 << 22, 1 << 16, 1, 1), 2),
-                    ((1 << 14, 1 << 14, 1, 3), 1), ((1 << 16, 1 << 14, 1, 3), 2), ((1 << 16, 1 << 16, 1, 3), 2), ((1 << 20, 1 << 20, 1, 3), 2)]
+        measured = [((1 << 12, 1 << 12, 1, 1), 1), ((1 << 14, 1 << 12, 1, 1), 1), ((1 << 14, 1 << 14, 1, 1), 1), ((1 << 16, 1 << 13, 1, 1), 1),
+                    ((1 << 16, 1 << 14, 1, 1), 1), ((1 << 16, 1 << 16, 1, 1), 2), ((1 << 18, 1 << 14, 1, 1), 2), ((1 << 18, 1 << 16, 1, 1), 2),
+                    ((1 << 18, 1 << 18, 1, 1), 2), ((1 << 20, 1 << 20, 1, 1), 2), ((1 << 22, 1 << 16, 1, 1), 2),
+                    ((1 << 14, 1 << 12, 1, 3), 1), ((1 << 14, 1 << 14, 1, 3), 1), ((1 << 16, 1 << 13, 1, 3), 2), ((1 << 16, 1 << 14, 1, 3), 2),
+                    ((1 << 16, 1 << 16, 1, 3), 2), ((1 << 18, 1 << 14, 1, 3), 2), ((1 << 20, 1 << 20, 1, 3), 2)]
         for shape, want in measured:
             assert plan(*shape) == want, shape
         assert plan(1 << 20, 100, 1, 1) == 1 and plan(5, 1 << 20, 1, 1) == 1 and plan(0, 1 << 20, 1, 1) == 1   # few points / a short polynomial
-        assert plan(1 << 26, 1 << 10, 1, 1) == 1                                                                 # too many chunks for the tree
+        assert plan(1 << 26, 1 << 10, 1, 1) == 2 and plan(1 << 16, 1 << 13, 64, 1) == 2  # many chunks / many polynomials walk the tree together
         assert plan(1 << 16, 1 << 16, 1, 2) == 0
         prev = 1                                   # at n = m the decision is monotone in the size
         for log in range(8, 24):

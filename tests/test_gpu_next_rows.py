@@ -1057,3 +1057,44 @@ def test_base_field_polynomials_at_extension_field_points(tf, oracle, n_coeffs, 
     ex = tf.Polynomial(oracle.to_raw([2, 5, 12]))
     at = np.array([oracle.bfe_new(1), 0, 0, oracle.bfe_new(2), 0, 0], dtype=np.uint64)
     assert [int(v) for v in oracle.to_values(ex.evaluate_at_xfe_points(at))] == [19, 0, 0, 60, 0, 0]
+
+
+@pytest.mark.parametrize("width,n_points,n_coeffs,batch", [(1, 700, 2500, 5), (1, 3000, 9000, 3), (1, 600, 40000, 2), (3, 300, 1000, 4), (3, 1100, 2048, 3)])
+def test_many_polynomials_and_chunks_walk_the_tree_together(tf, oracle, width, n_points, n_coeffs, batch):
+    """All chunks of all polynomials of a call ("units") go down the tree in one walk per slab of units: `batch` polynomials longer
+    than the padded point count through a prepared tree, and coset_extrapolate with the tree route forced, against Horner and the oracle."""
+    import torch
+
+    d = oracle.fill_random(n_points * width, 2400 + n_points)
+    c = oracle.fill_random(batch * n_coeffs * width, 2401 + n_coeffs)
+    dd, dc = _to_dev(d), _to_dev(c)
+    out = torch.empty(batch * n_points * width, dtype=torch.int64, device="cuda")
+    with tf.device.ZerofierTree(dd, width=width) as tree:
+        tree.batch_evaluate(dc, n_coeffs, out, batch=batch)
+    torch.cuda.synchronize()
+    got = _to_host(out).reshape(batch, n_points, width)
+    for b in range(batch):
+        one = torch.empty(n_points * width, dtype=torch.int64, device="cuda")
+        tf.lib().tf_set_batch_eval_route(1)
+        try:
+            tf.device.batch_evaluate(dc[b * n_coeffs * width:(b + 1) * n_coeffs * width], n_coeffs, dd, one, width=width)
+        finally:
+            tf.lib().tf_set_batch_eval_route(0)
+        torch.cuda.synchronize()
+        assert np.array_equal(got[b].reshape(-1), _to_host(one)), b
+    cb = c[(batch - 1) * n_coeffs * width:]
+    i = n_points - 1
+    want = oracle.poly_eval(cb, int(d[i])) if width == 1 else oracle.poly_eval_xfe_point(cb, d[3 * i: 3 * i + 3])
+    assert np.array_equal(got[batch - 1, i], np.asarray(want).reshape(-1))
+    # coset_extrapolate: `batch` codewords of 2^12 at the same points, tree route forced vs Horner
+    n = 1 << 12
+    cw = oracle.fill_random(batch * n * width, 2402)
+    off = oracle.bfe_new(7)
+    res = []
+    for route in (2, 1):
+        tf.lib().tf_set_batch_eval_route(route)
+        try:
+            res.append(tf.Polynomial.batch_coset_extrapolate(off, n, cw, d, width=width))
+        finally:
+            tf.lib().tf_set_batch_eval_route(0)
+    assert np.array_equal(res[0], res[1])

@@ -33,6 +33,9 @@ run "TF_NTT_WG_THREADS=256" "256-thread workgroups everywhere"
 run "TF_NTT_NT=3" "non-temporal loads / stores in the generic kernels as well"
 run "TF_BATCH_EVAL=tree" "zerofier tree wherever it applies"
 run "TF_BATCH_EVAL=horner" "Horner everywhere"
+run "TF_BATCH_EVAL=tree TF_TREE_UNIT_SLAB=3000" "zerofier tree with the units of a walk cut into slabs of a few units"
+run "TF_TREE_LEAF_LOG=6" "64-point leaves in the zerofier tree (deeper trees)"
+run "TF_TREE_LEAF_LOG=10" "1024-point leaves"
 echo "--- long randomised parity run (tools/fuzz_long.py, 3 seeds x 120 s)" | tee -a "$OUT"
 for seed in 11 12 13; do
   timeout 400 python tools/fuzz_long.py $seed 120 2>&1 | grep -v amdgpu.ids | tail -n 3 | tee -a "$OUT"

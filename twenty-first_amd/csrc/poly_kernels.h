@@ -237,9 +237,11 @@ __global__ void __launch_bounds__(256) newton_pointwise_kernel(u64* C, long long
 }
 
 // Leaves: remainder of degree < d per leaf, evaluated at the leaf's d points by Horner (coefficients through LDS).
-// vals[leaf * d + t] = r_leaf(points[leaf * d + t]);  grid = leaves, block = d threads
+// vals[leaf * d + t] = r_leaf(points[(leaf % leaves_per_unit) * d + t]);  grid = units * leaves_per_unit, block = d threads
+// (several polynomials -- "units" -- walk the tree together; they share the points)
 template <int L>
-__global__ void __launch_bounds__(kLeafMax) leaf_evaluate_kernel(const u64* rem, const u64* points, long long n_points, int d, u64* vals) {
+__global__ void __launch_bounds__(kLeafMax) leaf_evaluate_kernel(const u64* rem, const u64* points, long long n_points, int d, u64* vals,
+                                                                 long long leaves_per_unit) {
     extern __shared__ u64 leaf_lds[];  // d * L words
     u64* c = leaf_lds;
     const int t = threadIdx.x;
@@ -247,7 +249,7 @@ __global__ void __launch_bounds__(kLeafMax) leaf_evaluate_kernel(const u64* rem,
 #pragma unroll
     for (int k = 0; k < L; ++k) c[t * L + k] = rem[(leaf * d + t) * L + k];
     __syncthreads();
-    const long long pi = leaf * d + t;
+    const long long pi = (leaf % leaves_per_unit) * d + t;
     if (pi >= n_points) return;
     u64 x[L], a[L];
     fe_load<L>(points + pi * L, x);
@@ -261,15 +263,30 @@ __global__ void __launch_bounds__(kLeafMax) leaf_evaluate_kernel(const u64* rem,
 #pragma unroll
         for (int k = 0; k < L; ++k) a[k] = r[k];
     }
-    fe_store<L>(vals + pi * L, a);
+    fe_store<L>(vals + (leaf * d + t) * L, a);
 }
 
-// chunks of a long polynomial recombined per point: out[i] = sum_k vals[k][i] * (x_i^M)^k  (Horner over k), M = 2^log_m
+// out[i] = A[i] * B[i mod period]: the transforms of several units against the level's cached transforms (shared by the units)
+template <int L>
+__global__ void __launch_bounds__(256) product_bcast_kernel(const u64* A, const u64* B, u64* out, long long period, long long total) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    u64 a[L], b[L], r[L];
+    fe_load<L>(A + i * L, a);
+    fe_load<L>(B + (i % period) * L, b);
+    fe_mul<L>(a, b, r);
+    fe_store<L>(out + i * L, r);
+}
+
+// chunks of a long polynomial recombined per point: out[b][i] = sum_k vals[b][k][i] * (x_i^M)^k  (Horner over k), M = 2^log_m;
+// grid.y = polynomial b (vals: [b][n_chunks][chunk_stride], out: [b][n_points])
 template <int L>
 __global__ void __launch_bounds__(256) chunk_combine_kernel(const u64* vals, long long chunk_stride, int n_chunks, const u64* points,
                                                             long long n_points, int log_m, u64* out) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_points) return;
+    vals += (long long)blockIdx.y * n_chunks * chunk_stride * L;
+    out += (long long)blockIdx.y * n_points * L;
     u64 xm[L], acc[L];
     fe_load<L>(points + i * L, xm);
     for (int s = 0; s < log_m; ++s) {

@@ -1962,42 +1962,54 @@ int zerofier_tree_build(DeviceCtx* ctx, const u64* points, long long n_points, Z
     return TF_OK;
 }
 
-// F: one unit of exactly M coefficients (zero padded); vals: M values (the first n_points are meaningful)
+// product of U * batch transforms `a_hat` with the level's cached transforms `b_hat` (shared by the U units), back in the coefficient
+// domain in `out`: one unit over BFieldElement rides on the inverse transform's load, otherwise a pointwise pass of its own.
+template <int L>
+int inverse_of_cached_product(DeviceCtx* ctx, const u64* a_hat, const u64* b_hat, u64* out, size_t order, size_t batch, long long U, hipStream_t s) {
+    if (U == 1) return inverse_of_product<L>(ctx, a_hat, b_hat, (long long)order * L, out, order, batch, false, s);
+    const long long period = (long long)(batch * order), total = period * U;
+    int rc = launch_1d<L>(tfk::product_bcast_kernel<L>, total, s, a_hat, b_hat, out, period, total);
+    if (rc) return rc;
+    return run_ntt(ctx, out, out, (long long)order * L, (long long)order * L, order, batch * (size_t)U, L, true, nullptr, -1, s);
+}
+
+// F: U units of exactly M coefficients each (zero padded), walking the tree together; vals: U x M values (the first n_points of
+// every unit are meaningful); work: kTreeWorkArrays * U * M * L words.
 template <int L>
 int zerofier_tree_evaluate(DeviceCtx* ctx, const ZerofierTree& T, const u64* F, const u64* points, long long n_points, u64* vals, u64* work,
-                           hipStream_t s) {
+                           hipStream_t s, long long U = 1) {
     const int kTreeLeaf = tree_leaf(L);
-    const long long M = T.M;
-    const u64* cur = F;  // remainders of the level above: (M / 2d) polynomials of 2d coefficients
-    u64* ping = work;               // M
-    u64* pong = work + M * L;       // M
-    u64* fr = work + 2 * M * L;     // children x d      reversed upper halves, then the quotients
-    u64* Fh = work + 3 * M * L;     // children x 2d     their transforms
-    u64* prod = work + 5 * M * L;   // children x 2d     products back in the coefficient domain
-    u64* frq = work + 7 * M * L;    // children x d      the next level's reversed upper halves, written by this level's last kernel
+    const long long M = T.M, UM = U * M;
+    const u64* cur = F;  // remainders of the level above: U x (M / 2d) polynomials of 2d coefficients
+    u64* ping = work;                // U M
+    u64* pong = work + UM * L;       // U M
+    u64* fr = work + 2 * UM * L;     // U x children x d      reversed upper halves, then the quotients
+    u64* Fh = work + 3 * UM * L;     // U x children x 2d     their transforms
+    u64* prod = work + 5 * UM * L;   // U x children x 2d     products back in the coefficient domain
+    u64* frq = work + 7 * UM * L;    // U x children x d      the next level's reversed upper halves, written by this level's last kernel
     for (int l = T.h - 1; l >= 0; --l) {
-        const long long d = (long long)kTreeLeaf << l, children = M / d;
+        const long long d = (long long)kTreeLeaf << l, children = M / d, all = U * children;  // (children is even: global child / 2 = global parent)
         // rev(q) = rev(f_high) g mod x^d   (below the top level the reversed upper halves come from the level above's last kernel)
         int rc = TF_OK;
         const u64* fr_in = frq;
         if (l == T.h - 1) {
-            rc = launch_1d<L>(tfk::remainder_rev_high_kernel<L>, children * d, s, cur, fr, d, children);
+            rc = launch_1d<L>(tfk::remainder_rev_high_kernel<L>, all * d, s, cur, fr, d, all);
             fr_in = fr;
         }
-        if (!rc) rc = run_ntt(ctx, fr_in, Fh, d * L, 2 * d * L, (size_t)(2 * d), (size_t)children, L, false, nullptr, d, s);
-        if (!rc) rc = inverse_of_product<L>(ctx, Fh, T.Ghat[l], 2 * d * L, prod, (size_t)(2 * d), (size_t)children, false, s);
-        if (!rc) rc = launch_1d<L>(tfk::poly_reverse_kernel<L>, children * d, s, (const u64*)prod, 2 * d, fr, d, children);
+        if (!rc) rc = run_ntt(ctx, fr_in, Fh, d * L, 2 * d * L, (size_t)(2 * d), (size_t)all, L, false, nullptr, d, s);
+        if (!rc) rc = inverse_of_cached_product<L>(ctx, Fh, T.Ghat[l], prod, (size_t)(2 * d), (size_t)children, U, s);
+        if (!rc) rc = launch_1d<L>(tfk::poly_reverse_kernel<L>, all * d, s, (const u64*)prod, 2 * d, fr, d, all);
         // r = f_low - (q tail)_low
-        if (!rc) rc = run_ntt(ctx, fr, Fh, d * L, 2 * d * L, (size_t)(2 * d), (size_t)children, L, false, nullptr, d, s);
-        if (!rc) rc = inverse_of_product<L>(ctx, Fh, T.That[l], 2 * d * L, prod, (size_t)(2 * d), (size_t)children, false, s);
+        if (!rc) rc = run_ntt(ctx, fr, Fh, d * L, 2 * d * L, (size_t)(2 * d), (size_t)all, L, false, nullptr, d, s);
+        if (!rc) rc = inverse_of_cached_product<L>(ctx, Fh, T.That[l], prod, (size_t)(2 * d), (size_t)children, U, s);
         if (rc) return rc;
         u64* nxt = (cur == ping) ? pong : ping;
-        rc = launch_1d<L>(tfk::remainder_finish_kernel<L>, children * d, s, cur, (const u64*)prod, 2 * d, nxt, d, children, l > 0 ? frq : (u64*)nullptr);
+        rc = launch_1d<L>(tfk::remainder_finish_kernel<L>, all * d, s, cur, (const u64*)prod, 2 * d, nxt, d, all, l > 0 ? frq : (u64*)nullptr);
         if (rc) return rc;
         cur = nxt;
     }
-    hipLaunchKernelGGL(tfk::leaf_evaluate_kernel<L>, dim3((unsigned)(M / kTreeLeaf)), dim3(kTreeLeaf), kTreeLeaf * L * sizeof(u64), s, cur, points,
-                       n_points, kTreeLeaf, vals);
+    hipLaunchKernelGGL(tfk::leaf_evaluate_kernel<L>, dim3((unsigned)(UM / kTreeLeaf)), dim3(kTreeLeaf), kTreeLeaf * L * sizeof(u64), s, cur, points,
+                       n_points, kTreeLeaf, vals, M / kTreeLeaf);
     HIPCHK(hipGetLastError());
     return TF_OK;
 }
@@ -2019,52 +2031,62 @@ bool tree_route(size_t n_coeffs, size_t n_points, size_t batch, int L) {
     size_t M = kTreeLeaf;
     while (M < n_points) M <<= 1;
     const size_t units = batch * ((n_coeffs + M - 1) / M);
-    if (units > 256) return false;  // one pass down the tree per unit: a very long polynomial on few points stays with Horner
+    if (units > 65536) return false;  // (the walk's arrays are indexed per unit)
     {
         int h = 0;
         for (size_t v = kTreeLeaf; v < M; v <<= 1) ++h;
-        const size_t arena_words = (size_t)(kTreeLevelArrays * h + kTreeWorkArrays + 1 + (n_coeffs + M - 1) / M) * M * (size_t)L;  // batch_evaluate_tree_t's arena
-        if (arena_words * sizeof(u64) > (size_t(64) << 30)) return false;  // the tree's levels would not fit a sane work space (288 GB of HBM)
+        // the tree and its build work space, then the walk's: padded coefficients and values (2 units M) + work for a slab of units
+        const size_t slab = std::max<size_t>(1, std::min<size_t>(units, (size_t(1) << 25) / M));
+        const size_t words = ((size_t)(kTreeLevelArrays * h + kTreeWorkArrays) + 2 * units + (size_t)kTreeWorkArrays * slab) * M * (size_t)L;
+        if (words * sizeof(u64) > (size_t(64) << 30)) return false;  // would not fit a sane work space (288 GB of HBM)
     }
     if (force && !strcmp(force, "tree")) return true;
     // Cost model fitted to tools/batch_eval_sweep.py on MI355X (profiles/r02_batch_eval_sweep.txt), milliseconds:
     //   Horner  n m / 1.4e9            (x 8 over XFieldElement: nine base-field products per step; measured 7 - 10)
-    //   tree    walk (1.4 + units): one build (1.4 walks) plus one walk per unit; a walk is launch-bound per level
-    //           (7 launches, 0.115 ms) plus a term in the padded point count (0.06 ms per 2^16 points, 0.2 over XFE)
+    //   tree    2.4 walks for the first unit (one build = 1.4 walks; a walk is launch-bound per level: 7 launches, 0.115 ms,
+    //           plus 0.06 ms per 2^16 padded points, 0.2 over XFE); the units walk TOGETHER, so every further unit adds only its
+    //           share of the throughput term: 0.035 ms per 2^16 points (0.16 over XFE)
     int levels = 0;
     for (size_t v = kTreeLeaf; v < M; v <<= 1) ++levels;
-    const double horner_ms = (double)n_coeffs * (double)n_points / 1.4e9 * (L == 3 ? 8.0 : 1.0);
+    const double horner_ms = (double)batch * (double)n_coeffs * (double)n_points / 1.4e9 * (L == 3 ? 8.0 : 1.0);
     const double latency = std::max(0.1, -0.10 + 0.115 * levels) * (L == 3 ? 1.3 : 1.0);
     const double walk_ms = latency + (L == 3 ? 0.2 : 0.06) * (double)M / 65536.0;
-    const double tree_ms = walk_ms * (1.4 + (double)units);
+    const double tree_ms = 2.4 * walk_ms + (double)(units - 1) * (L == 3 ? 0.16 : 0.035) * (double)M / 65536.0;
     return tree_ms < 0.9 * horner_ms;
 }
 
-// `batch` polynomials down an existing tree (levels >= 1): work space, one padded unit and the chunk values are this call's own
-// stream-ordered temporaries, so one tree serves concurrent calls.
+// `batch` polynomials down an existing tree (levels >= 1).  A polynomial longer than M is cut into chunks of M coefficients; all
+// chunks of all polynomials ("units") walk the tree TOGETHER, a slab of units at a time: every level is the same handful of
+// launches whatever the number of units, and the level's cached transforms are shared.  Work space, the padded coefficients and
+// the chunk values are this call's own stream-ordered temporaries, so one tree serves concurrent calls.
 template <int L>
 int tree_batch_evaluate(DeviceCtx* ctx, const ZerofierTree& T, const u64* points, size_t n_points, const u64* coeffs, size_t n_coeffs,
                         size_t poly_stride, size_t batch, u64* out, hipStream_t s) {
     const long long M = T.M;
     const size_t chunks = std::max<size_t>(1, (n_coeffs + (size_t)M - 1) / (size_t)M);
-    const size_t words = (size_t)(kTreeWorkArrays + 1 + chunks) * (size_t)M * L;
+    const size_t units = batch * chunks, ML = (size_t)M * L;
+    // units per walk: 2^25 elements of work per array (TF_TREE_UNIT_SLAB = elements: the A/B and test knob for the slab boundary)
+    static const size_t slab_elems = [] { const char* e = getenv("TF_TREE_UNIT_SLAB"); const long long v = e ? atoll(e) : 0; return v > 0 ? (size_t)v : (size_t(1) << 25); }();
+    const size_t slab = std::max<size_t>(1, std::min<size_t>(units, slab_elems / (size_t)M));
+    // padded coefficients (units M) + values (units M) + walk work (8 slab M)
     u64* tmp = nullptr;
-    hipError_t e = hipMallocAsync(reinterpret_cast<void**>(&tmp), words * sizeof(u64), s);
+    hipError_t e = hipMallocAsync(reinterpret_cast<void**>(&tmp), (2 * units + (size_t)kTreeWorkArrays * slab) * ML * sizeof(u64), s);
     if (e != hipSuccess) return hip_fail(e, "hipMallocAsync(zerofier tree walk)", __FILE__, __LINE__);
-    u64* work = tmp;
-    u64* unit = work + (size_t)kTreeWorkArrays * M * L;
-    u64* vals = unit + (size_t)M * L;
-    int rc = TF_OK;
-    for (size_t b = 0; b < batch && !rc; ++b) {
-        for (size_t c = 0; c < chunks && !rc; ++c) {
-            const size_t len = n_coeffs > c * (size_t)M ? std::min<size_t>((size_t)M, n_coeffs - c * (size_t)M) : 0;
-            rc = pad_copy(coeffs + b * poly_stride + c * (size_t)M * L, unit, (long long)(len * L), (long long)M * L, 1, s);
-            if (!rc) rc = zerofier_tree_evaluate<L>(ctx, T, unit, points, (long long)n_points, vals + c * (size_t)M * L, work, s);
-        }
-        int log_m = 0;
-        while ((1ll << log_m) < M) ++log_m;
-        if (!rc) rc = launch_1d<L>(tfk::chunk_combine_kernel<L>, (long long)n_points, s, (const u64*)vals, M, (int)chunks, points,
-                                   (long long)n_points, log_m, out + b * n_points * L);
+    u64* padded = tmp;
+    u64* vals = padded + units * ML;
+    u64* work = vals + units * ML;
+    int rc = pad_copy(coeffs, padded, (long long)(n_coeffs * L), (long long)(chunks * ML), (long long)batch, s, (long long)poly_stride);
+    for (size_t u0 = 0; u0 < units && !rc; u0 += slab) {
+        const size_t nu = std::min(slab, units - u0);
+        rc = zerofier_tree_evaluate<L>(ctx, T, padded + u0 * ML, points, (long long)n_points, vals + u0 * ML, work, s, (long long)nu);
+    }
+    int log_m = 0;
+    while ((1ll << log_m) < M) ++log_m;
+    for (size_t b0 = 0; b0 < batch && !rc; b0 += 65535) {  // grid.y = polynomial
+        const unsigned nb = (unsigned)std::min<size_t>(65535, batch - b0);
+        hipLaunchKernelGGL(tfk::chunk_combine_kernel<L>, dim3((unsigned)((n_points + 255) / 256), nb), dim3(256), 0, s, (const u64*)(vals + b0 * chunks * ML),
+                           M, (int)chunks, points, (long long)n_points, log_m, out + b0 * n_points * L);
+        if (hipGetLastError() != hipSuccess) rc = TF_ERR_HIP;
     }
     hipError_t e2 = hipFreeAsync(tmp, s);
     if (rc) return rc;
