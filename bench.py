@@ -689,6 +689,12 @@ def side_measurements(tf, torch, dev):
                                                        "prepared_tree_evaluate_ms": round(ms_te, 3), "prepared_tree_interpolate_ms": round(ms_ti, 3),
                                                        "evaluate_then_interpolate_is_identity": ok}
             del dom, cf, vals, back
+        # a table of codewords extrapolated to many points: every codeword's chunks walk the zerofier tree together
+        cw, pts = rnd(64 << 16, 11), rnd(1 << 14, 12)
+        ex = torch.empty(64 << 14, dtype=torch.int64, device=dev)
+        ms = _timed(lambda: tf.device.coset_extrapolate(off, cw, 1 << 16, pts, ex, batch=64), reps=3)
+        extra["coset_extrapolate_64x_2p16_to_2p14_points"] = {"ms": round(ms, 3)}
+        del cw, pts, ex
         # PCIe-inclusive figure of the host-pointer entry point (pageable numpy buffers, 32 x 2^20 BFE = 256 MiB each way)
         import numpy as _np
 
