@@ -228,6 +228,11 @@ int tf_barycentric_evaluate_xfe_dev(const uint64_t *d_codewords, size_t n, size_
  * reference's batch_inversion.  na == 0 (zero dividend): TF_OK, nothing written.  The _dev call synchronises its stream once. */
 int tf_poly_clean_divide_bfe(const uint64_t *a, size_t na, const uint64_t *b, size_t nb, uint64_t *out);
 int tf_poly_clean_divide_bfe_dev(const uint64_t *d_a, size_t na, const uint64_t *d_b, size_t nb, uint64_t *d_out, void *stream);
+/* The same for `batch` dividends of na coefficients each (packed; na counts up to the longest dividend, shorter ones zero padded)
+ * over ONE divisor -- a prover's quotients: many numerators over the same zerofier.  The divisor's transform is inverted once.
+ * out: batch x (na - nb + 1) coefficients.  Any unclean row fails the call.  At most 65 535 dividends per call. */
+int tf_poly_clean_divide_many_bfe(const uint64_t *a, size_t na, size_t batch, const uint64_t *b, size_t nb, uint64_t *out);
+int tf_poly_clean_divide_many_bfe_dev(const uint64_t *d_a, size_t na, size_t batch, const uint64_t *d_b, size_t nb, uint64_t *d_out, void *stream);
 /* ZerofierTree  math/zerofier_tree.rs (new_from_domain :66-87, zerofier :93-99) with Polynomial::divide_and_conquer_batch_evaluate
  * math/polynomial.rs:1882-1894: the tree of a domain built ONCE and kept in HBM (levels, the cached level transforms, the root,
  * the domain, and after the first interpolation the inverse weights), for callers that evaluate or interpolate on the same

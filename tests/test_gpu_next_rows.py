@@ -1098,3 +1098,32 @@ def test_many_polynomials_and_chunks_walk_the_tree_together(tf, oracle, width, n
         finally:
             tf.lib().tf_set_batch_eval_route(0)
     assert np.array_equal(res[0], res[1])
+
+
+@pytest.mark.parametrize("nq,nb,batch", [(5, 3, 4), (300, 700, 7), (3000, 1100, 3), (1 << 15, 1 << 14, 5)])
+def test_many_dividends_over_one_divisor(tf, oracle, nq, nb, batch):
+    """tf_poly_clean_divide_many_bfe: `batch` products q_k * b divided by the same b give the q_k back (the quotients of a table of
+    numerators over one zerofier); a shorter dividend is zero padded; one unclean row fails the call."""
+    import torch
+
+    b = oracle.fill_random(nb, 2500 + nb)
+    qs = [oracle.fill_random(nq - (k % 2), 2501 + k) for k in range(batch)]   # every other quotient one coefficient shorter
+    na = nq + nb - 1
+    rows = []
+    for q in qs:
+        a = oracle.poly_mul(q, b)
+        rows.append(np.concatenate([a, np.zeros(na - a.size, dtype=np.uint64)]))
+    a_all = np.ascontiguousarray(np.concatenate(rows))
+    out = torch.empty(batch * nq, dtype=torch.int64, device="cuda")
+    tf.device.clean_divide_many(_to_dev(a_all), na, _to_dev(b), out, batch)
+    torch.cuda.synchronize()
+    got = _to_host(out).reshape(batch, nq)
+    for k, q in enumerate(qs):
+        assert np.array_equal(got[k, : q.size], q) and not got[k, q.size:].any(), k
+    bad = a_all.copy()
+    bad[(batch - 1) * na + 1] ^= np.uint64(1)
+    with pytest.raises(tf.NttPanic) as e:
+        tf.device.clean_divide_many(_to_dev(bad), na, _to_dev(b), out, batch)
+    assert e.value.code == 16
+    with pytest.raises(ValueError):
+        tf.device.clean_divide_many(_to_dev(a_all), na, _to_dev(b), out[:-1], batch)

@@ -510,11 +510,13 @@ __device__ __forceinline__ void xfe_pow(const u64 (&base)[3], unsigned long long
     }
 }
 
-// out[i] = c[i] * base^i (an XFieldElement) for i < n_c, zero up to order: Polynomial::scale with an extension-field offset
-// (polynomial.rs:760-773) followed by the zero padding of :2391-2392
+// out[row][i] = c[row][i] * base^i (an XFieldElement) for i < n_c, zero up to order: Polynomial::scale with an extension-field offset
+// (polynomial.rs:760-773) followed by the zero padding of :2391-2392.  grid.y = row (rows n_c words apart in, 3 * order words apart out)
 __global__ void __launch_bounds__(256) lift_scale_kernel(const u64* c, long long n_c, long long order, u64* out, u64 b0, u64 b1, u64 b2) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= order) return;
+    c += (long long)blockIdx.y * n_c;
+    out += (long long)blockIdx.y * order * 3;
     u64 r[3] = {0, 0, 0};
     if (i < n_c) {
         const u64 base[3] = {b0, b1, b2};
@@ -528,24 +530,25 @@ __global__ void __launch_bounds__(256) lift_scale_kernel(const u64* c, long long
     fe_store<3>(out + 3 * i, r);
 }
 
-// out[i] = a[i] / b[i]; flag bit 0 when some b[i] is zero (batch_inversion panics, traits.rs:106)
-__global__ void __launch_bounds__(256) xfe_divide_pointwise_kernel(const u64* a, const u64* b, u64* out, long long count, int* flag) {
+// b[i] <- 1 / b[i] in place; flag bit 0 when some b[i] is zero (batch_inversion panics, traits.rs:106)
+__global__ void __launch_bounds__(256) xfe_invert_inplace_kernel(u64* b, long long count, int* flag) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
-    u64 x[3], y[3], inv[3], r[3];
-    fe_load<3>(a + 3 * i, x);
+    u64 y[3], inv[3];
     fe_load<3>(b + 3 * i, y);
     if (!xfe_inverse(y, inv)) atomicOr(flag, 1);
-    xfe_mul(x, inv, r);
-    fe_store<3>(out + 3 * i, r);
+    fe_store<3>(b + 3 * i, inv);
 }
 
-// out[i] = unlift(q[i] * base_inv^i) for i < n_q; flag bit 1 when a coefficient does not come back to the base field
-// (unlift().unwrap() panics, :2410) or a coefficient beyond the quotient's degree is not zero (the division was not clean)
+// out[row][i] = unlift(q[row][i] * base_inv^i) for i < n_q; flag bit 1 when a coefficient does not come back to the base field
+// (unlift().unwrap() panics, :2410) or a coefficient beyond the quotient's degree is not zero (the division was not clean).
+// grid.y = row (rows 3 * order words apart in, n_q words apart out)
 __global__ void __launch_bounds__(256) unscale_unlift_kernel(const u64* q, long long order, long long n_q, u64* out, u64 b0, u64 b1, u64 b2,
                                                             int* flag) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= order) return;
+    q += (long long)blockIdx.y * order * 3;
+    out += (long long)blockIdx.y * n_q;
     const u64 base[3] = {b0, b1, b2};
     u64 pw[3], v[3], r[3];
     xfe_pow(base, (unsigned long long)i, pw);

@@ -2620,10 +2620,14 @@ int barycentric_dev(const u64* codewords, size_t n, size_t batch, int cw_width, 
 // X * <w_order> of the extension field (poly_kernels.h).  a, b: normalised coefficient arrays (non-zero leading coefficient),
 // out: na - nb + 1 coefficients.  The reference's factor-x workaround (:2368-2378) changes nothing on this coset (X w^i != 0) and
 // is not needed; the naive route it takes for divisors below degree 512 (:2360-2364) returns the same quotient.
-int clean_divide_dev(const u64* a, size_t na, const u64* b, size_t nb, u64* out, void* stream) {
+// `batch` dividends of na coefficients each (packed) by ONE divisor: the divisor's transform is inverted once and shared -- the
+// shape of a prover's quotients (many numerators over the same zerofier).
+int clean_divide_dev(const u64* a, size_t na, const u64* b, size_t nb, u64* out, void* stream, size_t batch = 1) {
     if (nb == 0) return TF_ERR_DIVISION_BY_ZERO;                      // naive_divide :556-559 "divisor should be non-zero"
     if (na < nb) return na ? TF_ERR_DIVISION_NOT_CLEAN : TF_OK;       // a non-zero dividend of lower degree: the remainder is the dividend
+    if (batch == 0) return TF_OK;
     if (!a || !b || !out) return TF_ERR_NULL_POINTER;
+    if (batch > 65535) return TF_ERR_LEN_TOO_LARGE;
     size_t order = 1;
     while (order < na) order <<= 1;                                   // (dividend.degree() + 1).next_power_of_two() :2388-2389
     int rc = check_len(order);
@@ -2632,31 +2636,33 @@ int clean_divide_dev(const u64* a, size_t na, const u64* b, size_t nb, u64* out,
     rc = current_ctx(&ctx);
     if (rc) return rc;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    u64* tmp = nullptr;
+    u64* tmp = nullptr;  // rows 0 .. batch-1: the dividends, row `batch`: the divisor; order XFieldElements each
     const size_t half = order * 3;
-    hipError_t e = hipMallocAsync(reinterpret_cast<void**>(&tmp), (2 * half + 2) * sizeof(u64), s);
+    hipError_t e = hipMallocAsync(reinterpret_cast<void**>(&tmp), ((batch + 1) * half + 2) * sizeof(u64), s);
     if (e != hipSuccess) return hip_fail(e, "hipMallocAsync(clean_divide)", __FILE__, __LINE__);
-    int* flag = reinterpret_cast<int*>(tmp + 2 * half);
+    u64* div = tmp + batch * half;
+    int* flag = reinterpret_cast<int*>(tmp + (batch + 1) * half);
     const u64 X[3] = {0, gl::ONE, 0};                                 // XFieldElement::from([0, 1, 0]) :2383
     const u64 Xinv[3] = {gl::ONE, 0, gl::neg(gl::ONE)};               // x (x^2 - 1) = -1  ->  x^-1 = 1 - x^2
     const unsigned blocks = (unsigned)((order + 255) / 256);
     e = hipMemsetAsync(flag, 0, sizeof(int), s);
     if (e != hipSuccess) rc = hip_fail(e, "hipMemsetAsync", __FILE__, __LINE__);
     if (!rc) {
-        hipLaunchKernelGGL(tfk::lift_scale_kernel, dim3(blocks), dim3(256), 0, s, a, (long long)na, (long long)order, tmp, X[0], X[1], X[2]);
-        hipLaunchKernelGGL(tfk::lift_scale_kernel, dim3(blocks), dim3(256), 0, s, b, (long long)nb, (long long)order, tmp + half, X[0], X[1], X[2]);
+        hipLaunchKernelGGL(tfk::lift_scale_kernel, dim3(blocks, (unsigned)batch), dim3(256), 0, s, a, (long long)na, (long long)order, tmp, X[0], X[1], X[2]);
+        hipLaunchKernelGGL(tfk::lift_scale_kernel, dim3(blocks, 1), dim3(256), 0, s, b, (long long)nb, (long long)order, div, X[0], X[1], X[2]);
         if (hipGetLastError() != hipSuccess) rc = TF_ERR_HIP;
     }
-    if (!rc) rc = run_ntt(ctx, tmp, tmp, (long long)half, (long long)half, order, 2, 3, false, nullptr, -1, s);
+    if (!rc) rc = run_ntt(ctx, tmp, tmp, (long long)half, (long long)half, order, batch + 1, 3, false, nullptr, -1, s);
     if (!rc) {
-        hipLaunchKernelGGL(tfk::xfe_divide_pointwise_kernel, dim3(blocks), dim3(256), 0, s, (const u64*)tmp, (const u64*)(tmp + half), tmp,
-                           (long long)order, flag);
+        hipLaunchKernelGGL(tfk::xfe_invert_inplace_kernel, dim3(blocks), dim3(256), 0, s, div, (long long)order, flag);
         if (hipGetLastError() != hipSuccess) rc = TF_ERR_HIP;
     }
-    if (!rc) rc = run_ntt(ctx, tmp, tmp, (long long)half, (long long)half, order, 1, 3, true, nullptr, -1, s);
+    if (!rc) rc = launch_1d<3>(tfk::product_bcast_kernel<3>, (long long)(batch * order), s, (const u64*)tmp, (const u64*)div, tmp, (long long)order,
+                               (long long)(batch * order));
+    if (!rc) rc = run_ntt(ctx, tmp, tmp, (long long)half, (long long)half, order, batch, 3, true, nullptr, -1, s);
     if (!rc) {
-        hipLaunchKernelGGL(tfk::unscale_unlift_kernel, dim3(blocks), dim3(256), 0, s, (const u64*)tmp, (long long)order, (long long)(na - nb + 1),
-                           out, Xinv[0], Xinv[1], Xinv[2], flag);
+        hipLaunchKernelGGL(tfk::unscale_unlift_kernel, dim3(blocks, (unsigned)batch), dim3(256), 0, s, (const u64*)tmp, (long long)order,
+                           (long long)(na - nb + 1), out, Xinv[0], Xinv[1], Xinv[2], flag);
         if (hipGetLastError() != hipSuccess) rc = TF_ERR_HIP;
     }
     if (!rc) {
@@ -3357,6 +3363,17 @@ int tf_poly_evaluate_bfe_at_xfe(const uint64_t* c, size_t nc, size_t batch, cons
 }
 int tf_poly_clean_divide_bfe_dev(const uint64_t* a, size_t na, const uint64_t* b, size_t nb, uint64_t* out, void* stream) {
     return clean_divide_dev(a, na, b, nb, out, stream);
+}
+int tf_poly_clean_divide_many_bfe_dev(const uint64_t* a, size_t na, size_t batch, const uint64_t* b, size_t nb, uint64_t* out, void* stream) {
+    return clean_divide_dev(a, na, b, nb, out, stream, batch);
+}
+int tf_poly_clean_divide_many_bfe(const uint64_t* a, size_t na, size_t batch, const uint64_t* b, size_t nb, uint64_t* out) {
+    if (nb == 0) return TF_ERR_DIVISION_BY_ZERO;
+    if (na < nb) return na ? TF_ERR_DIVISION_NOT_CLEAN : TF_OK;
+    if (batch == 0) return TF_OK;
+    if (!a || !b || !out) return TF_ERR_NULL_POINTER;
+    return host_roundtrip(a, batch * na, b, nb, out, batch * (na - nb + 1),
+                          [&](u64* da, u64* db, u64* o, hipStream_t s) { return clean_divide_dev(da, na, db, nb, o, s, batch); });
 }
 int tf_poly_clean_divide_bfe(const uint64_t* a, size_t na, const uint64_t* b, size_t nb, uint64_t* out) {
     if (nb == 0) return TF_ERR_DIVISION_BY_ZERO;

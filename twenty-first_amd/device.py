@@ -208,6 +208,13 @@ def clean_divide(a, b, out, stream=None) -> None:
     _chk(_lib.lib().tf_poly_clean_divide_bfe_dev(_p(a), a.numel(), _p(b), b.numel(), _p(out), _stream(stream)), "clean_divide")
 
 
+def clean_divide_many(a, na: int, b, out, batch: int, stream=None) -> None:
+    """`batch` dividends of na coefficients each over one divisor (tf_poly_clean_divide_many_bfe_dev): out = batch x (na - nb + 1)."""
+    a, b, out = _t(a, "a"), _t(b, "b"), _t(out, "out")
+    _need(a.numel() == batch * na and na >= b.numel() and out.numel() == batch * (na - b.numel() + 1), "a = batch * na, out = batch * (na - nb + 1) coefficients")
+    _chk(_lib.lib().tf_poly_clean_divide_many_bfe_dev(_p(a), na, batch, _p(b), b.numel(), _p(out), _stream(stream)), "clean_divide")
+
+
 def zerofier(roots, out, width: int = 1, stream=None) -> None:
     """Polynomial::zerofier (math/polynomial.rs:1435-1441) on device buffers: out = the n + 1 coefficients of prod (x - roots[i])."""
     roots, out = _t(roots, "roots"), _t(out, "out")
