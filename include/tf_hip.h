@@ -162,6 +162,10 @@ int tf_poly_square_bfe(const uint64_t *a, size_t na, uint64_t *out, size_t batch
 int tf_poly_square_xfe(const uint64_t *a, size_t na, uint64_t *out, size_t batch);
 int tf_poly_square_bfe_dev(const uint64_t *d_a, size_t na, uint64_t *d_out, size_t batch, void *stream);
 int tf_poly_square_xfe_dev(const uint64_t *d_a, size_t na, uint64_t *d_out, size_t batch, void *stream);
+/* fast_multiply (math/polynomial.rs:900-932) of `batch` polynomials of na coefficients each (packed) by ONE polynomial b -- a table of
+ * numerators times the same zerofier: b is transformed once.  out: batch x (na + nb - 1) coefficients.  Device-resident only. */
+int tf_poly_mul_shared_bfe_dev(const uint64_t *d_a, size_t na, size_t batch, const uint64_t *d_b, size_t nb, uint64_t *d_out, void *stream);
+int tf_poly_mul_shared_xfe_dev(const uint64_t *d_a, size_t na, size_t batch, const uint64_t *d_b, size_t nb, uint64_t *d_out, void *stream);
 int tf_lde_bfe_dev(const uint64_t *d_values, size_t n, uint64_t offset_in_raw, uint64_t *d_out, size_t m, uint64_t offset_out_raw, size_t batch, void *stream);
 int tf_lde_xfe_dev(const uint64_t *d_values, size_t n, uint64_t offset_in_raw, uint64_t *d_out, size_t m, uint64_t offset_out_raw, size_t batch, void *stream);
 /* Polynomial::batch_evaluate / iterative_batch_evaluate  math/polynomial.rs:1840-1894: out[i] = f(points[i]),

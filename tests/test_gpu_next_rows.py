@@ -1127,3 +1127,22 @@ def test_many_dividends_over_one_divisor(tf, oracle, nq, nb, batch):
     assert e.value.code == 16
     with pytest.raises(ValueError):
         tf.device.clean_divide_many(_to_dev(a_all), na, _to_dev(b), out[:-1], batch)
+
+
+@pytest.mark.parametrize("width,na,nb,batch", [(1, 3, 2, 3), (1, 5, 9, 2), (1, 700, 300, 5), (1, 40000, 25000, 3), (3, 6, 4, 2), (3, 2000, 900, 4)])
+def test_many_polynomials_times_one_shared_polynomial(tf, oracle, width, na, nb, batch):
+    """tf_poly_mul_shared_*_dev: `batch` polynomials times ONE polynomial (its transform computed once and broadcast) equal the
+    products the oracle's fast_multiply gives one by one (math/polynomial.rs:900-932)."""
+    import torch
+
+    a = oracle.fill_random(batch * na * width, 2600 + na)
+    b = oracle.fill_random(nb * width, 2601 + nb)
+    n_out = na + nb - 1
+    out = torch.empty(batch * n_out * width, dtype=torch.int64, device="cuda")
+    tf.device.poly_mul_shared(_to_dev(a), na, _to_dev(b), out, batch, width=width)
+    torch.cuda.synchronize()
+    got = _to_host(out).reshape(batch, -1)
+    for k in range(batch):
+        assert np.array_equal(got[k], oracle.poly_mul(a[k * na * width:(k + 1) * na * width], b, width=width)), k
+    with pytest.raises(ValueError):
+        tf.device.poly_mul_shared(_to_dev(a), na, _to_dev(b), out[:-1], batch, width=width)

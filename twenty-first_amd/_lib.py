@@ -73,6 +73,8 @@ SIGNATURES = {
     "tf_barycentric_evaluate_xfe": (C.c_int, [_vp, _sz, _sz, _vp, _vp]),
     "tf_barycentric_evaluate_bfe_dev": (C.c_int, [_vp, _sz, _sz, _vp, _vp, _vp]),
     "tf_barycentric_evaluate_xfe_dev": (C.c_int, [_vp, _sz, _sz, _vp, _vp, _vp]),
+    "tf_poly_mul_shared_bfe_dev": (C.c_int, [_vp, _sz, _sz, _vp, _sz, _vp, _vp]),
+    "tf_poly_mul_shared_xfe_dev": (C.c_int, [_vp, _sz, _sz, _vp, _sz, _vp, _vp]),
     "tf_poly_clean_divide_bfe": (C.c_int, [_vp, _sz, _vp, _sz, _vp]),
     "tf_poly_clean_divide_many_bfe": (C.c_int, [_vp, _sz, _sz, _vp, _sz, _vp]),
     "tf_poly_clean_divide_many_bfe_dev": (C.c_int, [_vp, _sz, _sz, _vp, _sz, _vp, _vp]),

@@ -1722,6 +1722,15 @@ int hadamard_dev(const u64* a, const u64* b, u64* out, size_t count, int L, void
     return TF_OK;
 }
 
+// one thread per item, 256-thread blocks (the glue kernels of poly_kernels.h)
+template <int L, class K, class... Args>
+int launch_1d(K kernel, long long threads, hipStream_t s, Args... args) {
+    if (threads <= 0) return TF_OK;
+    hipLaunchKernelGGL(kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, args...);
+    HIPCHK(hipGetLastError());
+    return TF_OK;
+}
+
 int pad_copy(const u64* src, u64* dst, long long n_src_words, long long n_dst_words, long long batch, hipStream_t s,
              long long src_stride_words = 0) {
     if (n_dst_words * batch == 0) return TF_OK;
@@ -1782,6 +1791,43 @@ int poly_mul_dev(const u64* a, size_t na, const u64* b, size_t nb, u64* out, siz
         if (!rc) rc = run_ntt(ctx, tmp, tmp, (long long)order * L, (long long)order * L, order, batch, L, true, nullptr, -1, s);
     }
     if (!rc && !copied) rc = pad_copy(tmp, out, (long long)order * L, (long long)n_out * L, (long long)batch, s);
+    hipError_t e2 = hipFreeAsync(tmp, s);
+    if (rc) return rc;
+    if (e2 != hipSuccess) return hip_fail(e2, "hipFreeAsync", __FILE__, __LINE__);
+    return TF_OK;
+}
+
+// fast_multiply of `batch` polynomials by ONE polynomial b (a table of numerators times the same zerofier; polynomial.rs:900-932
+// per product): b is transformed once and its transform broadcast.  out: batch x (na + nb - 1) coefficients.
+int poly_mul_shared_dev(const u64* a, size_t na, size_t batch, const u64* b, size_t nb, u64* out, int L, void* stream) {
+    if (batch == 0 || na == 0 || nb == 0) return TF_OK;  // a zero polynomial: empty products
+    if (!a || !b || !out) return TF_ERR_NULL_POINTER;
+    const size_t n_out = na + nb - 1;
+    size_t order = 1;
+    while (order < n_out) order <<= 1;
+    int rc = check_len(order);
+    if (rc) return rc;
+    if (order <= 16) {  // tiny products: the plain batched route with b repeated is not worth a special case -- one product at a time
+        for (size_t k = 0; k < batch && !rc; ++k) rc = poly_mul_dev(a + k * na * L, na, b, nb, out + k * n_out * L, 1, L, stream);
+        return rc;
+    }
+    DeviceCtx* ctx = nullptr;
+    rc = current_ctx(&ctx);
+    if (rc) return rc;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    u64* tmp = nullptr;  // batch transforms of a, one of b
+    const size_t row = order * size_t(L);
+    hipError_t e = hipMallocAsync(reinterpret_cast<void**>(&tmp), (batch + 1) * row * sizeof(u64), s);
+    if (e != hipSuccess) return hip_fail(e, "hipMallocAsync(poly_mul_shared)", __FILE__, __LINE__);
+    u64* bh = tmp + batch * row;
+    rc = run_ntt(ctx, a, tmp, (long long)na * L, (long long)row, order, batch, L, false, nullptr, (long long)na, s);
+    if (!rc) rc = run_ntt(ctx, b, bh, (long long)nb * L, (long long)row, order, 1, L, false, nullptr, (long long)nb, s);
+    if (!rc) rc = L == 1 ? launch_1d<1>(tfk::product_bcast_kernel<1>, (long long)(batch * order), s, (const u64*)tmp, (const u64*)bh, tmp, (long long)order,
+                                        (long long)(batch * order))
+                         : launch_1d<3>(tfk::product_bcast_kernel<3>, (long long)(batch * order), s, (const u64*)tmp, (const u64*)bh, tmp, (long long)order,
+                                        (long long)(batch * order));
+    if (!rc) rc = run_ntt(ctx, tmp, tmp, (long long)row, (long long)row, order, batch, L, true, nullptr, -1, s);
+    if (!rc) rc = pad_copy(tmp, out, (long long)row, (long long)(n_out * L), (long long)batch, s);
     hipError_t e2 = hipFreeAsync(tmp, s);
     if (rc) return rc;
     if (e2 != hipSuccess) return hip_fail(e2, "hipFreeAsync", __FILE__, __LINE__);
@@ -1878,14 +1924,6 @@ inline int tree_leaf_log(int L) {  // TF_TREE_LEAF_LOG = 6..10 overrides both fi
     return forced ? forced : (L == 1 ? 8 : 7);
 }
 inline int tree_leaf(int L) { return 1 << tree_leaf_log(L); }
-
-template <int L, class K, class... Args>
-int launch_1d(K kernel, long long threads, hipStream_t s, Args... args) {
-    if (threads <= 0) return TF_OK;
-    hipLaunchKernelGGL(kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, args...);
-    HIPCHK(hipGetLastError());
-    return TF_OK;
-}
 
 struct ZerofierTree {
     int h = 0;                 // levels 0 .. h-1 hold zerofiers of degree leaf << level (the root, level h, is never needed)
@@ -3363,6 +3401,12 @@ int tf_poly_evaluate_bfe_at_xfe(const uint64_t* c, size_t nc, size_t batch, cons
 }
 int tf_poly_clean_divide_bfe_dev(const uint64_t* a, size_t na, const uint64_t* b, size_t nb, uint64_t* out, void* stream) {
     return clean_divide_dev(a, na, b, nb, out, stream);
+}
+int tf_poly_mul_shared_bfe_dev(const uint64_t* a, size_t na, size_t batch, const uint64_t* b, size_t nb, uint64_t* out, void* stream) {
+    return poly_mul_shared_dev(a, na, batch, b, nb, out, 1, stream);
+}
+int tf_poly_mul_shared_xfe_dev(const uint64_t* a, size_t na, size_t batch, const uint64_t* b, size_t nb, uint64_t* out, void* stream) {
+    return poly_mul_shared_dev(a, na, batch, b, nb, out, 3, stream);
 }
 int tf_poly_clean_divide_many_bfe_dev(const uint64_t* a, size_t na, size_t batch, const uint64_t* b, size_t nb, uint64_t* out, void* stream) {
     return clean_divide_dev(a, na, b, nb, out, stream, batch);

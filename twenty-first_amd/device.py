@@ -150,6 +150,17 @@ def poly_mul(a, na: int, b, nb: int, out, batch: int = 1, width: int = 1, stream
     _chk(fn(_p(a), na, _p(b), nb, _p(out), batch, _stream(stream)), "fast_multiply")
 
 
+def poly_mul_shared(a, na: int, b, out, batch: int, width: int = 1, stream=None) -> None:
+    """`batch` polynomials of na coefficients each times ONE polynomial b (tf_poly_mul_shared_*_dev): out = batch x (na + nb - 1)."""
+    a, b, out = _t(a, "a"), _t(b, "b"), _t(out, "out")
+    w = _width(width)
+    _need(b.numel() % w == 0 and a.numel() == batch * na * w, "a must hold batch * na elements, b whole elements")
+    nb = b.numel() // w
+    _need(nb >= 1 and out.numel() == batch * (na + nb - 1) * w, "out must hold batch * (na + nb - 1) coefficients")
+    fn = _lib.lib().tf_poly_mul_shared_bfe_dev if width == 1 else _lib.lib().tf_poly_mul_shared_xfe_dev
+    _chk(fn(_p(a), na, batch, _p(b), nb, _p(out), _stream(stream)), "fast_multiply")
+
+
 def lde(values, n: int, offset_in_raw: int, out, m: int, offset_out_raw: int, batch: int = 1, width: int = 1, stream=None) -> None:
     """Low-degree extension: interpolate on {offset_in w_n^i}, evaluate on {offset_out w_m^i}; coefficients stay in HBM."""
     values, out = _t(values, "values"), _t(out, "out")
