@@ -1146,3 +1146,44 @@ def test_many_polynomials_times_one_shared_polynomial(tf, oracle, width, na, nb,
         assert np.array_equal(got[k], oracle.poly_mul(a[k * na * width:(k + 1) * na * width], b, width=width)), k
     with pytest.raises(ValueError):
         tf.device.poly_mul_shared(_to_dev(a), na, _to_dev(b), out[:-1], batch, width=width)
+
+
+def test_out_of_domain_row_and_quotients_compose(tf, oracle):
+    """The callers of the second half of round 2 chained the way a prover uses them, all device-resident: 8 base-field columns of
+    degree < 2^12; their out-of-domain row at an extension-field point through barycentric_evaluate on the trace-domain codewords
+    equals evaluate on the coefficients; the quotients (f_k(X) - f_k(x0)) / (X - x0) for a base-field x0 come from ONE
+    clean_divide_many call, and multiplying them back by (X - x0) (one shared factor) returns the numerators."""
+    import torch
+
+    n, cols = 1 << 12, 8
+    coeffs = torch.empty(cols * n, dtype=torch.int64, device="cuda")
+    tf.device.fill_random(coeffs, 81)
+    cw = coeffs.clone()
+    tf.device.ntt_(cw, n, batch=cols)                       # the columns' values on the subgroup <w_n>
+    x = oracle.fill_random(3, 82)                           # out-of-domain point in the extension field
+    row_b = torch.empty(3 * cols, dtype=torch.int64, device="cuda")
+    tf.device.barycentric_evaluate(cw, n, x, row_b, batch=cols)
+    row_e = torch.empty(3 * cols, dtype=torch.int64, device="cuda")
+    tf.device.evaluate_bfe_at_xfe(coeffs, n, _to_dev(x), row_e, batch=cols)
+    torch.cuda.synchronize()
+    assert torch.equal(row_b, row_e)
+    # quotients at a base-field point
+    x0 = oracle.bfe_new(123456789)
+    h = _to_host(coeffs).reshape(cols, n)
+    f_x0 = [int(oracle.poly_eval(h[k], x0)[0]) for k in range(cols)]
+    numer = h.copy()
+    for k in range(cols):
+        numer[k, 0] = oracle.bfe_sub(int(numer[k, 0]), f_x0[k])            # f_k - f_k(x0): divisible by X - x0
+    divisor = np.array([oracle.bfe_neg(x0), oracle.bfe_new(1)], dtype=np.uint64)
+    q = torch.empty(cols * (n - 1), dtype=torch.int64, device="cuda")
+    tf.device.clean_divide_many(_to_dev(np.ascontiguousarray(numer.reshape(-1))), n, _to_dev(divisor), q, cols)
+    back = torch.empty(cols * n, dtype=torch.int64, device="cuda")
+    tf.device.poly_mul_shared(q, n - 1, _to_dev(divisor), back, cols)
+    torch.cuda.synchronize()
+    assert np.array_equal(_to_host(back).reshape(cols, n), numer)
+    qh = _to_host(q).reshape(cols, n - 1)
+    assert np.array_equal(qh[3], oracle.naive_divide(numer[3], divisor)[0])
+    # a numerator that does not vanish at x0 is reported as unclean
+    with pytest.raises(tf.NttPanic) as e:
+        tf.device.clean_divide_many(coeffs, n, _to_dev(divisor), q, cols)
+    assert e.value.code == 16
