@@ -316,6 +316,10 @@ void tf_set_ntt_min_passes(int passes);
 /* Test hook: calls with little work (<= 2^21 words) are planned with narrower tiles; -1 = automatic (default),
  * 0 = never, 1 = always -- so that both geometries can be checked at every size. */
 void tf_set_ntt_small_launch(int mode);
+/* Test / A-B hook: transforms of 2^21 and 2^22 points run in TWO global passes (a 2048-point pass = pairs of 1024-point
+ * workgroups sharing their input) instead of three; -1 = automatic (default; TF_NTT_NO_PRE2 in the environment
+ * disables), 0 = never, 1 = whenever the shape supports it.  Same words either way. */
+void tf_set_ntt_two_pass(int mode);
 int tf_ntt_launch_count(size_t n, size_t batch, int width);
 /* Planner introspection (no device needed): number of global passes of one n-point transform (0 for lengths ntt rejects)
  * and log2 of each pass's radix in log2_radix_out[0..3] (unused entries 0).  The radices multiply to n. */

@@ -116,6 +116,7 @@ SIGNATURES = {
     "tf_ntt_plan": (C.c_int, [_sz, C.c_int, C.POINTER(C.c_int)]),
     "tf_batch_eval_plan": (C.c_int, [_sz, _sz, _sz, C.c_int]),
     "tf_set_ntt_small_launch": (None, [C.c_int]),
+    "tf_set_ntt_two_pass": (None, [C.c_int]),
     "tf_debug_stamps": (C.c_int, [_vp, _sz]),
     "tf_debug_sclk_mhz": (C.c_double, []),
     "tf_set_ntt_tile_bytes": (None, [_sz]),

@@ -80,6 +80,13 @@ struct NttPassArgs {
                                              // transforms only): streams that are touched once stay out of the Infinity Cache, which is
                                              // then left to the scratch tile between the passes (TF_NTT_NT, planner)
     unsigned long long* dbg;                 // MODE 3 only: per-wave cycle stamps (6 per wave)
+    // PRE2 instantiations only (a 2048-point pass as two 1024-point passes, see the kernel):
+    long long pre2_in_off;                   // words from a row to its partner row 1024 rows further
+    long long pre2_out_off;                  // words added to `out` by the odd half (the strides above already step two rows)
+    long long pre2_tw_off;                   // ... to post_tw
+    long long pre2_js_off;                   // ... to the output element index (SCALE 2)
+    const u64* pre2_cp;                      // SCALE 1: -> offset^(index distance of partner rows), multiplies the partner coefficient
+    int pre2_map;                            // 0: not a PRE2 launch; 1: half = bit 3 of the block id (a pair shares an XCD); 2: bit 0
 };
 
 // ---- buffer addressing for the R = 1024 instantiations --------------------------------------------------------------------
@@ -92,6 +99,9 @@ struct NttPassArgs {
 typedef unsigned int tf_v2u __attribute__((__vector_size__(2 * sizeof(unsigned int))));
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t buf_rsrc(const void* p) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, -1, 0x00020000);  // raw buffer, 4 GiB window, no swizzle
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t buf_rsrc_n(const void* p, u32 nbytes) {  // loads beyond nbytes return zero
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)nbytes, 0x00020000);
 }
 #ifndef TF_LOAD_AUX
 #define TF_LOAD_AUX 2  // cache-policy bits of the data stream's buffer loads / stores: 2 = nt (streamed once; 0 for an A/B build).  Measured on 256 x 2^20: 1.919 -> 1.845 ms with both (loads alone 1.889, stores alone 1.890, profiles/r02f)
@@ -294,7 +304,44 @@ __device__ __forceinline__ u32 div_by_L(u32 v, int L) {  // v / L for L in {1, 3
 //            (polynomial.rs:1907-1918: intt, then scale by the inverse offset).
 // MODE: 0 = product kernel.  1 / 2 are measurement-only ablations (TF_NTT_ABLATE, never the default):
 //   1 = no global loads/stores (synthetic operands), 2 = no arithmetic (loads, LDS exchange, stores only).
-template <bool INV, int SCALE, int MODE = 0, bool LAST1024 = false, bool R1024 = false, bool COL = false>
+// PRE2 (R = 1024 instantiations only): the pass is a 2048-point DFT per column.  One radix-2 decimation-in-frequency stage is
+//   fused into the load,  y_r = x_r + x_{r+1024},  z_r = (x_r - x_{r+1024}) w_2048^r,  and the 1024-point DFT of y gives the even
+//   outputs, that of z the odd ones: every tile is run by TWO workgroups (half 0: y, half 1: z) that read the same 32 Ki input
+//   elements and write interleaved output rows.  The pair is dispatched back to back on one XCD, so the second read of a line is
+//   served by its L2.  This is what lets 2^21 / 2^22-point transforms run in two HBM round trips with 16-column (128-byte)
+//   tiles: 2048 rows x 16 columns do not fit one workgroup next to a second one on the CU.
+//   w_2048^r, r = g + 32 i:  w_2048^(32 i) = w_64^i is a power of two (a shift per element), and w_2048^g rides on the inner
+//   twiddle: the odd half's table is w_1024^(g k1) w_2048^g = w_2048^(g (2 k1 + 1))  (inner_tw holds both tables, [2][32][32]).
+template <bool INV, int Q>
+struct Pre2Slot {  // register slot Q holds row g + 32 brev5(Q)
+    static constexpr int i = ((Q & 1) << 4) | ((Q & 2) << 2) | (Q & 4) | ((Q & 8) >> 2) | ((Q & 16) >> 4);
+    static constexpr int E = TwExp<INV, 6, i>::value;
+    static constexpr bool neg = gl::Pow2Mul<E>::negate;
+};
+// x[Q] = x[Q] -+ w (odd half, the sign of slot Q's power-of-two product folded in) or x[Q] + w (even half), slots Q0 .. Q0+7.
+// Even half: the sums feed level 1 of a lazy network, whose second operands (odd slots) must be canonical; the first operands
+// may be any representative (one correction instead of a compare-and-select).
+template <bool INV, int Q0, int I = 0>
+__device__ __forceinline__ void pre2_combine8(u64 (&x)[32], const u64 (&w)[8], bool odd) {
+    constexpr int Q = Q0 + I;
+    if (odd) {
+        x[Q] = Pre2Slot<INV, Q>::neg ? gl::sub(w[I], x[Q]) : gl::sub(x[Q], w[I]);
+    } else if constexpr (Q & 1) {
+        x[Q] = gl::add(x[Q], w[I]);
+    } else {
+        const u64 s = x[Q] + w[I];
+        x[Q] = s < w[I] ? s + gl::EPS : s;  // 2^64 = EPS (mod p); a + b - 2^64 + EPS < 2^64 for canonical a, b
+    }
+    if constexpr (I + 1 < 8) pre2_combine8<INV, Q0, I + 1>(x, w, odd);
+}
+// x[Q] *= w_64^(brev5 Q) up to the sign pre2_combine8 already took care of: shifts only
+template <bool INV, int Q = 1>
+__device__ __forceinline__ void pre2_shift(u64 (&x)[32]) {
+    x[Q] = gl::Pow2Mul<Pre2Slot<INV, Q>::E>::apply(x[Q]);
+    if constexpr (Q + 1 < 32) pre2_shift<INV, Q + 1>(x);
+}
+
+template <bool INV, int SCALE, int MODE = 0, bool LAST1024 = false, bool R1024 = false, bool COL = false, bool PRE2 = false>
 #ifndef TF_PRIO_LOAD
 #define TF_PRIO_LOAD 3
 #endif
@@ -321,6 +368,13 @@ __global__ void __launch_bounds__(512, TF_NTT_WAVES) ntt_pass_kernel(const NttPa
     constexpr bool LAZY2 = COLP && MODE == 0;
     const int L = A.L;
 
+    static_assert(!PRE2 || ((LAST1024 || R1024) && MODE == 0 && SCALE != 3), "PRE2 is a variant of the R = 1024 kernels");
+    // PRE2: two workgroups per tile; `half` selects the even (y) or odd (z) outputs
+    u32 bid = blockIdx.x, half = 0;
+    if constexpr (PRE2) {
+        if (A.pre2_map == 1) half = (bid >> 3) & 1u, bid = (bid & 7u) | ((bid >> 4) << 3);
+        else half = bid & 1u, bid >>= 1;
+    }
     u32 i0, i1, i2;
     if (A.xcd_order) {
         // Blocks are dealt round-robin to the 8 XCDs (b % 8).  Give XCD x the column tiles = x (mod 8) and let
@@ -329,7 +383,7 @@ __global__ void __launch_bounds__(512, TF_NTT_WAVES) ntt_pass_kernel(const NttPa
         // xcd_order = G (1 or 2): groups of G adjacent column tiles stay together; with G = 2 the two 64-byte
         // halves of every 128-byte line are requested back to back from the same XCD (second one hits its L2).
         const u32 G = (u32)A.xcd_order;
-        const u32 xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+        const u32 xcd = bid & 7u, slot = bid >> 3;
         // Order inside an XCD: column groups fastest when the inter-pass table slices of ALL its column tiles fit its L2
         // together (the planner decides: xcd_colfast) -- neighbouring workgroups then stream from different DRAM pages
         // instead of the same column of different batch entries (-1.1 % on 256 x 2^20); batch entries fastest otherwise.
@@ -341,7 +395,7 @@ __global__ void __launch_bounds__(512, TF_NTT_WAVES) ntt_pass_kernel(const NttPa
         i1 = rest % A.d1;
         i0 = rest / A.d1;
     } else {
-        const u32 tile = blockIdx.x;
+        const u32 tile = bid;
         i2 = tile % A.d2;
         const u32 rest = tile / A.d2;
         i1 = rest % A.d1;
@@ -371,6 +425,7 @@ __global__ void __launch_bounds__(512, TF_NTT_WAVES) ntt_pass_kernel(const NttPa
         in = A.in + (long long)i0 * A.ib0 + (long long)i1 * A.ib1 + (long long)ch0 * A.in_cs_hi;
         out = A.out + (long long)i0 * A.ob0 + (long long)i1 * A.ob1 + (long long)ch0 * A.out_cs_hi;
     }
+    if constexpr (PRE2) out += (long long)half * A.pre2_out_off;
 
     // LAST1024 always runs 512 threads in 16 column slots
     // gfast (single-pass transforms, whose "columns" are whole rows of contiguous elements): lanes along the row, g = t % P2
@@ -445,7 +500,8 @@ __global__ void __launch_bounds__(512, TF_NTT_WAVES) ntt_pass_kernel(const NttPa
     u64* const ltw = lds + (LAST1024 ? kL1024ExchangeWords : 32 * s1_);  // the staged inner table [P2][32], behind the exchange buffer
     if constexpr (LDS_TW) {
         if ((LAST1024 || R1024) || A.inner_tw) {  // uniform
-            for (int i = t; i < 32 * P2; i += blockDim.x) ltw[(i >> 5) * kLdsTwStride + (i & 31)] = A.inner_tw[i];
+            const u64* itw = A.inner_tw + (PRE2 ? (int)half * 1024 : 0);
+            for (int i = t; i < 32 * P2; i += blockDim.x) ltw[(i >> 5) * kLdsTwStride + (i & 31)] = itw[i];
             __syncthreads();
         }
     }
@@ -454,6 +510,58 @@ __global__ void __launch_bounds__(512, TF_NTT_WAVES) ntt_pass_kernel(const NttPa
     if constexpr (MODE == 1) {
 #pragma unroll
         for (int q = 0; q < 32; ++q) x[q] = (u64)(t * 32 + q) * 0x9e3779b97f4a7c15ULL >> 1;
+    } else if (PRE2 && act_in) {
+        // the tile's 32 Ki input elements: rows r = g + 32 i in x[], their partner rows r + 1024 eight at a time, combined at once
+        const u32 toff = (u32)(((long long)ch_in * A.in_cs_hi + cl_in + (long long)g_in * A.in_rs) * 8);
+        u32 nrec = 0xffffffffu;
+        if constexpr (SCALE == 1) {
+            if (A.n_coeffs >= 0) {  // rows beyond the coefficients read as zero: the buffer's record count does it
+                const long long rem = (A.n_coeffs * L - (long long)(in - (A.in + (long long)i0 * A.ib0))) * 8;
+                nrec = rem <= 0 ? 0u : (u32)min(rem, 0xffffffffll);
+            }
+        }
+        const __amdgpu_buffer_rsrc_t ri = buf_rsrc_n(in, nrec);
+        const u32 poff = (u32)(A.pre2_in_off * 8);
+        u64 pc = 0;
+        if constexpr (SCALE == 1) {
+            if (A.pre_scale) pc = *A.pre2_cp;  // uniform
+        }
+        // (the range check of a raw buffer covers the per-lane offset only, not the scalar one: with zero padding the whole
+        //  offset goes through the VGPR -- one v_add_u32 per load)
+        constexpr bool CHK = SCALE == 1;
+#ifndef TF_PRE2_LOAD_AUX
+#define TF_PRE2_LOAD_AUX 0  // default cache policy: the partner workgroup's read of the same lines should find them in the L2
+#endif
+        constexpr int AUX = TF_PRE2_LOAD_AUX;
+#pragma unroll
+        for (int q = 0; q < 32; ++q) {
+            const u32 so = (u32)((long long)(brev5(q) << p2) * A.in_rs * 8);
+            x[q] = CHK ? buf_load<AUX>(ri, toff + so, 0) : buf_load<AUX>(ri, toff, so);
+        }
+#pragma unroll
+        for (int q0 = 0; q0 < 32; q0 += 8) {
+            u64 w[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const u32 so = (u32)((long long)(brev5(q0 + i) << p2) * A.in_rs * 8) + poff;
+                w[i] = CHK ? buf_load<AUX>(ri, toff + so, 0) : buf_load<AUX>(ri, toff, so);
+            }
+            if constexpr (SCALE == 1) {
+                if (A.pre_scale) {  // coefficient j + d is scaled by offset^(j + d) = offset^j * c: the common factor follows below
+#pragma unroll
+                    for (int i = 0; i < 8; i += 4) {
+                        const u64 a4[4] = {w[i], w[i + 1], w[i + 2], w[i + 3]}, b4[4] = {pc, pc, pc, pc};
+                        u64 r4[4];
+                        gl::mont_mul4(a4, b4, r4);
+                        w[i] = r4[0], w[i + 1] = r4[1], w[i + 2] = r4[2], w[i + 3] = r4[3];
+                    }
+                }
+            }
+            if (q0 == 0) pre2_combine8<INV, 0>(x, w, half != 0);
+            else if (q0 == 8) pre2_combine8<INV, 8>(x, w, half != 0);
+            else if (q0 == 16) pre2_combine8<INV, 16>(x, w, half != 0);
+            else pre2_combine8<INV, 24>(x, w, half != 0);
+        }
     } else if (act_in) {
         const u32 toff = (u32)(((long long)ch_in * A.in_cs_hi + cl_in + (long long)g_in * A.in_rs) * 8);
         const char* base = reinterpret_cast<const char*>(in);
@@ -509,6 +617,9 @@ __global__ void __launch_bounds__(512, TF_NTT_WAVES) ntt_pass_kernel(const NttPa
                 for (int i = 0; i < 8; i += 4) mul4_inplace(x, q0 + i, w[i], w[i + 1], w[i + 2], w[i + 3]);
             }
         }
+    }
+    if constexpr (PRE2) {
+        if (half && act_in) pre2_shift<INV>(x);  // z_r = (x_r - x_{r+1024}) w_64^i; w_2048^g follows with the inner twiddle
     }
     __builtin_amdgcn_s_setprio(0);
     if constexpr (MODE != 2) {
@@ -599,7 +710,8 @@ __global__ void __launch_bounds__(512, TF_NTT_WAVES) ntt_pass_kernel(const NttPa
         char* base = reinterpret_cast<char*>(out);
         if constexpr (SCALE == 2) {
             // fast_coset_interpolate: output coefficient j times offset^-j; slot q holds element j0 + 32 q js_k (planner: n <= 2^28)
-            const long long j0 = (long long)i0 * A.js_i0 + (long long)i1 * A.js_i1 + (long long)(ch0 + ch) * A.js_c + (long long)g * A.js_k;
+            long long j0 = (long long)i0 * A.js_i0 + (long long)i1 * A.js_i1 + (long long)(ch0 + ch) * A.js_c + (long long)g * A.js_k;
+            if constexpr (PRE2) j0 += (long long)half * A.pre2_js_off;
             const char* sb = reinterpret_cast<const char*>(A.post_scale);
             const u32 soff = (u32)(j0 * 8);
             tail_p5<INV, 0, false, true>(x, act, base, toff, A.out_rs * 8, 32, sb, soff, A.js_k * 8);
@@ -645,8 +757,10 @@ __global__ void __launch_bounds__(512, TF_NTT_WAVES) ntt_pass_kernel(const NttPa
         if ((COLP && MODE == 0) || (MODE != 2 && A.post_tw)) {  // (R1024 / COL are only launched with an inter-pass table)
             // inter-pass twiddle: 8 table words at a time (bounded register footprint), multiply, store
             const u32 twoff = (u32)(((long long)g * A.tw_rs + bcol) * 8);
-            const char* tbase = reinterpret_cast<const char*>(A.post_tw);
-            const __amdgpu_buffer_rsrc_t rt = buf_rsrc(A.post_tw), ro = buf_rsrc(out);  // used by the R1024 / COL instantiations only
+            const u64* ptw = A.post_tw;
+            if constexpr (PRE2) ptw += (long long)half * A.pre2_tw_off;  // the odd half's rows of the inter-pass table
+            const char* tbase = reinterpret_cast<const char*>(ptw);
+            const __amdgpu_buffer_rsrc_t rt = buf_rsrc(ptw), ro = buf_rsrc(out);  // used by the R1024 / COL instantiations only
 #pragma unroll
             for (int q0 = 0; q0 < 32; q0 += 8) {
                 u64 w[8];

@@ -278,13 +278,15 @@ enum : u64 { TAG_INNER = 1, TAG_POST = 2, TAG_TINY = 3, TAG_BLOCK1 = 4, TAG_BLOC
 u64 make_key(u64 tag, u64 a, u64 b, u64 c, u64 d) { return (tag << 56) | (a << 40) | (b << 24) | (c << 8) | d; }
 
 // inner[g*32 + k1] = w_R^(+-g*k1) * (scale_log_n ? n^-1 : 1),  R = 32 << p2
-int get_inner_table(DeviceCtx* ctx, int a, bool inverse, int scale_log_n, const u64** out) {
+// pre2 (a = 10 only): a second table follows the first, inner[1024 + g*32 + k1] = w_2048^(+-g (2 k1 + 1)) * scale -- the inner
+// twiddles of the odd half of a 2048-point pass (ntt_kernels.h, PRE2)
+int get_inner_table(DeviceCtx* ctx, int a, bool inverse, int scale_log_n, const u64** out, bool pre2 = false) {
     const int p2 = a - 5;
     if (p2 == 0 && scale_log_n == 0) {
         *out = nullptr;
         return TF_OK;
     }
-    const u64 key = make_key(TAG_INNER, a, inverse, scale_log_n, 0);
+    const u64 key = make_key(TAG_INNER, a, inverse, scale_log_n, pre2 ? 1 : 0);
     std::lock_guard<std::mutex> lk(ctx->mu);
     auto it = ctx->tables.find(key);
     if (it != ctx->tables.end()) {
@@ -305,6 +307,16 @@ int get_inner_table(DeviceCtx* ctx, int a, bool inverse, int scale_log_n, const 
             acc = gl::mont_mul(acc, wg);
         }
         wg = gl::mont_mul(wg, w);
+    }
+    if (pre2) {
+        u64 w2 = root_of_unity_mont(a + 1);
+        if (inverse) w2 = gl::mont_inverse(w2);
+        t.resize(size_t(P2) * 64);
+        u64 w2g = gl::ONE;  // w_{2R}^g
+        for (int g = 0; g < P2; ++g) {
+            for (int k = 0; k < 32; ++k) t[size_t(P2) * 32 + size_t(g) * 32 + k] = gl::mont_mul(t[size_t(g) * 32 + k], w2g);
+            w2g = gl::mont_mul(w2g, w2);
+        }
     }
     u64* d = nullptr;
     int rc = upload_table(t, &d);
@@ -621,11 +633,12 @@ void finish_geometry(Launch* l, int nc, int p2) {
 }
 
 // Column pass: view [batch][outer][R][B*L words]; DFT along R for each of the B*L word-columns; same position in and out.
+// pre2: a = 11, run as pairs of 1024-point halves (ntt_kernels.h, PRE2): the kernel radix is 1024, the rows of a column 2048.
 Launch plan_column_pass(const u64* in, u64* out, long long in_bs, long long out_bs, size_t batch, long long outer, int a,
-                        long long B, int L) {
+                        long long B, int L, bool pre2 = false) {
     Launch l{};
     tfk::NttPassArgs& A = l.a;
-    const int p2 = a - 5, P2 = 1 << p2;
+    const int p2 = (pre2 ? a - 1 : a) - 5, P2 = 1 << p2;
     const long long R = 1ll << a, Bw = B * L;
     int nc = (int)std::min<long long>(std::max(1, wg_threads() / P2), Bw);
     A.in = in;
@@ -658,6 +671,15 @@ Launch plan_column_pass(const u64* in, u64* out, long long in_bs, long long out_
     }
     finish_geometry(&l, nc, p2);
     l.tiles = (unsigned)(batch * outer * A.d2);
+    if (pre2) {
+        A.out_rs = 2 * Bw;  // kernel row k' of half h is row 2 k' + h of the 2048
+        A.tw_rs = 2 * B;
+        A.pre2_in_off = 1024 * Bw;
+        A.pre2_out_off = Bw;
+        A.pre2_tw_off = B;
+        A.pre2_map = (l.tiles % 8 == 0) ? 1 : 2;
+        l.tiles *= 2;
+    }
     return l;
 }
 
@@ -677,11 +699,12 @@ int ablate_mode() {
 bool fits_buffer_offsets(const Launch& l) {
     const unsigned long long lim = 1ull << 32;
     const unsigned long long col_span = (unsigned long long)std::max(l.a.nc, 16) * 8ull * 3ull;  // columns of a tile, any limb
-    const auto ok = [&](long long rs_words, long long cs_hi_words) {
+    const auto ok = [&](long long rs_words, long long cs_hi_words, unsigned long long rows = 1024ull) {
         const unsigned long long cols = (unsigned long long)(cs_hi_words < 0 ? 0 : cs_hi_words) * 8ull * 16ull;  // ch < 16 columns of a tile
-        return 1024ull * (unsigned long long)rs_words * 8ull + cols + col_span < lim;
+        return rows * (unsigned long long)rs_words * 8ull + cols + col_span < lim;
     };
-    return ok(l.a.in_rs, l.a.in_cs_hi) && ok(l.a.out_rs, l.a.out_cs_hi) && ok(l.a.tw_rs, 0);
+    // (a PRE2 launch also reads the partner rows, 1024 rows further)
+    return ok(l.a.in_rs, l.a.in_cs_hi, l.a.pre2_map ? 2048ull : 1024ull) && ok(l.a.out_rs, l.a.out_cs_hi) && ok(l.a.tw_rs, 0);
 }
 
 // the specialised R = 1024 last-pass kernel (LAST1024) is available unless an A/B switch or an ablation run disables it
@@ -716,11 +739,11 @@ int rows_per_tile(int P2, int L, long long limit) {
 // words > 0: word-granular tiles of `words` adjacent output WORDS (whole 128-byte lines) instead of T whole elements; for
 // XFieldElement rows (24-byte elements) a tile then starts and ends inside an element (NttPassArgs::wtiles).
 Launch plan_transpose_pass(const u64* in, u64* out, long long in_bs, long long out_bs, size_t batch, int a, long long N1,
-                           long long Q, int L, long long split = 0, int words = 0) {
+                           long long Q, int L, long long split = 0, int words = 0, bool pre2 = false) {
     Launch l{};
     tfk::NttPassArgs& A = l.a;
-    const int p2 = a - 5, P2 = 1 << p2;
-    const long long R = 1ll << a;
+    const int p2 = (pre2 ? a - 1 : a) - 5, P2 = 1 << p2;
+    const long long R = 1ll << a;  // elements per row (pre2: 2048, transformed as two interleaved 1024-point halves)
     int T = rows_per_tile(P2, L, N1);
     {
         // the kernel addresses its loads as uniform 64-bit base + 32-bit per-thread byte offset; the offset spans the
@@ -768,6 +791,15 @@ Launch plan_transpose_pass(const u64* in, u64* out, long long in_bs, long long o
     }
     finish_geometry(&l, nc, p2);
     l.tiles = (unsigned)(batch * Q * A.d2);
+    if (pre2) {
+        A.pre2_in_off = 1024 * L;
+        A.pre2_out_off = A.out_rs;  // output k = 2 k' + h
+        A.pre2_js_off = A.js_k;
+        A.out_rs *= 2;
+        A.js_k *= 2;
+        A.pre2_map = (l.tiles % 8 == 0) ? 1 : 2;
+        l.tiles *= 2;
+    }
     return l;
 }
 
@@ -813,7 +845,7 @@ Launch plan_row_pass(const u64* in, u64* out, long long in_bs, long long out_bs,
     return l;
 }
 
-template <bool INV, int SCALE, int MODE, bool LAST1024 = false, bool R1024 = false, bool COL = false>
+template <bool INV, int SCALE, int MODE, bool LAST1024 = false, bool R1024 = false, bool COL = false, bool PRE2 = false>
 int launch_pass_t(const Launch& l, hipStream_t stream) {
     // one attribute call per (instantiation, device): the kernels use up to the full 160 KiB of dynamic LDS
     static std::atomic<unsigned long long> done_mask{0};
@@ -821,14 +853,14 @@ int launch_pass_t(const Launch& l, hipStream_t stream) {
     HIPCHK(hipGetDevice(&dev));
     const unsigned long long bit = 1ull << (dev & 63);
     if (!(done_mask.load(std::memory_order_acquire) & bit)) {
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&tfk::ntt_pass_kernel<INV, SCALE, MODE, LAST1024, R1024, COL>),
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&tfk::ntt_pass_kernel<INV, SCALE, MODE, LAST1024, R1024, COL, PRE2>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         done_mask.fetch_or(bit, std::memory_order_release);
     }
     // the R = 1024 column-pass instantiation stages its inner twiddle table behind the exchange buffer (LAST1024: part of
     // kLast1024LdsBytes already)
     const size_t lds_bytes = l.lds_bytes + ((TF_LDS_TW && !LAST1024 && MODE == 0 && l.a.inner_tw) ? (size_t(1) << l.a.p2) * tfk::kLdsTwStride * sizeof(u64) : 0);
-    hipLaunchKernelGGL((tfk::ntt_pass_kernel<INV, SCALE, MODE, LAST1024, R1024, COL>), dim3(l.tiles), dim3(l.threads), lds_bytes, stream,
+    hipLaunchKernelGGL((tfk::ntt_pass_kernel<INV, SCALE, MODE, LAST1024, R1024, COL, PRE2>), dim3(l.tiles), dim3(l.threads), lds_bytes, stream,
                        l.a);
     HIPCHK(hipGetLastError());
     return TF_OK;
@@ -855,6 +887,25 @@ int launch_pass(const Launch& l, bool inverse, hipStream_t stream) {
                          l.a.s1 == tfk::kR1024S1 && l.a.s2 == tfk::kR1024Cpr && l.a.s3 == 1 && !l.a.gfast;
     const bool plain_last1024 = l.a.p2 == 5 && !l.a.post_tw && !l.a.gfast && !l.a.pre_scale && l.a.n_coeffs < 0 && !l.a.in2 &&
                                 (!l.a.post_scale || (inverse && scaled_last1024_enabled())) && last1024_enabled() && fits;
+    if (l.a.pre2_map) {
+        // a 2048-point pass as two 1024-point halves per tile (ntt_kernels.h, PRE2): only planned by run_ntt when all of this holds
+        const bool column = l.a.post_tw != nullptr;
+        if (l.a.p2 != 5 || !fits || g_ablate || l.a.in2 || l.a.n_out >= 0 || l.a.gfast || (column && !std_geo) ||
+            (!column && (l.a.pre_scale || l.a.n_coeffs >= 0)) || (l.a.post_scale && (column || !inverse)) ||
+            ((l.a.pre_scale || l.a.n_coeffs >= 0) && inverse)) {
+            t_last_error = "internal: two-pass (PRE2) launch outside the shapes it supports";
+            return TF_ERR_HIP;
+        }
+        if (column) {
+            if (l.a.pre_scale || l.a.n_coeffs >= 0) return launch_pass_t<false, 1, 0, false, true, false, true>(l, stream);
+            return inverse ? launch_pass_t<true, 0, 0, false, true, false, true>(l, stream) : launch_pass_t<false, 0, 0, false, true, false, true>(l, stream);
+        }
+        Launch l2 = l;
+        l2.lds_bytes = std::max(l.lds_bytes, kLast1024LdsBytes);
+        l2.threads = 512;
+        if (l.a.post_scale) return launch_pass_t<true, 2, 0, true, false, false, true>(l2, stream);
+        return inverse ? launch_pass_t<true, 0, 0, true, false, false, true>(l2, stream) : launch_pass_t<false, 0, 0, true, false, false, true>(l2, stream);
+    }
     if ((l.a.n_out >= 0 || l.a.col_shift0 || l.a.col_shift_i0) && !plain_last1024) {  // anything else would overrun the caller's buffer
         t_last_error = "internal: truncated output or shifted tiles requested from a pass that does not support them";
         return TF_ERR_HIP;
@@ -1075,6 +1126,26 @@ bool can_truncate(size_t n, int L) {
     return P <= 3 && a[P - 1] == 10 && last1024_enabled() && (unsigned long long)n * L * 8 + (1ull << 20) < (1ull << 32);
 }
 
+// Two-pass plans for 2^21 / 2^22 points (a 2048-point pass = pairs of 1024-point workgroups, ntt_kernels.h PRE2).
+std::atomic<int> g_pre2_mode{-1};  // tf_set_ntt_two_pass: -1 automatic (TF_NTT_NO_PRE2 disables), 0 never, 1 whenever supported
+bool pre2_plan_ok(int log_n, int L, size_t n, size_t cosets, bool has_in2, long long n_out, bool inverse, bool load_work, bool store_scale) {
+    static const bool off = getenv("TF_NTT_NO_PRE2") != nullptr;  // A/B switch
+    const int mode = g_pre2_mode.load(std::memory_order_relaxed);
+    if (mode == 0 || (mode < 0 && off)) return false;
+    if (log_n < 21 || log_n > 22 || cosets != 1 || has_in2 || n_out >= 0) return false;
+    if ((load_work && inverse) || (store_scale && !inverse)) return false;          // shapes no caller produces
+    if (!last1024_enabled() || ablate_mode() != 0 || wg_threads() != 512) return false;
+    if (g_min_passes.load(std::memory_order_relaxed) > 2) return false;
+    return (unsigned long long)n * L * 8 + (1ull << 20) < (1ull << 32);              // buffer addressing (fits_buffer_offsets)
+}
+void pre2_split(int log_n, int (&a)[4]) {
+    // 2^21: the 2048-point pass last (the first pass of a coset evaluation then scales every coefficient once); 2^22: both
+    a[0] = log_n == 22 ? 11 : 10, a[1] = 11, a[2] = a[3] = 0;
+    if (const char* e = exp_env("TF_NTT_PRE2_FIRST")) {
+        if (log_n == 21 && atoi(e)) a[0] = 11, a[1] = 10;
+    }
+}
+
 // The transform proper.  in/out are device pointers; in == out for ntt/intt, distinct for coset evaluation
 // (then pre_scale != null and rows >= n_coeffs read as zero).  in_bs/out_bs: words per polynomial.
 // cosets = C > 1 (forward coset evaluation only, n > 1024): the output has C * n points per polynomial,
@@ -1162,11 +1233,19 @@ int run_ntt(DeviceCtx* ctx, const u64* in, u64* out, long long in_bs, long long 
     const bool small_call = (unsigned long long)n * cosets * batch * L <= (1ull << 21);
     SmallLaunchScope small_scope(n_out < 0 && !wg_env() && (small_mode == 1 || (small_mode < 0 && small_call && !no_small)));
     int a[4] = {0, 0, 0, 0};
-    const int P = pass_count(log_n);
+    int P = pass_count(log_n);
     choose_split(log_n, P, L, a);
+    // 2^21 and 2^22 points in TWO passes: a 2048-point pass runs as pairs of 1024-point workgroups that share their input
+    // (ntt_kernels.h, PRE2; a[i] = 11 below).  Plain transforms, coset evaluation (forward) and coset interpolation (inverse).
+    bool pre2[4] = {false, false, false, false};
+    if (pre2_plan_ok(log_n, L, n, cosets, in2 != nullptr, n_out, inverse, pre_scale != nullptr || n_coeffs >= 0, post_scale != nullptr)) {
+        P = 2;
+        pre2_split(log_n, a);
+        pre2[0] = a[0] == 11, pre2[1] = a[1] == 11;
+    }
     const u64* inner[4] = {nullptr, nullptr, nullptr, nullptr};
     for (int i = 0; i < P; ++i) {
-        rc = get_inner_table(ctx, a[i], inverse, (i == P - 1 && inverse) ? log_n : 0, &inner[i]);  // n^-1 rides on the last pass
+        rc = get_inner_table(ctx, pre2[i] ? 10 : a[i], inverse, (i == P - 1 && inverse) ? log_n : 0, &inner[i], pre2[i]);  // n^-1 rides on the last pass
         if (rc) return rc;
     }
     const u64* post[3] = {nullptr, nullptr, nullptr};
@@ -1260,9 +1339,13 @@ int run_ntt(DeviceCtx* ctx, const u64* in, u64* out, long long in_bs, long long 
             // INPUT, which the caller gives up (fast_multiply's temporary)
             u64* dst = to_scratch ? scratch : (n_out >= 0 ? const_cast<u64*>(tin) : tout);
             const long long dst_bs = to_scratch ? sbs : (n_out >= 0 ? in_bs : out_bs);
-            Launch p = plan_column_pass(src, dst, src_bs, dst_bs, nb, (i == 0) ? (long long)cosets : outer, a[i], B, L);
+            Launch p = plan_column_pass(src, dst, src_bs, dst_bs, nb, (i == 0) ? (long long)cosets : outer, a[i], B, L, pre2[i]);
             p.a.inner_tw = inner[i];
             p.a.post_tw = post[i];
+            if (pre2[i]) {
+                // partner coefficients are n / 2 apart: offset^(n/2) is word n / 2 of the scale table when the polynomial is that long
+                p.a.pre2_cp = pre_scale ? pre_scale + ((long long)(n / 2) < n_coeffs ? (long long)(n / 2) : 0) : nullptr;
+            }
             if (i == 0 && src != dst) p.a.nt = g_nt.load(std::memory_order_relaxed) & 1;  // the caller's input is read once
             if (i == 0) {
                 p.a.pre_scale = pre_scale;
@@ -1285,7 +1368,7 @@ int run_ntt(DeviceCtx* ctx, const u64* in, u64* out, long long in_bs, long long 
         if (P < 4) {
             // XFieldElement rows through the R = 1024 kernel: word-granular tiles (whole 128-byte lines on the output side)
             static const bool no_words16 = getenv("TF_NTT_NO_WORDS16") != nullptr;  // A/B switch
-            const bool plain1024 = a[P - 1] == 10 && last1024_enabled() && (!post_scale || (inverse && scaled_last1024_enabled() && log_n <= 28));
+            const bool plain1024 = (a[P - 1] == 10 || pre2[P - 1]) && last1024_enabled() && (!post_scale || (inverse && scaled_last1024_enabled() && log_n <= 28));
             // (the other last-pass kernels too: all their thread slots as word-columns, e.g. 32 words = 256 bytes for R = 512)
             int words = 0;
             if (L == 3 && !no_words16) {
@@ -1298,7 +1381,7 @@ int run_ntt(DeviceCtx* ctx, const u64* in, u64* out, long long in_bs, long long 
                 }
             }
             Launch pl = plan_transpose_pass(scratch, tout, sbs, out_bs, nb, a[P - 1], N[0] * (long long)cosets, P == 3 ? N[1] : 1, L, 0,
-                                            words);
+                                            words, pre2[P - 1]);
             pl.a.inner_tw = inner[P - 1];
             pl.a.post_scale = post_scale;
             pl.a.n_out = n_out;
@@ -2975,6 +3058,7 @@ int tf_debug_stamps(unsigned long long* host_out, size_t words) {
 }
 
 void tf_set_ntt_min_passes(int passes) { g_min_passes.store(passes, std::memory_order_relaxed); }
+void tf_set_ntt_two_pass(int mode) { g_pre2_mode.store(mode < 0 ? -1 : (mode ? 1 : 0), std::memory_order_relaxed); }
 void tf_set_ntt_small_launch(int mode) { g_small_launch_mode.store(mode < 0 ? -1 : (mode ? 1 : 0), std::memory_order_relaxed); }
 // The plan of one transform: number of global passes and log2 of each pass's radix (planner introspection for the CPU tests).
 // The route tf_poly_batch_evaluate_* takes for this shape: 1 Horner, 2 zerofier tree; 0 for a width that is not 1 / 3.  Host logic
