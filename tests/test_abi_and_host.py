@@ -147,8 +147,12 @@ def test_planner_splits_are_valid_for_every_length(tf):
                     r = list(radix)
                     assert 1 <= passes <= 4 and sum(r[:passes]) == log_n and all(v == 0 for v in r[passes:]), (force, width, log_n, r)
                     if passes > 1:
-                        assert all(5 <= v <= 10 for v in r[:passes]), (force, width, log_n, r)
-                        assert passes >= (2 if log_n <= 20 else 3 if log_n <= 30 else 4)
+                        # 2^21 / 2^22: two passes, a radix of 2^11 being a pass of paired 1024-point halves
+                        two_pass = force == 0 and log_n in (21, 22)
+                        assert all(5 <= v <= (11 if two_pass else 10) for v in r[:passes]), (force, width, log_n, r)
+                        assert passes >= (2 if log_n <= 20 or two_pass else 3 if log_n <= 30 else 4)
+                        if two_pass:
+                            assert passes == 2 and r[1] == 11, (width, log_n, r)
                     else:
                         assert log_n <= 10 or (log_n <= (14 if width == 1 else 12) and force == 0)  # whole transform per workgroup
                     if force and log_n >= 5 * force:

@@ -404,6 +404,48 @@ def test_deeper_pass_plans_match_oracle(tf, oracle, passes, log_n, width, batch)
         lib.tf_set_ntt_min_passes(0)
 
 
+@pytest.mark.parametrize("log_n,width,batch", [(21, 1, 2), (21, 3, 1), (22, 1, 1), (22, 3, 2)])
+def test_two_pass_plan_for_2p21_2p22_matches_oracle(tf, oracle, log_n, width, batch):
+    """2^21 / 2^22 points in two global passes (a 2048-point pass = pairs of 1024-point workgroups that share their input,
+    DESIGN 4.1; tf_set_ntt_two_pass): forward, inverse, coset evaluation (full and zero-padded coefficient lists) and
+    interpolation against the oracle's radix-2 sweeps (math/ntt.rs:153-228, polynomial.rs:1374-1399, :1907-1918), and word
+    for word against the three-pass plan."""
+    import ctypes as C
+    n = 1 << log_n
+    x = oracle.fill_random(batch * n * width, 2100 + log_n + width)
+    lib = tf._lib.lib()
+    radix = (C.c_int * 4)()
+    got = {}
+    try:
+        for mode in (1, 0):
+            lib.tf_set_ntt_two_pass(mode)
+            assert lib.tf_ntt_plan(n, width, radix) == (2 if mode else 3)
+            y = x.copy()
+            tf.ntt(y, width=width, batch=batch)
+            fwd = y.copy()
+            tf.intt(y, width=width, batch=batch)
+            assert np.array_equal(y, x)
+            off = oracle.bfe_new(7)
+            one = x[:n * width]
+            ev_full = tf.fast_coset_evaluate(one, off, n, width=width)
+            ev_pad = tf.fast_coset_evaluate(one[: (n // 2 + 3) * width], off, n, width=width)
+            ev_short = tf.fast_coset_evaluate(one[: (n - 5) * width], off, n, width=width)
+            ci = tf.fast_coset_interpolate(one, off, width=width)
+            got[mode] = (fwd, ev_full, ev_pad, ev_short, ci)
+    finally:
+        lib.tf_set_ntt_two_pass(-1)
+    for a, b in zip(got[0], got[1]):
+        assert np.array_equal(a, b)
+    fwd, ev_full, ev_pad, ev_short, ci = got[1]
+    assert np.array_equal(fwd, oracle.ntt(x, width=width, batch=batch, threads=8))
+    off = oracle.bfe_new(7)
+    one = x[:n * width]
+    assert np.array_equal(ev_full, oracle.coset_evaluate(one, off, n, width=width))
+    assert np.array_equal(ev_pad, oracle.coset_evaluate(one[: (n // 2 + 3) * width], off, n, width=width))
+    assert np.array_equal(ev_short, oracle.coset_evaluate(one[: (n - 5) * width], off, n, width=width))
+    assert np.array_equal(ci, oracle.coset_interpolate(one, off, width=width))
+
+
 @pytest.mark.parametrize("length", [0, 1, 9, 10, 11, 25, 40])
 def test_sponge_absorb_squeeze_matches_oracle(tf, oracle, length):
     """impl Sponge for Tip5 (tip5/mod.rs:677-699) + pad_and_absorb_all (sponge.rs:41-55), three sponges stepped together"""

@@ -3077,9 +3077,11 @@ int tf_ntt_plan(size_t n, int width, int* log2_radix_out) {
         log2_radix_out[0] = log_n;
         return 1;
     }
-    const int P = pass_count(log_n);
+    int P = pass_count(log_n);
     int a[4] = {0, 0, 0, 0};
     choose_split(log_n, P, width, a);
+    // a plain transform of 2^21 / 2^22 points with enough work for the wide tiles: two passes, 2^11 = a pass of paired 1024-point halves
+    if (pre2_plan_ok(log_n, width, n, 1, false, -1, false, false, false)) P = 2, pre2_split(log_n, a);
     for (int i = 0; i < P; ++i) log2_radix_out[i] = a[i];
     return P;
 }
@@ -3094,8 +3096,10 @@ int tf_ntt_launch_count(size_t n, size_t batch, int width) {
     const size_t poly_bytes = n * size_t(width) * sizeof(u64);
     size_t tb = std::min(std::max<size_t>(1, g_tile_bytes / poly_bytes), batch);
     const size_t tiles = (batch + tb - 1) / tb;
-    const int P = pass_count(log_n);
+    int P = pass_count(log_n);
     if (P == 4) return (int)(tiles * 3 + batch);  // the last pass of a four-pass plan is launched per polynomial
+    const bool small_call = (unsigned long long)n * batch * width <= (1ull << 21) && g_small_launch_mode.load(std::memory_order_relaxed) != 0;
+    if (!small_call && pre2_plan_ok(log_n, width, n, 1, false, -1, false, false, false)) P = 2;
     return (int)(tiles * P);
 }
 
