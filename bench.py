@@ -78,6 +78,7 @@ def cpu_baseline_ntt(log_n, batch, seed):
     """Oracle leg: time the CPU restatement on the same workload shape; returns (dict, first two transforms' outputs)."""
     from oracle import tfo
 
+    flags = tfo.use_native_build()
     n = 1 << log_n
     cores = os.cpu_count() or 1
     x = tfo.fill_random(n * batch, seed)
@@ -106,6 +107,7 @@ def cpu_baseline_ntt(log_n, batch, seed):
         "sample": f"{batch} x 2^{log_n} BFE forward NTT (the full workload shape), one transform per thread; best of "
                   + ", ".join(f"{k} threads: {v:.3f}" for k, v in tried.items())
                   + f" GFelts/s on {cores} host CPUs; C restatement of math/ntt.rs:153-215 (oracle/tf_oracle.c)",
+        "build_flags": flags,
         "single_thread_value": round(single, 5),
     }
     return info, sample_out
@@ -115,6 +117,7 @@ def cpu_baseline_merkle(n_leaves, seed):
     """Oracle leg of the Merkle metric: par_new restatement on the same leaves; returns (dict, root, a node sample)."""
     from oracle import tfo
 
+    flags = tfo.use_native_build()
     cores = os.cpu_count() or 1
     leaves = tfo.fill_random(5 * n_leaves, seed)
     ns = min(n_leaves, 1 << 20)  # single-thread figure on a bounded sample (sequential_new, ~1 s)
@@ -135,6 +138,7 @@ def cpu_baseline_merkle(n_leaves, seed):
         "sample": f"the full 2^{n_leaves.bit_length() - 1}-leaf tree (MerkleTree::par_new restatement, util_types/merkle_tree.rs:165-212; bench shape "
                   "benches/merkle_tree.rs:11-40); best of " + ", ".join(f"{k} threads: {v / 1e6:.2f} M" for k, v in tried.items())
                   + f" leaves/s on {cores} host CPUs",
+        "build_flags": flags,
         "single_thread_value": round(single, 1),
     }
     return info, nodes[5:10].copy(), nodes
@@ -338,6 +342,8 @@ def ntt_headline(ctx):
         "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 4),
         "traffic": traffic,
+        "traffic_source": (f"profiles/hbm_traffic_ntt.json ({tj.get('source', 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes')}; a stored "
+                           "profile of this kernel and shape, NOT measured in this run)") if traffic else None,
         "algorithmic_bytes_per_launch": alg_bytes_per_launch,
         "avg_launch_ms": round(avg_launch_ms, 5),
         "launches_per_step": launches_per_step,
@@ -352,12 +358,12 @@ def ntt_headline(ctx):
         gw = wi / (ev_ms / args.steps * 1e-3) / 1e9
         roofline["valu_bound"] = {"wave_instr_per_step": wi, "valu_instr_per_element": round(wi * 64.0 / (batch * n), 1),
                                   "achieved": round(gw, 1), "peak": VALU_PEAK_GWIPS, "unit": "G wave-instr/s",
-                                  "frac": round(gw / VALU_PEAK_GWIPS, 3), "clock_under_load_mhz": vc.get("ntt_clock_under_load_mhz")}
-        clk = vc.get("ntt_clock_under_load_mhz")
-        if clk:  # the same issue rate priced at the clock the chip holds under this kernel (profiled, GRBM_GUI_ACTIVE / duration)
-            peak_at_clk = 1024 * clk * 1e6 / 4 / 1e9
-            roofline["valu_bound"]["peak_at_clock_under_load"] = round(peak_at_clk, 1)
-            roofline["valu_bound"]["frac_at_clock_under_load"] = round(gw / peak_at_clk, 3)
+                                  "frac": round(gw / VALU_PEAK_GWIPS, 3),
+                                  "source": "instruction count: SQ_INSTS_VALU of the two pass kernels in profiles/valu_counts.json (a stored rocprofv3 --pmc "
+                                            "profile, NOT this run) x this run's step time; peak = 1024 SIMDs x 2.4 GHz / 4 cycles: every instruction of "
+                                            "these kernels is of the 4-cycle class (carry adds, v_mad_u64_u32, VOP3: 0.46-0.58 G wave-instr/s/SIMD in "
+                                            "profiles/r03_instr_rates.txt against 0.93-1.15 for plain v_add_u32 / logic / right shifts); the clock the chip "
+                                            "holds under this kernel is in the stored profile (profiles/r02p_rocprof_summary.txt), not measured here"}
 
     out = {
         "metric": "goldilocks_ntt_gfelts_per_s",
@@ -454,7 +460,11 @@ def merkle_leg(ctx):
         res["roofline"] = {"bound": "valu", "kernel": "tfk::tip5_hash_pairs_kernel (level sweep) + merkle_top_kernel",
                            "achieved": round(gw, 1), "peak": VALU_PEAK_GWIPS, "unit": "G wave-instr/s", "frac": round(gw / VALU_PEAK_GWIPS, 3),
                            "wave_instr_per_tree": wi, "valu_instr_per_hash_pair": round(wi * 64.0 / (nl - 1), 1),
-                           "source": "SQ_INSTS_VALU under rocprofv3 --pmc (profiles/valu_counts.json); peak = 1024 SIMDs x 2.4 GHz / 4 cycles"}
+                           "frac_at_2_cycle_issue": round(gw / (2 * VALU_PEAK_GWIPS), 3),
+                           "source": "instruction count: SQ_INSTS_VALU under rocprofv3 --pmc (profiles/valu_counts.json, a stored profile, NOT this run) x "
+                                     "this run's time.  `peak` prices every instruction at 4 cycles per wave64 (1024 SIMDs x 2.4 GHz / 4), "
+                                     "frac_at_2_cycle_issue at the 2-cycle rate of plain 32-bit VALU; the Tip5 mix (v_mad_u64_u32 and carry chains at 4 "
+                                     "cycles, logic / right shifts / v_add_u32 at 2: profiles/r03_instr_rates.txt) sits between, so neither is a hard ceiling"}
     if use_dist and world & (world - 1) == 0:
         # the same 2^24-leaf tree as ONE tree across the ranks (reference's subtree split, sharding.sharded_tree): rank g builds
         # the subtree over leaves [g n / G, (g + 1) n / G), the G subtree roots are all-gathered, every rank finishes the top

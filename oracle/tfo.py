@@ -26,12 +26,30 @@ def build(force: bool = False) -> str:
     stale = (not os.path.exists(_SO)) or any(
         os.path.getmtime(f) > os.path.getmtime(_SO) for f in (src, hdr)
     )
+    if _SO.endswith("_native.so"):
+        return _SO  # built by use_native_build()
     if force or stale:
         subprocess.check_call(["make", "-C", _HERE, "-B", "libtf_oracle.so"], stdout=subprocess.DEVNULL)
     return _SO
 
 
 _lib = None
+build_flags = "-O3 -march=x86-64-v2 (portable build, oracle/Makefile)"
+
+
+def use_native_build() -> str:
+    """bench.py's cpu_baseline leg: time the restatement built with -O3 -march=native ON THE HOST IT RUNS ON.
+    Must be called before the first lib(); falls back to the portable build when the compiler is missing.  Returns the flags."""
+    global _SO, build_flags
+    if _lib is not None:
+        return build_flags
+    try:
+        subprocess.check_call(["make", "-C", _HERE, "-B", "libtf_oracle_native.so"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        _SO = os.path.join(_HERE, "libtf_oracle_native.so")
+        build_flags = "-O3 -march=native (built on this host for the timed leg)"
+    except Exception:
+        pass
+    return build_flags
 
 
 def lib() -> C.CDLL:

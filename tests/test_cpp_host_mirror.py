@@ -29,3 +29,4 @@ def test_selftest_on_gpu():
     r = subprocess.run([BIN], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "all reference KATs pass" in r.stdout
+    assert "host threads" in r.stdout and "same words as one device alone" in r.stdout  # the multi-device section ran

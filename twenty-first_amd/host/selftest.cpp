@@ -3,7 +3,11 @@
 // Exit code 0 = all passed; 77 = no GPU (skipped); anything else = failure.
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <thread>
 #include <vector>
+
+#include <hip/hip_runtime_api.h>
 
 #include "twenty_first.hpp"
 
@@ -22,6 +26,52 @@ static std::vector<BFieldElement> bfe_vec(std::initializer_list<uint64_t> v) {
     std::vector<BFieldElement> out;
     for (auto x : v) out.push_back(BFieldElement::new_(x));
     return out;
+}
+
+// Every device of the node driven through the C ABI from its own host thread (independent transforms and
+// trees shard over the GPUs with no exchange step; the reference's callers are rayon workers, math/ntt.rs:250-274): thread i
+// binds device devs[i] (hipSetDevice), uploads the same words, runs one tf_ntt_bfe_dev and one tf_merkle_build_dev on its own
+// stream with that device's tables, and the results must equal the words device devs[0] produced alone beforehand.
+// With one GPU the same harness runs two threads on device 0 (the per-device state is then shared, not replicated).
+static void multi_device_check(const std::vector<int>& devs) {
+    const size_t n = size_t(1) << 16, batch = 8, leaves = size_t(1) << 12;
+    std::vector<uint64_t> x(n * batch), lv(5 * leaves);
+    uint64_t st = 0x7F210005ull;
+    auto next = [&]() { st += 0x9e3779b97f4a7c15ull; uint64_t z = st; z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull; z = (z ^ (z >> 27)) * 0x94d049bb133111ebull; z ^= z >> 31; return z % 0xffffffff00000001ull; };
+    for (auto& v : x) v = next();
+    for (auto& v : lv) v = next();
+    struct Result { std::vector<uint64_t> ntt, nodes; int rc = 0; };
+    auto run = [&](int dev, Result* r) {
+        r->ntt.resize(x.size());
+        r->nodes.resize(10 * leaves);
+        uint64_t *dx = nullptr, *dl = nullptr, *dn = nullptr;
+        hipStream_t s = nullptr;
+        if (hipSetDevice(dev) != hipSuccess || hipStreamCreate(&s) != hipSuccess || hipMalloc(&dx, x.size() * 8) != hipSuccess ||
+            hipMalloc(&dl, lv.size() * 8) != hipSuccess || hipMalloc(&dn, r->nodes.size() * 8) != hipSuccess) { r->rc = -1; return; }
+        if (hipMemcpyAsync(dx, x.data(), x.size() * 8, hipMemcpyHostToDevice, s) != hipSuccess ||
+            hipMemcpyAsync(dl, lv.data(), lv.size() * 8, hipMemcpyHostToDevice, s) != hipSuccess) { r->rc = -2; return; }
+        for (int rep = 0; rep < 3 && r->rc == 0; ++rep) {  // forward, inverse, forward: the final words are one forward transform
+            r->rc = tf_ntt_bfe_dev(dx, n, batch, rep == 1, s);
+        }
+        if (r->rc == 0) r->rc = tf_merkle_build_dev(dl, leaves, dn, 1, s);
+        if (r->rc == 0 && (hipMemcpyAsync(r->ntt.data(), dx, x.size() * 8, hipMemcpyDeviceToHost, s) != hipSuccess ||
+                           hipMemcpyAsync(r->nodes.data(), dn, r->nodes.size() * 8, hipMemcpyDeviceToHost, s) != hipSuccess ||
+                           hipStreamSynchronize(s) != hipSuccess)) r->rc = -3;
+        (void)hipFree(dx); (void)hipFree(dl); (void)hipFree(dn); (void)hipStreamDestroy(s);
+    };
+    Result ref;
+    run(devs[0], &ref);
+    EXPECT(ref.rc == 0);
+    std::vector<Result> res(devs.size());
+    std::vector<std::thread> th;
+    for (size_t i = 0; i < devs.size(); ++i) th.emplace_back(run, devs[i], &res[i]);
+    for (auto& t : th) t.join();
+    for (size_t i = 0; i < devs.size(); ++i) {
+        EXPECT(res[i].rc == 0);
+        EXPECT(res[i].ntt == ref.ntt);
+        EXPECT(res[i].nodes == ref.nodes);
+    }
+    (void)hipSetDevice(devs[0]);
 }
 
 int main() {
@@ -235,6 +285,15 @@ int main() {
         bool panicked = false;
         try { Polynomial<BFieldElement>::fast_coset_interpolate(BFieldElement::new_(0), bfe_vec({1, 2, 3, 4})); } catch (const NttPanic& e) { panicked = e.code == TF_ERR_INVERSE_OF_ZERO; }
         EXPECT(panicked);
+    }
+    {
+        const int nd = tf_device_count();
+        std::vector<int> devs;
+        if (nd > 1) for (int d = 0; d < nd; ++d) devs.push_back(d);
+        else devs = {0, 0};
+        multi_device_check(devs);
+        printf("C ABI from %zu host threads on %d device(s)%s: same words as one device alone\n", devs.size(), nd,
+               nd > 1 ? "" : " (one GPU here: both threads on device 0; the per-device path first runs on a multi-GPU node)");
     }
     if (failures) {
         fprintf(stderr, "%d failure(s)\n", failures);
