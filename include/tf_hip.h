@@ -190,7 +190,7 @@ int tf_poly_zerofier_xfe_dev(const uint64_t *d_roots, size_t n_roots, uint64_t *
  * in Polynomial::new, the caller does that -- the length here is data independent.
  * Errors: n_points == 0 -> TF_ERR_EMPTY_DOMAIN (:1503-1506); a repeated domain point -> TF_ERR_INVERSE_OF_ZERO (the reference
  * panics dividing by zero: traits.rs:106 / b_field_element.rs:264-268).  The _dev calls synchronise the stream once (the
- * repeated-point check). */
+ * repeated-point check); tf_poly_interpolate_*_dev_async (below) report it through a device status word instead. */
 int tf_poly_interpolate_bfe(const uint64_t *domain, const uint64_t *values, size_t n_points, size_t rows, uint64_t *out);
 int tf_poly_interpolate_xfe(const uint64_t *domain, const uint64_t *values, size_t n_points, size_t rows, uint64_t *out);
 int tf_poly_interpolate_bfe_dev(const uint64_t *d_domain, const uint64_t *d_values, size_t n_points, size_t rows, uint64_t *d_out, void *stream);
@@ -261,6 +261,24 @@ int tf_zerofier_tree_interpolate(tf_zerofier_tree *tree, const uint64_t *values,
 int tf_zerofier_tree_zerofier_dev(const tf_zerofier_tree *tree, uint64_t *d_out, void *stream);
 int tf_zerofier_tree_batch_evaluate_dev(const tf_zerofier_tree *tree, const uint64_t *d_coeffs, size_t n_coeffs, size_t batch, uint64_t *d_out, void *stream);
 int tf_zerofier_tree_interpolate_dev(tf_zerofier_tree *tree, const uint64_t *d_values, size_t rows, uint64_t *d_out, void *stream);
+/* ---- enqueue-and-return variants of the three _dev entry points above that otherwise synchronise their stream ------------------
+ * The reference PANICS on a repeated interpolation point (traits.rs:106), on a divisor with a root on the division coset and on
+ * an unclean division (polynomial.rs:2374, :2410).  The plain _dev calls detect these by copying a flag back, i.e. they block the
+ * host once; the _async variants never synchronise: they take `d_status`, ONE int in device memory owned by the caller (zero it
+ * before the first call of a chain), and a panic case writes its tf_status code there -- the first non-zero code written wins, so
+ * one word can serve a whole chain of calls; the output of a call that reported an error is unspecified.  Everything that can be
+ * checked on the host (null pointers, lengths, an empty domain, a zero divisor length) is still the return value.
+ * tf_zerofier_tree_new_*_dev_async returns the handle without waiting for the build: until the caller has synchronised (or
+ * ordered its other streams behind `stream` with an event) the handle may only be used on `stream`; the same holds for the
+ * inverse weights the first tf_zerofier_tree_interpolate_dev_async computes.  A handle whose weights met a repeated point keeps
+ * reporting TF_ERR_INVERSE_OF_ZERO through d_status on every later asynchronous interpolation. */
+int tf_poly_interpolate_bfe_dev_async(const uint64_t *d_domain, const uint64_t *d_values, size_t n_points, size_t rows, uint64_t *d_out, void *stream, int *d_status);
+int tf_poly_interpolate_xfe_dev_async(const uint64_t *d_domain, const uint64_t *d_values, size_t n_points, size_t rows, uint64_t *d_out, void *stream, int *d_status);
+int tf_poly_clean_divide_bfe_dev_async(const uint64_t *d_a, size_t na, const uint64_t *d_b, size_t nb, uint64_t *d_out, void *stream, int *d_status);
+int tf_poly_clean_divide_many_bfe_dev_async(const uint64_t *d_a, size_t na, size_t batch, const uint64_t *d_b, size_t nb, uint64_t *d_out, void *stream, int *d_status);
+int tf_zerofier_tree_new_bfe_dev_async(const uint64_t *d_domain, size_t n_points, void *stream, tf_zerofier_tree **tree);
+int tf_zerofier_tree_new_xfe_dev_async(const uint64_t *d_domain, size_t n_points, void *stream, tf_zerofier_tree **tree);
+int tf_zerofier_tree_interpolate_dev_async(tf_zerofier_tree *tree, const uint64_t *d_values, size_t rows, uint64_t *d_out, void *stream, int *d_status);
 /* The route tf_poly_batch_evaluate_* takes for a shape: 1 = Horner, 2 = zerofier tree (0: width not 1 / 3).  Pure host logic (the
  * fitted cost model of the router), checked by the CPU tests; honours tf_set_batch_eval_route / TF_BATCH_EVAL. */
 int tf_batch_eval_plan(size_t n_coeffs, size_t n_points, size_t batch, int width);

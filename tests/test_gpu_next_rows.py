@@ -1187,3 +1187,84 @@ def test_out_of_domain_row_and_quotients_compose(tf, oracle):
     with pytest.raises(tf.NttPanic) as e:
         tf.device.clean_divide_many(coeffs, n, _to_dev(divisor), q, cols)
     assert e.value.code == 16
+
+
+# ---- enqueue-and-return variants (tf_*_dev_async): the panic cases go to a status word in HBM, nothing blocks the host ----------
+def test_async_chain_interpolate_divide_evaluate_never_synchronises(tf, oracle):
+    """interpolate -> clean_divide -> batch_evaluate (+ a tree built and used asynchronously) enqueued on ONE stream behind a long
+    transform: the stream is still busy when the last call returns (torch's Stream.query() = hipStreamQuery), i.e. none of the
+    calls waited for the device; same words as the blocking entry points, status 0.  Then the three panic cases of the reference
+    (repeated point traits.rs:106; unclean division polynomial.rs:2410; the repeated point again through a tree handle) arrive
+    as status codes 12 / 16 / 12."""
+    import torch
+
+    n = 1 << 12
+    dom = torch.empty(n, dtype=torch.int64, device="cuda")
+    vals = torch.empty(n, dtype=torch.int64, device="cuda")
+    div = torch.empty(n // 4, dtype=torch.int64, device="cuda")
+    tf.device.fill_random(dom, 4101)
+    tf.device.fill_random(vals, 4102)
+    tf.device.fill_random(div, 4103)
+    # blocking reference run (also warms every table cache, whose first build synchronises)
+    coeffs = torch.empty(n, dtype=torch.int64, device="cuda")
+    tf.device.interpolate(dom, vals, coeffs)
+    prod = torch.empty(n + n // 4 - 1, dtype=torch.int64, device="cuda")
+    tf.device.poly_mul(coeffs, n, div, n // 4, prod)
+    quot = torch.empty(n, dtype=torch.int64, device="cuda")
+    tf.device.clean_divide(prod, div, quot)
+    ev = torch.empty(n, dtype=torch.int64, device="cuda")
+    tf.device.batch_evaluate(quot, n, dom, ev)
+    with tf.device.ZerofierTree(dom) as t0:
+        c_tree = torch.empty(n, dtype=torch.int64, device="cuda")
+        t0.interpolate(vals, c_tree)
+    big = torch.empty(256 << 20, dtype=torch.int64, device="cuda")
+    tf.device.fill_random(big, 4104)
+    tf.device.ntt_(big, 1 << 20, batch=256)
+    torch.cuda.synchronize()
+    assert torch.equal(quot, coeffs) and torch.equal(ev, vals) and torch.equal(c_tree, coeffs)
+
+    s = torch.cuda.Stream()
+    status = torch.zeros(1, dtype=torch.int32, device="cuda")
+    c2, q2, e2, c3 = (torch.empty(n, dtype=torch.int64, device="cuda") for _ in range(4))
+    p2 = torch.empty_like(prod)
+    with torch.cuda.stream(s):
+        for _ in range(20):                                   # ~40 ms of queued work in front of the chain
+            tf.device.ntt_(big, 1 << 20, batch=256, stream=s)
+        tf.device.interpolate(dom, vals, c2, stream=s, status=status)
+        tf.device.poly_mul(c2, n, div, n // 4, p2, stream=s)
+        tf.device.clean_divide(p2, div, q2, stream=s, status=status)
+        tf.device.batch_evaluate(q2, n, dom, e2, stream=s)
+        tree = tf.device.ZerofierTree(dom, stream=s, asynchronous=True)
+        tree.interpolate(vals, c3, stream=s, status=status)
+        pending = not s.query()
+    s.synchronize()
+    assert pending, "an entry point of the chain waited for the device"
+    assert int(status.item()) == 0
+    assert torch.equal(c2, coeffs) and torch.equal(q2, coeffs) and torch.equal(e2, vals) and torch.equal(c3, coeffs)
+    tree.close()
+
+    # the panic cases, asynchronously
+    bad_dom = dom.clone()
+    bad_dom[n - 1] = bad_dom[5]
+    st = torch.zeros(1, dtype=torch.int32, device="cuda")
+    tf.device.interpolate(bad_dom, vals, c2, status=st)
+    torch.cuda.synchronize()
+    assert int(st.item()) == 12                               # TF_ERR_INVERSE_OF_ZERO
+    st.zero_()
+    p2.copy_(prod)
+    p2[0] += 1                                                # no longer a multiple of the divisor
+    tf.device.clean_divide(p2, div, q2, status=st)
+    torch.cuda.synchronize()
+    assert int(st.item()) == 16                               # TF_ERR_DIVISION_NOT_CLEAN
+    tf.device.interpolate(bad_dom, vals, c2, status=st)       # the first error stays
+    torch.cuda.synchronize()
+    assert int(st.item()) == 16
+    st.zero_()
+    with tf.device.ZerofierTree(bad_dom, asynchronous=True) as bt:
+        bt.interpolate(vals, c2, status=st)
+        torch.cuda.synchronize()
+        assert int(st.item()) == 12
+        st.zero_()
+        bt.interpolate(vals, c2, status=st)                   # weights already there: the handle still reports them bad
+        torch.cuda.synchronize()
+        assert int(st.item()) == 12

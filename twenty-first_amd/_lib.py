@@ -115,6 +115,13 @@ SIGNATURES = {
     "tf_ntt_launch_count": (C.c_int, [_sz, _sz, C.c_int]),
     "tf_ntt_plan": (C.c_int, [_sz, C.c_int, C.POINTER(C.c_int)]),
     "tf_batch_eval_plan": (C.c_int, [_sz, _sz, _sz, C.c_int]),
+    "tf_poly_interpolate_bfe_dev_async": (C.c_int, [_vp, _vp, _sz, _sz, _vp, _vp, _vp]),
+    "tf_poly_interpolate_xfe_dev_async": (C.c_int, [_vp, _vp, _sz, _sz, _vp, _vp, _vp]),
+    "tf_poly_clean_divide_bfe_dev_async": (C.c_int, [_vp, _sz, _vp, _sz, _vp, _vp, _vp]),
+    "tf_poly_clean_divide_many_bfe_dev_async": (C.c_int, [_vp, _sz, _sz, _vp, _sz, _vp, _vp, _vp]),
+    "tf_zerofier_tree_new_bfe_dev_async": (C.c_int, [_vp, _sz, _vp, C.POINTER(C.c_void_p)]),
+    "tf_zerofier_tree_new_xfe_dev_async": (C.c_int, [_vp, _sz, _vp, C.POINTER(C.c_void_p)]),
+    "tf_zerofier_tree_interpolate_dev_async": (C.c_int, [_vp, _vp, _sz, _vp, _vp, _vp]),
     "tf_set_ntt_small_launch": (None, [C.c_int]),
     "tf_set_ntt_two_pass": (None, [C.c_int]),
     "tf_debug_stamps": (C.c_int, [_vp, _sz]),

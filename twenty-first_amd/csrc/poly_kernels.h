@@ -380,6 +380,13 @@ __global__ void __launch_bounds__(256) fe_inverse_kernel(const u64* x, long long
     fe_store<L>(w + i * L, r);
 }
 
+// The *_dev_async entry points report a panic case of the reference through a status word in DEVICE memory instead of
+// synchronising the stream to read a flag: status keeps the FIRST non-zero code written to it (0 = nothing happened).
+__global__ void status_merge_kernel(const int* flag, int* status, int code_bit0, int code_other) {
+    const int f = *flag;
+    if (f) atomicCAS(status, 0, (f & 1) ? code_bit0 : code_other);
+}
+
 // targets[row][i] = values[row][i] * w[i] for i < n, zero for n <= i < M   (grid.y = rows; values rows n elements apart)
 template <int L>
 __global__ void __launch_bounds__(256) interpolation_targets_kernel(const u64* values, const u64* w, long long n, long long M, u64* targets) {

@@ -2397,7 +2397,11 @@ int zerofier_dev(const u64* roots, size_t n_roots, u64* out, int L, void* stream
 // winv[i] = 1 / Z'(x_i), i < n (M L words are written: zero beyond n is NOT guaranteed, the consumers stop at n).  Synchronises
 // the stream once: a zero Z'(x_i) is a repeated domain point, where the reference panics (TF_ERR_INVERSE_OF_ZERO).
 template <int L>
-int tree_inverse_weights(DeviceCtx* ctx, const PaddedTree& pt, const u64* domain, u64* winv, hipStream_t s) {
+// d_status != null (the *_dev_async entry points): no synchronisation -- a zero weight denominator is reported by writing
+// TF_ERR_INVERSE_OF_ZERO to *d_status (device memory, first error wins) and, if sticky != null, by setting *sticky (a flag
+// that outlives the call: a ZerofierTree handle whose weights are bad keeps reporting it).
+int tree_inverse_weights(DeviceCtx* ctx, const PaddedTree& pt, const u64* domain, u64* winv, hipStream_t s, int* d_status = nullptr,
+                         int* sticky = nullptr) {
     const long long M = pt.T.M;
     const size_t ML = (size_t)M * L, n = pt.n;
     u64* tmp = nullptr;  // derivative (M), its values (M), walk work (8 M), flag
@@ -2414,7 +2418,11 @@ int tree_inverse_weights(DeviceCtx* ctx, const PaddedTree& pt, const u64* domain
         if (e != hipSuccess) rc = hip_fail(e, "hipMemsetAsync", __FILE__, __LINE__);
     }
     if (!rc) rc = launch_1d<L>(tfk::fe_inverse_kernel<L>, (long long)n, s, (const u64*)dz, (long long)n, winv, flag);
-    if (!rc) {
+    if (!rc && d_status) {
+        hipLaunchKernelGGL(tfk::status_merge_kernel, dim3(1), dim3(1), 0, s, (const int*)flag, d_status, (int)TF_ERR_INVERSE_OF_ZERO, (int)TF_ERR_INVERSE_OF_ZERO);
+        if (sticky) hipLaunchKernelGGL(tfk::status_merge_kernel, dim3(1), dim3(1), 0, s, (const int*)flag, sticky, 1, 1);
+        if (hipGetLastError() != hipSuccess) rc = TF_ERR_HIP;
+    } else if (!rc) {
         int host_flag = 0;
         e = hipMemcpyAsync(&host_flag, flag, sizeof(int), hipMemcpyDeviceToHost, s);
         if (e == hipSuccess) e = hipStreamSynchronize(s);
@@ -2476,7 +2484,7 @@ int tree_interpolate_rows(DeviceCtx* ctx, const PaddedTree& pt, const u64* domai
 }
 
 template <int L>
-int interpolate_dev_t(const u64* domain, const u64* values, size_t n, size_t rows, u64* out, hipStream_t s) {
+int interpolate_dev_t(const u64* domain, const u64* values, size_t n, size_t rows, u64* out, hipStream_t s, int* d_status) {
     const int kTreeLeaf = tree_leaf(L);
     long long M = kTreeLeaf;
     while (M < (long long)n) M <<= 1;
@@ -2484,13 +2492,13 @@ int interpolate_dev_t(const u64* domain, const u64* values, size_t n, size_t row
     int rc = padded_tree_build<L>(domain, n, (size_t)M * L, &pt, s);  // extra: the inverse weights
     DeviceCtx* ctx = nullptr;
     if (!rc) rc = current_ctx(&ctx);
-    if (!rc) rc = tree_inverse_weights<L>(ctx, pt, domain, pt.extra, s);
+    if (!rc) rc = tree_inverse_weights<L>(ctx, pt, domain, pt.extra, s, d_status);
     if (!rc) rc = tree_interpolate_rows<L>(ctx, pt, domain, pt.extra, values, rows, out, s);
     return padded_tree_free(&pt, s, rc);
 }
 
 // `rows` value rows of n elements over one domain of n distinct points -> rows x n coefficients (low to high).
-int interpolate_dev(const u64* domain, const u64* values, size_t n, size_t rows, u64* out, int L, void* stream) {
+int interpolate_dev(const u64* domain, const u64* values, size_t n, size_t rows, u64* out, int L, void* stream, int* d_status = nullptr) {
     if (n == 0) return TF_ERR_EMPTY_DOMAIN;  // "interpolation must happen through more than zero points" (:1503-1506)
     if (rows == 0) return TF_OK;
     if (!domain || !values || !out) return TF_ERR_NULL_POINTER;
@@ -2499,7 +2507,7 @@ int interpolate_dev(const u64* domain, const u64* values, size_t n, size_t rows,
     int rc = current_ctx(&ctx);
     if (rc) return rc;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    return L == 1 ? interpolate_dev_t<1>(domain, values, n, rows, out, s) : interpolate_dev_t<3>(domain, values, n, rows, out, s);
+    return L == 1 ? interpolate_dev_t<1>(domain, values, n, rows, out, s, d_status) : interpolate_dev_t<3>(domain, values, n, rows, out, s, d_status);
 }
 
 // ---- a zerofier tree that outlives the call (math/zerofier_tree.rs: ZerofierTree::new_from_domain, used with
@@ -2512,28 +2520,31 @@ struct TreeHandle {
     PaddedTree pt;
     u64* points = nullptr;  // the domain, M L words (pt.extra)
     u64* winv = nullptr;    // 1 / Z'(x_i), M L words (pt.extra + M L)
+    int* bad = nullptr;     // device flag behind the weights: set when an asynchronous weight computation met a repeated point
     std::mutex mu;
     bool have_winv = false;
 };
 
 template <int L>
-int tree_handle_new_t(const u64* d_domain, size_t n, hipStream_t s, TreeHandle* H) {
+int tree_handle_new_t(const u64* d_domain, size_t n, hipStream_t s, TreeHandle* H, bool async) {
     const int kTreeLeaf = tree_leaf(L);
     long long M = kTreeLeaf;
     while (M < (long long)n) M <<= 1;
-    int rc = padded_tree_build<L>(d_domain, n, 2 * (size_t)M * L, &H->pt, s, true);
+    int rc = padded_tree_build<L>(d_domain, n, 2 * (size_t)M * L + 1, &H->pt, s, true);
     if (rc) return rc;
     H->points = H->pt.extra;
     H->winv = H->points + (size_t)M * L;
+    H->bad = reinterpret_cast<int*>(H->winv + (size_t)M * L);
+    if (hipMemsetAsync(H->bad, 0, sizeof(u64), s) != hipSuccess) return TF_ERR_HIP;
     // the tree was built from the caller's array; the handle keeps its own copy for the leaf evaluations
     hipError_t e = hipMemsetAsync(H->points, 0, (size_t)M * L * sizeof(u64), s);
     if (e == hipSuccess && n) e = hipMemcpyAsync(H->points, d_domain, n * L * sizeof(u64), hipMemcpyDeviceToDevice, s);
-    if (e == hipSuccess) e = hipStreamSynchronize(s);  // the handle may be used from any stream afterwards
+    if (e == hipSuccess && !async) e = hipStreamSynchronize(s);  // the handle may be used from any stream afterwards
     if (e != hipSuccess) return hip_fail(e, "zerofier tree: domain copy", __FILE__, __LINE__);
     return TF_OK;
 }
 
-int tree_handle_new(const u64* d_domain, size_t n, int L, void* stream, TreeHandle** out) {
+int tree_handle_new(const u64* d_domain, size_t n, int L, void* stream, TreeHandle** out, bool async = false) {
     if (!out) return TF_ERR_NULL_POINTER;
     *out = nullptr;
     if (n && !d_domain) return TF_ERR_NULL_POINTER;
@@ -2545,7 +2556,7 @@ int tree_handle_new(const u64* d_domain, size_t n, int L, void* stream, TreeHand
     H->L = L;
     if (hipGetDevice(&H->device) != hipSuccess) return TF_ERR_NO_DEVICE;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    rc = L == 1 ? tree_handle_new_t<1>(d_domain, n, s, H.get()) : tree_handle_new_t<3>(d_domain, n, s, H.get());
+    rc = L == 1 ? tree_handle_new_t<1>(d_domain, n, s, H.get(), async) : tree_handle_new_t<3>(d_domain, n, s, H.get(), async);
     if (rc) {
         (void)hipStreamSynchronize(s);
         (void)padded_tree_free(&H->pt, s, rc);
@@ -2594,7 +2605,7 @@ int tree_handle_batch_evaluate(const TreeHandle* H, const u64* d_coeffs, size_t 
                   : tree_batch_evaluate<3>(ctx, H->pt.T, H->points, n, d_coeffs, n_coeffs, 3 * n_coeffs, batch, d_out, s);
 }
 
-int tree_handle_interpolate(TreeHandle* H, const u64* d_values, size_t rows, u64* d_out, void* stream) {
+int tree_handle_interpolate(TreeHandle* H, const u64* d_values, size_t rows, u64* d_out, void* stream, int* d_status = nullptr) {
     DeviceCtx* ctx = nullptr;
     int rc = tree_handle_check(H, &ctx);
     if (rc) return rc;
@@ -2605,9 +2616,13 @@ int tree_handle_interpolate(TreeHandle* H, const u64* d_values, size_t rows, u64
     {
         std::lock_guard<std::mutex> lk(H->mu);  // the first interpolation computes the weights (and synchronises its stream)
         if (!H->have_winv) {
-            rc = H->L == 1 ? tree_inverse_weights<1>(ctx, H->pt, H->points, H->winv, s) : tree_inverse_weights<3>(ctx, H->pt, H->points, H->winv, s);
+            rc = H->L == 1 ? tree_inverse_weights<1>(ctx, H->pt, H->points, H->winv, s, d_status, d_status ? H->bad : nullptr)
+                           : tree_inverse_weights<3>(ctx, H->pt, H->points, H->winv, s, d_status, d_status ? H->bad : nullptr);
             if (rc) return rc;
             H->have_winv = true;
+        } else if (d_status) {  // weights computed by an earlier asynchronous call: pass its verdict on
+            hipLaunchKernelGGL(tfk::status_merge_kernel, dim3(1), dim3(1), 0, s, (const int*)H->bad, d_status, (int)TF_ERR_INVERSE_OF_ZERO, (int)TF_ERR_INVERSE_OF_ZERO);
+            if (hipGetLastError() != hipSuccess) return TF_ERR_HIP;
         }
     }
     return H->L == 1 ? tree_interpolate_rows<1>(ctx, H->pt, H->points, H->winv, d_values, rows, d_out, s)
@@ -2743,7 +2758,8 @@ int barycentric_dev(const u64* codewords, size_t n, size_t batch, int cw_width, 
 // is not needed; the naive route it takes for divisors below degree 512 (:2360-2364) returns the same quotient.
 // `batch` dividends of na coefficients each (packed) by ONE divisor: the divisor's transform is inverted once and shared -- the
 // shape of a prover's quotients (many numerators over the same zerofier).
-int clean_divide_dev(const u64* a, size_t na, const u64* b, size_t nb, u64* out, void* stream, size_t batch = 1) {
+// d_status != null (the *_dev_async entry points): never synchronises; the two panic cases are written to *d_status on the device.
+int clean_divide_dev(const u64* a, size_t na, const u64* b, size_t nb, u64* out, void* stream, size_t batch = 1, int* d_status = nullptr) {
     if (nb == 0) return TF_ERR_DIVISION_BY_ZERO;                      // naive_divide :556-559 "divisor should be non-zero"
     if (na < nb) return na ? TF_ERR_DIVISION_NOT_CLEAN : TF_OK;       // a non-zero dividend of lower degree: the remainder is the dividend
     if (batch == 0) return TF_OK;
@@ -2786,7 +2802,10 @@ int clean_divide_dev(const u64* a, size_t na, const u64* b, size_t nb, u64* out,
                            (long long)(na - nb + 1), out, Xinv[0], Xinv[1], Xinv[2], flag);
         if (hipGetLastError() != hipSuccess) rc = TF_ERR_HIP;
     }
-    if (!rc) {
+    if (!rc && d_status) {
+        hipLaunchKernelGGL(tfk::status_merge_kernel, dim3(1), dim3(1), 0, s, (const int*)flag, d_status, (int)TF_ERR_INVERSE_OF_ZERO, (int)TF_ERR_DIVISION_NOT_CLEAN);
+        if (hipGetLastError() != hipSuccess) rc = TF_ERR_HIP;
+    } else if (!rc) {
         int host_flag = 0;
         e = hipMemcpyAsync(&host_flag, flag, sizeof(int), hipMemcpyDeviceToHost, s);
         if (e == hipSuccess) e = hipStreamSynchronize(s);
@@ -3387,6 +3406,15 @@ static int tree_new_any(const uint64_t* domain, size_t n, int L, bool on_device,
     *tree = reinterpret_cast<tf_zerofier_tree*>(H);
     return TF_OK;
 }
+static int tree_new_async(const uint64_t* d_domain, size_t n, int L, void* stream, tf_zerofier_tree** tree) {
+    if (!tree) return TF_ERR_NULL_POINTER;
+    *tree = nullptr;
+    TreeHandle* H = nullptr;
+    const int rc = tree_handle_new(d_domain, n, L, stream, &H, true);
+    if (rc) return rc;
+    *tree = reinterpret_cast<tf_zerofier_tree*>(H);
+    return TF_OK;
+}
 static TreeHandle* tree_of(const tf_zerofier_tree* t) { return const_cast<TreeHandle*>(reinterpret_cast<const TreeHandle*>(t)); }
 int tf_zerofier_tree_new_bfe(const uint64_t* domain, size_t n, tf_zerofier_tree** tree) { return tree_new_any(domain, n, 1, false, nullptr, tree); }
 int tf_zerofier_tree_new_xfe(const uint64_t* domain, size_t n, tf_zerofier_tree** tree) { return tree_new_any(domain, n, 3, false, nullptr, tree); }
@@ -3406,6 +3434,34 @@ int tf_zerofier_tree_batch_evaluate_dev(const tf_zerofier_tree* tree, const uint
 }
 int tf_zerofier_tree_interpolate_dev(tf_zerofier_tree* tree, const uint64_t* d_values, size_t rows, uint64_t* d_out, void* stream) {
     return tree_handle_interpolate(tree_of(tree), d_values, rows, d_out, stream);
+}
+// ---- enqueue-and-return variants (tf_hip.h): panic cases go to *d_status on the device, nothing synchronises
+int tf_poly_interpolate_bfe_dev_async(const uint64_t* d, const uint64_t* v, size_t n, size_t rows, uint64_t* out, void* stream, int* d_status) {
+    if (!d_status) return TF_ERR_NULL_POINTER;
+    return interpolate_dev(d, v, n, rows, out, 1, stream, d_status);
+}
+int tf_poly_interpolate_xfe_dev_async(const uint64_t* d, const uint64_t* v, size_t n, size_t rows, uint64_t* out, void* stream, int* d_status) {
+    if (!d_status) return TF_ERR_NULL_POINTER;
+    return interpolate_dev(d, v, n, rows, out, 3, stream, d_status);
+}
+int tf_poly_clean_divide_bfe_dev_async(const uint64_t* a, size_t na, const uint64_t* b, size_t nb, uint64_t* out, void* stream, int* d_status) {
+    if (!d_status) return TF_ERR_NULL_POINTER;
+    return clean_divide_dev(a, na, b, nb, out, stream, 1, d_status);
+}
+int tf_poly_clean_divide_many_bfe_dev_async(const uint64_t* a, size_t na, size_t batch, const uint64_t* b, size_t nb, uint64_t* out, void* stream,
+                                            int* d_status) {
+    if (!d_status) return TF_ERR_NULL_POINTER;
+    return clean_divide_dev(a, na, b, nb, out, stream, batch, d_status);
+}
+int tf_zerofier_tree_new_bfe_dev_async(const uint64_t* d_domain, size_t n, void* stream, tf_zerofier_tree** tree) {
+    return tree_new_async(d_domain, n, 1, stream, tree);
+}
+int tf_zerofier_tree_new_xfe_dev_async(const uint64_t* d_domain, size_t n, void* stream, tf_zerofier_tree** tree) {
+    return tree_new_async(d_domain, n, 3, stream, tree);
+}
+int tf_zerofier_tree_interpolate_dev_async(tf_zerofier_tree* tree, const uint64_t* d_values, size_t rows, uint64_t* d_out, void* stream, int* d_status) {
+    if (!d_status) return TF_ERR_NULL_POINTER;
+    return tree_handle_interpolate(tree_of(tree), d_values, rows, d_out, stream, d_status);
 }
 int tf_zerofier_tree_zerofier(const tf_zerofier_tree* tree, uint64_t* out) {
     if (!tree || !out) return TF_ERR_NULL_POINTER;

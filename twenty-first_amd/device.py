@@ -211,18 +211,34 @@ def evaluate_bfe_at_xfe(coeffs, n_coeffs: int, points, out, batch: int = 1, stre
     _chk(_lib.lib().tf_poly_evaluate_bfe_at_xfe_dev(_p(coeffs), n_coeffs, batch, _p(points), points.numel() // 3, _p(out), _stream(stream)), "evaluate")
 
 
-def clean_divide(a, b, out, stream=None) -> None:
+def _status(status):
+    """`status`: a one-element int32 CUDA tensor the *_dev_async entry points report the reference's panic cases through
+    (first non-zero tf_status code wins); with it a wrapper enqueues and returns without ever synchronising the stream."""
+    import torch
+
+    if not isinstance(status, torch.Tensor) or not status.is_cuda or status.dtype != torch.int32 or status.numel() != 1:
+        raise TypeError("status must be a one-element int32 CUDA tensor")
+    return C.c_void_p(status.data_ptr())
+
+
+def clean_divide(a, b, out, stream=None, status=None) -> None:
     """Polynomial::<BFieldElement>::clean_divide (math/polynomial.rs:2358-2411) on device buffers: a, b normalised coefficient
-    arrays, out = the na - nb + 1 quotient coefficients."""
+    arrays, out = the na - nb + 1 quotient coefficients.  status: see _status (no host synchronisation)."""
     a, b, out = _t(a, "a"), _t(b, "b"), _t(out, "out")
     _need(a.numel() >= b.numel() and out.numel() == a.numel() - b.numel() + 1, "out must hold na - nb + 1 coefficients")
+    if status is not None:
+        _chk(_lib.lib().tf_poly_clean_divide_bfe_dev_async(_p(a), a.numel(), _p(b), b.numel(), _p(out), _stream(stream), _status(status)), "clean_divide")
+        return
     _chk(_lib.lib().tf_poly_clean_divide_bfe_dev(_p(a), a.numel(), _p(b), b.numel(), _p(out), _stream(stream)), "clean_divide")
 
 
-def clean_divide_many(a, na: int, b, out, batch: int, stream=None) -> None:
+def clean_divide_many(a, na: int, b, out, batch: int, stream=None, status=None) -> None:
     """`batch` dividends of na coefficients each over one divisor (tf_poly_clean_divide_many_bfe_dev): out = batch x (na - nb + 1)."""
     a, b, out = _t(a, "a"), _t(b, "b"), _t(out, "out")
     _need(a.numel() == batch * na and na >= b.numel() and out.numel() == batch * (na - b.numel() + 1), "a = batch * na, out = batch * (na - nb + 1) coefficients")
+    if status is not None:
+        _chk(_lib.lib().tf_poly_clean_divide_many_bfe_dev_async(_p(a), na, batch, _p(b), b.numel(), _p(out), _stream(stream), _status(status)), "clean_divide")
+        return
     _chk(_lib.lib().tf_poly_clean_divide_many_bfe_dev(_p(a), na, batch, _p(b), b.numel(), _p(out), _stream(stream)), "clean_divide")
 
 
@@ -236,13 +252,17 @@ def zerofier(roots, out, width: int = 1, stream=None) -> None:
     _chk(fn(_p(roots), n, _p(out), _stream(stream)), "zerofier")
 
 
-def interpolate(domain, values, out, rows: int = 1, width: int = 1, stream=None) -> None:
+def interpolate(domain, values, out, rows: int = 1, width: int = 1, stream=None, status=None) -> None:
     """Polynomial::interpolate / batch_fast_interpolate (math/polynomial.rs:1502-1838) on device buffers: `rows` value rows over
-    one domain -> rows x n coefficients (untrimmed)."""
+    one domain -> rows x n coefficients (untrimmed).  status: see _status (no host synchronisation)."""
     domain, values, out = _t(domain, "domain"), _t(values, "values"), _t(out, "out")
     _need(domain.numel() % width == 0, "domain must hold whole elements")
     n = domain.numel() // width
     _need(values.numel() == rows * n * width and out.numel() == rows * n * width, "values / out must hold rows * n elements")
+    if status is not None:
+        fn = _lib.lib().tf_poly_interpolate_bfe_dev_async if width == 1 else _lib.lib().tf_poly_interpolate_xfe_dev_async
+        _chk(fn(_p(domain), _p(values), n, rows, _p(out), _stream(stream), _status(status)), "interpolate")
+        return
     fn = _lib.lib().tf_poly_interpolate_bfe_dev if width == 1 else _lib.lib().tf_poly_interpolate_xfe_dev
     _chk(fn(_p(domain), _p(values), n, rows, _p(out), _stream(stream)), "interpolate")
 
@@ -266,14 +286,19 @@ class ZerofierTree:
     """math/zerofier_tree.rs on device buffers: the tree of a device-resident domain, kept in HBM across calls
     (tf_zerofier_tree_* of include/tf_hip.h).  close() (or the context manager) releases the device memory."""
 
-    def __init__(self, domain, width: int = 1, stream=None):
+    def __init__(self, domain, width: int = 1, stream=None, asynchronous: bool = False):
+        """asynchronous: return without waiting for the build (tf_zerofier_tree_new_*_dev_async): until the caller synchronises,
+        the tree may only be used on the stream it was built on."""
         domain = _t(domain, "domain")
         _need(domain.numel() % _width(width) == 0, "domain must hold whole elements")
         self.width = width
         self.num_points = domain.numel() // width
         self._h = C.c_void_p(0)
         self._free = _lib.lib().tf_zerofier_tree_free
-        fn = _lib.lib().tf_zerofier_tree_new_bfe_dev if width == 1 else _lib.lib().tf_zerofier_tree_new_xfe_dev
+        if asynchronous:
+            fn = _lib.lib().tf_zerofier_tree_new_bfe_dev_async if width == 1 else _lib.lib().tf_zerofier_tree_new_xfe_dev_async
+        else:
+            fn = _lib.lib().tf_zerofier_tree_new_bfe_dev if width == 1 else _lib.lib().tf_zerofier_tree_new_xfe_dev
         _chk(fn(_p(domain), self.num_points, _stream(stream), C.byref(self._h)), "ZerofierTree::new_from_domain")
 
     def close(self) -> None:
@@ -302,9 +327,12 @@ class ZerofierTree:
         _chk(_lib.lib().tf_zerofier_tree_batch_evaluate_dev(self._h, _p(coeffs), n_coeffs, batch, _p(out), _stream(stream)),
              "divide_and_conquer_batch_evaluate")
 
-    def interpolate(self, values, out, rows: int = 1, stream=None) -> None:
+    def interpolate(self, values, out, rows: int = 1, stream=None, status=None) -> None:
         values, out = _t(values, "values"), _t(out, "out")
         _need(values.numel() == rows * self.num_points * self.width and out.numel() == values.numel(), "values / out must hold rows * n elements")
+        if status is not None:
+            _chk(_lib.lib().tf_zerofier_tree_interpolate_dev_async(self._h, _p(values), rows, _p(out), _stream(stream), _status(status)), "interpolate")
+            return
         _chk(_lib.lib().tf_zerofier_tree_interpolate_dev(self._h, _p(values), rows, _p(out), _stream(stream)), "interpolate")
 
 
