@@ -65,6 +65,11 @@ const char *tf_last_error(void);
 int tf_version(void);
 /* Number of visible HIP devices (0 if the runtime is unusable). */
 int tf_device_count(void);
+/* What the library keeps in HBM for speed, per device and for the life of the process: work space between the passes of the
+ * multi-pass transforms (at most 12 GiB), inter-pass twiddle tables (at most 4 GiB), coset power tables (at most 1 GiB).
+ * tf_release_caches() waits for the current device and frees all of it (the next call rebuilds what it needs); meant for hosts
+ * that share the GPU with other users of its memory. */
+int tf_release_caches(void);
 
 /* ---------------------------------------------------------------------------------------------
  * NTT / iNTT            replaces  pub fn ntt<FF>(x: &mut [FF])   math/ntt.rs:67-82
@@ -220,6 +225,7 @@ int tf_poly_evaluate_bfe_at_xfe_dev(const uint64_t *d_coeffs, size_t n_coeffs, s
  * :2620); the indeterminate inside the subgroup, or n == 0 -> TF_ERR_INVERSE_OF_ZERO (batch_inversion / inverse of zero). */
 int tf_barycentric_evaluate_bfe(const uint64_t *codewords, size_t n, size_t batch, const uint64_t indeterminate[3], uint64_t *out);
 int tf_barycentric_evaluate_xfe(const uint64_t *codewords, size_t n, size_t batch, const uint64_t indeterminate[3], uint64_t *out);
+/* (at most 65 534 x 8 codewords per call: more -> TF_ERR_LEN_TOO_LARGE; split the batch) */
 int tf_barycentric_evaluate_bfe_dev(const uint64_t *d_codewords, size_t n, size_t batch, const uint64_t indeterminate[3], uint64_t *d_out, void *stream);
 int tf_barycentric_evaluate_xfe_dev(const uint64_t *d_codewords, size_t n, size_t batch, const uint64_t indeterminate[3], uint64_t *d_out, void *stream);
 /* Polynomial::<BFieldElement>::clean_divide  math/polynomial.rs:2358-2411: the quotient a / b of a division KNOWN to be clean
@@ -228,8 +234,14 @@ int tf_barycentric_evaluate_xfe_dev(const uint64_t *d_codewords, size_t n, size_
  * as Polynomial::degree does); out receives na - nb + 1 coefficients.
  * Errors (where the reference panics): nb == 0 -> TF_ERR_DIVISION_BY_ZERO; the division is not clean (including
  * 0 < na < nb) -> TF_ERR_DIVISION_NOT_CLEAN (the reference: "might panic or produce a wrong result"; here it is always
- * detected); a divisor with a root on the coset (an irreducible cubic factor of a special form) -> TF_ERR_INVERSE_OF_ZERO as in the
- * reference's batch_inversion.  na == 0 (zero dividend): TF_OK, nothing written.  The _dev call synchronises its stream once. */
+ * detected).  na == 0 (zero dividend): TF_OK, nothing written.  The _dev call synchronises its stream once.
+ * Where this differs from the reference: (1) the reference takes the coset route only for divisors of degree >= 512 and long
+ * division below (:2360-2364); here every divisor takes the coset route.  A divisor with a root ON the coset x * <w_order>
+ * (x^3 - x + 1 and its relatives y^3 - w^2i y + w^3i) cannot be inverted there: the blocking calls repeat the division once on
+ * the coset (x + 1) * <w_order> (a clean quotient is the same on any coset) and only then report TF_ERR_INVERSE_OF_ZERO, the
+ * code of the reference's batch_inversion panic; the _dev_async variant reports it after the first coset.  (2) 0 < na < nb is
+ * TF_ERR_DIVISION_NOT_CLEAN, where a release build of the reference returns the zero quotient.  (3) An unclean division is
+ * always detected. */
 int tf_poly_clean_divide_bfe(const uint64_t *a, size_t na, const uint64_t *b, size_t nb, uint64_t *out);
 int tf_poly_clean_divide_bfe_dev(const uint64_t *d_a, size_t na, const uint64_t *d_b, size_t nb, uint64_t *d_out, void *stream);
 /* The same for `batch` dividends of na coefficients each (packed; na counts up to the longest dividend, shorter ones zero padded)
@@ -321,7 +333,7 @@ void tf_set_ntt_tile_bytes(size_t bytes);
 /*   TF_NTT_PIPE       : K = 1..4 side streams the batch tiles of a multi-pass NTT are dealt to round-robin (each with its own
  *                       scratch tile), so the column pass of tile t + 1 overlaps the transposing pass of tile t and a tile
  *                       sized for the Infinity Cache is re-read out of it; the caller's stream forks/joins with events. */
-void tf_set_ntt_pipe(int streams);
+void tf_set_ntt_pipe(int streams);  /* K > 1 is for ONE caller per device: all callers share the device's K side streams */
 int tf_get_ntt_pipe(void);
 /*   TF_NTT_NT         : bit 0 = non-temporal loads of the caller's input in the first pass, bit 1 = non-temporal stores of the
  *                       result in the last pass of a plain multi-pass transform (keeps the Infinity Cache for the scratch tile). */

@@ -1268,3 +1268,44 @@ def test_async_chain_interpolate_divide_evaluate_never_synchronises(tf, oracle):
         bt.interpolate(vals, c2, status=st)                   # weights already there: the handle still reports them bad
         torch.cuda.synchronize()
         assert int(st.item()) == 12
+
+
+def test_clean_divide_by_a_divisor_with_a_root_on_the_division_coset(tf, oracle):
+    """x^3 - x + 1 is the minimal polynomial of X = x, the offset of the reference's division coset (polynomial.rs:2383): its
+    transform has a zero there.  The reference divides by such a small divisor on its naive route (:2360-2364) and succeeds; the
+    device repeats the division on the coset (x + 1) * <w> and returns the same quotient as the oracle's long division."""
+    P_ = tf.Polynomial
+    one, neg1 = oracle.bfe_new(1), oracle.bfe_new((1 << 64) - (1 << 32))
+    b = np.array([one, neg1, 0, one], dtype=np.uint64)  # 1 - x + x^3
+    for nq in (1, 5, 300, 5000):
+        q = oracle.fill_random(nq, 900 + nq)
+        a = oracle.poly_mul(q, b)
+        assert np.array_equal(P_(a).clean_divide(P_(b)).coefficients, q)
+        assert np.array_equal(oracle.clean_divide(a, b, 512), q)  # the reference's route for this divisor: naive_divide
+    # ... times another factor, and an unclean dividend still reports so
+    b2 = oracle.poly_mul(b, oracle.fill_random(40, 950))
+    q = oracle.fill_random(100, 951)
+    a = oracle.poly_mul(q, b2)
+    assert np.array_equal(P_(a).clean_divide(P_(b2)).coefficients, q)
+    a[3] ^= np.uint64(1)
+    with pytest.raises(tf.NttPanic) as e:
+        P_(a).clean_divide(P_(b2))
+    assert e.value.code == 16
+
+
+def test_release_caches_and_recompute(tf, oracle):
+    """tf_release_caches drops the scratch blocks and the large cached tables of the device; the next calls rebuild them and
+    give the same words."""
+    n, batch = 1 << 16, 4
+    x = oracle.fill_random(n * batch, 77)
+    want = oracle.ntt(x, batch=batch, threads=4)
+    y = x.copy()
+    tf.ntt(y, batch=batch)
+    assert np.array_equal(y, want)
+    ev = tf.fast_coset_evaluate(x[:n], oracle.bfe_new(7), 2 * n)
+    assert tf.lib().tf_release_caches() == 0
+    y = x.copy()
+    tf.ntt(y, batch=batch)
+    assert np.array_equal(y, want)
+    assert np.array_equal(tf.fast_coset_evaluate(x[:n], oracle.bfe_new(7), 2 * n), ev)
+    assert tf.lib().tf_release_caches() == 0

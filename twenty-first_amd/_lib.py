@@ -122,6 +122,7 @@ SIGNATURES = {
     "tf_zerofier_tree_new_bfe_dev_async": (C.c_int, [_vp, _sz, _vp, C.POINTER(C.c_void_p)]),
     "tf_zerofier_tree_new_xfe_dev_async": (C.c_int, [_vp, _sz, _vp, C.POINTER(C.c_void_p)]),
     "tf_zerofier_tree_interpolate_dev_async": (C.c_int, [_vp, _vp, _sz, _vp, _vp, _vp]),
+    "tf_release_caches": (C.c_int, []),
     "tf_set_ntt_small_launch": (None, [C.c_int]),
     "tf_set_ntt_two_pass": (None, [C.c_int]),
     "tf_debug_stamps": (C.c_int, [_vp, _sz]),

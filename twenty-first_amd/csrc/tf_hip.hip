@@ -215,6 +215,39 @@ void scratch_release(DeviceCtx* ctx, DeviceCtx::ScratchBlock blk, hipStream_t st
     }
 }
 
+// tf_release_caches: give back what the current device's context pins for speed -- the scratch blocks between transform passes
+// (up to 12 GiB), the inter-pass twiddle tables (up to 4 GiB) and the coset power tables (up to 1 GiB).  Waits for the device
+// first (tables may be read by kernels in flight); the next call rebuilds what it needs.  The small tables (inner twiddles,
+// Tip5 constants) stay.
+int release_caches(DeviceCtx* ctx) {
+    HIPCHK(hipDeviceSynchronize());
+    std::vector<DeviceCtx::ScratchBlock> drop;
+    std::vector<u64*> tabs;
+    {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        drop.swap(ctx->scratch_free);
+        ctx->scratch_bytes = 0;
+        for (auto it = ctx->tables.begin(); it != ctx->tables.end();) {
+            if ((it->first >> 56) == 2 /* TAG_POST */) {
+                tabs.push_back(it->second);
+                it = ctx->tables.erase(it);
+            } else {
+                ++it;
+            }
+        }
+        ctx->cached_post_bytes = 0;
+        for (auto& kv : ctx->pow_tables) tabs.push_back(kv.second);
+        ctx->pow_tables.clear();
+        ctx->cached_pow_bytes = 0;
+    }
+    for (auto& b : drop) {
+        (void)hipEventDestroy(b.ready);
+        (void)hipFree(b.p);
+    }
+    for (u64* t : tabs) (void)hipFree(t);
+    return TF_OK;
+}
+
 size_t g_tile_bytes = 0;
 // Pipelined tiles: with g_pipe = K > 1 the batch tiles of a multi-pass transform are dealt round-robin to K side streams,
 // each with its own scratch tile, so that the column pass of tile t + 1 runs beside the transposing pass of tile t: the
@@ -2779,8 +2812,18 @@ int clean_divide_dev(const u64* a, size_t na, const u64* b, size_t nb, u64* out,
     if (e != hipSuccess) return hip_fail(e, "hipMallocAsync(clean_divide)", __FILE__, __LINE__);
     u64* div = tmp + batch * half;
     int* flag = reinterpret_cast<int*>(tmp + (batch + 1) * half);
-    const u64 X[3] = {0, gl::ONE, 0};                                 // XFieldElement::from([0, 1, 0]) :2383
-    const u64 Xinv[3] = {gl::ONE, 0, gl::neg(gl::ONE)};               // x (x^2 - 1) = -1  ->  x^-1 = 1 - x^2
+    // The division coset is X * <w_order> with X = x, the reference's choice (:2383).  A divisor with a root ON that coset (e.g.
+    // x^3 - x + 1 itself, which the reference only meets on its naive route below degree 512) makes the pointwise division
+    // impossible there: the blocking call then repeats the division once on the coset (x + 1) * <w_order> -- a clean quotient is
+    // the same polynomial on any coset -- before it reports TF_ERR_INVERSE_OF_ZERO.
+    for (int attempt = 0; attempt < 2; ++attempt) {
+    u64 X[3] = {0, gl::ONE, 0};                                       // XFieldElement::from([0, 1, 0]) :2383
+    u64 Xinv[3] = {gl::ONE, 0, gl::neg(gl::ONE)};                     // x (x^2 - 1) = -1  ->  x^-1 = 1 - x^2
+    if (attempt == 1) {
+        X[0] = gl::ONE;                                               // x + 1
+        if (!xfe_inverse_host(X, Xinv)) { rc = TF_ERR_INVERSE_OF_ZERO; break; }
+        rc = TF_OK;
+    }
     const unsigned blocks = (unsigned)((order + 255) / 256);
     e = hipMemsetAsync(flag, 0, sizeof(int), s);
     if (e != hipSuccess) rc = hip_fail(e, "hipMemsetAsync", __FILE__, __LINE__);
@@ -2812,6 +2855,8 @@ int clean_divide_dev(const u64* a, size_t na, const u64* b, size_t nb, u64* out,
         if (e != hipSuccess) rc = hip_fail(e, "clean_divide: flag", __FILE__, __LINE__);
         else if (host_flag & 1) rc = TF_ERR_INVERSE_OF_ZERO;     // a zero of the divisor on the coset: batch_inversion panics
         else if (host_flag & 2) rc = TF_ERR_DIVISION_NOT_CLEAN;  // unlift().unwrap() :2410
+    }
+    if (rc != TF_ERR_INVERSE_OF_ZERO || d_status) break;         // (the asynchronous variant cannot look at the flag: one coset)
     }
     hipError_t e2 = hipFreeAsync(tmp, s);
     if (rc) return rc;
@@ -3000,6 +3045,13 @@ const char* tf_status_string(int status) {
 
 const char* tf_last_error(void) { return t_last_error.c_str(); }
 int tf_version(void) { return 1000; }
+
+int tf_release_caches(void) {
+    DeviceCtx* ctx = nullptr;
+    const int rc = current_ctx(&ctx);
+    if (rc) return rc;
+    return release_caches(ctx);
+}
 
 int tf_device_count(void) {
     int count = 0;
