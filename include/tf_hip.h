@@ -350,6 +350,10 @@ void tf_set_ntt_small_launch(int mode);
  * workgroups sharing their input) instead of three; -1 = automatic (default; TF_NTT_NO_PRE2 in the environment
  * disables), 0 = never, 1 = whenever the shape supports it.  Same words either way. */
 void tf_set_ntt_two_pass(int mode);
+/* Test / A-B hook: calls of 64 .. 4096-point transforms with little work (<= 2^18 words) take the latency-shaped kernel (8
+ * elements per thread, radix-8 stages through LDS) instead of the 32-elements-per-thread pass kernels; -1 =
+ * automatic (default; TF_NTT_NO_LAT disables), 0 = never, 1 = whenever the shape allows.  Same words either way. */
+void tf_set_ntt_latency_kernel(int mode);
 int tf_ntt_launch_count(size_t n, size_t batch, int width);
 /* Planner introspection (no device needed): number of global passes of one n-point transform (0 for lengths ntt rejects)
  * and log2 of each pass's radix in log2_radix_out[0..3] (unused entries 0).  The radices multiply to n. */

@@ -761,3 +761,35 @@ def test_tip5_trace_matches_oracle(tf, oracle, count):
     assert np.array_equal(dt.cpu().numpy().view(np.uint64).reshape(count, 6, 16), trace)
     with pytest.raises(ValueError):
         tf.device.tip5_trace_(ds, dt[:-1])
+
+
+@pytest.mark.parametrize("width", [1, 3])
+@pytest.mark.parametrize("log_n", [6, 7, 8, 9, 10, 11, 12])
+def test_latency_shaped_transform_matches_oracle(tf, oracle, log_n, width):
+    """The 8-elements-per-thread kernel for calls with little work (ntt_lat_kernel, tf_set_ntt_latency_kernel): forced on and
+    off, forward / inverse / zero-padded coset evaluation input / ragged batch, word for word against the oracle's radix-2
+    sweeps (math/ntt.rs:153-228) and against the pass kernels."""
+    n = 1 << log_n
+    lib = tf._lib.lib()
+    batch = 5
+    x = oracle.fill_random(batch * n * width, 3000 + log_n + width)
+    want = oracle.ntt(x, width=width, batch=batch, threads=4)
+    got = {}
+    try:
+        for mode in (1, 0):
+            lib.tf_set_ntt_latency_kernel(mode)
+            y = x.copy()
+            tf.ntt(y, width=width, batch=batch)
+            assert np.array_equal(y, want), (mode, "forward")
+            tf.intt(y, width=width, batch=batch)
+            assert np.array_equal(y, x), (mode, "inverse")
+            # fast_multiply of n / 2 by n / 2 - 3 coefficients: zero-padded forward transforms of order n, product, inverse
+            a, b = x[: (n // 2) * width], x[n * width: n * width + (n // 2 - 3) * width]
+            got[mode] = tf.fast_multiply(a, b, width=width)
+            off = oracle.bfe_new(7)
+            ev = tf.fast_coset_evaluate(a, off, n, width=width)
+            assert np.array_equal(ev, oracle.coset_evaluate(a, off, n, width=width)), (mode, "coset")
+    finally:
+        lib.tf_set_ntt_latency_kernel(-1)
+    assert np.array_equal(got[0], got[1])
+    assert np.array_equal(got[1], oracle.poly_mul(x[: (n // 2) * width], x[n * width: n * width + (n // 2 - 3) * width], width=width))

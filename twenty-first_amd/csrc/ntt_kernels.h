@@ -32,6 +32,7 @@
 //                      level; R1024: constant P2) are the two kernels of the 2^20-point headline transform
 //   ntt_block_kernel   2^11 <= n <= 2^14, BFE one workgroup owns a whole transform: radix 32 x 32 x P3 with two LDS
 //                      exchanges, so these lengths cost one HBM pass instead of two
+//   ntt_lat_kernel     64 <= n <= 4096, calls with little work: 8 elements per thread, radix-8 Stockham stages through LDS
 #pragma once
 
 #include "gl64.h"
@@ -1094,6 +1095,146 @@ __global__ void __launch_bounds__(512, 4) ntt_rows32_kernel(const NttRows32Args 
             }
             dst[w] = lds[(lt - h * half_lt) * 33 + e];
         }
+    }
+}
+
+// ---- 64 <= n <= 4096, LITTLE work per call: the latency-shaped transform -----------------------------------------------
+// The pass kernels above give a thread 32 elements: one thread's program is ~3 500 dependent-ish instructions, 15-25 us however
+// few transforms a call holds (a tree walk over 2^12 points, one slice of a caller that transforms one polynomial at a time).
+// When a call cannot fill the chip anyway this kernel spends threads instead: EIGHT elements per thread, n / 8 threads per
+// transform, Stockham autosort stages of radix 8 (shift-only networks, as everywhere: w_8 = 2^24) joined through LDS, one
+// general twiddle per element and stage from a table w_n^e -- three or four short steps instead of one long one.
+//   stage (radix R, Ns = product of the radices before it), butterfly unit u < n / R:   k = u mod Ns,
+//     v[r] = in[u + r n / R] w_{Ns R}^(k r),   V = DFT_R(v),   out[(u / Ns) Ns R + k + r Ns] = V[r]
+// (natural order in and out, no bit reversal).  The last stage has radix 8, 4 or 2 (8 / R units per thread).
+// XFieldElement slices are three limb transforms of element stride 3 (ntt.rs:203-207).
+struct NttLatArgs {
+    const u64* in;
+    u64* out;
+    const u64* in2;        // or null: second operand laid out like `in`, multiplied in on load (L = 1 only)
+    const u64* tw;         // [2][n]: w_n^(+-e), then n^-1 w_n^(+-e) (the inverse's last stage)
+    long long n_coeffs;    // < 0: none; else elements >= n_coeffs read as zero
+    long long in_bs, out_bs;  // words between consecutive slices
+    long long total;       // limb transforms = batch * L
+    u64 ninv;              // Montgomery n^-1 (inverse only)
+    int L;
+};
+__host__ __device__ __forceinline__ constexpr int lat_pad(int i) { return i + (i >> 3); }
+template <int LOGR>
+__device__ __forceinline__ constexpr int lat_brev(int r) {
+    int o = 0;
+    for (int b = 0; b < LOGR; ++b) o |= ((r >> b) & 1) << (LOGR - 1 - b);
+    return o;
+}
+template <bool INV, int LOGR>
+__device__ __forceinline__ void lat_dft(u64 (&x)[32]) {  // 8 >> LOGR independent DFTs of 2^LOGR points on slots 0 .. 7 (bit-reversed in, natural out)
+    DitRange<INV, 1, 0, 4, false>::run(x);
+    if constexpr (LOGR >= 2) DitRange<INV, 2, 0, 4, false>::run(x);
+    if constexpr (LOGR >= 3) DitRange<INV, 3, 0, 4, false>::run(x);
+}
+
+template <int LOGN, bool INV>
+__global__ void __launch_bounds__(LOGN == 12 ? 512 : 256) ntt_lat_kernel(const NttLatArgs A) {
+    constexpr int N = 1 << LOGN, TPT = N / 8, WG = LOGN == 12 ? 512 : 256, T = WG / TPT;
+    constexpr int S = (LOGN + 2) / 3;                 // stages; the first S - 1 have radix 8
+    constexpr int LOGRL = LOGN - 3 * (S - 1);         // log2 of the last radix (1 .. 3)
+    constexpr int BUF = lat_pad(N * T) + 8;
+    extern __shared__ __attribute__((aligned(16))) u64 lds[];  // two buffers of BUF words
+    const int t = threadIdx.x, tr = t / TPT, j = t - tr * TPT;
+    const long long gtr = (long long)blockIdx.x * T + tr;
+    const bool act = gtr < A.total;
+    const int L = A.L;
+    const long long b = act ? gtr / L : 0;
+    const int limb = act ? (int)(gtr - b * L) : 0;
+    const u64* src = A.in + b * A.in_bs + limb;
+    u64* dst = A.out + b * A.out_bs + limb;
+    u64 x[32];
+#pragma unroll
+    for (int q = 0; q < 32; ++q) x[q] = 0;
+    // the general twiddles of every stage after the first, requested before anything else: w_{Ns R}^(k r) = w_n^(k r n / (Ns R))
+    u64 tw[S > 1 ? S - 1 : 1][8];
+    {
+        int Ns = 8;
+#pragma unroll
+        for (int s = 1; s < S; ++s) {
+            const int logr = s + 1 < S ? 3 : LOGRL, R = 1 << logr, U = 8 >> logr;
+            const bool last = s + 1 == S;
+#pragma unroll
+            for (int a = 0; a < U; ++a) {
+                const int u = j + a * TPT, k = u & (Ns - 1);
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const int e = k * r * (N / (Ns * R));
+                    tw[s - 1][a * R + r] = (r == 0) ? 0 : A.tw[((INV && last) ? N : 0) + e];
+                }
+            }
+            Ns *= R;
+        }
+    }
+    // ---- stage 1: from global memory, no twiddles
+    if (act) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int idx = j + r * TPT;
+            u64 v = 0;
+            if (A.n_coeffs < 0 || idx < A.n_coeffs) {
+                v = src[(long long)idx * L];
+                if (A.in2) v = gl::mont_mul(v, (A.in2 + b * A.in_bs + limb)[(long long)idx * L]);
+            }
+            x[lat_brev<3>(r)] = v;
+        }
+    }
+    lat_dft<INV, 3>(x);
+    u64* bufs[2] = {lds + 0, lds + BUF};
+    {
+        u64* o = bufs[0] + 0;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) o[lat_pad(tr * N + j * 8 + r)] = x[r];
+    }
+    __syncthreads();
+    int Ns = 8;
+#pragma unroll
+    for (int s = 1; s < S; ++s) {
+        const bool last = s + 1 == S;
+        const int logr = last ? LOGRL : 3, R = 1 << logr, U = 8 >> logr;
+        const u64* in = bufs[(s - 1) & 1];
+        u64* o = bufs[s & 1];
+        u64 v[8];
+#pragma unroll
+        for (int a = 0; a < U; ++a) {
+            const int u = j + a * TPT;
+#pragma unroll
+            for (int r = 0; r < R; ++r) v[a * R + r] = in[lat_pad(tr * N + u + r * (N / R))];
+        }
+#pragma unroll
+        for (int a = 0; a < U; ++a) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                u64 w = v[a * R + r];
+                if (r) w = gl::mont_mul(w, tw[s - 1][a * R + r]);
+                else if (INV && last) w = gl::mont_mul(w, A.ninv);
+                const int slot = a * R + (logr == 3 ? lat_brev<3>(r) : (logr == 2 ? lat_brev<2>(r) : r));
+                x[slot] = w;
+            }
+        }
+        if (logr == 3) lat_dft<INV, 3>(x);
+        else if (logr == 2) lat_dft<INV, 2>(x);
+        else lat_dft<INV, 1>(x);
+#pragma unroll
+        for (int a = 0; a < U; ++a) {
+            const int u = j + a * TPT, k = u & (Ns - 1), j0 = (u - k) * R + k;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int idx = j0 + r * Ns;
+                if (last) {
+                    if (act) dst[(long long)idx * L] = x[a * R + r];
+                } else {
+                    o[lat_pad(tr * N + idx)] = x[a * R + r];
+                }
+            }
+        }
+        if (!last) __syncthreads();
+        Ns *= R;
     }
 }
 

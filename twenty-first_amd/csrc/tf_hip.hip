@@ -307,7 +307,7 @@ void split_powers(u64 base, int log_total, int* h_out, std::vector<u64>* hi, std
     *h_out = h;
 }
 
-enum : u64 { TAG_INNER = 1, TAG_POST = 2, TAG_TINY = 3, TAG_BLOCK1 = 4, TAG_BLOCK2 = 5 };
+enum : u64 { TAG_INNER = 1, TAG_POST = 2, TAG_TINY = 3, TAG_BLOCK1 = 4, TAG_BLOCK2 = 5, TAG_LAT = 6 };
 u64 make_key(u64 tag, u64 a, u64 b, u64 c, u64 d) { return (tag << 56) | (a << 40) | (b << 24) | (c << 8) | d; }
 
 // inner[g*32 + k1] = w_R^(+-g*k1) * (scale_log_n ? n^-1 : 1),  R = 32 << p2
@@ -1088,6 +1088,108 @@ int launch_block(DeviceCtx* ctx, const u64* in, u64* out, long long in_bs, long 
     }
 }
 
+// ---- the latency-shaped transform (ntt_lat_kernel): calls with little work, 64 <= n <= 4096
+// t[e] = w_n^(+-e), e < n, then n^-1 t[e]
+int get_lat_table(DeviceCtx* ctx, int log_n, bool inverse, const u64** out) {
+    const u64 key = make_key(TAG_LAT, log_n, inverse, 0, 0);
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    auto it = ctx->tables.find(key);
+    if (it != ctx->tables.end()) {
+        *out = it->second;
+        return TF_OK;
+    }
+    const size_t n = size_t(1) << log_n;
+    u64 w = root_of_unity_mont(log_n);
+    if (inverse) w = gl::mont_inverse(w);
+    const u64 ninv = gl::mont_inverse(gl::to_mont(u64(n)));
+    std::vector<u64> t(2 * n);
+    u64 acc = gl::ONE;
+    for (size_t e = 0; e < n; ++e) {
+        t[e] = acc;
+        t[n + e] = gl::mont_mul(acc, ninv);
+        acc = gl::mont_mul(acc, w);
+    }
+    u64* d = nullptr;
+    int rc = upload_table(t, &d);
+    if (rc) return rc;
+    ctx->tables[key] = d;
+    *out = d;
+    return TF_OK;
+}
+
+template <int LOGN, bool INV>
+int launch_lat_t(const tfk::NttLatArgs& a, hipStream_t stream) {
+    constexpr int N = 1 << LOGN, WG = LOGN == 12 ? 512 : 256, T = WG / (N / 8);
+    constexpr size_t lds = size_t(2) * (tfk::lat_pad(N * T) + 8) * sizeof(u64);
+    if constexpr (lds > 48 * 1024) {
+        static std::atomic<unsigned long long> done_mask{0};
+        int dev = 0;
+        HIPCHK(hipGetDevice(&dev));
+        const unsigned long long bit = 1ull << (dev & 63);
+        if (!(done_mask.load(std::memory_order_acquire) & bit)) {
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&tfk::ntt_lat_kernel<LOGN, INV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            done_mask.fetch_or(bit, std::memory_order_release);
+        }
+    }
+    const long long blocks = (a.total + T - 1) / T;
+    hipLaunchKernelGGL((tfk::ntt_lat_kernel<LOGN, INV>), dim3((unsigned)blocks), dim3(WG), lds, stream, a);
+    HIPCHK(hipGetLastError());
+    return TF_OK;
+}
+template <bool INV>
+int launch_lat_dir(int log_n, const tfk::NttLatArgs& a, hipStream_t s) {
+    switch (log_n) {
+        case 6: return launch_lat_t<6, INV>(a, s);
+        case 7: return launch_lat_t<7, INV>(a, s);
+        case 8: return launch_lat_t<8, INV>(a, s);
+        case 9: return launch_lat_t<9, INV>(a, s);
+        case 10: return launch_lat_t<10, INV>(a, s);
+        case 11: return launch_lat_t<11, INV>(a, s);
+        case 12: return launch_lat_t<12, INV>(a, s);
+    }
+    return TF_ERR_HIP;
+}
+// When: the call holds too little work to fill the chip with 32-element threads (measured crossover, tools/lat_sweep.py).
+std::atomic<int> g_lat_mode{-1};  // tf_set_ntt_latency_kernel: -1 automatic (TF_NTT_NO_LAT disables), 0 never, 1 whenever the shape allows
+bool lat_wanted(int log_n, size_t batch, int L) {
+    static const bool off = getenv("TF_NTT_NO_LAT") != nullptr;  // A/B switch
+    // measured crossover against the pass / block kernels (tools/lat_sweep.py, profiles/r03_lat_sweep_*.txt): 2.0 - 2.9 x faster up
+    // to 2^20 words per call, level at 2^22 words (BFieldElement) / 1.5 x 2^20 words (XFieldElement: its loads step 24 bytes)
+    static const long long env_limit = [] {
+        const char* e = getenv("TF_NTT_LAT_MAX_WORDS");
+        return e ? atoll(e) : 0ll;
+    }();
+    const long long limit = env_limit ? env_limit : (L == 1 ? (1ll << 22) : (3ll << 19));
+    const int mode = g_lat_mode.load(std::memory_order_relaxed);
+    if (mode == 0 || (mode < 0 && off)) return false;
+    if (log_n < 6 || log_n > 12) return false;
+    if (mode == 1) return true;
+    return (long long)(batch * size_t(L)) << log_n <= limit;
+}
+int launch_lat(DeviceCtx* ctx, const u64* in, u64* out, long long in_bs, long long out_bs, int log_n, size_t batch, int L, bool inverse,
+               long long n_coeffs, const u64* in2, hipStream_t stream) {
+    const u64* tw = nullptr;
+    int rc = get_lat_table(ctx, log_n, inverse, &tw);
+    if (rc) return rc;
+    const size_t max_batch = size_t(1) << 22;  // 2^31 threads per launch at most
+    for (size_t b0 = 0; b0 < batch && !rc; b0 += max_batch) {
+        const size_t nb = std::min(max_batch, batch - b0);
+        tfk::NttLatArgs a{};
+        a.in = in + (long long)b0 * in_bs;
+        a.out = out + (long long)b0 * out_bs;
+        a.in2 = in2 ? in2 + (long long)b0 * in_bs : nullptr;
+        a.tw = tw;
+        a.n_coeffs = n_coeffs;
+        a.in_bs = in_bs;
+        a.out_bs = out_bs;
+        a.total = (long long)nb * L;
+        a.ninv = inverse ? gl::mont_inverse(gl::to_mont(u64(1) << log_n)) : 0;
+        a.L = L;
+        rc = inverse ? launch_lat_dir<true>(log_n, a, stream) : launch_lat_dir<false>(log_n, a, stream);
+    }
+    return rc;
+}
+
 std::atomic<int> g_min_passes{0};  // tf_set_ntt_min_passes
 
 // Experiment switches for tools/split3.py: looked up on every call only when TF_NTT_EXPERIMENT is set at load time
@@ -1219,6 +1321,9 @@ int run_ntt(DeviceCtx* ctx, const u64* in, u64* out, long long in_bs, long long 
         static const bool no_rows32 = getenv("TF_NTT_NO_ROWS32") != nullptr;  // A/B switch
         if (!no_rows32) return launch_rows32(in, out, batch, L, inverse, stream);
     }
+    if (!pre_scale && !post_scale && n_out < 0 && cosets == 1 && (!in2 || L == 1) && g_min_passes.load(std::memory_order_relaxed) == 0 &&
+        lat_wanted(log_n, batch, L))
+        return launch_lat(ctx, in, out, in_bs, out_bs, log_n, batch, L, inverse, n_coeffs, in2, stream);
     if (log_n <= 10) {
         const u64* inner = nullptr;
         rc = get_inner_table(ctx, log_n, inverse, inverse ? log_n : 0, &inner);
@@ -2633,6 +2738,15 @@ int tree_handle_batch_evaluate(const TreeHandle* H, const u64* d_coeffs, size_t 
     const int L = H->L;
     if (H->pt.T.h == 0 || n_coeffs < 2)  // a single leaf (or a constant): Horner on the handle's copy of the domain
         return batch_evaluate_horner(d_coeffs, n_coeffs, n_coeffs * L, batch, H->points, n, d_out, L, stream);
+    {
+        // the guards tree_route applies to the one-shot call: the walk indexes its arrays per unit (<= 65 536) and brings
+        // 2 units M words of padded coefficients and values plus the slab's work space -- a batch beyond that takes Horner
+        const size_t M = (size_t)H->pt.T.M, units = batch * ((n_coeffs + M - 1) / M);
+        const size_t slab = std::max<size_t>(1, std::min<size_t>(units, (size_t(1) << 25) / M));
+        const size_t words = (2 * units + (size_t)kTreeWorkArrays * slab) * M * (size_t)L;
+        if (units > 65536 || words * sizeof(u64) > (size_t(64) << 30))
+            return batch_evaluate_horner(d_coeffs, n_coeffs, n_coeffs * L, batch, H->points, n, d_out, L, stream);
+    }
     hipStream_t s = static_cast<hipStream_t>(stream);
     return L == 1 ? tree_batch_evaluate<1>(ctx, H->pt.T, H->points, n, d_coeffs, n_coeffs, n_coeffs, batch, d_out, s)
                   : tree_batch_evaluate<3>(ctx, H->pt.T, H->points, n, d_coeffs, n_coeffs, 3 * n_coeffs, batch, d_out, s);
@@ -3129,6 +3243,7 @@ int tf_debug_stamps(unsigned long long* host_out, size_t words) {
 }
 
 void tf_set_ntt_min_passes(int passes) { g_min_passes.store(passes, std::memory_order_relaxed); }
+void tf_set_ntt_latency_kernel(int mode) { g_lat_mode.store(mode < 0 ? -1 : (mode ? 1 : 0), std::memory_order_relaxed); }
 void tf_set_ntt_two_pass(int mode) { g_pre2_mode.store(mode < 0 ? -1 : (mode ? 1 : 0), std::memory_order_relaxed); }
 void tf_set_ntt_small_launch(int mode) { g_small_launch_mode.store(mode < 0 ? -1 : (mode ? 1 : 0), std::memory_order_relaxed); }
 // The plan of one transform: number of global passes and log2 of each pass's radix (planner introspection for the CPU tests).
