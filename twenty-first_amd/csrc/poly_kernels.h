@@ -48,29 +48,48 @@ __device__ __forceinline__ void fe_store(u64* p, const u64 (&r)[L]) {
 constexpr int kLeafMax = 1024;  // threads per leaf workgroup = points per leaf
 template <int L>
 __global__ void __launch_bounds__(kLeafMax) leaf_zerofier_kernel(const u64* points, long long n_points, int d, u64* tails, u64* inv) {
-    extern __shared__ u64 leaf_lds[];  // 2 * d * L words (dynamic: a small leaf leaves the LDS to more workgroups)
+    extern __shared__ u64 leaf_lds[];  // 3 * d * L words (dynamic: a small leaf leaves the LDS to more workgroups)
     u64* c = leaf_lds;                 // coefficients 0 .. d - 1 of the running product (the leading 1 leaves the array at the last point)
-    u64* acc = leaf_lds + d * L;       // partial sums of the series inversion
+    u64* acc = leaf_lds + d * L;       // second product buffer, then the partial sums of the series inversion
+    u64* pts = leaf_lds + 2 * d * L;   // the leaf's points
     const int t = threadIdx.x;
     const long long leaf = blockIdx.x;
-    // product: c = 1; for every point p: c_new[j] = c[j - 1] - p * c[j]
+    // product: c = 1; for every point p: c_new[j] = c[j - 1] - p * c[j].  The points are staged once and the product alternates
+    // between two buffers: one barrier and no global load per step (a step is on the critical path d times).
+    {
+        const long long pi = leaf * d + t;
 #pragma unroll
-    for (int k = 0; k < L; ++k) c[t * L + k] = (t == 0 && k == 0) ? gl::ONE : 0;
+        for (int k = 0; k < L; ++k) {
+            c[t * L + k] = (t == 0 && k == 0) ? gl::ONE : 0;
+            pts[t * L + k] = pi < n_points ? points[pi * L + k] : 0;
+        }
+    }
     __syncthreads();
-    for (int i = 0; i < d; ++i) {
-        const long long pi = leaf * d + i;
-        u64 p[L], cur[L], prev[L];
+    {
+        u64* from = c;
+        u64* to = acc;
+        for (int i = 0; i < d; ++i) {
+            u64 p[L], cur[L], prev[L];
+            fe_load<L>(&pts[i * L], p);
+            fe_load<L>(&from[t * L], cur);
 #pragma unroll
-        for (int k = 0; k < L; ++k) p[k] = pi < n_points ? points[pi * L + k] : 0;
-        fe_load<L>(&c[t * L], cur);
-#pragma unroll
-        for (int k = 0; k < L; ++k) prev[k] = t > 0 ? c[(t - 1) * L + k] : 0;
-        __syncthreads();
-        u64 pc[L], nv[L];
-        fe_mul<L>(p, cur, pc);
-        fe_sub<L>(prev, pc, nv);
-        fe_store<L>(&c[t * L], nv);
-        __syncthreads();
+            for (int k = 0; k < L; ++k) prev[k] = t > 0 ? from[(t - 1) * L + k] : 0;
+            u64 pc[L], nv[L];
+            fe_mul<L>(p, cur, pc);
+            fe_sub<L>(prev, pc, nv);
+            fe_store<L>(&to[t * L], nv);
+            __syncthreads();
+            u64* sw = from;
+            from = to;
+            to = sw;
+        }
+        if (from != c) {  // d odd: the product ended in the second buffer
+            u64 v[L];
+            fe_load<L>(&from[t * L], v);
+            __syncthreads();
+            fe_store<L>(&c[t * L], v);
+            __syncthreads();
+        }
     }
     // the product is monic of degree d: c holds its tail
     {
@@ -253,6 +272,37 @@ __global__ void __launch_bounds__(kLeafMax) leaf_evaluate_kernel(const u64* rem,
     if (pi >= n_points) return;
     u64 x[L], a[L];
     fe_load<L>(points + pi * L, x);
+    if ((d & 3) == 0) {
+        // r(x) = sum_{s < 4} x^s R_s(x^4): four independent Horner chains in x^4 (a single chain is d dependent products, the whole
+        // latency of this kernel), recombined with three more products
+        u64 x2[L], x4[L], acc4[4][L];
+        fe_mul<L>(x, x, x2);
+        fe_mul<L>(x2, x2, x4);
+#pragma unroll
+        for (int c4 = 0; c4 < 4; ++c4)
+#pragma unroll
+            for (int k = 0; k < L; ++k) acc4[c4][k] = 0;
+        for (int j = d - 4; j >= 0; j -= 4) {
+#pragma unroll
+            for (int c4 = 0; c4 < 4; ++c4) {
+                u64 m[L], cj[L], r[L];
+                fe_mul<L>(acc4[c4], x4, m);
+                fe_load<L>(&c[(j + c4) * L], cj);
+                fe_add<L>(m, cj, r);
+#pragma unroll
+                for (int k = 0; k < L; ++k) acc4[c4][k] = r[k];
+            }
+        }
+        u64 t3[L], t2[L], t1[L], u3[L], u2[L];
+        fe_mul<L>(acc4[3], x, t3);          // ((R3 x + R2) x + R1) x + R0
+        fe_add<L>(t3, acc4[2], u3);
+        fe_mul<L>(u3, x, t2);
+        fe_add<L>(t2, acc4[1], u2);
+        fe_mul<L>(u2, x, t1);
+        fe_add<L>(t1, acc4[0], a);
+        fe_store<L>(vals + (leaf * d + t) * L, a);
+        return;
+    }
 #pragma unroll
     for (int k = 0; k < L; ++k) a[k] = 0;
     for (int j = d - 1; j >= 0; --j) {
@@ -410,25 +460,31 @@ __global__ void __launch_bounds__(256) interpolation_targets_kernel(const u64* v
 template <int L>
 __global__ void __launch_bounds__(kLeafMax) leaf_interpolant_kernel(const u64* points, const u64* targets, long long n_points, int d,
                                                                     long long M, u64* N) {
-    extern __shared__ u64 leaf_lds[];  // 2 * d * L words
-    u64* c = leaf_lds;                 // Z, coefficients 0 .. d - 1 (its leading 1 is still inside while it is needed)
-    u64* nn = leaf_lds + d * L;        // N
+    extern __shared__ u64 leaf_lds[];  // 6 * d * L words: Z and N twice (the step alternates between the copies), points, targets
     const int t = threadIdx.x;
     const long long leaf = blockIdx.x, row = blockIdx.y;
-#pragma unroll
-    for (int k = 0; k < L; ++k) {
-        c[t * L + k] = (t == 0 && k == 0) ? gl::ONE : 0;
-        nn[t * L + k] = 0;
-    }
-    __syncthreads();
-    for (int i = 0; i < d; ++i) {
-        const long long pi = leaf * d + i;
-        u64 p[L], w[L], cur[L], prev[L], ncur[L], nprev[L];
+    u64* zb[2] = {leaf_lds, leaf_lds + 2 * d * L};          // Z, coefficients 0 .. d - 1 (its leading 1 is still inside while it is needed)
+    u64* nb[2] = {leaf_lds + d * L, leaf_lds + 3 * d * L};  // N
+    u64* pts = leaf_lds + 4 * d * L;
+    u64* tgt = leaf_lds + 5 * d * L;
+    {
+        const long long pi = leaf * d + t;
 #pragma unroll
         for (int k = 0; k < L; ++k) {
-            p[k] = pi < n_points ? points[pi * L + k] : 0;
-            w[k] = pi < n_points ? targets[(row * M + pi) * L + k] : 0;
+            zb[0][t * L + k] = (t == 0 && k == 0) ? gl::ONE : 0;
+            nb[0][t * L + k] = 0;
+            pts[t * L + k] = pi < n_points ? points[pi * L + k] : 0;
+            tgt[t * L + k] = pi < n_points ? targets[(row * M + pi) * L + k] : 0;
         }
+    }
+    __syncthreads();
+    int cur_buf = 0;
+    for (int i = 0; i < d; ++i) {  // one barrier and no global load per step: the d steps are the kernel's whole latency
+        const u64* c = zb[cur_buf];
+        const u64* nn = nb[cur_buf];
+        u64 p[L], w[L], cur[L], prev[L], ncur[L], nprev[L];
+        fe_load<L>(&pts[i * L], p);
+        fe_load<L>(&tgt[i * L], w);
         fe_load<L>(&c[t * L], cur);
         fe_load<L>(&nn[t * L], ncur);
 #pragma unroll
@@ -436,7 +492,6 @@ __global__ void __launch_bounds__(kLeafMax) leaf_interpolant_kernel(const u64* p
             prev[k] = t > 0 ? c[(t - 1) * L + k] : 0;
             nprev[k] = t > 0 ? nn[(t - 1) * L + k] : 0;
         }
-        __syncthreads();
         u64 pc[L], pn[L], wz[L], a[L], b[L], zc[L];
         fe_mul<L>(p, cur, pc);
         fe_mul<L>(p, ncur, pn);
@@ -444,12 +499,13 @@ __global__ void __launch_bounds__(kLeafMax) leaf_interpolant_kernel(const u64* p
         fe_sub<L>(nprev, pn, a);
         fe_add<L>(a, wz, b);
         fe_sub<L>(prev, pc, zc);
-        fe_store<L>(&nn[t * L], b);
-        fe_store<L>(&c[t * L], zc);
+        fe_store<L>(&nb[cur_buf ^ 1][t * L], b);
+        fe_store<L>(&zb[cur_buf ^ 1][t * L], zc);
         __syncthreads();
+        cur_buf ^= 1;
     }
     u64 v[L];
-    fe_load<L>(&nn[t * L], v);
+    fe_load<L>(&nb[cur_buf][t * L], v);
     fe_store<L>(N + (row * M + leaf * d + t) * L, v);
 }
 

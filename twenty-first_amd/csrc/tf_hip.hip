@@ -2145,8 +2145,23 @@ inline int tree_leaf_log(int L) {  // TF_TREE_LEAF_LOG = 6..10 overrides both fi
     return forced ? forced : (L == 1 ? 8 : 7);
 }
 inline int tree_leaf(int L) { return 1 << tree_leaf_log(L); }
+// Trees that are also walked UPWARDS (interpolation; the padded trees behind zerofier / interpolate / the ZerofierTree handle) are
+// built down to 64-point leaves: the interpolant of a leaf is d sequential steps of ~0.4 us each (leaf_interpolant_kernel), 102 us
+// for 256 points, while a level costs ~15 us since the latency-shaped transform -- prepared-tree interpolation of 2^12 points
+// 176 -> 122 us, 2^16 434 -> 383, XFieldElement 2^12 358 -> 234 (tools/tree_latency.py, profiles/r03_tree_latency_leaf.txt).
+// Evaluations on such a tree stop their walk at the level whose nodes have tree_leaf(L) points (Horner is parallel over the
+// points: the bigger leaf is the faster one there).  TF_TREE_INTERP_LEAF_LOG = 6..10 overrides.
+inline int tree_interp_leaf(int L) {
+    static const int forced = [] {
+        const char* e = getenv("TF_TREE_INTERP_LEAF_LOG");
+        const int v = e ? atoi(e) : 0;
+        return (v >= 6 && v <= 10) ? v : 0;
+    }();
+    return 1 << std::min(forced ? forced : 6, tree_leaf_log(L));
+}
 
 struct ZerofierTree {
+    int leaf = 0;              // points per leaf (tree_leaf(L) for a tree that is only evaluated on, tree_interp_leaf(L) otherwise)
     int h = 0;                 // levels 0 .. h-1 hold zerofiers of degree leaf << level (the root, level h, is never needed)
     long long M = 0;           // padded point count = leaf << h
     std::vector<u64*> tails;   // [level]: (M / d) nodes x d elements
@@ -2192,8 +2207,10 @@ int zerofier_tree_build(DeviceCtx* ctx, const u64* points, long long n_points, Z
         T->Ghat[l] = base + 4 * M * L;
     }
     if (h == 0) return TF_OK;
-    const int kTreeLeaf = tree_leaf(L);
-    hipLaunchKernelGGL(tfk::leaf_zerofier_kernel<L>, dim3((unsigned)(M / kTreeLeaf)), dim3(kTreeLeaf), 2 * kTreeLeaf * L * sizeof(u64), s, points,
+    const int kTreeLeaf = T->leaf;
+    if (3 * kTreeLeaf * L * sizeof(u64) > 48 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tfk::leaf_zerofier_kernel<L>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(3 * kTreeLeaf * L * sizeof(u64)));
+    hipLaunchKernelGGL(tfk::leaf_zerofier_kernel<L>, dim3((unsigned)(M / kTreeLeaf)), dim3(kTreeLeaf), 3 * kTreeLeaf * L * sizeof(u64), s, points,
                        n_points, kTreeLeaf, T->tails[0], T->inv[0]);
     HIPCHK(hipGetLastError());
     for (int l = 0; l < h; ++l) {
@@ -2237,8 +2254,12 @@ int inverse_of_cached_product(DeviceCtx* ctx, const u64* a_hat, const u64* b_hat
 template <int L>
 int zerofier_tree_evaluate(DeviceCtx* ctx, const ZerofierTree& T, const u64* F, const u64* points, long long n_points, u64* vals, u64* work,
                            hipStream_t s, long long U = 1) {
-    const int kTreeLeaf = tree_leaf(L);
+    const int kTreeLeaf = T.leaf;
     const long long M = T.M, UM = U * M;
+    // the walk stops at the level whose nodes hold tree_leaf(L) points (a tree built for interpolation has smaller leaves)
+    int l_stop = 0;
+    while ((kTreeLeaf << l_stop) < tree_leaf(L) && l_stop < T.h) ++l_stop;
+    const int eval_leaf = kTreeLeaf << l_stop;
     const u64* cur = F;  // remainders of the level above: U x (M / 2d) polynomials of 2d coefficients
     u64* ping = work;                // U M
     u64* pong = work + UM * L;       // U M
@@ -2246,7 +2267,7 @@ int zerofier_tree_evaluate(DeviceCtx* ctx, const ZerofierTree& T, const u64* F, 
     u64* Fh = work + 3 * UM * L;     // U x children x 2d     their transforms
     u64* prod = work + 5 * UM * L;   // U x children x 2d     products back in the coefficient domain
     u64* frq = work + 7 * UM * L;    // U x children x d      the next level's reversed upper halves, written by this level's last kernel
-    for (int l = T.h - 1; l >= 0; --l) {
+    for (int l = T.h - 1; l >= l_stop; --l) {
         const long long d = (long long)kTreeLeaf << l, children = M / d, all = U * children;  // (children is even: global child / 2 = global parent)
         // rev(q) = rev(f_high) g mod x^d   (below the top level the reversed upper halves come from the level above's last kernel)
         int rc = TF_OK;
@@ -2263,12 +2284,12 @@ int zerofier_tree_evaluate(DeviceCtx* ctx, const ZerofierTree& T, const u64* F, 
         if (!rc) rc = inverse_of_cached_product<L>(ctx, Fh, T.That[l], prod, (size_t)(2 * d), (size_t)children, U, s);
         if (rc) return rc;
         u64* nxt = (cur == ping) ? pong : ping;
-        rc = launch_1d<L>(tfk::remainder_finish_kernel<L>, all * d, s, cur, (const u64*)prod, 2 * d, nxt, d, all, l > 0 ? frq : (u64*)nullptr);
+        rc = launch_1d<L>(tfk::remainder_finish_kernel<L>, all * d, s, cur, (const u64*)prod, 2 * d, nxt, d, all, l > l_stop ? frq : (u64*)nullptr);
         if (rc) return rc;
         cur = nxt;
     }
-    hipLaunchKernelGGL(tfk::leaf_evaluate_kernel<L>, dim3((unsigned)(UM / kTreeLeaf)), dim3(kTreeLeaf), kTreeLeaf * L * sizeof(u64), s, cur, points,
-                       n_points, kTreeLeaf, vals, M / kTreeLeaf);
+    hipLaunchKernelGGL(tfk::leaf_evaluate_kernel<L>, dim3((unsigned)(UM / eval_leaf)), dim3(eval_leaf), eval_leaf * L * sizeof(u64), s, cur, points,
+                       n_points, eval_leaf, vals, M / eval_leaf);
     HIPCHK(hipGetLastError());
     return TF_OK;
 }
@@ -2361,6 +2382,7 @@ int batch_evaluate_tree_t(const u64* coeffs, size_t n_coeffs, size_t poly_stride
     long long M = kTreeLeaf;
     int h = 0;
     while (M < (long long)n_points) M <<= 1, ++h;
+    T.leaf = kTreeLeaf;
     T.M = M;
     T.h = h;
     // the tree (6 h M) and the build's work space (8 M); the walks bring their own
@@ -2461,10 +2483,11 @@ struct PaddedTree {
 // Builds the padded tree of `points` (levels, root).  The build's work space is a temporary of the build alone.
 template <int L>
 int padded_tree_build(const u64* points, size_t n_points, size_t extra_words, PaddedTree* pt, hipStream_t s, bool persistent = false) {
-    const int kTreeLeaf = tree_leaf(L);
+    const int kTreeLeaf = tree_interp_leaf(L);
     long long M = kTreeLeaf;
     int h = 0;
     while (M < (long long)n_points) M <<= 1, ++h;
+    pt->T.leaf = kTreeLeaf;
     pt->T.M = M;
     pt->T.h = h;
     pt->n = n_points;
@@ -2484,7 +2507,9 @@ int padded_tree_build(const u64* points, size_t n_points, size_t extra_words, Pa
     u64* leaf_inv = pt->root_tail + (size_t)M * L;
     pt->extra = leaf_inv + (size_t)M * L;
     if (h == 0) {  // one leaf: it is the root
-        hipLaunchKernelGGL(tfk::leaf_zerofier_kernel<L>, dim3(1), dim3(kTreeLeaf), 2 * kTreeLeaf * L * sizeof(u64), s, points, (long long)n_points,
+        if (3 * kTreeLeaf * L * sizeof(u64) > 48 * 1024)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tfk::leaf_zerofier_kernel<L>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(3 * kTreeLeaf * L * sizeof(u64)));
+        hipLaunchKernelGGL(tfk::leaf_zerofier_kernel<L>, dim3(1), dim3(kTreeLeaf), 3 * kTreeLeaf * L * sizeof(u64), s, points, (long long)n_points,
                            kTreeLeaf, pt->root_tail, leaf_inv);
         HIPCHK(hipGetLastError());
         return TF_OK;
@@ -2576,7 +2601,7 @@ int tree_inverse_weights(DeviceCtx* ctx, const PaddedTree& pt, const u64* domain
 template <int L>
 int tree_interpolate_rows(DeviceCtx* ctx, const PaddedTree& pt, const u64* domain, const u64* winv, const u64* values, size_t rows, u64* out,
                           hipStream_t s) {
-    const int kTreeLeaf = tree_leaf(L);
+    const int kTreeLeaf = pt.T.leaf;
     const long long M = pt.T.M;
     const size_t ML = (size_t)M * L, n = pt.n;
     const int h = pt.T.h;
@@ -2594,8 +2619,11 @@ int tree_interpolate_rows(DeviceCtx* ctx, const PaddedTree& pt, const u64* domai
         const size_t nr = std::min(slab, rows - r0);
         hipLaunchKernelGGL(tfk::interpolation_targets_kernel<L>, dim3((unsigned)((M + 255) / 256), (unsigned)nr), dim3(256), 0, s,
                            values + r0 * n * L, winv, (long long)n, M, targets);
+        if (6 * kTreeLeaf * L * sizeof(u64) > 48 * 1024)  // only with a leaf size forced through TF_TREE_LEAF_LOG
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tfk::leaf_interpolant_kernel<L>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)(6 * kTreeLeaf * L * sizeof(u64)));
         hipLaunchKernelGGL(tfk::leaf_interpolant_kernel<L>, dim3((unsigned)(M / kTreeLeaf), (unsigned)nr), dim3(kTreeLeaf),
-                           2 * kTreeLeaf * L * sizeof(u64), s, domain, (const u64*)targets, (long long)n, kTreeLeaf, M, na);
+                           6 * kTreeLeaf * L * sizeof(u64), s, domain, (const u64*)targets, (long long)n, kTreeLeaf, M, na);
         if (hipGetLastError() != hipSuccess) rc = TF_ERR_HIP;
         u64* cur = na;
         u64* nxt = nb;
@@ -2623,7 +2651,7 @@ int tree_interpolate_rows(DeviceCtx* ctx, const PaddedTree& pt, const u64* domai
 
 template <int L>
 int interpolate_dev_t(const u64* domain, const u64* values, size_t n, size_t rows, u64* out, hipStream_t s, int* d_status) {
-    const int kTreeLeaf = tree_leaf(L);
+    const int kTreeLeaf = tree_interp_leaf(L);
     long long M = kTreeLeaf;
     while (M < (long long)n) M <<= 1;
     PaddedTree pt;
@@ -2665,7 +2693,7 @@ struct TreeHandle {
 
 template <int L>
 int tree_handle_new_t(const u64* d_domain, size_t n, hipStream_t s, TreeHandle* H, bool async) {
-    const int kTreeLeaf = tree_leaf(L);
+    const int kTreeLeaf = tree_interp_leaf(L);
     long long M = kTreeLeaf;
     while (M < (long long)n) M <<= 1;
     int rc = padded_tree_build<L>(d_domain, n, 2 * (size_t)M * L + 1, &H->pt, s, true);
