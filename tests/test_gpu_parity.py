@@ -793,3 +793,30 @@ def test_latency_shaped_transform_matches_oracle(tf, oracle, log_n, width):
         lib.tf_set_ntt_latency_kernel(-1)
     assert np.array_equal(got[0], got[1])
     assert np.array_equal(got[1], oracle.poly_mul(x[: (n // 2) * width], x[n * width: n * width + (n // 2 - 3) * width], width=width))
+
+
+@pytest.mark.parametrize("log_n,width,batch", [(13, 1, 3), (14, 3, 2), (15, 1, 1), (16, 1, 2), (16, 3, 1), (17, 1, 1), (18, 3, 1), (19, 1, 1), (20, 1, 1)])
+def test_latency_shaped_two_pass_plan_matches_oracle(tf, oracle, log_n, width, batch):
+    """2^13 .. 2^20 points with little work per call (one slice is the reference's own call shape, math/ntt.rs:67-82): the two
+    passes n = N1 N2 on the 8-elements-per-thread stages (ntt_lat2_kernel), forced on and off: forward, inverse, fast_multiply
+    (zero-padded forward transforms, product fused into the inverse's load) and coset evaluation against the oracle."""
+    n = 1 << log_n
+    lib = tf._lib.lib()
+    x = oracle.fill_random(batch * n * width, 3100 + log_n + width)
+    want = oracle.ntt(x, width=width, batch=batch, threads=8)
+    got = {}
+    a, b = x[: (n // 2) * width], x[(n // 2) * width: (n // 2) * width + (n // 2 - 3) * width]
+    try:
+        for mode in (1, 0):
+            lib.tf_set_ntt_latency_kernel(mode)
+            y = x.copy()
+            tf.ntt(y, width=width, batch=batch)
+            assert np.array_equal(y, want), (mode, "forward")
+            tf.intt(y, width=width, batch=batch)
+            assert np.array_equal(y, x), (mode, "inverse")
+            got[mode] = tf.fast_multiply(a, b, width=width)
+    finally:
+        lib.tf_set_ntt_latency_kernel(-1)
+    assert np.array_equal(got[0], got[1])
+    if log_n <= 16:
+        assert np.array_equal(got[1], oracle.poly_mul(a, b, width=width))

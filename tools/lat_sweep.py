@@ -9,10 +9,11 @@ import twenty_first_amd as tf
 from twenty_first_amd import _lib
 lib = _lib.lib()
 width = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+lo, hi = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (6, 12)
 dev = torch.device("cuda:0")
 
 
-def timed(fn, reps=200):
+def timed(fn, reps=100):
     for _ in range(10):
         fn()
     torch.cuda.synchronize()
@@ -25,9 +26,9 @@ def timed(fn, reps=200):
 
 
 ok = True
-for log_n in range(6, 13):
+for log_n in range(lo, hi + 1):
     n = 1 << log_n
-    for log_total in (log_n, 13, 16, 18, 20, 21, 22, 23, 24):
+    for log_total in sorted(set((log_n, 13, 16, 18, 20, 21, 22, 23, 24))):
         if log_total < log_n:
             continue
         batch = max(1, (1 << log_total) // (n * (1 if width == 1 else 4)))

@@ -1238,6 +1238,150 @@ __global__ void __launch_bounds__(LOGN == 12 ? 512 : 256) ntt_lat_kernel(const N
     }
 }
 
+// ---- 2^13 <= n <= 2^20, little work per call: the same eight-elements-per-thread stages as the two passes of n = N1 N2 ------
+// (one slice per call is the reference's own call shape: math/ntt.rs:67-82 takes ONE slice).  A "line" is one DFT instance:
+//   column pass (LAST = false): line c = word-column c of the N2 L words of a row; element i at  i * es + c;  after the last stage
+//       output k is multiplied by the inter-pass twiddle w_n^(k b), b = c / L, and stored where it came from (or into scratch);
+//   last pass (LAST = true):    line c = (k1, limb) = (c / L, c % L): input row k1 of N2 contiguous elements, output k at
+//       (k1 + N1 k) L + limb -- natural order, no bit reversal.
+// cfast: adjacent threads take adjacent lines (the column pass: coalesced both ways); otherwise adjacent threads walk along the line
+// (the last pass: contiguous loads, strided 8-byte stores -- a call this small is bound by latency, not by store efficiency).
+struct NttLat2Args {
+    const u64* in;
+    u64* out;
+    const u64* in2;            // or null: second operand laid out like `in`, multiplied in on load (first pass, L = 1)
+    const u64* tw;             // [2][N]: w_N^(+-e), then scale * w_N^(+-e)
+    const u64* post_tw;        // column pass: T[k * tw_rs + b]
+    long long n_coeffs;        // column pass: < 0 none; else input element index i * nc_es + c / L >= n_coeffs reads as zero
+    long long nc_es;
+    long long in_bs, out_bs;   // words between batch entries
+    long long lines;           // lines per batch entry
+    long long in_es, out_es;   // words between consecutive elements of a line
+    long long in_lhi, out_lhi; // line c starts at (c / L) * lhi + (c % L)
+    long long tw_rs;
+    u64 scale;                 // last pass of an inverse: n^-1 (Montgomery); 0 otherwise
+    int L;
+    int cfast;
+    int tiles_per_entry;       // ceil(lines / T)
+};
+
+template <int LOGN, bool INV, bool LAST>
+__global__ void __launch_bounds__(256) ntt_lat2_kernel(const NttLat2Args A) {
+    constexpr int N = 1 << LOGN, TPT = N / 8, WG = 256, T = WG / TPT;
+    constexpr int S = (LOGN + 2) / 3, LOGRL = LOGN - 3 * (S - 1);
+    constexpr int BUF = lat_pad(N * T) + 8;
+    static_assert(LOGN >= 6 && LOGN <= 10, "");
+    extern __shared__ __attribute__((aligned(16))) u64 lds[];
+    const int t = threadIdx.x;
+    const int lc = A.cfast ? t % T : t / TPT;   // line within the tile
+    const int j = A.cfast ? t / T : t % TPT;    // butterfly unit within the line
+    const long long entry = blockIdx.x / A.tiles_per_entry, tile = blockIdx.x - entry * A.tiles_per_entry;
+    const long long c = tile * T + lc;
+    const bool act = c < A.lines;
+    const int L = A.L;
+    const long long chi = act ? c / L : 0;
+    const int clo = act ? (int)(c - chi * L) : 0;
+    const u64* src = A.in + entry * A.in_bs + chi * A.in_lhi + clo;
+    u64* dst = A.out + entry * A.out_bs + chi * A.out_lhi + clo;
+    const auto li = [&](int idx) { return A.cfast ? lat_pad(idx * T + lc) : lat_pad(lc * N + idx); };  // LDS index of element idx of my line
+    u64 x[32];
+#pragma unroll
+    for (int q = 0; q < 32; ++q) x[q] = 0;
+    u64 tw[S > 1 ? S - 1 : 1][8];
+    {
+        int Ns = 8;
+#pragma unroll
+        for (int s = 1; s < S; ++s) {
+            const int logr = s + 1 < S ? 3 : LOGRL, R = 1 << logr, U = 8 >> logr;
+            const bool last = s + 1 == S;
+#pragma unroll
+            for (int a = 0; a < U; ++a) {
+                const int u = j + a * TPT, k = u & (Ns - 1);
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const int e = k * r * (N / (Ns * R));
+                    tw[s - 1][a * R + r] = (r == 0) ? 0 : A.tw[((LAST && INV && last) ? N : 0) + e];
+                }
+            }
+            Ns *= R;
+        }
+    }
+    if (act) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int idx = j + r * TPT;
+            u64 v = 0;
+            if (LAST || A.n_coeffs < 0 || (long long)idx * A.nc_es + chi < A.n_coeffs) {
+                v = src[(long long)idx * A.in_es];
+                if (!LAST && A.in2) v = gl::mont_mul(v, (A.in2 + entry * A.in_bs + chi * A.in_lhi + clo)[(long long)idx * A.in_es]);
+            }
+            x[lat_brev<3>(r)] = v;
+        }
+    }
+    lat_dft<INV, 3>(x);
+    u64* bufs[2] = {lds + 0, lds + BUF};
+#pragma unroll
+    for (int r = 0; r < 8; ++r) bufs[0][li(j * 8 + r)] = x[r];
+    __syncthreads();
+    int Ns = 8;
+#pragma unroll
+    for (int s = 1; s < S; ++s) {
+        const bool last = s + 1 == S;
+        const int logr = last ? LOGRL : 3, R = 1 << logr, U = 8 >> logr;
+        const u64* in = bufs[(s - 1) & 1];
+        u64* o = bufs[s & 1];
+        u64 v[8];
+#pragma unroll
+        for (int a = 0; a < U; ++a) {
+            const int u = j + a * TPT;
+#pragma unroll
+            for (int r = 0; r < R; ++r) v[a * R + r] = in[li(u + r * (N / R))];
+        }
+        u64 ptw[8];
+        if (last && !LAST && act) {  // inter-pass twiddles of my outputs, requested before the arithmetic
+#pragma unroll
+            for (int a = 0; a < U; ++a) {
+                const int u = j + a * TPT, k = u & (Ns - 1), j0 = (u - k) * R + k;
+#pragma unroll
+                for (int r = 0; r < R; ++r) ptw[a * R + r] = A.post_tw[(long long)(j0 + r * Ns) * A.tw_rs + chi];
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < U; ++a) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                u64 w = v[a * R + r];
+                if (r) w = gl::mont_mul(w, tw[s - 1][a * R + r]);
+                else if (LAST && INV && last) w = gl::mont_mul(w, A.scale);
+                const int slot = a * R + (logr == 3 ? lat_brev<3>(r) : (logr == 2 ? lat_brev<2>(r) : r));
+                x[slot] = w;
+            }
+        }
+        if (logr == 3) lat_dft<INV, 3>(x);
+        else if (logr == 2) lat_dft<INV, 2>(x);
+        else lat_dft<INV, 1>(x);
+#pragma unroll
+        for (int a = 0; a < U; ++a) {
+            const int u = j + a * TPT, k = u & (Ns - 1), j0 = (u - k) * R + k;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int idx = j0 + r * Ns;
+                if (last) {
+                    if (act) {
+                        u64 val = x[a * R + r];
+                        if (!LAST) val = gl::mont_mul(val, ptw[a * R + r]);
+                        dst[(long long)idx * A.out_es] = val;
+                    }
+                } else {
+                    o[li(idx)] = x[a * R + r];
+                }
+            }
+        }
+        if (!last) __syncthreads();
+        Ns *= R;
+    }
+}
+
 // ---- n <= 16: one thread per (transform, limb); reference-shaped radix-2 loop, tables in global memory.
 struct NttTinyArgs {
     const u64* in;

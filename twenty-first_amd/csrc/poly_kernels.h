@@ -458,7 +458,8 @@ __global__ void __launch_bounds__(256) interpolation_targets_kernel(const u64* v
 // Leaves of the interpolant: N = sum_i w_i prod_{k != i} (x - p_k) over the leaf's d points, built with the zerofier one point at
 // a time:  N <- N (x - p) + w Z,  Z <- Z (x - p).   grid = (leaves, rows), block = d threads (thread t owns coefficient t).
 template <int L>
-__global__ void __launch_bounds__(kLeafMax) leaf_interpolant_kernel(const u64* points, const u64* targets, long long n_points, int d,
+// The targets w_i = values[row][i] / Z'(x_i) are formed while the leaf's points are staged (winv = the inverse weights).
+__global__ void __launch_bounds__(kLeafMax) leaf_interpolant_kernel(const u64* points, const u64* values, const u64* winv, long long n_points, int d,
                                                                     long long M, u64* N) {
     extern __shared__ u64 leaf_lds[];  // 6 * d * L words: Z and N twice (the step alternates between the copies), points, targets
     const int t = threadIdx.x;
@@ -474,8 +475,17 @@ __global__ void __launch_bounds__(kLeafMax) leaf_interpolant_kernel(const u64* p
             zb[0][t * L + k] = (t == 0 && k == 0) ? gl::ONE : 0;
             nb[0][t * L + k] = 0;
             pts[t * L + k] = pi < n_points ? points[pi * L + k] : 0;
-            tgt[t * L + k] = pi < n_points ? targets[(row * M + pi) * L + k] : 0;
         }
+        u64 tv[L];
+#pragma unroll
+        for (int k = 0; k < L; ++k) tv[k] = 0;
+        if (pi < n_points) {
+            u64 v[L], wi[L];
+            fe_load<L>(values + (row * n_points + pi) * L, v);
+            fe_load<L>(winv + pi * L, wi);
+            fe_mul<L>(v, wi, tv);
+        }
+        fe_store<L>(&tgt[t * L], tv);
     }
     __syncthreads();
     int cur_buf = 0;

@@ -1090,8 +1090,9 @@ int launch_block(DeviceCtx* ctx, const u64* in, u64* out, long long in_bs, long 
 
 // ---- the latency-shaped transform (ntt_lat_kernel): calls with little work, 64 <= n <= 4096
 // t[e] = w_n^(+-e), e < n, then n^-1 t[e]
-int get_lat_table(DeviceCtx* ctx, int log_n, bool inverse, const u64** out) {
-    const u64 key = make_key(TAG_LAT, log_n, inverse, 0, 0);
+int get_lat_table(DeviceCtx* ctx, int log_n, bool inverse, const u64** out, int scale_log = -1) {
+    if (scale_log < 0) scale_log = log_n;  // second half: 2^-scale_log w^e (the n^-1 of the whole transform rides on the last stage)
+    const u64 key = make_key(TAG_LAT, log_n, inverse, scale_log, 0);
     std::lock_guard<std::mutex> lk(ctx->mu);
     auto it = ctx->tables.find(key);
     if (it != ctx->tables.end()) {
@@ -1101,7 +1102,7 @@ int get_lat_table(DeviceCtx* ctx, int log_n, bool inverse, const u64** out) {
     const size_t n = size_t(1) << log_n;
     u64 w = root_of_unity_mont(log_n);
     if (inverse) w = gl::mont_inverse(w);
-    const u64 ninv = gl::mont_inverse(gl::to_mont(u64(n)));
+    const u64 ninv = gl::mont_inverse(gl::to_mont(u64(1) << scale_log));
     std::vector<u64> t(2 * n);
     u64 acc = gl::ONE;
     for (size_t e = 0; e < n; ++e) {
@@ -1187,6 +1188,103 @@ int launch_lat(DeviceCtx* ctx, const u64* in, u64* out, long long in_bs, long lo
         a.L = L;
         rc = inverse ? launch_lat_dir<true>(log_n, a, stream) : launch_lat_dir<false>(log_n, a, stream);
     }
+    return rc;
+}
+
+// ---- 2^13 .. 2^20 points with little work: the two passes of n = N1 N2 on the eight-elements-per-thread stages (ntt_lat2_kernel)
+template <int LOGN, bool INV, bool LAST>
+int launch_lat2_t(const tfk::NttLat2Args& a, size_t batch, hipStream_t stream) {
+    constexpr int N = 1 << LOGN, T = 256 / (N / 8);
+    constexpr size_t lds = size_t(2) * (tfk::lat_pad(N * T) + 8) * sizeof(u64);
+    tfk::NttLat2Args b = a;
+    b.tiles_per_entry = (int)((a.lines + T - 1) / T);
+    const long long blocks = (long long)batch * b.tiles_per_entry;
+    hipLaunchKernelGGL((tfk::ntt_lat2_kernel<LOGN, INV, LAST>), dim3((unsigned)blocks), dim3(256), lds, stream, b);
+    HIPCHK(hipGetLastError());
+    return TF_OK;
+}
+template <bool INV, bool LAST>
+int launch_lat2_dir(int log_n, const tfk::NttLat2Args& a, size_t batch, hipStream_t s) {
+    switch (log_n) {
+        case 6: return launch_lat2_t<6, INV, LAST>(a, batch, s);
+        case 7: return launch_lat2_t<7, INV, LAST>(a, batch, s);
+        case 8: return launch_lat2_t<8, INV, LAST>(a, batch, s);
+        case 9: return launch_lat2_t<9, INV, LAST>(a, batch, s);
+        case 10: return launch_lat2_t<10, INV, LAST>(a, batch, s);
+    }
+    return TF_ERR_HIP;
+}
+bool lat2_wanted(int log_n, size_t batch, int L) {
+    static const bool off = getenv("TF_NTT_NO_LAT") != nullptr || getenv("TF_NTT_NO_LAT2") != nullptr;  // A/B switches
+    static const long long env_limit = [] {
+        const char* e = getenv("TF_NTT_LAT2_MAX_WORDS");
+        return e ? atoll(e) : 0ll;
+    }();
+    const int mode = g_lat_mode.load(std::memory_order_relaxed);
+    if (mode == 0 || (mode < 0 && off)) return false;
+    if (log_n < 13 || log_n > 20) return false;
+    if (mode == 1) return true;
+    // measured crossover against the pass / block kernels, words per call (tools/lat_sweep.py 13 20, profiles/r03_lat2_sweep_*.txt):
+    // one 2^16-point slice 33 -> 16 us; the win ends where the chip fills, and earlier for the longest lines (a 1024-point line
+    // leaves two lines per workgroup: 16-byte segments)
+    static const long long lim1[8] = {1ll << 21, 1ll << 21, 1ll << 21, 1ll << 21, 1ll << 21, 1ll << 20, 1ll << 19, 0};  // log_n = 13 .. 20
+    static const long long lim3[8] = {3ll << 20, 3ll << 20, 3ll << 19, 3ll << 20, 3ll << 19, 3ll << 18, 0, 0};
+    const long long limit = env_limit ? env_limit : (L == 1 ? lim1 : lim3)[log_n - 13];
+    return (long long)(batch * size_t(L)) << log_n <= limit;
+}
+int launch_lat2(DeviceCtx* ctx, const u64* in, u64* out, long long in_bs, long long out_bs, int log_n, size_t batch, int L, bool inverse,
+                long long n_coeffs, const u64* in2, hipStream_t stream) {
+    const int a1 = (log_n + 1) / 2, a2 = log_n - a1;
+    const long long N1 = 1ll << a1, N2 = 1ll << a2, n = 1ll << log_n;
+    const u64 *tw1 = nullptr, *tw2 = nullptr, *post = nullptr;
+    bool post_temp = false;
+    int rc = get_lat_table(ctx, a1, inverse, &tw1, 0);
+    if (!rc) rc = get_lat_table(ctx, a2, inverse, &tw2, inverse ? log_n : 0);
+    if (!rc) rc = get_post_table(ctx, log_n, a1, inverse, stream, &post, &post_temp);
+    if (rc) return rc;
+    DeviceCtx::ScratchBlock sblk;
+    rc = scratch_acquire(ctx, batch * (size_t)n * L * sizeof(u64), stream, &sblk);
+    if (rc) {
+        if (post_temp) (void)hipFreeAsync(const_cast<u64*>(post), stream);
+        return rc;
+    }
+    tfk::NttLat2Args c{};  // column pass: the caller's input -> scratch
+    c.in = in;
+    c.out = sblk.p;
+    c.in2 = in2;
+    c.tw = tw1;
+    c.post_tw = post;
+    c.n_coeffs = n_coeffs;
+    c.nc_es = N2;
+    c.in_bs = in_bs;
+    c.out_bs = n * L;
+    c.lines = N2 * L;
+    c.in_es = c.out_es = N2 * L;
+    c.in_lhi = c.out_lhi = L;
+    c.tw_rs = N2;
+    c.L = L;
+    c.cfast = 1;
+    rc = inverse ? launch_lat2_dir<true, false>(a1, c, batch, stream) : launch_lat2_dir<false, false>(a1, c, batch, stream);
+    if (!rc) {
+        tfk::NttLat2Args r{};  // last pass: rows of the scratch -> natural order in the caller's output
+        r.in = sblk.p;
+        r.out = out;
+        r.tw = tw2;
+        r.n_coeffs = -1;
+        r.in_bs = n * L;
+        r.out_bs = out_bs;
+        r.lines = N1 * L;
+        r.in_es = L;
+        r.in_lhi = N2 * L;
+        r.out_es = N1 * L;
+        r.out_lhi = L;
+        r.scale = inverse ? gl::mont_inverse(gl::to_mont(u64(1) << log_n)) : 0;
+        r.L = L;
+        r.cfast = 0;
+        rc = inverse ? launch_lat2_dir<true, true>(a2, r, batch, stream) : launch_lat2_dir<false, true>(a2, r, batch, stream);
+    }
+    scratch_release(ctx, sblk, stream);
+    if (post_temp) (void)hipFreeAsync(const_cast<u64*>(post), stream);
     return rc;
 }
 
@@ -1324,6 +1422,9 @@ int run_ntt(DeviceCtx* ctx, const u64* in, u64* out, long long in_bs, long long 
     if (!pre_scale && !post_scale && n_out < 0 && cosets == 1 && (!in2 || L == 1) && g_min_passes.load(std::memory_order_relaxed) == 0 &&
         lat_wanted(log_n, batch, L))
         return launch_lat(ctx, in, out, in_bs, out_bs, log_n, batch, L, inverse, n_coeffs, in2, stream);
+    if (!pre_scale && !post_scale && n_out < 0 && cosets == 1 && (!in2 || L == 1) && g_min_passes.load(std::memory_order_relaxed) == 0 &&
+        lat2_wanted(log_n, batch, L))
+        return launch_lat2(ctx, in, out, in_bs, out_bs, log_n, batch, L, inverse, n_coeffs, in2, stream);
     if (log_n <= 10) {
         const u64* inner = nullptr;
         rc = get_inner_table(ctx, log_n, inverse, inverse ? log_n : 0, &inner);
@@ -2617,13 +2718,11 @@ int tree_interpolate_rows(DeviceCtx* ctx, const PaddedTree& pt, const u64* domai
     int rc = TF_OK;
     for (size_t r0 = 0; r0 < rows && !rc; r0 += slab) {
         const size_t nr = std::min(slab, rows - r0);
-        hipLaunchKernelGGL(tfk::interpolation_targets_kernel<L>, dim3((unsigned)((M + 255) / 256), (unsigned)nr), dim3(256), 0, s,
-                           values + r0 * n * L, winv, (long long)n, M, targets);
         if (6 * kTreeLeaf * L * sizeof(u64) > 48 * 1024)  // only with a leaf size forced through TF_TREE_LEAF_LOG
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tfk::leaf_interpolant_kernel<L>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)(6 * kTreeLeaf * L * sizeof(u64)));
         hipLaunchKernelGGL(tfk::leaf_interpolant_kernel<L>, dim3((unsigned)(M / kTreeLeaf), (unsigned)nr), dim3(kTreeLeaf),
-                           6 * kTreeLeaf * L * sizeof(u64), s, domain, (const u64*)targets, (long long)n, kTreeLeaf, M, na);
+                           6 * kTreeLeaf * L * sizeof(u64), s, domain, values + r0 * n * L, winv, (long long)n, kTreeLeaf, M, na);
         if (hipGetLastError() != hipSuccess) rc = TF_ERR_HIP;
         u64* cur = na;
         u64* nxt = nb;
