@@ -166,17 +166,20 @@ def test_planner_splits_are_valid_for_every_length(tf):
 
 def test_batch_evaluation_router_is_host_logic_with_the_measured_crossovers(tf):
     """tf_batch_eval_plan (host logic, no device): the router of tf_poly_batch_evaluate_* picks the zerofier tree where it measured
-    faster than Horner (profiles/r02_batch_eval_sweep.txt) and Horner elsewhere; the test hook forces either route; a tree never
+    faster than Horner (profiles/r03_batch_eval_fine_w*.txt) and Horner elsewhere; the test hook forces either route; a tree never
     applies below two leaves."""
     lib = tf._lib.lib()
     plan = lib.tf_batch_eval_plan
     lib.tf_set_batch_eval_route(0)
     try:
         # (n_coeffs, n_points, batch, width) -> route; 1 = Horner, 2 = tree
-        measured = [((1 << 12, 1 << 12, 1, 1), 1), ((1 << 14, 1 << 12, 1, 1), 1), ((1 << 14, 1 << 14, 1, 1), 1), ((1 << 16, 1 << 13, 1, 1), 1),
-                    ((1 << 16, 1 << 14, 1, 1), 1), ((1 << 16, 1 << 16, 1, 1), 2), ((1 << 18, 1 << 14, 1, 1), 2), ((1 << 18, 1 << 16, 1, 1), 2),
-                    ((1 << 18, 1 << 18, 1, 1), 2), ((1 << 20, 1 << 20, 1, 1), 2), ((1 << 22, 1 << 16, 1, 1), 2),
-                    ((1 << 14, 1 << 12, 1, 3), 1), ((1 << 14, 1 << 14, 1, 3), 1), ((1 << 16, 1 << 13, 1, 3), 2), ((1 << 16, 1 << 14, 1, 3), 2),
+        # (round 3: profiles/r03_batch_eval_fine_w1.txt / _w3.txt -- the latency-shaped transforms moved every crossover down)
+        measured = [((1 << 12, 1 << 12, 1, 1), 1), ((1 << 14, 1 << 12, 1, 1), 1), ((1 << 14, 1 << 14, 1, 1), 1), ((1 << 14, 1 << 16, 1, 1), 1),
+                    ((1 << 16, 1 << 13, 1, 1), 1), ((1 << 16, 1 << 14, 1, 1), 1), ((1 << 16, 1 << 15, 1, 1), 2), ((1 << 16, 1 << 16, 1, 1), 2),
+                    ((1 << 18, 1 << 11, 1, 1), 1), ((1 << 18, 1 << 12, 1, 1), 2), ((1 << 18, 1 << 14, 1, 1), 2), ((1 << 18, 1 << 16, 1, 1), 2),
+                    ((1 << 18, 1 << 18, 1, 1), 2), ((1 << 20, 1 << 12, 1, 1), 2), ((1 << 20, 1 << 20, 1, 1), 2), ((1 << 22, 1 << 16, 1, 1), 2),
+                    ((1 << 12, 1 << 14, 1, 3), 1), ((1 << 14, 1 << 12, 1, 3), 1), ((1 << 14, 1 << 14, 1, 3), 2), ((1 << 16, 1 << 10, 1, 3), 1),
+                    ((1 << 16, 1 << 12, 1, 3), 2), ((1 << 16, 1 << 13, 1, 3), 2), ((1 << 16, 1 << 14, 1, 3), 2),
                     ((1 << 16, 1 << 16, 1, 3), 2), ((1 << 18, 1 << 14, 1, 3), 2), ((1 << 20, 1 << 20, 1, 3), 2)]
         for shape, want in measured:
             assert plan(*shape) == want, shape

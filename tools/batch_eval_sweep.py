@@ -23,7 +23,10 @@ def timed(fn, reps):
     return e0.elapsed_time(e1) / reps
 
 
-for log_n, log_m in [(12, 12), (14, 12), (14, 14), (16, 13), (16, 14), (16, 16), (18, 14), (18, 16), (18, 18), (20, 16), (20, 20), (22, 16)]:
+PAIRS = [(12, 12), (14, 12), (14, 14), (16, 13), (16, 14), (16, 16), (18, 14), (18, 16), (18, 18), (20, 16), (20, 20), (22, 16)]
+if len(sys.argv) > 2 and sys.argv[2] == "fine":  # the grid the router's cost model is fitted on
+    PAIRS = [(ln, lm) for ln in range(10, 21, 2) for lm in range(9, 19) if lm <= ln + 2]
+for log_n, log_m in PAIRS:
     n, m = 1 << log_n, 1 << log_m
     c = torch.empty(n * width, dtype=torch.int64, device=dev)
     p = torch.empty(m * width, dtype=torch.int64, device=dev)

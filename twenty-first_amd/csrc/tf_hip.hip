@@ -2422,17 +2422,19 @@ bool tree_route(size_t n_coeffs, size_t n_points, size_t batch, int L) {
         if (words * sizeof(u64) > (size_t(64) << 30)) return false;  // would not fit a sane work space (288 GB of HBM)
     }
     if (force && !strcmp(force, "tree")) return true;
-    // Cost model fitted to tools/batch_eval_sweep.py on MI355X (profiles/r02_batch_eval_sweep.txt), milliseconds:
+    // Cost model fitted to tools/batch_eval_sweep.py <width> fine on MI355X (profiles/r03_batch_eval_fine_w*.txt), milliseconds:
     //   Horner  n m / 1.4e9            (x 8 over XFieldElement: nine base-field products per step; measured 7 - 10)
-    //   tree    2.4 walks for the first unit (one build = 1.4 walks; a walk is launch-bound per level: 7 launches, 0.115 ms,
-    //           plus 0.06 ms per 2^16 padded points, 0.2 over XFE); the units walk TOGETHER, so every further unit adds only its
-    //           share of the throughput term: 0.035 ms per 2^16 points (0.16 over XFE)
+    //   tree    build + one walk for the first unit: latency-bound per level up to 2^12 points (0.09 ms a level with the
+    //           latency-shaped transforms of round 3), twice that per level above, plus a throughput term in M beyond 2^16 points;
+    //           the units walk TOGETHER, so every further unit adds only its share of the throughput term: 0.04 ms per 2^16
+    //           points (0.16 over XFE)
     int levels = 0;
     for (size_t v = kTreeLeaf; v < M; v <<= 1) ++levels;
     const double horner_ms = (double)batch * (double)n_coeffs * (double)n_points / 1.4e9 * (L == 3 ? 8.0 : 1.0);
-    const double latency = std::max(0.1, -0.10 + 0.115 * levels) * (L == 3 ? 1.3 : 1.0);
-    const double walk_ms = latency + (L == 3 ? 0.2 : 0.06) * (double)M / 65536.0;
-    const double tree_ms = 2.4 * walk_ms + (double)(units - 1) * (L == 3 ? 0.16 : 0.035) * (double)M / 65536.0;
+    const double m16 = (double)M / 65536.0;
+    const double first_ms = L == 3 ? 0.25 + 0.085 * levels + 0.10 * std::max(0, levels - 4) + 0.25 * m16
+                                   : 0.10 + 0.09 * levels + 0.09 * std::max(0, levels - 4) + 0.055 * m16;
+    const double tree_ms = first_ms + (double)(units - 1) * (L == 3 ? 0.16 : 0.04) * m16;
     return tree_ms < 0.9 * horner_ms;
 }
 
