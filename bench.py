@@ -534,6 +534,24 @@ def coset_leg(ctx):
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
     gbs = 48.0 * n * b / (ms * 1e-3) / 1e9
+    # the same call on the three-pass plan of rounds 1-2 (tf_set_ntt_two_pass(0)), in this run on this box: what the two-pass plan
+    # (a 2048-point pass as pairs of 1024-point workgroups) buys
+    three_ms = None
+    try:
+        tf.lib().tf_set_ntt_two_pass(0)
+        for _ in range(2):
+            tf.device.coset_evaluate(c, n, off, o, n, batch=b, width=3)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(5):
+            tf.device.coset_evaluate(c, n, off, o, n, batch=b, width=3)
+        e1.record()
+        torch.cuda.synchronize()
+        three_ms = e0.elapsed_time(e1) / 5
+    finally:
+        tf.lib().tf_set_ntt_two_pass(-1)
+    tf.device.coset_evaluate(c, n, off, o, n, batch=b, width=3)  # the parity sample below is the two-pass plan's output
+    torch.cuda.synchronize()
     res = {
         "metric": "xfe_coset_evaluate_gpoints_per_s",
         "value": round(n * b / ms / 1e6, 3),
@@ -542,7 +560,9 @@ def coset_leg(ctx):
         "config": {"workload": "64 XFieldElement polynomials x 2^22 coefficients, fast_coset_evaluate(offset = 7, order = 2^22) (BASELINE configs[3])",
                    "inputs": f"SplitMix64, seed 0x{SEED_C4:X}"},
         "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
-                     "algorithmic_bytes_per_point": 48, "launches_per_step": int(tf.lib().tf_ntt_launch_count(n, b, 3))},
+                     "algorithmic_bytes_per_point": 48, "launches_per_step": int(tf.lib().tf_ntt_launch_count(n, b, 3)),
+                     "plan": "two global passes (2048 x 2048 points; 32 B/point through HBM each way)"},
+        "three_pass_plan_ms": round(three_ms, 4) if three_ms else None,
     }
     if not args.no_cpu_baseline:
         from oracle import tfo
@@ -705,6 +725,21 @@ def side_measurements(tf, torch, dev):
         ms = _timed(lambda: tf.device.coset_extrapolate(off, cw, 1 << 16, pts, ex, batch=64), reps=3)
         extra["coset_extrapolate_64x_2p16_to_2p14_points"] = {"ms": round(ms, 3)}
         del cw, pts, ex
+        # the reference's own call shape: ONE slice per call (math/ntt.rs:67-82), device-resident, back-to-back calls
+        lat = {}
+        for log_n in (10, 12, 16, 18, 20):
+            sx = rnd(1 << log_n, 13)
+            us = _timed(lambda: tf.device.ntt_(sx, 1 << log_n), reps=100) * 1e3
+            lat[f"2p{log_n}"] = round(us, 1)
+        extra["single_slice_ntt_us"] = lat
+        dom, cf = rnd(1 << 12, 14), rnd(1 << 12, 15)
+        vals, back = torch.empty(1 << 12, dtype=torch.int64, device=dev), torch.empty(1 << 12, dtype=torch.int64, device=dev)
+        with tf.device.ZerofierTree(dom) as tree:
+            us_e = _timed(lambda: tree.batch_evaluate(cf, 1 << 12, vals), reps=50) * 1e3
+            us_i = _timed(lambda: tree.interpolate(vals, back), reps=50) * 1e3
+        extra["zerofier_tree_2p12_points"] = {"prepared_tree_evaluate_us": round(us_e, 1), "prepared_tree_interpolate_us": round(us_i, 1),
+                                              "evaluate_then_interpolate_is_identity": bool(torch.equal(back, cf))}
+        del dom, cf, vals, back
         # PCIe-inclusive figure of the host-pointer entry point (pageable numpy buffers, 32 x 2^20 BFE = 256 MiB each way)
         import numpy as _np
 

@@ -184,7 +184,10 @@ def lib() -> C.CDLL:
             )
         _load_hip_runtime()
         L = C.CDLL(SO_PATH)
+        older = os.environ.get("TF_HIP_ALLOW_OLDER_LIBRARY") == "1"  # tools/ab.sh only: time an earlier build through this harness
         for name, (res, args) in SIGNATURES.items():
+            if older and not hasattr(L, name):
+                continue
             fn = getattr(L, name)  # AttributeError if the .so does not export what the header declares
             fn.restype = res
             fn.argtypes = args

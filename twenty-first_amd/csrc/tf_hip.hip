@@ -1512,6 +1512,7 @@ int run_ntt(DeviceCtx* ctx, const u64* in, u64* out, long long in_bs, long long 
     // pipelined tiles (g_pipe): tile t runs on side stream t % K with scratch tile t % K; the caller's stream forks into
     // the side streams before the first tile and joins them after the last (event edges only, no host synchronisation)
     const size_t ntiles = (batch + tb - 1) / tb;
+    tb = (batch + ntiles - 1) / ntiles;  // equal tiles: 64 polynomials at 21 per tile are 4 x 16, not 21 + 21 + 21 + 1
     int K = (P < 4) ? (int)std::min<size_t>((size_t)g_pipe.load(std::memory_order_relaxed), ntiles) : 1;
     hipStream_t side[kMaxPipe] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[kMaxPipe] = {nullptr, nullptr, nullptr, nullptr};
