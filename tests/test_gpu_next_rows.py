@@ -385,7 +385,9 @@ def test_fast_multiply_batched_products_with_unaligned_outputs(tf, oracle, width
 
 
 @pytest.mark.parametrize("width,log_n,batch,shift", [(1, 15, 3, 5), (1, 17, 2, 1), (1, 20, 2, 15), (1, 21, 1, 9), (1, 23, 1, 8),
-                                                     (3, 15, 3, 5), (3, 13, 2, 1), (3, 20, 2, 7), (3, 23, 1, 2), (3, 24, 1, 0)])
+                                                     (3, 15, 3, 5), (3, 13, 2, 1), (3, 20, 2, 7), (3, 23, 1, 2), (3, 24, 1, 0),
+                                                     (1, 21, 2, 9), (3, 21, 1, 3), (1, 22, 1, 11), (3, 22, 1, 5),   # the two-pass plan (PRE2)
+                                                     (1, 9, 3, 7), (3, 12, 1, 1), (1, 16, 1, 13), (3, 14, 2, 6)])     # the latency-shaped kernels
 @pytest.mark.parametrize("inverse", [False, True])
 def test_ntt_on_unaligned_device_pointer(tf, oracle, width, log_n, batch, shift, inverse):
     """ntt / intt (math/ntt.rs:67-125) in place on a device slice that does not start on a 128-byte line; the XFE lengths are
@@ -1309,3 +1311,23 @@ def test_release_caches_and_recompute(tf, oracle):
     assert np.array_equal(y, want)
     assert np.array_equal(tf.fast_coset_evaluate(x[:n], oracle.bfe_new(7), 2 * n), ev)
     assert tf.lib().tf_release_caches() == 0
+
+
+def test_two_pass_plan_over_several_batch_tiles(tf, oracle):
+    """tf_set_ntt_tile_bytes smaller than the call: a batch of 2^21-point transforms goes through the two-pass plan in several
+    equal tiles (here 5 slices as 2 + 2 + 1 ... the planner evens them out); same words as the oracle, forward and inverse,
+    BFieldElement and XFieldElement."""
+    lib = tf._lib.lib()
+    keep = lib.tf_get_ntt_tile_bytes()
+    try:
+        for width, batch in ((1, 5), (3, 3)):
+            n = 1 << 21
+            lib.tf_set_ntt_tile_bytes(2 * n * width * 8)
+            x = oracle.fill_random(n * width * batch, 5100 + width)
+            y = x.copy()
+            tf.ntt(y, width=width, batch=batch)
+            assert np.array_equal(y, oracle.ntt(x, width=width, batch=batch, threads=8))
+            tf.intt(y, width=width, batch=batch)
+            assert np.array_equal(y, x)
+    finally:
+        lib.tf_set_ntt_tile_bytes(keep)
