@@ -29,7 +29,7 @@ for f in glob.glob(os.path.join(src, "pmc_sq/**/*counter_collection.csv"), recur
 rec = {"source": f"rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_VALU ... (tools/prof_r02.sh {tag} -> profiles/{tag}_rocprof_summary.json): SQ_INSTS_VALU summed over the dispatches of one step / one tree",
        "ntt_valu_wave_instr_per_transform_2p20": ntt / 256, "ntt_valu_instr_per_element": ntt * 64 / 2 ** 28,
        "ntt_clock_under_load_mhz": round(sum(clocks) / len(clocks), 1) if clocks else None,
-       "valu_peak_note": "peak = 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction = 614.4 G wave-instr/s (SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU = 1.00 quad-cycles on every kernel measured)"}
+       "valu_peak_note": "peak = 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction = 614.4 G wave-instr/s: every instruction of these kernels is of the 4-cycle class (carry adds, v_mad_u64_u32, VOP3; profiles/r03_instr_rates.txt).  SQ_ACTIVE_INST_VALU counts quad-cycles, so its ratio to SQ_INSTS_VALU is the counter's granularity, not a cost"}
 old = {}
 try:
     old = json.load(open(os.path.join(root, "profiles", "valu_counts.json")))
