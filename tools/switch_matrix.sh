@@ -31,6 +31,11 @@ run "TF_NTT_NO_SCALED_LAST1024=1" "generic last pass for fast_coset_interpolate 
 run "TF_NTT_NO_SMALL_LAUNCH=1" "512-thread tiles and the R = 1024 last pass for small calls too"
 run "TF_NTT_WG_THREADS=256" "256-thread workgroups everywhere"
 run "TF_NTT_NT=3" "non-temporal loads / stores in the generic kernels as well"
+run "TF_NTT_NO_PRE2=1" "2^21 / 2^22 points in three passes instead of two (round 3)"
+run "TF_NTT_NO_LAT=1" "no latency-shaped kernels: small calls on the pass / block kernels (round 3)"
+run "TF_NTT_NO_LAT2=1" "latency-shaped kernel for 64..4096 points only, not the two-pass latency plan (round 3)"
+run "TF_NTT_LAT_MAX_WORDS=1073741824 TF_NTT_LAT2_MAX_WORDS=1073741824" "latency-shaped kernels for every call they can serve, whatever its size"
+run "TF_TREE_INTERP_LEAF_LOG=8" "trees that are walked upwards with 256-point leaves as in round 2"
 run "TF_BATCH_EVAL=tree" "zerofier tree wherever it applies"
 run "TF_BATCH_EVAL=horner" "Horner everywhere"
 run "TF_BATCH_EVAL=tree TF_TREE_UNIT_SLAB=3000" "zerofier tree with the units of a walk cut into slabs of a few units"

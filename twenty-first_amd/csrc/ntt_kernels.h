@@ -534,21 +534,14 @@ __global__ void __launch_bounds__(512, TF_NTT_WAVES) ntt_pass_kernel(const NttPa
 #define TF_PRE2_LOAD_AUX 0  // default cache policy: the partner workgroup's read of the same lines should find them in the L2
 #endif
         constexpr int AUX = TF_PRE2_LOAD_AUX;
-#pragma unroll
-        for (int q = 0; q < 32; ++q) {
-            const u32 so = (u32)((long long)(brev5(q) << p2) * A.in_rs * 8);
-            x[q] = CHK ? buf_load<AUX>(ri, toff + so, 0) : buf_load<AUX>(ri, toff, so);
-        }
-#pragma unroll
-        for (int q0 = 0; q0 < 32; q0 += 8) {
-            u64 w[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const u32 so = (u32)((long long)(brev5(q0 + i) << p2) * A.in_rs * 8) + poff;
-                w[i] = CHK ? buf_load<AUX>(ri, toff + so, 0) : buf_load<AUX>(ri, toff, so);
-            }
+#ifndef TF_PRE2_BURST16
+#define TF_PRE2_BURST16 1  // 1: two bursts of 32 loads (16 slots and their 16 partners each); 0: 32 loads, then the partners eight at a time (A/B)
+#endif
+        const auto slot_off = [&](int q) { return (u32)((long long)(brev5(q) << p2) * A.in_rs * 8); };
+        const auto ld = [&](u32 so) { return CHK ? buf_load<AUX>(ri, toff + so, 0) : buf_load<AUX>(ri, toff, so); };
+        const auto scale8 = [&](u64 (&w)[8]) {  // coefficient j + d is scaled by offset^(j + d) = offset^j * c: the common factor follows below
             if constexpr (SCALE == 1) {
-                if (A.pre_scale) {  // coefficient j + d is scaled by offset^(j + d) = offset^j * c: the common factor follows below
+                if (A.pre_scale) {
 #pragma unroll
                     for (int i = 0; i < 8; i += 4) {
                         const u64 a4[4] = {w[i], w[i + 1], w[i + 2], w[i + 3]}, b4[4] = {pc, pc, pc, pc};
@@ -558,11 +551,42 @@ __global__ void __launch_bounds__(512, TF_NTT_WAVES) ntt_pass_kernel(const NttPa
                     }
                 }
             }
+        };
+#if TF_PRE2_BURST16
+#pragma unroll
+        for (int h0 = 0; h0 < 32; h0 += 16) {
+#pragma unroll
+            for (int q = h0; q < h0 + 16; ++q) x[q] = ld(slot_off(q));
+            u64 wa[8], wb[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) wa[i] = ld(slot_off(h0 + i) + poff);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) wb[i] = ld(slot_off(h0 + 8 + i) + poff);
+            scale8(wa);
+            scale8(wb);
+            if (h0 == 0) {
+                pre2_combine8<INV, 0>(x, wa, half != 0);
+                pre2_combine8<INV, 8>(x, wb, half != 0);
+            } else {
+                pre2_combine8<INV, 16>(x, wa, half != 0);
+                pre2_combine8<INV, 24>(x, wb, half != 0);
+            }
+        }
+#else
+#pragma unroll
+        for (int q = 0; q < 32; ++q) x[q] = ld(slot_off(q));
+#pragma unroll
+        for (int q0 = 0; q0 < 32; q0 += 8) {
+            u64 w[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) w[i] = ld(slot_off(q0 + i) + poff);
+            scale8(w);
             if (q0 == 0) pre2_combine8<INV, 0>(x, w, half != 0);
             else if (q0 == 8) pre2_combine8<INV, 8>(x, w, half != 0);
             else if (q0 == 16) pre2_combine8<INV, 16>(x, w, half != 0);
             else pre2_combine8<INV, 24>(x, w, half != 0);
         }
+#endif
     } else if (act_in) {
         const u32 toff = (u32)(((long long)ch_in * A.in_cs_hi + cl_in + (long long)g_in * A.in_rs) * 8);
         const char* base = reinterpret_cast<const char*>(in);
