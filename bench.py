@@ -190,6 +190,14 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
         dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+        # bring the communicator up NOW (RCCL builds its rings lazily inside the first collective: hundreds of milliseconds with
+        # the GPU idle).  Left to the barrier in front of the timed region that idle period lets the clocks drop and the first timed
+        # steps run cold: measured on one GPU with --force-dist, 1.97 ms per step over the 20 timed steps against 1.85 ms for the ten
+        # steps after them (profiles/r03_bench_forcedist_before.json)
+        _w = torch.zeros(1, dtype=torch.float64, device=dev)
+        dist.all_reduce(_w, op=dist.ReduceOp.MAX)
+        dist.barrier()
+        torch.cuda.synchronize()
 
     def barrier():
         if use_dist:
