@@ -3,7 +3,8 @@
 // What the reference computes (twenty-first/src/math/ntt.rs:67-82, :109-125, :153-228):
 //   out[k] = sum_j x[j] * w_n^(j k)   (natural order in and out; intt uses w^-1 and scales by n^-1)
 // as log2(n) radix-2 sweeps over the whole slice.  Here the same transform is a generalized
-// Cooley-Tukey factorisation n = N_1 * ... * N_s (s <= 3, N_i <= 1024), one HBM pass per factor:
+// Cooley-Tukey factorisation n = N_1 * ... * N_s (s <= 4, N_i <= 1024 -- or 2048, run as pairs of 1024-point workgroups that
+// share their input: PRE2 below, the two-pass plan of 2^21 / 2^22 points), one HBM pass per factor:
 //
 //   pass i (not last):  for every (k_1..k_{i-1}, j_{i+1}..j_s):  DFT over j_i, then multiply by the
 //                       inter-pass twiddle w_{N_i...N_s}^(k_i * b_i); data stays in place.
@@ -327,7 +328,7 @@ __device__ __forceinline__ void pre2_combine8(u64 (&x)[32], const u64 (&w)[8], b
     constexpr int Q = Q0 + I;
     if (odd) {
         x[Q] = Pre2Slot<INV, Q>::neg ? gl::sub(w[I], x[Q]) : gl::sub(x[Q], w[I]);
-    } else if constexpr (Q & 1) {
+    } else if constexpr ((Q & 1) || !TF_LAZY) {  // (an all-canonical A/B build, TF_LAZY = 0, keeps every sum canonical)
         x[Q] = gl::add(x[Q], w[I]);
     } else {
         const u64 s = x[Q] + w[I];
