@@ -355,6 +355,9 @@ void tf_set_ntt_two_pass(int mode);
  * elements per thread, radix-8 stages through LDS) instead of the 32-elements-per-thread pass kernels; -1 =
  * automatic (default; TF_NTT_NO_LAT disables), 0 = never, 1 = whenever the shape allows.  Same words either way. */
 void tf_set_ntt_latency_kernel(int mode);
+/* A/B hook: the R = 1024 column pass as a chain of k tiles per workgroup, the next tile's loads issued inside the store phase of
+ * the current one (0 / 1: one tile per workgroup; environment: TF_NTT_PERSIST).  Same words. */
+void tf_set_ntt_chain(int tiles_per_workgroup);
 int tf_ntt_launch_count(size_t n, size_t batch, int width);
 /* Planner introspection (no device needed): number of global passes of one n-point transform (0 for lengths ntt rejects)
  * and log2 of each pass's radix in log2_radix_out[0..3] (unused entries 0).  The radices multiply to n. */

@@ -126,6 +126,7 @@ SIGNATURES = {
     "tf_set_ntt_small_launch": (None, [C.c_int]),
     "tf_set_ntt_two_pass": (None, [C.c_int]),
     "tf_set_ntt_latency_kernel": (None, [C.c_int]),
+    "tf_set_ntt_chain": (None, [C.c_int]),
     "tf_debug_stamps": (C.c_int, [_vp, _sz]),
     "tf_debug_sclk_mhz": (C.c_double, []),
     "tf_set_ntt_tile_bytes": (None, [_sz]),

@@ -854,6 +854,143 @@ __global__ void __launch_bounds__(512, TF_NTT_WAVES) ntt_pass_kernel(const NttPa
     }
 }
 
+// ---- the R = 1024 column pass with the NEXT tile's loads issued inside the store phase -----------------------------------
+// ntt_pass_kernel's R1024 instantiation, plain transform, as a loop over `tiles_per_wg` tiles (tile, tile + gridDim.x, ...): the
+// eight registers a store group frees are filled at once with the next tile's loads, so a workgroup's load latency (a fifth of a
+// wave's lifetime in the one-tile kernel) runs under its own stores and under the partner workgroup's arithmetic instead of in
+// front of its first butterfly.  Few tiles per workgroup keep the dispatcher's dynamic balancing (a fully static assignment
+// measured slower in round 1).  Same arithmetic, same words.  Selected by TF_NTT_PERSIST = tiles per workgroup (A/B).
+template <bool INV>
+__global__ void __launch_bounds__(512, TF_NTT_WAVES) ntt_col1024_chain_kernel(const NttPassArgs A, u32 total_tiles, u32 tiles_per_wg) {
+    extern __shared__ __attribute__((aligned(16))) u64 lds[];
+    const int t = threadIdx.x, g = t >> 4, c = t & 15;
+    const int L = A.L;
+    u64* const ltw = lds + 32 * kR1024S1;
+    for (int i = t; i < 1024; i += 512) ltw[(i >> 5) * kLdsTwStride + (i & 31)] = A.inner_tw[i];
+    __syncthreads();
+    const int ch = (int)div_by_L((u32)c, L), cl = c - ch * L;
+    // per-tile quantities: input / output bases, the element column of my word-column, whether my column exists
+    struct Tile {
+        const u64* in;
+        u64* out;
+        long long bcol;
+        bool act;
+    };
+    const auto decode = [&](u32 bid) {
+        u32 i0, i1, i2;
+        if (A.xcd_order) {
+            const u32 G = (u32)A.xcd_order, xcd = bid & 7u, slot = bid >> 3, ngrp = A.d2 / (8u * G);
+            const u32 grp = A.xcd_colfast ? slot % ngrp : slot / (G * A.d01);
+            const u32 within = A.xcd_colfast ? slot / ngrp : slot % (G * A.d01);
+            i2 = ((grp << 3) | xcd) * G + within % G;
+            const u32 rest = within / G;
+            i1 = rest % A.d1;
+            i0 = rest / A.d1;
+        } else {
+            i2 = bid % A.d2;
+            const u32 rest = bid / A.d2;
+            i1 = rest % A.d1;
+            i0 = rest / A.d1;
+        }
+        Tile T;
+        T.in = A.in + (long long)i0 * A.ib0 + (long long)i1 * A.ib1 + (long long)i2 * A.ib2;
+        T.out = A.out + (long long)i0 * A.ob0 + (long long)i1 * A.ob1 + (long long)i2 * A.ob2;
+        const int col0 = (int)i2 * kR1024Nc;
+        T.act = c < min(kR1024Nc, A.col_limit - col0);
+        T.bcol = (long long)div_by_L((u32)(col0 + c), L);
+        return T;
+    };
+    const u32 toff_in = (u32)(((long long)ch * A.in_cs_hi + cl + (long long)g * A.in_rs) * 8);
+    const u32 toff_out = (u32)(((long long)ch * A.out_cs_hi + cl + (long long)g * A.out_rs) * 8);
+    const int myround = c >> 3, cc = c & 7;
+    u64* const wr = lds + g * kR1024Cpr + cc;
+    const u64* const rd = lds + cc + g * kR1024S1;
+    u64 x[32];
+#pragma unroll
+    for (int q = 0; q < 32; ++q) x[q] = 0;
+    u32 bid = blockIdx.x;
+    Tile cur = decode(bid);
+    if (cur.act) {
+        const __amdgpu_buffer_rsrc_t ri = buf_rsrc(cur.in);
+#pragma unroll
+        for (int q = 0; q < 32; ++q) x[q] = buf_load<TF_LOAD_AUX>(ri, toff_in, (u32)((long long)(brev5(q) << 5) * A.in_rs * 8));
+    }
+#pragma unroll 1
+    for (u32 k = 0;; ++k) {
+        // ---- step 1
+        dit_half<INV, 0, true>(x);
+        __builtin_amdgcn_sched_barrier(0);
+        dit_half<INV, 16, true>(x);
+        dit_level<INV, 5, true>(x);
+        {
+            const u64* tw = ltw + g * kLdsTwStride;
+#pragma unroll
+            for (int q = 0; q < 32; q += 4) mul4_inplace(x, q, tw[q], tw[q + 1], tw[q + 2], tw[q + 3]);
+        }
+        // ---- exchange (two rounds of eight columns); the barrier in front also separates it from the previous tile's reads
+        if (k) __syncthreads();
+#pragma unroll 1
+        for (int r = 0; r < kR1024Rounds; ++r) {
+            if (r) __syncthreads();
+            if (myround == r) {
+#pragma unroll
+                for (int q = 0; q < 32; ++q) wr[q * kR1024S1] = x[q];
+            }
+            __syncthreads();
+            if (myround == r) {
+#pragma unroll
+                for (int q = 0; q < 32; ++q) x[q] = rd[brev5(q) * kR1024Cpr];
+            }
+        }
+        // ---- step 2
+        dit_level<INV, 1, true>(x);
+        dit_level<INV, 2, true>(x);
+        dit_level<INV, 3, true>(x);
+        dit_level<INV, 4, true>(x);
+        dit_level<INV, 5, true>(x);
+        // ---- inter-pass twiddles, stores, and the next tile's loads into the registers the stores free
+        const u32 nbid = bid + gridDim.x;
+        const bool has_next = k + 1 < tiles_per_wg && nbid < total_tiles;  // uniform
+        Tile nxt = cur;
+        if (has_next) nxt = decode(nbid);
+        if (cur.act) {
+            const u32 twoff = (u32)(((long long)g * A.tw_rs + cur.bcol) * 8);
+            const __amdgpu_buffer_rsrc_t rt = buf_rsrc(A.post_tw), ro = buf_rsrc(cur.out), rn = buf_rsrc(nxt.in);
+#pragma unroll
+            for (int q0 = 0; q0 < 32; q0 += 8) {
+                u64 w[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) w[i] = buf_load_tab(rt, twoff, (u32)((long long)((q0 + i) << 5) * A.tw_rs * 8));
+#pragma unroll
+                for (int i = 0; i < 8; i += 4) {
+                    const int q = q0 + i;
+                    const u64 a4[4] = {x[q], x[q + 1], x[q + 2], x[q + 3]}, b4[4] = {w[i], w[i + 1], w[i + 2], w[i + 3]};
+                    u64 r4[4];
+                    gl::mont_mul4(a4, b4, r4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) buf_store<TF_AUX_COL_STORE>(ro, toff_out, (u32)((long long)((q + e) << 5) * A.out_rs * 8), r4[e]);
+                }
+                if (has_next && nxt.act) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) x[q0 + i] = buf_load<TF_LOAD_AUX>(rn, toff_in, (u32)((long long)(brev5(q0 + i) << 5) * A.in_rs * 8));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else if (has_next && nxt.act) {
+            const __amdgpu_buffer_rsrc_t rn = buf_rsrc(nxt.in);
+#pragma unroll
+            for (int q = 0; q < 32; ++q) x[q] = buf_load<TF_LOAD_AUX>(rn, toff_in, (u32)((long long)(brev5(q) << 5) * A.in_rs * 8));
+        }
+        if (!has_next) break;
+        if (!nxt.act) {
+#pragma unroll
+            for (int q = 0; q < 32; ++q) x[q] = 0;
+        }
+        bid = nbid;
+        cur = nxt;
+    }
+}
+
 // ---- 2^11 <= n <= 2^14, contiguous BFieldElement transforms: the WHOLE transform in one workgroup pass --------------
 // 16 384 elements are exactly one 512-thread tile, so n = 32 * 32 * P3 (P3 = 2 .. 16) runs as three register stages joined by
 // two LDS exchanges and touches HBM once instead of twice:

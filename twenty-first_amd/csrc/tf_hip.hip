@@ -899,6 +899,37 @@ int launch_pass_t(const Launch& l, hipStream_t stream) {
     return TF_OK;
 }
 
+// the R = 1024 column pass as a chain of `k` tiles per workgroup with the next tile's loads inside the store phase
+// (ntt_col1024_chain_kernel); k from TF_NTT_PERSIST / tf_set_ntt_chain (0 or 1: the one-tile kernel)
+std::atomic<int> g_chain{-1};
+int chain_tiles() {
+    int v = g_chain.load(std::memory_order_relaxed);
+    if (v < 0) {
+        const char* e = getenv("TF_NTT_PERSIST");
+        v = e ? std::max(0, atoi(e)) : 0;
+        g_chain.store(v, std::memory_order_relaxed);
+    }
+    return v;
+}
+template <bool INV>
+int launch_chain_t(const Launch& l, int k, hipStream_t stream) {
+    static std::atomic<unsigned long long> done_mask{0};
+    int dev = 0;
+    HIPCHK(hipGetDevice(&dev));
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(done_mask.load(std::memory_order_acquire) & bit)) {
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&tfk::ntt_col1024_chain_kernel<INV>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        done_mask.fetch_or(bit, std::memory_order_release);
+    }
+    const size_t lds_bytes = l.lds_bytes + size_t(32) * tfk::kLdsTwStride * sizeof(u64);
+    unsigned grid = (l.tiles + (unsigned)k - 1) / (unsigned)k;
+    grid = (grid + 7u) & ~7u;  // block id mod 8 is the XCD: tile, tile + grid, ... stay on one XCD
+    grid = std::min(grid, l.tiles);
+    hipLaunchKernelGGL((tfk::ntt_col1024_chain_kernel<INV>), dim3(grid), dim3(512), lds_bytes, stream, l.a, l.tiles, (unsigned)k);
+    HIPCHK(hipGetLastError());
+    return TF_OK;
+}
+
 unsigned long long* g_dbg_buf = nullptr;  // TF_NTT_ABLATE=3: per-wave phase stamps of the last launch (tf_debug_stamps)
 constexpr size_t kLast1024LdsBytes = (size_t(tfk::kL1024ExchangeWords) + (TF_LDS_TW ? 32 * tfk::kLdsTwStride : 0)) * sizeof(u64);
 
@@ -974,6 +1005,8 @@ int launch_pass(const Launch& l, bool inverse, hipStream_t stream) {
     }
     // any other column pass whose offsets fit: the same treatment with a run-time P2 (COL)
     const bool col = l.a.post_tw && !r1024 && fits && !l.a.gfast && g_ablate == 0 && col_enabled();
+    if (r1024 && chain_tiles() > 1 && l.tiles >= 1024 && !l.a.dbg)
+        return inverse ? launch_chain_t<true>(l, chain_tiles(), stream) : launch_chain_t<false>(l, chain_tiles(), stream);
     if (inverse) return r1024 ? launch_pass_t<true, 0, 0, false, true>(l, stream)
                               : (col ? launch_pass_t<true, 0, 0, false, false, true>(l, stream) : launch_pass_t<true, 0, 0>(l, stream));
     if (r1024) return launch_pass_t<false, 0, 0, false, true>(l, stream);
@@ -3373,6 +3406,7 @@ int tf_debug_stamps(unsigned long long* host_out, size_t words) {
 }
 
 void tf_set_ntt_min_passes(int passes) { g_min_passes.store(passes, std::memory_order_relaxed); }
+void tf_set_ntt_chain(int tiles_per_workgroup) { g_chain.store(std::max(0, tiles_per_workgroup), std::memory_order_relaxed); }
 void tf_set_ntt_latency_kernel(int mode) { g_lat_mode.store(mode < 0 ? -1 : (mode ? 1 : 0), std::memory_order_relaxed); }
 void tf_set_ntt_two_pass(int mode) { g_pre2_mode.store(mode < 0 ? -1 : (mode ? 1 : 0), std::memory_order_relaxed); }
 void tf_set_ntt_small_launch(int mode) { g_small_launch_mode.store(mode < 0 ? -1 : (mode ? 1 : 0), std::memory_order_relaxed); }
