@@ -1427,9 +1427,9 @@ struct NttLat2Args {
     int tiles_per_entry;       // ceil(lines / T)
 };
 
-template <int LOGN, bool INV, bool LAST>
-__global__ void __launch_bounds__(256) ntt_lat2_kernel(const NttLat2Args A) {
-    constexpr int N = 1 << LOGN, TPT = N / 8, WG = 256, T = WG / TPT;
+template <int LOGN, bool INV, bool LAST, int WG = 256>
+__global__ void __launch_bounds__(WG) ntt_lat2_kernel(const NttLat2Args A) {
+    constexpr int N = 1 << LOGN, TPT = N / 8, T = WG / TPT;
     constexpr int S = (LOGN + 2) / 3, LOGRL = LOGN - 3 * (S - 1);
     constexpr int BUF = lat_pad(N * T) + 8;
     static_assert(LOGN >= 6 && LOGN <= 10, "");

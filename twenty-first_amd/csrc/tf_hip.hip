@@ -1225,14 +1225,24 @@ int launch_lat(DeviceCtx* ctx, const u64* in, u64* out, long long in_bs, long lo
 }
 
 // ---- 2^13 .. 2^20 points with little work: the two passes of n = N1 N2 on the eight-elements-per-thread stages (ntt_lat2_kernel)
-template <int LOGN, bool INV, bool LAST>
+template <int LOGN, bool INV, bool LAST, int WG = 256>
 int launch_lat2_t(const tfk::NttLat2Args& a, size_t batch, hipStream_t stream) {
-    constexpr int N = 1 << LOGN, T = 256 / (N / 8);
+    constexpr int N = 1 << LOGN, T = WG / (N / 8);
     constexpr size_t lds = size_t(2) * (tfk::lat_pad(N * T) + 8) * sizeof(u64);
+    if constexpr (lds > 48 * 1024) {
+        static std::atomic<unsigned long long> done_mask{0};
+        int dev = 0;
+        HIPCHK(hipGetDevice(&dev));
+        const unsigned long long bit = 1ull << (dev & 63);
+        if (!(done_mask.load(std::memory_order_acquire) & bit)) {
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&tfk::ntt_lat2_kernel<LOGN, INV, LAST, WG>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            done_mask.fetch_or(bit, std::memory_order_release);
+        }
+    }
     tfk::NttLat2Args b = a;
     b.tiles_per_entry = (int)((a.lines + T - 1) / T);
     const long long blocks = (long long)batch * b.tiles_per_entry;
-    hipLaunchKernelGGL((tfk::ntt_lat2_kernel<LOGN, INV, LAST>), dim3((unsigned)blocks), dim3(256), lds, stream, b);
+    hipLaunchKernelGGL((tfk::ntt_lat2_kernel<LOGN, INV, LAST, WG>), dim3((unsigned)blocks), dim3(WG), lds, stream, b);
     HIPCHK(hipGetLastError());
     return TF_OK;
 }
@@ -1243,7 +1253,11 @@ int launch_lat2_dir(int log_n, const tfk::NttLat2Args& a, size_t batch, hipStrea
         case 7: return launch_lat2_t<7, INV, LAST>(a, batch, s);
         case 8: return launch_lat2_t<8, INV, LAST>(a, batch, s);
         case 9: return launch_lat2_t<9, INV, LAST>(a, batch, s);
-        case 10: return launch_lat2_t<10, INV, LAST>(a, batch, s);
+        case 10: {
+            // 1024-point lines: 512-thread workgroups take four lines instead of two (32-byte segments on the column side)
+            static const bool wide = getenv("TF_NTT_LAT2_NO_WIDE") == nullptr;  // A/B switch
+            return wide ? launch_lat2_t<10, INV, LAST, 512>(a, batch, s) : launch_lat2_t<10, INV, LAST>(a, batch, s);
+        }
     }
     return TF_ERR_HIP;
 }
@@ -1260,7 +1274,7 @@ bool lat2_wanted(int log_n, size_t batch, int L) {
     // measured crossover against the pass / block kernels, words per call (tools/lat_sweep.py 13 20, profiles/r03_lat2_sweep_*.txt):
     // one 2^16-point slice 33 -> 16 us; the win ends where the chip fills, and earlier for the longest lines (a 1024-point line
     // leaves two lines per workgroup: 16-byte segments)
-    static const long long lim1[8] = {1ll << 21, 1ll << 21, 1ll << 21, 1ll << 21, 1ll << 21, 1ll << 20, 1ll << 19, 0};  // log_n = 13 .. 20
+    static const long long lim1[8] = {1ll << 21, 1ll << 21, 1ll << 21, 1ll << 21, 1ll << 21, 1ll << 20, 1ll << 20, 1ll << 20};  // log_n = 13 .. 20
     static const long long lim3[8] = {3ll << 20, 3ll << 20, 3ll << 19, 3ll << 20, 3ll << 19, 3ll << 18, 0, 0};
     const long long limit = env_limit ? env_limit : (L == 1 ? lim1 : lim3)[log_n - 13];
     return (long long)(batch * size_t(L)) << log_n <= limit;
