@@ -1280,6 +1280,22 @@ struct NttLatArgs {
     long long total;       // limb transforms = batch * L
     u64 ninv;              // Montgomery n^-1 (inverse only)
     int L;
+    // ---- the steps of a zerofier-tree walk that used to be kernels of their own, as modifiers of this kernel's load and store
+    // (math/zerofier_tree.rs / polynomial.rs:1882-1894 remaindering; the tree code in tf_hip.hip says which step is which)
+    int load_mode;         // 0: element idx of slice b is in[b * in_bs + idx * L]
+                           // 1: REVERSED: in[(b >> src_shift) * in_bs + (rev_top - idx) * L] for idx < n_coeffs (poly_reverse /
+                           //    remainder_rev_high fused into the forward transform that follows them)
+                           // 2: (L = 1) the interpolation walk's parent N_l (Z_r + s) + N_r (Z_l + s), s = (-1)^idx, from the children's
+                           //    transforms in[2 b], in[2 b + 1] and the level's cached tail transforms th[2 node], th[2 node + 1],
+                           //    node = b % parents (interpolant_pointwise_kernel fused into the inverse transform that follows it)
+    int src_shift;
+    long long rev_top;
+    const u64* th;
+    long long parents;
+    int store_mode;        // 0: all n outputs; 1: only outputs k < keep, stored as  sub_src[(b >> 1) * sub_bs + k * L] - value
+                           //    (remainder_finish_kernel fused into the inverse transform in front of it: r = f_low - (q * tail)_low)
+    const u64* sub_src;
+    long long sub_bs, keep;
 };
 __host__ __device__ __forceinline__ constexpr int lat_pad(int i) { return i + (i >> 3); }
 template <int LOGR>
@@ -1339,7 +1355,15 @@ __global__ void __launch_bounds__(LOGN == 12 ? 512 : 256) ntt_lat_kernel(const N
         for (int r = 0; r < 8; ++r) {
             const int idx = j + r * TPT;
             u64 v = 0;
-            if (A.n_coeffs < 0 || idx < A.n_coeffs) {
+            if (A.load_mode == 1) {
+                if (idx < A.n_coeffs) v = (A.in + (b >> A.src_shift) * A.in_bs + limb)[(A.rev_top - idx) * L];
+            } else if (A.load_mode == 2) {
+                const u64* c0 = A.in + 2 * b * A.in_bs;
+                const u64* t0 = A.th + 2 * (b % A.parents) * A.in_bs;
+                const u64 sgn = (idx & 1) ? gl::P - gl::ONE : gl::ONE;
+                const u64 zl = gl::add(t0[idx], sgn), zr = gl::add(t0[A.in_bs + idx], sgn);
+                v = gl::add(gl::mont_mul(c0[idx], zr), gl::mont_mul(c0[A.in_bs + idx], zl));
+            } else if (A.n_coeffs < 0 || idx < A.n_coeffs) {
                 v = src[(long long)idx * L];
                 if (A.in2) v = gl::mont_mul(v, (A.in2 + b * A.in_bs + limb)[(long long)idx * L]);
             }
@@ -1389,7 +1413,13 @@ __global__ void __launch_bounds__(LOGN == 12 ? 512 : 256) ntt_lat_kernel(const N
             for (int r = 0; r < R; ++r) {
                 const int idx = j0 + r * Ns;
                 if (last) {
-                    if (act) dst[(long long)idx * L] = x[a * R + r];
+                    if (act) {
+                        if (A.store_mode == 1) {
+                            if (idx < A.keep) dst[(long long)idx * L] = gl::sub((A.sub_src + (b >> 1) * A.sub_bs + limb)[(long long)idx * L], x[a * R + r]);
+                        } else {
+                            dst[(long long)idx * L] = x[a * R + r];
+                        }
+                    }
                 } else {
                     o[lat_pad(tr * N + idx)] = x[a * R + r];
                 }

@@ -1200,15 +1200,18 @@ bool lat_wanted(int log_n, size_t batch, int L) {
     if (mode == 1) return true;
     return (long long)(batch * size_t(L)) << log_n <= limit;
 }
+// mods (tree walks only): the load / store modifier fields of NttLatArgs; such calls are one launch (batch < 2^22)
 int launch_lat(DeviceCtx* ctx, const u64* in, u64* out, long long in_bs, long long out_bs, int log_n, size_t batch, int L, bool inverse,
-               long long n_coeffs, const u64* in2, hipStream_t stream) {
+               long long n_coeffs, const u64* in2, hipStream_t stream, const tfk::NttLatArgs* mods = nullptr) {
     const u64* tw = nullptr;
     int rc = get_lat_table(ctx, log_n, inverse, &tw);
     if (rc) return rc;
     const size_t max_batch = size_t(1) << 22;  // 2^31 threads per launch at most
+    if (mods && batch > max_batch) return TF_ERR_HIP;
     for (size_t b0 = 0; b0 < batch && !rc; b0 += max_batch) {
         const size_t nb = std::min(max_batch, batch - b0);
         tfk::NttLatArgs a{};
+        if (mods) a = *mods;
         a.in = in + (long long)b0 * in_bs;
         a.out = out + (long long)b0 * out_bs;
         a.in2 = in2 ? in2 + (long long)b0 * in_bs : nullptr;
@@ -2398,6 +2401,16 @@ int inverse_of_cached_product(DeviceCtx* ctx, const u64* a_hat, const u64* b_hat
     return run_ntt(ctx, out, out, (long long)order * L, (long long)order * L, order, batch * (size_t)U, L, true, nullptr, -1, s);
 }
 
+// The elementwise steps of a walk (reverse, remainder, the interpolation's pointwise combination) ride on the load / store of the
+// latency-shaped transform next to them whenever that kernel serves the level (round 3): a level of the walk down is 4 launches
+// instead of 7, of the walk up 2 instead of 3.  TF_TREE_NO_FUSE keeps them as kernels of their own (A/B, tests).
+bool tree_fuse(long long order, long long lines, int L) {
+    static const bool off = getenv("TF_TREE_NO_FUSE") != nullptr;
+    if (off || order > 4096 || order < 64 || g_min_passes.load(std::memory_order_relaxed) != 0) return false;
+    if (lines >= (1ll << 22)) return false;
+    return lat_wanted(ilog2((size_t)order), (size_t)lines, L);
+}
+
 // F: U units of exactly M coefficients each (zero padded), walking the tree together; vals: U x M values (the first n_points of
 // every unit are meaningful); work: kTreeWorkArrays * U * M * L words.
 template <int L>
@@ -2420,8 +2433,32 @@ int zerofier_tree_evaluate(DeviceCtx* ctx, const ZerofierTree& T, const u64* F, 
         const long long d = (long long)kTreeLeaf << l, children = M / d, all = U * children;  // (children is even: global child / 2 = global parent)
         // rev(q) = rev(f_high) g mod x^d   (below the top level the reversed upper halves come from the level above's last kernel)
         int rc = TF_OK;
+        u64* nxt = (cur == ping) ? pong : ping;
+        if (tree_fuse(2 * d, all, L)) {
+            // the same steps with the reversals read on load and the remainder formed on store (ntt_lat_kernel's modifiers)
+            const int lg = ilog2((size_t)(2 * d));
+            tfk::NttLatArgs m{};
+            m.load_mode = 1, m.src_shift = 1, m.rev_top = 2 * d - 1;  // line `child` <- reversed upper half of its parent's remainder
+            rc = launch_lat(ctx, cur, Fh, 2 * d * L, 2 * d * L, lg, (size_t)all, L, false, d, nullptr, s, &m);
+            if (!rc) rc = inverse_of_cached_product<L>(ctx, Fh, T.Ghat[l], prod, (size_t)(2 * d), (size_t)children, U, s);
+            m.src_shift = 0, m.rev_top = d - 1;                        // q = the reversed low half of that product
+            if (!rc) rc = launch_lat(ctx, prod, Fh, 2 * d * L, 2 * d * L, lg, (size_t)all, L, false, d, nullptr, s, &m);
+            // r = f_low - (q tail)_low: the product's inverse transform stores f_low - value for the low d outputs only
+            tfk::NttLatArgs st{};
+            st.store_mode = 1, st.sub_src = cur, st.sub_bs = 2 * d * L, st.keep = d;
+            if (!rc && U == 1 && L == 1) {
+                rc = launch_lat(ctx, Fh, nxt, 2 * d, d, lg, (size_t)all, 1, true, -1, T.That[l], s, &st);
+            } else if (!rc) {
+                if (U == 1) rc = hadamard_dev(Fh, T.That[l], prod, (size_t)(all * 2 * d), L, s);
+                else rc = launch_1d<L>(tfk::product_bcast_kernel<L>, all * 2 * d, s, (const u64*)Fh, (const u64*)T.That[l], prod, children * 2 * d, all * 2 * d);
+                if (!rc) rc = launch_lat(ctx, prod, nxt, 2 * d * L, d * L, lg, (size_t)all, L, true, -1, nullptr, s, &st);
+            }
+            if (rc) return rc;
+            cur = nxt;
+            continue;
+        }
         const u64* fr_in = frq;
-        if (l == T.h - 1) {
+        if (l == T.h - 1 || tree_fuse(4 * d, all / 2, L)) {  // (a fused level above this one did not write frq)
             rc = launch_1d<L>(tfk::remainder_rev_high_kernel<L>, all * d, s, cur, fr, d, all);
             fr_in = fr;
         }
@@ -2432,7 +2469,6 @@ int zerofier_tree_evaluate(DeviceCtx* ctx, const ZerofierTree& T, const u64* F, 
         if (!rc) rc = run_ntt(ctx, fr, Fh, d * L, 2 * d * L, (size_t)(2 * d), (size_t)all, L, false, nullptr, d, s);
         if (!rc) rc = inverse_of_cached_product<L>(ctx, Fh, T.That[l], prod, (size_t)(2 * d), (size_t)children, U, s);
         if (rc) return rc;
-        u64* nxt = (cur == ping) ? pong : ping;
         rc = launch_1d<L>(tfk::remainder_finish_kernel<L>, all * d, s, cur, (const u64*)prod, 2 * d, nxt, d, all, l > l_stop ? frq : (u64*)nullptr);
         if (rc) return rc;
         cur = nxt;
@@ -2782,9 +2818,20 @@ int tree_interpolate_rows(DeviceCtx* ctx, const PaddedTree& pt, const u64* domai
             // in the next level's layout
             const long long d = (long long)kTreeLeaf << l, children = M / d, parents = children / 2;
             rc = run_ntt(ctx, cur, Nh, d * L, 2 * d * L, (size_t)(2 * d), (size_t)(children * (long long)nr), L, false, nullptr, d, s);
-            if (!rc) rc = launch_1d<L>(tfk::interpolant_pointwise_kernel<L>, (long long)nr * parents * 2 * d, s, (const u64*)Nh,
-                                       (const u64*)pt.T.That[l], nxt, d, parents, (long long)nr);
-            if (!rc) rc = run_ntt(ctx, nxt, nxt, 2 * d * L, 2 * d * L, (size_t)(2 * d), (size_t)(parents * (long long)nr), L, true, nullptr, -1, s);
+            // (measured, tools/tree_latency.py on one box: prepared-tree interpolation of 2^12 points 129.0 us with the pointwise
+            //  kernel, 135.8 us with it fused -- four strided loads and two products per element in front of the transform's first
+            //  stage cost more than the 1.5 us a pipelined elementwise launch really adds; off unless TF_TREE_FUSE_INTERP is set)
+            static const bool fuse_interp = getenv("TF_TREE_FUSE_INTERP") != nullptr;
+            if (!rc && L == 1 && fuse_interp && tree_fuse(2 * d, parents * (long long)nr, 1)) {
+                // the pointwise combination rides on the load of the inverse transform (ntt_lat_kernel, load_mode 2)
+                tfk::NttLatArgs m{};
+                m.load_mode = 2, m.th = pt.T.That[l], m.parents = parents;
+                rc = launch_lat(ctx, Nh, nxt, 2 * d, 2 * d, ilog2((size_t)(2 * d)), (size_t)(parents * (long long)nr), 1, true, -1, nullptr, s, &m);
+            } else {
+                if (!rc) rc = launch_1d<L>(tfk::interpolant_pointwise_kernel<L>, (long long)nr * parents * 2 * d, s, (const u64*)Nh,
+                                           (const u64*)pt.T.That[l], nxt, d, parents, (long long)nr);
+                if (!rc) rc = run_ntt(ctx, nxt, nxt, 2 * d * L, 2 * d * L, (size_t)(2 * d), (size_t)(parents * (long long)nr), L, true, nullptr, -1, s);
+            }
             std::swap(cur, nxt);
         }
         if (!rc) {
