@@ -36,6 +36,10 @@ run "TF_NTT_NO_LAT=1" "no latency-shaped kernels: small calls on the pass / bloc
 run "TF_NTT_NO_LAT2=1" "latency-shaped kernel for 64..4096 points only, not the two-pass latency plan (round 3)"
 run "TF_NTT_LAT_MAX_WORDS=1073741824 TF_NTT_LAT2_MAX_WORDS=1073741824" "latency-shaped kernels for every call they can serve, whatever its size"
 run "TF_TREE_INTERP_LEAF_LOG=8" "trees that are walked upwards with 256-point leaves as in round 2"
+run "TF_TREE_NO_FUSE=1" "tree walks with the reverse / remainder steps as kernels of their own (round 3)"
+run "TF_TREE_FUSE_INTERP=1" "the interpolation's pointwise combination fused into the inverse transform's load (round 3, off by default)"
+run "TF_NTT_PERSIST=4" "the R = 1024 column pass as chains of four tiles per workgroup (round 3, off by default)"
+run "TF_NTT_LAT2_NO_WIDE=1" "256-thread slices for the 1024-point lines of the latency plan (round 3)"
 run "TF_BATCH_EVAL=tree" "zerofier tree wherever it applies"
 run "TF_BATCH_EVAL=horner" "Horner everywhere"
 run "TF_BATCH_EVAL=tree TF_TREE_UNIT_SLAB=3000" "zerofier tree with the units of a walk cut into slabs of a few units"
