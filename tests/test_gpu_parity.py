@@ -821,3 +821,30 @@ def test_latency_shaped_two_pass_plan_matches_oracle(tf, oracle, log_n, width, b
     assert np.array_equal(got[0], got[1])
     if log_n <= 16:
         assert np.array_equal(got[1], oracle.poly_mul(a, b, width=width))
+
+
+def test_chained_column_pass_gives_the_same_words(tf, oracle):
+    """tf_set_ntt_chain: the R = 1024 column pass as chains of k tiles per workgroup with the next tile's loads issued inside the
+    store phase (an A/B path, slower) -- 128 transforms of 2^20 points (2048 tiles per launch), k = 2, 3, 8, against
+    the one-tile kernel word for word, and the first two transforms against the oracle."""
+    import torch
+
+    lib = tf._lib.lib()
+    n, batch = 1 << 20, 128
+    src = torch.empty(n * batch, dtype=torch.int64, device="cuda")
+    tf.device.fill_random(src, 7100)
+    ref = src.clone()
+    tf.device.ntt_(ref, n, batch=batch)
+    torch.cuda.synchronize()
+    want = oracle.ntt(src[: 2 * n].cpu().numpy().view(np.uint64), batch=2, threads=2)
+    assert np.array_equal(ref[: 2 * n].cpu().numpy().view(np.uint64), want)
+    try:
+        for k in (2, 3, 8):
+            lib.tf_set_ntt_chain(k)
+            for inverse in (False, True):
+                x = (ref if inverse else src).clone()
+                tf.device.ntt_(x, n, batch=batch, inverse=inverse)
+                torch.cuda.synchronize()
+                assert torch.equal(x, src if inverse else ref), (k, inverse)
+    finally:
+        lib.tf_set_ntt_chain(0)
