@@ -336,11 +336,11 @@ __device__ __forceinline__ void pre2_combine8(u64 (&x)[32], const u64 (&w)[8], b
     }
     if constexpr (I + 1 < 8) pre2_combine8<INV, Q0, I + 1>(x, w, odd);
 }
-// x[Q] *= w_64^(brev5 Q) up to the sign pre2_combine8 already took care of: shifts only
-template <bool INV, int Q = 1>
+// x[Q] *= w_64^(brev5 Q) up to the sign pre2_combine8 already took care of: shifts only (slots Q .. END-1; slot 0 has exponent 0)
+template <bool INV, int Q = 1, int END = 32>
 __device__ __forceinline__ void pre2_shift(u64 (&x)[32]) {
     x[Q] = gl::Pow2Mul<Pre2Slot<INV, Q>::E>::apply(x[Q]);
-    if constexpr (Q + 1 < 32) pre2_shift<INV, Q + 1>(x);
+    if constexpr (Q + 1 < END) pre2_shift<INV, Q + 1, END>(x);
 }
 
 template <bool INV, int SCALE, int MODE = 0, bool LAST1024 = false, bool R1024 = false, bool COL = false, bool PRE2 = false>
@@ -536,7 +536,8 @@ __global__ void __launch_bounds__(512, TF_NTT_WAVES) ntt_pass_kernel(const NttPa
 #endif
         constexpr int AUX = TF_PRE2_LOAD_AUX;
 #ifndef TF_PRE2_BURST16
-#define TF_PRE2_BURST16 1  // 1: two bursts of 32 loads (16 slots and their 16 partners each); 0: 32 loads, then the partners eight at a time (A/B)
+#define TF_PRE2_BURST16 2  // 2: 48 loads (slots 0-15, their partners, slots 16-31), then the last 16 partners in flight under the first
+                           //    half's scaling / shifts / levels 1-4; 1: two bursts of 32 loads; 0: 32 loads, then the partners eight at a time (A/B)
 #endif
         const auto slot_off = [&](int q) { return (u32)((long long)(brev5(q) << p2) * A.in_rs * 8); };
         const auto ld = [&](u32 so) { return CHK ? buf_load<AUX>(ri, toff + so, 0) : buf_load<AUX>(ri, toff, so); };
@@ -553,7 +554,58 @@ __global__ void __launch_bounds__(512, TF_NTT_WAVES) ntt_pass_kernel(const NttPa
                 }
             }
         };
-#if TF_PRE2_BURST16
+        // (the overlapped order costs the coset-scaling instantiation 22 spilled VGPRs and 9 % -- profiles/r03_two_pass_ab.txt -- so
+        //  that one keeps the two plain bursts)
+        if constexpr (TF_PRE2_BURST16 == 2 && SCALE != 1) {
+            const auto scale_half = [&](int h0) {  // coefficient j times offset^j for slots h0 .. h0+15 (as the SCALE 1 block below does for 32)
+                if constexpr (SCALE == 1) {
+                    if (A.pre_scale) {
+                        const u64* ps = A.pre_scale + (long long)i1 * A.ps_i1;
+#pragma unroll
+                        for (int q0 = 0; q0 < 16; q0 += 8) {
+                            u64 w[8];
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) {
+                                const long long ur = (long long)(brev5(h0 + q0 + i) << p2);
+                                const long long j = (ur + g) * A.ps_rs + (A.ps_col ? bcol : 0);
+                                w[i] = ps[j < A.n_coeffs ? j : 0];
+                            }
+#pragma unroll
+                            for (int i = 0; i < 8; i += 4) mul4_inplace(x, h0 + q0 + i, w[i], w[i + 1], w[i + 2], w[i + 3]);
+                        }
+                    }
+                }
+            };
+#pragma unroll
+            for (int q = 0; q < 16; ++q) x[q] = ld(slot_off(q));
+            u64 wa[8], wb[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) wa[i] = ld(slot_off(i) + poff);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) wb[i] = ld(slot_off(8 + i) + poff);
+#pragma unroll
+            for (int q = 16; q < 32; ++q) x[q] = ld(slot_off(q));
+            scale8(wa);
+            scale8(wb);
+            pre2_combine8<INV, 0>(x, wa, half != 0);
+            pre2_combine8<INV, 8>(x, wb, half != 0);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) wa[i] = ld(slot_off(16 + i) + poff);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) wb[i] = ld(slot_off(24 + i) + poff);
+            __builtin_amdgcn_sched_barrier(0);
+            // the first half goes all the way through levels 1-4 while the last 16 partners are in flight
+            scale_half(0);
+            if (half) pre2_shift<INV, 1, 16>(x);
+            dit_half<INV, 0, LAZY1>(x);
+            __builtin_amdgcn_sched_barrier(0);
+            scale8(wa);
+            scale8(wb);
+            pre2_combine8<INV, 16>(x, wa, half != 0);
+            pre2_combine8<INV, 24>(x, wb, half != 0);
+            scale_half(16);
+            if (half) pre2_shift<INV, 16, 32>(x);
+        } else if constexpr (TF_PRE2_BURST16 != 0) {
 #pragma unroll
         for (int h0 = 0; h0 < 32; h0 += 16) {
 #pragma unroll
@@ -573,7 +625,7 @@ __global__ void __launch_bounds__(512, TF_NTT_WAVES) ntt_pass_kernel(const NttPa
                 pre2_combine8<INV, 24>(x, wb, half != 0);
             }
         }
-#else
+        } else {
 #pragma unroll
         for (int q = 0; q < 32; ++q) x[q] = ld(slot_off(q));
 #pragma unroll
@@ -587,7 +639,7 @@ __global__ void __launch_bounds__(512, TF_NTT_WAVES) ntt_pass_kernel(const NttPa
             else if (q0 == 16) pre2_combine8<INV, 16>(x, w, half != 0);
             else pre2_combine8<INV, 24>(x, w, half != 0);
         }
-#endif
+        }
     } else if (act_in) {
         const u32 toff = (u32)(((long long)ch_in * A.in_cs_hi + cl_in + (long long)g_in * A.in_rs) * 8);
         const char* base = reinterpret_cast<const char*>(in);
@@ -644,11 +696,11 @@ __global__ void __launch_bounds__(512, TF_NTT_WAVES) ntt_pass_kernel(const NttPa
             }
         }
     }
-    if constexpr (PRE2) {
+    if constexpr (PRE2 && !(TF_PRE2_BURST16 == 2 && SCALE != 1)) {
         if (half && act_in) pre2_shift<INV>(x);  // z_r = (x_r - x_{r+1024}) w_64^i; w_2048^g follows with the inner twiddle
     }
     __builtin_amdgcn_s_setprio(0);
-    if constexpr (MODE != 2) {
+    if constexpr (MODE != 2 && !(PRE2 && TF_PRE2_BURST16 == 2 && SCALE != 1)) {  // (the overlapped PRE2 load above has done this already: zeros stay zeros)
         // Levels 1-4 of the first 16 slots need only the first 16 loads: start on them while the second half of the
         // burst is still in flight (the levels below 5 never mix the two halves).  Measured: 2.56 -> 2.44 ms.
         dit_half<INV, 0, LAZY1>(x);
