@@ -2812,6 +2812,7 @@ int tree_interpolate_rows(DeviceCtx* ctx, const PaddedTree& pt, const u64* domai
         if (hipGetLastError() != hipSuccess) rc = TF_ERR_HIP;
         u64* cur = na;
         u64* nxt = nb;
+        bool wrote_direct = false;
         for (int l = 0; l < h && !rc; ++l) {
             // one level for all rows of the slab: transforms of order 2d of every child's interpolant against the level's cached
             // tail transforms, the combination N_left Z_right + N_right Z_left pointwise, one inverse transform -- which lands
@@ -2830,11 +2831,15 @@ int tree_interpolate_rows(DeviceCtx* ctx, const PaddedTree& pt, const u64* domai
             } else {
                 if (!rc) rc = launch_1d<L>(tfk::interpolant_pointwise_kernel<L>, (long long)nr * parents * 2 * d, s, (const u64*)Nh,
                                            (const u64*)pt.T.That[l], nxt, d, parents, (long long)nr);
-                if (!rc) rc = run_ntt(ctx, nxt, nxt, 2 * d * L, 2 * d * L, (size_t)(2 * d), (size_t)(parents * (long long)nr), L, true, nullptr, -1, s);
+                // the root level of an unpadded domain (n = M) transforms straight into the caller's rows: no copy-out launch
+                const bool direct = l == h - 1 && (long long)n == M;
+                u64* dst = direct ? out + r0 * n * L : nxt;
+                wrote_direct = direct;
+                if (!rc) rc = run_ntt(ctx, nxt, dst, 2 * d * L, 2 * d * L, (size_t)(2 * d), (size_t)(parents * (long long)nr), L, true, nullptr, -1, s);
             }
             std::swap(cur, nxt);
         }
-        if (!rc) {
+        if (!rc && !wrote_direct) {
             hipLaunchKernelGGL(tfk::interpolant_unpad_kernel<L>, dim3((unsigned)((n + 255) / 256), (unsigned)nr), dim3(256), 0, s,
                                (const u64*)cur, M, (long long)n, out + r0 * n * L);
             if (hipGetLastError() != hipSuccess) rc = TF_ERR_HIP;
