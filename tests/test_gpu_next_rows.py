@@ -1029,6 +1029,60 @@ def test_zerofier_tree_handle_serves_concurrent_host_threads(tf, oracle):
     assert not errors, errors
 
 
+@pytest.mark.gpu
+def test_concurrent_tree_walks_stress_gives_single_threaded_words():
+    """Six host threads on their own streams walking prepared trees of 2^8 .. 2^14 points for a few seconds
+    (tools/stress_threads.py, a fresh process).  Round 3 found wrong words here about once in 10^4 calls: the runtime's
+    hipMemPoolReuseFollowEventDependencies policy handed a stream blocks another stream was still using once the two had
+    exchanged a scratch block (profiles/r03_pool_reuse.txt); the library's temporaries now come from a pool with that policy off."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "stress_threads.py"), "6", "6"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "all words match" in r.stdout, (r.stdout[-600:], r.stderr[-600:])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("log_n", [7, 8, 9, 10, 11, 12, 13])
+@pytest.mark.parametrize("rows", [1, 3])
+def test_one_launch_per_level_walks_match_the_separate_kernels(tf, oracle, log_n, rows):
+    """tree_down_level_kernel / tree_up_level_kernel (a whole level of the walk in one launch, round 3) against the same walk
+    with TF_TREE_NO_LEVEL-style separate kernels is covered by the switch matrix; here: against the oracle's Horner values at
+    sampled points and the round trip, for every level size the kernels are instantiated for (2d = 64 .. 4096), one and
+    several rows / units per call."""
+    import torch
+
+    n = 1 << log_n
+    dom = oracle.fill_random(n, 4100 + log_n)
+    coeffs = oracle.fill_random(rows * n, 4200 + log_n)
+    d_dom, d_c = _to_dev(dom), _to_dev(coeffs)
+    vals = torch.empty(rows * n, dtype=torch.int64, device="cuda")
+    back = torch.empty(rows * n, dtype=torch.int64, device="cuda")
+    with tf.device.ZerofierTree(d_dom) as tree:
+        tree.batch_evaluate(d_c, n, vals, batch=rows)
+        tree.interpolate(vals, back, rows=rows)
+    torch.cuda.synchronize()
+    got = _to_host(vals).reshape(rows, n)
+    for r in range(rows):
+        for i in sorted({0, 1, n // 3, n - 1}):
+            assert int(got[r, i]) == int(oracle.poly_eval(coeffs[r * n:(r + 1) * n], int(dom[i]))[0]), (r, i)
+    assert np.array_equal(_to_host(back), coeffs)
+    # several units walking together (a polynomial longer than the point count) through the one-shot call
+    long_c = oracle.fill_random(4 * n, 4300 + log_n)
+    out = torch.empty(n, dtype=torch.int64, device="cuda")
+    tf.lib().tf_set_batch_eval_route(2)
+    try:
+        tf.device.batch_evaluate(_to_dev(long_c), 4 * n, d_dom, out)
+        torch.cuda.synchronize()
+    finally:
+        tf.lib().tf_set_batch_eval_route(0)
+    got = _to_host(out)
+    for i in sorted({0, n // 2, n - 1}):
+        assert int(got[i]) == int(oracle.poly_eval(long_c, int(dom[i]))[0]), i
+
+
 @pytest.mark.parametrize("n_coeffs,n_points,batch", [(0, 3, 1), (1, 1, 1), (7, 5, 3), (1024, 2, 2), (5000, 9, 4), (1 << 16, 3, 2)])
 def test_base_field_polynomials_at_extension_field_points(tf, oracle, n_coeffs, n_points, batch):
     """Polynomial<BFieldElement>::evaluate::<XFieldElement, XFieldElement> (math/polynomial.rs:309-320), batched over polynomials

@@ -1482,6 +1482,206 @@ __global__ void __launch_bounds__(LOGN == 12 ? 512 : 256) ntt_lat_kernel(const N
     }
 }
 
+// ---- a whole LEVEL of a zerofier-tree walk in one launch (BFieldElement, 2d <= 4096, the latency regime) -------------------
+// A small walk is a chain of dependent launches, each ~4 us of dispatch + drain around ~2 us of work: the walk down spends four
+// transforms per level, the walk up three.  Here one workgroup keeps a line's data in LDS through ALL of a level's transforms
+// (the stages of ntt_lat_kernel as a device function whose first-stage load and last-stage store are the caller's lambdas).
+template <int LOGN, bool INV, class LoadFn, class StoreFn>
+__device__ __forceinline__ void lat_xform(const u64* __restrict__ twtab, u64 ninv, int tr, int j, u64* buf0, u64* buf1, LoadFn load, StoreFn store) {
+    constexpr int N = 1 << LOGN, TPT = N / 8;
+    constexpr int S = (LOGN + 2) / 3, LOGRL = LOGN - 3 * (S - 1);
+    static_assert(S >= 2, "64 points at least");
+    u64 x[32];
+#pragma unroll
+    for (int q = 0; q < 32; ++q) x[q] = 0;
+    u64 tw[S - 1][8];
+    {
+        int Ns = 8;
+#pragma unroll
+        for (int s = 1; s < S; ++s) {
+            const int logr = s + 1 < S ? 3 : LOGRL, R = 1 << logr, U = 8 >> logr;
+            const bool last = s + 1 == S;
+#pragma unroll
+            for (int a = 0; a < U; ++a) {
+                const int u = j + a * TPT, k = u & (Ns - 1);
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const int e = k * r * (N / (Ns * R));
+                    tw[s - 1][a * R + r] = (r == 0) ? 0 : twtab[((INV && last) ? N : 0) + e];
+                }
+            }
+            Ns *= R;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) x[lat_brev<3>(r)] = load(r, j + r * TPT);
+    lat_dft<INV, 3>(x);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) buf0[lat_pad(tr * N + j * 8 + r)] = x[r];
+    __syncthreads();
+    int Ns = 8;
+#pragma unroll
+    for (int s = 1; s < S; ++s) {
+        const bool last = s + 1 == S;
+        const int logr = last ? LOGRL : 3, R = 1 << logr, U = 8 >> logr;
+        const u64* in = ((s - 1) & 1) ? buf1 : buf0;
+        u64* o = (s & 1) ? buf1 : buf0;
+        u64 v[8];
+#pragma unroll
+        for (int a = 0; a < U; ++a) {
+            const int u = j + a * TPT;
+#pragma unroll
+            for (int r = 0; r < R; ++r) v[a * R + r] = in[lat_pad(tr * N + u + r * (N / R))];
+        }
+#pragma unroll
+        for (int a = 0; a < U; ++a) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                u64 w = v[a * R + r];
+                if (r) w = gl::mont_mul(w, tw[s - 1][a * R + r]);
+                else if (INV && last) w = gl::mont_mul(w, ninv);
+                const int slot = a * R + (logr == 3 ? lat_brev<3>(r) : (logr == 2 ? lat_brev<2>(r) : r));
+                x[slot] = w;
+            }
+        }
+        if (logr == 3) lat_dft<INV, 3>(x);
+        else if (logr == 2) lat_dft<INV, 2>(x);
+        else lat_dft<INV, 1>(x);
+#pragma unroll
+        for (int a = 0; a < U; ++a) {
+            const int u = j + a * TPT, k = u & (Ns - 1), j0 = (u - k) * R + k;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int idx = j0 + r * Ns;
+                if (last) store(idx, x[a * R + r]);
+                else o[lat_pad(tr * N + idx)] = x[a * R + r];
+            }
+        }
+        if (!last) __syncthreads();
+        Ns *= R;
+    }
+}
+
+struct TreeLevelArgs {
+    const u64* cur;   // down: remainders of the level above (lines / 2 polynomials of 2d coefficients); up: the children's interpolants
+    u64* nxt;         // down: lines x d remainders; up: lines x 2d interpolants
+    const u64* ghat;  // down only: the level's cached transforms of the reversed-zerofier inverses, [children][2d]
+    const u64* that;  // the level's cached tail transforms, [children][2d]
+    const u64* tw_f;  // ntt_lat_kernel's tables of order 2d, forward and inverse
+    const u64* tw_i;
+    u64 ninv;
+    long long lines;  // down: units x children; up: rows x parents
+    long long per;    // down: children; up: parents  (the cached transforms repeat with this period)
+};
+
+// LDS: TWO buffers in all.  A transform run as lat_xform(first, second) leaves one of them unread by its last stage -- `second`
+// when the stage count is even, `first` when odd -- so its store lambda writes the result THERE, and the next transform, which
+// reads that buffer only in its first stage, runs as lat_xform(other, that one).
+template <int LOGN>
+struct LatChain {
+    static constexpr bool EVEN = (((LOGN + 2) / 3) % 2) == 0;
+    u64* first;
+    u64* second;
+    __device__ __forceinline__ u64* out() const { return EVEN ? second : first; }
+    __device__ __forceinline__ void next() {  // the result just written becomes the next transform's `second`
+        u64* o = out();
+        u64* other = (o == first) ? second : first;
+        first = other, second = o;
+    }
+};
+
+// Walk down (polynomial.rs:1882-1894's remaindering through the tree, math/zerofier_tree.rs): line = one child.
+//   rev(q) = rev(f_high) g mod x^d;   r = f_low - (q tail)_low          -- four transforms of order N = 2d, nothing leaves LDS
+template <int LOGN>
+__global__ void __launch_bounds__(LOGN == 12 ? 512 : 256) tree_down_level_kernel(const TreeLevelArgs A) {
+    constexpr int N = 1 << LOGN, D = N / 2, TPT = N / 8, WG = LOGN == 12 ? 512 : 256, T = WG / TPT;
+    constexpr int BUF = lat_pad(N * T) + 8;
+    extern __shared__ __attribute__((aligned(16))) u64 lds[];
+    LatChain<LOGN> ch{lds, lds + BUF};
+    const int t = threadIdx.x, tr = t / TPT, j = t - tr * TPT;
+    const long long line = (long long)blockIdx.x * T + tr;
+    const bool act = line < A.lines;
+    const long long c = act ? (long long)((u32)line % (u32)A.per) : 0;  // (lines < 2^31: the grid is 32-bit)
+    const u64* f = A.cur + (act ? (line >> 1) : 0) * N;
+    const u64* gh = A.ghat + c * N;
+    const u64* th = A.that + c * N;
+    u64* dst = A.nxt + (act ? line : 0) * D;
+    u64 ghv[8], thv[8];  // the cached transforms at this thread's first-stage indices, requested up front
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int idx = j + r * TPT;
+        ghv[r] = gh[idx];
+        thv[r] = th[idx];
+    }
+    u64* o = ch.out();
+    lat_xform<LOGN, false>(A.tw_f, 0, tr, j, ch.first, ch.second,
+                           [&](int r, int idx) -> u64 { return (act && r < 4) ? f[N - 1 - idx] : 0; },
+                           [&](int idx, u64 v) { o[lat_pad(tr * N + idx)] = v; });
+    __syncthreads();
+    const u64* in = o;
+    ch.next(), o = ch.out();
+    lat_xform<LOGN, true>(A.tw_i, A.ninv, tr, j, ch.first, ch.second,
+                          [&](int r, int idx) -> u64 { return gl::mont_mul(in[lat_pad(tr * N + idx)], ghv[r]); },
+                          [&](int idx, u64 v) { if (idx < D) o[lat_pad(tr * N + D - 1 - idx)] = v; });
+    __syncthreads();
+    in = o;
+    ch.next(), o = ch.out();
+    lat_xform<LOGN, false>(A.tw_f, 0, tr, j, ch.first, ch.second,
+                           [&](int r, int idx) -> u64 { return r < 4 ? in[lat_pad(tr * N + idx)] : 0; },
+                           [&](int idx, u64 v) { o[lat_pad(tr * N + idx)] = v; });
+    __syncthreads();
+    in = o;
+    ch.next();
+    lat_xform<LOGN, true>(A.tw_i, A.ninv, tr, j, ch.first, ch.second,
+                          [&](int r, int idx) -> u64 { return gl::mont_mul(in[lat_pad(tr * N + idx)], thv[r]); },
+                          [&](int idx, u64 v) { if (act && idx < D) dst[idx] = gl::sub(f[idx], v); });
+}
+
+// Walk up (the interpolation's combination N = N_left Z_right + N_right Z_left, Z = tail + x^d): line = one parent; three LDS
+// buffers (both children's transforms are alive when the inverse transform starts).  Measured against two thread groups per
+// line transforming the children side by side (1024 threads at 2d = 4096, group 1 idle through the inverse): 122.2 vs 126.0 us
+// per prepared-tree interpolation of 2^12 points -- the wider workgroup costs more than the parallel child saves.
+template <int LOGN>
+__global__ void __launch_bounds__(LOGN == 12 ? 512 : 256) tree_up_level_kernel(const TreeLevelArgs A) {
+    constexpr int N = 1 << LOGN, D = N / 2, TPT = N / 8, WG = LOGN == 12 ? 512 : 256, T = WG / TPT;
+    constexpr int BUF = lat_pad(N * T) + 8;
+    constexpr bool EVEN = LatChain<LOGN>::EVEN;
+    extern __shared__ __attribute__((aligned(16))) u64 lds[];
+    u64* p = lds;
+    u64* q = lds + BUF;
+    u64* c = lds + 2 * BUF;
+    const int t = threadIdx.x, tr = t / TPT, j = t - tr * TPT;
+    const long long line = (long long)blockIdx.x * T + tr;
+    const bool act = line < A.lines;
+    const u32 node = act ? (u32)line % (u32)A.per : 0;
+    const u64* c0 = A.cur + (act ? line : 0) * N;  // the two children, d coefficients each, side by side
+    const u64* t0 = A.that + 2 * (long long)node * N;
+    u64* dst = A.nxt + (act ? line : 0) * N;
+    u64 zlv[8], zrv[8];  // Z_left, Z_right transforms at this thread's first-stage indices, requested up front
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int idx = j + r * TPT;
+        const u64 sgn = (idx & 1) ? gl::P - gl::ONE : gl::ONE;
+        zlv[r] = gl::add(t0[idx], sgn);
+        zrv[r] = gl::add(t0[N + idx], sgn);
+    }
+    u64* a = EVEN ? q : p;  // left child's transform: the buffer lat_xform(p, q)'s last stage does not read
+    lat_xform<LOGN, false>(A.tw_f, 0, tr, j, p, q, [&](int r, int idx) -> u64 { return (act && r < 4) ? c0[idx] : 0; },
+                           [&](int idx, u64 v) { a[lat_pad(tr * N + idx)] = v; });
+    __syncthreads();
+    u64* w0 = EVEN ? p : q;  // the right child's transform works in the other two buffers
+    u64* b = EVEN ? c : w0;
+    lat_xform<LOGN, false>(A.tw_f, 0, tr, j, w0, c, [&](int r, int idx) -> u64 { return (act && r < 4) ? c0[D + idx] : 0; },
+                           [&](int idx, u64 v) { b[lat_pad(tr * N + idx)] = v; });
+    __syncthreads();
+    u64* f0 = EVEN ? w0 : c;  // the inverse transform's first stage writes the one buffer that holds neither
+    lat_xform<LOGN, true>(A.tw_i, A.ninv, tr, j, f0, b,
+                          [&](int r, int idx) -> u64 {
+                              return gl::add(gl::mont_mul(a[lat_pad(tr * N + idx)], zrv[r]), gl::mont_mul(b[lat_pad(tr * N + idx)], zlv[r]));
+                          },
+                          [&](int idx, u64 v) { if (act) dst[idx] = v; });
+}
+
 // ---- 2^13 <= n <= 2^20, little work per call: the same eight-elements-per-thread stages as the two passes of n = N1 N2 ------
 // (one slice per call is the reference's own call shape: math/ntt.rs:67-82 takes ONE slice).  A "line" is one DFT instance:
 //   column pass (LAST = false): line c = word-column c of the N2 L words of a row; element i at  i * es + c;  after the last stage

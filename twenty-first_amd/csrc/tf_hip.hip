@@ -89,6 +89,7 @@ struct DeviceCtx {
     std::map<std::pair<u64, u64>, u64*> pow_tables;  // (offset_raw, n) -> offset^j table
     bool tip5_ready = false;               // guarded by mu
     std::atomic<bool> pool_ready{false};  // double-checked under mu
+    hipMemPool_t pool = nullptr;           // the library's stream-ordered temporaries (current_ctx); written once before pool_ready
     hipStream_t side[4] = {nullptr, nullptr, nullptr, nullptr};  // pipelined tiles (run_ntt); created on first use under mu
     struct ScratchBlock {
         u64* p = nullptr;
@@ -121,20 +122,53 @@ int current_ctx(DeviceCtx** out) {
     if (dev < 0 || dev >= kMaxDevices) return TF_ERR_NO_DEVICE;
     *out = &g_ctx[dev];
     if (!g_ctx[dev].pool_ready.load(std::memory_order_acquire)) {
-        // Keep freed stream-ordered allocations cached in the device's default pool (default threshold 0 hands
-        // the memory back to the OS at every synchronisation, which makes the per-call scratch expensive).
+        // The library's stream-ordered temporaries come from a pool of its own:
+        //  - freed blocks stay cached (release threshold: the default 0 hands memory back to the OS at every synchronisation,
+        //    which makes per-call work space expensive);
+        //  - hipMemPoolReuseFollowEventDependencies OFF.  The scratch cache below makes callers' streams wait on each other's
+        //    events; with that reuse policy on, the runtime then hands a block freed on stream A to stream B while A's kernels
+        //    still use it (ROCm 7.0: several host threads walking one zerofier tree on their own streams got wrong words about
+        //    once in 10^4 calls, tools/stress_threads.py; every other policy combination ran clean, profiles/r03_pool_reuse.txt).
+        // The application's default pool is left alone.
         std::lock_guard<std::mutex> lk(g_ctx[dev].mu);
         if (!g_ctx[dev].pool_ready.load(std::memory_order_relaxed)) {
+            hipMemPoolProps props{};
+            props.allocType = hipMemAllocationTypePinned;
+            props.handleTypes = hipMemHandleTypeNone;
+            props.location.type = hipMemLocationTypeDevice;
+            props.location.id = dev;
             hipMemPool_t pool = nullptr;
-            if (hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess && pool) {
+            if (hipMemPoolCreate(&pool, &props) != hipSuccess) {
+                pool = nullptr;
+                (void)hipGetLastError();
+                (void)hipDeviceGetDefaultMemPool(&pool, dev);  // no pool of our own: the default one, same settings
+            }
+            if (pool) {
                 uint64_t thr = UINT64_MAX;
                 (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &thr);
+                int follow = 0;
+                if (const char* e = getenv("TF_POOL_REUSE_FOLLOW_EVENTS")) follow = atoi(e);  // (to reproduce the failure)
+                (void)hipMemPoolSetAttribute(pool, hipMemPoolReuseFollowEventDependencies, &follow);
             }
             (void)hipGetLastError();
+            g_ctx[dev].pool = pool;
             g_ctx[dev].pool_ready.store(true, std::memory_order_release);
         }
     }
     return TF_OK;
+}
+
+// Every stream-ordered temporary of the library: from the context's pool (hipFreeAsync gives it back, whatever the pool).
+hipError_t pool_malloc_async(void** p, size_t bytes, hipStream_t stream) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    hipMemPool_t pool = (dev >= 0 && dev < kMaxDevices && g_ctx[dev].pool_ready.load(std::memory_order_acquire)) ? g_ctx[dev].pool : nullptr;
+    if (!pool) {  // (an entry point that allocates before it looked its context up)
+        DeviceCtx* ctx = nullptr;
+        if (current_ctx(&ctx) == TF_OK) pool = ctx->pool;
+    }
+    return pool ? hipMallocFromPoolAsync(p, bytes, pool, stream) : hipMallocAsync(p, bytes, stream);
 }
 
 // Work space between the passes of a multi-pass transform.  Round 1 took it from the stream-ordered pool on every call; a
@@ -245,6 +279,8 @@ int release_caches(DeviceCtx* ctx) {
         (void)hipFree(b.p);
     }
     for (u64* t : tabs) (void)hipFree(t);
+    if (ctx->pool) (void)hipMemPoolTrimTo(ctx->pool, 0);  // the cached stream-ordered temporaries too
+    (void)hipGetLastError();
     return TF_OK;
 }
 
@@ -392,11 +428,11 @@ int get_post_table(DeviceCtx* ctx, int log_m, int a, bool inverse, hipStream_t s
     const long long M = 1ll << log_m, R = 1ll << a, B = M / R;
     if (*temp) {
         lk.unlock();
-        hipError_t e = hipMallocAsync(reinterpret_cast<void**>(&d), size_t(M) * sizeof(u64), stream);
+        hipError_t e = pool_malloc_async(reinterpret_cast<void**>(&d), size_t(M) * sizeof(u64), stream);
         if (e != hipSuccess) {
             (void)hipFree(d_hi);
             (void)hipFree(d_lo);
-            return hip_fail(e, "hipMallocAsync(twiddle table)", __FILE__, __LINE__);
+            return hip_fail(e, "pool_malloc_async(twiddle table)", __FILE__, __LINE__);
         }
     } else {
         hipError_t e = hipMalloc(&d, size_t(M) * sizeof(u64));
@@ -573,8 +609,8 @@ int get_pow_table(DeviceCtx* ctx, u64 offset_raw, size_t n, hipStream_t stream, 
         return TF_OK;
     }
     lk.unlock();  // a temporary is private to this call: build it without holding the device context
-    hipError_t e = hipMallocAsync(reinterpret_cast<void**>(&d), words * sizeof(u64), stream);
-    if (e != hipSuccess) return hip_fail(e, "hipMallocAsync(pow table)", __FILE__, __LINE__);
+    hipError_t e = pool_malloc_async(reinterpret_cast<void**>(&d), words * sizeof(u64), stream);
+    if (e != hipSuccess) return hip_fail(e, "pool_malloc_async(pow table)", __FILE__, __LINE__);
     int rc = build_pow_tables(offset_raw, w, cosets, n, d, stream);
     if (rc) {
         (void)hipFreeAsync(d, stream);
@@ -878,18 +914,27 @@ Launch plan_row_pass(const u64* in, u64* out, long long in_bs, long long out_bs,
     return l;
 }
 
+// One hipFuncSetAttribute per (kernel instantiation, device) to open the dynamic LDS above 48 KiB.  First use is serialised
+// under a lock: a launch of the same function from another host thread while the attribute is being set is not safe (seen as a
+// rare failure of the four-threads-one-tree test when a kernel's first use fell inside the threaded section).
+std::mutex g_func_attr_mutex;
+int ensure_dynamic_lds(const void* fn, int bytes, std::atomic<unsigned long long>& done_mask) {
+    int dev = 0;
+    HIPCHK(hipGetDevice(&dev));
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (done_mask.load(std::memory_order_acquire) & bit) return TF_OK;
+    std::lock_guard<std::mutex> guard(g_func_attr_mutex);
+    if (done_mask.load(std::memory_order_acquire) & bit) return TF_OK;
+    HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    done_mask.fetch_or(bit, std::memory_order_release);
+    return TF_OK;
+}
+
 template <bool INV, int SCALE, int MODE, bool LAST1024 = false, bool R1024 = false, bool COL = false, bool PRE2 = false>
 int launch_pass_t(const Launch& l, hipStream_t stream) {
     // one attribute call per (instantiation, device): the kernels use up to the full 160 KiB of dynamic LDS
     static std::atomic<unsigned long long> done_mask{0};
-    int dev = 0;
-    HIPCHK(hipGetDevice(&dev));
-    const unsigned long long bit = 1ull << (dev & 63);
-    if (!(done_mask.load(std::memory_order_acquire) & bit)) {
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&tfk::ntt_pass_kernel<INV, SCALE, MODE, LAST1024, R1024, COL, PRE2>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        done_mask.fetch_or(bit, std::memory_order_release);
-    }
+    if (int rc_attr = ensure_dynamic_lds(reinterpret_cast<const void*>(&tfk::ntt_pass_kernel<INV, SCALE, MODE, LAST1024, R1024, COL, PRE2>), (int)(160 * 1024), done_mask)) return rc_attr;
     // the R = 1024 column-pass instantiation stages its inner twiddle table behind the exchange buffer (LAST1024: part of
     // kLast1024LdsBytes already)
     const size_t lds_bytes = l.lds_bytes + ((TF_LDS_TW && !LAST1024 && MODE == 0 && l.a.inner_tw) ? (size_t(1) << l.a.p2) * tfk::kLdsTwStride * sizeof(u64) : 0);
@@ -914,13 +959,7 @@ int chain_tiles() {
 template <bool INV>
 int launch_chain_t(const Launch& l, int k, hipStream_t stream) {
     static std::atomic<unsigned long long> done_mask{0};
-    int dev = 0;
-    HIPCHK(hipGetDevice(&dev));
-    const unsigned long long bit = 1ull << (dev & 63);
-    if (!(done_mask.load(std::memory_order_acquire) & bit)) {
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&tfk::ntt_col1024_chain_kernel<INV>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        done_mask.fetch_or(bit, std::memory_order_release);
-    }
+    if (int rc_attr = ensure_dynamic_lds(reinterpret_cast<const void*>(&tfk::ntt_col1024_chain_kernel<INV>), (int)(160 * 1024), done_mask)) return rc_attr;
     const size_t lds_bytes = l.lds_bytes + size_t(32) * tfk::kLdsTwStride * sizeof(u64);
     unsigned grid = (l.tiles + (unsigned)k - 1) / (unsigned)k;
     grid = (grid + 7u) & ~7u;  // block id mod 8 is the XCD: tile, tile + grid, ... stay on one XCD
@@ -1031,14 +1070,7 @@ int check_len(size_t n) {
 template <bool INV>
 int launch_rows32_t(const tfk::NttRows32Args& a, unsigned grid, hipStream_t stream) {
     static std::atomic<unsigned long long> done_mask{0};
-    int dev = 0;
-    HIPCHK(hipGetDevice(&dev));
-    const unsigned long long bit = 1ull << (dev & 63);
-    if (!(done_mask.load(std::memory_order_acquire) & bit)) {
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&tfk::ntt_rows32_kernel<INV>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   160 * 1024));
-        done_mask.fetch_or(bit, std::memory_order_release);
-    }
+    if (int rc_attr = ensure_dynamic_lds(reinterpret_cast<const void*>(&tfk::ntt_rows32_kernel<INV>), (int)(160 * 1024), done_mask)) return rc_attr;
     hipLaunchKernelGGL((tfk::ntt_rows32_kernel<INV>), dim3(grid), dim3(512), size_t(256) * 33 * sizeof(u64), stream, a);
     HIPCHK(hipGetLastError());
     return TF_OK;
@@ -1066,14 +1098,7 @@ int launch_rows32(const u64* in, u64* out, size_t batch, int L, bool inverse, hi
 template <int LOGP3, bool INV, int SCALE>
 int launch_block_t(const tfk::NttBlockArgs& a, unsigned grid, hipStream_t stream) {
     static std::atomic<unsigned long long> done_mask{0};
-    int dev = 0;
-    HIPCHK(hipGetDevice(&dev));
-    const unsigned long long bit = 1ull << (dev & 63);
-    if (!(done_mask.load(std::memory_order_acquire) & bit)) {
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&tfk::ntt_block_kernel<LOGP3, INV, SCALE>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        done_mask.fetch_or(bit, std::memory_order_release);
-    }
+    if (int rc_attr = ensure_dynamic_lds(reinterpret_cast<const void*>(&tfk::ntt_block_kernel<LOGP3, INV, SCALE>), (int)(160 * 1024), done_mask)) return rc_attr;
     constexpr int P3 = 1 << LOGP3;
     const size_t lds_bytes = size_t(8) * (1056 + 32 / P3) * sizeof(u64);  // exchange 1 is the larger of the two layouts
     hipLaunchKernelGGL((tfk::ntt_block_kernel<LOGP3, INV, SCALE>), dim3(grid), dim3(512), lds_bytes, stream, a);
@@ -1157,13 +1182,7 @@ int launch_lat_t(const tfk::NttLatArgs& a, hipStream_t stream) {
     constexpr size_t lds = size_t(2) * (tfk::lat_pad(N * T) + 8) * sizeof(u64);
     if constexpr (lds > 48 * 1024) {
         static std::atomic<unsigned long long> done_mask{0};
-        int dev = 0;
-        HIPCHK(hipGetDevice(&dev));
-        const unsigned long long bit = 1ull << (dev & 63);
-        if (!(done_mask.load(std::memory_order_acquire) & bit)) {
-            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&tfk::ntt_lat_kernel<LOGN, INV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            done_mask.fetch_or(bit, std::memory_order_release);
-        }
+        if (int rc_attr = ensure_dynamic_lds(reinterpret_cast<const void*>(&tfk::ntt_lat_kernel<LOGN, INV>), (int)((int)lds), done_mask)) return rc_attr;
     }
     const long long blocks = (a.total + T - 1) / T;
     hipLaunchKernelGGL((tfk::ntt_lat_kernel<LOGN, INV>), dim3((unsigned)blocks), dim3(WG), lds, stream, a);
@@ -1227,6 +1246,54 @@ int launch_lat(DeviceCtx* ctx, const u64* in, u64* out, long long in_bs, long lo
     return rc;
 }
 
+std::atomic<int> g_min_passes{0};  // tf_set_ntt_min_passes
+
+// ---- one launch per LEVEL of a small zerofier-tree walk (tree_down_level_kernel / tree_up_level_kernel, BFieldElement)
+template <int LOGN, bool UP>
+int launch_tree_level_t(const tfk::TreeLevelArgs& a, hipStream_t stream) {
+    constexpr int N = 1 << LOGN, WG = LOGN == 12 ? 512 : 256, T = WG / (N / 8);
+    constexpr size_t lds = size_t(UP ? 3 : 2) * (tfk::lat_pad(N * T) + 8) * sizeof(u64);
+    const void* fn = UP ? reinterpret_cast<const void*>(&tfk::tree_up_level_kernel<LOGN>) : reinterpret_cast<const void*>(&tfk::tree_down_level_kernel<LOGN>);
+    if constexpr (lds > 48 * 1024) {
+        static std::atomic<unsigned long long> done_mask{0};
+        if (int rc_attr = ensure_dynamic_lds(fn, (int)((int)lds), done_mask)) return rc_attr;
+    }
+    const long long blocks = (a.lines + T - 1) / T;
+    if (UP) hipLaunchKernelGGL((tfk::tree_up_level_kernel<LOGN>), dim3((unsigned)blocks), dim3(WG), lds, stream, a);
+    else hipLaunchKernelGGL((tfk::tree_down_level_kernel<LOGN>), dim3((unsigned)blocks), dim3(WG), lds, stream, a);
+    HIPCHK(hipGetLastError());
+    return TF_OK;
+}
+// When: the level's transforms are the latency-shaped kernel's anyway AND the level is small enough that launches, not work,
+// are what it costs (measured crossover, tools/tree_latency.py / profiles/r03_tree_level_ab.txt).  TF_TREE_NO_LEVEL: A/B switch.
+bool tree_level_wanted(long long order, long long lines) {
+    static const bool off = getenv("TF_TREE_NO_LEVEL") != nullptr;
+    static const long long limit = [] {
+        const char* e = getenv("TF_TREE_LEVEL_MAX_WORDS");
+        return e ? atoll(e) : (1ll << 22);  // (every width the latency-shaped transform serves: faster at each, profiles/r03_tree_level_ab.txt)
+    }();
+    if (off || order < 64 || order > 4096 || g_min_passes.load(std::memory_order_relaxed) != 0) return false;
+    if (!lat_wanted(ilog2((size_t)order), (size_t)lines, 1)) return false;
+    return lines * order <= limit;
+}
+template <bool UP>
+int launch_tree_level(DeviceCtx* ctx, int log_n, tfk::TreeLevelArgs a, hipStream_t s) {
+    int rc = get_lat_table(ctx, log_n, false, &a.tw_f);
+    if (!rc) rc = get_lat_table(ctx, log_n, true, &a.tw_i);
+    if (rc) return rc;
+    a.ninv = gl::mont_inverse(gl::to_mont(u64(1) << log_n));
+    switch (log_n) {
+        case 6: return launch_tree_level_t<6, UP>(a, s);
+        case 7: return launch_tree_level_t<7, UP>(a, s);
+        case 8: return launch_tree_level_t<8, UP>(a, s);
+        case 9: return launch_tree_level_t<9, UP>(a, s);
+        case 10: return launch_tree_level_t<10, UP>(a, s);
+        case 11: return launch_tree_level_t<11, UP>(a, s);
+        case 12: return launch_tree_level_t<12, UP>(a, s);
+    }
+    return TF_ERR_HIP;
+}
+
 // ---- 2^13 .. 2^20 points with little work: the two passes of n = N1 N2 on the eight-elements-per-thread stages (ntt_lat2_kernel)
 template <int LOGN, bool INV, bool LAST, int WG = 256>
 int launch_lat2_t(const tfk::NttLat2Args& a, size_t batch, hipStream_t stream) {
@@ -1234,13 +1301,7 @@ int launch_lat2_t(const tfk::NttLat2Args& a, size_t batch, hipStream_t stream) {
     constexpr size_t lds = size_t(2) * (tfk::lat_pad(N * T) + 8) * sizeof(u64);
     if constexpr (lds > 48 * 1024) {
         static std::atomic<unsigned long long> done_mask{0};
-        int dev = 0;
-        HIPCHK(hipGetDevice(&dev));
-        const unsigned long long bit = 1ull << (dev & 63);
-        if (!(done_mask.load(std::memory_order_acquire) & bit)) {
-            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&tfk::ntt_lat2_kernel<LOGN, INV, LAST, WG>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            done_mask.fetch_or(bit, std::memory_order_release);
-        }
+        if (int rc_attr = ensure_dynamic_lds(reinterpret_cast<const void*>(&tfk::ntt_lat2_kernel<LOGN, INV, LAST, WG>), (int)((int)lds), done_mask)) return rc_attr;
     }
     tfk::NttLat2Args b = a;
     b.tiles_per_entry = (int)((a.lines + T - 1) / T);
@@ -1338,7 +1399,6 @@ int launch_lat2(DeviceCtx* ctx, const u64* in, u64* out, long long in_bs, long l
     return rc;
 }
 
-std::atomic<int> g_min_passes{0};  // tf_set_ntt_min_passes
 
 // Experiment switches for tools/split3.py: looked up on every call only when TF_NTT_EXPERIMENT is set at load time
 // (the sweep tool changes them while the process runs); otherwise the planner never touches the environment.
@@ -2031,9 +2091,9 @@ int merkle_root_dev(const u64* d_leaves, size_t n, u64* d_root, size_t batch, vo
     // ping-pong level buffers: n/2 + n/4 digests per tree
     u64* buf = nullptr;
     const size_t words = size_t(batch) * size_t(5) * size_t(N / 2 + N / 4);
-    hipError_t e = hipMallocAsync(reinterpret_cast<void**>(&buf), words * sizeof(u64), s);
+    hipError_t e = pool_malloc_async(reinterpret_cast<void**>(&buf), words * sizeof(u64), s);
     if (e != hipSuccess) {
-        hip_fail(e, "hipMallocAsync(merkle levels)", __FILE__, __LINE__);
+        hip_fail(e, "pool_malloc_async(merkle levels)", __FILE__, __LINE__);
         return TF_ERR_TREE_TOO_HIGH;
     }
     u64* a = buf;
@@ -2135,8 +2195,8 @@ int poly_mul_dev(const u64* a, size_t na, const u64* b, size_t nb, u64* out, siz
     hipStream_t s = static_cast<hipStream_t>(stream);
     u64* tmp = nullptr;
     const size_t half = batch * order * size_t(L);
-    hipError_t e = hipMallocAsync(reinterpret_cast<void**>(&tmp), 2 * half * sizeof(u64), s);
-    if (e != hipSuccess) return hip_fail(e, "hipMallocAsync(poly_mul)", __FILE__, __LINE__);
+    hipError_t e = pool_malloc_async(reinterpret_cast<void**>(&tmp), 2 * half * sizeof(u64), s);
+    if (e != hipSuccess) return hip_fail(e, "pool_malloc_async(poly_mul)", __FILE__, __LINE__);
     static const bool no_fuse = getenv("TF_POLY_MUL_NO_FUSE") != nullptr;  // A/B switch
     bool copied = false;
     if (order > 16 && !no_fuse) {
@@ -2190,8 +2250,8 @@ int poly_mul_shared_dev(const u64* a, size_t na, size_t batch, const u64* b, siz
     hipStream_t s = static_cast<hipStream_t>(stream);
     u64* tmp = nullptr;  // batch transforms of a, one of b
     const size_t row = order * size_t(L);
-    hipError_t e = hipMallocAsync(reinterpret_cast<void**>(&tmp), (batch + 1) * row * sizeof(u64), s);
-    if (e != hipSuccess) return hip_fail(e, "hipMallocAsync(poly_mul_shared)", __FILE__, __LINE__);
+    hipError_t e = pool_malloc_async(reinterpret_cast<void**>(&tmp), (batch + 1) * row * sizeof(u64), s);
+    if (e != hipSuccess) return hip_fail(e, "pool_malloc_async(poly_mul_shared)", __FILE__, __LINE__);
     u64* bh = tmp + batch * row;
     rc = run_ntt(ctx, a, tmp, (long long)na * L, (long long)row, order, batch, L, false, nullptr, (long long)na, s);
     if (!rc) rc = run_ntt(ctx, b, bh, (long long)nb * L, (long long)row, order, 1, L, false, nullptr, (long long)nb, s);
@@ -2222,8 +2282,8 @@ int poly_square_dev(const u64* a, size_t na, u64* out, size_t batch, int L, void
     hipStream_t s = static_cast<hipStream_t>(stream);
     u64* tmp = nullptr;
     const size_t words = batch * order * size_t(L);
-    hipError_t e = hipMallocAsync(reinterpret_cast<void**>(&tmp), words * sizeof(u64), s);
-    if (e != hipSuccess) return hip_fail(e, "hipMallocAsync(poly_square)", __FILE__, __LINE__);
+    hipError_t e = pool_malloc_async(reinterpret_cast<void**>(&tmp), words * sizeof(u64), s);
+    if (e != hipSuccess) return hip_fail(e, "pool_malloc_async(poly_square)", __FILE__, __LINE__);
     static const bool no_fuse = getenv("TF_POLY_MUL_NO_FUSE") != nullptr;  // A/B switch
     bool copied = false;
     if (order > 16 && !no_fuse) {
@@ -2268,8 +2328,8 @@ int lde_dev(const u64* values, size_t n, u64 offset_in, u64* out, size_t m, u64 
         return TF_OK;
     }
     u64* coeffs = nullptr;
-    hipError_t e = hipMallocAsync(reinterpret_cast<void**>(&coeffs), batch * n * size_t(L) * sizeof(u64), s);
-    if (e != hipSuccess) return hip_fail(e, "hipMallocAsync(lde)", __FILE__, __LINE__);
+    hipError_t e = pool_malloc_async(reinterpret_cast<void**>(&coeffs), batch * n * size_t(L) * sizeof(u64), s);
+    if (e != hipSuccess) return hip_fail(e, "pool_malloc_async(lde)", __FILE__, __LINE__);
     rc = coset_interp_dev(values, n, offset_in, coeffs, batch, L, s);
     if (!rc) rc = coset_eval_dev(coeffs, n, offset_out, out, m, batch, L, s);
     hipError_t e2 = hipFreeAsync(coeffs, s);
@@ -2434,6 +2494,15 @@ int zerofier_tree_evaluate(DeviceCtx* ctx, const ZerofierTree& T, const u64* F, 
         // rev(q) = rev(f_high) g mod x^d   (below the top level the reversed upper halves come from the level above's last kernel)
         int rc = TF_OK;
         u64* nxt = (cur == ping) ? pong : ping;
+        if (L == 1 && tree_level_wanted(2 * d, all)) {
+            // the whole level in one launch: a line's four transforms never leave LDS
+            tfk::TreeLevelArgs a{};
+            a.cur = cur, a.nxt = nxt, a.ghat = T.Ghat[l], a.that = T.That[l], a.lines = all, a.per = children;
+            rc = launch_tree_level<false>(ctx, ilog2((size_t)(2 * d)), a, s);
+            if (rc) return rc;
+            cur = nxt;
+            continue;
+        }
         if (tree_fuse(2 * d, all, L)) {
             // the same steps with the reversals read on load and the remainder formed on store (ntt_lat_kernel's modifiers)
             const int lg = ilog2((size_t)(2 * d));
@@ -2458,7 +2527,7 @@ int zerofier_tree_evaluate(DeviceCtx* ctx, const ZerofierTree& T, const u64* F, 
             continue;
         }
         const u64* fr_in = frq;
-        if (l == T.h - 1 || tree_fuse(4 * d, all / 2, L)) {  // (a fused level above this one did not write frq)
+        if (l == T.h - 1 || tree_fuse(4 * d, all / 2, L) || (L == 1 && tree_level_wanted(4 * d, all / 2))) {  // (a fused level above this one did not write frq)
             rc = launch_1d<L>(tfk::remainder_rev_high_kernel<L>, all * d, s, cur, fr, d, all);
             fr_in = fr;
         }
@@ -2508,8 +2577,8 @@ bool tree_route(size_t n_coeffs, size_t n_points, size_t batch, int L) {
     if (force && !strcmp(force, "tree")) return true;
     // Cost model fitted to tools/batch_eval_sweep.py <width> fine on MI355X (profiles/r03_batch_eval_fine_w*.txt), milliseconds:
     //   Horner  n m / 1.4e9            (x 8 over XFieldElement: nine base-field products per step; measured 7 - 10)
-    //   tree    build + one walk for the first unit: latency-bound per level up to 2^12 points (0.09 ms a level with the
-    //           latency-shaped transforms of round 3), twice that per level above, plus a throughput term in M beyond 2^16 points;
+    //   tree    build + one walk for the first unit: latency-bound per level up to 2^12 points (0.08 ms a level with one
+    //           launch per level of the walk down, round 3), twice that per level above, plus a throughput term in M beyond 2^16 points;
     //           the units walk TOGETHER, so every further unit adds only its share of the throughput term: 0.04 ms per 2^16
     //           points (0.16 over XFE)
     int levels = 0;
@@ -2517,7 +2586,7 @@ bool tree_route(size_t n_coeffs, size_t n_points, size_t batch, int L) {
     const double horner_ms = (double)batch * (double)n_coeffs * (double)n_points / 1.4e9 * (L == 3 ? 8.0 : 1.0);
     const double m16 = (double)M / 65536.0;
     const double first_ms = L == 3 ? 0.25 + 0.085 * levels + 0.10 * std::max(0, levels - 4) + 0.25 * m16
-                                   : 0.10 + 0.09 * levels + 0.09 * std::max(0, levels - 4) + 0.055 * m16;
+                                   : 0.10 + 0.08 * levels + 0.09 * std::max(0, levels - 4) + 0.055 * m16;
     const double tree_ms = first_ms + (double)(units - 1) * (L == 3 ? 0.16 : 0.04) * m16;
     return tree_ms < 0.9 * horner_ms;
 }
@@ -2537,8 +2606,8 @@ int tree_batch_evaluate(DeviceCtx* ctx, const ZerofierTree& T, const u64* points
     const size_t slab = std::max<size_t>(1, std::min<size_t>(units, slab_elems / (size_t)M));
     // padded coefficients (units M) + values (units M) + walk work (8 slab M)
     u64* tmp = nullptr;
-    hipError_t e = hipMallocAsync(reinterpret_cast<void**>(&tmp), (2 * units + (size_t)kTreeWorkArrays * slab) * ML * sizeof(u64), s);
-    if (e != hipSuccess) return hip_fail(e, "hipMallocAsync(zerofier tree walk)", __FILE__, __LINE__);
+    hipError_t e = pool_malloc_async(reinterpret_cast<void**>(&tmp), (2 * units + (size_t)kTreeWorkArrays * slab) * ML * sizeof(u64), s);
+    if (e != hipSuccess) return hip_fail(e, "pool_malloc_async(zerofier tree walk)", __FILE__, __LINE__);
     u64* padded = tmp;
     u64* vals = padded + units * ML;
     u64* work = vals + units * ML;
@@ -2578,8 +2647,8 @@ int batch_evaluate_tree_t(const u64* coeffs, size_t n_coeffs, size_t poly_stride
     DeviceCtx* ctx = nullptr;
     int rc = current_ctx(&ctx);
     if (rc) return rc;
-    hipError_t e = hipMallocAsync(reinterpret_cast<void**>(&arena), words * sizeof(u64), s);
-    if (e != hipSuccess) return hip_fail(e, "hipMallocAsync(zerofier tree)", __FILE__, __LINE__);
+    hipError_t e = pool_malloc_async(reinterpret_cast<void**>(&arena), words * sizeof(u64), s);
+    if (e != hipSuccess) return hip_fail(e, "pool_malloc_async(zerofier tree)", __FILE__, __LINE__);
     rc = zerofier_tree_build<L>(ctx, points, (long long)n_points, &T, arena, arena + (size_t)(kTreeLevelArrays * h) * M * L, s);
     if (!rc) rc = tree_batch_evaluate<L>(ctx, T, points, n_points, coeffs, n_coeffs, poly_stride, batch, out, s);
     hipError_t e2 = hipFreeAsync(arena, s);
@@ -2684,7 +2753,7 @@ int padded_tree_build(const u64* points, size_t n_points, size_t extra_words, Pa
     const size_t work_words = (size_t)kTreeWorkArrays * (size_t)M * L;
     if ((words + work_words) * sizeof(u64) > (size_t(64) << 30)) return TF_ERR_OUT_OF_MEMORY;
     hipError_t e = persistent ? hipMalloc(reinterpret_cast<void**>(&pt->arena), words * sizeof(u64))
-                              : hipMallocAsync(reinterpret_cast<void**>(&pt->arena), words * sizeof(u64), s);
+                              : pool_malloc_async(reinterpret_cast<void**>(&pt->arena), words * sizeof(u64), s);
     if (e != hipSuccess) {
         pt->arena = nullptr;
         (void)hipGetLastError();
@@ -2705,8 +2774,8 @@ int padded_tree_build(const u64* points, size_t n_points, size_t extra_words, Pa
     int rc = current_ctx(&ctx);
     if (rc) return rc;
     u64* work = nullptr;
-    e = hipMallocAsync(reinterpret_cast<void**>(&work), work_words * sizeof(u64), s);
-    if (e != hipSuccess) return hip_fail(e, "hipMallocAsync(zerofier tree build)", __FILE__, __LINE__);
+    e = pool_malloc_async(reinterpret_cast<void**>(&work), work_words * sizeof(u64), s);
+    if (e != hipSuccess) return hip_fail(e, "pool_malloc_async(zerofier tree build)", __FILE__, __LINE__);
     rc = zerofier_tree_build<L>(ctx, points, (long long)n_points, &pt->T, pt->arena, work, s);
     // the root from the transforms of the two nodes of level h - 1 (d = M / 2, order M)
     const long long d = M / 2;
@@ -2755,8 +2824,8 @@ int tree_inverse_weights(DeviceCtx* ctx, const PaddedTree& pt, const u64* domain
     const long long M = pt.T.M;
     const size_t ML = (size_t)M * L, n = pt.n;
     u64* tmp = nullptr;  // derivative (M), its values (M), walk work (8 M), flag
-    hipError_t e = hipMallocAsync(reinterpret_cast<void**>(&tmp), ((2 + kTreeWorkArrays) * ML + 2) * sizeof(u64), s);
-    if (e != hipSuccess) return hip_fail(e, "hipMallocAsync(interpolation weights)", __FILE__, __LINE__);
+    hipError_t e = pool_malloc_async(reinterpret_cast<void**>(&tmp), ((2 + kTreeWorkArrays) * ML + 2) * sizeof(u64), s);
+    if (e != hipSuccess) return hip_fail(e, "pool_malloc_async(interpolation weights)", __FILE__, __LINE__);
     u64* deriv = tmp;
     u64* dz = deriv + ML;
     u64* work = dz + ML;
@@ -2795,8 +2864,8 @@ int tree_interpolate_rows(DeviceCtx* ctx, const PaddedTree& pt, const u64* domai
     // rows go up the tree in slabs: targets, two interpolant levels and the children's transforms (2 M) per row
     const size_t slab = std::max<size_t>(1, std::min<size_t>(std::min<size_t>(rows, 32768), (size_t(1) << 26) / ML));
     u64* tmp = nullptr;
-    hipError_t e = hipMallocAsync(reinterpret_cast<void**>(&tmp), 5 * slab * ML * sizeof(u64), s);
-    if (e != hipSuccess) return hip_fail(e, "hipMallocAsync(interpolation rows)", __FILE__, __LINE__);
+    hipError_t e = pool_malloc_async(reinterpret_cast<void**>(&tmp), 5 * slab * ML * sizeof(u64), s);
+    if (e != hipSuccess) return hip_fail(e, "pool_malloc_async(interpolation rows)", __FILE__, __LINE__);
     u64* targets = tmp;
     u64* na = targets + slab * ML;
     u64* nb = na + slab * ML;
@@ -2818,6 +2887,16 @@ int tree_interpolate_rows(DeviceCtx* ctx, const PaddedTree& pt, const u64* domai
             // tail transforms, the combination N_left Z_right + N_right Z_left pointwise, one inverse transform -- which lands
             // in the next level's layout
             const long long d = (long long)kTreeLeaf << l, children = M / d, parents = children / 2;
+            if (L == 1 && tree_level_wanted(2 * d, parents * (long long)nr)) {
+                // the whole level in one launch (both children's transforms, the combination and the inverse transform in LDS)
+                const bool direct = l == h - 1 && (long long)n == M;
+                tfk::TreeLevelArgs a{};
+                a.cur = cur, a.nxt = direct ? out + r0 * n : nxt, a.that = pt.T.That[l], a.lines = parents * (long long)nr, a.per = parents;
+                rc = launch_tree_level<true>(ctx, ilog2((size_t)(2 * d)), a, s);
+                wrote_direct = direct;
+                std::swap(cur, nxt);
+                continue;
+            }
             rc = run_ntt(ctx, cur, Nh, d * L, 2 * d * L, (size_t)(2 * d), (size_t)(children * (long long)nr), L, false, nullptr, d, s);
             // (measured, tools/tree_latency.py on one box: prepared-tree interpolation of 2^12 points 129.0 us with the pointwise
             //  kernel, 135.8 us with it fused -- four strided loads and two products per element in front of the transform's first
@@ -3097,8 +3176,8 @@ int barycentric_dev(const u64* codewords, size_t n, size_t batch, int cw_width, 
     const long long per_chunk = (long long)tfk::kBaryPerThread * 256, n_chunks = ((long long)n + per_chunk - 1) / per_chunk;
     u64* tmp = nullptr;  // weights (3 n) + partial sums ((batch + 1) n_chunks 3)
     const size_t words = 3 * n + 3 * (batch + 1) * (size_t)n_chunks;
-    hipError_t e = hipMallocAsync(reinterpret_cast<void**>(&tmp), words * sizeof(u64), s);
-    if (e != hipSuccess) return hip_fail(e, "hipMallocAsync(barycentric)", __FILE__, __LINE__);
+    hipError_t e = pool_malloc_async(reinterpret_cast<void**>(&tmp), words * sizeof(u64), s);
+    if (e != hipSuccess) return hip_fail(e, "pool_malloc_async(barycentric)", __FILE__, __LINE__);
     u64* w = tmp;
     u64* partial = tmp + 3 * n;
     const int log_n = ilog2(n);
@@ -3151,8 +3230,8 @@ int clean_divide_dev(const u64* a, size_t na, const u64* b, size_t nb, u64* out,
     hipStream_t s = static_cast<hipStream_t>(stream);
     u64* tmp = nullptr;  // rows 0 .. batch-1: the dividends, row `batch`: the divisor; order XFieldElements each
     const size_t half = order * 3;
-    hipError_t e = hipMallocAsync(reinterpret_cast<void**>(&tmp), ((batch + 1) * half + 2) * sizeof(u64), s);
-    if (e != hipSuccess) return hip_fail(e, "hipMallocAsync(clean_divide)", __FILE__, __LINE__);
+    hipError_t e = pool_malloc_async(reinterpret_cast<void**>(&tmp), ((batch + 1) * half + 2) * sizeof(u64), s);
+    if (e != hipSuccess) return hip_fail(e, "pool_malloc_async(clean_divide)", __FILE__, __LINE__);
     u64* div = tmp + batch * half;
     int* flag = reinterpret_cast<int*>(tmp + (batch + 1) * half);
     // The division coset is X * <w_order> with X = x, the reference's choice (:2383).  A divisor with a root ON that coset (e.g.
@@ -3224,8 +3303,8 @@ int coset_extrapolate_dev(u64 offset_raw, const u64* codewords, size_t n, size_t
     rc = current_ctx(&ctx);
     if (rc) return rc;
     u64* coeffs = nullptr;
-    hipError_t e = hipMallocAsync(reinterpret_cast<void**>(&coeffs), batch * n * size_t(L) * sizeof(u64), s);
-    if (e != hipSuccess) return hip_fail(e, "hipMallocAsync(coset_extrapolate)", __FILE__, __LINE__);
+    hipError_t e = pool_malloc_async(reinterpret_cast<void**>(&coeffs), batch * n * size_t(L) * sizeof(u64), s);
+    if (e != hipSuccess) return hip_fail(e, "pool_malloc_async(coset_extrapolate)", __FILE__, __LINE__);
     rc = coset_interp_dev(codewords, n, offset_raw, coeffs, batch, L, s);
     if (!rc) rc = batch_evaluate_dev(coeffs, n, n * size_t(L), batch, points, n_points, out, L, s);
     hipError_t e2 = hipFreeAsync(coeffs, s);
@@ -3261,7 +3340,7 @@ struct DevBuf {
     explicit DevBuf(hipStream_t st) : s(st) {}
     int alloc(size_t words) {
         if (words == 0) return TF_OK;
-        hipError_t e = hipMallocAsync(reinterpret_cast<void**>(&p), words * sizeof(u64), s);
+        hipError_t e = pool_malloc_async(reinterpret_cast<void**>(&p), words * sizeof(u64), s);
         if (e != hipSuccess) return hip_fail(e, "hipMallocAsync", __FILE__, __LINE__);
         return TF_OK;
     }
