@@ -66,7 +66,9 @@ int tf_version(void);
 /* Number of visible HIP devices (0 if the runtime is unusable). */
 int tf_device_count(void);
 /* What the library keeps in HBM for speed, per device and for the life of the process: work space between the passes of the
- * multi-pass transforms (at most 12 GiB), inter-pass twiddle tables (at most 4 GiB), coset power tables (at most 1 GiB).
+ * multi-pass transforms (at most 12 GiB), inter-pass twiddle tables (at most 4 GiB), coset power tables (at most 1 GiB), and
+ * the freed blocks of the memory pool its stream-ordered temporaries come from (a pool of the library's own per device: the
+ * application's default pool and its attributes are left alone).
  * tf_release_caches() waits for the current device and frees all of it (the next call rebuilds what it needs); meant for hosts
  * that share the GPU with other users of its memory.  Call it when no other thread is inside the library on that device: a
  * call in flight on another host thread may hold a pointer to a table this frees. */
