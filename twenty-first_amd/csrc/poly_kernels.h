@@ -316,6 +316,78 @@ __global__ void __launch_bounds__(kLeafMax) leaf_evaluate_kernel(const u64* rem,
     fe_store<L>(vals + (leaf * d + t) * L, a);
 }
 
+// The same leaves for a SMALL walk (few leaves: the chip is mostly idle and a thread's d products in a row are the whole latency):
+// S threads per point, thread (point, s) evaluates the block of d / S coefficients  P_s(x) = sum_j c[s d/S + j] x^j  with the same
+// four chains, the partial values meet in LDS and thread (point, 0) finishes  r(x) = sum_s y^s P_s(x),  y = x^(d/S).
+// block = d * S threads (<= 1024), d / S a power of two and a multiple of 4.
+template <int L, int S>
+__global__ void __launch_bounds__(kLeafMax) leaf_evaluate_split_kernel(const u64* rem, const u64* points, long long n_points, int d, u64* vals,
+                                                                       long long leaves_per_unit) {
+    extern __shared__ u64 leaf_lds[];  // d L coefficients, then S d L partial values
+    u64* c = leaf_lds;
+    u64* part = leaf_lds + (size_t)d * L;
+    const int t = threadIdx.x, s = t / d, pt = t - s * d;
+    const long long leaf = blockIdx.x;
+    for (int i = t; i < d * L; i += d * S) c[i] = rem[leaf * d * L + i];
+    __syncthreads();
+    const long long pi = (leaf % leaves_per_unit) * d + pt;
+    const bool live = pi < n_points;
+    u64 x[L], x2[L], x4[L], acc4[4][L];
+#pragma unroll
+    for (int k = 0; k < L; ++k) x[k] = 0;
+    if (live) fe_load<L>(points + pi * L, x);
+    fe_mul<L>(x, x, x2);
+    fe_mul<L>(x2, x2, x4);
+#pragma unroll
+    for (int c4 = 0; c4 < 4; ++c4)
+#pragma unroll
+        for (int k = 0; k < L; ++k) acc4[c4][k] = 0;
+    const int seg = d / S, base = s * seg;
+    for (int j = seg - 4; j >= 0; j -= 4) {
+#pragma unroll
+        for (int c4 = 0; c4 < 4; ++c4) {
+            u64 m[L], cj[L], r[L];
+            fe_mul<L>(acc4[c4], x4, m);
+            fe_load<L>(&c[(base + j + c4) * L], cj);
+            fe_add<L>(m, cj, r);
+#pragma unroll
+            for (int k = 0; k < L; ++k) acc4[c4][k] = r[k];
+        }
+    }
+    {
+        u64 t3[L], t2[L], t1[L], u3[L], u2[L], a[L];
+        fe_mul<L>(acc4[3], x, t3);
+        fe_add<L>(t3, acc4[2], u3);
+        fe_mul<L>(u3, x, t2);
+        fe_add<L>(t2, acc4[1], u2);
+        fe_mul<L>(u2, x, t1);
+        fe_add<L>(t1, acc4[0], a);
+        fe_store<L>(&part[((size_t)s * d + pt) * L], a);
+    }
+    __syncthreads();
+    if (s != 0 || !live) return;
+    u64 y[L], a[L];
+#pragma unroll
+    for (int k = 0; k < L; ++k) y[k] = x4[k];
+    for (int e = 4; e < seg; e <<= 1) {  // y = x^seg
+        u64 q[L];
+        fe_mul<L>(y, y, q);
+#pragma unroll
+        for (int k = 0; k < L; ++k) y[k] = q[k];
+    }
+    fe_load<L>(&part[((size_t)(S - 1) * d + pt) * L], a);
+#pragma unroll
+    for (int q = S - 2; q >= 0; --q) {
+        u64 m[L], pq[L], r[L];
+        fe_mul<L>(a, y, m);
+        fe_load<L>(&part[((size_t)q * d + pt) * L], pq);
+        fe_add<L>(m, pq, r);
+#pragma unroll
+        for (int k = 0; k < L; ++k) a[k] = r[k];
+    }
+    fe_store<L>(vals + (leaf * d + pt) * L, a);
+}
+
 // out[i] = A[i] * B[i mod period]: the transforms of several units against the level's cached transforms (shared by the units)
 template <int L>
 __global__ void __launch_bounds__(256) product_bcast_kernel(const u64* A, const u64* B, u64* out, long long period, long long total) {
@@ -517,6 +589,89 @@ __global__ void __launch_bounds__(kLeafMax) leaf_interpolant_kernel(const u64* p
     u64 v[L];
     fe_load<L>(&nb[cur_buf][t * L], v);
     fe_store<L>(N + (row * M + leaf * d + t) * L, v);
+}
+
+// The same leaf interpolants from the leaf zerofiers the tree already holds (tails of level 0), without the d barrier-separated
+// steps:  N = sum_i w_i Z / (x - p_i).   Thread i (group 0) divides Z by (x - p_i) synthetically -- q_{d-1} = 1,
+// q_{j-1} = z_j + p_i q_j: one product per step, no barrier -- into column i of a d x d matrix in LDS; then S threads per coefficient
+// j add up  sum_i w_i q_{i,j}  over a quarter of the points each (independent products), and group 0 adds the S partial sums.
+// grid = (leaves, rows), block = d * S threads;  LDS: z, w (d L each), the matrix d x (d + 1) x L (rows padded: the second phase
+// reads it by rows with the lanes along j), S d L partial sums.
+template <int L, int S>
+__global__ void __launch_bounds__(kLeafMax) leaf_interpolant_div_kernel(const u64* points, const u64* values, const u64* winv, const u64* tails0,
+                                                                        long long n_points, int d, long long M, u64* N) {
+    extern __shared__ u64 leaf_lds[];
+    u64* z = leaf_lds;
+    u64* w = z + (size_t)d * L;
+    u64* Q = w + (size_t)d * L;
+    const int stride = d + 1;
+    u64* part = Q + (size_t)d * stride * L;
+    const int t = threadIdx.x, s = t / d, j = t - s * d;
+    const long long leaf = blockIdx.x, row = blockIdx.y;
+    u64 p[L];
+#pragma unroll
+    for (int k = 0; k < L; ++k) p[k] = 0;
+    if (s == 0) {
+        const long long pi = leaf * d + j;
+        u64 tv[L], zj[L];
+#pragma unroll
+        for (int k = 0; k < L; ++k) tv[k] = 0;
+        if (pi < n_points) {
+            u64 v[L], wi[L];
+            fe_load<L>(points + pi * L, p);
+            fe_load<L>(values + (row * n_points + pi) * L, v);
+            fe_load<L>(winv + pi * L, wi);
+            fe_mul<L>(v, wi, tv);
+        }
+        fe_store<L>(&w[j * L], tv);
+        fe_load<L>(tails0 + (leaf * d + j) * L, zj);
+        fe_store<L>(&z[j * L], zj);
+    }
+    __syncthreads();
+    if (s == 0) {  // column j of Q: the quotient Z / (x - p_j)
+        u64 q[L];
+#pragma unroll
+        for (int k = 0; k < L; ++k) q[k] = k ? 0 : gl::ONE;
+        for (int c = d - 1; c >= 0; --c) {
+            fe_store<L>(&Q[((size_t)c * stride + j) * L], q);
+            u64 zc[L], m[L], r[L];
+            fe_load<L>(&z[c * L], zc);
+            fe_mul<L>(p, q, m);
+            fe_add<L>(zc, m, r);
+#pragma unroll
+            for (int k = 0; k < L; ++k) q[k] = r[k];
+        }
+    }
+    __syncthreads();
+    {
+        const int seg = d / S, i0 = s * seg;
+        u64 acc[L];
+#pragma unroll
+        for (int k = 0; k < L; ++k) acc[k] = 0;
+        for (int i = i0; i < i0 + seg; ++i) {
+            u64 wi[L], qi[L], m[L], r[L];
+            fe_load<L>(&w[i * L], wi);
+            fe_load<L>(&Q[((size_t)j * stride + i) * L], qi);
+            fe_mul<L>(wi, qi, m);
+            fe_add<L>(acc, m, r);
+#pragma unroll
+            for (int k = 0; k < L; ++k) acc[k] = r[k];
+        }
+        fe_store<L>(&part[((size_t)s * d + j) * L], acc);
+    }
+    __syncthreads();
+    if (s != 0) return;
+    u64 a[L];
+    fe_load<L>(&part[(size_t)j * L], a);
+#pragma unroll
+    for (int q = 1; q < S; ++q) {
+        u64 b[L], r[L];
+        fe_load<L>(&part[((size_t)q * d + j) * L], b);
+        fe_add<L>(a, b, r);
+#pragma unroll
+        for (int k = 0; k < L; ++k) a[k] = r[k];
+    }
+    fe_store<L>(N + (row * M + leaf * d + j) * L, a);
 }
 
 // N_parent = N_left Z_right + N_right Z_left in the transform domain of order 2d (deg N_parent < 2d: no wrap-around).

@@ -2542,8 +2542,17 @@ int zerofier_tree_evaluate(DeviceCtx* ctx, const ZerofierTree& T, const u64* F, 
         if (rc) return rc;
         cur = nxt;
     }
-    hipLaunchKernelGGL(tfk::leaf_evaluate_kernel<L>, dim3((unsigned)(UM / eval_leaf)), dim3(eval_leaf), eval_leaf * L * sizeof(u64), s, cur, points,
-                       n_points, eval_leaf, vals, M / eval_leaf);
+    // few leaves: four threads per point (the chip is idle anyway; a thread's eval_leaf products in a row were 16 of the 116 us of
+    // a 2^12-point walk).  TF_TREE_NO_LEAF_SPLIT: A/B switch.
+    static const bool no_split = getenv("TF_TREE_NO_LEAF_SPLIT") != nullptr;
+    constexpr int kSplit = 4;
+    if (!no_split && UM <= (1ll << 15) && eval_leaf * kSplit <= 1024 && eval_leaf >= 16 * kSplit) {
+        hipLaunchKernelGGL((tfk::leaf_evaluate_split_kernel<L, kSplit>), dim3((unsigned)(UM / eval_leaf)), dim3(eval_leaf * kSplit),
+                           (size_t)(1 + kSplit) * eval_leaf * L * sizeof(u64), s, cur, points, n_points, eval_leaf, vals, M / eval_leaf);
+    } else {
+        hipLaunchKernelGGL(tfk::leaf_evaluate_kernel<L>, dim3((unsigned)(UM / eval_leaf)), dim3(eval_leaf), eval_leaf * L * sizeof(u64), s, cur, points,
+                           n_points, eval_leaf, vals, M / eval_leaf);
+    }
     HIPCHK(hipGetLastError());
     return TF_OK;
 }
@@ -2873,11 +2882,24 @@ int tree_interpolate_rows(DeviceCtx* ctx, const PaddedTree& pt, const u64* domai
     int rc = TF_OK;
     for (size_t r0 = 0; r0 < rows && !rc; r0 += slab) {
         const size_t nr = std::min(slab, rows - r0);
-        if (6 * kTreeLeaf * L * sizeof(u64) > 48 * 1024)  // only with a leaf size forced through TF_TREE_LEAF_LOG
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tfk::leaf_interpolant_kernel<L>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)(6 * kTreeLeaf * L * sizeof(u64)));
-        hipLaunchKernelGGL(tfk::leaf_interpolant_kernel<L>, dim3((unsigned)(M / kTreeLeaf), (unsigned)nr), dim3(kTreeLeaf),
-                           6 * kTreeLeaf * L * sizeof(u64), s, domain, values + r0 * n * L, winv, (long long)n, kTreeLeaf, M, na);
+        // few leaves: the quotient form on the leaf zerofiers the tree holds (no barrier per point; four threads per coefficient in
+        // its second phase).  TF_TREE_NO_LEAF_SPLIT: A/B switch
+        static const bool no_split = getenv("TF_TREE_NO_LEAF_SPLIT") != nullptr;
+        constexpr int kSplit = 4;
+        const size_t div_lds = ((size_t)2 * kTreeLeaf + (size_t)kTreeLeaf * (kTreeLeaf + 1) + (size_t)kSplit * kTreeLeaf) * L * sizeof(u64);
+        if (!no_split && h > 0 /* (a single leaf has no tree: no stored zerofier) */ && (long long)nr * M <= (1ll << 15) && kTreeLeaf * kSplit <= 1024 && kTreeLeaf >= 4 * kSplit && div_lds <= 144 * 1024) {
+            static std::atomic<unsigned long long> done_mask{0};
+            if (div_lds > 48 * 1024) rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&tfk::leaf_interpolant_div_kernel<L, kSplit>), 144 * 1024, done_mask);
+            if (!rc)
+                hipLaunchKernelGGL((tfk::leaf_interpolant_div_kernel<L, kSplit>), dim3((unsigned)(M / kTreeLeaf), (unsigned)nr), dim3(kTreeLeaf * kSplit),
+                                   div_lds, s, domain, values + r0 * n * L, winv, (const u64*)(h > 0 ? pt.T.tails[0] : nullptr), (long long)n, kTreeLeaf, M, na);
+        } else {
+            if (6 * kTreeLeaf * L * sizeof(u64) > 48 * 1024)  // only with a leaf size forced through TF_TREE_LEAF_LOG
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tfk::leaf_interpolant_kernel<L>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)(6 * kTreeLeaf * L * sizeof(u64)));
+            hipLaunchKernelGGL(tfk::leaf_interpolant_kernel<L>, dim3((unsigned)(M / kTreeLeaf), (unsigned)nr), dim3(kTreeLeaf),
+                               6 * kTreeLeaf * L * sizeof(u64), s, domain, values + r0 * n * L, winv, (long long)n, kTreeLeaf, M, na);
+        }
         if (hipGetLastError() != hipSuccess) rc = TF_ERR_HIP;
         u64* cur = na;
         u64* nxt = nb;
