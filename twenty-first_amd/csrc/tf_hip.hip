@@ -2372,6 +2372,17 @@ inline int tree_interp_leaf(int L) {
     return 1 << std::min(forced ? forced : 6, tree_leaf_log(L));
 }
 
+// widest walk (points in flight) that takes the four-threads-per-point leaf kernels (TF_TREE_LEAF_SPLIT_MAX: sweep hook).  Measured,
+// tools/tree_latency.py with the limit lifted: 2^16 points evaluate 726 -> 681 us (XFE), interpolate 265 -> 253 (BFE) but 450 -> 487
+// (XFE: 109 KB of LDS per leaf), level at 2^18, XFE interpolation 1.5 x slower at 2^20 -- hence 2^16 / 2^16 / 2^15.
+inline long long leaf_split_max() {
+    static const long long v = [] {
+        const char* e = getenv("TF_TREE_LEAF_SPLIT_MAX");
+        return e ? atoll(e) : (1ll << 15);
+    }();
+    return v;
+}
+
 struct ZerofierTree {
     int leaf = 0;              // points per leaf (tree_leaf(L) for a tree that is only evaluated on, tree_interp_leaf(L) otherwise)
     int h = 0;                 // levels 0 .. h-1 hold zerofiers of degree leaf << level (the root, level h, is never needed)
@@ -2546,7 +2557,7 @@ int zerofier_tree_evaluate(DeviceCtx* ctx, const ZerofierTree& T, const u64* F, 
     // a 2^12-point walk).  TF_TREE_NO_LEAF_SPLIT: A/B switch.
     static const bool no_split = getenv("TF_TREE_NO_LEAF_SPLIT") != nullptr;
     constexpr int kSplit = 4;
-    if (!no_split && UM <= (1ll << 15) && eval_leaf * kSplit <= 1024 && eval_leaf >= 16 * kSplit) {
+    if (!no_split && UM <= 2 * leaf_split_max() && eval_leaf * kSplit <= 1024 && eval_leaf >= 16 * kSplit) {
         hipLaunchKernelGGL((tfk::leaf_evaluate_split_kernel<L, kSplit>), dim3((unsigned)(UM / eval_leaf)), dim3(eval_leaf * kSplit),
                            (size_t)(1 + kSplit) * eval_leaf * L * sizeof(u64), s, cur, points, n_points, eval_leaf, vals, M / eval_leaf);
     } else {
@@ -2887,7 +2898,7 @@ int tree_interpolate_rows(DeviceCtx* ctx, const PaddedTree& pt, const u64* domai
         static const bool no_split = getenv("TF_TREE_NO_LEAF_SPLIT") != nullptr;
         constexpr int kSplit = 4;
         const size_t div_lds = ((size_t)2 * kTreeLeaf + (size_t)kTreeLeaf * (kTreeLeaf + 1) + (size_t)kSplit * kTreeLeaf) * L * sizeof(u64);
-        if (!no_split && h > 0 /* (a single leaf has no tree: no stored zerofier) */ && (long long)nr * M <= (1ll << 15) && kTreeLeaf * kSplit <= 1024 && kTreeLeaf >= 4 * kSplit && div_lds <= 144 * 1024) {
+        if (!no_split && h > 0 /* (a single leaf has no tree: no stored zerofier) */ && (long long)nr * M <= (L == 1 ? 2 : 1) * leaf_split_max() && kTreeLeaf * kSplit <= 1024 && kTreeLeaf >= 4 * kSplit && div_lds <= 144 * 1024) {
             static std::atomic<unsigned long long> done_mask{0};
             if (div_lds > 48 * 1024) rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&tfk::leaf_interpolant_div_kernel<L, kSplit>), 144 * 1024, done_mask);
             if (!rc)
