@@ -1682,6 +1682,125 @@ __global__ void __launch_bounds__(LOGN == 12 ? 512 : 256) tree_up_level_kernel(c
                           [&](int idx, u64 v) { if (act) dst[idx] = v; });
 }
 
+// ---- the same over XFieldElement: a line's three limb transforms run SIDE BY SIDE in three thread groups of one workgroup
+// (one after the other they would lose to separate launches); the extension-field products between the transforms read all three
+// limbs of an element from LDS and every group forms its own limb of the product (x_field_element.rs:512-536).
+__device__ __forceinline__ u64 xfe_mul_limb(u64 s0, u64 s1, u64 s2, u64 o0, u64 o1, u64 o2, int limb) {
+    if (limb == 0) return gl::sub(gl::sub(gl::mont_mul(s0, o0), gl::mont_mul(s2, o1)), gl::mont_mul(s1, o2));
+    if (limb == 1)
+        return gl::add(gl::add(gl::sub(gl::add(gl::mont_mul(s1, o0), gl::mont_mul(s0, o1)), gl::mont_mul(s2, o2)), gl::mont_mul(s2, o1)), gl::mont_mul(s1, o2));
+    return gl::add(gl::add(gl::add(gl::mont_mul(s2, o0), gl::mont_mul(s1, o1)), gl::mont_mul(s0, o2)), gl::mont_mul(s2, o2));
+}
+// threads of a workgroup: T lines x 3 limbs x N / 8
+template <int LOGN>
+struct TreeXfeGeom {
+    static constexpr int N = 1 << LOGN, TPT = N / 8;
+    static constexpr int T = TPT >= 128 ? 1 : 128 / TPT;
+    static constexpr int WG = 3 * TPT * T;
+    static constexpr int BUF = lat_pad(N * 3 * T) + 8;
+};
+
+template <int LOGN>
+__global__ void __launch_bounds__(TreeXfeGeom<LOGN>::WG) tree_down_level_xfe_kernel(const TreeLevelArgs A) {
+    using G = TreeXfeGeom<LOGN>;
+    constexpr int N = G::N, D = N / 2, TPT = G::TPT, T = G::T, BUF = G::BUF;
+    extern __shared__ __attribute__((aligned(16))) u64 lds[];
+    LatChain<LOGN> ch{lds, lds + BUF};
+    const int t = threadIdx.x, g = t / TPT, j = t - g * TPT, lw = g / 3, limb = g - 3 * lw, g0 = g - limb;
+    const long long line = (long long)blockIdx.x * T + lw;
+    const bool act = line < A.lines;
+    const long long c = act ? (long long)((u32)line % (u32)A.per) : 0;
+    const u64* f = A.cur + (act ? (line >> 1) : 0) * N * 3;
+    const u64* gh = A.ghat + c * N * 3;
+    const u64* th = A.that + c * N * 3;
+    u64* dst = A.nxt + (act ? line : 0) * D * 3;
+    u64 cv[8][3];  // the cached transform an extension-field product needs, at this thread's first-stage indices, requested ahead
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) cv[r][k] = gh[(j + r * TPT) * 3 + k];
+    u64* o = ch.out();
+    lat_xform<LOGN, false>(A.tw_f, 0, g, j, ch.first, ch.second,
+                           [&](int r, int idx) -> u64 { return (act && r < 4) ? f[(N - 1 - idx) * 3 + limb] : 0; },
+                           [&](int idx, u64 v) { o[lat_pad(g * N + idx)] = v; });
+    __syncthreads();
+    const u64* in = o;
+    ch.next(), o = ch.out();
+    lat_xform<LOGN, true>(A.tw_i, A.ninv, g, j, ch.first, ch.second,
+                          [&](int r, int idx) -> u64 {
+                              return xfe_mul_limb(in[lat_pad(g0 * N + idx)], in[lat_pad((g0 + 1) * N + idx)], in[lat_pad((g0 + 2) * N + idx)],
+                                                  cv[r][0], cv[r][1], cv[r][2], limb);
+                          },
+                          [&](int idx, u64 v) { if (idx < D) o[lat_pad(g * N + D - 1 - idx)] = v; });
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) cv[r][k] = th[(j + r * TPT) * 3 + k];
+    __syncthreads();
+    in = o;
+    ch.next(), o = ch.out();
+    lat_xform<LOGN, false>(A.tw_f, 0, g, j, ch.first, ch.second,
+                           [&](int r, int idx) -> u64 { return r < 4 ? in[lat_pad(g * N + idx)] : 0; },
+                           [&](int idx, u64 v) { o[lat_pad(g * N + idx)] = v; });
+    __syncthreads();
+    in = o;
+    ch.next();
+    lat_xform<LOGN, true>(A.tw_i, A.ninv, g, j, ch.first, ch.second,
+                          [&](int r, int idx) -> u64 {
+                              return xfe_mul_limb(in[lat_pad(g0 * N + idx)], in[lat_pad((g0 + 1) * N + idx)], in[lat_pad((g0 + 2) * N + idx)],
+                                                  cv[r][0], cv[r][1], cv[r][2], limb);
+                          },
+                          [&](int idx, u64 v) { if (act && idx < D) dst[idx * 3 + limb] = gl::sub(f[idx * 3 + limb], v); });
+}
+
+template <int LOGN>
+__global__ void __launch_bounds__(TreeXfeGeom<LOGN>::WG) tree_up_level_xfe_kernel(const TreeLevelArgs A) {
+    using G = TreeXfeGeom<LOGN>;
+    constexpr int N = G::N, D = N / 2, TPT = G::TPT, T = G::T, BUF = G::BUF;
+    constexpr bool EVEN = LatChain<LOGN>::EVEN;
+    extern __shared__ __attribute__((aligned(16))) u64 lds[];
+    u64* p = lds;
+    u64* q = lds + BUF;
+    u64* c = lds + 2 * BUF;
+    const int t = threadIdx.x, g = t / TPT, j = t - g * TPT, lw = g / 3, limb = g - 3 * lw, g0 = g - limb;
+    const long long line = (long long)blockIdx.x * T + lw;
+    const bool act = line < A.lines;
+    const u32 node = act ? (u32)line % (u32)A.per : 0;
+    const u64* c0 = A.cur + (act ? line : 0) * N * 3;
+    const u64* t0 = A.that + 2 * (long long)node * N * 3;
+    u64* dst = A.nxt + (act ? line : 0) * N * 3;
+    // Z_left, Z_right transforms (tail + x^d: (-1)^idx on limb 0) at this thread's first-stage indices (one array per limb: arrays
+    // of arrays captured by the lambdas below end up in scratch memory)
+    u64 zl0[8], zl1[8], zl2[8], zr0[8], zr1[8], zr2[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int idx = j + r * TPT;
+        const u64 sgn = (idx & 1) ? gl::P - gl::ONE : gl::ONE;
+        zl0[r] = gl::add(t0[idx * 3], sgn), zl1[r] = t0[idx * 3 + 1], zl2[r] = t0[idx * 3 + 2];
+        zr0[r] = gl::add(t0[(N + idx) * 3], sgn), zr1[r] = t0[(N + idx) * 3 + 1], zr2[r] = t0[(N + idx) * 3 + 2];
+    }
+    u64* a = EVEN ? q : p;
+    lat_xform<LOGN, false>(A.tw_f, 0, g, j, p, q, [&](int r, int idx) -> u64 { return (act && r < 4) ? c0[idx * 3 + limb] : 0; },
+                           [&](int idx, u64 v) { a[lat_pad(g * N + idx)] = v; });
+    __syncthreads();
+    u64* w0 = EVEN ? p : q;
+    u64* b = EVEN ? c : w0;
+    lat_xform<LOGN, false>(A.tw_f, 0, g, j, w0, c, [&](int r, int idx) -> u64 { return (act && r < 4) ? c0[(D + idx) * 3 + limb] : 0; },
+                           [&](int idx, u64 v) { b[lat_pad(g * N + idx)] = v; });
+    __syncthreads();
+    u64* f0 = EVEN ? w0 : c;
+    u64 v8[8];  // the combination N_left Z_right + N_right Z_left at this thread's first-stage indices
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int idx = j + r * TPT;
+        const u64 x = xfe_mul_limb(a[lat_pad(g0 * N + idx)], a[lat_pad((g0 + 1) * N + idx)], a[lat_pad((g0 + 2) * N + idx)], zr0[r], zr1[r], zr2[r], limb);
+        const u64 y = xfe_mul_limb(b[lat_pad(g0 * N + idx)], b[lat_pad((g0 + 1) * N + idx)], b[lat_pad((g0 + 2) * N + idx)], zl0[r], zl1[r], zl2[r], limb);
+        v8[r] = gl::add(x, y);
+    }
+    lat_xform<LOGN, true>(A.tw_i, A.ninv, g, j, f0, b, [&](int r, int) -> u64 { return v8[r]; },
+                          [&](int idx, u64 v) { if (act) dst[idx * 3 + limb] = v; });
+}
+
 // ---- 2^13 <= n <= 2^20, little work per call: the same eight-elements-per-thread stages as the two passes of n = N1 N2 ------
 // (one slice per call is the reference's own call shape: math/ntt.rs:67-82 takes ONE slice).  A "line" is one DFT instance:
 //   column pass (LAST = false): line c = word-column c of the N2 L words of a row; element i at  i * es + c;  after the last stage

@@ -1264,24 +1264,59 @@ int launch_tree_level_t(const tfk::TreeLevelArgs& a, hipStream_t stream) {
     HIPCHK(hipGetLastError());
     return TF_OK;
 }
+template <int LOGN, bool UP>
+int launch_tree_level_xfe_t(const tfk::TreeLevelArgs& a, hipStream_t stream) {
+    using G = tfk::TreeXfeGeom<LOGN>;
+    constexpr size_t lds = size_t(UP ? 3 : 2) * G::BUF * sizeof(u64);
+    static_assert(lds <= 160 * 1024, "level too long for one workgroup");
+    const void* fn = UP ? reinterpret_cast<const void*>(&tfk::tree_up_level_xfe_kernel<LOGN>) : reinterpret_cast<const void*>(&tfk::tree_down_level_xfe_kernel<LOGN>);
+    if constexpr (lds > 48 * 1024) {
+        static std::atomic<unsigned long long> done_mask{0};
+        if (int rc_attr = ensure_dynamic_lds(fn, (int)lds, done_mask)) return rc_attr;
+    }
+    const long long blocks = (a.lines + G::T - 1) / G::T;
+    if (UP) hipLaunchKernelGGL((tfk::tree_up_level_xfe_kernel<LOGN>), dim3((unsigned)blocks), dim3(G::WG), lds, stream, a);
+    else hipLaunchKernelGGL((tfk::tree_down_level_xfe_kernel<LOGN>), dim3((unsigned)blocks), dim3(G::WG), lds, stream, a);
+    HIPCHK(hipGetLastError());
+    return TF_OK;
+}
 // When: the level's transforms are the latency-shaped kernel's anyway AND the level is small enough that launches, not work,
 // are what it costs (measured crossover, tools/tree_latency.py / profiles/r03_tree_level_ab.txt).  TF_TREE_NO_LEVEL: A/B switch.
-bool tree_level_wanted(long long order, long long lines) {
+bool tree_level_wanted(long long order, long long lines, int L = 1, bool up = false) {
     static const bool off = getenv("TF_TREE_NO_LEVEL") != nullptr;
+    static const bool on_xfe = getenv("TF_TREE_LEVEL_XFE") != nullptr;  // measured loss, opt-in (below)
     static const long long limit = [] {
         const char* e = getenv("TF_TREE_LEVEL_MAX_WORDS");
         return e ? atoll(e) : (1ll << 22);  // (every width the latency-shaped transform serves: faster at each, profiles/r03_tree_level_ab.txt)
     }();
     if (off || order < 64 || order > 4096 || g_min_passes.load(std::memory_order_relaxed) != 0) return false;
-    if (!lat_wanted(ilog2((size_t)order), (size_t)lines, 1)) return false;
-    return lines * order <= limit;
+    // XFieldElement (tree_*_level_xfe_kernel: three thread groups per line; 2d <= 2048 fits a workgroup on the way down, 2d <= 1024
+    // on the way up) is a measured LOSS and off unless TF_TREE_LEVEL_XFE is set: prepared tree, 2^12 points, evaluate 243 -> 258 us,
+    // interpolate 160 -> 201 us (profiles/r03_tree_level_ab.txt) -- the extension-field products between the transforms are up to
+    // five base-field products per element and limb, 8 elements per thread: they lengthen the one instruction stream that bounds a
+    // level, where the separate pointwise kernels spread them over one thread per element.
+    if (L == 3 && (!on_xfe || order > (up ? 1024 : 2048))) return false;
+    if (!lat_wanted(ilog2((size_t)order), (size_t)lines, L)) return false;
+    return lines * order * L <= limit;
 }
 template <bool UP>
-int launch_tree_level(DeviceCtx* ctx, int log_n, tfk::TreeLevelArgs a, hipStream_t s) {
+int launch_tree_level(DeviceCtx* ctx, int log_n, tfk::TreeLevelArgs a, hipStream_t s, int L = 1) {
     int rc = get_lat_table(ctx, log_n, false, &a.tw_f);
     if (!rc) rc = get_lat_table(ctx, log_n, true, &a.tw_i);
     if (rc) return rc;
     a.ninv = gl::mont_inverse(gl::to_mont(u64(1) << log_n));
+    if (L == 3) {
+        switch (log_n) {
+            case 6: return launch_tree_level_xfe_t<6, UP>(a, s);
+            case 7: return launch_tree_level_xfe_t<7, UP>(a, s);
+            case 8: return launch_tree_level_xfe_t<8, UP>(a, s);
+            case 9: return launch_tree_level_xfe_t<9, UP>(a, s);
+            case 10: return launch_tree_level_xfe_t<10, UP>(a, s);
+            case 11:
+                if constexpr (!UP) return launch_tree_level_xfe_t<11, false>(a, s);
+        }
+        return TF_ERR_HIP;
+    }
     switch (log_n) {
         case 6: return launch_tree_level_t<6, UP>(a, s);
         case 7: return launch_tree_level_t<7, UP>(a, s);
@@ -2505,11 +2540,11 @@ int zerofier_tree_evaluate(DeviceCtx* ctx, const ZerofierTree& T, const u64* F, 
         // rev(q) = rev(f_high) g mod x^d   (below the top level the reversed upper halves come from the level above's last kernel)
         int rc = TF_OK;
         u64* nxt = (cur == ping) ? pong : ping;
-        if (L == 1 && tree_level_wanted(2 * d, all)) {
+        if (tree_level_wanted(2 * d, all, L, false)) {
             // the whole level in one launch: a line's four transforms never leave LDS
             tfk::TreeLevelArgs a{};
             a.cur = cur, a.nxt = nxt, a.ghat = T.Ghat[l], a.that = T.That[l], a.lines = all, a.per = children;
-            rc = launch_tree_level<false>(ctx, ilog2((size_t)(2 * d)), a, s);
+            rc = launch_tree_level<false>(ctx, ilog2((size_t)(2 * d)), a, s, L);
             if (rc) return rc;
             cur = nxt;
             continue;
@@ -2538,7 +2573,7 @@ int zerofier_tree_evaluate(DeviceCtx* ctx, const ZerofierTree& T, const u64* F, 
             continue;
         }
         const u64* fr_in = frq;
-        if (l == T.h - 1 || tree_fuse(4 * d, all / 2, L) || (L == 1 && tree_level_wanted(4 * d, all / 2))) {  // (a fused level above this one did not write frq)
+        if (l == T.h - 1 || tree_fuse(4 * d, all / 2, L) || tree_level_wanted(4 * d, all / 2, L, false)) {  // (a fused level above this one did not write frq)
             rc = launch_1d<L>(tfk::remainder_rev_high_kernel<L>, all * d, s, cur, fr, d, all);
             fr_in = fr;
         }
@@ -2920,12 +2955,12 @@ int tree_interpolate_rows(DeviceCtx* ctx, const PaddedTree& pt, const u64* domai
             // tail transforms, the combination N_left Z_right + N_right Z_left pointwise, one inverse transform -- which lands
             // in the next level's layout
             const long long d = (long long)kTreeLeaf << l, children = M / d, parents = children / 2;
-            if (L == 1 && tree_level_wanted(2 * d, parents * (long long)nr)) {
+            if (tree_level_wanted(2 * d, parents * (long long)nr, L, true)) {
                 // the whole level in one launch (both children's transforms, the combination and the inverse transform in LDS)
                 const bool direct = l == h - 1 && (long long)n == M;
                 tfk::TreeLevelArgs a{};
-                a.cur = cur, a.nxt = direct ? out + r0 * n : nxt, a.that = pt.T.That[l], a.lines = parents * (long long)nr, a.per = parents;
-                rc = launch_tree_level<true>(ctx, ilog2((size_t)(2 * d)), a, s);
+                a.cur = cur, a.nxt = direct ? out + r0 * n * L : nxt, a.that = pt.T.That[l], a.lines = parents * (long long)nr, a.per = parents;
+                rc = launch_tree_level<true>(ctx, ilog2((size_t)(2 * d)), a, s, L);
                 wrote_direct = direct;
                 std::swap(cur, nxt);
                 continue;
