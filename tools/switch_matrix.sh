@@ -39,6 +39,7 @@ run "TF_TREE_INTERP_LEAF_LOG=8" "trees that are walked upwards with 256-point le
 run "TF_TREE_NO_FUSE=1" "tree walks with the reverse / remainder steps as kernels of their own (round 3)"
 run "TF_TREE_NO_LEVEL=1" "tree walks with a level's transforms as launches of their own instead of one launch per level (round 3)"
 run "TF_TREE_NO_LEVEL=1 TF_TREE_NO_FUSE=1" "... and the elementwise steps as kernels too"
+run "TF_TREE_NO_BUILD_LEVEL=1" "tree build with a level's transforms as launches of their own (round 3)"
 run "TF_TREE_LEVEL_XFE=1" "one launch per level over XFieldElement too (three thread groups per line; measured loss, off by default)"
 run "TF_TREE_NO_LEAF_SPLIT=1" "one thread per point / per coefficient in the leaf kernels of small walks too (round 3)"
 run "TF_TREE_FUSE_INTERP=1" "the interpolation's pointwise combination fused into the inverse transform's load (round 3, off by default)"

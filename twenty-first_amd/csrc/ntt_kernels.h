@@ -1682,6 +1682,117 @@ __global__ void __launch_bounds__(LOGN == 12 ? 512 : 256) tree_up_level_kernel(c
                           [&](int idx, u64 v) { if (act) dst[idx] = v; });
 }
 
+// ---- a whole level of the zerofier-tree BUILD in one launch (BFieldElement, 2d <= 2048) ---------------------------------------
+// Per parent the build runs nine transforms (math/zerofier_tree.rs builds the same products with fast_multiply; the power-series
+// inverses are this design's own):
+//   phase 1  four transforms of order 2d: both children's tails and inverses  -> That, Ghat (kept for the walks)
+//   phase 2  tail_parent = iNTT((TL^ + s)(TR^ + s) - 1),   G = iNTT(GL^ GR^) mod x^d
+//   phase 3  two transforms of order 4d: G and H = rev(Z_parent) mod x^2d
+//   phase 4  inv_parent = iNTT(G^ (2 - H^ G^)) mod x^2d                       (one Newton step)
+// One workgroup slice (4 * 2d / 8 threads) per parent: the four / two transforms of a phase run side by side in thread groups,
+// everything between the phases stays in LDS (two buffers; LatChain's rule for where a result lands).  Groups without a
+// transform in a phase walk through its barriers on zeros.
+struct TreeBuildArgs {
+    const u64* tails;   // level l: [children][d]
+    const u64* inv;     // level l: [children][d]
+    u64* that;          // level l: [children][2d]
+    u64* ghat;          // level l: [children][2d]
+    u64* ptails;        // level l + 1: [parents][2d]   (null: top level, phase 1 only)
+    u64* pinv;          // level l + 1: [parents][2d]
+    const u64 *tw_f2, *tw_i2, *tw_f4, *tw_i4;  // ntt_lat_kernel's tables of order 2d and 4d
+    u64 ninv2, ninv4;
+    long long parents;
+};
+template <int LOGN2>
+struct TreeBuildGeom {
+    static constexpr int N2 = 1 << LOGN2, TPT2 = N2 / 8;
+    static constexpr int T = 4 * TPT2 >= 256 ? 1 : 256 / (4 * TPT2);  // parents per workgroup
+    static constexpr int WG = 4 * TPT2 * T;
+    static constexpr int BUF = lat_pad(N2 * 4 * T) + 8;
+};
+template <int LOGN2>
+__global__ void __launch_bounds__(TreeBuildGeom<LOGN2>::WG) tree_build_level_kernel(const TreeBuildArgs A) {
+    using G = TreeBuildGeom<LOGN2>;
+    constexpr int N2 = G::N2, D = N2 / 2, TPT2 = G::TPT2, T = G::T, BUF = G::BUF, LOGN4 = LOGN2 + 1, N4 = 2 * N2, TPT4 = 2 * TPT2;
+    constexpr bool EVEN2 = LatChain<LOGN2>::EVEN, EVEN4 = LatChain<LOGN4>::EVEN;
+    extern __shared__ __attribute__((aligned(16))) u64 lds[];
+    u64* P = lds;
+    u64* Q = lds + BUF;
+    const int t = threadIdx.x;
+    const int g = t / TPT2, j = t - g * TPT2, slot = g >> 2, role = g & 3;
+    const int g4 = t / TPT4, j4 = t - g4 * TPT4, role4 = g4 & 1;
+    const long long parent = (long long)blockIdx.x * T + slot;
+    const bool act = parent < A.parents;
+    const long long child = 2 * (act ? parent : 0) + (role & 1);
+    // ---- phase 1
+    u64* O1 = EVEN2 ? Q : P;
+    {
+        const u64* src = (role < 2 ? A.tails : A.inv) + child * D;
+        u64* dst = (role < 2 ? A.that : A.ghat) + child * N2;
+        lat_xform<LOGN2, false>(A.tw_f2, 0, g, j, P, Q, [&](int r, int idx) -> u64 { return (act && r < 4) ? src[idx] : 0; },
+                                [&](int idx, u64 v) {
+                                    O1[lat_pad(g * N2 + idx)] = v;
+                                    if (act) dst[idx] = v;
+                                });
+    }
+    if (!A.ptails) return;
+    __syncthreads();
+    // ---- phase 2: group 0 the parent's tail, group 2 the product of the children's inverses
+    u64* F2 = EVEN2 ? P : Q;           // = the buffer that does not hold O1
+    u64* O2 = EVEN2 ? O1 : F2;
+    {
+        const int gb = g & ~3;
+        u64* pt = A.ptails + (act ? parent : 0) * N2;
+        lat_xform<LOGN2, true>(A.tw_i2, A.ninv2, g, j, F2, O1,
+                               [&](int, int idx) -> u64 {
+                                   if (role == 0) {
+                                       const u64 sgn = (idx & 1) ? gl::P - gl::ONE : gl::ONE;
+                                       const u64 a = gl::add(O1[lat_pad(gb * N2 + idx)], sgn), b = gl::add(O1[lat_pad((gb + 1) * N2 + idx)], sgn);
+                                       return gl::sub(gl::mont_mul(a, b), gl::ONE);
+                                   }
+                                   if (role == 2) return gl::mont_mul(O1[lat_pad((gb + 2) * N2 + idx)], O1[lat_pad((gb + 3) * N2 + idx)]);
+                                   return 0;
+                               },
+                               [&](int idx, u64 v) {
+                                   if (role == 0) {
+                                       O2[lat_pad(g * N2 + idx)] = v;
+                                       if (act) pt[idx] = v;
+                                   } else if (role == 2 && idx < D) {
+                                       O2[lat_pad(g * N2 + idx)] = v;
+                                   }
+                               });
+    }
+    __syncthreads();
+    // ---- phase 3 (order 4d, two groups per parent): G^ and H^
+    u64* F3 = (O2 == P) ? Q : P;
+    u64* O3 = EVEN4 ? O2 : F3;
+    {
+        const int nb = (g4 & ~1) * 2;  // first 2d-sized region of this parent
+        lat_xform<LOGN4, false>(A.tw_f4, 0, g4, j4, F3, O2,
+                                [&](int r, int idx) -> u64 {
+                                    if (role4 == 0) return idx < D ? O2[lat_pad((nb + 2) * N2 + idx)] : 0;  // G = (g_l g_r) mod x^d
+                                    if (idx >= N2) return 0;                                                  // H = rev(Z_parent) mod x^2d
+                                    return idx == 0 ? gl::ONE : O2[lat_pad(nb * N2 + N2 - idx)];
+                                },
+                                [&](int idx, u64 v) { O3[lat_pad(g4 * N4 + idx)] = v; });
+    }
+    __syncthreads();
+    // ---- phase 4 (order 4d): one Newton step, its low 2d coefficients are the parent's inverse
+    u64* F4 = (O3 == P) ? Q : P;
+    {
+        const int gp = g4 & ~1;
+        u64* pi = A.pinv + (act ? parent : 0) * N2;
+        const u64 two = gl::add(gl::ONE, gl::ONE);
+        lat_xform<LOGN4, true>(A.tw_i4, A.ninv4, g4, j4, F4, O3,
+                               [&](int, int idx) -> u64 {
+                                   if (role4) return 0;
+                                   const u64 gh = O3[lat_pad(gp * N4 + idx)], hh = O3[lat_pad((gp + 1) * N4 + idx)];
+                                   return gl::mont_mul(gh, gl::sub(two, gl::mont_mul(hh, gh)));
+                               },
+                               [&](int idx, u64 v) { if (act && role4 == 0 && idx < N2) pi[idx] = v; });
+    }
+}
+
 // ---- the same over XFieldElement: a line's three limb transforms run SIDE BY SIDE in three thread groups of one workgroup
 // (one after the other they would lose to separate launches); the extension-field products between the transforms read all three
 // limbs of an element from LDS and every group forms its own limb of the product (x_field_element.rs:512-536).

@@ -1329,6 +1329,51 @@ int launch_tree_level(DeviceCtx* ctx, int log_n, tfk::TreeLevelArgs a, hipStream
     return TF_ERR_HIP;
 }
 
+// ---- one launch per level of a small zerofier-tree BUILD (tree_build_level_kernel, BFieldElement, 128 <= 2d <= 2048)
+template <int LOGN2>
+int launch_tree_build_level_t(const tfk::TreeBuildArgs& a, hipStream_t stream) {
+    using G = tfk::TreeBuildGeom<LOGN2>;
+    constexpr size_t lds = size_t(2) * G::BUF * sizeof(u64);
+    static_assert(lds <= 160 * 1024, "level too long for one workgroup");
+    if constexpr (lds > 48 * 1024) {
+        static std::atomic<unsigned long long> done_mask{0};
+        if (int rc_attr = ensure_dynamic_lds(reinterpret_cast<const void*>(&tfk::tree_build_level_kernel<LOGN2>), (int)lds, done_mask)) return rc_attr;
+    }
+    const long long blocks = (a.parents + G::T - 1) / G::T;
+    hipLaunchKernelGGL((tfk::tree_build_level_kernel<LOGN2>), dim3((unsigned)blocks), dim3(G::WG), lds, stream, a);
+    HIPCHK(hipGetLastError());
+    return TF_OK;
+}
+// When: a small tree (the build of 2^12 points was 58 launches, 378 of the 655 us of a one-shot interpolation).  TF_TREE_NO_BUILD_LEVEL:
+// A/B switch; TF_TREE_BUILD_MAX_WORDS: sweep hook (words of one level's transforms, 2 M).
+bool tree_build_level_wanted(long long order, long long parents) {
+    static const bool off = getenv("TF_TREE_NO_BUILD_LEVEL") != nullptr;
+    static const long long limit = [] {
+        const char* e = getenv("TF_TREE_BUILD_MAX_WORDS");
+        return e ? atoll(e) : (1ll << 22);  // (2^16 / 2^18 words lose 7 % / 5 % on one-shot calls at 2^16 / 2^18 points; 2^20 and 2^22 level)
+    }();
+    if (off || order < 128 || order > 2048 || g_min_passes.load(std::memory_order_relaxed) != 0) return false;
+    if (g_lat_mode.load(std::memory_order_relaxed) == 0 || !lat_wanted(ilog2((size_t)order), (size_t)(2 * parents), 1)) return false;
+    return 2 * parents * order <= limit;
+}
+int launch_tree_build_level(DeviceCtx* ctx, int log_n2, tfk::TreeBuildArgs a, hipStream_t s) {
+    int rc = get_lat_table(ctx, log_n2, false, &a.tw_f2);
+    if (!rc) rc = get_lat_table(ctx, log_n2, true, &a.tw_i2);
+    if (!rc) rc = get_lat_table(ctx, log_n2 + 1, false, &a.tw_f4);
+    if (!rc) rc = get_lat_table(ctx, log_n2 + 1, true, &a.tw_i4);
+    if (rc) return rc;
+    a.ninv2 = gl::mont_inverse(gl::to_mont(u64(1) << log_n2));
+    a.ninv4 = gl::mont_inverse(gl::to_mont(u64(2) << log_n2));
+    switch (log_n2) {
+        case 7: return launch_tree_build_level_t<7>(a, s);
+        case 8: return launch_tree_build_level_t<8>(a, s);
+        case 9: return launch_tree_build_level_t<9>(a, s);
+        case 10: return launch_tree_build_level_t<10>(a, s);
+        case 11: return launch_tree_build_level_t<11>(a, s);
+    }
+    return TF_ERR_HIP;
+}
+
 // ---- 2^13 .. 2^20 points with little work: the two passes of n = N1 N2 on the eight-elements-per-thread stages (ntt_lat2_kernel)
 template <int LOGN, bool INV, bool LAST, int WG = 256>
 int launch_lat2_t(const tfk::NttLat2Args& a, size_t batch, hipStream_t stream) {
@@ -2473,6 +2518,15 @@ int zerofier_tree_build(DeviceCtx* ctx, const u64* points, long long n_points, Z
     HIPCHK(hipGetLastError());
     for (int l = 0; l < h; ++l) {
         const long long d = (long long)kTreeLeaf << l, children = M / d, parents = children / 2;
+        if (L == 1 && tree_build_level_wanted(2 * d, parents)) {
+            // the whole level in one launch: this level's transforms and, unless it is the top one, the parents' tails and inverses
+            tfk::TreeBuildArgs a{};
+            a.tails = T->tails[l], a.inv = T->inv[l], a.that = T->That[l], a.ghat = T->Ghat[l], a.parents = parents;
+            if (l + 1 < h) a.ptails = T->tails[l + 1], a.pinv = T->inv[l + 1];
+            int rcl = launch_tree_build_level(ctx, ilog2((size_t)(2 * d)), a, s);
+            if (rcl) return rcl;
+            continue;
+        }
         // transforms of order 2d of this level's tails and inverses: kept for the walks, and the parents are built from them
         int rc = run_ntt(ctx, T->tails[l], T->That[l], d * L, 2 * d * L, (size_t)(2 * d), (size_t)children, L, false, nullptr, d, s);
         if (!rc) rc = run_ntt(ctx, T->inv[l], T->Ghat[l], d * L, 2 * d * L, (size_t)(2 * d), (size_t)children, L, false, nullptr, d, s);
@@ -3006,6 +3060,9 @@ int interpolate_dev_t(const u64* domain, const u64* values, size_t n, size_t row
     int rc = padded_tree_build<L>(domain, n, (size_t)M * L, &pt, s);  // extra: the inverse weights
     DeviceCtx* ctx = nullptr;
     if (!rc) rc = current_ctx(&ctx);
+    // (The synchronising entry points wait for the repeated-point check between the weights and the walk up.  Reading it back
+    //  once, after the whole call had been enqueued, was tried: isolated-call latency 481.8 vs 479.2 us at 2^12 points, 170.5 vs
+    //  167.5 at 2^8 -- the extra status launches cost what the removed bubble saved; not kept.)
     if (!rc) rc = tree_inverse_weights<L>(ctx, pt, domain, pt.extra, s, d_status);
     if (!rc) rc = tree_interpolate_rows<L>(ctx, pt, domain, pt.extra, values, rows, out, s);
     return padded_tree_free(&pt, s, rc);
