@@ -173,11 +173,12 @@ def test_batch_evaluation_router_is_host_logic_with_the_measured_crossovers(tf):
     lib.tf_set_batch_eval_route(0)
     try:
         # (n_coeffs, n_points, batch, width) -> route; 1 = Horner, 2 = tree
-        # (round 3: profiles/r03_batch_eval_fine_w1.txt / _w3.txt -- the latency-shaped transforms moved every crossover down)
+        # (round 3: profiles/r03_batch_eval_fine_w1_b.txt / _w3_b.txt -- the latency-shaped transforms and the one-launch-per-level
+        #  build and walks moved every crossover down; Horner has a floor of n dependent steps however few the points)
         measured = [((1 << 12, 1 << 12, 1, 1), 1), ((1 << 14, 1 << 12, 1, 1), 1), ((1 << 14, 1 << 14, 1, 1), 1), ((1 << 14, 1 << 16, 1, 1), 1),
-                    ((1 << 16, 1 << 13, 1, 1), 1), ((1 << 16, 1 << 14, 1, 1), 1), ((1 << 16, 1 << 15, 1, 1), 2), ((1 << 16, 1 << 16, 1, 1), 2),
+                    ((1 << 16, 1 << 13, 1, 1), 1), ((1 << 16, 1 << 14, 1, 1), 2), ((1 << 16, 1 << 15, 1, 1), 2), ((1 << 16, 1 << 16, 1, 1), 2),
                     ((1 << 18, 1 << 11, 1, 1), 1), ((1 << 18, 1 << 12, 1, 1), 2), ((1 << 18, 1 << 14, 1, 1), 2), ((1 << 18, 1 << 16, 1, 1), 2),
-                    ((1 << 18, 1 << 18, 1, 1), 2), ((1 << 20, 1 << 12, 1, 1), 2), ((1 << 20, 1 << 20, 1, 1), 2), ((1 << 22, 1 << 16, 1, 1), 2),
+                    ((1 << 18, 1 << 18, 1, 1), 2), ((1 << 20, 1 << 9, 1, 1), 2), ((1 << 20, 1 << 10, 1, 1), 2), ((1 << 20, 1 << 12, 1, 1), 2), ((1 << 20, 1 << 20, 1, 1), 2), ((1 << 22, 1 << 16, 1, 1), 2),
                     ((1 << 12, 1 << 14, 1, 3), 1), ((1 << 14, 1 << 12, 1, 3), 1), ((1 << 14, 1 << 14, 1, 3), 2), ((1 << 16, 1 << 10, 1, 3), 1),
                     ((1 << 16, 1 << 12, 1, 3), 2), ((1 << 16, 1 << 13, 1, 3), 2), ((1 << 16, 1 << 14, 1, 3), 2),
                     ((1 << 16, 1 << 16, 1, 3), 2), ((1 << 18, 1 << 14, 1, 3), 2), ((1 << 20, 1 << 20, 1, 3), 2)]

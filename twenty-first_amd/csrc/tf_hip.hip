@@ -2686,18 +2686,21 @@ bool tree_route(size_t n_coeffs, size_t n_points, size_t batch, int L) {
     if (force && !strcmp(force, "tree")) return true;
     // Cost model fitted to tools/batch_eval_sweep.py <width> fine on MI355X (profiles/r03_batch_eval_fine_w*.txt), milliseconds:
     //   Horner  n m / 1.4e9            (x 8 over XFieldElement: nine base-field products per step; measured 7 - 10)
-    //   tree    build + one walk for the first unit: latency-bound per level up to 2^12 points (0.08 ms a level with one
-    //           launch per level of the walk down, round 3), twice that per level above, plus a throughput term in M beyond 2^16 points;
-    //           the units walk TOGETHER, so every further unit adds only its share of the throughput term: 0.04 ms per 2^16
+    //   tree    build + one walk for the first unit: latency-bound per level up to 2^12 points (0.07 ms a level with one
+    //           launch per level of the build and of the walk down, round 3), twice that per level above, plus a throughput term in M beyond 2^16 points;
+    //           the units walk TOGETHER, so every further unit adds only its share of the throughput term: 0.03 ms per 2^16
     //           points (0.16 over XFE)
     int levels = 0;
     for (size_t v = kTreeLeaf; v < M; v <<= 1) ++levels;
-    const double horner_ms = (double)batch * (double)n_coeffs * (double)n_points / 1.4e9 * (L == 3 ? 8.0 : 1.0);
+    // (Horner is one thread per point: however few the points, a polynomial costs its n dependent steps -- 1.0 ns each, 3.1 over
+    //  XFieldElement: 2^20 coefficients at 2^9 points 1.09 ms where the product term says 0.38)
+    const double horner_ms = std::max((double)batch * (double)n_coeffs * (double)n_points / 1.4e9 * (L == 3 ? 8.0 : 1.0),
+                                      (double)n_coeffs * (L == 3 ? 3.1e-6 : 1.0e-6));
     const double m16 = (double)M / 65536.0;
     const double first_ms = L == 3 ? 0.25 + 0.085 * levels + 0.10 * std::max(0, levels - 4) + 0.25 * m16
-                                   : 0.10 + 0.08 * levels + 0.09 * std::max(0, levels - 4) + 0.055 * m16;
-    const double tree_ms = first_ms + (double)(units - 1) * (L == 3 ? 0.16 : 0.04) * m16;
-    return tree_ms < 0.9 * horner_ms;
+                                   : 0.09 + 0.07 * levels + 0.09 * std::max(0, levels - 4) + 0.055 * m16;
+    const double tree_ms = first_ms + (double)(units - 1) * (L == 3 ? 0.16 : 0.03) * m16;
+    return tree_ms < 0.95 * horner_ms;
 }
 
 // `batch` polynomials down an existing tree (levels >= 1).  A polynomial longer than M is cut into chunks of M coefficients; all
