@@ -745,7 +745,9 @@ def side_measurements(tf, torch, dev):
         with tf.device.ZerofierTree(dom) as tree:
             us_e = _timed(lambda: tree.batch_evaluate(cf, 1 << 12, vals), reps=50) * 1e3
             us_i = _timed(lambda: tree.interpolate(vals, back), reps=50) * 1e3
+        us_o = _timed(lambda: tf.device.interpolate(dom, vals, back), reps=20) * 1e3  # the reference's call shape: tree built inside the call
         extra["zerofier_tree_2p12_points"] = {"prepared_tree_evaluate_us": round(us_e, 1), "prepared_tree_interpolate_us": round(us_i, 1),
+                                              "one_shot_interpolate_us": round(us_o, 1),
                                               "evaluate_then_interpolate_is_identity": bool(torch.equal(back, cf))}
         del dom, cf, vals, back
         # PCIe-inclusive figure of the host-pointer entry point (pageable numpy buffers, 32 x 2^20 BFE = 256 MiB each way)

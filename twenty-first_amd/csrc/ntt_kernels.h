@@ -1322,6 +1322,9 @@ __global__ void __launch_bounds__(512, 4) ntt_rows32_kernel(const NttRows32Args 
 //     v[r] = in[u + r n / R] w_{Ns R}^(k r),   V = DFT_R(v),   out[(u / Ns) Ns R + k + r Ns] = V[r]
 // (natural order in and out, no bit reversal).  The last stage has radix 8, 4 or 2 (8 / R units per thread).
 // XFieldElement slices are three limb transforms of element stride 3 (ntt.rs:203-207).
+#ifndef TF_LAT_MUL4
+#define TF_LAT_MUL4 1  // 0 (A/B build): the stage twiddles of the latency-shaped kernels as eight single products
+#endif
 struct NttLatArgs {
     const u64* in;
     u64* out;
@@ -1444,6 +1447,17 @@ __global__ void __launch_bounds__(LOGN == 12 ? 512 : 256) ntt_lat_kernel(const N
 #pragma unroll
             for (int r = 0; r < R; ++r) v[a * R + r] = in[lat_pad(tr * N + u + r * (N / R))];
         }
+#if TF_LAT_MUL4
+        if (logr == 3) {  // (see lat_xform: two blocks of four interleaved products)
+            u64 a0[4] = {v[1], v[2], v[3], v[4]}, b0[4] = {tw[s - 1][1], tw[s - 1][2], tw[s - 1][3], tw[s - 1][4]}, r0[4];
+            u64 a1[4] = {v[5], v[6], v[7], v[0]}, b1[4] = {tw[s - 1][5], tw[s - 1][6], tw[s - 1][7], (INV && last) ? A.ninv : gl::ONE}, r1[4];
+            gl::mont_mul4(a0, b0, r0);
+            gl::mont_mul4(a1, b1, r1);
+            x[lat_brev<3>(0)] = (INV && last) ? r1[3] : v[0];
+            x[lat_brev<3>(1)] = r0[0], x[lat_brev<3>(2)] = r0[1], x[lat_brev<3>(3)] = r0[2], x[lat_brev<3>(4)] = r0[3];
+            x[lat_brev<3>(5)] = r1[0], x[lat_brev<3>(6)] = r1[1], x[lat_brev<3>(7)] = r1[2];
+        } else
+#endif
 #pragma unroll
         for (int a = 0; a < U; ++a) {
 #pragma unroll
@@ -1533,15 +1547,30 @@ __device__ __forceinline__ void lat_xform(const u64* __restrict__ twtab, u64 nin
 #pragma unroll
             for (int r = 0; r < R; ++r) v[a * R + r] = in[lat_pad(tr * N + u + r * (N / R))];
         }
+#if TF_LAT_MUL4
+        if (logr == 3) {
+            // eight products in two blocks of four interleaved carry chains (gl::mont_mul4: 15 VALU per product and no wait-state
+            // nops, against 18 + nops for products issued one by one); the slot of r = 0 rides along with n^-1 or with one
+            u64 a0[4] = {v[1], v[2], v[3], v[4]}, b0[4] = {tw[s - 1][1], tw[s - 1][2], tw[s - 1][3], tw[s - 1][4]}, r0[4];
+            u64 a1[4] = {v[5], v[6], v[7], v[0]}, b1[4] = {tw[s - 1][5], tw[s - 1][6], tw[s - 1][7], (INV && last) ? ninv : gl::ONE}, r1[4];
+            gl::mont_mul4(a0, b0, r0);
+            gl::mont_mul4(a1, b1, r1);
+            x[lat_brev<3>(0)] = (INV && last) ? r1[3] : v[0];
+            x[lat_brev<3>(1)] = r0[0], x[lat_brev<3>(2)] = r0[1], x[lat_brev<3>(3)] = r0[2], x[lat_brev<3>(4)] = r0[3];
+            x[lat_brev<3>(5)] = r1[0], x[lat_brev<3>(6)] = r1[1], x[lat_brev<3>(7)] = r1[2];
+        } else
+#endif
+        {
 #pragma unroll
-        for (int a = 0; a < U; ++a) {
+            for (int a = 0; a < U; ++a) {
 #pragma unroll
-            for (int r = 0; r < R; ++r) {
-                u64 w = v[a * R + r];
-                if (r) w = gl::mont_mul(w, tw[s - 1][a * R + r]);
-                else if (INV && last) w = gl::mont_mul(w, ninv);
-                const int slot = a * R + (logr == 3 ? lat_brev<3>(r) : (logr == 2 ? lat_brev<2>(r) : r));
-                x[slot] = w;
+                for (int r = 0; r < R; ++r) {
+                    u64 w = v[a * R + r];
+                    if (r) w = gl::mont_mul(w, tw[s - 1][a * R + r]);
+                    else if (INV && last) w = gl::mont_mul(w, ninv);
+                    const int slot = a * R + (logr == 3 ? lat_brev<3>(r) : (logr == 2 ? lat_brev<2>(r) : r));
+                    x[slot] = w;
+                }
             }
         }
         if (logr == 3) lat_dft<INV, 3>(x);
@@ -2020,6 +2049,17 @@ __global__ void __launch_bounds__(WG) ntt_lat2_kernel(const NttLat2Args A) {
                 for (int r = 0; r < R; ++r) ptw[a * R + r] = A.post_tw[(long long)(j0 + r * Ns) * A.tw_rs + chi];
             }
         }
+#if TF_LAT_MUL4
+        if (logr == 3) {  // (see lat_xform: two blocks of four interleaved products)
+            u64 a0[4] = {v[1], v[2], v[3], v[4]}, b0[4] = {tw[s - 1][1], tw[s - 1][2], tw[s - 1][3], tw[s - 1][4]}, r0[4];
+            u64 a1[4] = {v[5], v[6], v[7], v[0]}, b1[4] = {tw[s - 1][5], tw[s - 1][6], tw[s - 1][7], (LAST && INV && last) ? A.scale : gl::ONE}, r1[4];
+            gl::mont_mul4(a0, b0, r0);
+            gl::mont_mul4(a1, b1, r1);
+            x[lat_brev<3>(0)] = (LAST && INV && last) ? r1[3] : v[0];
+            x[lat_brev<3>(1)] = r0[0], x[lat_brev<3>(2)] = r0[1], x[lat_brev<3>(3)] = r0[2], x[lat_brev<3>(4)] = r0[3];
+            x[lat_brev<3>(5)] = r1[0], x[lat_brev<3>(6)] = r1[1], x[lat_brev<3>(7)] = r1[2];
+        } else
+#endif
 #pragma unroll
         for (int a = 0; a < U; ++a) {
 #pragma unroll

@@ -2528,8 +2528,9 @@ int zerofier_tree_build(DeviceCtx* ctx, const u64* points, long long n_points, Z
             continue;
         }
         // transforms of order 2d of this level's tails and inverses: kept for the walks, and the parents are built from them
-        int rc = run_ntt(ctx, T->tails[l], T->That[l], d * L, 2 * d * L, (size_t)(2 * d), (size_t)children, L, false, nullptr, d, s);
-        if (!rc) rc = run_ntt(ctx, T->inv[l], T->Ghat[l], d * L, 2 * d * L, (size_t)(2 * d), (size_t)children, L, false, nullptr, d, s);
+        // (ONE call: the level's tails and inverses are neighbours in the arena, and so are their transforms)
+        static_assert(kTreeLevelArrays == 6, "tails | inv | That (2) | Ghat (2)");
+        int rc = run_ntt(ctx, T->tails[l], T->That[l], d * L, 2 * d * L, (size_t)(2 * d), (size_t)(2 * children), L, false, nullptr, d, s);
         if (rc) return rc;
         if (l + 1 == h) break;
         u64* S1 = work;              // parents x 2d    g_left g_right (its low half is G)
@@ -2990,12 +2991,12 @@ int tree_interpolate_rows(DeviceCtx* ctx, const PaddedTree& pt, const u64* domai
         static const bool no_split = getenv("TF_TREE_NO_LEAF_SPLIT") != nullptr;
         constexpr int kSplit = 4;
         const size_t div_lds = ((size_t)2 * kTreeLeaf + (size_t)kTreeLeaf * (kTreeLeaf + 1) + (size_t)kSplit * kTreeLeaf) * L * sizeof(u64);
-        if (!no_split && h > 0 /* (a single leaf has no tree: no stored zerofier) */ && (long long)nr * M <= (L == 1 ? 2 : 1) * leaf_split_max() && kTreeLeaf * kSplit <= 1024 && kTreeLeaf >= 4 * kSplit && div_lds <= 144 * 1024) {
+        if (!no_split && (long long)nr * M <= (L == 1 ? 2 : 1) * leaf_split_max() && kTreeLeaf * kSplit <= 1024 && kTreeLeaf >= 4 * kSplit && div_lds <= 144 * 1024) {
             static std::atomic<unsigned long long> done_mask{0};
             if (div_lds > 48 * 1024) rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&tfk::leaf_interpolant_div_kernel<L, kSplit>), 144 * 1024, done_mask);
             if (!rc)
                 hipLaunchKernelGGL((tfk::leaf_interpolant_div_kernel<L, kSplit>), dim3((unsigned)(M / kTreeLeaf), (unsigned)nr), dim3(kTreeLeaf * kSplit),
-                                   div_lds, s, domain, values + r0 * n * L, winv, (const u64*)(h > 0 ? pt.T.tails[0] : nullptr), (long long)n, kTreeLeaf, M, na);
+                                   div_lds, s, domain, values + r0 * n * L, winv, (const u64*)(h > 0 ? pt.T.tails[0] : pt.root_tail) /* a single leaf is the root */, (long long)n, kTreeLeaf, M, na);
         } else {
             if (6 * kTreeLeaf * L * sizeof(u64) > 48 * 1024)  // only with a leaf size forced through TF_TREE_LEAF_LOG
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tfk::leaf_interpolant_kernel<L>), hipFuncAttributeMaxDynamicSharedMemorySize,
