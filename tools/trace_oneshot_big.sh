@@ -8,7 +8,7 @@ OUT=$REPO/gpurun_out/${TAG}_oneshotbig_$LOG.txt
 cd /tmp && export TMPDIR=/tmp
 D=$REPO/gpurun_out/trace_${TAG}_oneshotbig$LOG
 rm -rf "$D"
-rocprofv3 --kernel-trace --output-format csv -d "$D" -o t -- python $REPO/tools/oneshot_target.py 1 $LOG > /dev/null 2>&1
+rocprofv3 --kernel-trace --output-format csv -d "$D" -o t -- python $REPO/tools/oneshot_target.py ${WIDTH:-1} $LOG > /dev/null 2>&1
 F=$(find "$D" -name '*kernel_trace.csv' | head -1)
 python3 - "$F" > "$OUT" <<'PY'
 import csv,sys
