@@ -97,8 +97,6 @@ def cpu_baseline_ntt(log_n, batch, seed):
         tried[th] = batch * n / (t1 - t0) / 1e9
     threads = max(tried, key=tried.get)
     multi = tried[threads]
-    k = min(batch, 32)  # word-for-word parity sample: the first 32 transforms
-    sample_out = tfo.ntt(x[: k * n], batch=k, threads=min(threads, k))
     info = {
         "value": round(multi, 4),
         "unit": "GFelts/s",
@@ -110,7 +108,7 @@ def cpu_baseline_ntt(log_n, batch, seed):
         "build_flags": flags,
         "single_thread_value": round(single, 5),
     }
-    return info, sample_out
+    return info, None
 
 
 def cpu_baseline_merkle(n_leaves, seed):
@@ -142,6 +140,96 @@ def cpu_baseline_merkle(n_leaves, seed):
         "single_thread_value": round(single, 1),
     }
     return info, nodes[5:10].copy(), nodes
+
+
+def cpu_baseline_coset(n, batch, seed, offset_raw):
+    """Oracle leg of configs[3]: `batch` XFieldElement polynomials of n coefficients, fast_coset_evaluate on the coset of order n,
+    one polynomial per thread (benches/polynomial_coset.rs:15-47 is the reference's own, single-polynomial, shape).  Returns
+    (dict, the evaluations of polynomial 0)."""
+    from oracle import tfo
+
+    flags = tfo.use_native_build()
+    cores = os.cpu_count() or 1
+    c = tfo.fill_random(3 * n * batch, seed)
+    tfo.ntt(c[:n].copy())  # twiddle cache outside the timed region
+    t0 = time.perf_counter()
+    want0 = tfo.coset_evaluate(c[: 3 * n], offset_raw, n, width=3)
+    single = n / (time.perf_counter() - t0) / 1e9
+    tried = {}
+    for th in sorted(set(max(1, min(k, batch)) for k in (16, 32, 64, cores))):
+        t0 = time.perf_counter()
+        tfo.coset_evaluate_batch(c, offset_raw, n, batch, width=3, threads=th)
+        tried[th] = batch * n / (time.perf_counter() - t0) / 1e9
+    threads = max(tried, key=tried.get)
+    info = {
+        "value": round(tried[threads], 5),
+        "unit": "G points/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": f"all {batch} polynomials (2^{n.bit_length() - 1} XFE coefficients each), one polynomial per thread; best of "
+                  + ", ".join(f"{k} threads: {v:.4f}" for k, v in tried.items())
+                  + f" G points/s on {cores} host CPUs; scale + ntt restatement of math/polynomial.rs:760-773,1374-1399 (oracle/tf_oracle.c)",
+        "build_flags": flags,
+        "single_thread_value": round(single, 5),
+    }
+    return info, want0
+
+
+def library_identity(tf):
+    """What the timed library is: its ABI version and the hash of the sources it was built from (tf_source_hash, stamped by
+    csrc/Makefile).  Stored profiles carry the same pair; a figure taken from a profile of ANOTHER build is dropped."""
+    L = tf.lib()
+    return {"tf_version": int(L.tf_version()), "source_hash": L.tf_source_hash().decode()}
+
+
+def profile_matches(profile, ident):
+    lib = (profile or {}).get("library")
+    return bool(lib) and lib.get("source_hash") == ident["source_hash"] and lib.get("tf_version") == ident["tf_version"]
+
+
+def sharding_all_true(ctx, flag):
+    from twenty_first_amd import sharding
+
+    return sharding.all_ranks_true(flag, device=ctx["dev"]) if ctx["use_dist"] else bool(flag)
+
+
+def check_ntt_units(ctx, seed, units, n, threads=1):
+    """Word-for-word parity of whole transforms against the oracle: unit u of the job is elements [u n, (u + 1) n) of the seed's
+    counter-based sequence; the inputs are regenerated on the device and on the host, transformed by the HIP path and by the
+    oracle (math/ntt.rs:153-215 restatement), and compared.  Returns True when every word of every unit agrees."""
+    from oracle import tfo
+
+    tf, torch, np, dev = ctx["tf"], ctx["torch"], ctx["np"], ctx["dev"]
+    units = list(units)
+    if not units:
+        return True
+    t = torch.empty(len(units) * n, dtype=torch.int64, device=dev)
+    for i, u in enumerate(units):
+        tf.device.fill_random(t[i * n:(i + 1) * n], seed, first_index=u * n)
+    tf.device.ntt_(t, n, batch=len(units))
+    torch.cuda.synchronize()
+    got = t.cpu().numpy().view(np.uint64)
+    host = np.concatenate([tfo.fill_random(n, seed, first_index=u * n) for u in units])
+    want = tfo.ntt(host, batch=len(units), threads=max(1, min(threads, len(units))))
+    return bool(np.array_equal(got, want))
+
+
+def check_tree_units(ctx, seed, units, nl, threads=1):
+    """Every node of whole trees against the oracle's par_new restatement (util_types/merkle_tree.rs:165-212): tree u of the job
+    has leaves [u 5 nl, (u + 1) 5 nl) of the seed's sequence."""
+    from oracle import tfo
+
+    tf, torch, np, dev = ctx["tf"], ctx["torch"], ctx["np"], ctx["dev"]
+    for u in units:
+        lv = torch.empty(5 * nl, dtype=torch.int64, device=dev)
+        tf.device.fill_random(lv, seed, first_index=u * 5 * nl)
+        nodes = torch.empty(10 * nl, dtype=torch.int64, device=dev)
+        tf.device.merkle_build(lv, nl, nodes)
+        torch.cuda.synchronize()
+        want = tfo.merkle_build(tfo.fill_random(5 * nl, seed, first_index=u * 5 * nl), threads=threads)
+        if not np.array_equal(nodes.cpu().numpy().view(np.uint64)[5:], want[5:]):
+            return False
+    return True
 
 
 def main():
@@ -176,6 +264,12 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    if rank == 0 and not args.no_cpu_baseline:
+        # the timed CPU legs run the oracle built -O3 -march=native on THIS host: it has to be chosen before the oracle library is
+        # first loaded (the parity checks load it too).  Rank 0 times; the other ranks only check parity, on the portable build.
+        from oracle import tfo
+
+        tfo.use_native_build()
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != max(1, args.gpus):
         raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE={world}")
@@ -212,7 +306,7 @@ def main():
         return float(t.item())
 
     ctx = dict(tf=tf, torch=torch, dist=dist, np=np, dev=dev, world=world, rank=rank, use_dist=use_dist, barrier=barrier,
-               max_over_ranks=max_over_ranks, args=args)
+               max_over_ranks=max_over_ranks, args=args, ident=library_identity(tf), cpu_cache={})
 
     if args.config == 5:
         out = config5_leg(ctx, steps=args.steps, warmup=args.warmup, headline=True)
@@ -254,9 +348,6 @@ def ntt_headline(ctx):
     x = torch.empty(n * batch, dtype=torch.int64, device=dev)
     # the whole job is ONE counter-based sequence: rank r holds elements [r * batch * n, (r + 1) * batch * n)
     tf.device.fill_random(x, SEED_C2, first_index=rank * batch * n)
-    k_par = min(batch, 32)
-    sample_in = x[: k_par * n].clone()  # in-run parity sample: the first 32 transforms of this rank's batch
-
     launches_per_step = tf.lib().tf_ntt_launch_count(n, batch, 1)
 
     # settle: untimed passes until the GPU is in steady state.  A cold GPU runs the first passes at 4.2 -> 2.3 ms and only
@@ -321,11 +412,6 @@ def ntt_headline(ctx):
     step_ms = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(10))
     sclk_after = tf.lib().tf_debug_sclk_mhz()
     copy_after = copy_gbs()
-    # parity is checked on a fresh run of the sample, AFTER the timed region (x has been transformed many times by now; nothing
-    # of another shape runs between the warmup and the timed steps)
-    sample_gpu = sample_in.clone()
-    tf.device.ntt_(sample_gpu, n, batch=k_par)
-    torch.cuda.synchronize()
     barrier()
     elapsed = ctx["max_over_ranks"](elapsed)
 
@@ -338,12 +424,24 @@ def ntt_headline(ctx):
     avg_launch_ms = ev_ms / launches
     alg_bytes_per_launch = 16.0 * batch * n / launches_per_step  # 16 B/element per transform, spread over its launches
     achieved = alg_bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9
-    traffic = None
+    # stored profiles (PMC passes of tools/prof_r02.sh) are only quoted when they were taken on THIS build of the library
+    ident = ctx["ident"]
     tj = load_profile_json("hbm_traffic_ntt.json")
-    if tj and tj.get("log_n") == log_n and tj.get("batch") == batch and tj.get("launches_per_step") == launches_per_step:
-        traffic = tj.get("hbm_bytes_per_launch")
+    vc = load_profile_json("valu_counts.json")
+    tj_ok = bool(tj) and profile_matches(tj, ident) and tj.get("log_n") == log_n and tj.get("batch") == batch and tj.get("launches_per_step") == launches_per_step
+    vc_ok = bool(vc) and profile_matches(vc, ident) and log_n == 20 and bool(vc.get("ntt_valu_wave_instr_per_transform_2p20"))
+    traffic = tj.get("hbm_bytes_per_launch") if tj_ok else None
+    busy = [k.get("valu_busy_frac_at_4_cycles") for k in (tj.get("per_kernel") or {}).values()] if tj_ok else []
+    busy = [b for b in busy if b is not None]
+    # `bound`: SURVEY.md 8(d) prices this kernel against HBM (16 B/element) and achieved / peak / frac are that roofline; the
+    # resource that actually limits it, by the stored counters of this build, is VALU issue (two resident workgroups per CU keep
+    # the vector ALU busy ~0.88 of the cycles while HBM runs at about half its rate) -- the field says which one the profile shows.
+    valu_limited = bool(busy) and min(busy) >= 0.75
     roofline = {
-        "bound": "hbm",
+        "bound": "valu" if valu_limited else "hbm",
+        "priced_against": "hbm (SURVEY.md 8(d): 16 B per element and transform)",
+        "bound_evidence": (f"stored PMC profile of this build: VALU busy {min(busy):.2f}-{max(busy):.2f} of the cycles at 4 cycles per instruction on the two pass kernels "
+                           "(profiles/hbm_traffic_ntt.json per_kernel)") if busy else "no stored profile of this build: the HBM roofline named by SURVEY.md 8(d)",
         "kernel": "tfk::ntt_pass_kernel (column pass + transposing pass; one launch of each per batch tile)",
         "achieved": round(achieved, 1),
         "peak": HBM_PEAK_GBS,
@@ -351,27 +449,27 @@ def ntt_headline(ctx):
         "frac": round(achieved / HBM_PEAK_GBS, 4),
         "traffic": traffic,
         "traffic_source": (f"profiles/hbm_traffic_ntt.json ({tj.get('source', 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes')}; a stored "
-                           "profile of this kernel and shape, NOT measured in this run)") if traffic else None,
+                           "profile of this kernel, shape and library build, NOT measured in this run)") if traffic else None,
+        "profile_matches_library": {"hbm_traffic_ntt.json": tj_ok, "valu_counts.json": vc_ok, "library": ident},
         "algorithmic_bytes_per_launch": alg_bytes_per_launch,
         "avg_launch_ms": round(avg_launch_ms, 5),
         "launches_per_step": launches_per_step,
         "tile_bytes": int(tf.lib().tf_get_ntt_tile_bytes()),
         "tile_streams": int(tf.lib().tf_get_ntt_pipe()),
     }
-    vc = load_profile_json("valu_counts.json")
-    if vc and log_n == 20 and vc.get("ntt_valu_wave_instr_per_transform_2p20"):
+    if vc_ok:
         # Informational second roofline: integer VALU issue.  The instruction count is the DYNAMIC one,
-        # SQ_INSTS_VALU of the two pass kernels under rocprofv3 --pmc (profiles/valu_counts.json, tools/pmc_r02.sh).
+        # SQ_INSTS_VALU of the two pass kernels under rocprofv3 --pmc (profiles/valu_counts.json, tools/prof_r02.sh).
         wi = vc["ntt_valu_wave_instr_per_transform_2p20"] * batch
         gw = wi / (ev_ms / args.steps * 1e-3) / 1e9
         roofline["valu_bound"] = {"wave_instr_per_step": wi, "valu_instr_per_element": round(wi * 64.0 / (batch * n), 1),
                                   "achieved": round(gw, 1), "peak": VALU_PEAK_GWIPS, "unit": "G wave-instr/s",
                                   "frac": round(gw / VALU_PEAK_GWIPS, 3),
                                   "source": "instruction count: SQ_INSTS_VALU of the two pass kernels in profiles/valu_counts.json (a stored rocprofv3 --pmc "
-                                            "profile, NOT this run) x this run's step time; peak = 1024 SIMDs x 2.4 GHz / 4 cycles: every instruction of "
-                                            "these kernels is of the 4-cycle class (carry adds, v_mad_u64_u32, VOP3: 0.46-0.58 G wave-instr/s/SIMD in "
+                                            "profile of this library build, NOT this run) x this run's step time; peak = 1024 SIMDs x 2.4 GHz / 4 cycles: every "
+                                            "instruction of these kernels is of the 4-cycle class (carry adds, v_mad_u64_u32, VOP3: 0.46-0.58 G wave-instr/s/SIMD in "
                                             "profiles/r03_instr_rates.txt against 0.93-1.15 for plain v_add_u32 / logic / right shifts); the clock the chip "
-                                            "holds under this kernel is in the stored profile (profiles/r02p_rocprof_summary.txt), not measured here"}
+                                            "holds under this kernel is in the stored profile, not measured here"}
 
     out = {
         "metric": "goldilocks_ntt_gfelts_per_s",
@@ -403,17 +501,35 @@ def ntt_headline(ctx):
                             "note": "torch copy of the 2 GiB workload buffer, read + write: a platform reference (normally ~4500-5000)"},
     }
     del x
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        info, sample_out = cpu_baseline_ntt(log_n, batch, SEED_C2)
-        out["cpu_baseline"] = info
-        got = sample_gpu.cpu().numpy().view(np.uint64)
-        ok = np.array_equal(got, sample_out)
-        out["parity"] = f"bit-exact vs oracle on {k_par} transforms (word for word)" if ok else "MISMATCH"
-        if not ok:
-            sys.stderr.write(json.dumps(out) + "\n")
-            raise SystemExit("GPU output differs from the oracle")
-    elif world == 1:
+    # ---- parity (every rank, every world size): whole transforms of THIS rank's shard against the oracle, word for word, on a
+    # fresh run after the timed region.  One rank: the first 32 and the last transform of the batch; several ranks: the first
+    # and the last transform of every rank's shard (rank r holds transforms [r batch, (r + 1) batch) of the job's sequence).
+    cores = os.cpu_count() or 1
+    if args.no_cpu_baseline:
+        out["parity"] = "not checked (--no-cpu-baseline)"
         out["cpu_baseline"] = None
+        return out
+    first, last = rank * batch, rank * batch + batch - 1
+    units = sorted(set(list(range(first, first + min(batch, 32))) + [last])) if world == 1 else sorted({first, last})
+    ok = check_ntt_units(ctx, SEED_C2, units, n, threads=max(1, min(32, cores // world)))
+    all_ok = sharding_all_true(ctx, ok)
+    out["parity"] = (("bit-exact vs oracle, word for word, on " + (f"{len(units)} transforms (the first {len(units) - 1} and the last of the batch)" if world == 1 else
+                      f"the first and the last transform of each of the {world} ranks' shards ({2 * world} transforms; every rank checked its own)"))
+                     if all_ok else "MISMATCH")
+    if not all_ok:
+        if rank == 0:
+            sys.stderr.write(json.dumps(out) + "\n")
+        raise SystemExit(f"rank {rank}: GPU output differs from the oracle" if not ok else f"rank {rank}: another rank reported a mismatch")
+    # ---- CPU baseline: rank 0, on the GPU box's host cores, the full single-GPU workload shape, after a barrier (the other
+    # ranks sit idle at the next one)
+    barrier()
+    if rank == 0:
+        info, _ = cpu_baseline_ntt(log_n, batch, SEED_C2)
+        if world > 1:
+            info["sample"] += f"; timed on rank 0 while the other {world - 1} rank(s) wait at a barrier"
+        out["cpu_baseline"] = info
+        ctx["cpu_cache"][("ntt", log_n, batch)] = info
+    barrier()
     return out
 
 
@@ -462,14 +578,15 @@ def merkle_leg(ctx):
         "hbm_frac_at_120B_per_leaf": round(120.0 * nl / (e0.elapsed_time(e1) / iters * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
     }
     vc = load_profile_json("valu_counts.json")
-    if vc and vc.get("merkle_valu_wave_instr_per_tree_2p24"):
+    res["profile_matches_library"] = {"valu_counts.json": bool(vc) and profile_matches(vc, ctx["ident"])}
+    if vc and profile_matches(vc, ctx["ident"]) and vc.get("merkle_valu_wave_instr_per_tree_2p24"):
         wi = vc["merkle_valu_wave_instr_per_tree_2p24"]
         gw = wi / (e0.elapsed_time(e1) / iters * 1e-3) / 1e9
         res["roofline"] = {"bound": "valu", "kernel": "tfk::tip5_hash_pairs_kernel (level sweep) + merkle_top_kernel",
                            "achieved": round(gw, 1), "peak": VALU_PEAK_GWIPS, "unit": "G wave-instr/s", "frac": round(gw / VALU_PEAK_GWIPS, 3),
                            "wave_instr_per_tree": wi, "valu_instr_per_hash_pair": round(wi * 64.0 / (nl - 1), 1),
                            "frac_at_2_cycle_issue": round(gw / (2 * VALU_PEAK_GWIPS), 3),
-                           "source": "instruction count: SQ_INSTS_VALU under rocprofv3 --pmc (profiles/valu_counts.json, a stored profile, NOT this run) x "
+                           "source": "instruction count: SQ_INSTS_VALU under rocprofv3 --pmc (profiles/valu_counts.json, a stored profile of this library build, NOT this run) x "
                                      "this run's time.  `peak` prices every instruction at 4 cycles per wave64 (1024 SIMDs x 2.4 GHz / 4), "
                                      "frac_at_2_cycle_issue at the 2-cycle rate of plain 32-bit VALU; the Tip5 mix (v_mad_u64_u32 and carry chains at 4 "
                                      "cycles, logic / right shifts / v_add_u32 at 2: profiles/r03_instr_rates.txt) sits between, so neither is a hard ceiling"}
@@ -507,22 +624,51 @@ def merkle_leg(ctx):
             del sl, sub_nodes
         except Exception as e:
             res["single_tree_sharded"] = {"error": repr(e)}
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        info, want_root, want_nodes = cpu_baseline_merkle(nl, SEED_C3)
-        res["cpu_baseline"] = info
-        got_root = roots[0].cpu().numpy().view(np.uint64)
+    if not args.no_cpu_baseline:
+        # parity, every rank: the root and 69k sampled nodes of THIS rank's 2^24-leaf tree against the oracle's par_new on the same
+        # leaves (rank r's leaves are elements [r 5 nl, (r + 1) 5 nl) of the seed's sequence).  Rank 0 takes the oracle tree from its
+        # timed CPU leg; the other ranks build theirs first, then wait while rank 0 times the baseline on an otherwise idle host.
+        from oracle import tfo
+
+        cores = os.cpu_count() or 1
         idx = np.unique(np.concatenate([np.arange(1, 4096), np.random.default_rng(3).integers(1, 2 * nl, 1 << 16)]))
+        got_root = roots[rank if use_dist else 0].cpu().numpy().view(np.uint64)
         got_nodes = nodes.view(-1, 5)[torch.from_numpy(idx).to(dev)].cpu().numpy().view(np.uint64)
-        ok = np.array_equal(got_root, want_root) and np.array_equal(got_nodes, want_nodes.reshape(-1, 5)[idx])
-        res["parity"] = "root and 69k sampled nodes match the oracle's par_new" if ok else "MISMATCH"
-        res["root"] = tf.Digest.to_hex(got_root)
-        if not ok:
-            raise SystemExit("GPU Merkle tree differs from the oracle")
+        ok = True
+        if rank != 0:
+            want = tfo.merkle_build(tfo.fill_random(5 * nl, SEED_C3, first_index=rank * 5 * nl), threads=max(1, cores // world)).reshape(-1, 5)
+            ok = bool(np.array_equal(got_root, want[1]) and np.array_equal(got_nodes, want[idx]))
+            del want
+        barrier()
+        if rank == 0:
+            info, want_root, want_nodes = cpu_baseline_merkle(nl, SEED_C3)
+            if world > 1:
+                info["sample"] += f"; timed on rank 0 while the other {world - 1} rank(s) wait at a barrier"
+            res["cpu_baseline"] = info
+            ok = bool(np.array_equal(got_root, want_root) and np.array_equal(got_nodes, want_nodes.reshape(-1, 5)[idx]))
+            res["root"] = tf.Digest.to_hex(got_root)
+        all_ok = sharding_all_true(ctx, ok)
+        res["parity"] = (("root and 69k sampled nodes match the oracle's par_new" + (f" on every one of the {world} ranks' trees" if world > 1 else ""))
+                         if all_ok else "MISMATCH")
+        if not all_ok:
+            raise SystemExit(f"rank {rank}: GPU Merkle tree differs from the oracle" if not ok else f"rank {rank}: another rank reported a Merkle mismatch")
     del leaves, nodes
     return res
 
 
 # ------------------------------------------------------------------------------------------------ configs[3]: XFE coset evaluation
+def coset_bound(ctx):
+    """`bound` of the configs[3] roofline: priced against HBM (48 B/point); "valu" when the stored PMC profile of
+    this library build shows both PRE2 pass kernels VALU-busy (profiles/valu_counts.json: coset_eval_valu_busy)."""
+    vc = load_profile_json("valu_counts.json")
+    busy = (vc or {}).get("coset_eval_valu_busy_frac_at_4_cycles") if profile_matches(vc, ctx["ident"]) else None
+    if busy and min(busy) >= 0.75:
+        return {"bound": "valu", "priced_against": "hbm (48 B per point)",
+                "bound_evidence": f"stored PMC profile of this build: VALU busy {min(busy):.2f}-{max(busy):.2f} on the two pass kernels (profiles/valu_counts.json)"}
+    return {"bound": "hbm", "priced_against": "hbm (48 B per point)",
+            "bound_evidence": "no stored profile of this build" if not busy else f"stored profile: VALU busy {min(busy):.2f}-{max(busy):.2f}"}
+
+
 def coset_leg(ctx):
     tf, torch, np, dev, args = ctx["tf"], ctx["torch"], ctx["np"], ctx["dev"], ctx["args"]
     n, b = 1 << 22, 64
@@ -567,24 +713,21 @@ def coset_leg(ctx):
         "ms_per_step": round(ms, 4),
         "config": {"workload": "64 XFieldElement polynomials x 2^22 coefficients, fast_coset_evaluate(offset = 7, order = 2^22) (BASELINE configs[3])",
                    "inputs": f"SplitMix64, seed 0x{SEED_C4:X}"},
-        "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
-                     "algorithmic_bytes_per_point": 48, "launches_per_step": int(tf.lib().tf_ntt_launch_count(n, b, 3)),
-                     "plan": "two global passes (2048 x 2048 points; 32 B/point through HBM each way)"},
+        "roofline": dict(coset_bound(ctx), achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(gbs / HBM_PEAK_GBS, 4),
+                         algorithmic_bytes_per_point=48, launches_per_step=int(tf.lib().tf_ntt_launch_count(n, b, 3)),
+                         plan="two global passes (2048 x 2048 points; 32 B/point through HBM each way)"),
         "three_pass_plan_ms": round(three_ms, 4) if three_ms else None,
     }
     if not args.no_cpu_baseline:
-        from oracle import tfo
-
-        c0 = tfo.fill_random(3 * n, SEED_C4)  # polynomial 0 of the batch
-        t0 = time.perf_counter()
-        want = tfo.coset_evaluate(c0, off, n, width=3)
-        dt = time.perf_counter() - t0
-        res["cpu_baseline"] = {"value": round(n / dt / 1e9, 5), "unit": "G points/s", "cores": 1, "kind": "port",
-                               "sample": "1 of the 64 polynomials (2^22 XFE coefficients), single thread: scale + ntt restatement of math/polynomial.rs:760-773,1374-1399"}
-        ok = np.array_equal(o[: 3 * n].cpu().numpy().view(np.uint64), want)
+        got0 = o[: 3 * n].cpu().numpy().view(np.uint64)
+        del c, o  # the CPU leg holds the same 6 GiB on the host; free the device side first
+        info, want = cpu_baseline_coset(n, b, SEED_C4, off)
+        res["cpu_baseline"] = info
+        ok = np.array_equal(got0, want)
         res["parity"] = "polynomial 0 bit-exact vs oracle (all 3 * 2^22 words)" if ok else "MISMATCH"
         if not ok:
             raise SystemExit("GPU coset evaluation differs from the oracle")
+        return res
     del c, o
     return res
 
@@ -669,8 +812,70 @@ def config5_leg(ctx, steps, warmup, headline):
         alg = 16.0 * nt * n
         gbs = alg * steps / t_ntt / 1e9
         res["roofline"] = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
-                           "traffic": None, "note": "this rank's NTT phase: 16 B/element over the max-over-ranks time"}
+                           "traffic": None, "note": "this rank's NTT phase: 16 B/element over the max-over-ranks time; the kernels are the headline's "
+                                                    "(its roofline block says which resource bounds them)"}
     del x, leaves, nodes
+    # ---- one digest for the whole job (every world size must print the same one): Tip5 hash_varlen of the gathered roots, by the
+    # HIP path; every rank checks it against the oracle's hash_varlen of the same roots and against every other rank's digest
+    dig = torch.empty(5, dtype=torch.int64, device=dev)
+
+    def gpu_hash_varlen(flat):
+        tf.device.tip5_hash_varlen_rows(flat, flat.numel(), dig)
+        return dig
+
+    digest = sharding.roots_digest(roots, gpu_hash_varlen)
+    torch.cuda.synchronize()
+    res["roots_digest"] = tf.Digest.to_hex(digest.cpu().numpy().view(np.uint64))
+    same = sharding.identical_on_all_ranks(roots) and sharding.identical_on_all_ranks(digest)
+    if not same:
+        raise SystemExit(f"rank {rank}: the gathered roots / their digest differ between the ranks")
+    res["roots_identical_on_all_ranks"] = True
+    if args.no_cpu_baseline:
+        res["parity"] = "not checked (--no-cpu-baseline)"
+        res["cpu_baseline"] = None
+        return res
+    # ---- parity, every rank: the first and the last transform and the first and the last tree (every node) of THIS rank's shard
+    # against the oracle, plus the digest
+    from oracle import tfo
+
+    cores = os.cpu_count() or 1
+    th = max(1, min(16, cores // world))
+    ok = bool(np.array_equal(digest.cpu().numpy().view(np.uint64), tfo.hash_varlen(roots.cpu().numpy().view(np.uint64).reshape(-1))))
+    ok = ok and check_ntt_units(ctx, SEED_C5, sorted({t_lo, t_hi - 1}) if nt else [], n, threads=2)
+    tree_units = sorted({m_lo, m_hi - 1}) if nm else []
+    ok = ok and check_tree_units(ctx, SEED_C5 ^ (1 << 40), tree_units, nl, threads=th)
+    # ... and the gathered roots of those trees are the ones this rank just rebuilt and checked node by node
+    all_ok = sharding_all_true(ctx, ok)
+    res["parity"] = ((f"bit-exact vs oracle on every rank: first + last transform and first + last tree (all 2^21 nodes) of each of the {world} shard(s), "
+                      "and the roots digest (oracle hash_varlen of the gathered roots)") if all_ok else "MISMATCH")
+    if not all_ok:
+        raise SystemExit(f"rank {rank}: config 5 differs from the oracle" if not ok else f"rank {rank}: another rank reported a config-5 mismatch")
+    barrier()
+    if rank == 0:
+        # CPU baseline on a REDUCED sample of the job (the whole job is 4096 transforms + 256 trees: ~3 minutes of host time):
+        # 256 of the 4096 transforms, one per thread (the headline's CPU leg when it ran in this process), and 4 of the 256 trees
+        info = ctx["cpu_cache"].get(("ntt", 20, 256))
+        reused = info is not None
+        if info is None:
+            info, _ = cpu_baseline_ntt(20, 256, SEED_C5)
+        info = dict(info)
+        tfo.use_native_build()
+        lv = tfo.fill_random(5 * nl, SEED_C5 ^ (1 << 40))
+        tried = {}
+        for tth in sorted(set(max(1, k) for k in (32, 64, cores))):
+            t0 = time.perf_counter()
+            tfo.merkle_build(lv, threads=tth)
+            tried[tth] = nl / (time.perf_counter() - t0)
+        bt = max(tried, key=tried.get)
+        info["sample"] = ("REDUCED sample of the job: NTT = 256 of the 4096 transforms" + (" (the headline leg's timing, same shape, this process)" if reused else "")
+                          + "; " + info["sample"] + f" | Merkle = 1 of the {args.c5_trees} trees (2^20 leaves, par_new restatement), best of "
+                          + ", ".join(f"{k} threads: {v / 1e6:.2f} M" for k, v in tried.items()) + " leaves/s"
+                          + (f"; timed on rank 0 while the other {world - 1} rank(s) wait at a barrier" if world > 1 else ""))
+        info["merkle_value"] = round(tried[bt], 1)
+        info["merkle_unit"] = "leaves/s"
+        info["merkle_cores"] = bt
+        res["cpu_baseline"] = info
+    barrier()
     return res
 
 

@@ -63,12 +63,17 @@ const char *tf_status_string(int status);
 const char *tf_last_error(void);
 /* Library/ABI version (major * 1000 + minor). */
 int tf_version(void);
+/* First 16 hex digits of the SHA-256 of the sources this library was built from (csrc/Makefile); "-ab" appended for the
+ * laboratory build (TF_AB_BUILD).  Stored rocprof records carry it so that a figure is never quoted for another build. */
+const char *tf_source_hash(void);
 /* Number of visible HIP devices (0 if the runtime is unusable). */
 int tf_device_count(void);
 /* What the library keeps in HBM for speed, per device and for the life of the process: work space between the passes of the
  * multi-pass transforms (at most 12 GiB), inter-pass twiddle tables (at most 4 GiB), coset power tables (at most 1 GiB), and
  * the freed blocks of the memory pool its stream-ordered temporaries come from (a pool of the library's own per device: the
- * application's default pool and its attributes are left alone).
+ * application's default pool and its attributes are left alone.  Only if the runtime refuses to create a pool does the library
+ * fall back to the device's default pool, and then it changes ONE attribute of it -- hipMemPoolReuseFollowEventDependencies
+ * off, which correctness needs when several streams share the library's scratch cache -- and nothing else).
  * tf_release_caches() waits for the current device and frees all of it (the next call rebuilds what it needs); meant for hosts
  * that share the GPU with other users of its memory.  Call it when no other thread is inside the library on that device: a
  * call in flight on another host thread may hold a pointer to a table this frees. */
@@ -327,48 +332,68 @@ int tf_merkle_authentication_structure_dev(const uint64_t *d_nodes, size_t num_l
                                            uint64_t *out_digests, size_t capacity_digests, size_t *out_count, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
- * Tuning knobs (process-wide; also read once from the environment):
+ * Deployment settings (process-wide).  These two are the ONLY environment variables the product library reads (once, at the
+ * first call); every other TF_* switch of DESIGN_HISTORY.md exists in the laboratory build alone (TF_AB_BUILD, below).
  *   TF_NTT_TILE_BYTES : bytes of batch processed between the passes of a multi-pass NTT (scratch size),
  *                       (default 2 GiB: measured on MI355X the pass kernels are VALU-bound and larger
  *                       launches overlap better than Infinity-Cache-sized ones).
  */
 void tf_set_ntt_tile_bytes(size_t bytes);
+size_t tf_get_ntt_tile_bytes(void);
 /*   TF_NTT_PIPE       : K = 1..4 side streams the batch tiles of a multi-pass NTT are dealt to round-robin (each with its own
  *                       scratch tile), so the column pass of tile t + 1 overlaps the transposing pass of tile t and a tile
  *                       sized for the Infinity Cache is re-read out of it; the caller's stream forks/joins with events. */
 void tf_set_ntt_pipe(int streams);  /* K > 1 is for ONE caller per device: all callers share the device's K side streams */
 int tf_get_ntt_pipe(void);
-/*   TF_NTT_NT         : bit 0 = non-temporal loads of the caller's input in the first pass, bit 1 = non-temporal stores of the
- *                       result in the last pass of a plain multi-pass transform (keeps the Infinity Cache for the scratch tile). */
-void tf_set_ntt_nt(int mask);
-/* Test hook: plan at least `passes` (2..4) global passes whenever n >= 32^passes, so the three- and four-pass paths
- * (normally n > 2^20 and n = 2^31) can be checked against the oracle at small sizes.  0 restores the automatic plan. */
+
+/* ---------------------------------------------------------------------------------------------
+ * Test hooks.  The planner picks between code paths by shape (number of passes, tile geometry, latency-shaped kernels, the
+ * batch-evaluation route); each hook forces one side so that the parity tests can run BOTH against the oracle at any size.  Every
+ * setting produces the same words.  Process-wide, not meant for production callers.
+ *
+ * Plan at least `passes` (2..4) global passes whenever n >= 32^passes, so the three- and four-pass paths (normally
+ * n > 2^22 and n = 2^31) can be checked at small sizes.  0 restores the automatic plan. */
 void tf_set_ntt_min_passes(int passes);
+/* Calls with little work (<= 2^21 words) are planned with narrower tiles (256-thread workgroups); -1 = automatic
+ * (default), 0 = never, 1 = always. */
+void tf_set_ntt_small_launch(int mode);
+/* Transforms of 2^21 and 2^22 points run in TWO global passes (a 2048-point pass = pairs of 1024-point workgroups sharing their
+ * input) instead of three; -1 = automatic (default), 0 = never (the three-pass plan, which also serves the shapes the
+ * two-pass plan does not: small launches, truncated products), 1 = whenever the shape supports it. */
+void tf_set_ntt_two_pass(int mode);
+/* The latency-shaped kernels (8 elements per thread, radix-8 stages through LDS) instead of the 32-elements-per-thread
+ * pass kernels: ntt_lat_kernel for 64 .. 4096-point transforms in calls of up to 2^22 words (BFieldElement; 3 * 2^19 words
+ * XFieldElement), ntt_lat2_kernel for 2^13 .. 2^20-point transforms in calls below a per-length threshold (tf_ntt.hip:
+ * lat_wanted / lat2_wanted hold the measured crossovers).  -1 = automatic (default), 0 = never, 1 = whenever the shape allows. */
+void tf_set_ntt_latency_kernel(int mode);
 /* Number of ntt_pass_kernel launches one tf_ntt_*_dev call enqueues for this shape (diagnostic; used by
  * bench.py to turn a HIP-event interval into an average launch duration). */
-/* Test hook: calls with little work (<= 2^21 words) are planned with narrower tiles; -1 = automatic (default),
- * 0 = never, 1 = always -- so that both geometries can be checked at every size. */
-void tf_set_ntt_small_launch(int mode);
-/* Test / A-B hook: transforms of 2^21 and 2^22 points run in TWO global passes (a 2048-point pass = pairs of 1024-point
- * workgroups sharing their input) instead of three; -1 = automatic (default; TF_NTT_NO_PRE2 in the environment
- * disables), 0 = never, 1 = whenever the shape supports it.  Same words either way. */
-void tf_set_ntt_two_pass(int mode);
-/* Test / A-B hook: calls of 64 .. 4096-point transforms with little work (<= 2^18 words) take the latency-shaped kernel (8
- * elements per thread, radix-8 stages through LDS) instead of the 32-elements-per-thread pass kernels; -1 =
- * automatic (default; TF_NTT_NO_LAT disables), 0 = never, 1 = whenever the shape allows.  Same words either way. */
-void tf_set_ntt_latency_kernel(int mode);
-/* A/B hook: the R = 1024 column pass as a chain of k tiles per workgroup, the next tile's loads issued inside the store phase of
- * the current one (0 / 1: one tile per workgroup; environment: TF_NTT_PERSIST).  Same words. */
-void tf_set_ntt_chain(int tiles_per_workgroup);
 int tf_ntt_launch_count(size_t n, size_t batch, int width);
 /* Planner introspection (no device needed): number of global passes of one n-point transform (0 for lengths ntt rejects)
- * and log2 of each pass's radix in log2_radix_out[0..3] (unused entries 0).  The radices multiply to n. */
+ * and log2 of each pass's radix in log2_radix_out[0..3] (unused entries 0).  The radices multiply to n.  This is the plan of a
+ * LARGE call (enough work for 512-thread tiles); a call small enough for the narrow tiles -- e.g. ONE 2^21-point BFieldElement
+ * slice -- runs 2^21 / 2^22 points on the three-pass plan instead of {10, 11} / {11, 11}: tf_ntt_launch_count(n, batch, width)
+ * is exact for a given batch. */
 int tf_ntt_plan(size_t n, int width, int* log2_radix_out);
-/* Measurement helper for tools/phase_timeline.py (TF_NTT_ABLATE=3): per-wave phase cycle stamps of the NTT pass kernel. */
-int tf_debug_stamps(unsigned long long *host_out, size_t words);
 /* Measurement helper: the shader clock (MHz) the current device is running at right now (one-wave ~0.5 ms spin; < 0 on failure). */
 double tf_debug_sclk_mhz(void);
-size_t tf_get_ntt_tile_bytes(void);
+
+#ifdef TF_AB_BUILD
+/* ---------------------------------------------------------------------------------------------
+ * Laboratory build only (csrc: make ab -> libtf_hip_ab.so).  The product library neither exports these nor contains the kernels
+ * behind them: measured losers and diagnostics that are kept so that every claim of DESIGN_HISTORY.md stays reproducible
+ * (tools/switch_matrix.sh runs the GPU suite under each switch against this library).
+ *   TF_NTT_NT / tf_set_ntt_nt : bit 0 = non-temporal loads of the caller's input in the first pass, bit 1 = non-temporal stores
+ *                               of the result in the last pass of a plain multi-pass transform (generic kernels).
+ *   tf_set_ntt_chain          : the R = 1024 column pass as a chain of k tiles per workgroup, the next tile's loads issued inside
+ *                               the store phase of the current one (TF_NTT_PERSIST): +11..22 % time, profiles/r03_chain_ab.txt.
+ *   tf_debug_stamps           : per-wave phase cycle stamps of the NTT pass kernel (TF_NTT_ABLATE=3, tools/phase_timeline.py).
+ *   environment               : TF_NTT_NO_* / TF_NTT_WG_THREADS / TF_NTT_ABLATE / TF_TREE_* / TF_POLY_MUL_NO_FUSE /
+ *                               TF_POOL_REUSE_FOLLOW_EVENTS ... (the list is `grep ab_env csrc/`). */
+void tf_set_ntt_nt(int mask);
+void tf_set_ntt_chain(int tiles_per_workgroup);
+int tf_debug_stamps(unsigned long long *host_out, size_t words);
+#endif
 /* Synthetic inputs for benches/tests: d_out[i] = BFieldElement::new(splitmix64(seed ^ (first_index + i)) mod p),
  * raw Montgomery words, generated on the device (the oracle's tfo_fill_random is the same counter-based sequence). */
 int tf_debug_fill_random_dev(uint64_t *d_out, size_t count, uint64_t seed, uint64_t first_index, void *stream);

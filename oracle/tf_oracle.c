@@ -377,6 +377,52 @@ int tfo_coset_evaluate(const uint64_t *coeffs, size_t n_coeffs, int width, uint6
     return ntt_any(out, order, width, 0);    /* :1396 */
 }
 
+/* `batch` polynomials of n_coeffs coefficients each, contiguous in and out, one polynomial per thread: what a rayon caller of the
+ * single-threaded fast_coset_evaluate does (the reference itself is sequential per polynomial, polynomial.rs:1374-1399; bench
+ * shape benches/polynomial_coset.rs:15-47).  bench.py's all-core cpu_baseline of BASELINE configs[3]. */
+typedef struct {
+    const u64 *coeffs;
+    u64 *out;
+    size_t n_coeffs, order, batch;
+    int width;
+    u64 offset;
+    size_t next;
+    pthread_mutex_t *lock;
+    int rc;
+} coset_job_t;
+
+static void *coset_worker(void *arg) {
+    coset_job_t *job = (coset_job_t *)arg;
+    for (;;) {
+        pthread_mutex_lock(job->lock);
+        size_t b = job->next++;
+        pthread_mutex_unlock(job->lock);
+        if (b >= job->batch) break;
+        int rc = tfo_coset_evaluate(job->coeffs + b * job->n_coeffs * (size_t)job->width, job->n_coeffs, job->width, job->offset,
+                                    job->out + b * job->order * (size_t)job->width, job->order);
+        if (rc) job->rc = rc;
+    }
+    return NULL;
+}
+
+int tfo_coset_evaluate_batch(const uint64_t *coeffs, size_t n_coeffs, int width, uint64_t offset, uint64_t *out, size_t order,
+                             size_t batch, int threads) {
+    int rc = check_len(order);
+    if (rc) return rc;
+    if (order > 1) (void)get_twiddles((uint32_t)order, 0); /* build the cache before fan-out */
+    pthread_mutex_t lock = PTHREAD_MUTEX_INITIALIZER;
+    coset_job_t job = {coeffs, out, n_coeffs, order, batch, width, offset, 0, &lock, 0};
+    if (threads <= 1) {
+        coset_worker(&job);
+        return job.rc;
+    }
+    pthread_t *tid = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)threads);
+    for (int t = 0; t < threads; t++) pthread_create(&tid[t], NULL, coset_worker, &job);
+    for (int t = 0; t < threads; t++) pthread_join(tid[t], NULL);
+    free(tid);
+    return job.rc;
+}
+
 /* polynomial.rs:1907-1918 : intt then scale by offset^-1 */
 int tfo_coset_interpolate(const uint64_t *values, size_t n, int width, uint64_t offset, uint64_t *out) {
     memcpy(out, values, n * (size_t)width * sizeof(u64));
@@ -1150,13 +1196,15 @@ uint64_t tfo_splitmix64(uint64_t *state) {
 }
 
 /* element i = new(mix(seed ^ i) mod p), counter-based so any slice can be regenerated */
-void tfo_fill_random(uint64_t *out, size_t count, uint64_t seed) {
+void tfo_fill_random_from(uint64_t *out, size_t count, uint64_t seed, uint64_t first_index) {
     for (size_t i = 0; i < count; i++) {
-        u64 st = seed ^ (u64)i;
+        u64 st = seed ^ (first_index + (u64)i);
         u64 v = tfo_splitmix64(&st);
         out[i] = bfe_new(v % P);
     }
 }
+
+void tfo_fill_random(uint64_t *out, size_t count, uint64_t seed) { tfo_fill_random_from(out, count, seed, 0); }
 
 void tfo_digest_to_hex(const uint64_t d[5], char out[81]) {
     static const char *hx = "0123456789abcdef";

@@ -61,6 +61,9 @@ void tfo_poly_scale(uint64_t *coeffs, size_t n_coeffs, int width, uint64_t alpha
 /* fast_coset_evaluate :1374-1399 ; out has `order` elements.  Returns nonzero where the reference panics. */
 int tfo_coset_evaluate(const uint64_t *coeffs, size_t n_coeffs, int width, uint64_t offset_raw,
                        uint64_t *out, size_t order);
+/* `batch` contiguous polynomials, one per thread (bench.py's all-core cpu_baseline of BASELINE configs[3]) */
+int tfo_coset_evaluate_batch(const uint64_t *coeffs, size_t n_coeffs, int width, uint64_t offset_raw, uint64_t *out, size_t order,
+                             size_t batch, int threads);
 /* fast_coset_interpolate :1907-1918 ; values -> coefficients (n of them) */
 int tfo_coset_interpolate(const uint64_t *values, size_t n, int width, uint64_t offset_raw, uint64_t *out);
 /* Horner evaluation of a BFE/XFE polynomial at a BFE point (used to cross-check NTT == evaluation,
@@ -96,6 +99,8 @@ void tfo_poly_eval_xfe_point(const uint64_t *coeffs, size_t n_coeffs, const uint
 uint64_t tfo_splitmix64(uint64_t *state);
 /* fill `count` raw BFE words: new(splitmix64(seed ^ (b<<32) ^ i) mod p)   */
 void tfo_fill_random(uint64_t *out, size_t count, uint64_t seed);
+/* elements [first_index, first_index + count) of the same counter-based sequence (a rank's shard of a job-wide input) */
+void tfo_fill_random_from(uint64_t *out, size_t count, uint64_t seed, uint64_t first_index);
 /* digest -> 80 lowercase hex chars + NUL: canonical value, little-endian bytes (tip5/digest.rs:85-90,:144-153) */
 void tfo_digest_to_hex(const uint64_t d[5], char out[81]);
 

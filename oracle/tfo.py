@@ -79,6 +79,7 @@ def lib() -> C.CDLL:
             "tfo_ntt_batch": (i32, [pu, sz, sz, i32, i32, i32]),
             "tfo_poly_scale": (None, [pu, sz, i32, u64]),
             "tfo_coset_evaluate": (i32, [pu, sz, i32, u64, pu, sz]),
+            "tfo_coset_evaluate_batch": (i32, [pu, sz, i32, u64, pu, sz, sz, i32]),
             "tfo_coset_interpolate": (i32, [pu, sz, i32, u64, pu]),
             "tfo_poly_eval": (None, [pu, sz, i32, u64, pu]),
             "tfo_tip5_permutation": (None, [pu]),
@@ -107,6 +108,7 @@ def lib() -> C.CDLL:
             "tfo_barycentric_evaluate": (i32, [pu, sz, i32, pu, pu]),
             "tfo_poly_clean_divide_bfe": (i32, [pu, sz, pu, sz, sz, pu]),
             "tfo_fill_random": (None, [pu, sz, u64]),
+            "tfo_fill_random_from": (None, [pu, sz, u64, u64]),
             "tfo_digest_to_hex": (None, [pu, C.c_char_p]),
         }
         for name, (res, args) in sig.items():
@@ -239,6 +241,18 @@ def coset_evaluate(coeffs, offset_raw: int, order: int, width: int = 1) -> np.nd
     n_coeffs = c.size // width
     out = np.zeros(order * width, dtype=np.uint64)
     rc = lib().tfo_coset_evaluate(_p(c) if c.size else _p(np.zeros(1, np.uint64)), n_coeffs, width, offset_raw, _p(out) if out.size else _p(np.zeros(1, np.uint64)), order)
+    if rc:
+        raise OraclePanic(rc)
+    return out
+
+
+def coset_evaluate_batch(coeffs, offset_raw: int, order: int, batch: int, width: int = 1, threads: int = 1) -> np.ndarray:
+    """`batch` contiguous polynomials of equal length, one polynomial per thread."""
+    c = _arr(coeffs).reshape(-1)
+    assert batch > 0 and c.size % (batch * width) == 0
+    n_coeffs = c.size // (batch * width)
+    out = np.zeros(batch * order * width, dtype=np.uint64)
+    rc = lib().tfo_coset_evaluate_batch(_p(c), n_coeffs, width, offset_raw, _p(out), order, batch, threads)
     if rc:
         raise OraclePanic(rc)
     return out
@@ -514,10 +528,11 @@ def merkle_from_rows(rows, row_len: int) -> np.ndarray:
 
 # ---- helpers -------------------------------------------------------------------------
 
-def fill_random(count: int, seed: int) -> np.ndarray:
+def fill_random(count: int, seed: int, first_index: int = 0) -> np.ndarray:
+    """Elements [first_index, first_index + count) of the counter-based sequence of `seed`."""
     out = np.zeros(count, dtype=np.uint64)
     if count:
-        lib().tfo_fill_random(_p(out), count, seed)
+        lib().tfo_fill_random_from(_p(out), count, seed, first_index)
     return out
 
 

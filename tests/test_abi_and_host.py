@@ -11,9 +11,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HEADER = os.path.join(ROOT, "include", "tf_hip.h")
 
 
-def declared_functions():
+def declared_functions(ab=False):
+    """Function names the header declares: the product's (outside #ifdef TF_AB_BUILD) or the laboratory build's extras."""
     text = open(HEADER).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    ab_blocks = re.findall(r"#ifdef TF_AB_BUILD(.*?)#endif", text, flags=re.S)
+    if ab:
+        text = "\n".join(ab_blocks)
+    else:
+        text = re.sub(r"#ifdef TF_AB_BUILD.*?#endif", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(tf_[a-z0-9_]+)\s*\(", text)))
 
 
@@ -34,7 +40,14 @@ def test_library_exports_every_declared_symbol(tf):
         assert hasattr(lib, n), f"libtf_hip.so does not export {n}"
         assert n in _lib.SIGNATURES, f"{n} has no ctypes signature"
     assert sorted(_lib.SIGNATURES) == names
-    assert lib.tf_version() >= 1000
+    # the laboratory hooks are declared under #ifdef TF_AB_BUILD and the product library does not export them
+    ab_names = declared_functions(ab=True)
+    assert sorted(_lib.AB_SIGNATURES) == ab_names
+    if not _lib.is_ab_build():
+        for n in ab_names:
+            assert not hasattr(lib, n), f"the product library exports the laboratory hook {n}"
+    assert len(lib.tf_source_hash()) >= 16
+    assert lib.tf_version() >= 1001
     assert lib.tf_status_string(2) == b"TF_ERR_INCORRECT_NUMBER_OF_LEAFS"
 
 

@@ -984,6 +984,33 @@ def test_poly_goldens_reproduced_by_the_device(tf, oracle):
         assert [int(v) for v in oracle.to_values(np.asarray(got, dtype=np.uint64).reshape(-1))] == case["out"], o
 
 
+def test_pyref_goldens_reproduced_by_the_device(tf, oracle):
+    """tests/golden/poly_goldens_pyref.json through the HIP path.  The fixture was generated by tests/pyref.py alone -- pure-Python
+    schoolbook definitions, no C oracle (tests/golden/make_poly_goldens_pyref.py) -- with explicit canonical inputs and outputs, so
+    this is device-vs-independent, not device-vs-oracle: zerofier, interpolate, barycentric_evaluate, fast_coset_evaluate with
+    base-field and extension-field offsets, ntt, fast_multiply (BFieldElement and XFieldElement), clean_divide."""
+    from tests.test_oracle_kat import pyref_golden_cases, pyref_golden_eval
+
+    def ntt(x, w):
+        y = np.array(x, dtype=np.uint64)
+        tf.ntt(y, width=w)
+        return y
+
+    ops = {"to_raw": oracle.to_raw, "to_values": oracle.to_values,
+           "zerofier": lambda r, w: tf.Polynomial.zerofier(r, width=w).coefficients,
+           "interpolate": lambda d, v, w: tf.Polynomial.interpolate(d, v, width=w).coefficients,
+           "barycentric": lambda cw, x, w: tf.barycentric_evaluate(cw, x, width=w),
+           "coset": lambda c, off, order, w: tf.fast_coset_evaluate(c, off, order, width=w),
+           "coset_xoff": lambda c, off, order: tf.fast_coset_evaluate(c, off, order, width=3),
+           "ntt": ntt,
+           "multiply": lambda a, b, w: tf.fast_multiply(a, b, width=w),
+           "clean_divide": lambda a, b: tf.Polynomial(a).clean_divide(tf.Polynomial(b)).coefficients}
+    cases = pyref_golden_cases()
+    assert len(cases) == 49
+    for case in cases:
+        assert pyref_golden_eval(case, ops) == case["out"], (case["op"], case.get("width"), case.get("n"))
+
+
 def test_zerofier_tree_handle_serves_concurrent_host_threads(tf, oracle):
     """One prepared tree, four host threads, each on its own stream, evaluating and interpolating at the same time (ctypes releases
     the GIL during the calls; the first interpolation takes the handle's lock to compute the weights): every thread gets the

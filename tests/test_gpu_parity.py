@@ -829,6 +829,8 @@ def test_chained_column_pass_gives_the_same_words(tf, oracle):
     the one-tile kernel word for word, and the first two transforms against the oracle."""
     import torch
 
+    if not tf._lib.is_ab_build():
+        pytest.skip("ntt_col1024_chain_kernel is a measured loss: compiled into the laboratory library only (csrc: make ab; TF_HIP_LIBRARY=.../libtf_hip_ab.so)")
     lib = tf._lib.lib()
     n, batch = 1 << 20, 128
     src = torch.empty(n * batch, dtype=torch.int64, device="cuda")

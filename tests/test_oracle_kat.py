@@ -698,3 +698,71 @@ def test_poly_goldens_reproduced_by_the_oracle(oracle):
     for case in cases:
         got = np.asarray(_poly_golden_eval(case, ops), dtype=np.uint64).reshape(-1)
         assert [int(v) for v in oracle.to_values(got)] == case["out"], case["op"]
+
+
+# ---- the independent fixture: tests/golden/poly_goldens_pyref.json, generated by tests/pyref.py alone (pure-Python schoolbook
+# definitions; tests/golden/make_poly_goldens_pyref.py).  Inputs and outputs are explicit canonical values.
+def pyref_golden_cases():
+    return json.load(open(os.path.join(HERE, "golden", "poly_goldens_pyref.json")))["cases"]
+
+
+def pyref_golden_eval(case, ops):
+    """One case of the pyref fixture through `ops` (the oracle here, the HIP path in tests/test_gpu_next_rows.py).  `ops` functions
+    take and return raw Montgomery words; returns the canonical values, padded with zeros to the fixture's length (the routes
+    return trimmed polynomials)."""
+    raw = ops["to_raw"]
+    o, w = case["op"], case.get("width", 1)
+    if o == "zerofier":
+        got = ops["zerofier"](raw(case["roots"]), w)
+    elif o == "interpolate":
+        got = ops["interpolate"](raw(case["domain"]), raw(case["values"]), w)
+    elif o == "barycentric_evaluate":
+        got = ops["barycentric"](raw(case["codeword"]), raw(case["indeterminate"]), w)
+    elif o == "coset_evaluate":
+        got = ops["coset"](raw(case["coeffs"]), int(raw([case["offset"]])[0]), case["order"], w)
+    elif o == "coset_evaluate_xfe_offset":
+        got = ops["coset_xoff"](raw(case["coeffs"]), raw(case["offset"]), case["order"])
+    elif o == "ntt":
+        got = ops["ntt"](raw(case["in"]), w)
+    elif o == "multiply":
+        got = ops["multiply"](raw(case["a"]), raw(case["b"]), w)
+    elif o == "clean_divide":
+        got = ops["clean_divide"](raw(case["dividend"]), raw(case["divisor"]))
+    else:
+        raise AssertionError(o)
+    vals = [int(v) for v in ops["to_values"](np.asarray(got, dtype=np.uint64).reshape(-1))]
+    return vals + [0] * (len(case["out"]) - len(vals))
+
+
+def test_pyref_splitmix_is_the_oracles_fill_random(oracle):
+
+    for seed, first in ((0x7F210002, 0), (5, 1 << 20), (0xDEADBEEF, 12345)):
+        want = [int(v) for v in oracle.to_values(oracle.fill_random(64, seed, first_index=first))]
+        assert pyref.splitmix_values(64, seed, first_index=first) == want
+
+
+def test_pyref_goldens_reproduced_by_the_oracle(oracle):
+    """The oracle's fast routes (zerofier / interpolation through trees, NTT-based division and coset evaluation, the barycentric
+    formula) against the pure-Python schoolbook definitions: 49 committed cases, BFieldElement and XFieldElement."""
+    ops = {"to_raw": oracle.to_raw, "to_values": oracle.to_values, "zerofier": oracle.zerofier, "interpolate": oracle.lagrange_interpolate,
+           "barycentric": oracle.barycentric_evaluate, "coset": lambda c, off, order, w: oracle.coset_evaluate(c, off, order, width=w),
+           "coset_xoff": oracle.coset_evaluate_xfe_offset, "ntt": lambda x, w: oracle.ntt(x, width=w),
+           "multiply": lambda a, b, w: oracle.poly_mul(a, b, width=w), "clean_divide": lambda a, b: oracle.clean_divide(a, b, 0)}
+    cases = pyref_golden_cases()
+    assert len(cases) == 49
+    for case in cases:
+        assert pyref_golden_eval(case, ops) == case["out"], (case["op"], case.get("width"), case.get("n"))
+
+
+def test_pyref_golden_file_is_what_pyref_generates(tmp_path):
+    """The committed fixture is exactly the generator's output (a hand edit or a stale file shows up here)."""
+    import subprocess
+    import sys
+
+    want = open(os.path.join(HERE, "golden", "poly_goldens_pyref.json")).read()
+    gen = os.path.join(HERE, "golden", "make_poly_goldens_pyref.py")
+    src = open(gen).read().replace('os.path.join(HERE, "poly_goldens_pyref.json")', repr(str(tmp_path / "out.json")))
+    script = tmp_path / "gen.py"
+    script.write_text(src.replace("HERE = os.path.dirname(os.path.abspath(__file__))", f"HERE = {os.path.join(HERE, 'golden')!r}"))
+    subprocess.check_call([sys.executable, str(script)])
+    assert open(tmp_path / "out.json").read() == want

@@ -8,7 +8,7 @@ dev = torch.device("cuda:0")
 g = torch.Generator(device=dev); g.manual_seed(1)
 off = tf.BFieldElement.new(7)
 for width in (1, 3):
-    for log_c, log_m in [(14, 16), (16, 19), (17, 20), (18, 21), (19, 22), (20, 22), (20, 23), (22, 24)]:
+    for log_c, log_m in [(14, 16), (16, 19), (17, 20), (18, 21), (19, 21), (20, 21), (19, 22), (20, 22), (21, 22), (20, 23), (22, 24)]:
         total_out = (1 << 28) // (2 if width == 3 else 1)
         batch = max(1, total_out // ((1 << log_m) * width))
         nc, m = 1 << log_c, 1 << log_m

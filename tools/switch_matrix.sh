@@ -1,6 +1,8 @@
 #!/bin/bash
-# tools/switch_matrix.sh [outfile] -- the whole GPU suite under every A/B switch of the library in turn (each alternative path
-# must be bit-exact too), then the long randomised parity run on the default build.
+# tools/switch_matrix.sh [outfile] -- the whole GPU suite under every A/B switch in turn (each alternative path must be bit-exact
+# too), then the long randomised parity run on the product build.  The switches exist in the LABORATORY library only
+# (csrc: make ab -> twenty-first_amd/libtf_hip_ab.so, selected through TF_HIP_LIBRARY); the product library ignores them.
+# First line of the record: the product library with no switch.
 set -u
 REPO=$(cd "$(dirname "$0")/.." && pwd)
 OUT=${1:-$REPO/gpurun_out/switch_matrix.txt}
@@ -12,7 +14,10 @@ run() {  # <env assignment> <description>
   res=$(env $1 timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -n 1)
   printf "%-34s %-100s %s\n" "$1" "($2)" "$res" | tee -a "$OUT"
 }
-run "TF_DEFAULT=1" "no switch: the shipped plan"
+run "TF_DEFAULT=1" "no switch: the shipped plan, PRODUCT library"
+export TF_HIP_LIBRARY=${TF_HIP_LIBRARY:-$REPO/twenty-first_amd/libtf_hip_ab.so}
+[ -f "$TF_HIP_LIBRARY" ] || { echo "missing $TF_HIP_LIBRARY: make -C twenty-first_amd/csrc ab" | tee -a "$OUT"; exit 1; }
+run "TF_DEFAULT=1" "no switch: the shipped plan, laboratory library"
 run "TF_NTT_TILE_BYTES=33554432" "32 MiB scratch slabs: every batched multi-pass transform runs in many tiles"
 run "TF_NTT_TILE_BYTES=33554432 TF_NTT_PIPE=3" "... dealt to three side streams"
 run "TF_NTT_NO_LAST1024=1" "generic kernel instead of the R = 1024 last-pass specialisation"
@@ -50,7 +55,8 @@ run "TF_BATCH_EVAL=horner" "Horner everywhere"
 run "TF_BATCH_EVAL=tree TF_TREE_UNIT_SLAB=3000" "zerofier tree with the units of a walk cut into slabs of a few units"
 run "TF_TREE_LEAF_LOG=6" "64-point leaves in the zerofier tree (deeper trees)"
 run "TF_TREE_LEAF_LOG=10" "1024-point leaves"
-echo "--- long randomised parity run (tools/fuzz_long.py, 3 seeds x 120 s)" | tee -a "$OUT"
+unset TF_HIP_LIBRARY
+echo "--- long randomised parity run on the product library (tools/fuzz_long.py, 3 seeds x 120 s)" | tee -a "$OUT"
 for seed in 11 12 13; do
   timeout 400 python tools/fuzz_long.py $seed 120 2>&1 | grep -v amdgpu.ids | tail -n 3 | tee -a "$OUT"
 done

@@ -22,6 +22,7 @@ SIGNATURES = {
     "tf_status_string": (C.c_char_p, [C.c_int]),
     "tf_last_error": (C.c_char_p, []),
     "tf_version": (C.c_int, []),
+    "tf_source_hash": (C.c_char_p, []),
     "tf_device_count": (C.c_int, []),
     "tf_ntt_bfe": (C.c_int, [_vp, _sz, _sz, C.c_int]),
     "tf_ntt_xfe": (C.c_int, [_vp, _sz, _sz, C.c_int]),
@@ -126,17 +127,23 @@ SIGNATURES = {
     "tf_set_ntt_small_launch": (None, [C.c_int]),
     "tf_set_ntt_two_pass": (None, [C.c_int]),
     "tf_set_ntt_latency_kernel": (None, [C.c_int]),
-    "tf_set_ntt_chain": (None, [C.c_int]),
-    "tf_debug_stamps": (C.c_int, [_vp, _sz]),
     "tf_debug_sclk_mhz": (C.c_double, []),
     "tf_set_ntt_tile_bytes": (None, [_sz]),
     "tf_set_ntt_min_passes": (None, [C.c_int]),
     "tf_get_ntt_tile_bytes": (_sz, []),
     "tf_set_ntt_pipe": (None, [C.c_int]),
     "tf_get_ntt_pipe": (C.c_int, []),
-    "tf_set_ntt_nt": (None, [C.c_int]),
     "tf_set_batch_eval_route": (None, [C.c_int]),
     "tf_debug_fill_random_dev": (C.c_int, [_vp, _sz, C.c_uint64, C.c_uint64, _vp]),
+}
+
+
+# declared under #ifdef TF_AB_BUILD in the header: present in the laboratory library (csrc: make ab, selected with
+# TF_HIP_LIBRARY=.../libtf_hip_ab.so) only -- the product library neither exports them nor contains the kernels behind them
+AB_SIGNATURES = {
+    "tf_set_ntt_chain": (None, [C.c_int]),
+    "tf_debug_stamps": (C.c_int, [_vp, _sz]),
+    "tf_set_ntt_nt": (None, [C.c_int]),
 }
 
 
@@ -146,6 +153,7 @@ def build(force: bool = False) -> str:
     args = ["make", "-C", csrc]
     if force:
         args.append("-B")
+    args.append(f"-j{min(8, os.cpu_count() or 1)}")
     subprocess.check_call(args, stdout=subprocess.DEVNULL)
     return SO_PATH
 
@@ -192,5 +200,15 @@ def lib() -> C.CDLL:
             fn = getattr(L, name)  # AttributeError if the .so does not export what the header declares
             fn.restype = res
             fn.argtypes = args
+        for name, (res, args) in AB_SIGNATURES.items():
+            if hasattr(L, name):
+                fn = getattr(L, name)
+                fn.restype = res
+                fn.argtypes = args
         _lib = L
     return _lib
+
+
+def is_ab_build() -> bool:
+    """True when the loaded library is the laboratory build (every A/B switch and measured-loser kernel compiled in)."""
+    return lib().tf_source_hash().decode().endswith("-ab")

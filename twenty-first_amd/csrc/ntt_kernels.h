@@ -37,6 +37,8 @@
 #pragma once
 
 #include "gl64.h"
+#include "ntt_args.h"
+#include "ntt_network.h"
 
 namespace tfk {
 
@@ -135,132 +137,7 @@ __device__ __forceinline__ void buf_store(__amdgpu_buffer_rsrc_t r, u32 voff, u3
     __builtin_amdgcn_raw_buffer_store_b64(v, r, voff, soff, AUX);
 }
 
-// ---- radix-2^k DIT network with power-of-two twiddles --------------------------------------
-// w_{2^l} = 2^(39 * 2^(6-l))  (b_field_element.rs:46-51: w_64 = 2^39, ..., w_2 = 2^96 = -1), order 192.
-template <bool INV, int LVL, int J>
-struct TwExp {
-    static constexpr int fwd = ((39 << (6 - LVL)) * J) % 192;
-    static constexpr int value = INV ? (192 - fwd) % 192 : fwd;
-};
-
-#ifndef TF_ASM_BFLY
-#define TF_ASM_BFLY 1  // 0: the compiler's compare-and-select add/sub (12 VALU per butterfly instead of 10)
-#endif
-#ifndef TF_LDS_TW
-#define TF_LDS_TW 1  // the R = 1024 instantiations stage their [32][32] inner twiddle table in LDS (0: per-thread global loads, A/B build)
-#endif
-// The inner table w_R^(g k1) is read by row g: 32 words = 256 contiguous bytes per THREAD, i.e. a wave-load touches up to 64
-// different cache lines.  Through global memory those 16 dwordx4 loads per thread compete with the data stream for the
-// texture-addresser / L1 path (measured: 2.148 -> 2.081 ms per 256 x 2^20 with the column pass alone reading it from LDS,
-// profiles/r02b_ab_variants.txt); staged once per workgroup behind the exchange buffer, rows padded to 34 words (272 bytes:
-// 16-byte aligned for ds_read_b128, consecutive rows 4 banks apart), the reads are conflict-free LDS traffic.
-constexpr int kLdsTwStride = 34;
-// exchange geometry of the R1024 instantiation (= what finish_geometry computes for 512 threads and rounds of 8 192 elements)
-constexpr int kR1024Nc = 16, kR1024Cpr = 8, kR1024Rounds = 2, kR1024S1 = 264;
-// LAST1024 exchange layout: element (k1, g, cc) at k1 * kL1024S1 + cc * kL1024CS + g  (see the kernel)
-constexpr int kL1024S1 = 273, kL1024CS = 34;
-constexpr int kL1024ExchangeWords = ((31 * kL1024S1 + 7 * kL1024CS + 32 + 1) / 2) * 2;  // 16-byte aligned end
-#ifndef TF_LAZY
-#define TF_LAZY 1  // 0: every network canonical (A/B build); 1: lazy butterflies in the networks that are followed by a Montgomery product
-#endif
-
-// Butterfly I (0 .. 15) of level LVL over 32 register slots: groups of 2^LVL consecutive slots, butterfly j of a group pairs
-// slots (base + j, base + j + 2^(LVL-1)) with the twiddle w_{2^LVL}^j (inputs of a group in bit-reversed order, outputs natural).
-template <bool INV, int LVL, int I>
-struct Bf {
-    static constexpr int H = 1 << (LVL - 1);
-    static constexpr int j = I % H;
-    static constexpr int ia = (I / H) * 2 * H + j;
-    static constexpr int ib = ia + H;
-    static constexpr int E = TwExp<INV, LVL, j>::value;
-    static constexpr bool neg = gl::Pow2Mul<E>::negate;  // the power-of-two product comes back negated: swap the outputs
-};
-
-// x * 2^E up to the sign Bf::neg, as a CANONICAL word whatever 64-bit word x is (shl_fold / shl_monty reduce fully).
-// E = 0 passes x through: canonical in a canonical network; in a lazy network only level 1 meets that case with canonical inputs
-// (loaded words or Montgomery products), the levels above canonicalise the operand first (LAZY_IN).
-template <int E, bool LAZY_IN>
-__device__ __forceinline__ u64 tw_operand(u64 b) {
-    if constexpr (E % 192 == 0) {
-        if constexpr (LAZY_IN) return gl::add(b, 0);  // b >= p ? b - p : b   (4 VALU)
-        return b;
-    } else {
-        return gl::Pow2Mul<E>::apply(b);
-    }
-}
-
-// Two butterflies (I, I + 1) of one level in one block of interleaved carry chains (gl::add_sub2 / gl::add_sub_lazy2).
-//   LAZY = false: canonical inputs and outputs (ten VALU per butterfly).
-//   LAZY = true:  the first operand of a butterfly may be any 64-bit word congruent to the element, the outputs are such words
-//                 (eight VALU per butterfly); the twiddled operand is always canonical (tw_operand).
-template <bool INV, int LVL, int I, bool LAZY>
-__device__ __forceinline__ void butterfly_pair(u64 (&x)[32]) {
-    using B0 = Bf<INV, LVL, I>;
-    using B1 = Bf<INV, LVL, I + 1>;
-    const u64 v0 = tw_operand<B0::E, LAZY && (LVL > 1)>(x[B0::ib]);
-    const u64 v1 = tw_operand<B1::E, LAZY && (LVL > 1)>(x[B1::ib]);
-    u64 s0, d0, s1, d1;
-    if constexpr (LAZY) gl::add_sub_lazy2(x[B0::ia], v0, x[B1::ia], v1, s0, d0, s1, d1);
-    else gl::add_sub2(x[B0::ia], v0, x[B1::ia], v1, s0, d0, s1, d1);
-    x[B0::ia] = B0::neg ? d0 : s0;
-    x[B0::ib] = B0::neg ? s0 : d0;
-    x[B1::ia] = B1::neg ? d1 : s1;
-    x[B1::ib] = B1::neg ? s1 : d1;
-}
-
-template <int E>
-__device__ __forceinline__ void butterfly_pow2(u64& a, u64& b) {
-    // (a, b) -> (a + b * 2^E, a - b * 2^E), canonical in and out; the sign of the power-of-two product is folded into add/sub
-    const u64 v = gl::Pow2Mul<E>::apply(b);
-#if TF_ASM_BFLY
-    if constexpr (!gl::Pow2Mul<E>::negate) gl::add_sub(a, v, a, b);
-    else gl::add_sub(a, v, b, a);
-    return;
-#endif
-    if constexpr (!gl::Pow2Mul<E>::negate) {
-        const u64 s = gl::add(a, v);
-        b = gl::sub(a, v);
-        a = s;
-    } else {
-        const u64 s = gl::sub(a, v);
-        b = gl::add(a, v);
-        a = s;
-    }
-}
-
-// butterflies [I, END) of level LVL, two at a time
-template <bool INV, int LVL, int I, int END, bool LAZY>
-struct DitRange {
-    static __device__ __forceinline__ void run(u64 (&x)[32]) {
-#if TF_ASM_BFLY
-        butterfly_pair<INV, LVL, I, LAZY>(x);
-#else
-        butterfly_pow2<Bf<INV, LVL, I>::E>(x[Bf<INV, LVL, I>::ia], x[Bf<INV, LVL, I>::ib]);
-        butterfly_pow2<Bf<INV, LVL, I + 1>::E>(x[Bf<INV, LVL, I + 1>::ia], x[Bf<INV, LVL, I + 1>::ib]);
-#endif
-        if constexpr (I + 2 < END) DitRange<INV, LVL, I + 2, END, LAZY>::run(x);
-    }
-};
-// Level LVL of a DIT network over all 32 registers.
-template <bool INV, int LVL, bool LAZY = false>
-__device__ __forceinline__ void dit_level(u64 (&x)[32]) { DitRange<INV, LVL, 0, 16, LAZY && TF_LAZY>::run(x); }
-
-// levels 1..4 restricted to the 16 register slots starting at FIRST (0 or 16): butterflies FIRST/2 .. FIRST/2 + 7 of each level
-template <bool INV, int FIRST, bool LAZY = false>
-__device__ __forceinline__ void dit_half(u64 (&x)[32]) {
-    DitRange<INV, 1, FIRST / 2, FIRST / 2 + 8, LAZY && TF_LAZY>::run(x);
-    DitRange<INV, 2, FIRST / 2, FIRST / 2 + 8, LAZY && TF_LAZY>::run(x);
-    DitRange<INV, 3, FIRST / 2, FIRST / 2 + 8, LAZY && TF_LAZY>::run(x);
-    DitRange<INV, 4, FIRST / 2, FIRST / 2 + 8, LAZY && TF_LAZY>::run(x);
-}
-
-// x[q0 .. q0+3] *= w[0 .. 3]  (four Montgomery products, no wait-state nops: gl::mont_mul4)
-__device__ __forceinline__ void mul4_inplace(u64 (&x)[32], int q0, u64 w0, u64 w1, u64 w2, u64 w3) {
-    const u64 a4[4] = {x[q0], x[q0 + 1], x[q0 + 2], x[q0 + 3]}, b4[4] = {w0, w1, w2, w3};
-    u64 r4[4];
-    gl::mont_mul4(a4, b4, r4);
-    x[q0] = r4[0], x[q0 + 1] = r4[1], x[q0 + 2] = r4[2], x[q0 + 3] = r4[3];
-}
+// (the radix-2^k networks with power-of-two twiddles, butterfly blocks and mul4_inplace: ntt_network.h)
 
 // Level 5 of the radix-32 network for the four butterflies (Q0+i, Q0+i+16), i < 4, followed by their eight stores.
 // TRUNC: only the slots q < qlim are stored (output truncated to the first n_out elements, fast_multiply).
@@ -656,7 +533,11 @@ __global__ void __launch_bounds__(512, TF_NTT_WAVES) ntt_pass_kernel(const NttPa
                 const long long j = (ur + g) * A.ps_rs + (A.ps_col ? bcol : 0);
                 if (A.n_coeffs < 0 || j < A.n_coeffs) x[q] = *ptr;  // rows beyond the coefficients read as zero; scaled below
             } else {
+#ifdef TF_AB_BUILD
                 x[q] = (A.nt & 1) ? __builtin_nontemporal_load(ptr) : *ptr;  // uniform: the compiler emits the burst twice
+#else
+                x[q] = *ptr;  // (the run-time non-temporal variant, tf_set_ntt_nt, is a laboratory switch: TF_AB_BUILD)
+#endif
             }
         }
     }
@@ -906,6 +787,7 @@ __global__ void __launch_bounds__(512, TF_NTT_WAVES) ntt_pass_kernel(const NttPa
     }
 }
 
+#ifdef TF_AB_BUILD  // measured loss (2.08 / 2.21 / 2.29 ms against 1.87, profiles/r03_chain_ab.txt): laboratory build only
 // ---- the R = 1024 column pass with the NEXT tile's loads issued inside the store phase -----------------------------------
 // ntt_pass_kernel's R1024 instantiation, plain transform, as a loop over `tiles_per_wg` tiles (tile, tile + gridDim.x, ...): the
 // eight registers a store group frees are filled at once with the next tile's loads, so a workgroup's load latency (a fifth of a
@@ -1042,6 +924,8 @@ __global__ void __launch_bounds__(512, TF_NTT_WAVES) ntt_col1024_chain_kernel(co
         cur = nxt;
     }
 }
+
+#endif  // TF_AB_BUILD
 
 // ---- 2^11 <= n <= 2^14, contiguous BFieldElement transforms: the WHOLE transform in one workgroup pass --------------
 // 16 384 elements are exactly one 512-thread tile, so n = 32 * 32 * P3 (P3 = 2 .. 16) runs as three register stages joined by
@@ -1312,789 +1196,7 @@ __global__ void __launch_bounds__(512, 4) ntt_rows32_kernel(const NttRows32Args 
     }
 }
 
-// ---- 64 <= n <= 4096, LITTLE work per call: the latency-shaped transform -----------------------------------------------
-// The pass kernels above give a thread 32 elements: one thread's program is ~3 500 dependent-ish instructions, 15-25 us however
-// few transforms a call holds (a tree walk over 2^12 points, one slice of a caller that transforms one polynomial at a time).
-// When a call cannot fill the chip anyway this kernel spends threads instead: EIGHT elements per thread, n / 8 threads per
-// transform, Stockham autosort stages of radix 8 (shift-only networks, as everywhere: w_8 = 2^24) joined through LDS, one
-// general twiddle per element and stage from a table w_n^e -- three or four short steps instead of one long one.
-//   stage (radix R, Ns = product of the radices before it), butterfly unit u < n / R:   k = u mod Ns,
-//     v[r] = in[u + r n / R] w_{Ns R}^(k r),   V = DFT_R(v),   out[(u / Ns) Ns R + k + r Ns] = V[r]
-// (natural order in and out, no bit reversal).  The last stage has radix 8, 4 or 2 (8 / R units per thread).
-// XFieldElement slices are three limb transforms of element stride 3 (ntt.rs:203-207).
-#ifndef TF_LAT_MUL4
-#define TF_LAT_MUL4 1  // 0 (A/B build): the stage twiddles of the latency-shaped kernels as eight single products
-#endif
-struct NttLatArgs {
-    const u64* in;
-    u64* out;
-    const u64* in2;        // or null: second operand laid out like `in`, multiplied in on load (L = 1 only)
-    const u64* tw;         // [2][n]: w_n^(+-e), then n^-1 w_n^(+-e) (the inverse's last stage)
-    long long n_coeffs;    // < 0: none; else elements >= n_coeffs read as zero
-    long long in_bs, out_bs;  // words between consecutive slices
-    long long total;       // limb transforms = batch * L
-    u64 ninv;              // Montgomery n^-1 (inverse only)
-    int L;
-    // ---- the steps of a zerofier-tree walk that used to be kernels of their own, as modifiers of this kernel's load and store
-    // (math/zerofier_tree.rs / polynomial.rs:1882-1894 remaindering; the tree code in tf_hip.hip says which step is which)
-    int load_mode;         // 0: element idx of slice b is in[b * in_bs + idx * L]
-                           // 1: REVERSED: in[(b >> src_shift) * in_bs + (rev_top - idx) * L] for idx < n_coeffs (poly_reverse /
-                           //    remainder_rev_high fused into the forward transform that follows them)
-                           // 2: (L = 1) the interpolation walk's parent N_l (Z_r + s) + N_r (Z_l + s), s = (-1)^idx, from the children's
-                           //    transforms in[2 b], in[2 b + 1] and the level's cached tail transforms th[2 node], th[2 node + 1],
-                           //    node = b % parents (interpolant_pointwise_kernel fused into the inverse transform that follows it)
-    int src_shift;
-    long long rev_top;
-    const u64* th;
-    long long parents;
-    int store_mode;        // 0: all n outputs; 1: only outputs k < keep, stored as  sub_src[(b >> 1) * sub_bs + k * L] - value
-                           //    (remainder_finish_kernel fused into the inverse transform in front of it: r = f_low - (q * tail)_low)
-    const u64* sub_src;
-    long long sub_bs, keep;
-};
-__host__ __device__ __forceinline__ constexpr int lat_pad(int i) { return i + (i >> 3); }
-template <int LOGR>
-__device__ __forceinline__ constexpr int lat_brev(int r) {
-    int o = 0;
-    for (int b = 0; b < LOGR; ++b) o |= ((r >> b) & 1) << (LOGR - 1 - b);
-    return o;
-}
-template <bool INV, int LOGR>
-__device__ __forceinline__ void lat_dft(u64 (&x)[32]) {  // 8 >> LOGR independent DFTs of 2^LOGR points on slots 0 .. 7 (bit-reversed in, natural out)
-    DitRange<INV, 1, 0, 4, false>::run(x);
-    if constexpr (LOGR >= 2) DitRange<INV, 2, 0, 4, false>::run(x);
-    if constexpr (LOGR >= 3) DitRange<INV, 3, 0, 4, false>::run(x);
-}
-
-template <int LOGN, bool INV>
-__global__ void __launch_bounds__(LOGN == 12 ? 512 : 256) ntt_lat_kernel(const NttLatArgs A) {
-    constexpr int N = 1 << LOGN, TPT = N / 8, WG = LOGN == 12 ? 512 : 256, T = WG / TPT;
-    constexpr int S = (LOGN + 2) / 3;                 // stages; the first S - 1 have radix 8
-    constexpr int LOGRL = LOGN - 3 * (S - 1);         // log2 of the last radix (1 .. 3)
-    constexpr int BUF = lat_pad(N * T) + 8;
-    extern __shared__ __attribute__((aligned(16))) u64 lds[];  // two buffers of BUF words
-    const int t = threadIdx.x, tr = t / TPT, j = t - tr * TPT;
-    const long long gtr = (long long)blockIdx.x * T + tr;
-    const bool act = gtr < A.total;
-    const int L = A.L;
-    const long long b = act ? gtr / L : 0;
-    const int limb = act ? (int)(gtr - b * L) : 0;
-    const u64* src = A.in + b * A.in_bs + limb;
-    u64* dst = A.out + b * A.out_bs + limb;
-    u64 x[32];
-#pragma unroll
-    for (int q = 0; q < 32; ++q) x[q] = 0;
-    // the general twiddles of every stage after the first, requested before anything else: w_{Ns R}^(k r) = w_n^(k r n / (Ns R))
-    u64 tw[S > 1 ? S - 1 : 1][8];
-    {
-        int Ns = 8;
-#pragma unroll
-        for (int s = 1; s < S; ++s) {
-            const int logr = s + 1 < S ? 3 : LOGRL, R = 1 << logr, U = 8 >> logr;
-            const bool last = s + 1 == S;
-#pragma unroll
-            for (int a = 0; a < U; ++a) {
-                const int u = j + a * TPT, k = u & (Ns - 1);
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    const int e = k * r * (N / (Ns * R));
-                    tw[s - 1][a * R + r] = (r == 0) ? 0 : A.tw[((INV && last) ? N : 0) + e];
-                }
-            }
-            Ns *= R;
-        }
-    }
-    // ---- stage 1: from global memory, no twiddles
-    if (act) {
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            const int idx = j + r * TPT;
-            u64 v = 0;
-            if (A.load_mode == 1) {
-                if (idx < A.n_coeffs) v = (A.in + (b >> A.src_shift) * A.in_bs + limb)[(A.rev_top - idx) * L];
-            } else if (A.load_mode == 2) {
-                const u64* c0 = A.in + 2 * b * A.in_bs;
-                const u64* t0 = A.th + 2 * (b % A.parents) * A.in_bs;
-                const u64 sgn = (idx & 1) ? gl::P - gl::ONE : gl::ONE;
-                const u64 zl = gl::add(t0[idx], sgn), zr = gl::add(t0[A.in_bs + idx], sgn);
-                v = gl::add(gl::mont_mul(c0[idx], zr), gl::mont_mul(c0[A.in_bs + idx], zl));
-            } else if (A.n_coeffs < 0 || idx < A.n_coeffs) {
-                v = src[(long long)idx * L];
-                if (A.in2) v = gl::mont_mul(v, (A.in2 + b * A.in_bs + limb)[(long long)idx * L]);
-            }
-            x[lat_brev<3>(r)] = v;
-        }
-    }
-    lat_dft<INV, 3>(x);
-    u64* bufs[2] = {lds + 0, lds + BUF};
-    {
-        u64* o = bufs[0] + 0;
-#pragma unroll
-        for (int r = 0; r < 8; ++r) o[lat_pad(tr * N + j * 8 + r)] = x[r];
-    }
-    __syncthreads();
-    int Ns = 8;
-#pragma unroll
-    for (int s = 1; s < S; ++s) {
-        const bool last = s + 1 == S;
-        const int logr = last ? LOGRL : 3, R = 1 << logr, U = 8 >> logr;
-        const u64* in = bufs[(s - 1) & 1];
-        u64* o = bufs[s & 1];
-        u64 v[8];
-#pragma unroll
-        for (int a = 0; a < U; ++a) {
-            const int u = j + a * TPT;
-#pragma unroll
-            for (int r = 0; r < R; ++r) v[a * R + r] = in[lat_pad(tr * N + u + r * (N / R))];
-        }
-#if TF_LAT_MUL4
-        if (logr == 3) {  // (see lat_xform: two blocks of four interleaved products)
-            u64 a0[4] = {v[1], v[2], v[3], v[4]}, b0[4] = {tw[s - 1][1], tw[s - 1][2], tw[s - 1][3], tw[s - 1][4]}, r0[4];
-            u64 a1[4] = {v[5], v[6], v[7], v[0]}, b1[4] = {tw[s - 1][5], tw[s - 1][6], tw[s - 1][7], (INV && last) ? A.ninv : gl::ONE}, r1[4];
-            gl::mont_mul4(a0, b0, r0);
-            gl::mont_mul4(a1, b1, r1);
-            x[lat_brev<3>(0)] = (INV && last) ? r1[3] : v[0];
-            x[lat_brev<3>(1)] = r0[0], x[lat_brev<3>(2)] = r0[1], x[lat_brev<3>(3)] = r0[2], x[lat_brev<3>(4)] = r0[3];
-            x[lat_brev<3>(5)] = r1[0], x[lat_brev<3>(6)] = r1[1], x[lat_brev<3>(7)] = r1[2];
-        } else
-#endif
-#pragma unroll
-        for (int a = 0; a < U; ++a) {
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                u64 w = v[a * R + r];
-                if (r) w = gl::mont_mul(w, tw[s - 1][a * R + r]);
-                else if (INV && last) w = gl::mont_mul(w, A.ninv);
-                const int slot = a * R + (logr == 3 ? lat_brev<3>(r) : (logr == 2 ? lat_brev<2>(r) : r));
-                x[slot] = w;
-            }
-        }
-        if (logr == 3) lat_dft<INV, 3>(x);
-        else if (logr == 2) lat_dft<INV, 2>(x);
-        else lat_dft<INV, 1>(x);
-#pragma unroll
-        for (int a = 0; a < U; ++a) {
-            const int u = j + a * TPT, k = u & (Ns - 1), j0 = (u - k) * R + k;
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const int idx = j0 + r * Ns;
-                if (last) {
-                    if (act) {
-                        if (A.store_mode == 1) {
-                            if (idx < A.keep) dst[(long long)idx * L] = gl::sub((A.sub_src + (b >> 1) * A.sub_bs + limb)[(long long)idx * L], x[a * R + r]);
-                        } else {
-                            dst[(long long)idx * L] = x[a * R + r];
-                        }
-                    }
-                } else {
-                    o[lat_pad(tr * N + idx)] = x[a * R + r];
-                }
-            }
-        }
-        if (!last) __syncthreads();
-        Ns *= R;
-    }
-}
-
-// ---- a whole LEVEL of a zerofier-tree walk in one launch (BFieldElement, 2d <= 4096, the latency regime) -------------------
-// A small walk is a chain of dependent launches, each ~4 us of dispatch + drain around ~2 us of work: the walk down spends four
-// transforms per level, the walk up three.  Here one workgroup keeps a line's data in LDS through ALL of a level's transforms
-// (the stages of ntt_lat_kernel as a device function whose first-stage load and last-stage store are the caller's lambdas).
-template <int LOGN, bool INV, class LoadFn, class StoreFn>
-__device__ __forceinline__ void lat_xform(const u64* __restrict__ twtab, u64 ninv, int tr, int j, u64* buf0, u64* buf1, LoadFn load, StoreFn store) {
-    constexpr int N = 1 << LOGN, TPT = N / 8;
-    constexpr int S = (LOGN + 2) / 3, LOGRL = LOGN - 3 * (S - 1);
-    static_assert(S >= 2, "64 points at least");
-    u64 x[32];
-#pragma unroll
-    for (int q = 0; q < 32; ++q) x[q] = 0;
-    u64 tw[S - 1][8];
-    {
-        int Ns = 8;
-#pragma unroll
-        for (int s = 1; s < S; ++s) {
-            const int logr = s + 1 < S ? 3 : LOGRL, R = 1 << logr, U = 8 >> logr;
-            const bool last = s + 1 == S;
-#pragma unroll
-            for (int a = 0; a < U; ++a) {
-                const int u = j + a * TPT, k = u & (Ns - 1);
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    const int e = k * r * (N / (Ns * R));
-                    tw[s - 1][a * R + r] = (r == 0) ? 0 : twtab[((INV && last) ? N : 0) + e];
-                }
-            }
-            Ns *= R;
-        }
-    }
-#pragma unroll
-    for (int r = 0; r < 8; ++r) x[lat_brev<3>(r)] = load(r, j + r * TPT);
-    lat_dft<INV, 3>(x);
-#pragma unroll
-    for (int r = 0; r < 8; ++r) buf0[lat_pad(tr * N + j * 8 + r)] = x[r];
-    __syncthreads();
-    int Ns = 8;
-#pragma unroll
-    for (int s = 1; s < S; ++s) {
-        const bool last = s + 1 == S;
-        const int logr = last ? LOGRL : 3, R = 1 << logr, U = 8 >> logr;
-        const u64* in = ((s - 1) & 1) ? buf1 : buf0;
-        u64* o = (s & 1) ? buf1 : buf0;
-        u64 v[8];
-#pragma unroll
-        for (int a = 0; a < U; ++a) {
-            const int u = j + a * TPT;
-#pragma unroll
-            for (int r = 0; r < R; ++r) v[a * R + r] = in[lat_pad(tr * N + u + r * (N / R))];
-        }
-#if TF_LAT_MUL4
-        if (logr == 3) {
-            // eight products in two blocks of four interleaved carry chains (gl::mont_mul4: 15 VALU per product and no wait-state
-            // nops, against 18 + nops for products issued one by one); the slot of r = 0 rides along with n^-1 or with one
-            u64 a0[4] = {v[1], v[2], v[3], v[4]}, b0[4] = {tw[s - 1][1], tw[s - 1][2], tw[s - 1][3], tw[s - 1][4]}, r0[4];
-            u64 a1[4] = {v[5], v[6], v[7], v[0]}, b1[4] = {tw[s - 1][5], tw[s - 1][6], tw[s - 1][7], (INV && last) ? ninv : gl::ONE}, r1[4];
-            gl::mont_mul4(a0, b0, r0);
-            gl::mont_mul4(a1, b1, r1);
-            x[lat_brev<3>(0)] = (INV && last) ? r1[3] : v[0];
-            x[lat_brev<3>(1)] = r0[0], x[lat_brev<3>(2)] = r0[1], x[lat_brev<3>(3)] = r0[2], x[lat_brev<3>(4)] = r0[3];
-            x[lat_brev<3>(5)] = r1[0], x[lat_brev<3>(6)] = r1[1], x[lat_brev<3>(7)] = r1[2];
-        } else
-#endif
-        {
-#pragma unroll
-            for (int a = 0; a < U; ++a) {
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    u64 w = v[a * R + r];
-                    if (r) w = gl::mont_mul(w, tw[s - 1][a * R + r]);
-                    else if (INV && last) w = gl::mont_mul(w, ninv);
-                    const int slot = a * R + (logr == 3 ? lat_brev<3>(r) : (logr == 2 ? lat_brev<2>(r) : r));
-                    x[slot] = w;
-                }
-            }
-        }
-        if (logr == 3) lat_dft<INV, 3>(x);
-        else if (logr == 2) lat_dft<INV, 2>(x);
-        else lat_dft<INV, 1>(x);
-#pragma unroll
-        for (int a = 0; a < U; ++a) {
-            const int u = j + a * TPT, k = u & (Ns - 1), j0 = (u - k) * R + k;
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const int idx = j0 + r * Ns;
-                if (last) store(idx, x[a * R + r]);
-                else o[lat_pad(tr * N + idx)] = x[a * R + r];
-            }
-        }
-        if (!last) __syncthreads();
-        Ns *= R;
-    }
-}
-
-struct TreeLevelArgs {
-    const u64* cur;   // down: remainders of the level above (lines / 2 polynomials of 2d coefficients); up: the children's interpolants
-    u64* nxt;         // down: lines x d remainders; up: lines x 2d interpolants
-    const u64* ghat;  // down only: the level's cached transforms of the reversed-zerofier inverses, [children][2d]
-    const u64* that;  // the level's cached tail transforms, [children][2d]
-    const u64* tw_f;  // ntt_lat_kernel's tables of order 2d, forward and inverse
-    const u64* tw_i;
-    u64 ninv;
-    long long lines;  // down: units x children; up: rows x parents
-    long long per;    // down: children; up: parents  (the cached transforms repeat with this period)
-};
-
-// LDS: TWO buffers in all.  A transform run as lat_xform(first, second) leaves one of them unread by its last stage -- `second`
-// when the stage count is even, `first` when odd -- so its store lambda writes the result THERE, and the next transform, which
-// reads that buffer only in its first stage, runs as lat_xform(other, that one).
-template <int LOGN>
-struct LatChain {
-    static constexpr bool EVEN = (((LOGN + 2) / 3) % 2) == 0;
-    u64* first;
-    u64* second;
-    __device__ __forceinline__ u64* out() const { return EVEN ? second : first; }
-    __device__ __forceinline__ void next() {  // the result just written becomes the next transform's `second`
-        u64* o = out();
-        u64* other = (o == first) ? second : first;
-        first = other, second = o;
-    }
-};
-
-// Walk down (polynomial.rs:1882-1894's remaindering through the tree, math/zerofier_tree.rs): line = one child.
-//   rev(q) = rev(f_high) g mod x^d;   r = f_low - (q tail)_low          -- four transforms of order N = 2d, nothing leaves LDS
-template <int LOGN>
-__global__ void __launch_bounds__(LOGN == 12 ? 512 : 256) tree_down_level_kernel(const TreeLevelArgs A) {
-    constexpr int N = 1 << LOGN, D = N / 2, TPT = N / 8, WG = LOGN == 12 ? 512 : 256, T = WG / TPT;
-    constexpr int BUF = lat_pad(N * T) + 8;
-    extern __shared__ __attribute__((aligned(16))) u64 lds[];
-    LatChain<LOGN> ch{lds, lds + BUF};
-    const int t = threadIdx.x, tr = t / TPT, j = t - tr * TPT;
-    const long long line = (long long)blockIdx.x * T + tr;
-    const bool act = line < A.lines;
-    const long long c = act ? (long long)((u32)line % (u32)A.per) : 0;  // (lines < 2^31: the grid is 32-bit)
-    const u64* f = A.cur + (act ? (line >> 1) : 0) * N;
-    const u64* gh = A.ghat + c * N;
-    const u64* th = A.that + c * N;
-    u64* dst = A.nxt + (act ? line : 0) * D;
-    u64 ghv[8], thv[8];  // the cached transforms at this thread's first-stage indices, requested up front
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-        const int idx = j + r * TPT;
-        ghv[r] = gh[idx];
-        thv[r] = th[idx];
-    }
-    u64* o = ch.out();
-    lat_xform<LOGN, false>(A.tw_f, 0, tr, j, ch.first, ch.second,
-                           [&](int r, int idx) -> u64 { return (act && r < 4) ? f[N - 1 - idx] : 0; },
-                           [&](int idx, u64 v) { o[lat_pad(tr * N + idx)] = v; });
-    __syncthreads();
-    const u64* in = o;
-    ch.next(), o = ch.out();
-    lat_xform<LOGN, true>(A.tw_i, A.ninv, tr, j, ch.first, ch.second,
-                          [&](int r, int idx) -> u64 { return gl::mont_mul(in[lat_pad(tr * N + idx)], ghv[r]); },
-                          [&](int idx, u64 v) { if (idx < D) o[lat_pad(tr * N + D - 1 - idx)] = v; });
-    __syncthreads();
-    in = o;
-    ch.next(), o = ch.out();
-    lat_xform<LOGN, false>(A.tw_f, 0, tr, j, ch.first, ch.second,
-                           [&](int r, int idx) -> u64 { return r < 4 ? in[lat_pad(tr * N + idx)] : 0; },
-                           [&](int idx, u64 v) { o[lat_pad(tr * N + idx)] = v; });
-    __syncthreads();
-    in = o;
-    ch.next();
-    lat_xform<LOGN, true>(A.tw_i, A.ninv, tr, j, ch.first, ch.second,
-                          [&](int r, int idx) -> u64 { return gl::mont_mul(in[lat_pad(tr * N + idx)], thv[r]); },
-                          [&](int idx, u64 v) { if (act && idx < D) dst[idx] = gl::sub(f[idx], v); });
-}
-
-// Walk up (the interpolation's combination N = N_left Z_right + N_right Z_left, Z = tail + x^d): line = one parent; three LDS
-// buffers (both children's transforms are alive when the inverse transform starts).  Measured against two thread groups per
-// line transforming the children side by side (1024 threads at 2d = 4096, group 1 idle through the inverse): 122.2 vs 126.0 us
-// per prepared-tree interpolation of 2^12 points -- the wider workgroup costs more than the parallel child saves.
-template <int LOGN>
-__global__ void __launch_bounds__(LOGN == 12 ? 512 : 256) tree_up_level_kernel(const TreeLevelArgs A) {
-    constexpr int N = 1 << LOGN, D = N / 2, TPT = N / 8, WG = LOGN == 12 ? 512 : 256, T = WG / TPT;
-    constexpr int BUF = lat_pad(N * T) + 8;
-    constexpr bool EVEN = LatChain<LOGN>::EVEN;
-    extern __shared__ __attribute__((aligned(16))) u64 lds[];
-    u64* p = lds;
-    u64* q = lds + BUF;
-    u64* c = lds + 2 * BUF;
-    const int t = threadIdx.x, tr = t / TPT, j = t - tr * TPT;
-    const long long line = (long long)blockIdx.x * T + tr;
-    const bool act = line < A.lines;
-    const u32 node = act ? (u32)line % (u32)A.per : 0;
-    const u64* c0 = A.cur + (act ? line : 0) * N;  // the two children, d coefficients each, side by side
-    const u64* t0 = A.that + 2 * (long long)node * N;
-    u64* dst = A.nxt + (act ? line : 0) * N;
-    u64 zlv[8], zrv[8];  // Z_left, Z_right transforms at this thread's first-stage indices, requested up front
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-        const int idx = j + r * TPT;
-        const u64 sgn = (idx & 1) ? gl::P - gl::ONE : gl::ONE;
-        zlv[r] = gl::add(t0[idx], sgn);
-        zrv[r] = gl::add(t0[N + idx], sgn);
-    }
-    u64* a = EVEN ? q : p;  // left child's transform: the buffer lat_xform(p, q)'s last stage does not read
-    lat_xform<LOGN, false>(A.tw_f, 0, tr, j, p, q, [&](int r, int idx) -> u64 { return (act && r < 4) ? c0[idx] : 0; },
-                           [&](int idx, u64 v) { a[lat_pad(tr * N + idx)] = v; });
-    __syncthreads();
-    u64* w0 = EVEN ? p : q;  // the right child's transform works in the other two buffers
-    u64* b = EVEN ? c : w0;
-    lat_xform<LOGN, false>(A.tw_f, 0, tr, j, w0, c, [&](int r, int idx) -> u64 { return (act && r < 4) ? c0[D + idx] : 0; },
-                           [&](int idx, u64 v) { b[lat_pad(tr * N + idx)] = v; });
-    __syncthreads();
-    u64* f0 = EVEN ? w0 : c;  // the inverse transform's first stage writes the one buffer that holds neither
-    lat_xform<LOGN, true>(A.tw_i, A.ninv, tr, j, f0, b,
-                          [&](int r, int idx) -> u64 {
-                              return gl::add(gl::mont_mul(a[lat_pad(tr * N + idx)], zrv[r]), gl::mont_mul(b[lat_pad(tr * N + idx)], zlv[r]));
-                          },
-                          [&](int idx, u64 v) { if (act) dst[idx] = v; });
-}
-
-// ---- a whole level of the zerofier-tree BUILD in one launch (BFieldElement, 2d <= 2048) ---------------------------------------
-// Per parent the build runs nine transforms (math/zerofier_tree.rs builds the same products with fast_multiply; the power-series
-// inverses are this design's own):
-//   phase 1  four transforms of order 2d: both children's tails and inverses  -> That, Ghat (kept for the walks)
-//   phase 2  tail_parent = iNTT((TL^ + s)(TR^ + s) - 1),   G = iNTT(GL^ GR^) mod x^d
-//   phase 3  two transforms of order 4d: G and H = rev(Z_parent) mod x^2d
-//   phase 4  inv_parent = iNTT(G^ (2 - H^ G^)) mod x^2d                       (one Newton step)
-// One workgroup slice (4 * 2d / 8 threads) per parent: the four / two transforms of a phase run side by side in thread groups,
-// everything between the phases stays in LDS (two buffers; LatChain's rule for where a result lands).  Groups without a
-// transform in a phase walk through its barriers on zeros.
-struct TreeBuildArgs {
-    const u64* tails;   // level l: [children][d]
-    const u64* inv;     // level l: [children][d]
-    u64* that;          // level l: [children][2d]
-    u64* ghat;          // level l: [children][2d]
-    u64* ptails;        // level l + 1: [parents][2d]   (null: top level, phase 1 only)
-    u64* pinv;          // level l + 1: [parents][2d]
-    const u64 *tw_f2, *tw_i2, *tw_f4, *tw_i4;  // ntt_lat_kernel's tables of order 2d and 4d
-    u64 ninv2, ninv4;
-    long long parents;
-};
-template <int LOGN2>
-struct TreeBuildGeom {
-    static constexpr int N2 = 1 << LOGN2, TPT2 = N2 / 8;
-    static constexpr int T = 4 * TPT2 >= 256 ? 1 : 256 / (4 * TPT2);  // parents per workgroup
-    static constexpr int WG = 4 * TPT2 * T;
-    static constexpr int BUF = lat_pad(N2 * 4 * T) + 8;
-};
-template <int LOGN2>
-__global__ void __launch_bounds__(TreeBuildGeom<LOGN2>::WG) tree_build_level_kernel(const TreeBuildArgs A) {
-    using G = TreeBuildGeom<LOGN2>;
-    constexpr int N2 = G::N2, D = N2 / 2, TPT2 = G::TPT2, T = G::T, BUF = G::BUF, LOGN4 = LOGN2 + 1, N4 = 2 * N2, TPT4 = 2 * TPT2;
-    constexpr bool EVEN2 = LatChain<LOGN2>::EVEN, EVEN4 = LatChain<LOGN4>::EVEN;
-    extern __shared__ __attribute__((aligned(16))) u64 lds[];
-    u64* P = lds;
-    u64* Q = lds + BUF;
-    const int t = threadIdx.x;
-    const int g = t / TPT2, j = t - g * TPT2, slot = g >> 2, role = g & 3;
-    const int g4 = t / TPT4, j4 = t - g4 * TPT4, role4 = g4 & 1;
-    const long long parent = (long long)blockIdx.x * T + slot;
-    const bool act = parent < A.parents;
-    const long long child = 2 * (act ? parent : 0) + (role & 1);
-    // ---- phase 1
-    u64* O1 = EVEN2 ? Q : P;
-    {
-        const u64* src = (role < 2 ? A.tails : A.inv) + child * D;
-        u64* dst = (role < 2 ? A.that : A.ghat) + child * N2;
-        lat_xform<LOGN2, false>(A.tw_f2, 0, g, j, P, Q, [&](int r, int idx) -> u64 { return (act && r < 4) ? src[idx] : 0; },
-                                [&](int idx, u64 v) {
-                                    O1[lat_pad(g * N2 + idx)] = v;
-                                    if (act) dst[idx] = v;
-                                });
-    }
-    if (!A.ptails) return;
-    __syncthreads();
-    // ---- phase 2: group 0 the parent's tail, group 2 the product of the children's inverses
-    u64* F2 = EVEN2 ? P : Q;           // = the buffer that does not hold O1
-    u64* O2 = EVEN2 ? O1 : F2;
-    {
-        const int gb = g & ~3;
-        u64* pt = A.ptails + (act ? parent : 0) * N2;
-        lat_xform<LOGN2, true>(A.tw_i2, A.ninv2, g, j, F2, O1,
-                               [&](int, int idx) -> u64 {
-                                   if (role == 0) {
-                                       const u64 sgn = (idx & 1) ? gl::P - gl::ONE : gl::ONE;
-                                       const u64 a = gl::add(O1[lat_pad(gb * N2 + idx)], sgn), b = gl::add(O1[lat_pad((gb + 1) * N2 + idx)], sgn);
-                                       return gl::sub(gl::mont_mul(a, b), gl::ONE);
-                                   }
-                                   if (role == 2) return gl::mont_mul(O1[lat_pad((gb + 2) * N2 + idx)], O1[lat_pad((gb + 3) * N2 + idx)]);
-                                   return 0;
-                               },
-                               [&](int idx, u64 v) {
-                                   if (role == 0) {
-                                       O2[lat_pad(g * N2 + idx)] = v;
-                                       if (act) pt[idx] = v;
-                                   } else if (role == 2 && idx < D) {
-                                       O2[lat_pad(g * N2 + idx)] = v;
-                                   }
-                               });
-    }
-    __syncthreads();
-    // ---- phase 3 (order 4d, two groups per parent): G^ and H^
-    u64* F3 = (O2 == P) ? Q : P;
-    u64* O3 = EVEN4 ? O2 : F3;
-    {
-        const int nb = (g4 & ~1) * 2;  // first 2d-sized region of this parent
-        lat_xform<LOGN4, false>(A.tw_f4, 0, g4, j4, F3, O2,
-                                [&](int r, int idx) -> u64 {
-                                    if (role4 == 0) return idx < D ? O2[lat_pad((nb + 2) * N2 + idx)] : 0;  // G = (g_l g_r) mod x^d
-                                    if (idx >= N2) return 0;                                                  // H = rev(Z_parent) mod x^2d
-                                    return idx == 0 ? gl::ONE : O2[lat_pad(nb * N2 + N2 - idx)];
-                                },
-                                [&](int idx, u64 v) { O3[lat_pad(g4 * N4 + idx)] = v; });
-    }
-    __syncthreads();
-    // ---- phase 4 (order 4d): one Newton step, its low 2d coefficients are the parent's inverse
-    u64* F4 = (O3 == P) ? Q : P;
-    {
-        const int gp = g4 & ~1;
-        u64* pi = A.pinv + (act ? parent : 0) * N2;
-        const u64 two = gl::add(gl::ONE, gl::ONE);
-        lat_xform<LOGN4, true>(A.tw_i4, A.ninv4, g4, j4, F4, O3,
-                               [&](int, int idx) -> u64 {
-                                   if (role4) return 0;
-                                   const u64 gh = O3[lat_pad(gp * N4 + idx)], hh = O3[lat_pad((gp + 1) * N4 + idx)];
-                                   return gl::mont_mul(gh, gl::sub(two, gl::mont_mul(hh, gh)));
-                               },
-                               [&](int idx, u64 v) { if (act && role4 == 0 && idx < N2) pi[idx] = v; });
-    }
-}
-
-// ---- the same over XFieldElement: a line's three limb transforms run SIDE BY SIDE in three thread groups of one workgroup
-// (one after the other they would lose to separate launches); the extension-field products between the transforms read all three
-// limbs of an element from LDS and every group forms its own limb of the product (x_field_element.rs:512-536).
-__device__ __forceinline__ u64 xfe_mul_limb(u64 s0, u64 s1, u64 s2, u64 o0, u64 o1, u64 o2, int limb) {
-    if (limb == 0) return gl::sub(gl::sub(gl::mont_mul(s0, o0), gl::mont_mul(s2, o1)), gl::mont_mul(s1, o2));
-    if (limb == 1)
-        return gl::add(gl::add(gl::sub(gl::add(gl::mont_mul(s1, o0), gl::mont_mul(s0, o1)), gl::mont_mul(s2, o2)), gl::mont_mul(s2, o1)), gl::mont_mul(s1, o2));
-    return gl::add(gl::add(gl::add(gl::mont_mul(s2, o0), gl::mont_mul(s1, o1)), gl::mont_mul(s0, o2)), gl::mont_mul(s2, o2));
-}
-// threads of a workgroup: T lines x 3 limbs x N / 8
-template <int LOGN>
-struct TreeXfeGeom {
-    static constexpr int N = 1 << LOGN, TPT = N / 8;
-    static constexpr int T = TPT >= 128 ? 1 : 128 / TPT;
-    static constexpr int WG = 3 * TPT * T;
-    static constexpr int BUF = lat_pad(N * 3 * T) + 8;
-};
-
-template <int LOGN>
-__global__ void __launch_bounds__(TreeXfeGeom<LOGN>::WG) tree_down_level_xfe_kernel(const TreeLevelArgs A) {
-    using G = TreeXfeGeom<LOGN>;
-    constexpr int N = G::N, D = N / 2, TPT = G::TPT, T = G::T, BUF = G::BUF;
-    extern __shared__ __attribute__((aligned(16))) u64 lds[];
-    LatChain<LOGN> ch{lds, lds + BUF};
-    const int t = threadIdx.x, g = t / TPT, j = t - g * TPT, lw = g / 3, limb = g - 3 * lw, g0 = g - limb;
-    const long long line = (long long)blockIdx.x * T + lw;
-    const bool act = line < A.lines;
-    const long long c = act ? (long long)((u32)line % (u32)A.per) : 0;
-    const u64* f = A.cur + (act ? (line >> 1) : 0) * N * 3;
-    const u64* gh = A.ghat + c * N * 3;
-    const u64* th = A.that + c * N * 3;
-    u64* dst = A.nxt + (act ? line : 0) * D * 3;
-    u64 cv[8][3];  // the cached transform an extension-field product needs, at this thread's first-stage indices, requested ahead
-#pragma unroll
-    for (int r = 0; r < 8; ++r)
-#pragma unroll
-        for (int k = 0; k < 3; ++k) cv[r][k] = gh[(j + r * TPT) * 3 + k];
-    u64* o = ch.out();
-    lat_xform<LOGN, false>(A.tw_f, 0, g, j, ch.first, ch.second,
-                           [&](int r, int idx) -> u64 { return (act && r < 4) ? f[(N - 1 - idx) * 3 + limb] : 0; },
-                           [&](int idx, u64 v) { o[lat_pad(g * N + idx)] = v; });
-    __syncthreads();
-    const u64* in = o;
-    ch.next(), o = ch.out();
-    lat_xform<LOGN, true>(A.tw_i, A.ninv, g, j, ch.first, ch.second,
-                          [&](int r, int idx) -> u64 {
-                              return xfe_mul_limb(in[lat_pad(g0 * N + idx)], in[lat_pad((g0 + 1) * N + idx)], in[lat_pad((g0 + 2) * N + idx)],
-                                                  cv[r][0], cv[r][1], cv[r][2], limb);
-                          },
-                          [&](int idx, u64 v) { if (idx < D) o[lat_pad(g * N + D - 1 - idx)] = v; });
-#pragma unroll
-    for (int r = 0; r < 8; ++r)
-#pragma unroll
-        for (int k = 0; k < 3; ++k) cv[r][k] = th[(j + r * TPT) * 3 + k];
-    __syncthreads();
-    in = o;
-    ch.next(), o = ch.out();
-    lat_xform<LOGN, false>(A.tw_f, 0, g, j, ch.first, ch.second,
-                           [&](int r, int idx) -> u64 { return r < 4 ? in[lat_pad(g * N + idx)] : 0; },
-                           [&](int idx, u64 v) { o[lat_pad(g * N + idx)] = v; });
-    __syncthreads();
-    in = o;
-    ch.next();
-    lat_xform<LOGN, true>(A.tw_i, A.ninv, g, j, ch.first, ch.second,
-                          [&](int r, int idx) -> u64 {
-                              return xfe_mul_limb(in[lat_pad(g0 * N + idx)], in[lat_pad((g0 + 1) * N + idx)], in[lat_pad((g0 + 2) * N + idx)],
-                                                  cv[r][0], cv[r][1], cv[r][2], limb);
-                          },
-                          [&](int idx, u64 v) { if (act && idx < D) dst[idx * 3 + limb] = gl::sub(f[idx * 3 + limb], v); });
-}
-
-template <int LOGN>
-__global__ void __launch_bounds__(TreeXfeGeom<LOGN>::WG) tree_up_level_xfe_kernel(const TreeLevelArgs A) {
-    using G = TreeXfeGeom<LOGN>;
-    constexpr int N = G::N, D = N / 2, TPT = G::TPT, T = G::T, BUF = G::BUF;
-    constexpr bool EVEN = LatChain<LOGN>::EVEN;
-    extern __shared__ __attribute__((aligned(16))) u64 lds[];
-    u64* p = lds;
-    u64* q = lds + BUF;
-    u64* c = lds + 2 * BUF;
-    const int t = threadIdx.x, g = t / TPT, j = t - g * TPT, lw = g / 3, limb = g - 3 * lw, g0 = g - limb;
-    const long long line = (long long)blockIdx.x * T + lw;
-    const bool act = line < A.lines;
-    const u32 node = act ? (u32)line % (u32)A.per : 0;
-    const u64* c0 = A.cur + (act ? line : 0) * N * 3;
-    const u64* t0 = A.that + 2 * (long long)node * N * 3;
-    u64* dst = A.nxt + (act ? line : 0) * N * 3;
-    // Z_left, Z_right transforms (tail + x^d: (-1)^idx on limb 0) at this thread's first-stage indices (one array per limb: arrays
-    // of arrays captured by the lambdas below end up in scratch memory)
-    u64 zl0[8], zl1[8], zl2[8], zr0[8], zr1[8], zr2[8];
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-        const int idx = j + r * TPT;
-        const u64 sgn = (idx & 1) ? gl::P - gl::ONE : gl::ONE;
-        zl0[r] = gl::add(t0[idx * 3], sgn), zl1[r] = t0[idx * 3 + 1], zl2[r] = t0[idx * 3 + 2];
-        zr0[r] = gl::add(t0[(N + idx) * 3], sgn), zr1[r] = t0[(N + idx) * 3 + 1], zr2[r] = t0[(N + idx) * 3 + 2];
-    }
-    u64* a = EVEN ? q : p;
-    lat_xform<LOGN, false>(A.tw_f, 0, g, j, p, q, [&](int r, int idx) -> u64 { return (act && r < 4) ? c0[idx * 3 + limb] : 0; },
-                           [&](int idx, u64 v) { a[lat_pad(g * N + idx)] = v; });
-    __syncthreads();
-    u64* w0 = EVEN ? p : q;
-    u64* b = EVEN ? c : w0;
-    lat_xform<LOGN, false>(A.tw_f, 0, g, j, w0, c, [&](int r, int idx) -> u64 { return (act && r < 4) ? c0[(D + idx) * 3 + limb] : 0; },
-                           [&](int idx, u64 v) { b[lat_pad(g * N + idx)] = v; });
-    __syncthreads();
-    u64* f0 = EVEN ? w0 : c;
-    u64 v8[8];  // the combination N_left Z_right + N_right Z_left at this thread's first-stage indices
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-        const int idx = j + r * TPT;
-        const u64 x = xfe_mul_limb(a[lat_pad(g0 * N + idx)], a[lat_pad((g0 + 1) * N + idx)], a[lat_pad((g0 + 2) * N + idx)], zr0[r], zr1[r], zr2[r], limb);
-        const u64 y = xfe_mul_limb(b[lat_pad(g0 * N + idx)], b[lat_pad((g0 + 1) * N + idx)], b[lat_pad((g0 + 2) * N + idx)], zl0[r], zl1[r], zl2[r], limb);
-        v8[r] = gl::add(x, y);
-    }
-    lat_xform<LOGN, true>(A.tw_i, A.ninv, g, j, f0, b, [&](int r, int) -> u64 { return v8[r]; },
-                          [&](int idx, u64 v) { if (act) dst[idx * 3 + limb] = v; });
-}
-
-// ---- 2^13 <= n <= 2^20, little work per call: the same eight-elements-per-thread stages as the two passes of n = N1 N2 ------
-// (one slice per call is the reference's own call shape: math/ntt.rs:67-82 takes ONE slice).  A "line" is one DFT instance:
-//   column pass (LAST = false): line c = word-column c of the N2 L words of a row; element i at  i * es + c;  after the last stage
-//       output k is multiplied by the inter-pass twiddle w_n^(k b), b = c / L, and stored where it came from (or into scratch);
-//   last pass (LAST = true):    line c = (k1, limb) = (c / L, c % L): input row k1 of N2 contiguous elements, output k at
-//       (k1 + N1 k) L + limb -- natural order, no bit reversal.
-// cfast: adjacent threads take adjacent lines (the column pass: coalesced both ways); otherwise adjacent threads walk along the line
-// (the last pass: contiguous loads, strided 8-byte stores -- a call this small is bound by latency, not by store efficiency).
-struct NttLat2Args {
-    const u64* in;
-    u64* out;
-    const u64* in2;            // or null: second operand laid out like `in`, multiplied in on load (first pass, L = 1)
-    const u64* tw;             // [2][N]: w_N^(+-e), then scale * w_N^(+-e)
-    const u64* post_tw;        // column pass: T[k * tw_rs + b]
-    long long n_coeffs;        // column pass: < 0 none; else input element index i * nc_es + c / L >= n_coeffs reads as zero
-    long long nc_es;
-    long long in_bs, out_bs;   // words between batch entries
-    long long lines;           // lines per batch entry
-    long long in_es, out_es;   // words between consecutive elements of a line
-    long long in_lhi, out_lhi; // line c starts at (c / L) * lhi + (c % L)
-    long long tw_rs;
-    u64 scale;                 // last pass of an inverse: n^-1 (Montgomery); 0 otherwise
-    int L;
-    int cfast;
-    int tiles_per_entry;       // ceil(lines / T)
-};
-
-template <int LOGN, bool INV, bool LAST, int WG = 256>
-__global__ void __launch_bounds__(WG) ntt_lat2_kernel(const NttLat2Args A) {
-    constexpr int N = 1 << LOGN, TPT = N / 8, T = WG / TPT;
-    constexpr int S = (LOGN + 2) / 3, LOGRL = LOGN - 3 * (S - 1);
-    constexpr int BUF = lat_pad(N * T) + 8;
-    static_assert(LOGN >= 6 && LOGN <= 10, "");
-    extern __shared__ __attribute__((aligned(16))) u64 lds[];
-    const int t = threadIdx.x;
-    const int lc = A.cfast ? t % T : t / TPT;   // line within the tile
-    const int j = A.cfast ? t / T : t % TPT;    // butterfly unit within the line
-    const long long entry = blockIdx.x / A.tiles_per_entry, tile = blockIdx.x - entry * A.tiles_per_entry;
-    const long long c = tile * T + lc;
-    const bool act = c < A.lines;
-    const int L = A.L;
-    const long long chi = act ? c / L : 0;
-    const int clo = act ? (int)(c - chi * L) : 0;
-    const u64* src = A.in + entry * A.in_bs + chi * A.in_lhi + clo;
-    u64* dst = A.out + entry * A.out_bs + chi * A.out_lhi + clo;
-    const auto li = [&](int idx) { return A.cfast ? lat_pad(idx * T + lc) : lat_pad(lc * N + idx); };  // LDS index of element idx of my line
-    u64 x[32];
-#pragma unroll
-    for (int q = 0; q < 32; ++q) x[q] = 0;
-    u64 tw[S > 1 ? S - 1 : 1][8];
-    {
-        int Ns = 8;
-#pragma unroll
-        for (int s = 1; s < S; ++s) {
-            const int logr = s + 1 < S ? 3 : LOGRL, R = 1 << logr, U = 8 >> logr;
-            const bool last = s + 1 == S;
-#pragma unroll
-            for (int a = 0; a < U; ++a) {
-                const int u = j + a * TPT, k = u & (Ns - 1);
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    const int e = k * r * (N / (Ns * R));
-                    tw[s - 1][a * R + r] = (r == 0) ? 0 : A.tw[((LAST && INV && last) ? N : 0) + e];
-                }
-            }
-            Ns *= R;
-        }
-    }
-    if (act) {
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            const int idx = j + r * TPT;
-            u64 v = 0;
-            if (LAST || A.n_coeffs < 0 || (long long)idx * A.nc_es + chi < A.n_coeffs) {
-                v = src[(long long)idx * A.in_es];
-                if (!LAST && A.in2) v = gl::mont_mul(v, (A.in2 + entry * A.in_bs + chi * A.in_lhi + clo)[(long long)idx * A.in_es]);
-            }
-            x[lat_brev<3>(r)] = v;
-        }
-    }
-    lat_dft<INV, 3>(x);
-    u64* bufs[2] = {lds + 0, lds + BUF};
-#pragma unroll
-    for (int r = 0; r < 8; ++r) bufs[0][li(j * 8 + r)] = x[r];
-    __syncthreads();
-    int Ns = 8;
-#pragma unroll
-    for (int s = 1; s < S; ++s) {
-        const bool last = s + 1 == S;
-        const int logr = last ? LOGRL : 3, R = 1 << logr, U = 8 >> logr;
-        const u64* in = bufs[(s - 1) & 1];
-        u64* o = bufs[s & 1];
-        u64 v[8];
-#pragma unroll
-        for (int a = 0; a < U; ++a) {
-            const int u = j + a * TPT;
-#pragma unroll
-            for (int r = 0; r < R; ++r) v[a * R + r] = in[li(u + r * (N / R))];
-        }
-        u64 ptw[8];
-        if (last && !LAST && act) {  // inter-pass twiddles of my outputs, requested before the arithmetic
-#pragma unroll
-            for (int a = 0; a < U; ++a) {
-                const int u = j + a * TPT, k = u & (Ns - 1), j0 = (u - k) * R + k;
-#pragma unroll
-                for (int r = 0; r < R; ++r) ptw[a * R + r] = A.post_tw[(long long)(j0 + r * Ns) * A.tw_rs + chi];
-            }
-        }
-#if TF_LAT_MUL4
-        if (logr == 3) {  // (see lat_xform: two blocks of four interleaved products)
-            u64 a0[4] = {v[1], v[2], v[3], v[4]}, b0[4] = {tw[s - 1][1], tw[s - 1][2], tw[s - 1][3], tw[s - 1][4]}, r0[4];
-            u64 a1[4] = {v[5], v[6], v[7], v[0]}, b1[4] = {tw[s - 1][5], tw[s - 1][6], tw[s - 1][7], (LAST && INV && last) ? A.scale : gl::ONE}, r1[4];
-            gl::mont_mul4(a0, b0, r0);
-            gl::mont_mul4(a1, b1, r1);
-            x[lat_brev<3>(0)] = (LAST && INV && last) ? r1[3] : v[0];
-            x[lat_brev<3>(1)] = r0[0], x[lat_brev<3>(2)] = r0[1], x[lat_brev<3>(3)] = r0[2], x[lat_brev<3>(4)] = r0[3];
-            x[lat_brev<3>(5)] = r1[0], x[lat_brev<3>(6)] = r1[1], x[lat_brev<3>(7)] = r1[2];
-        } else
-#endif
-#pragma unroll
-        for (int a = 0; a < U; ++a) {
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                u64 w = v[a * R + r];
-                if (r) w = gl::mont_mul(w, tw[s - 1][a * R + r]);
-                else if (LAST && INV && last) w = gl::mont_mul(w, A.scale);
-                const int slot = a * R + (logr == 3 ? lat_brev<3>(r) : (logr == 2 ? lat_brev<2>(r) : r));
-                x[slot] = w;
-            }
-        }
-        if (logr == 3) lat_dft<INV, 3>(x);
-        else if (logr == 2) lat_dft<INV, 2>(x);
-        else lat_dft<INV, 1>(x);
-#pragma unroll
-        for (int a = 0; a < U; ++a) {
-            const int u = j + a * TPT, k = u & (Ns - 1), j0 = (u - k) * R + k;
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const int idx = j0 + r * Ns;
-                if (last) {
-                    if (act) {
-                        u64 val = x[a * R + r];
-                        if (!LAST) val = gl::mont_mul(val, ptw[a * R + r]);
-                        dst[(long long)idx * A.out_es] = val;
-                    }
-                } else {
-                    o[li(idx)] = x[a * R + r];
-                }
-            }
-        }
-        if (!last) __syncthreads();
-        Ns *= R;
-    }
-}
+// (the latency-shaped kernels -- ntt_lat_kernel, ntt_lat2_kernel, the one-launch-per-level kernels of the zerofier-tree walks: lat_kernels.h, tf_lat.hip)
 
 // ---- n <= 16: one thread per (transform, limb); reference-shaped radix-2 loop, tables in global memory.
 struct NttTinyArgs {
@@ -2170,188 +1272,6 @@ __global__ void __launch_bounds__(256) build_pow_tables_kernel(u64* out, const u
     const u64* hi = tabs + (long long)blockIdx.y * (nhi + nlo);
     const u64* lo = hi + nhi;
     out[(long long)blockIdx.y * n + id] = gl::mont_mul(hi[id >> h], lo[id & ((1ll << h) - 1)]);
-}
-
-// ---- pointwise products (Hadamard) ---------------------------------------------------------------
-// out[i] = a[i] * b[i] over BFieldElement (b_field_element.rs:755-762)
-__global__ void __launch_bounds__(256) hadamard_bfe_kernel(const u64* a, const u64* b, u64* out, long long count) {
-    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long long stride = (long long)gridDim.x * blockDim.x;
-    // two elements per lane and access (16-byte loads/stores) when the three arrays are 16-byte aligned
-    if ((((unsigned long long)a | (unsigned long long)b | (unsigned long long)out) & 15) == 0) {
-        typedef unsigned long long ull2 __attribute__((ext_vector_type(2)));
-        const long long pairs = count >> 1;
-        const ull2* a2 = reinterpret_cast<const ull2*>(a);
-        const ull2* b2 = reinterpret_cast<const ull2*>(b);
-        ull2* o2 = reinterpret_cast<ull2*>(out);
-        for (long long k = i; k < pairs; k += stride) {
-            const ull2 x = a2[k], y = b2[k];
-            u64 r0, r1;
-            gl::mont_mul2(x.x, y.x, x.y, y.y, r0, r1);
-            ull2 r;
-            r.x = r0;
-            r.y = r1;
-            o2[k] = r;
-        }
-        if ((count & 1) && i == 0) out[count - 1] = gl::mont_mul(a[count - 1], b[count - 1]);
-        return;
-    }
-    for (; i < count; i += stride) out[i] = gl::mont_mul(a[i], b[i]);
-}
-
-// out[i] = a[i] * b[i] over XFieldElement = F_p[x]/(x^3 - x + 1)  (x_field_element.rs:512-536):
-// with self = [c, b, a], other = [f, e, d]:  r0 = cf - ae - bd;  r1 = bf + ce - ad + ae + bd;  r2 = af + be + cd + ad
-__global__ void __launch_bounds__(256) hadamard_xfe_kernel(const u64* pa, const u64* pb, u64* out, long long count) {
-    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long long stride = (long long)gridDim.x * blockDim.x;
-    for (; i < count; i += stride) {
-        const u64 c = pa[3 * i], b = pa[3 * i + 1], a = pa[3 * i + 2];
-        const u64 f = pb[3 * i], e = pb[3 * i + 1], d = pb[3 * i + 2];
-        const u64 ae = gl::mont_mul(a, e), bd = gl::mont_mul(b, d), ad = gl::mont_mul(a, d);
-        const u64 r0 = gl::sub(gl::sub(gl::mont_mul(c, f), ae), bd);
-        const u64 r1 = gl::add(gl::add(gl::sub(gl::add(gl::mont_mul(b, f), gl::mont_mul(c, e)), ad), ae), bd);
-        const u64 r2 = gl::add(gl::add(gl::add(gl::mont_mul(a, f), gl::mont_mul(b, e)), gl::mont_mul(c, d)), ad);
-        out[3 * i] = r0;
-        out[3 * i + 1] = r1;
-        out[3 * i + 2] = r2;
-    }
-}
-
-// dst[b][0..n_dst) = src[b][0..min(n_src, n_dst)) then zeros (resize(order, ZERO), polynomial.rs:913-914); words, not elements
-__global__ void __launch_bounds__(256) pad_copy_kernel(const u64* src, u64* dst, long long n_src, long long n_dst, long long batch,
-                                                       long long src_stride) {
-    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long long stride = (long long)gridDim.x * blockDim.x;
-    for (; i < n_dst * batch; i += stride) {
-        const long long b = i / n_dst, j = i - b * n_dst;
-        dst[i] = j < n_src ? src[b * src_stride + j] : 0;
-    }
-}
-
-// out[i] = f(points[i]) by Horner's rule, one lane per point (Polynomial::iterative_batch_evaluate,
-// polynomial.rs:1876-1878; same values as batch_evaluate :1840-1852).  The coefficient reads are wave-uniform.
-__device__ __forceinline__ void xfe_mul(const u64 (&s)[3], const u64 (&o)[3], u64 (&r)[3]) {
-    // x_field_element.rs:512-536 with self = [c, b, a], other = [f, e, d]
-    const u64 c = s[0], b = s[1], a = s[2], f = o[0], e = o[1], d = o[2];
-    const u64 ae = gl::mont_mul(a, e), bd = gl::mont_mul(b, d), ad = gl::mont_mul(a, d);
-    r[0] = gl::sub(gl::sub(gl::mont_mul(c, f), ae), bd);
-    r[1] = gl::add(gl::add(gl::sub(gl::add(gl::mont_mul(b, f), gl::mont_mul(c, e)), ad), ae), bd);
-    r[2] = gl::add(gl::add(gl::add(gl::mont_mul(a, f), gl::mont_mul(b, e)), gl::mont_mul(c, d)), ad);
-}
-
-// Field element of width L (1: BFieldElement, 3: XFieldElement) for the evaluation kernels.
-template <int L>
-__device__ __forceinline__ void fe_mul(const u64 (&a)[L], const u64 (&b)[L], u64 (&r)[L]) {
-    if constexpr (L == 1) r[0] = gl::mont_mul(a[0], b[0]);
-    else xfe_mul(a, b, r);
-}
-
-// Lane per point: the right shape for short polynomials at many points.  grid = (ceil(m / 256), batch).
-// CL = words per COEFFICIENT (L: same field as the points; 1 with L = 3: Polynomial<BFieldElement>::evaluate::<XFieldElement, _>,
-// polynomial.rs:309-320 -- the base-field coefficient is added to limb 0 of the extension-field accumulator).
-template <int L, int CL = L>
-__global__ void __launch_bounds__(256) batch_evaluate_kernel(const u64* coeffs, long long n_coeffs, long long poly_stride,
-                                                            const u64* points, long long n_points, u64* out, long long out_stride) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_points) return;
-    const u64* c = coeffs + (long long)blockIdx.y * poly_stride;
-    u64 x[L], acc[L];
-#pragma unroll
-    for (int k = 0; k < L; ++k) { x[k] = points[L * i + k]; acc[k] = 0; }
-    for (long long j = n_coeffs - 1; j >= 0; --j) {
-        u64 t[L];
-        fe_mul<L>(acc, x, t);
-#pragma unroll
-        for (int k = 0; k < L; ++k) acc[k] = k < CL ? gl::add(t[k], c[CL * j + k]) : t[k];
-    }
-    u64* o = out + ((long long)blockIdx.y * out_stride + i) * L;  // out_stride: the points of the whole call (a launch may be a slab of them)
-#pragma unroll
-    for (int k = 0; k < L; ++k) o[k] = acc[k];
-}
-
-// Workgroup per (point, polynomial): thread t runs Horner in X = x^256 over coefficients t, t + 256, ... (coalesced
-// reads), scales by x^t, and the 256 partial values are summed through LDS:
-//   f(x) = sum_t x^t * sum_j c[t + 256 j] X^j.   grid = (m, batch).
-template <int L, int CL = L>
-__global__ void __launch_bounds__(256) batch_evaluate_split_kernel(const u64* coeffs, long long n_coeffs, long long poly_stride,
-                                                                  const u64* points, long long n_points, u64* out, long long out_stride) {
-    __shared__ u64 part[256 * L];
-    const int t = threadIdx.x;
-    const long long i = blockIdx.x;
-    const u64* c = coeffs + (long long)blockIdx.y * poly_stride;
-    u64 x[L], X[L], acc[L], pw[L], sq[L], tmp[L];
-#pragma unroll
-    for (int k = 0; k < L; ++k) { x[k] = points[L * i + k]; X[k] = x[k]; sq[k] = x[k]; acc[k] = 0; pw[k] = k ? 0 : gl::ONE; }
-#pragma unroll 1
-    for (int b = 0; b < 8; ++b) {  // X = x^256 and pw = x^t by square-and-multiply on the bits of t
-        if ((t >> b) & 1) {
-            fe_mul<L>(pw, sq, tmp);
-#pragma unroll
-            for (int k = 0; k < L; ++k) pw[k] = tmp[k];
-        }
-        fe_mul<L>(sq, sq, tmp);
-#pragma unroll
-        for (int k = 0; k < L; ++k) sq[k] = tmp[k];
-    }
-#pragma unroll
-    for (int k = 0; k < L; ++k) X[k] = sq[k];
-    if (t < n_coeffs) {
-        for (long long j = (n_coeffs - 1 - t) >> 8; j >= 0; --j) {
-            fe_mul<L>(acc, X, tmp);
-            const u64* cj = c + (t + (j << 8)) * CL;
-#pragma unroll
-            for (int k = 0; k < L; ++k) acc[k] = k < CL ? gl::add(tmp[k], cj[k]) : tmp[k];
-        }
-        fe_mul<L>(acc, pw, tmp);
-#pragma unroll
-        for (int k = 0; k < L; ++k) acc[k] = tmp[k];
-    }
-#pragma unroll
-    for (int k = 0; k < L; ++k) part[t * L + k] = acc[k];
-    __syncthreads();
-#pragma unroll 1
-    for (int h = 128; h > 0; h >>= 1) {
-        if (t < h) {
-#pragma unroll
-            for (int k = 0; k < L; ++k) part[t * L + k] = gl::add(part[t * L + k], part[(t + h) * L + k]);
-        }
-        __syncthreads();
-    }
-    if (t < L) out[((long long)blockIdx.y * out_stride + i) * L + t] = part[t];
-}
-
-// out[0] = shader cycles, out[1] = wall-clock ticks spent in a fixed spin (tf_debug_sclk_mhz)
-__global__ void sclk_probe_kernel(unsigned long long* out) {
-    const unsigned long long w0 = wall_clock64(), c0 = clock64();
-    unsigned v = threadIdx.x;
-    for (int i = 0; i < 200000; ++i) v = v * 1664525u + 1013904223u;
-    const unsigned long long c1 = clock64(), w1 = wall_clock64();
-    if (threadIdx.x == 0) {
-        out[0] = c1 - c0 + (v == 0xdeadbeefu);
-        out[1] = w1 - w0;
-    }
-}
-
-// Synthetic inputs for benches and tests: element i = BFieldElement::new(splitmix64(seed ^ i) mod p), raw
-// Montgomery word -- counter-based, so any slice can be regenerated; the oracle's tfo_fill_random is the same sequence.
-__global__ void __launch_bounds__(256) fill_random_kernel(u64* out, unsigned long long count, u64 seed, unsigned long long first) {
-    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
-    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
-        u64 z = (seed ^ (first + i)) + 0x9e3779b97f4a7c15ULL;
-        z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL;
-        z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL;
-        z ^= z >> 31;
-        if (z >= gl::P) z -= gl::P;          // z mod p (z < 2^64 < 2p)
-        out[i] = gl::mont_mul(z, gl::R2);    // BFieldElement::new (b_field_element.rs:235-237)
-    }
-}
-
-// out[k] = nodes[idx[k]] for digests (5 words): authentication structures from a device-resident tree
-__global__ void __launch_bounds__(256) gather_digests_kernel(const u64* nodes, const unsigned long long* idx, long long count, u64* out) {
-    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= count * 5) return;
-    const long long k = i / 5, w = i - 5 * k;
-    out[i] = nodes[idx[k] * 5 + w];
 }
 
 }  // namespace tfk

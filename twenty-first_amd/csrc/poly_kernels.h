@@ -17,9 +17,161 @@
 // The kernels in this file are the glue between those batched products; field elements are L words (1 BFE, 3 XFE).
 #pragma once
 
-#include "ntt_kernels.h"
+#include "gl64.h"
 
 namespace tfk {
+
+using gl::u32;
+using gl::u64;
+
+// ---- pointwise products (Hadamard) ---------------------------------------------------------------
+// out[i] = a[i] * b[i] over BFieldElement (b_field_element.rs:755-762)
+__global__ void __launch_bounds__(256) hadamard_bfe_kernel(const u64* a, const u64* b, u64* out, long long count) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    // two elements per lane and access (16-byte loads/stores) when the three arrays are 16-byte aligned
+    if ((((unsigned long long)a | (unsigned long long)b | (unsigned long long)out) & 15) == 0) {
+        typedef unsigned long long ull2 __attribute__((ext_vector_type(2)));
+        const long long pairs = count >> 1;
+        const ull2* a2 = reinterpret_cast<const ull2*>(a);
+        const ull2* b2 = reinterpret_cast<const ull2*>(b);
+        ull2* o2 = reinterpret_cast<ull2*>(out);
+        for (long long k = i; k < pairs; k += stride) {
+            const ull2 x = a2[k], y = b2[k];
+            u64 r0, r1;
+            gl::mont_mul2(x.x, y.x, x.y, y.y, r0, r1);
+            ull2 r;
+            r.x = r0;
+            r.y = r1;
+            o2[k] = r;
+        }
+        if ((count & 1) && i == 0) out[count - 1] = gl::mont_mul(a[count - 1], b[count - 1]);
+        return;
+    }
+    for (; i < count; i += stride) out[i] = gl::mont_mul(a[i], b[i]);
+}
+
+// out[i] = a[i] * b[i] over XFieldElement = F_p[x]/(x^3 - x + 1)  (x_field_element.rs:512-536):
+// with self = [c, b, a], other = [f, e, d]:  r0 = cf - ae - bd;  r1 = bf + ce - ad + ae + bd;  r2 = af + be + cd + ad
+__global__ void __launch_bounds__(256) hadamard_xfe_kernel(const u64* pa, const u64* pb, u64* out, long long count) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (; i < count; i += stride) {
+        const u64 c = pa[3 * i], b = pa[3 * i + 1], a = pa[3 * i + 2];
+        const u64 f = pb[3 * i], e = pb[3 * i + 1], d = pb[3 * i + 2];
+        const u64 ae = gl::mont_mul(a, e), bd = gl::mont_mul(b, d), ad = gl::mont_mul(a, d);
+        const u64 r0 = gl::sub(gl::sub(gl::mont_mul(c, f), ae), bd);
+        const u64 r1 = gl::add(gl::add(gl::sub(gl::add(gl::mont_mul(b, f), gl::mont_mul(c, e)), ad), ae), bd);
+        const u64 r2 = gl::add(gl::add(gl::add(gl::mont_mul(a, f), gl::mont_mul(b, e)), gl::mont_mul(c, d)), ad);
+        out[3 * i] = r0;
+        out[3 * i + 1] = r1;
+        out[3 * i + 2] = r2;
+    }
+}
+
+// dst[b][0..n_dst) = src[b][0..min(n_src, n_dst)) then zeros (resize(order, ZERO), polynomial.rs:913-914); words, not elements
+__global__ void __launch_bounds__(256) pad_copy_kernel(const u64* src, u64* dst, long long n_src, long long n_dst, long long batch,
+                                                       long long src_stride) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (; i < n_dst * batch; i += stride) {
+        const long long b = i / n_dst, j = i - b * n_dst;
+        dst[i] = j < n_src ? src[b * src_stride + j] : 0;
+    }
+}
+
+// out[i] = f(points[i]) by Horner's rule, one lane per point (Polynomial::iterative_batch_evaluate,
+// polynomial.rs:1876-1878; same values as batch_evaluate :1840-1852).  The coefficient reads are wave-uniform.
+__device__ __forceinline__ void xfe_mul(const u64 (&s)[3], const u64 (&o)[3], u64 (&r)[3]) {
+    // x_field_element.rs:512-536 with self = [c, b, a], other = [f, e, d]
+    const u64 c = s[0], b = s[1], a = s[2], f = o[0], e = o[1], d = o[2];
+    const u64 ae = gl::mont_mul(a, e), bd = gl::mont_mul(b, d), ad = gl::mont_mul(a, d);
+    r[0] = gl::sub(gl::sub(gl::mont_mul(c, f), ae), bd);
+    r[1] = gl::add(gl::add(gl::sub(gl::add(gl::mont_mul(b, f), gl::mont_mul(c, e)), ad), ae), bd);
+    r[2] = gl::add(gl::add(gl::add(gl::mont_mul(a, f), gl::mont_mul(b, e)), gl::mont_mul(c, d)), ad);
+}
+
+// Field element of width L (1: BFieldElement, 3: XFieldElement) for the evaluation kernels.
+template <int L>
+__device__ __forceinline__ void fe_mul(const u64 (&a)[L], const u64 (&b)[L], u64 (&r)[L]) {
+    if constexpr (L == 1) r[0] = gl::mont_mul(a[0], b[0]);
+    else xfe_mul(a, b, r);
+}
+
+// Lane per point: the right shape for short polynomials at many points.  grid = (ceil(m / 256), batch).
+// CL = words per COEFFICIENT (L: same field as the points; 1 with L = 3: Polynomial<BFieldElement>::evaluate::<XFieldElement, _>,
+// polynomial.rs:309-320 -- the base-field coefficient is added to limb 0 of the extension-field accumulator).
+template <int L, int CL = L>
+__global__ void __launch_bounds__(256) batch_evaluate_kernel(const u64* coeffs, long long n_coeffs, long long poly_stride,
+                                                            const u64* points, long long n_points, u64* out, long long out_stride) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_points) return;
+    const u64* c = coeffs + (long long)blockIdx.y * poly_stride;
+    u64 x[L], acc[L];
+#pragma unroll
+    for (int k = 0; k < L; ++k) { x[k] = points[L * i + k]; acc[k] = 0; }
+    for (long long j = n_coeffs - 1; j >= 0; --j) {
+        u64 t[L];
+        fe_mul<L>(acc, x, t);
+#pragma unroll
+        for (int k = 0; k < L; ++k) acc[k] = k < CL ? gl::add(t[k], c[CL * j + k]) : t[k];
+    }
+    u64* o = out + ((long long)blockIdx.y * out_stride + i) * L;  // out_stride: the points of the whole call (a launch may be a slab of them)
+#pragma unroll
+    for (int k = 0; k < L; ++k) o[k] = acc[k];
+}
+
+// Workgroup per (point, polynomial): thread t runs Horner in X = x^256 over coefficients t, t + 256, ... (coalesced
+// reads), scales by x^t, and the 256 partial values are summed through LDS:
+//   f(x) = sum_t x^t * sum_j c[t + 256 j] X^j.   grid = (m, batch).
+template <int L, int CL = L>
+__global__ void __launch_bounds__(256) batch_evaluate_split_kernel(const u64* coeffs, long long n_coeffs, long long poly_stride,
+                                                                  const u64* points, long long n_points, u64* out, long long out_stride) {
+    __shared__ u64 part[256 * L];
+    const int t = threadIdx.x;
+    const long long i = blockIdx.x;
+    const u64* c = coeffs + (long long)blockIdx.y * poly_stride;
+    u64 x[L], X[L], acc[L], pw[L], sq[L], tmp[L];
+#pragma unroll
+    for (int k = 0; k < L; ++k) { x[k] = points[L * i + k]; X[k] = x[k]; sq[k] = x[k]; acc[k] = 0; pw[k] = k ? 0 : gl::ONE; }
+#pragma unroll 1
+    for (int b = 0; b < 8; ++b) {  // X = x^256 and pw = x^t by square-and-multiply on the bits of t
+        if ((t >> b) & 1) {
+            fe_mul<L>(pw, sq, tmp);
+#pragma unroll
+            for (int k = 0; k < L; ++k) pw[k] = tmp[k];
+        }
+        fe_mul<L>(sq, sq, tmp);
+#pragma unroll
+        for (int k = 0; k < L; ++k) sq[k] = tmp[k];
+    }
+#pragma unroll
+    for (int k = 0; k < L; ++k) X[k] = sq[k];
+    if (t < n_coeffs) {
+        for (long long j = (n_coeffs - 1 - t) >> 8; j >= 0; --j) {
+            fe_mul<L>(acc, X, tmp);
+            const u64* cj = c + (t + (j << 8)) * CL;
+#pragma unroll
+            for (int k = 0; k < L; ++k) acc[k] = k < CL ? gl::add(tmp[k], cj[k]) : tmp[k];
+        }
+        fe_mul<L>(acc, pw, tmp);
+#pragma unroll
+        for (int k = 0; k < L; ++k) acc[k] = tmp[k];
+    }
+#pragma unroll
+    for (int k = 0; k < L; ++k) part[t * L + k] = acc[k];
+    __syncthreads();
+#pragma unroll 1
+    for (int h = 128; h > 0; h >>= 1) {
+        if (t < h) {
+#pragma unroll
+            for (int k = 0; k < L; ++k) part[t * L + k] = gl::add(part[t * L + k], part[(t + h) * L + k]);
+        }
+        __syncthreads();
+    }
+    if (t < L) out[((long long)blockIdx.y * out_stride + i) * L + t] = part[t];
+}
+
 
 template <int L>
 __device__ __forceinline__ void fe_add(const u64 (&a)[L], const u64 (&b)[L], u64 (&r)[L]) {

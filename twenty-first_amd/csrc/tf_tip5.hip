@@ -1,0 +1,341 @@
+// tf_tip5.hip -- Tip5 / Merkle launchers of libtf_hip.so (tip5_kernels.h) and the authentication structures.
+#include "tf_internal.h"
+#include "tip5_kernels.h"
+
+namespace tfi {
+
+// ------------------------------------------------------------------------------------ Tip5 constants
+// ROUND_CONSTANTS, tip5/mod.rs:68-149 (canonical values; converted to Montgomery form at upload).
+const u64 kRoundConstants[80] = {
+    13630775303355457758ULL, 16896927574093233874ULL, 10379449653650130495ULL, 1965408364413093495ULL,
+    15232538947090185111ULL, 15892634398091747074ULL, 3989134140024871768ULL,  2851411912127730865ULL,
+    8709136439293758776ULL,  3694858669662939734ULL,  12692440244315327141ULL, 10722316166358076749ULL,
+    12745429320441639448ULL, 17932424223723990421ULL, 7558102534867937463ULL,  15551047435855531404ULL,
+    17532528648579384106ULL, 5216785850422679555ULL,  15418071332095031847ULL, 11921929762955146258ULL,
+    9738718993677019874ULL,  3464580399432997147ULL,  13408434769117164050ULL, 264428218649616431ULL,
+    4436247869008081381ULL,  4063129435850804221ULL,  2865073155741120117ULL,  5749834437609765994ULL,
+    6804196764189408435ULL,  17060469201292988508ULL, 9475383556737206708ULL,  12876344085611465020ULL,
+    13835756199368269249ULL, 1648753455944344172ULL,  9836124473569258483ULL,  12867641597107932229ULL,
+    11254152636692960595ULL, 16550832737139861108ULL, 11861573970480733262ULL, 1256660473588673495ULL,
+    13879506000676455136ULL, 10564103842682358721ULL, 16142842524796397521ULL, 3287098591948630584ULL,
+    685911471061284805ULL,   5285298776918878023ULL,  18310953571768047354ULL, 3142266350630002035ULL,
+    549990724933663297ULL,   4901984846118077401ULL,  11458643033696775769ULL, 8706785264119212710ULL,
+    12521758138015724072ULL, 11877914062416978196ULL, 11333318251134523752ULL, 3933899631278608623ULL,
+    16635128972021157924ULL, 10291337173108950450ULL, 4142107155024199350ULL,  16973934533787743537ULL,
+    11068111539125175221ULL, 17546769694830203606ULL, 5315217744825068993ULL,  4609594252909613081ULL,
+    3350107164315270407ULL,  17715942834299349177ULL, 9600609149219873996ULL,  12894357635820003949ULL,
+    4597649658040514631ULL,  7735563950920491847ULL,  1663379455870887181ULL,  13889298103638829706ULL,
+    7375530351220884434ULL,  3502022433285269151ULL,  9231805330431056952ULL,  9252272755288523725ULL,
+    10014268662326746219ULL, 15565031632950843234ULL, 1209725273521819323ULL,  6024642864597845108ULL,
+};
+
+
+int ensure_tip5(DeviceCtx* ctx) {
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (ctx->tip5_ready) return TF_OK;
+    tfk::Tip5Consts c;
+    for (int i = 0; i < 80; ++i) c.rc[i] = gl::to_mont(kRoundConstants[i]);
+    unsigned char lut[256];
+    for (int x = 0; x < 256; ++x) {  // L(x) = ((x+1)^3 mod 257) - 1, tip5/mod.rs:1022-1026 (table :50-64)
+        u64 xx = u64(x) + 1;
+        lut[x] = (unsigned char)(((xx * xx * xx) + 256) % 257);
+    }
+    memcpy(c.lut, lut, 256);
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(tfk::g_tip5), &c, sizeof(c)));
+    HIPCHK(hipDeviceSynchronize());
+    ctx->tip5_ready = true;
+    return TF_OK;
+}
+
+
+// ------------------------------------------------------------------------------------ Tip5 / Merkle
+// Launches of at most this many permutation chains use the 16-lanes-per-permutation kernels (measured crossover: one
+// permutation per lane costs ~19 us however few there are; 2^15 items x 16 lanes = 2 waves per SIMD)
+constexpr long long kCoopMaxCount = 1ll << 15;
+
+int tip5_permute_dev(u64* d_states, size_t count, void* stream) {
+    if (count == 0) return TF_OK;
+    if (!d_states) return TF_ERR_NULL_POINTER;
+    DeviceCtx* ctx = nullptr;
+    int rc = current_ctx(&ctx);
+    if (rc) return rc;
+    rc = ensure_tip5(ctx);
+    if (rc) return rc;
+    if ((long long)count <= kCoopMaxCount) {
+        hipLaunchKernelGGL(tfk::tip5_permute_coop_kernel, dim3((unsigned)((count + 15) / 16)), dim3(256), 0,
+                           static_cast<hipStream_t>(stream), d_states, (long long)count);
+    } else {
+        const long long blocks = ((long long)count + 255) / 256;
+        hipLaunchKernelGGL(tfk::tip5_permute_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                           d_states, (long long)count);
+    }
+    HIPCHK(hipGetLastError());
+    return TF_OK;
+}
+
+int tip5_trace_dev(u64* d_states, u64* d_trace, size_t count, void* stream) {
+    if (count == 0) return TF_OK;
+    if (!d_states || !d_trace) return TF_ERR_NULL_POINTER;
+    DeviceCtx* ctx = nullptr;
+    int rc = current_ctx(&ctx);
+    if (rc) return rc;
+    rc = ensure_tip5(ctx);
+    if (rc) return rc;
+    const long long blocks = ((long long)count + 255) / 256;
+    hipLaunchKernelGGL(tfk::tip5_trace_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), d_states, d_trace,
+                       (long long)count);
+    HIPCHK(hipGetLastError());
+    return TF_OK;
+}
+
+int launch_hash_pairs(const u64* in, u64* out, u64* leaf_copy, long long count, long long per_tree, long long in_ts,
+                      long long out_ts, long long copy_ts, hipStream_t s) {
+    if (count == 0) return TF_OK;
+    if (count <= kCoopMaxCount && !leaf_copy) {
+        // fewer permutations than the GPU has lanes: latency, not throughput, is what this launch costs -> 16 lanes each
+        const long long blocks = (count + 15) / 16;
+        hipLaunchKernelGGL(tfk::tip5_hash_pairs_coop_kernel, dim3((unsigned)blocks), dim3(256), 0, s, in, out, count, per_tree, in_ts,
+                           out_ts);
+        HIPCHK(hipGetLastError());
+        return TF_OK;
+    }
+    const long long blocks = (count + 255) / 256;
+    hipLaunchKernelGGL(tfk::tip5_hash_pairs_kernel, dim3((unsigned)blocks), dim3(256), 0, s, in, out, leaf_copy, count,
+                       per_tree, in_ts, out_ts, copy_ts);
+    HIPCHK(hipGetLastError());
+    return TF_OK;
+}
+
+// hash_varlen of n_rows rows: few rows (or one long input) are latency-bound -> 16 lanes per row
+int launch_hash_varlen_rows(const u64* rows, long long row_len, long long n_rows, u64* out, long long per_tree, long long out_ts,
+                            hipStream_t s) {
+    if (n_rows == 0) return TF_OK;
+    if (n_rows <= kCoopMaxCount) {
+        hipLaunchKernelGGL(tfk::tip5_hash_varlen_rows_coop_kernel, dim3((unsigned)((n_rows + 15) / 16)), dim3(256), 0, s, rows, row_len,
+                           n_rows, out, per_tree, out_ts);
+    } else {
+        hipLaunchKernelGGL(tfk::tip5_hash_varlen_rows_kernel, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, s, rows, row_len,
+                           n_rows, out, per_tree, out_ts);
+    }
+    HIPCHK(hipGetLastError());
+    return TF_OK;
+}
+
+int tip5_hash_pairs_dev(const u64* d_in, u64* d_out, size_t count, void* stream) {
+    if (count == 0) return TF_OK;
+    if (!d_in || !d_out) return TF_ERR_NULL_POINTER;
+    DeviceCtx* ctx = nullptr;
+    int rc = current_ctx(&ctx);
+    if (rc) return rc;
+    rc = ensure_tip5(ctx);
+    if (rc) return rc;
+    return launch_hash_pairs(d_in, d_out, nullptr, (long long)count, (long long)count, 0, 0, 0,
+                             static_cast<hipStream_t>(stream));
+}
+
+int tip5_hash_varlen_rows_dev(const u64* d_rows, size_t row_len, size_t n_rows, u64* d_out, void* stream) {
+    if (n_rows == 0) return TF_OK;
+    if (!d_out || (row_len && !d_rows)) return TF_ERR_NULL_POINTER;
+    DeviceCtx* ctx = nullptr;
+    int rc = current_ctx(&ctx);
+    if (rc) return rc;
+    rc = ensure_tip5(ctx);
+    if (rc) return rc;
+    return launch_hash_varlen_rows(d_rows, (long long)row_len, (long long)n_rows, d_out, (long long)n_rows, 0ll,
+                                   static_cast<hipStream_t>(stream));
+}
+
+int check_leaves(size_t n) {
+    if (n == 0) return TF_ERR_TOO_FEW_LEAFS;                  // merkle_tree.rs:394-396
+    if (n & (n - 1)) return TF_ERR_INCORRECT_NUMBER_OF_LEAFS;  // :398-401
+    return TF_OK;
+}
+
+constexpr long long kTopWidth = 256;  // levels of at most this many nodes finish in one workgroup per tree
+
+// Levels above the leaf level for trees whose leaves are already at nodes[n..2n) (nodes[0] gets zeroed).
+int merkle_levels_in_place(u64* d_nodes, long long N, size_t batch, hipStream_t s) {
+    const long long nodes_ts = 10 * N;
+    long long w = N;
+    while (w > kTopWidth) {  // nodes[w/2 .. w) from nodes[w .. 2w)
+        const long long nw = w / 2;
+        int rc = launch_hash_pairs(d_nodes + 5 * w, d_nodes + 5 * nw, nullptr, nw * (long long)batch, nw, nodes_ts, nodes_ts, 0, s);
+        if (rc) return rc;
+        w = nw;
+    }
+    hipLaunchKernelGGL(tfk::merkle_top_kernel, dim3((unsigned)batch), dim3(1024), 0, s, d_nodes + 5 * w, nodes_ts, (int)w,
+                       d_nodes, nodes_ts, (u64*)nullptr, (const u64*)nullptr, 0ll);
+    HIPCHK(hipGetLastError());
+    return TF_OK;
+}
+
+// hash_varlen of the rows of `batch` column-major tables (one codeword per column): digests to out + t * out_ts + 5 * i
+int launch_hash_table_rows(const u64* table, long long n_rows, long long n_cols, int width, long long col_stride, long long table_stride,
+                           long long batch, u64* out, long long out_ts, hipStream_t s) {
+    const long long total = n_rows * batch;
+    if (total == 0) return TF_OK;
+    if (total <= kCoopMaxCount) {
+        hipLaunchKernelGGL(tfk::tip5_hash_table_rows_coop_kernel, dim3((unsigned)((total + 15) / 16)), dim3(256), 0, s, table, n_rows, n_cols,
+                           width, col_stride, table_stride, total, out, out_ts);
+    } else {
+        hipLaunchKernelGGL(tfk::tip5_hash_table_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, table, n_rows, n_cols,
+                           width, col_stride, table_stride, total, out, out_ts);
+    }
+    HIPCHK(hipGetLastError());
+    return TF_OK;
+}
+
+// Rows of a COLUMN-major table ("hash_varlen over rows of a column-major table, the producer of leaves")
+// -> leaf digests -> Merkle tree.  table: batch x n_cols columns of n_rows elements of `width` words, col_stride words apart.
+int hash_table_rows_dev(const u64* d_table, size_t n_rows, size_t n_cols, int width, size_t col_stride, u64* d_digests, size_t batch,
+                        void* stream) {
+    if (width != 1 && width != 3) return TF_ERR_NULL_POINTER;
+    if (n_rows == 0 || batch == 0) return TF_OK;
+    if (!d_digests || (n_cols && !d_table)) return TF_ERR_NULL_POINTER;
+    if (n_cols * size_t(width) >= (size_t(1) << 31) || col_stride < n_rows * size_t(width)) return TF_ERR_LEN_TOO_LARGE;
+    DeviceCtx* ctx = nullptr;
+    int rc = current_ctx(&ctx);
+    if (rc) return rc;
+    rc = ensure_tip5(ctx);
+    if (rc) return rc;
+    return launch_hash_table_rows(d_table, (long long)n_rows, (long long)n_cols, width, (long long)col_stride,
+                                  (long long)(n_cols * col_stride), (long long)batch, d_digests, 5ll * (long long)n_rows,
+                                  static_cast<hipStream_t>(stream));
+}
+
+int merkle_from_columns_dev(const u64* d_table, size_t n_rows, size_t n_cols, int width, size_t col_stride, u64* d_nodes, size_t batch,
+                            void* stream) {
+    if (width != 1 && width != 3) return TF_ERR_NULL_POINTER;
+    int rc = check_leaves(n_rows);
+    if (rc) return rc;
+    if (batch == 0) return TF_OK;
+    if (!d_nodes || (n_cols && !d_table)) return TF_ERR_NULL_POINTER;
+    if (n_cols * size_t(width) >= (size_t(1) << 31) || col_stride < n_rows * size_t(width)) return TF_ERR_LEN_TOO_LARGE;
+    DeviceCtx* ctx = nullptr;
+    rc = current_ctx(&ctx);
+    if (rc) return rc;
+    rc = ensure_tip5(ctx);
+    if (rc) return rc;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const long long N = (long long)n_rows;
+    rc = launch_hash_table_rows(d_table, N, (long long)n_cols, width, (long long)col_stride, (long long)(n_cols * col_stride),
+                                (long long)batch, d_nodes + 5 * N, 10 * N, s);
+    if (rc) return rc;
+    return merkle_levels_in_place(d_nodes, N, batch, s);
+}
+
+// Rows of a row-major table -> leaf digests (hash_varlen per row, tip5/mod.rs:617-623) -> Merkle tree, without the
+// leaves ever leaving HBM.  rows: batch x n_rows x row_len words.
+int merkle_from_rows_dev(const u64* d_rows, size_t row_len, size_t n_rows, u64* d_nodes, size_t batch, void* stream) {
+    int rc = check_leaves(n_rows);
+    if (rc) return rc;
+    if (batch == 0) return TF_OK;
+    if (!d_nodes || (row_len && !d_rows)) return TF_ERR_NULL_POINTER;
+    DeviceCtx* ctx = nullptr;
+    rc = current_ctx(&ctx);
+    if (rc) return rc;
+    rc = ensure_tip5(ctx);
+    if (rc) return rc;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const long long N = (long long)n_rows, total = N * (long long)batch;
+    rc = launch_hash_varlen_rows(d_rows, (long long)row_len, total, d_nodes + 5 * N, N, 10 * N, s);
+    if (rc) return rc;
+    return merkle_levels_in_place(d_nodes, N, batch, s);
+}
+
+// nodes layout per tree: 2n digests (merkle_tree.rs:85-88, :393-429).
+int merkle_build_dev(const u64* d_leaves, size_t n, u64* d_nodes, size_t batch, void* stream) {
+    int rc = check_leaves(n);
+    if (rc) return rc;
+    if (batch == 0) return TF_OK;
+    if (!d_leaves || !d_nodes) return TF_ERR_NULL_POINTER;
+    DeviceCtx* ctx = nullptr;
+    rc = current_ctx(&ctx);
+    if (rc) return rc;
+    rc = ensure_tip5(ctx);
+    if (rc) return rc;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const long long N = (long long)n, nodes_ts = 10 * N, leaves_ts = 5 * N;
+    if (N <= kTopWidth) {
+        hipLaunchKernelGGL(tfk::merkle_top_kernel, dim3((unsigned)batch), dim3(1024), 0, s, d_leaves, leaves_ts, (int)N,
+                           d_nodes, nodes_ts, (u64*)nullptr, d_leaves, leaves_ts);
+        HIPCHK(hipGetLastError());
+        return TF_OK;
+    }
+    // first level: read leaves, write the leaf copy nodes[n..2n) and the parents nodes[n/2..n)
+    long long w = N / 2;
+    rc = launch_hash_pairs(d_leaves, d_nodes + 5 * w, d_nodes + 5 * N, w * (long long)batch, w, leaves_ts, nodes_ts,
+                           nodes_ts, s);
+    if (rc) return rc;
+    while (w > kTopWidth) {  // nodes[w/2 .. w) from nodes[w .. 2w)
+        const long long nw = w / 2;
+        rc = launch_hash_pairs(d_nodes + 5 * w, d_nodes + 5 * nw, nullptr, nw * (long long)batch, nw, nodes_ts, nodes_ts, 0,
+                               s);
+        if (rc) return rc;
+        w = nw;
+    }
+    hipLaunchKernelGGL(tfk::merkle_top_kernel, dim3((unsigned)batch), dim3(1024), 0, s, d_nodes + 5 * w, nodes_ts, (int)w,
+                       d_nodes, nodes_ts, (u64*)nullptr, (const u64*)nullptr, 0ll);
+    HIPCHK(hipGetLastError());
+    return TF_OK;
+}
+
+int merkle_root_dev(const u64* d_leaves, size_t n, u64* d_root, size_t batch, void* stream) {
+    int rc = check_leaves(n);
+    if (rc) return rc;
+    if (batch == 0) return TF_OK;
+    if (!d_leaves || !d_root) return TF_ERR_NULL_POINTER;
+    DeviceCtx* ctx = nullptr;
+    rc = current_ctx(&ctx);
+    if (rc) return rc;
+    rc = ensure_tip5(ctx);
+    if (rc) return rc;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const long long N = (long long)n, leaves_ts = 5 * N;
+    if (N <= kTopWidth) {
+        hipLaunchKernelGGL(tfk::merkle_top_kernel, dim3((unsigned)batch), dim3(1024), 0, s, d_leaves, leaves_ts, (int)N,
+                           (u64*)nullptr, 0ll, d_root, (const u64*)nullptr, 0ll);
+        HIPCHK(hipGetLastError());
+        return TF_OK;
+    }
+    // ping-pong level buffers: n/2 + n/4 digests per tree
+    u64* buf = nullptr;
+    const size_t words = size_t(batch) * size_t(5) * size_t(N / 2 + N / 4);
+    hipError_t e = pool_malloc_async(reinterpret_cast<void**>(&buf), words * sizeof(u64), s);
+    if (e != hipSuccess) {
+        hip_fail(e, "pool_malloc_async(merkle levels)", __FILE__, __LINE__);
+        return TF_ERR_TREE_TOO_HIGH;
+    }
+    u64* a = buf;
+    u64* b = buf + size_t(batch) * 5 * size_t(N / 2);
+    long long w = N / 2;
+    rc = launch_hash_pairs(d_leaves, a, nullptr, w * (long long)batch, w, leaves_ts, 5 * w, 0, s);
+    while (rc == TF_OK && w > kTopWidth) {
+        const long long nw = w / 2;
+        rc = launch_hash_pairs(a, b, nullptr, nw * (long long)batch, nw, 5 * w, 5 * nw, 0, s);
+        std::swap(a, b);
+        w = nw;
+    }
+    if (rc == TF_OK) {
+        hipLaunchKernelGGL(tfk::merkle_top_kernel, dim3((unsigned)batch), dim3(1024), 0, s, a, 5 * w, (int)w, (u64*)nullptr,
+                           0ll, d_root, (const u64*)nullptr, 0ll);
+        hipError_t le = hipGetLastError();
+        if (le != hipSuccess) rc = hip_fail(le, "merkle_top_kernel", __FILE__, __LINE__);
+    }
+    e = hipFreeAsync(buf, s);
+    if (rc) return rc;
+    if (e != hipSuccess) return hip_fail(e, "hipFreeAsync", __FILE__, __LINE__);
+    return TF_OK;
+}
+
+
+// out[k] = nodes[idx[k]]: the digests of an authentication structure from a device-resident tree
+int gather_digests_dev(const u64* d_nodes, const unsigned long long* d_idx, size_t count, u64* d_out, hipStream_t s) {
+    if (count == 0) return TF_OK;
+    const long long total = (long long)count * 5;
+    hipLaunchKernelGGL(tfk::gather_digests_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, d_nodes, d_idx, (long long)count, d_out);
+    HIPCHK(hipGetLastError());
+    return TF_OK;
+}
+
+}  // namespace tfi

@@ -406,4 +406,12 @@ __global__ void __launch_bounds__(1024) merkle_top_kernel(const u64* level_in, l
     if (root_out && t < 5) root_out[tree * 5 + t] = buf[cur][t];
 }
 
+// out[k] = nodes[idx[k]] for digests (5 words): authentication structures from a device-resident tree
+__global__ void __launch_bounds__(256) gather_digests_kernel(const u64* nodes, const unsigned long long* idx, long long count, u64* out) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count * 5) return;
+    const long long k = i / 5, w = i - 5 * k;
+    out[i] = nodes[idx[k] * 5 + w];
+}
+
 }  // namespace tfk

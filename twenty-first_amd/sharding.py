@@ -45,6 +45,39 @@ def gather_roots(local_roots, total_units: int):
     return torch.cat(parts, dim=0)
 
 
+def roots_digest(all_roots, hash_varlen):
+    """One digest for the whole job: Tip5 hash_varlen (tip5/mod.rs:640-660) over the gathered roots in batch order, 5 words per
+    unit.  The roots of a job do not depend on how it was split, so this digest must be the same for every world size (bench.py
+    prints it as `roots_digest`; 1 / 2 / 4 / 8 GPUs must agree).  `hash_varlen(flat_int64_tensor) -> (5,) int64 tensor` is the
+    HIP path on the GPU node (tf.device.tip5_hash_varlen_rows on one row) and the oracle in the CPU test."""
+    return hash_varlen(all_roots.reshape(-1).contiguous()).reshape(5)
+
+
+def identical_on_all_ranks(t) -> bool:
+    """True when every rank holds the same tensor `t` (all_gather + compare; a few words: bandwidth-irrelevant)."""
+    import torch
+    import torch.distributed as dist
+
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return True
+    t = t.contiguous()
+    parts = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(parts, t)
+    return all(bool(torch.equal(parts[0], q)) for q in parts[1:])
+
+
+def all_ranks_true(flag: bool, device=None) -> bool:
+    """Logical AND of a per-rank verdict over the ranks (MIN all-reduce)."""
+    import torch
+    import torch.distributed as dist
+
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return bool(flag)
+    t = torch.tensor([1 if flag else 0], dtype=torch.int64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(int(t.item()))
+
+
 def sharded_tree(local_leaves, build_subtree, finish_top):
     """ONE Merkle tree across the ranks, by the reference's own subtree split (MerkleTree::par_new hands the num_threads
     subtrees below the top log2(num_threads) layers to one worker each, util_types/merkle_tree.rs:165-212, :247-275): rank g of G
