@@ -1508,12 +1508,15 @@ int coset_eval_dev(const u64* d_coeffs, size_t n_coeffs, u64 offset_raw, u64* d_
     size_t len = 1;
     while (len < n_coeffs) len <<= 1;
     static const bool no_split = ab_env("TF_COSET_EVAL_NO_SPLIT") != nullptr;  // A/B switch
-    // Passes of the PLAIN plan for this call: orders 2^21 / 2^22 run in two (PRE2) whenever run_ntt will plan them so -- a large
-    // enough call (512-thread tiles) within the buffer window -- and then the split saves no pass (the comparison used
-    // pass_count alone and sent the 2^20 -> 2^21 / 2^22 shapes down the multi-coset route, which cannot use PRE2).
-    static const bool old_rule = ab_env("TF_COSET_EVAL_OLD_SPLIT_RULE") != nullptr;  // A/B switch: the round-3 comparison
+    // ADVICE r3 asked whether the comparison should use the EFFECTIVE pass count of the plain plan (orders 2^21 / 2^22 run in two
+    // passes under PRE2, so the split then saves no pass).  Built and measured (profiles/r04_lde_split_rule.txt, 2^28 words per
+    // call): the split still wins where it matters -- BFE 2^20 -> 2^22 2.05 vs 2.48 ms, 2^19 -> 2^22 2.03 vs 2.40, 2^20 -> 2^21
+    // 2.07 vs 2.17; XFE 2^20 -> 2^22 1.01 vs 1.13 -- because its first pass reads n_coeffs rows instead of `order` and none of its
+    // passes pays the PRE2 pair's second read and second scaling; only XFE 2^18 / 2^19 -> 2^21 is 3 % faster on the plain plan.
+    // The round-3 rule (nominal pass counts) therefore stays; the other one is a laboratory switch.
+    static const bool effective_rule = ab_env("TF_COSET_EVAL_EFFECTIVE_PASSES") != nullptr;
     int plain_passes = pass_count(ilog2(order));
-    if (!old_rule && !small_launch_for(order, 1, batch, L, -1)) {
+    if (effective_rule && !small_launch_for(order, 1, batch, L, -1)) {
         // (wg_threads() is 512 outside a small-launch scope, which is the geometry the big call will be planned with)
         if (pre2_plan_ok(ilog2(order), L, order, 1, false, -1, false, true, false)) plain_passes = 2;
     }
