@@ -114,3 +114,60 @@ def test_single_tree_sharded_over_two_ranks_by_subtrees(tmp_path):
         where = global_node(idx, n_leaves, world)
         got = tops[0][where[1]] if where[0] == "top" else subs[where[1]][where[2]]
         assert np.array_equal(got, want[idx]), (idx, where)
+
+
+def _job_worker(rank, world, port, total_trees, n_leaves, out_path):
+    """The config-5 job of bench.py with the oracle as per-rank compute: shard the trees, build, gather the roots, digest them, and
+    run the cross-rank checks bench.py runs (identical_on_all_ranks, all_ranks_true)."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+
+    from oracle import tfo
+    from twenty_first_amd import sharding
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = sharding.shard_range(total_trees, world, rank)
+    seed = 0x7F210005 ^ (1 << 40)
+    roots = []
+    for tree in range(lo, hi):  # tree u of the job = leaves [u 5 nl, (u + 1) 5 nl) of ONE counter-based sequence (bench.py's layout)
+        leaves = tfo.fill_random(5 * n_leaves, seed, first_index=tree * 5 * n_leaves)
+        roots.append(tfo.merkle_build(leaves)[5:10].view(np.int64))
+    local = torch.from_numpy(np.stack(roots)) if roots else torch.zeros((0, 5), dtype=torch.int64)
+    all_roots = sharding.gather_roots(local, total_trees)
+
+    def hash_varlen(flat):  # the oracle stands in for tf.device.tip5_hash_varlen_rows
+        return torch.from_numpy(tfo.hash_varlen(flat.numpy().view(np.uint64)).view(np.int64).copy())
+
+    digest = sharding.roots_digest(all_roots, hash_varlen)
+    same = sharding.identical_on_all_ranks(all_roots) and sharding.identical_on_all_ranks(digest)
+    # a deliberately rank-dependent tensor must be reported as different, a mismatch on ONE rank must reach every rank
+    differs = not sharding.identical_on_all_ranks(torch.tensor([rank], dtype=torch.int64)) if world > 1 else True
+    verdict = sharding.all_ranks_true(rank != world - 1 or world == 1)
+    np.save(f"{out_path}_{rank}.npy", np.concatenate([digest.numpy().reshape(5), np.array([int(same), int(differs), int(verdict)], dtype=np.int64)]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_roots_digest_is_the_same_for_one_and_two_ranks(tmp_path):
+    """bench.py --config 5 prints `roots_digest` (Tip5 hash_varlen of the gathered roots) and requires it identical at 1 / 2 / 4 / 8
+    GPUs: here the same job at world sizes 1 and 2 over gloo with the oracle as compute, against the digest computed serially."""
+    import torch.multiprocessing as mp
+
+    from oracle import tfo
+
+    total_trees, n_leaves = 7, 32
+    seed = 0x7F210005 ^ (1 << 40)
+    serial = np.concatenate([tfo.merkle_build(tfo.fill_random(5 * n_leaves, seed, first_index=t * 5 * n_leaves))[5:10] for t in range(total_trees)])
+    want = tfo.hash_varlen(serial)
+    for world in (1, 2):
+        port = _free_port()
+        out = str(tmp_path / f"job{world}")
+        mp.spawn(_job_worker, args=(world, port, total_trees, n_leaves, out), nprocs=world, join=True)
+        for r in range(world):
+            got = np.load(f"{out}_{r}.npy")
+            assert np.array_equal(got[:5].view(np.uint64), want), (world, r)
+            assert got[5] == 1 and got[6] == 1, (world, r)          # gathered roots identical everywhere; a differing tensor is detected
+            assert got[7] == (1 if world == 1 else 0), (world, r)   # one rank's mismatch reaches every rank

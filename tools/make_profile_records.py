@@ -7,6 +7,10 @@ import collections, csv, glob, json, os, sys
 src, tag = sys.argv[1], sys.argv[2]
 root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 summ = json.load(open(os.path.join(src, "summary.json")))
+try:
+    library = json.load(open(os.path.join(src, "library.json")))  # the build these counters were taken on (tf_source_hash)
+except Exception:
+    library = None
 ntt, clocks, per, tot, n = 0.0, [], {}, 0.0, 0
 for k, e in summ["kernels"].items():
     if "ntt_pass_kernel" in k and e.get("duration", {}).get("grid") == 8388608:  # the 256 x 2^20 BFE dispatches
@@ -26,7 +30,11 @@ for f in glob.glob(os.path.join(src, "pmc_sq/**/*counter_collection.csv"), recur
             mer[r["Kernel_Name"]] += float(r["Counter_Value"])
             if "merkle_top_kernel" in r["Kernel_Name"]:
                 trees += 1
-rec = {"source": f"rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_VALU ... (tools/prof_r02.sh {tag} -> profiles/{tag}_rocprof_summary.json): SQ_INSTS_VALU summed over the dispatches of one step / one tree",
+# configs[3]: the two PRE2 pass kernels of the 64 x 2^22 XFE coset evaluation (SCALE 1 column pass, LAST1024 pass)
+coset_busy = [e["derived"]["valu_busy_frac_at_4_cycles"] for k, e in summ["kernels"].items()
+              if "ntt_pass_kernel" in k and k.rstrip(">").endswith("true") and "valu_busy_frac_at_4_cycles" in e.get("derived", {})
+              and (k.startswith("ntt_pass_kernel<false, 1, 0, false, true, false, true") or k.startswith("ntt_pass_kernel<false, 0, 0, true, false, false, true"))]
+rec = {"library": library, "coset_eval_valu_busy_frac_at_4_cycles": coset_busy or None, "source": f"rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_VALU ... (tools/prof_r02.sh {tag} -> profiles/{tag}_rocprof_summary.json): SQ_INSTS_VALU summed over the dispatches of one step / one tree",
        "ntt_valu_wave_instr_per_transform_2p20": ntt / 256, "ntt_valu_instr_per_element": ntt * 64 / 2 ** 28,
        "ntt_clock_under_load_mhz": round(sum(clocks) / len(clocks), 1) if clocks else None,
        "valu_peak_note": "peak = 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction = 614.4 G wave-instr/s: every instruction of these kernels is of the 4-cycle class (carry adds, v_mad_u64_u32, VOP3; profiles/r03_instr_rates.txt).  SQ_ACTIVE_INST_VALU counts quad-cycles, so its ratio to SQ_INSTS_VALU is the counter's granularity, not a cost"}
@@ -44,7 +52,7 @@ else:  # NTT-only profile: keep the Merkle figures of the last record
         if k in old:
             rec[k] = old[k]
 json.dump(rec, open(os.path.join(root, "profiles", "valu_counts.json"), "w"), indent=1)
-json.dump({"log_n": 20, "batch": 256, "launches_per_step": 2,
+json.dump({"library": library, "log_n": 20, "batch": 256, "launches_per_step": 2,
            "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes (tools/prof_r02.sh {tag} -> profiles/{tag}_rocprof_summary.json), tools/prof_target.py: every dispatch is a full-size one",
            "per_kernel": per,
            "correction": "FETCH_SIZE doubled: on gfx950 it tallies the 128-byte requests of a fully coalesced stream at 64 B (MI355X_MICROARCH.md, HBM section); WRITE_SIZE taken as is (it equals the 2^31 bytes each pass must write)",

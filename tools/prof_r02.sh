@@ -11,6 +11,7 @@ REPO=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
+export TF_PROF_IDENTITY=$OUT/library.json   # tools/prof_target.py writes the library's tf_version + source hash here
 CMD="python $REPO/tools/prof_target.py $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o t -- $CMD > "$OUT/stats.log" 2>&1
 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --output-format csv -d "$OUT/pmc_sq" -o t -- $CMD > "$OUT/pmc_sq.log" 2>&1

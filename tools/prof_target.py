@@ -29,6 +29,11 @@ def main():
     if a.pipe:
         tf.lib().tf_set_ntt_pipe(a.pipe)
     dev = torch.device("cuda", 0)
+    ident_path = os.environ.get("TF_PROF_IDENTITY")  # tools/prof_r02.sh: which library these counters belong to
+    if ident_path:
+        import json
+
+        json.dump({"tf_version": int(tf.lib().tf_version()), "source_hash": tf.lib().tf_source_hash().decode()}, open(ident_path, "w"))
     if a.ntt:
         n, batch = 1 << 20, 256
         x = torch.empty(n * batch, dtype=torch.int64, device=dev)

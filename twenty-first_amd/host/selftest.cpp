@@ -70,6 +70,10 @@ static void multi_device_check(const std::vector<int>& devs) {
         EXPECT(res[i].rc == 0);
         EXPECT(res[i].ntt == ref.ntt);
         EXPECT(res[i].nodes == ref.nodes);
+        // one line of evidence per host thread / device, so that the first multi-GPU box leaves a record (README.md, "8 GPUs")
+        const bool ok = res[i].rc == 0 && res[i].ntt == ref.ntt && res[i].nodes == ref.nodes;
+        printf("  host thread %zu on device %d: %s (tf_ntt_bfe_dev 8 x 2^16 x3, tf_merkle_build_dev 2^12 leaves; rc %d, root word 0 %016llx)\n", i, devs[i],
+               ok ? "PASS, same words as device 0 alone" : "FAIL", res[i].rc, (unsigned long long)(res[i].nodes.size() > 5 ? res[i].nodes[5] : 0));
     }
     (void)hipSetDevice(devs[0]);
 }
