@@ -21,7 +21,7 @@ struct NttLatArgs {
     u64 ninv;              // Montgomery n^-1 (inverse only)
     int L;
     // ---- the steps of a zerofier-tree walk that used to be kernels of their own, as modifiers of this kernel's load and store
-    // (math/zerofier_tree.rs / polynomial.rs:1882-1894 remaindering; the tree code in tf_hip.hip says which step is which)
+    // (math/zerofier_tree.rs / polynomial.rs:1882-1894 remaindering; the tree code in tf_poly.hip says which step is which)
     int load_mode;         // 0: element idx of slice b is in[b * in_bs + idx * L]
                            // 1: REVERSED: in[(b >> src_shift) * in_bs + (rev_top - idx) * L] for idx < n_coeffs (poly_reverse /
                            //    remainder_rev_high fused into the forward transform that follows them)

@@ -24,7 +24,7 @@
 // XFE slices ([c0,c1,c2] per element, x_field_element.rs:56-59) are three interleaved BFE columns
 // with the same twiddles (ntt.rs:203-207, x_field_element.rs:540-548): L = 3 words per element.
 //
-// Kernels in this file and the lengths they serve (planner: run_ntt in tf_hip.hip):
+// Kernels in this file and the lengths they serve (planner: run_ntt in tf_ntt.hip):
 //   ntt_tiny_kernel    n <= 16                the reference's radix-2 sweeps, one transform per thread
 //   ntt_rows32_kernel  n == 32, BFE           tiles of 512 transforms staged through LDS, one per thread, no exchange
 //   ntt_pass_kernel    32 <= n <= 1024        one pass, rows of T whole transforms per workgroup
@@ -33,8 +33,10 @@
 //                      level; R1024: constant P2) are the two kernels of the 2^20-point headline transform
 //   ntt_block_kernel   2^11 <= n <= 2^14, BFE one workgroup owns a whole transform: radix 32 x 32 x P3 with two LDS
 //                      exchanges, so these lengths cost one HBM pass instead of two
-//   ntt_lat_kernel     64 <= n <= 4096, calls with little work: 8 elements per thread, radix-8 Stockham stages through LDS
+//   (the latency-shaped kernels for calls with little work -- ntt_lat_kernel, ntt_lat2_kernel, the tree level kernels: lat_kernels.h)
 #pragma once
+
+#include <type_traits>
 
 #include "gl64.h"
 #include "ntt_args.h"
@@ -91,6 +93,8 @@ struct NttPassArgs {
     long long pre2_js_off;                   // ... to the output element index (SCALE 2)
     const u64* pre2_cp;                      // SCALE 1: -> offset^(index distance of partner rows), multiplies the partner coefficient
     int pre2_map;                            // 0: not a PRE2 launch; 1: half = bit 3 of the block id (a pair shares an XCD); 2: bit 0
+                                             // (PRE4: the residue class q = bits 3-4 / bits 0-1)
+    const u64* pre4_stw;                     // PRE4 only: [2][32] Montgomery words w_128^(+-q i), q = 1, 3 (the per-slot part of w_4096^(q c))
 };
 
 // ---- buffer addressing for the R = 1024 instantiations --------------------------------------------------------------------
@@ -98,7 +102,7 @@ struct NttPassArgs {
 // forms every address with a 64-bit VALU add (v_lshl_add_u64 / v_mad_u64_u32: ~100 VALU instructions per burst, 7 % of a pass).
 // A buffer instruction adds  resource base (4 SGPRs, per workgroup) + 32-bit per-lane offset (ONE VGPR for all slots) + 32-bit
 // uniform offset (one SGPR per slot)  in the address unit: no VALU work at all.  The planner only selects these instantiations
-// when every slot offset plus thread offset fits 32 bits (fits_buffer_offsets in tf_hip.hip); larger transforms take the
+// when every slot offset plus thread offset fits 32 bits (fits_buffer_offsets in tf_ntt.hip); larger transforms take the
 // generic kernel with plain pointers.
 typedef unsigned int tf_v2u __attribute__((__vector_size__(2 * sizeof(unsigned int))));
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t buf_rsrc(const void* p) {
@@ -220,7 +224,39 @@ __device__ __forceinline__ void pre2_shift(u64 (&x)[32]) {
     if constexpr (Q + 1 < END) pre2_shift<INV, Q + 1, END>(x);
 }
 
-template <bool INV, int SCALE, int MODE = 0, bool LAST1024 = false, bool R1024 = false, bool COL = false, bool PRE2 = false>
+// PRE4 (LAST1024, forward, no scaling): the pass is a 4096-point DFT per row, run as FOUR 1024-point workgroups per tile that share
+//   their input.  One radix-4 decimation-in-frequency stage is fused into the load: with x_m = x[c + 1024 m],
+//     class q:  z_q[c] = w_4096^(q c) * sum_m x_m w_4^(q m)   and the 1024-point DFT of z_q gives the outputs k = 4 k' + q
+//     q = 0: (x_0 + x_2) + (x_1 + x_3)          q = 2: ((x_0 + x_2) - (x_1 + x_3)) w_64^i
+//     q = 1: ((x_0 - x_2) + w_4 (x_1 - x_3)) w_128^i        q = 3: ((x_0 - x_2) - w_4 (x_1 - x_3)) w_128^(3 i)
+//   where c = g + 32 i: w_4 and w_64^i are powers of two (shifts); w_128^(q i) is one Montgomery product per element for the odd
+//   classes, its 32 words uniform per register slot (A.pre4_stw, scalar loads); w_4096^(q g) rides on the inner twiddle (inner_tw
+//   holds the four tables, [4][32][32]).  This is the last pass of the 2^22-point plan 1024 x 4096 that fast_coset_evaluate takes:
+//   its FIRST pass (where every coefficient is scaled by offset^j) is then an ordinary 1024-point column pass -- the 2048 x 2048
+//   plan scales every coefficient twice there, once per half of a PRE2 pair.
+// slots Q0 .. Q0+3 from their four quarter-row words; cls = q (uniform)
+template <bool INV, int Q0, int I = 0>
+__device__ __forceinline__ void pre4_combine4(u64 (&x)[32], const u64 (&v0)[4], const u64 (&v1)[4], const u64 (&v2)[4], const u64 (&v3)[4], u32 cls) {
+    constexpr int Q = Q0 + I;
+    if ((cls & 1u) == 0) {
+        const u64 s = gl::add(v0[I], v2[I]), t = gl::add(v1[I], v3[I]);
+        if (cls == 0) {
+            x[Q] = gl::add(s, t);
+        } else {  // (s - t) w_64^i, the sign of the power-of-two product folded into the subtraction
+            const u64 d = Pre2Slot<INV, Q>::neg ? gl::sub(t, s) : gl::sub(s, t);
+            x[Q] = gl::Pow2Mul<Pre2Slot<INV, Q>::E>::apply(d);
+        }
+    } else {
+        constexpr int E4 = TwExp<INV, 2, 1>::value;  // w_4^(+-1)
+        const u64 b = gl::sub(v0[I], v2[I]);
+        const u64 w = gl::Pow2Mul<E4>::apply(gl::sub(v1[I], v3[I]));  // +- w_4 (x_1 - x_3)
+        const bool plus = (cls == 1) != gl::Pow2Mul<E4>::negate;
+        x[Q] = plus ? gl::add(b, w) : gl::sub(b, w);
+    }
+    if constexpr (I + 1 < 4) pre4_combine4<INV, Q0, I + 1>(x, v0, v1, v2, v3, cls);
+}
+
+template <bool INV, int SCALE, int MODE = 0, bool LAST1024 = false, bool R1024 = false, bool COL = false, bool PRE2 = false, bool PRE4 = false>
 #ifndef TF_PRIO_LOAD
 #define TF_PRIO_LOAD 3
 #endif
@@ -248,11 +284,16 @@ __global__ void __launch_bounds__(512, TF_NTT_WAVES) ntt_pass_kernel(const NttPa
     const int L = A.L;
 
     static_assert(!PRE2 || ((LAST1024 || R1024) && MODE == 0 && SCALE != 3), "PRE2 is a variant of the R = 1024 kernels");
-    // PRE2: two workgroups per tile; `half` selects the even (y) or odd (z) outputs
+    static_assert(!PRE4 || (LAST1024 && !PRE2 && !INV && MODE == 0 && SCALE == 0), "PRE4 is a variant of the plain forward R = 1024 last pass");
+    // PRE2: two workgroups per tile; `half` selects the even (y) or odd (z) outputs.  PRE4: four, `half` is the residue class q
     u32 bid = blockIdx.x, half = 0;
     if constexpr (PRE2) {
         if (A.pre2_map == 1) half = (bid >> 3) & 1u, bid = (bid & 7u) | ((bid >> 4) << 3);
         else half = bid & 1u, bid >>= 1;
+    }
+    if constexpr (PRE4) {
+        if (A.pre2_map == 1) half = (bid >> 3) & 3u, bid = (bid & 7u) | ((bid >> 5) << 3);
+        else half = bid & 3u, bid >>= 2;
     }
     u32 i0, i1, i2;
     if (A.xcd_order) {
@@ -304,7 +345,7 @@ __global__ void __launch_bounds__(512, TF_NTT_WAVES) ntt_pass_kernel(const NttPa
         in = A.in + (long long)i0 * A.ib0 + (long long)i1 * A.ib1 + (long long)ch0 * A.in_cs_hi;
         out = A.out + (long long)i0 * A.ob0 + (long long)i1 * A.ob1 + (long long)ch0 * A.out_cs_hi;
     }
-    if constexpr (PRE2) out += (long long)half * A.pre2_out_off;
+    if constexpr (PRE2 || PRE4) out += (long long)half * A.pre2_out_off;
 
     // LAST1024 always runs 512 threads in 16 column slots
     // gfast (single-pass transforms, whose "columns" are whole rows of contiguous elements): lanes along the row, g = t % P2
@@ -379,7 +420,7 @@ __global__ void __launch_bounds__(512, TF_NTT_WAVES) ntt_pass_kernel(const NttPa
     u64* const ltw = lds + (LAST1024 ? kL1024ExchangeWords : 32 * s1_);  // the staged inner table [P2][32], behind the exchange buffer
     if constexpr (LDS_TW) {
         if ((LAST1024 || R1024) || A.inner_tw) {  // uniform
-            const u64* itw = A.inner_tw + (PRE2 ? (int)half * 1024 : 0);
+            const u64* itw = A.inner_tw + ((PRE2 || PRE4) ? (int)half * 1024 : 0);
             for (int i = t; i < 32 * P2; i += blockDim.x) ltw[(i >> 5) * kLdsTwStride + (i & 31)] = itw[i];
             __syncthreads();
         }
@@ -389,6 +430,34 @@ __global__ void __launch_bounds__(512, TF_NTT_WAVES) ntt_pass_kernel(const NttPa
     if constexpr (MODE == 1) {
 #pragma unroll
         for (int q = 0; q < 32; ++q) x[q] = (u64)(t * 32 + q) * 0x9e3779b97f4a7c15ULL >> 1;
+    } else if (PRE4 && act_in) {
+        // the tile's 64 Ki input elements, four slots at a time: the words c, c + 1024, c + 2048, c + 3072 of the row (c = g + 32 i),
+        // combined into class `half`'s z[c]; default cache policy -- the three partner workgroups read the same lines out of the L2
+        const u32 toff = (u32)(((long long)ch_in * A.in_cs_hi + cl_in + (long long)g_in * A.in_rs) * 8);
+        const __amdgpu_buffer_rsrc_t ri = buf_rsrc(in);
+        const u32 poff = (u32)(A.pre2_in_off * 8);
+        const auto slot_off = [&](int q) { return (u32)((long long)(brev5(q) << p2) * A.in_rs * 8); };
+        const auto ld = [&](u32 so) { return buf_load<0>(ri, toff, so); };
+        const u64* stw = A.pre4_stw + (half >> 1) * 32;  // uniform: scalar loads
+        const auto group = [&](auto q0c) {
+            constexpr int Q0 = decltype(q0c)::value;
+            u64 v0[4], v1[4], v2[4], v3[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const u32 so = slot_off(Q0 + i);
+                v0[i] = ld(so), v1[i] = ld(so + poff), v2[i] = ld(so + 2 * poff), v3[i] = ld(so + 3 * poff);
+            }
+            pre4_combine4<INV, Q0>(x, v0, v1, v2, v3, half);
+            if (half & 1u) mul4_inplace(x, Q0, stw[brev5(Q0)], stw[brev5(Q0 + 1)], stw[brev5(Q0 + 2)], stw[brev5(Q0 + 3)]);
+        };
+        group(std::integral_constant<int, 0>{});
+        group(std::integral_constant<int, 4>{});
+        group(std::integral_constant<int, 8>{});
+        group(std::integral_constant<int, 12>{});
+        group(std::integral_constant<int, 16>{});
+        group(std::integral_constant<int, 20>{});
+        group(std::integral_constant<int, 24>{});
+        group(std::integral_constant<int, 28>{});
     } else if (PRE2 && act_in) {
         // the tile's 32 Ki input elements: rows r = g + 32 i in x[], their partner rows r + 1024 eight at a time, combined at once
         const u32 toff = (u32)(((long long)ch_in * A.in_cs_hi + cl_in + (long long)g_in * A.in_rs) * 8);
@@ -613,7 +682,7 @@ __global__ void __launch_bounds__(512, TF_NTT_WAVES) ntt_pass_kernel(const NttPa
         // groups of ds_read_b64 two consecutive k1) fall on different 8-byte bank pairs because 34 = 2 and 273 = 17 (mod 32):
         // cc * 2 + 17 * (k1 & 1) takes 16 different values.  All 64 offsets are immediates on both sides.  (Round 1 used 36 /
         // 289; the tighter pitch leaves room for the staged twiddle table with two workgroups per CU.  kLast1024LdsBytes in
-        // tf_hip.hip sizes the buffer.)
+        // tf_ntt.hip sizes the buffer.)
         constexpr int S1 = kL1024S1, CS = kL1024CS;
         const int wround = c_in >> 3, wcc = c_in & 7, rround = c >> 3, rcc = c & 7;
         u64* wr = lds + wcc * CS + g_in;

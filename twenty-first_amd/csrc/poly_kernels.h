@@ -6,7 +6,7 @@
 // tree here is laid out for the device instead of mirrored node by node:
 //   * leaves of 256 (BFE) / 128 (XFE) points, one workgroup each (O(leaf^2) work in LDS); a level is ONE array [nodes][d] of
 //     monic zerofiers stored without their leading 1 ("tails") beside its forward transforms of order 2d, so every product /
-//     remainder of a level is a batched transform, a pointwise kernel and a batched inverse transform (tf_hip.hip: zerofier_tree_*);
+//     remainder of a level is a batched transform, a pointwise kernel and a batched inverse transform (tf_poly.hip: zerofier_tree_*);
 //   * a remainder f mod Z (deg f < 2d, deg Z = d) is taken with the power-series inverse g of rev(Z) mod x^d:
 //     rev(q) = rev(f_high) * g mod x^d,  r = f_low - (q * tail(Z))_low   (two products of size d x d against cached transforms);
 //     g of a parent = g_left * g_right (precision d) followed by one Newton step to precision 2d at order 4d, so no division is

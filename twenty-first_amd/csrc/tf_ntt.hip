@@ -283,22 +283,26 @@ void split_powers(u64 base, int log_total, int* h_out, std::vector<u64>* hi, std
 // (table keys: tf_internal.h)
 
 // inner[g*32 + k1] = w_R^(+-g*k1) * (scale_log_n ? n^-1 : 1),  R = 32 << p2
-// pre2 (a = 10 only): a second table follows the first, inner[1024 + g*32 + k1] = w_2048^(+-g (2 k1 + 1)) * scale -- the inner
-// twiddles of the odd half of a 2048-point pass (ntt_kernels.h, PRE2)
-int get_inner_table(DeviceCtx* ctx, int a, bool inverse, int scale_log_n, const u64** out, bool pre2 = false) {
+// pre = 2 or 4 (a = 10 only): the pass is a 2048- / 4096-point DFT run as `pre` 1024-point workgroups per tile (ntt_kernels.h, PRE2 /
+// PRE4); `pre` tables back to back, table q: inner[q * 1024 + g*32 + k1] = w_1024^(+-g k1) * w_{1024 pre}^(+-q g) * scale -- the part
+// of the radix-`pre` stage's twiddle that depends on g rides on the inner twiddle.  pre = 4: 64 more words follow,
+// stw[(q >> 1) * 32 + i] = w_128^(+-q i), q = 1, 3: the per-slot part of w_4096^(q c), c = g + 32 i (*stw_out).
+int get_inner_table(DeviceCtx* ctx, int a, bool inverse, int scale_log_n, const u64** out, int pre = 1, const u64** stw_out = nullptr) {
     const int p2 = a - 5;
+    if (stw_out) *stw_out = nullptr;
     if (p2 == 0 && scale_log_n == 0) {
         *out = nullptr;
         return TF_OK;
     }
-    const u64 key = make_key(TAG_INNER, a, inverse, scale_log_n, pre2 ? 1 : 0);
+    const u64 key = make_key(TAG_INNER, a, inverse, scale_log_n, pre > 1 ? pre - 1 : 0);  // (pre = 2 keeps its round-3 key)
     std::lock_guard<std::mutex> lk(ctx->mu);
+    const int P2 = 1 << p2;
     auto it = ctx->tables.find(key);
     if (it != ctx->tables.end()) {
         *out = it->second;
+        if (stw_out && pre == 4) *stw_out = it->second + size_t(P2) * 32 * 4;
         return TF_OK;
     }
-    const int P2 = 1 << p2;
     u64 w = root_of_unity_mont(a);
     if (inverse) w = gl::mont_inverse(w);
     u64 scale = gl::ONE;
@@ -313,14 +317,29 @@ int get_inner_table(DeviceCtx* ctx, int a, bool inverse, int scale_log_n, const 
         }
         wg = gl::mont_mul(wg, w);
     }
-    if (pre2) {
-        u64 w2 = root_of_unity_mont(a + 1);
-        if (inverse) w2 = gl::mont_inverse(w2);
-        t.resize(size_t(P2) * 64);
-        u64 w2g = gl::ONE;  // w_{2R}^g
-        for (int g = 0; g < P2; ++g) {
-            for (int k = 0; k < 32; ++k) t[size_t(P2) * 32 + size_t(g) * 32 + k] = gl::mont_mul(t[size_t(g) * 32 + k], w2g);
-            w2g = gl::mont_mul(w2g, w2);
+    if (pre > 1) {
+        u64 wp = root_of_unity_mont(a + (pre == 4 ? 2 : 1));  // w_{R pre}
+        if (inverse) wp = gl::mont_inverse(wp);
+        t.resize(size_t(P2) * 32 * pre + (pre == 4 ? 64 : 0));
+        u64 wq = wp;  // w_{R pre}^q
+        for (int q = 1; q < pre; ++q) {
+            u64 wqg = gl::ONE;  // w_{R pre}^(q g)
+            for (int g = 0; g < P2; ++g) {
+                for (int k = 0; k < 32; ++k) t[size_t(q) * P2 * 32 + size_t(g) * 32 + k] = gl::mont_mul(t[size_t(g) * 32 + k], wqg);
+                wqg = gl::mont_mul(wqg, wq);
+            }
+            wq = gl::mont_mul(wq, wp);
+        }
+        if (pre == 4) {
+            const u64 w128 = gl::mont_pow(wp, u64(P2));  // w_{R pre}^32 = w_{R pre / 32}: w_128 for R = 1024
+            for (int h = 0; h < 2; ++h) {
+                const u64 step = gl::mont_pow(w128, u64(2 * h + 1));
+                u64 acc = gl::ONE;
+                for (int i = 0; i < 32; ++i) {
+                    t[size_t(P2) * 32 * 4 + size_t(h) * 32 + i] = acc;
+                    acc = gl::mont_mul(acc, step);
+                }
+            }
         }
     }
     u64* d = nullptr;
@@ -328,6 +347,7 @@ int get_inner_table(DeviceCtx* ctx, int a, bool inverse, int scale_log_n, const 
     if (rc) return rc;
     ctx->tables[key] = d;
     *out = d;
+    if (stw_out && pre == 4) *stw_out = d + size_t(P2) * 32 * 4;
     return TF_OK;
 }
 
@@ -697,7 +717,7 @@ bool fits_buffer_offsets(const Launch& l) {
         return rows * (unsigned long long)rs_words * 8ull + cols + col_span < lim;
     };
     // (a PRE2 launch also reads the partner rows, 1024 rows further)
-    return ok(l.a.in_rs, l.a.in_cs_hi, l.a.pre2_map ? 2048ull : 1024ull) && ok(l.a.out_rs, l.a.out_cs_hi) && ok(l.a.tw_rs, 0);
+    return ok(l.a.in_rs, l.a.in_cs_hi, l.a.pre2_map ? (l.a.pre4_stw ? 4096ull : 2048ull) : 1024ull) && ok(l.a.out_rs, l.a.out_cs_hi) && ok(l.a.tw_rs, 0);
 }
 
 // the specialised R = 1024 last-pass kernel (LAST1024) is available unless an A/B switch or an ablation run disables it
@@ -732,11 +752,11 @@ int rows_per_tile(int P2, int L, long long limit) {
 // words > 0: word-granular tiles of `words` adjacent output WORDS (whole 128-byte lines) instead of T whole elements; for
 // XFieldElement rows (24-byte elements) a tile then starts and ends inside an element (NttPassArgs::wtiles).
 Launch plan_transpose_pass(const u64* in, u64* out, long long in_bs, long long out_bs, size_t batch, int a, long long N1,
-                           long long Q, int L, long long split = 0, int words = 0, bool pre2 = false) {
+                           long long Q, int L, long long split = 0, int words = 0, int pre = 1) {
     Launch l{};
     tfk::NttPassArgs& A = l.a;
-    const int p2 = (pre2 ? a - 1 : a) - 5, P2 = 1 << p2;
-    const long long R = 1ll << a;  // elements per row (pre2: 2048, transformed as two interleaved 1024-point halves)
+    const int p2 = a - (pre == 4 ? 2 : (pre == 2 ? 1 : 0)) - 5, P2 = 1 << p2;
+    const long long R = 1ll << a;  // elements per row (pre = 2 / 4: 2048 / 4096, transformed as two / four interleaved 1024-point classes)
     int T = rows_per_tile(P2, L, N1);
     {
         // the kernel addresses its loads as uniform 64-bit base + 32-bit per-thread byte offset; the offset spans the
@@ -784,14 +804,14 @@ Launch plan_transpose_pass(const u64* in, u64* out, long long in_bs, long long o
     }
     finish_geometry(&l, nc, p2);
     l.tiles = (unsigned)(batch * Q * A.d2);
-    if (pre2) {
+    if (pre > 1) {
         A.pre2_in_off = 1024 * L;
-        A.pre2_out_off = A.out_rs;  // output k = 2 k' + h
+        A.pre2_out_off = A.out_rs;  // output k = pre k' + q
         A.pre2_js_off = A.js_k;
-        A.out_rs *= 2;
-        A.js_k *= 2;
+        A.out_rs *= pre;
+        A.js_k *= pre;
         A.pre2_map = (l.tiles % 8 == 0) ? 1 : 2;
-        l.tiles *= 2;
+        l.tiles *= (unsigned)pre;
     }
     return l;
 }
@@ -854,15 +874,15 @@ int ensure_dynamic_lds(const void* fn, int bytes, std::atomic<unsigned long long
     return TF_OK;
 }
 
-template <bool INV, int SCALE, int MODE, bool LAST1024 = false, bool R1024 = false, bool COL = false, bool PRE2 = false>
+template <bool INV, int SCALE, int MODE, bool LAST1024 = false, bool R1024 = false, bool COL = false, bool PRE2 = false, bool PRE4 = false>
 int launch_pass_t(const Launch& l, hipStream_t stream) {
     // one attribute call per (instantiation, device): the kernels use up to the full 160 KiB of dynamic LDS
     static std::atomic<unsigned long long> done_mask{0};
-    if (int rc_attr = ensure_dynamic_lds(reinterpret_cast<const void*>(&tfk::ntt_pass_kernel<INV, SCALE, MODE, LAST1024, R1024, COL, PRE2>), (int)(160 * 1024), done_mask)) return rc_attr;
+    if (int rc_attr = ensure_dynamic_lds(reinterpret_cast<const void*>(&tfk::ntt_pass_kernel<INV, SCALE, MODE, LAST1024, R1024, COL, PRE2, PRE4>), (int)(160 * 1024), done_mask)) return rc_attr;
     // the R = 1024 column-pass instantiation stages its inner twiddle table behind the exchange buffer (LAST1024: part of
     // kLast1024LdsBytes already)
     const size_t lds_bytes = l.lds_bytes + ((TF_LDS_TW && !LAST1024 && MODE == 0 && l.a.inner_tw) ? (size_t(1) << l.a.p2) * tfk::kLdsTwStride * sizeof(u64) : 0);
-    hipLaunchKernelGGL((tfk::ntt_pass_kernel<INV, SCALE, MODE, LAST1024, R1024, COL, PRE2>), dim3(l.tiles), dim3(l.threads), lds_bytes, stream,
+    hipLaunchKernelGGL((tfk::ntt_pass_kernel<INV, SCALE, MODE, LAST1024, R1024, COL, PRE2, PRE4>), dim3(l.tiles), dim3(l.threads), lds_bytes, stream,
                        l.a);
     HIPCHK(hipGetLastError());
     return TF_OK;
@@ -920,6 +940,18 @@ int launch_pass(const Launch& l, bool inverse, hipStream_t stream) {
                          l.a.s1 == tfk::kR1024S1 && l.a.s2 == tfk::kR1024Cpr && l.a.s3 == 1 && !l.a.gfast;
     const bool plain_last1024 = l.a.p2 == 5 && !l.a.post_tw && !l.a.gfast && !l.a.pre_scale && l.a.n_coeffs < 0 && !l.a.in2 &&
                                 (!l.a.post_scale || (inverse && scaled_last1024_enabled())) && last1024_enabled() && fits;
+    if (l.a.pre2_map && l.a.pre4_stw) {
+        // a 4096-point last pass as four 1024-point classes per tile (ntt_kernels.h, PRE4): forward, plain, planned by run_ntt only
+        if (l.a.p2 != 5 || !fits || g_ablate || l.a.in2 || l.a.n_out >= 0 || l.a.gfast || l.a.post_tw || l.a.pre_scale || l.a.n_coeffs >= 0 ||
+            l.a.post_scale || inverse || l.a.col_shift0 || l.a.col_shift_i0) {
+            t_last_error = "internal: radix-4 last pass (PRE4) launch outside the shapes it supports";
+            return TF_ERR_HIP;
+        }
+        Launch l2 = l;
+        l2.lds_bytes = std::max(l.lds_bytes, kLast1024LdsBytes);
+        l2.threads = 512;
+        return launch_pass_t<false, 0, 0, true, false, false, false, true>(l2, stream);
+    }
     if (l.a.pre2_map) {
         // a 2048-point pass as two 1024-point halves per tile (ntt_kernels.h, PRE2): only planned by run_ntt when all of this holds
         const bool column = l.a.post_tw != nullptr;
@@ -1165,9 +1197,22 @@ std::atomic<int> g_pre2_mode{-1};  // tf_set_ntt_two_pass: -1 automatic (TF_NTT_
 bool pre2_plan_ok(int log_n, int L, size_t n, size_t cosets, bool has_in2, long long n_out, bool inverse, bool load_work, bool store_scale) {
     static const bool off = ab_env("TF_NTT_NO_PRE2") != nullptr;  // A/B switch
     const int mode = g_pre2_mode.load(std::memory_order_relaxed);
-    if (mode == 0 || (mode < 0 && off)) return false;
+    if (mode == 0 || (mode < 0 && off)) return false;  // (mode 2: the radix-4 plan where it applies, this one elsewhere)
     if (log_n < 21 || log_n > 22 || cosets != 1 || has_in2 || n_out >= 0) return false;
     if ((load_work && inverse) || (store_scale && !inverse)) return false;          // shapes no caller produces
+    if (!last1024_enabled() || ablate_mode() != 0 || wg_threads() != 512) return false;
+    if (g_min_passes.load(std::memory_order_relaxed) > 2) return false;
+    return (unsigned long long)n * L * 8 + (1ull << 20) < (1ull << 32);              // buffer addressing (fits_buffer_offsets)
+}
+// 2^22 points as 1024 x 4096 with the 4096-point LAST pass run as four 1024-point classes per tile (ntt_kernels.h, PRE4):
+// the plan of a forward transform WITH WORK ON LOAD (fast_coset_evaluate's scaling, zero padding) -- its first pass is then an
+// ordinary 1024-point column pass that scales every coefficient once, where the 2048 x 2048 plan scales it in both workgroups
+// of a PRE2 pair.  mode 2 of tf_set_ntt_two_pass forces it for every forward 2^22-point transform (tests), mode 1 forbids it.
+bool pre4_plan_ok(int log_n, int L, size_t n, size_t cosets, bool has_in2, long long n_out, bool inverse, bool load_work, bool store_scale) {
+    static const bool off = ab_env("TF_NTT_NO_PRE4") != nullptr;  // A/B switch
+    const int mode = g_pre2_mode.load(std::memory_order_relaxed);
+    if (mode == 0 || mode == 1 || (mode < 0 && (off || !load_work))) return false;
+    if (log_n != 22 || cosets != 1 || has_in2 || n_out >= 0 || inverse || store_scale) return false;
     if (!last1024_enabled() || ablate_mode() != 0 || wg_threads() != 512) return false;
     if (g_min_passes.load(std::memory_order_relaxed) > 2) return false;
     return (unsigned long long)n * L * 8 + (1ull << 20) < (1ull << 32);              // buffer addressing (fits_buffer_offsets)
@@ -1275,14 +1320,22 @@ int run_ntt(DeviceCtx* ctx, const u64* in, u64* out, long long in_bs, long long 
     // 2^21 and 2^22 points in TWO passes: a 2048-point pass runs as pairs of 1024-point workgroups that share their input
     // (ntt_kernels.h, PRE2; a[i] = 11 below).  Plain transforms, coset evaluation (forward) and coset interpolation (inverse).
     bool pre2[4] = {false, false, false, false};
-    if (pre2_plan_ok(log_n, L, n, cosets, in2 != nullptr, n_out, inverse, pre_scale != nullptr || n_coeffs >= 0, post_scale != nullptr)) {
+    bool pre4_last = false;  // the last pass is a 4096-point one in four classes (a[P - 1] = 12)
+    const u64* pre4_stw = nullptr;
+    if (pre4_plan_ok(log_n, L, n, cosets, in2 != nullptr, n_out, inverse, pre_scale != nullptr || n_coeffs >= 0, post_scale != nullptr)) {
+        P = 2;
+        a[0] = 10, a[1] = 12, a[2] = a[3] = 0;
+        pre4_last = true;
+    } else if (pre2_plan_ok(log_n, L, n, cosets, in2 != nullptr, n_out, inverse, pre_scale != nullptr || n_coeffs >= 0, post_scale != nullptr)) {
         P = 2;
         pre2_split(log_n, a);
         pre2[0] = a[0] == 11, pre2[1] = a[1] == 11;
     }
     const u64* inner[4] = {nullptr, nullptr, nullptr, nullptr};
     for (int i = 0; i < P; ++i) {
-        rc = get_inner_table(ctx, pre2[i] ? 10 : a[i], inverse, (i == P - 1 && inverse) ? log_n : 0, &inner[i], pre2[i]);  // n^-1 rides on the last pass
+        const bool p4 = pre4_last && i == P - 1;
+        rc = get_inner_table(ctx, (pre2[i] || p4) ? 10 : a[i], inverse, (i == P - 1 && inverse) ? log_n : 0, &inner[i], p4 ? 4 : (pre2[i] ? 2 : 1),
+                             p4 ? &pre4_stw : nullptr);  // n^-1 rides on the last pass
         if (rc) return rc;
     }
     const u64* post[3] = {nullptr, nullptr, nullptr};
@@ -1406,7 +1459,7 @@ int run_ntt(DeviceCtx* ctx, const u64* in, u64* out, long long in_bs, long long 
         if (P < 4) {
             // XFieldElement rows through the R = 1024 kernel: word-granular tiles (whole 128-byte lines on the output side)
             static const bool no_words16 = ab_env("TF_NTT_NO_WORDS16") != nullptr;  // A/B switch
-            const bool plain1024 = (a[P - 1] == 10 || pre2[P - 1]) && last1024_enabled() && (!post_scale || (inverse && scaled_last1024_enabled() && log_n <= 28));
+            const bool plain1024 = (a[P - 1] == 10 || pre2[P - 1] || pre4_last) && last1024_enabled() && (!post_scale || (inverse && scaled_last1024_enabled() && log_n <= 28));
             // (the other last-pass kernels too: all their thread slots as word-columns, e.g. 32 words = 256 bytes for R = 512)
             int words = 0;
             if (L == 3 && !no_words16) {
@@ -1419,12 +1472,13 @@ int run_ntt(DeviceCtx* ctx, const u64* in, u64* out, long long in_bs, long long 
                 }
             }
             Launch pl = plan_transpose_pass(scratch, tout, sbs, out_bs, nb, a[P - 1], N[0] * (long long)cosets, P == 3 ? N[1] : 1, L, 0,
-                                            words, pre2[P - 1]);
+                                            words, pre4_last ? 4 : (pre2[P - 1] ? 2 : 1));
             pl.a.inner_tw = inner[P - 1];
+            pl.a.pre4_stw = pre4_last ? pre4_stw : nullptr;
             pl.a.post_scale = post_scale;
             pl.a.n_out = n_out;
             pl.a.nt = g_nt.load(std::memory_order_relaxed) & 2;  // the result is written once
-            if (plain1024 && pl.a.nc == 16 && !no_col_shift && (unsigned long long)n * L * sizeof(u64) < (1ull << 32)) {
+            if (plain1024 && !pre4_last && pl.a.nc == 16 && !no_col_shift && (unsigned long long)n * L * sizeof(u64) < (1ull << 32)) {
                 // The R = 1024 last pass stores 128-byte segments of 16 adjacent output words.  When the output of batch entry
                 // b does not start on a cache line (a truncated product: stride n_out = na + nb - 1 words, or a caller's
                 // unaligned pointer) every segment would straddle two lines written by workgroups on different XCDs: shift

@@ -245,7 +245,7 @@ __global__ void __launch_bounds__(256) tip5_hash_table_rows_kernel(const u64* ta
 // circulant, out[r] = sum_k M[k] * state[(r - k) mod 16] is 16 row rotations (v_mov_b32 row_ror:k) each followed by one
 // v_mad_u64_u32 with the same constant M[k] in every lane.  ~1 600 instructions per permutation (the lookup lanes and
 // the x^7 lanes take turns): 3x the total work of the lane-per-permutation form, 1/5 of its latency -- measured 4.6 us
-// per tree level instead of 19 us.  Used for launches of at most kCoopMaxCount permutation chains (tf_hip.hip).
+// per tree level instead of 19 us.  Used for launches of at most kCoopMaxCount permutation chains (tf_tip5.hip).
 template <int K>
 __device__ __forceinline__ void mds_coop_terms(u32 lo, u32 hi, u64& alo, u64& ahi) {
     if constexpr (K < 16) {
