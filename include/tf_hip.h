@@ -359,7 +359,9 @@ void tf_set_ntt_min_passes(int passes);
 void tf_set_ntt_small_launch(int mode);
 /* Transforms of 2^21 and 2^22 points run in TWO global passes (a 2048-point pass = pairs of 1024-point workgroups sharing their
  * input) instead of three; -1 = automatic (default), 0 = never (the three-pass plan, which also serves the shapes the
- * two-pass plan does not: small launches, truncated products), 1 = whenever the shape supports it. */
+ * two-pass plan does not: small launches, truncated products), 1 = the 2048-point pairs whenever the shape supports them.
+ * (2: laboratory build only -- every FORWARD 2^22-point transform on the 1024 x 4096 plan whose last pass runs as four 1024-point
+ * classes per tile, a measured loss, profiles/r04_c4_plan_ab.txt; the product library treats 2 as 1.) */
 void tf_set_ntt_two_pass(int mode);
 /* The latency-shaped kernels (8 elements per thread, radix-8 stages through LDS) instead of the 32-elements-per-thread
  * pass kernels: ntt_lat_kernel for 64 .. 4096-point transforms in calls of up to 2^22 words (BFieldElement; 3 * 2^19 words

@@ -1351,6 +1351,18 @@ def test_async_chain_interpolate_divide_evaluate_never_synchronises(tf, oracle):
         bt.interpolate(vals, c2, status=st)                   # weights already there: the handle still reports them bad
         torch.cuda.synchronize()
         assert int(st.item()) == 12
+        # ... and so does a BLOCKING call on the same handle: the asynchronous first call left its verdict on the device only; the
+        # blocking path reads it back once instead of returning TF_OK with garbage coefficients
+        for _ in range(2):
+            with pytest.raises(tf.TwentyFirstError) as ei:
+                bt.interpolate(vals, c2)
+            assert ei.value.code == 12
+    with tf.device.ZerofierTree(dom, asynchronous=True) as gt:  # a good domain: async weights, then the blocking call succeeds
+        gt.interpolate(vals, c3, status=st)
+        gt.interpolate(vals, c2)
+        torch.cuda.synchronize()
+        assert int(st.item()) == 12 or int(st.item()) == 0       # (st still holds the sticky 12 from above unless it was cleared)
+        assert torch.equal(c2, coeffs) and torch.equal(c3, coeffs)
 
 
 def test_clean_divide_by_a_divisor_with_a_root_on_the_division_coset(tf, oracle):

@@ -447,6 +447,48 @@ def test_two_pass_plan_for_2p21_2p22_matches_oracle(tf, oracle, log_n, width, ba
     assert np.array_equal(ci, oracle.coset_interpolate(one, off, width=width))
 
 
+@pytest.mark.parametrize("width,batch", [(1, 3), (3, 2)])
+def test_radix4_last_pass_plan_for_2p22_matches_oracle(tf, oracle, width, batch):
+    """2^22 points as 1024 x 4096 with the 4096-point last pass run as four 1024-point classes per tile (ntt_kernels.h PRE4: a measured
+    loss, so the laboratory library only -- tf_set_ntt_two_pass(2); the product library treats mode 2 as mode 1): forward NTT and
+    coset evaluation with full, zero-padded and ragged coefficient lists against the oracle's radix-2 sweeps (math/ntt.rs:153-228,
+    polynomial.rs:1374-1399) and word for word against the 2048 x 2048 plan (mode 1) and the three-pass plan (mode 0); also
+    device-resident with several polynomials per call and from an unaligned output pointer."""
+    import torch
+
+    n = 1 << 22
+    x = oracle.fill_random(batch * n * width, 2300 + width)
+    lib = tf._lib.lib()
+    off = oracle.bfe_new(7)
+    one = x[:n * width]
+    got = {}
+    try:
+        for mode in (2, 1, 0, -1):
+            lib.tf_set_ntt_two_pass(mode)
+            y = x.copy()
+            tf.ntt(y, width=width, batch=batch)
+            ev_full = tf.fast_coset_evaluate(one, off, n, width=width)
+            ev_pad = tf.fast_coset_evaluate(one[: (n // 2 + 3) * width], off, n, width=width)
+            ev_short = tf.fast_coset_evaluate(one[: (n - 5) * width], off, n, width=width)
+            # several polynomials per call, device-resident, output 8 bytes off a cache line
+            c = torch.from_numpy(x.view(np.int64)).cuda()
+            o = torch.empty(batch * n * width + 1, dtype=torch.int64, device="cuda")
+            tf.device.coset_evaluate(c, n, off, o[1:], n, batch=batch, width=width)
+            torch.cuda.synchronize()
+            got[mode] = (y, ev_full, ev_pad, ev_short, o[1:].cpu().numpy().view(np.uint64))
+    finally:
+        lib.tf_set_ntt_two_pass(-1)
+    for mode in (1, 0, -1):
+        for a, b in zip(got[2], got[mode]):
+            assert np.array_equal(a, b), mode
+    fwd, ev_full, ev_pad, ev_short, ev_batch = got[2]
+    assert np.array_equal(fwd, oracle.ntt(x, width=width, batch=batch, threads=8))
+    assert np.array_equal(ev_full, oracle.coset_evaluate(one, off, n, width=width))
+    assert np.array_equal(ev_pad, oracle.coset_evaluate(one[: (n // 2 + 3) * width], off, n, width=width))
+    assert np.array_equal(ev_short, oracle.coset_evaluate(one[: (n - 5) * width], off, n, width=width))
+    assert np.array_equal(ev_batch, oracle.coset_evaluate_batch(x, off, n, batch, width=width, threads=batch))
+
+
 @pytest.mark.parametrize("length", [0, 1, 9, 10, 11, 25, 40])
 def test_sponge_absorb_squeeze_matches_oracle(tf, oracle, length):
     """impl Sponge for Tip5 (tip5/mod.rs:677-699) + pad_and_absorb_all (sponge.rs:41-55), three sponges stepped together"""

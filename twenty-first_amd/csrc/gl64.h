@@ -132,6 +132,69 @@ __device__ __forceinline__ void add_sub_lazy2(u64 a, u64 v, u64 c, u64 w, u64& s
     diff1 = ((u64)t1 << 32) | t0;
 }
 
+// FOUR independent lazy sums  r = a + v  (a any 64-bit word congruent to its element, v <= p; r any such word): the sum half of
+// add_sub_lazy2, four VALU instructions each, the four carry chains issued round-robin (no wait-state nops).
+__device__ __forceinline__ void add_lazy4(const u64 (&a)[4], const u64 (&v)[4], u64 (&r)[4]) {
+    u32 lo[4], hi[4];
+    u64 m[4], n[4];  // m: carry / borrow of the 64-bit operation, n: of the correction's low word
+    asm("v_add_co_u32_e64 %[l0], %[m0], %[a0], %[v0]\n\t"
+        "v_add_co_u32_e64 %[l1], %[m1], %[a1], %[v1]\n\t"
+        "v_add_co_u32_e64 %[l2], %[m2], %[a2], %[v2]\n\t"
+        "v_add_co_u32_e64 %[l3], %[m3], %[a3], %[v3]\n\t"
+        "v_addc_co_u32_e64 %[h0], %[m0], %[b0], %[w0], %[m0]\n\t"
+        "v_addc_co_u32_e64 %[h1], %[m1], %[b1], %[w1], %[m1]\n\t"
+        "v_addc_co_u32_e64 %[h2], %[m2], %[b2], %[w2], %[m2]\n\t"
+        "v_addc_co_u32_e64 %[h3], %[m3], %[b3], %[w3], %[m3]\n\t"
+        "v_subbrev_co_u32_e64 %[l0], %[n0], 0, %[l0], %[m0]\n\t"
+        "v_subbrev_co_u32_e64 %[l1], %[n1], 0, %[l1], %[m1]\n\t"
+        "v_subbrev_co_u32_e64 %[l2], %[n2], 0, %[l2], %[m2]\n\t"
+        "v_subbrev_co_u32_e64 %[l3], %[n3], 0, %[l3], %[m3]\n\t"
+        "s_andn2_b64 %[m0], %[m0], %[n0]\n\t"
+        "s_andn2_b64 %[m1], %[m1], %[n1]\n\t"
+        "s_andn2_b64 %[m2], %[m2], %[n2]\n\t"
+        "s_andn2_b64 %[m3], %[m3], %[n3]\n\t"
+        "v_addc_co_u32_e64 %[h0], %[n0], 0, %[h0], %[m0]\n\t"
+        "v_addc_co_u32_e64 %[h1], %[n1], 0, %[h1], %[m1]\n\t"
+        "v_addc_co_u32_e64 %[h2], %[n2], 0, %[h2], %[m2]\n\t"
+        "v_addc_co_u32_e64 %[h3], %[n3], 0, %[h3], %[m3]"
+        : [l0] "=&v"(lo[0]), [h0] "=&v"(hi[0]), [m0] "=&s"(m[0]), [n0] "=&s"(n[0]), [l1] "=&v"(lo[1]), [h1] "=&v"(hi[1]), [m1] "=&s"(m[1]), [n1] "=&s"(n[1]), [l2] "=&v"(lo[2]), [h2] "=&v"(hi[2]), [m2] "=&s"(m[2]), [n2] "=&s"(n[2]), [l3] "=&v"(lo[3]), [h3] "=&v"(hi[3]), [m3] "=&s"(m[3]), [n3] "=&s"(n[3])
+        : [a0] "v"((u32)a[0]), [b0] "v"((u32)(a[0] >> 32)), [v0] "v"((u32)v[0]), [w0] "v"((u32)(v[0] >> 32)), [a1] "v"((u32)a[1]), [b1] "v"((u32)(a[1] >> 32)), [v1] "v"((u32)v[1]), [w1] "v"((u32)(v[1] >> 32)), [a2] "v"((u32)a[2]), [b2] "v"((u32)(a[2] >> 32)), [v2] "v"((u32)v[2]), [w2] "v"((u32)(v[2] >> 32)), [a3] "v"((u32)a[3]), [b3] "v"((u32)(a[3] >> 32)), [v3] "v"((u32)v[3]), [w3] "v"((u32)(v[3] >> 32))
+        : "scc");
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r[i] = ((u64)hi[i] << 32) | lo[i];
+}
+
+// FOUR independent lazy differences  r = a - v  (a any representative, v <= p): the difference half of add_sub_lazy2.
+__device__ __forceinline__ void sub_lazy4(const u64 (&a)[4], const u64 (&v)[4], u64 (&r)[4]) {
+    u32 lo[4], hi[4];
+    u64 m[4], n[4];  // m: carry / borrow of the 64-bit operation, n: of the correction's low word
+    asm("v_sub_co_u32_e64 %[l0], %[m0], %[a0], %[v0]\n\t"
+        "v_sub_co_u32_e64 %[l1], %[m1], %[a1], %[v1]\n\t"
+        "v_sub_co_u32_e64 %[l2], %[m2], %[a2], %[v2]\n\t"
+        "v_sub_co_u32_e64 %[l3], %[m3], %[a3], %[v3]\n\t"
+        "v_subb_co_u32_e64 %[h0], %[m0], %[b0], %[w0], %[m0]\n\t"
+        "v_subb_co_u32_e64 %[h1], %[m1], %[b1], %[w1], %[m1]\n\t"
+        "v_subb_co_u32_e64 %[h2], %[m2], %[b2], %[w2], %[m2]\n\t"
+        "v_subb_co_u32_e64 %[h3], %[m3], %[b3], %[w3], %[m3]\n\t"
+        "v_addc_co_u32_e64 %[l0], %[n0], 0, %[l0], %[m0]\n\t"
+        "v_addc_co_u32_e64 %[l1], %[n1], 0, %[l1], %[m1]\n\t"
+        "v_addc_co_u32_e64 %[l2], %[n2], 0, %[l2], %[m2]\n\t"
+        "v_addc_co_u32_e64 %[l3], %[n3], 0, %[l3], %[m3]\n\t"
+        "s_andn2_b64 %[m0], %[m0], %[n0]\n\t"
+        "s_andn2_b64 %[m1], %[m1], %[n1]\n\t"
+        "s_andn2_b64 %[m2], %[m2], %[n2]\n\t"
+        "s_andn2_b64 %[m3], %[m3], %[n3]\n\t"
+        "v_subbrev_co_u32_e64 %[h0], %[n0], 0, %[h0], %[m0]\n\t"
+        "v_subbrev_co_u32_e64 %[h1], %[n1], 0, %[h1], %[m1]\n\t"
+        "v_subbrev_co_u32_e64 %[h2], %[n2], 0, %[h2], %[m2]\n\t"
+        "v_subbrev_co_u32_e64 %[h3], %[n3], 0, %[h3], %[m3]"
+        : [l0] "=&v"(lo[0]), [h0] "=&v"(hi[0]), [m0] "=&s"(m[0]), [n0] "=&s"(n[0]), [l1] "=&v"(lo[1]), [h1] "=&v"(hi[1]), [m1] "=&s"(m[1]), [n1] "=&s"(n[1]), [l2] "=&v"(lo[2]), [h2] "=&v"(hi[2]), [m2] "=&s"(m[2]), [n2] "=&s"(n[2]), [l3] "=&v"(lo[3]), [h3] "=&v"(hi[3]), [m3] "=&s"(m[3]), [n3] "=&s"(n[3])
+        : [a0] "v"((u32)a[0]), [b0] "v"((u32)(a[0] >> 32)), [v0] "v"((u32)v[0]), [w0] "v"((u32)(v[0] >> 32)), [a1] "v"((u32)a[1]), [b1] "v"((u32)(a[1] >> 32)), [v1] "v"((u32)v[1]), [w1] "v"((u32)(v[1] >> 32)), [a2] "v"((u32)a[2]), [b2] "v"((u32)(a[2] >> 32)), [v2] "v"((u32)v[2]), [w2] "v"((u32)(v[2] >> 32)), [a3] "v"((u32)a[3]), [b3] "v"((u32)(a[3] >> 32)), [v3] "v"((u32)v[3]), [w3] "v"((u32)(v[3] >> 32))
+        : "scc");
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r[i] = ((u64)hi[i] << 32) | lo[i];
+}
+
 // The canonical butterfly of add_sub for TWO butterflies at once: canonical inputs and outputs, ten VALU instructions each
 // as in add_sub, but the six carry chains (n = p - v, a - n, a - v, twice) are issued round-robin, so every carry mask is read
 // at least three instructions after it was written and no wait-state s_nop is needed (add_sub spends three per butterfly).

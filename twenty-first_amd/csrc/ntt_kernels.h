@@ -234,27 +234,51 @@ __device__ __forceinline__ void pre2_shift(u64 (&x)[32]) {
 //   holds the four tables, [4][32][32]).  This is the last pass of the 2^22-point plan 1024 x 4096 that fast_coset_evaluate takes:
 //   its FIRST pass (where every coefficient is scaled by offset^j) is then an ordinary 1024-point column pass -- the 2048 x 2048
 //   plan scales every coefficient twice there, once per half of a PRE2 pair.
-// slots Q0 .. Q0+3 from their four quarter-row words; cls = q (uniform)
+#ifdef TF_AB_BUILD  // measured loss (7.9 vs 7.6 ms on BASELINE configs[3], profiles/r04_c4_plan_ab.txt): laboratory build only
+// slots Q0 .. Q0+3 from their four quarter-row words; cls = q (uniform).  Every step adds or subtracts a CANONICAL word (a loaded
+// word or a power-of-two product) to an accumulator that may be any representative (gl::add_lazy4 / sub_lazy4: four instructions, four
+// slots round-robin, no wait states); what leaves is canonical: a power-of-two product, a Montgomery product (stw), or -- class 0 --
+// the odd slots' sums made canonical (the second operands of the lazy network's first level, ntt_network.h), the even slots' left lazy.
 template <bool INV, int Q0, int I = 0>
-__device__ __forceinline__ void pre4_combine4(u64 (&x)[32], const u64 (&v0)[4], const u64 (&v1)[4], const u64 (&v2)[4], const u64 (&v3)[4], u32 cls) {
-    constexpr int Q = Q0 + I;
-    if ((cls & 1u) == 0) {
-        const u64 s = gl::add(v0[I], v2[I]), t = gl::add(v1[I], v3[I]);
-        if (cls == 0) {
-            x[Q] = gl::add(s, t);
-        } else {  // (s - t) w_64^i, the sign of the power-of-two product folded into the subtraction
-            const u64 d = Pre2Slot<INV, Q>::neg ? gl::sub(t, s) : gl::sub(s, t);
-            x[Q] = gl::Pow2Mul<Pre2Slot<INV, Q>::E>::apply(d);
-        }
-    } else {
-        constexpr int E4 = TwExp<INV, 2, 1>::value;  // w_4^(+-1)
-        const u64 b = gl::sub(v0[I], v2[I]);
-        const u64 w = gl::Pow2Mul<E4>::apply(gl::sub(v1[I], v3[I]));  // +- w_4 (x_1 - x_3)
-        const bool plus = (cls == 1) != gl::Pow2Mul<E4>::negate;
-        x[Q] = plus ? gl::add(b, w) : gl::sub(b, w);
-    }
-    if constexpr (I + 1 < 4) pre4_combine4<INV, Q0, I + 1>(x, v0, v1, v2, v3, cls);
+__device__ __forceinline__ void pre4_shift4(u64 (&x)[32], const u64 (&d)[4]) {  // x[Q] = d * w_64^i up to the sign the caller folded in
+    x[Q0 + I] = gl::Pow2Mul<Pre2Slot<INV, Q0 + I>::E>::apply(d[I]);
+    if constexpr (I + 1 < 4) pre4_shift4<INV, Q0, I + 1>(x, d);
 }
+template <bool INV, int Q0>
+__device__ __forceinline__ void pre4_combine4(u64 (&x)[32], const u64 (&v0)[4], const u64 (&v1)[4], const u64 (&v2)[4], const u64 (&v3)[4], u32 cls,
+                                              const u64* stw) {
+    u64 t[4], u[4];
+    if (cls == 0) {  // ((x_0 + x_2) + x_1) + x_3
+        gl::add_lazy4(v0, v2, t);
+        gl::add_lazy4(t, v1, u);
+        gl::add_lazy4(u, v3, t);
+        x[Q0] = t[0], x[Q0 + 1] = gl::add(t[1], 0), x[Q0 + 2] = t[2], x[Q0 + 3] = gl::add(t[3], 0);
+    } else if (cls == 2) {  // ((x_0 + x_2) - x_1 - x_3) w_64^i; a slot whose power-of-two product comes back negated takes x_1 + x_3 - x_0 - x_2
+        const u64 p0[4] = {Pre2Slot<INV, Q0>::neg ? v1[0] : v0[0], Pre2Slot<INV, Q0 + 1>::neg ? v1[1] : v0[1], Pre2Slot<INV, Q0 + 2>::neg ? v1[2] : v0[2],
+                           Pre2Slot<INV, Q0 + 3>::neg ? v1[3] : v0[3]};
+        const u64 p1[4] = {Pre2Slot<INV, Q0>::neg ? v3[0] : v2[0], Pre2Slot<INV, Q0 + 1>::neg ? v3[1] : v2[1], Pre2Slot<INV, Q0 + 2>::neg ? v3[2] : v2[2],
+                           Pre2Slot<INV, Q0 + 3>::neg ? v3[3] : v2[3]};
+        const u64 m0[4] = {Pre2Slot<INV, Q0>::neg ? v0[0] : v1[0], Pre2Slot<INV, Q0 + 1>::neg ? v0[1] : v1[1], Pre2Slot<INV, Q0 + 2>::neg ? v0[2] : v1[2],
+                           Pre2Slot<INV, Q0 + 3>::neg ? v0[3] : v1[3]};
+        const u64 m1[4] = {Pre2Slot<INV, Q0>::neg ? v2[0] : v3[0], Pre2Slot<INV, Q0 + 1>::neg ? v2[1] : v3[1], Pre2Slot<INV, Q0 + 2>::neg ? v2[2] : v3[2],
+                           Pre2Slot<INV, Q0 + 3>::neg ? v2[3] : v3[3]};
+        gl::add_lazy4(p0, p1, t);
+        gl::sub_lazy4(t, m0, u);
+        gl::sub_lazy4(u, m1, t);
+        pre4_shift4<INV, Q0>(x, t);
+    } else {  // ((x_0 - x_2) +- w_4 (x_1 - x_3)) w_128^(q i)
+        constexpr int E4 = TwExp<INV, 2, 1>::value;  // w_4^(+-1)
+        gl::sub_lazy4(v0, v2, t);
+        gl::sub_lazy4(v1, v3, u);
+        const u64 w[4] = {gl::Pow2Mul<E4>::apply(u[0]), gl::Pow2Mul<E4>::apply(u[1]), gl::Pow2Mul<E4>::apply(u[2]), gl::Pow2Mul<E4>::apply(u[3])};
+        if ((cls == 1) != gl::Pow2Mul<E4>::negate) gl::add_lazy4(t, w, u);
+        else gl::sub_lazy4(t, w, u);
+        const u64 b4[4] = {stw[brev5(Q0)], stw[brev5(Q0 + 1)], stw[brev5(Q0 + 2)], stw[brev5(Q0 + 3)]};
+        gl::mont_mul4(u, b4, t);
+        x[Q0] = t[0], x[Q0 + 1] = t[1], x[Q0 + 2] = t[2], x[Q0 + 3] = t[3];
+    }
+}
+#endif  // TF_AB_BUILD
 
 template <bool INV, int SCALE, int MODE = 0, bool LAST1024 = false, bool R1024 = false, bool COL = false, bool PRE2 = false, bool PRE4 = false>
 #ifndef TF_PRIO_LOAD
@@ -285,6 +309,9 @@ __global__ void __launch_bounds__(512, TF_NTT_WAVES) ntt_pass_kernel(const NttPa
 
     static_assert(!PRE2 || ((LAST1024 || R1024) && MODE == 0 && SCALE != 3), "PRE2 is a variant of the R = 1024 kernels");
     static_assert(!PRE4 || (LAST1024 && !PRE2 && !INV && MODE == 0 && SCALE == 0), "PRE4 is a variant of the plain forward R = 1024 last pass");
+#ifndef TF_AB_BUILD
+    static_assert(!PRE4, "the radix-4 last pass is a measured loss: laboratory build only");
+#endif
     // PRE2: two workgroups per tile; `half` selects the even (y) or odd (z) outputs.  PRE4: four, `half` is the residue class q
     u32 bid = blockIdx.x, half = 0;
     if constexpr (PRE2) {
@@ -430,6 +457,7 @@ __global__ void __launch_bounds__(512, TF_NTT_WAVES) ntt_pass_kernel(const NttPa
     if constexpr (MODE == 1) {
 #pragma unroll
         for (int q = 0; q < 32; ++q) x[q] = (u64)(t * 32 + q) * 0x9e3779b97f4a7c15ULL >> 1;
+#ifdef TF_AB_BUILD
     } else if (PRE4 && act_in) {
         // the tile's 64 Ki input elements, four slots at a time: the words c, c + 1024, c + 2048, c + 3072 of the row (c = g + 32 i),
         // combined into class `half`'s z[c]; default cache policy -- the three partner workgroups read the same lines out of the L2
@@ -447,8 +475,7 @@ __global__ void __launch_bounds__(512, TF_NTT_WAVES) ntt_pass_kernel(const NttPa
                 const u32 so = slot_off(Q0 + i);
                 v0[i] = ld(so), v1[i] = ld(so + poff), v2[i] = ld(so + 2 * poff), v3[i] = ld(so + 3 * poff);
             }
-            pre4_combine4<INV, Q0>(x, v0, v1, v2, v3, half);
-            if (half & 1u) mul4_inplace(x, Q0, stw[brev5(Q0)], stw[brev5(Q0 + 1)], stw[brev5(Q0 + 2)], stw[brev5(Q0 + 3)]);
+            pre4_combine4<INV, Q0>(x, v0, v1, v2, v3, half, stw);
         };
         group(std::integral_constant<int, 0>{});
         group(std::integral_constant<int, 4>{});
@@ -458,6 +485,7 @@ __global__ void __launch_bounds__(512, TF_NTT_WAVES) ntt_pass_kernel(const NttPa
         group(std::integral_constant<int, 20>{});
         group(std::integral_constant<int, 24>{});
         group(std::integral_constant<int, 28>{});
+#endif  // TF_AB_BUILD
     } else if (PRE2 && act_in) {
         // the tile's 32 Ki input elements: rows r = g + 32 i in x[], their partner rows r + 1024 eight at a time, combined at once
         const u32 toff = (u32)(((long long)ch_in * A.in_cs_hi + cl_in + (long long)g_in * A.in_rs) * 8);

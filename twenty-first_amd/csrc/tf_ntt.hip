@@ -947,10 +947,15 @@ int launch_pass(const Launch& l, bool inverse, hipStream_t stream) {
             t_last_error = "internal: radix-4 last pass (PRE4) launch outside the shapes it supports";
             return TF_ERR_HIP;
         }
+#ifdef TF_AB_BUILD
         Launch l2 = l;
         l2.lds_bytes = std::max(l.lds_bytes, kLast1024LdsBytes);
         l2.threads = 512;
         return launch_pass_t<false, 0, 0, true, false, false, false, true>(l2, stream);
+#else
+        t_last_error = "internal: radix-4 last pass (PRE4) planned in the product build";
+        return TF_ERR_HIP;
+#endif
     }
     if (l.a.pre2_map) {
         // a 2048-point pass as two 1024-point halves per tile (ntt_kernels.h, PRE2): only planned by run_ntt when all of this holds
@@ -1204,18 +1209,26 @@ bool pre2_plan_ok(int log_n, int L, size_t n, size_t cosets, bool has_in2, long 
     if (g_min_passes.load(std::memory_order_relaxed) > 2) return false;
     return (unsigned long long)n * L * 8 + (1ull << 20) < (1ull << 32);              // buffer addressing (fits_buffer_offsets)
 }
-// 2^22 points as 1024 x 4096 with the 4096-point LAST pass run as four 1024-point classes per tile (ntt_kernels.h, PRE4):
-// the plan of a forward transform WITH WORK ON LOAD (fast_coset_evaluate's scaling, zero padding) -- its first pass is then an
-// ordinary 1024-point column pass that scales every coefficient once, where the 2048 x 2048 plan scales it in both workgroups
-// of a PRE2 pair.  mode 2 of tf_set_ntt_two_pass forces it for every forward 2^22-point transform (tests), mode 1 forbids it.
+// 2^22 points as 1024 x 4096 with the 4096-point LAST pass run as four 1024-point classes per tile (ntt_kernels.h, PRE4) -- round 4's
+// attempt on BASELINE configs[3]: the first pass of a coset evaluation is then an ordinary 1024-point column pass that scales every
+// coefficient once, where the 2048 x 2048 plan scales it in both workgroups of a PRE2 pair.  MEASURED (profiles/r04_c4_plan_ab.txt,
+// 64 x 2^22 XFE, per 16-polynomial tile): the first pass does get cheaper, 1 194 -> 981 us, but the radix-4 load stage costs the last
+// pass more than that, 752 -> 1 047 us (four reads of every input through the L2 in bursts of 16, 27 more instructions per element):
+// 7.9 ms against 7.6 -- a loss, so the product never plans it.  Laboratory build: TF_NTT_PRE4 in the environment makes it the
+// automatic plan of fast_coset_evaluate at 2^22, tf_set_ntt_two_pass(2) of every forward 2^22-point transform.
 bool pre4_plan_ok(int log_n, int L, size_t n, size_t cosets, bool has_in2, long long n_out, bool inverse, bool load_work, bool store_scale) {
-    static const bool off = ab_env("TF_NTT_NO_PRE4") != nullptr;  // A/B switch
+#ifdef TF_AB_BUILD
+    static const bool on = ab_env("TF_NTT_PRE4") != nullptr;
     const int mode = g_pre2_mode.load(std::memory_order_relaxed);
-    if (mode == 0 || mode == 1 || (mode < 0 && (off || !load_work))) return false;
+    if (mode == 0 || mode == 1 || (mode < 0 && !(on && load_work))) return false;
     if (log_n != 22 || cosets != 1 || has_in2 || n_out >= 0 || inverse || store_scale) return false;
     if (!last1024_enabled() || ablate_mode() != 0 || wg_threads() != 512) return false;
     if (g_min_passes.load(std::memory_order_relaxed) > 2) return false;
     return (unsigned long long)n * L * 8 + (1ull << 20) < (1ull << 32);              // buffer addressing (fits_buffer_offsets)
+#else
+    (void)log_n, (void)L, (void)n, (void)cosets, (void)has_in2, (void)n_out, (void)inverse, (void)load_work, (void)store_scale;
+    return false;
+#endif
 }
 void pre2_split(int log_n, int (&a)[4]) {
     // 2^21: the 2048-point pass last (the first pass of a coset evaluation then scales every coefficient once); 2^22: both
