@@ -32,7 +32,7 @@ for f in glob.glob(os.path.join(src, "pmc_sq/**/*counter_collection.csv"), recur
                 trees += 1
 # configs[3]: the two PRE2 pass kernels of the 64 x 2^22 XFE coset evaluation (SCALE 1 column pass, LAST1024 pass)
 coset_busy = [e["derived"]["valu_busy_frac_at_4_cycles"] for k, e in summ["kernels"].items()
-              if "ntt_pass_kernel" in k and k.rstrip(">").endswith("true") and "valu_busy_frac_at_4_cycles" in e.get("derived", {})
+              if "ntt_pass_kernel" in k and "valu_busy_frac_at_4_cycles" in e.get("derived", {})
               and (k.startswith("ntt_pass_kernel<false, 1, 0, false, true, false, true") or k.startswith("ntt_pass_kernel<false, 0, 0, true, false, false, true"))]
 rec = {"library": library, "coset_eval_valu_busy_frac_at_4_cycles": coset_busy or None, "source": f"rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_VALU ... (tools/prof_r02.sh {tag} -> profiles/{tag}_rocprof_summary.json): SQ_INSTS_VALU summed over the dispatches of one step / one tree",
        "ntt_valu_wave_instr_per_transform_2p20": ntt / 256, "ntt_valu_instr_per_element": ntt * 64 / 2 ** 28,
