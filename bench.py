@@ -264,12 +264,6 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    if rank == 0 and not args.no_cpu_baseline:
-        # the timed CPU legs run the oracle built -O3 -march=native on THIS host: it has to be chosen before the oracle library is
-        # first loaded (the parity checks load it too).  Rank 0 times; the other ranks only check parity, on the portable build.
-        from oracle import tfo
-
-        tfo.use_native_build()
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != max(1, args.gpus):
         raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE={world}")
@@ -304,6 +298,20 @@ def main():
         t = torch.tensor([seconds], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
+
+    if not args.no_cpu_baseline:
+        # The oracle is loaded by every rank (each checks its own shard).  Rank 0 goes first: it rebuilds the portable library if it is
+        # stale -- so that no two ranks ever run the compiler on the same file -- and then switches ITSELF to the -O3 -march=native build
+        # for the timed CPU legs (which has to be chosen before the oracle is first loaded); the other ranks load the portable one after.
+        from oracle import tfo
+
+        if rank == 0:
+            tfo.build()
+            tfo.use_native_build()
+            tfo.lib()
+        barrier()
+        if rank != 0:
+            tfo.lib()
 
     ctx = dict(tf=tf, torch=torch, dist=dist, np=np, dev=dev, world=world, rank=rank, use_dist=use_dist, barrier=barrier,
                max_over_ranks=max_over_ranks, args=args, ident=library_identity(tf), cpu_cache={})
