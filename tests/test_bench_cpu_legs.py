@@ -1,0 +1,54 @@
+"""bench.py's CPU legs and record-matching logic, exercised without a GPU at small sizes: the oracle timings the bench reports as
+`cpu_baseline` (kind "port") must run and return what the parity checks compare with, and a stored profile must only be quoted for
+the library build it was taken on."""
+import importlib.util
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench():
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_cpu_baseline_legs_run_and_return_oracle_words(oracle):
+    b = _bench()
+    info, _ = b.cpu_baseline_ntt(10, 8, b.SEED_C2)
+    assert info["kind"] == "port" and info["unit"] == "GFelts/s" and info["value"] > 0 and info["cores"] >= 1 and "build_flags" in info
+    info, root, nodes = b.cpu_baseline_merkle(1 << 10, b.SEED_C3)
+    want = oracle.merkle_build(oracle.fill_random(5 << 10, b.SEED_C3))
+    assert np.array_equal(nodes, want) and np.array_equal(root, want[5:10]) and info["unit"] == "leaves/s"
+    off = oracle.bfe_new(7)
+    info, want0 = b.cpu_baseline_coset(1 << 10, 4, b.SEED_C4, off)
+    assert np.array_equal(want0, oracle.coset_evaluate(oracle.fill_random(3 << 10, b.SEED_C4), off, 1 << 10, width=3))
+    assert info["unit"] == "G points/s" and info["cores"] >= 1 and info["single_thread_value"] > 0
+
+
+def test_stored_profile_is_quoted_only_for_the_build_it_was_taken_on():
+    b = _bench()
+    ident = {"tf_version": 1001, "source_hash": "0123456789abcdef"}
+    assert b.profile_matches({"library": dict(ident)}, ident)
+    assert not b.profile_matches({"library": {"tf_version": 1001, "source_hash": "fedcba9876543210"}}, ident)
+    assert not b.profile_matches({"library": {"tf_version": 1000, "source_hash": "0123456789abcdef"}}, ident)
+    assert not b.profile_matches({"library": None}, ident) and not b.profile_matches({}, ident) and not b.profile_matches(None, ident)
+
+
+def test_library_reports_the_hash_of_its_sources(tf):
+    """tf_source_hash() (no device needed) is the first 16 hex digits of the SHA-256 of the csrc sources in the Makefile's order."""
+    import hashlib
+    import re
+
+    csrc = os.path.join(ROOT, "twenty-first_amd", "csrc")
+    mk = open(os.path.join(csrc, "Makefile")).read()
+    common = re.search(r"^COMMON := (.*)$", mk, re.M).group(1).split()
+    sources = re.search(r"^SOURCES := (.*)$", mk, re.M).group(1).replace("$(COMMON)", " ".join(common)).split()
+    h = hashlib.sha256()
+    for name in sorted(sources):
+        h.update(open(os.path.join(csrc, name), "rb").read())
+    got = tf.lib().tf_source_hash().decode()
+    assert got in (h.hexdigest()[:16], h.hexdigest()[:16] + "-ab"), "libtf_hip.so is older than its sources: rebuild (make -C twenty-first_amd/csrc)"
