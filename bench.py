@@ -594,6 +594,9 @@ def merkle_leg(ctx):
                            "achieved": round(gw, 1), "peak": VALU_PEAK_GWIPS, "unit": "G wave-instr/s", "frac": round(gw / VALU_PEAK_GWIPS, 3),
                            "wave_instr_per_tree": wi, "valu_instr_per_hash_pair": round(wi * 64.0 / (nl - 1), 1),
                            "frac_at_2_cycle_issue": round(gw / (2 * VALU_PEAK_GWIPS), 3),
+                           "status": "at its instruction floor: 8 093 VALU instructions per hash_pair (48 Montgomery products for x^7, 512 multiply-adds "
+                                     "for the MDS, the byte look-ups and one recombination per word, per round), the vector ALU issuing every cycle it is "
+                                     "offered; the alternatives (Karatsuba / CRT MDS) were built and measured slower (DESIGN.md 4.3)",
                            "source": "instruction count: SQ_INSTS_VALU under rocprofv3 --pmc (profiles/valu_counts.json, a stored profile of this library build, NOT this run) x "
                                      "this run's time.  `peak` prices every instruction at 4 cycles per wave64 (1024 SIMDs x 2.4 GHz / 4), "
                                      "frac_at_2_cycle_issue at the 2-cycle rate of plain 32-bit VALU; the Tip5 mix (v_mad_u64_u32 and carry chains at 4 "
