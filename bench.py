@@ -246,6 +246,8 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="headline NTT leg only (no Merkle / coset-evaluation / config-5 legs)")
     ap.add_argument("--c5-ntts", type=int, default=4096, help="config 5: transforms of 2^20 points in the whole job")
     ap.add_argument("--c5-trees", type=int, default=256, help="config 5: trees of 2^20 leaves in the whole job")
+    ap.add_argument("--c5-log-n", type=int, default=20, help="diagnostic: log2 of config 5's transform length and leaves per tree (BASELINE: 20; the record names the size)")
+    ap.add_argument("--merkle-log-leaves", type=int, default=24, help="diagnostic: log2 of the Merkle leg's leaves per tree (BASELINE: 24; the record names the size)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -548,7 +550,8 @@ def merkle_leg(ctx):
     world, rank, barrier, use_dist = ctx["world"], ctx["rank"], ctx["barrier"], ctx["use_dist"]
     from twenty_first_amd import sharding
 
-    nl = 1 << 24
+    log_nl = args.merkle_log_leaves
+    nl = 1 << log_nl
     leaves = torch.empty(5 * nl, dtype=torch.int64, device=dev)
     tf.device.fill_random(leaves, SEED_C3, first_index=rank * 5 * nl)
     nodes = torch.empty(10 * nl, dtype=torch.int64, device=dev)
@@ -580,14 +583,14 @@ def merkle_leg(ctx):
         "scaling": "weak",
         "ms_per_step": round(ms, 4),
         "device_ms_per_tree": round(e0.elapsed_time(e1) / iters, 4),
-        "config": {"workload": "one 2^24-leaf Tip5 Merkle tree per GPU: hash_pair ladder to the full 2^25-node array (BASELINE configs[2])"
+        "config": {"workload": f"one 2^{log_nl}-leaf Tip5 Merkle tree per GPU: hash_pair ladder to the full 2^{log_nl + 1}-node array" + (" (BASELINE configs[2])" if log_nl == 24 else " (NOT the BASELINE size)")
                                + ("; roots all-gathered over RCCL inside the timed region" if use_dist else ""),
                    "inputs": f"SplitMix64, seed 0x{SEED_C3:X}"},
         "hbm_frac_at_120B_per_leaf": round(120.0 * nl / (e0.elapsed_time(e1) / iters * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
     }
     vc = load_profile_json("valu_counts.json")
     res["profile_matches_library"] = {"valu_counts.json": bool(vc) and profile_matches(vc, ctx["ident"])}
-    if vc and profile_matches(vc, ctx["ident"]) and vc.get("merkle_valu_wave_instr_per_tree_2p24"):
+    if vc and profile_matches(vc, ctx["ident"]) and vc.get("merkle_valu_wave_instr_per_tree_2p24") and log_nl == 24:
         wi = vc["merkle_valu_wave_instr_per_tree_2p24"]
         gw = wi / (e0.elapsed_time(e1) / iters * 1e-3) / 1e9
         res["roofline"] = {"bound": "valu", "kernel": "tfk::tip5_hash_pairs_kernel (level sweep) + merkle_top_kernel",
@@ -631,7 +634,7 @@ def merkle_leg(ctx):
             dt = ctx["max_over_ranks"](time.perf_counter() - t0) / iters
             res["single_tree_sharded"] = {"value": round(nl / dt, 1), "unit": "leaves/s", "ms_per_tree": round(dt * 1e3, 4), "scaling": "strong",
                                           "root": tf.Digest.to_hex(sroot.cpu().numpy().view(np.uint64)),
-                                          "note": f"one 2^24-leaf tree over {world} ranks: subtrees of 2^24 / {world} leaves + all_gather of {world} roots + {world.bit_length() - 1} finishing levels"}
+                                          "note": f"one 2^{log_nl}-leaf tree over {world} ranks: subtrees of 2^{log_nl} / {world} leaves + all_gather of {world} roots + {world.bit_length() - 1} finishing levels"}
             del sl, sub_nodes
         except Exception as e:
             res["single_tree_sharded"] = {"error": repr(e)}
@@ -642,7 +645,7 @@ def merkle_leg(ctx):
         from oracle import tfo
 
         cores = os.cpu_count() or 1
-        idx = np.unique(np.concatenate([np.arange(1, 4096), np.random.default_rng(3).integers(1, 2 * nl, 1 << 16)]))
+        idx = np.unique(np.concatenate([np.arange(1, min(4096, 2 * nl)), np.random.default_rng(3).integers(1, 2 * nl, 1 << 16)]))
         got_root = roots[rank if use_dist else 0].cpu().numpy().view(np.uint64)
         got_nodes = nodes.view(-1, 5)[torch.from_numpy(idx).to(dev)].cpu().numpy().view(np.uint64)
         ok = True
@@ -751,7 +754,8 @@ def config5_leg(ctx, steps, warmup, headline):
     world, rank, barrier, use_dist = ctx["world"], ctx["rank"], ctx["barrier"], ctx["use_dist"]
     from twenty_first_amd import sharding
 
-    n = nl = 1 << 20
+    log_n5 = args.c5_log_n
+    n = nl = 1 << log_n5
     t_lo, t_hi = sharding.shard_range(args.c5_ntts, world, rank)
     m_lo, m_hi = sharding.shard_range(args.c5_trees, world, rank)
     nt, nm = t_hi - t_lo, m_hi - m_lo
@@ -809,8 +813,8 @@ def config5_leg(ctx, steps, warmup, headline):
         "vs_baseline": None,
         "dtype": "u64",
         "data": "synthetic",
-        "config": {"workload": f"{args.c5_ntts} x 2^20-point BFE NTTs + {args.c5_trees} x 2^20-leaf Tip5 Merkle trees, the whole job split contiguously over "
-                               f"{world} GPU(s), roots all-gathered (BASELINE configs[4])",
+        "config": {"workload": f"{args.c5_ntts} x 2^{log_n5}-point BFE NTTs + {args.c5_trees} x 2^{log_n5}-leaf Tip5 Merkle trees, the whole job split contiguously over "
+                               f"{world} GPU(s), roots all-gathered" + (" (BASELINE configs[4])" if (log_n5, args.c5_ntts, args.c5_trees) == (20, 4096, 256) else " (NOT the BASELINE shape)"),
                    "ntts_this_rank": nt, "trees_this_rank": nm,
                    "parallelism": f"contiguous batch split x{world} (sharding.shard_range); one RCCL all_gather of 40-byte roots per step",
                    "inputs": f"SplitMix64, seed 0x{SEED_C5:X}"},
@@ -857,7 +861,7 @@ def config5_leg(ctx, steps, warmup, headline):
     ok = ok and check_tree_units(ctx, SEED_C5 ^ (1 << 40), tree_units, nl, threads=th)
     # ... and the gathered roots of those trees are the ones this rank just rebuilt and checked node by node
     all_ok = sharding_all_true(ctx, ok)
-    res["parity"] = ((f"bit-exact vs oracle on every rank: first + last transform and first + last tree (all 2^21 nodes) of each of the {world} shard(s), "
+    res["parity"] = ((f"bit-exact vs oracle on every rank: first + last transform and first + last tree (all 2^{log_n5 + 1} nodes) of each of the {world} shard(s), "
                       "and the roots digest (oracle hash_varlen of the gathered roots)") if all_ok else "MISMATCH")
     if not all_ok:
         raise SystemExit(f"rank {rank}: config 5 differs from the oracle" if not ok else f"rank {rank}: another rank reported a config-5 mismatch")
@@ -865,10 +869,11 @@ def config5_leg(ctx, steps, warmup, headline):
     if rank == 0:
         # CPU baseline on a REDUCED sample of the job (the whole job is 4096 transforms + 256 trees: ~3 minutes of host time):
         # 256 of the 4096 transforms, one per thread (the headline's CPU leg when it ran in this process), and 4 of the 256 trees
-        info = ctx["cpu_cache"].get(("ntt", 20, 256))
+        nb5 = min(256, args.c5_ntts)
+        info = ctx["cpu_cache"].get(("ntt", log_n5, nb5))
         reused = info is not None
         if info is None:
-            info, _ = cpu_baseline_ntt(20, 256, SEED_C5)
+            info, _ = cpu_baseline_ntt(log_n5, nb5, SEED_C5)
         info = dict(info)
         tfo.use_native_build()
         lv = tfo.fill_random(5 * nl, SEED_C5 ^ (1 << 40))
@@ -878,8 +883,8 @@ def config5_leg(ctx, steps, warmup, headline):
             tfo.merkle_build(lv, threads=tth)
             tried[tth] = nl / (time.perf_counter() - t0)
         bt = max(tried, key=tried.get)
-        info["sample"] = ("REDUCED sample of the job: NTT = 256 of the 4096 transforms" + (" (the headline leg's timing, same shape, this process)" if reused else "")
-                          + "; " + info["sample"] + f" | Merkle = 1 of the {args.c5_trees} trees (2^20 leaves, par_new restatement), best of "
+        info["sample"] = (f"REDUCED sample of the job: NTT = {nb5} of the {args.c5_ntts} transforms" + (" (the headline leg's timing, same shape, this process)" if reused else "")
+                          + "; " + info["sample"] + f" | Merkle = 1 of the {args.c5_trees} trees (2^{log_n5} leaves, par_new restatement), best of "
                           + ", ".join(f"{k} threads: {v / 1e6:.2f} M" for k, v in tried.items()) + " leaves/s"
                           + (f"; timed on rank 0 while the other {world - 1} rank(s) wait at a barrier" if world > 1 else ""))
         info["merkle_value"] = round(tried[bt], 1)
