@@ -282,7 +282,7 @@ def test_hadamard_bfe_alignment_and_odd_counts(tf, oracle, count, shift):
 @pytest.mark.parametrize("n_rows,n_cols", [(1, 1), (8, 0), (8, 3), (64, 10), (256, 7), (1 << 12, 11), (1 << 16, 4)])
 def test_rows_of_column_major_tables(tf, oracle, width, n_rows, n_cols):
     """hash_varlen (tip5/mod.rs:617-623) of the rows of a column-major table (XFE rows flattened as
-    x_field_element.rs:217-231) and the tree over them; both kernel shapes (16 lanes per row up to 2^15 rows)"""
+    x_field_element.rs:217-231) and the tree over them; both kernel shapes (16 lanes per row up to 2^13 rows)"""
     cols = oracle.fill_random(max(1, n_cols * n_rows * width), 60 + n_rows + n_cols)[: n_cols * n_rows * width]
     # the same table row-major on the host: row i = [col_0[i], col_1[i], ...]
     rows = cols.reshape(n_cols, n_rows, width).transpose(1, 0, 2).reshape(-1) if n_cols else np.zeros(0, dtype=np.uint64)
@@ -315,6 +315,26 @@ def test_column_major_tables_on_device_with_stride_and_batch(tf, oracle):
         want = oracle.hash_varlen_rows(rows, n_cols * width)
         assert np.array_equal(gd[b * 5 * n_rows:(b + 1) * 5 * n_rows], want)
         assert np.array_equal(gn[b * 10 * n_rows:(b + 1) * 10 * n_rows], oracle.merkle_build(want))
+
+
+@pytest.mark.parametrize("width", [1, 3])
+def test_column_major_tables_odd_row_counts_in_batches(tf, oracle, width):
+    """hash_table_rows of a batch of tables whose row count is NOT a power of two, with more rows in total than the 16-lane
+    kernels take: the matrix-pipe kernel finds (table, row) of an item by division, and its last wave is ragged"""
+    import torch
+
+    n_rows, n_cols, batch = 3001, 4, 5
+    cs = n_rows * width + 3
+    raw = oracle.fill_random(batch * n_cols * cs, 72 + width)
+    dt = torch.from_numpy(raw.view(np.int64)).cuda()
+    digs = torch.empty(batch * 5 * n_rows, dtype=torch.int64, device="cuda")
+    tf.device.hash_table_rows(dt, n_rows, n_cols, digs, width=width, col_stride=cs, batch=batch)
+    torch.cuda.synchronize()
+    gd = digs.cpu().numpy().view(np.uint64)
+    for b in range(batch):
+        t = raw[b * n_cols * cs:(b + 1) * n_cols * cs].reshape(n_cols, cs)[:, : n_rows * width].reshape(n_cols, n_rows, width)
+        rows = t.transpose(1, 0, 2).reshape(-1)
+        assert np.array_equal(gd[b * 5 * n_rows:(b + 1) * 5 * n_rows], oracle.hash_varlen_rows(rows, n_cols * width))
 
 
 @pytest.mark.parametrize("width", [1, 3])

@@ -516,21 +516,61 @@ def test_sponge_absorb_squeeze_matches_oracle(tf, oracle, length):
     assert list(fixed.state[0]) == [0] * 10 + [0xFFFFFFFF] * 6  # Tip5::new(Domain::FixedLength), mod.rs:511-526
 
 
-@pytest.mark.parametrize("count", [1, 15, 17, 32768, 32769, 40000])
+@pytest.mark.parametrize("count", [1, 15, 17, 8192, 8193, 8207, 8208, 40000, 65599])
 def test_tip5_both_kernel_shapes_match_oracle(tf, oracle, count):
-    """launches of <= 2^15 permutation chains run 16 lanes per permutation, larger ones one lane per permutation:
-    permutation, hash_pair and hash_varlen on both sides of the switch"""
+    """launches of <= 2^13 permutation chains run 16 lanes per permutation, larger ones in the matrix-pipe form (4 lanes per
+    permutation, 16 permutations per wave: counts that are not multiples of 16 leave clamped lanes in the last wave):
+    permutation, hash_pair and hash_varlen on both sides of the switch, every output word"""
     states = oracle.fill_random(count * 16, 900 + count)
     got = states.copy()
     tf.Tip5.permute_states(got)
-    idx = sorted(set([0, min(1, count - 1), count // 2, count - 1]))
+    idx = range(count) if count <= 8300 else sorted(set([0, 1, 15, 16, count // 2, count - 17, count - 16, count - 2, count - 1]))
     for i in idx:
         assert np.array_equal(got[16 * i:16 * i + 16], oracle.tip5_permutation(states[16 * i:16 * i + 16]))
     pairs = states[:count * 10]
     assert np.array_equal(tf.Tip5.hash_pairs(pairs), oracle.hash_pairs(pairs))
-    for row_len in (0, 7, 13):
-        rows = states[:count * row_len]
+    for row_len in (0, 7, 10, 13, 29):
+        rows = oracle.fill_random(count * row_len, 901 + count)
         assert np.array_equal(tf.Tip5.hash_varlen_rows(rows, row_len), oracle.hash_varlen_rows(rows, row_len))
+
+
+def test_tip5_matrix_pipe_extreme_words(tf, oracle):
+    """the matrix-pipe MDS is exact f64 arithmetic on 32-bit halves: states of the largest canonical words (p - 1, 2^32 - 1 halves),
+    zeros and single non-zero words, in a launch large enough for that kernel"""
+    count = 8192 + 64
+    p = (1 << 64) - (1 << 32) + 1
+    states = oracle.fill_random(count * 16, 4242).reshape(count, 16)
+    states[0, :] = p - 1
+    states[1, :] = 0
+    states[2, :] = 0xFFFFFFFF
+    states[3, :] = 0xFFFFFFFF00000000
+    for k in range(16):
+        states[4 + k, :] = 0
+        states[4 + k, k] = p - 1
+    states[20, ::2] = p - 1
+    states[21, 1::2] = 0xFFFFFFFEFFFFFFFF
+    flat = states.reshape(-1).copy()
+    got = flat.copy()
+    tf.Tip5.permute_states(got)
+    for i in list(range(24)) + [count - 1]:
+        assert np.array_equal(got[16 * i:16 * i + 16], oracle.tip5_permutation(flat[16 * i:16 * i + 16]))
+
+
+@pytest.mark.parametrize("count", [1, 33, 9000])
+def test_tip5_trace_matrix_pipe(tf, oracle, count):
+    """Tip5::trace (mod.rs:538-548) runs in the matrix-pipe form at every size: all six states of every permutation"""
+    import torch
+
+    states = oracle.fill_random(count * 16, 950 + count)
+    d = torch.from_numpy(states.view(np.int64)).cuda()
+    tr = torch.empty(count * 96, dtype=torch.int64, device="cuda")
+    tf.device.tip5_trace_(d, tr)
+    torch.cuda.synchronize()
+    got_tr, got_st = tr.cpu().numpy().view(np.uint64), d.cpu().numpy().view(np.uint64)
+    for i in (range(count) if count < 100 else [0, 15, 16, 4500, count - 9, count - 1]):
+        want, after = oracle.tip5_trace(states[16 * i:16 * i + 16])
+        assert np.array_equal(got_tr[96 * i:96 * i + 96], want.reshape(-1))
+        assert np.array_equal(got_st[16 * i:16 * i + 16], after)
 
 
 def test_hash_varlen_one_long_input(tf, oracle):

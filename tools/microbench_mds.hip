@@ -5,7 +5,11 @@
 //      a_i +- a_{i+8} must stay below 32 bits, which two 32-bit halves do not): x^16 - 1 = (x^8 - 1)(x^8 + 1), the cyclic half
 //      computed once (64 mads) and used as the addend of both signed negacyclic chains (2 x 64 v_mad_i64_i32) -- no post-additions
 //      at all, 3 x 192 = 576 mads + limb split + pre-additions
-// Both are checked against 128-bit arithmetic first.  The question: does the Karatsuba / CRT shape beat 512
+//   C  (round 5) the FP64 matrix pipe: 4 lanes per permutation (lane l: hash column j = l & 15, quarter q = l >> 4, state words
+//      4 i + q in register i), the two 32-bit halves of every word converted with v_cvt_f64_u32 and multiplied by the constant
+//      circulant with 8 x v_mfma_f64_16x16x4_f64 per 16 permutations (products < 2^48, sums of 16 < 2^52: exact in f64; the
+//      accumulator starts at 2^52 so the mantissa of the result IS the integer sum), then the same 85-bit recombination
+// All are checked against 128-bit arithmetic first.  The question: does the Karatsuba / CRT shape beat 512
 // multiply-adds on this ISA?  On gfx950 a 64-bit addition costs as much as a multiply-add (profiles/r03_instr_rates.txt), so
 // every saved product that needs a post-addition is a wash; the variant that needs none needs a third limb.
 //   build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I twenty-first_amd/csrc -o tools/microbench_mds tools/microbench_mds.hip
@@ -13,13 +17,15 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#include <cstring>
 #include "gl64.h"
+#include "tip5_kernels.h"  // the shipping lane-per-permutation round (tfk::tip5_permutation) and its constant block
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1);} } while (0)
 using gl::u32;
 using gl::u64;
 typedef long long i64;
 
-__host__ __device__ constexpr u32 mds_entry(int i) {
+__host__ __device__ constexpr u32 mds_entry_hd(int i) {
     constexpr u32 col[16] = {61402, 1108, 28750, 33823, 7454, 43244, 53865, 12034, 56951, 27521, 41351, 40901, 12021, 59689, 26798, 17845};
     return col[i & 15];
 }
@@ -46,7 +52,7 @@ __device__ __forceinline__ void mds_a(u64 (&s)[16]) {
         u64 alo = 0, ahi = 0;
 #pragma unroll
         for (int c = 0; c < 16; ++c) {
-            const u32 m = mds_entry(16 + r - c);
+            const u32 m = mds_entry_hd(16 + r - c);
             alo += (u64)m * lo[c];
             ahi += (u64)m * hi[c];
         }
@@ -65,13 +71,13 @@ __device__ __forceinline__ void crt_limb(const u32 (&a)[16], i64 (&out)[16]) {
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
             const int k = (r - c) & 7;
-            p += (i64)(int)(mds_entry(k) + mds_entry(k + 8)) * ap[c];
+            p += (i64)(int)(mds_entry_hd(k) + mds_entry_hd(k + 8)) * ap[c];
         }
         i64 q0 = p, q1 = p;  // negacyclic half with both signs, accumulated straight onto the cyclic one
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
             const int k = (r - c) & 7;
-            const int mm = (int)mds_entry(k) - (int)mds_entry(k + 8);
+            const int mm = (int)mds_entry_hd(k) - (int)mds_entry_hd(k + 8);
             const int sg = (r - c) < 0 ? -mm : mm;
             q0 += (i64)sg * am[c];
             q1 -= (i64)sg * am[c];
@@ -111,8 +117,58 @@ __device__ __forceinline__ void mds_b(u64 (&s)[16]) {
     }
 }
 
+// ---- variant C: FP64 matrix pipe ------------------------------------------------------------------------------------
+typedef double d4 __attribute__((ext_vector_type(4)));
+constexpr u64 MASK52 = (1ull << 52) - 1;
+__device__ __forceinline__ u64 dbits(double d) { return (u64)__double_as_longlong(d); }
+
+// per-lane A operands: K-block i, lane (r = l & 15, k = l >> 4) holds M[(r - 4 i - k) mod 16]
+__device__ __forceinline__ void mds_a_operands(double (&a)[4]) {
+    const int l = threadIdx.x & 63, r = l & 15, k = l >> 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int e = (r - 4 * i - k) & 15;
+        u32 m = 0;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) m = (e == t) ? mds_entry_hd(t) : m;
+        a[i] = (double)m;
+    }
+}
+
+// s[i] = word 4 i + q of the permutation in column j.  c_lo / c_hi: accumulator start (2^52, or 2^52 + a round-constant half).
+__device__ __forceinline__ void mds_c(u64 (&s)[4], const double (&a)[4], d4 c_lo, d4 c_hi) {
+    double lo[4], hi[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) lo[i] = (double)(u32)s[i], hi[i] = (double)(u32)(s[i] >> 32);
+    d4 dlo = c_lo, dhi = c_hi;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        dlo = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], lo[i], dlo, 0, 0, 0);
+        dhi = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], hi[i], dhi, 0, 0, 0);
+    }
+#pragma unroll
+    for (int v = 0; v < 4; ++v) s[v] = fold85(dbits(dlo[v]) & MASK52, dbits(dhi[v]) & MASK52);
+}
+
 template <int V>
 __global__ void __launch_bounds__(256) bench(u64* out, int iters, u64 seed) {
+    if (V == 2) {
+        u64 s[4];
+        double a[4];
+        mds_a_operands(a);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            u64 z = seed + (u64)(blockIdx.x * 256 + threadIdx.x) * 4 + i;
+            z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL;
+            s[i] = z ^ (z >> 27);
+        }
+        const double two52 = 4503599627370496.0;
+        const d4 c = {two52, two52, two52, two52};
+#pragma unroll 1
+        for (int it = 0; it < iters; ++it) mds_c(s, a, c, c);
+        out[blockIdx.x * 256 + threadIdx.x] = s[0] ^ s[1] ^ s[2] ^ s[3];
+        return;
+    }
     u64 s[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
@@ -138,11 +194,127 @@ __global__ void check(const u64* in, int* bad) {
     mds_b(b);
     for (int r = 0; r < 16; ++r) {
         unsigned __int128 acc = 0;
-        for (int c = 0; c < 16; ++c) acc += (unsigned __int128)mds_entry(16 + r - c) * x[c];
+        for (int c = 0; c < 16; ++c) acc += (unsigned __int128)mds_entry_hd(16 + r - c) * x[c];
         const u64 want = (u64)(acc % gl::P);
         if (a[r] != want) atomicOr(bad, 1);
         if (b[r] != want) atomicOr(bad, 2);
     }
+}
+
+// variant C against 128-bit arithmetic: wave w of the grid takes states 16 w .. 16 w + 15
+__global__ void __launch_bounds__(256) check_c(const u64* in, int* bad) {
+    const int l = threadIdx.x & 63, j = l & 15, q = l >> 4;
+    const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const u64* x = in + (wave * 16 + j) * 16;
+    u64 s[4];
+    double a[4];
+    mds_a_operands(a);
+    for (int i = 0; i < 4; ++i) s[i] = x[4 * i + q];
+    const double two52 = 4503599627370496.0;
+    const d4 c = {two52, two52, two52, two52};
+    mds_c(s, a, c, c);
+    for (int v = 0; v < 4; ++v) {
+        const int r = 4 * v + q;
+        unsigned __int128 acc = 0;
+        for (int cc = 0; cc < 16; ++cc) acc += (unsigned __int128)mds_entry_hd(16 + r - cc) * x[cc];
+        if (s[v] != (u64)(acc % gl::P)) atomicOr(bad, 4);
+    }
+}
+
+// ---- raw rates: v_mfma_f64_16x16x4_f64 (independent / dependent accumulators) and v_cvt_f64_u32 -----------------------
+template <int CHAINS>
+__global__ void __launch_bounds__(256) mfma_rate(double* out, int iters) {
+    d4 acc[CHAINS];
+    const double a = 1.0 + threadIdx.x, b = 0.5;
+#pragma unroll
+    for (int c = 0; c < CHAINS; ++c) acc[c] = d4{0, 0, 0, 0};
+#pragma unroll 1
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int r = 0; r < 8 / CHAINS * 2; ++r)
+#pragma unroll
+            for (int c = 0; c < CHAINS; ++c) acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[c], 0, 0, 0);
+    }
+    double t = 0;
+#pragma unroll
+    for (int c = 0; c < CHAINS; ++c) t += acc[c][0] + acc[c][1] + acc[c][2] + acc[c][3];
+    out[blockIdx.x * 256 + threadIdx.x] = t;
+}
+
+__global__ void __launch_bounds__(256) cvt_rate(double* out, int iters, u32 seed) {
+    u32 x[12];
+    double d[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) x[i] = seed * (i + 3) + threadIdx.x, d[i] = 0;
+#pragma unroll 1
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int i = 0; i < 12; ++i) asm volatile("v_cvt_f64_u32 %0, %1" : "=v"(d[i]) : "v"(x[i]));
+    }
+    double t = 0;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) t += d[i];
+    out[blockIdx.x * 256 + threadIdx.x] = t;
+}
+
+// mont_mul3 on operands that are NOT canonical (any 64-bit words): the result must be congruent to a b 2^-64 -- what the lazy
+// recombination of the matrix-pipe round relies on (tip5_kernels.h, mx_fold4<false>)
+__global__ void __launch_bounds__(256) check_mm3(const u64* in, int* bad) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    u64 a[3], b[3], r[3];
+    for (int k = 0; k < 3; ++k) {
+        a[k] = in[i * 16 + k] | 0xffffffff00000000ULL;       // >= p unless the low word is 0
+        b[k] = (k == 1) ? a[k] : (in[i * 16 + 3 + k] | ((i & 1) ? 0xffffffff00000000ULL : 0));  // a square, and mixed pairs
+    }
+    gl::mont_mul3(a, b, r);
+    for (int k = 0; k < 3; ++k) {
+        const unsigned __int128 prod = (unsigned __int128)(a[k] % gl::P) * (b[k] % gl::P);
+        // want = prod * 2^-64 mod p; check r * 2^64 == prod (mod p)
+        const u64 lhs = (u64)((((unsigned __int128)(r[k] % gl::P)) << 64) % gl::P), rhs = (u64)(prod % gl::P);
+        if (lhs != rhs) atomicOr(bad, 16);
+    }
+}
+
+// ---- whole permutations: the lane-per-permutation round against the matrix-pipe round of tip5_kernels.h --------------------
+// NS = permutations per lane quartet (1: 16 per wave, 2: 32 per wave).
+// states: count x 16 words.  A block of 256 threads = 4 waves; a wave takes 16 NS consecutive states.
+template <int NS>
+__global__ void __launch_bounds__(256) perm_mx_kernel(u64* states, long long count, int reps) {
+    __shared__ __attribute__((aligned(32))) tfk::Tip5MxLds lds;
+    tfk::stage_mx(&lds);
+    const int l = threadIdx.x & 63, j = l & 15, q = l >> 4;
+    const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wave * 16 * NS >= count) return;
+    double a[4];
+    tfk::mx_a_operands(&lds, a);
+    u64 s[4 * NS];
+#pragma unroll
+    for (int n = 0; n < NS; ++n)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s[4 * n + i] = states[((wave * NS + n) * 16 + j) * 16 + 4 * i + q];
+#pragma unroll 1
+    for (int rep = 0; rep < reps; ++rep) tfk::tip5_permutation_mx<NS>(s, &lds, a, q);
+#pragma unroll
+    for (int n = 0; n < NS; ++n)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) states[((wave * NS + n) * 16 + j) * 16 + 4 * i + q] = s[4 * n + i];
+}
+
+__global__ void __launch_bounds__(256) perm_a_kernel(u64* states, long long count, int reps) {
+    __shared__ __attribute__((aligned(16))) unsigned char lut[256];
+    tfk::stage_lut(lut);
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    u64 s[16];
+    u64* p = states + i * 16;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s[k] = p[k];
+#pragma unroll 1
+    for (int rep = 0; rep < reps; ++rep) tfk::tip5_permutation(s, lut);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) p[k] = s[k];
 }
 
 int main() {
@@ -154,6 +326,7 @@ int main() {
     u64 st = 99;
     for (auto& v : h) { st += 0x9e3779b97f4a7c15ULL; u64 z = st; z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL; z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL; v = z ^ (z >> 31); }
     for (int i = 0; i < 64; ++i) h[i] = (i & 1) ? 0xffffffffffffffffULL : 0xffffffff00000000ULL;  // extreme words (S-box outputs may exceed p)
+    for (int i = 64; i < 128; ++i) h[i] = 0xffffffffffffffffULL;                                    // the largest half-sums
     u64* d_in;
     int* d_bad;
     CK(hipMalloc(&d_in, h.size() * 8));
@@ -161,13 +334,18 @@ int main() {
     CK(hipMemset(d_bad, 0, 4));
     CK(hipMemcpy(d_in, h.data(), h.size() * 8, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(check, dim3(n / 256), dim3(256), 0, 0, d_in, d_bad);
+    hipLaunchKernelGGL(check_c, dim3(n / 64), dim3(256), 0, 0, d_in, d_bad);
+    hipLaunchKernelGGL(check_mm3, dim3(n / 256), dim3(256), 0, 0, d_in, d_bad);
     int bad = 0;
     CK(hipMemcpy(&bad, d_bad, 4, hipMemcpyDeviceToHost));
-    printf("MDS of %d random / extreme states against 128-bit arithmetic: %s (mask %d: 1 = halves, 2 = three-limb CRT)\n", n, bad ? "MISMATCH" : "both bit-exact", bad);
+    printf("MDS of %d random / extreme states (and mont_mul3 on words >= p) against 128-bit arithmetic: %s (mask %d: 1 = halves, 2 = three-limb CRT, 4 = f64 MFMA, 16 = mont_mul3 on non-canonical operands)\n", n,
+           bad ? "MISMATCH" : "all bit-exact", bad);
     u64* d_out;
     CK(hipMalloc(&d_out, (size_t)cus * 8 * 256 * 8));
     const int iters = 400, grid = cus * 8;
-    for (int v = 0; v < 2; ++v) {
+    const char* names[3] = {"A two 32-bit halves, plain circulant (512 mads)", "B three 22-bit limbs, one CRT level (576 mads)",
+                            "C f64 MFMA, 4 lanes per state (8 mfma / 16 states)"};
+    for (int v = 0; v < 3; ++v) {
         float ms = 0;
         for (int rep = 0; rep < 2; ++rep) {
             hipEvent_t e0, e1;
@@ -175,13 +353,116 @@ int main() {
             CK(hipEventCreate(&e1));
             CK(hipEventRecord(e0));
             if (v == 0) hipLaunchKernelGGL(bench<0>, dim3(grid), dim3(256), 0, 0, d_out, iters, 7ull);
-            else hipLaunchKernelGGL(bench<1>, dim3(grid), dim3(256), 0, 0, d_out, iters, 7ull);
+            else if (v == 1) hipLaunchKernelGGL(bench<1>, dim3(grid), dim3(256), 0, 0, d_out, iters, 7ull);
+            else hipLaunchKernelGGL(bench<2>, dim3(grid), dim3(256), 0, 0, d_out, iters * 4, 7ull);
             CK(hipEventRecord(e1));
             CK(hipDeviceSynchronize());
             CK(hipEventElapsedTime(&ms, e0, e1));
         }
-        printf("%s: %8.3f ms for %d x %d MDS layers = %7.2f G MDS/s\n", v ? "B three 22-bit limbs, one CRT level (576 mads)" : "A two 32-bit halves, plain circulant (512 mads)",
-               ms, grid * 256, iters, (double)grid * 256 * iters / (ms * 1e-3) / 1e9);
+        // variant C: a thread is a quarter state and runs 4 x the iterations: the same number of MDS layers per launch
+        printf("%-52s: %8.3f ms for %d x %d MDS layers = %7.2f G MDS/s\n", names[v], ms, grid * 256, iters,
+               (double)grid * 256 * iters / (ms * 1e-3) / 1e9);
+    }
+    // raw rates
+    double* d_d = reinterpret_cast<double*>(d_out);
+    for (int w : {1, 2, 4, 8}) {
+        const int g = cus * w, it = 2000;
+        float ms[3];
+        for (int ch = 0; ch < 3; ++ch) {
+            for (int rep = 0; rep < 2; ++rep) {
+                hipEvent_t e0, e1;
+                CK(hipEventCreate(&e0));
+                CK(hipEventCreate(&e1));
+                CK(hipEventRecord(e0));
+                if (ch == 0) hipLaunchKernelGGL(mfma_rate<1>, dim3(g), dim3(256), 0, 0, d_d, it);
+                else if (ch == 1) hipLaunchKernelGGL(mfma_rate<2>, dim3(g), dim3(256), 0, 0, d_d, it);
+                else hipLaunchKernelGGL(mfma_rate<4>, dim3(g), dim3(256), 0, 0, d_d, it);
+                CK(hipEventRecord(e1));
+                CK(hipDeviceSynchronize());
+                CK(hipEventElapsedTime(&ms[ch], e0, e1));
+            }
+        }
+        // 16 mfma per iteration per wave; w waves per SIMD
+        printf("v_mfma_f64_16x16x4_f64, %d waves/SIMD: ", w);
+        for (int ch = 0; ch < 3; ++ch) {
+            const double per_simd = 16.0 * it * w / (ms[ch] * 1e-3);  // mfma / s / SIMD
+            printf(" %d chain(s) %6.2f M mfma/s/SIMD (%5.1f ns each, %5.1f TFLOP/s chip)", 1 << ch, per_simd / 1e6, 1e9 / per_simd,
+                   per_simd * cus * 4 * 2048 / 1e12);
+        }
+        printf("\n");
+    }
+    for (int w : {4, 8}) {
+        const int g = cus * w, it = 3000;
+        float ms = 0;
+        for (int rep = 0; rep < 2; ++rep) {
+            hipEvent_t e0, e1;
+            CK(hipEventCreate(&e0));
+            CK(hipEventCreate(&e1));
+            CK(hipEventRecord(e0));
+            hipLaunchKernelGGL(cvt_rate, dim3(g), dim3(256), 0, 0, d_d, it, 3u);
+            CK(hipEventRecord(e1));
+            CK(hipDeviceSynchronize());
+            CK(hipEventElapsedTime(&ms, e0, e1));
+        }
+        printf("v_cvt_f64_u32, %d waves/SIMD: %6.3f G wave-instr/s/SIMD\n", w, 48.0 * it * w / (ms * 1e-3) / 1e9);
+    }
+    // whole permutations (arbitrary canonical round constants: the two kernels must agree word for word)
+    {
+        tfk::Tip5Consts c;
+        u64 z = 12345;
+        for (int i = 0; i < 80; ++i) { z = z * 6364136223846793005ULL + 1442695040888963407ULL; c.rc[i] = z % gl::P; }
+        unsigned char lutb[256];
+        for (int x = 0; x < 256; ++x) { u64 xx = (u64)x + 1; lutb[x] = (unsigned char)(((xx * xx * xx) + 256) % 257); }
+        memcpy(c.lut, lutb, 256);
+        CK(hipMemcpyToSymbol(HIP_SYMBOL(tfk::g_tip5), &c, sizeof(c)));
+        const long long count = 1ll << 22;
+        std::vector<u64> hs((size_t)count * 16);
+        for (auto& v : hs) { st += 0x9e3779b97f4a7c15ULL; u64 y = st; y = (y ^ (y >> 30)) * 0xbf58476d1ce4e5b9ULL; y = (y ^ (y >> 27)) * 0x94d049bb133111ebULL; v = (y ^ (y >> 31)) % gl::P; }
+        u64 *d_a, *d_c;
+        CK(hipMalloc(&d_a, hs.size() * 8));
+        CK(hipMalloc(&d_c, hs.size() * 8));
+        CK(hipMemcpy(d_a, hs.data(), hs.size() * 8, hipMemcpyHostToDevice));
+        CK(hipMemcpy(d_c, hs.data(), hs.size() * 8, hipMemcpyHostToDevice));
+        tfk::Tip5MxConsts mx;
+        tfk::fill_tip5_mx(mx, c.rc);
+        CK(hipMemcpyToSymbol(HIP_SYMBOL(tfk::g_tip5_mx), &mx, sizeof(mx)));
+        std::vector<u64> ra(hs.size()), rx(hs.size());
+        hipLaunchKernelGGL(perm_a_kernel, dim3(count / 256), dim3(256), 0, 0, d_a, count, 3);
+        CK(hipMemcpy(ra.data(), d_a, hs.size() * 8, hipMemcpyDeviceToHost));
+        for (int ns = 1; ns <= 2; ++ns) {
+            CK(hipMemcpy(d_c, hs.data(), hs.size() * 8, hipMemcpyHostToDevice));
+            if (ns == 1) hipLaunchKernelGGL(perm_mx_kernel<1>, dim3(count / 64), dim3(256), 0, 0, d_c, count, 3);
+            else hipLaunchKernelGGL(perm_mx_kernel<2>, dim3(count / 128), dim3(256), 0, 0, d_c, count, 3);
+            CK(hipMemcpy(rx.data(), d_c, hs.size() * 8, hipMemcpyDeviceToHost));
+            size_t diff = 0;
+            for (size_t i = 0; i < hs.size(); ++i) diff += ra[i] != rx[i];
+            printf("3 chained permutations of %lld states, matrix-pipe round (%d per lane quartet) against the lane-per-permutation round: %s (%zu words differ)\n",
+                   count, ns, diff ? "MISMATCH" : "bit-exact", diff);
+            if (diff) bad |= 8;
+        }
+        const char* pn[3] = {"permutation, one lane per state (shipping through round 4)", "permutation, matrix pipe, 4 lanes x 1 state (8 mfma / round / wave)",
+                             "permutation, matrix pipe, 4 lanes x 2 states (16 mfma / round / wave)"};
+        // reps = 40: one long launch (sustained clocks, set-up amortised); reps = 1: the shape of a Merkle level (set-up, loads and stores per permutation)
+        for (int reps : {40, 1}) {
+            for (int v = 0; v < 3; ++v) {
+                float ms = 0, best = 1e30f;
+                for (int rep = 0; rep < (reps == 1 ? 6 : 2); ++rep) {
+                    hipEvent_t e0, e1;
+                    CK(hipEventCreate(&e0));
+                    CK(hipEventCreate(&e1));
+                    CK(hipEventRecord(e0));
+                    if (v == 0) hipLaunchKernelGGL(perm_a_kernel, dim3(count / 256), dim3(256), 0, 0, d_a, count, reps);
+                    else if (v == 1) hipLaunchKernelGGL(perm_mx_kernel<1>, dim3(count / 64), dim3(256), 0, 0, d_c, count, reps);
+                    else hipLaunchKernelGGL(perm_mx_kernel<2>, dim3(count / 128), dim3(256), 0, 0, d_c, count, reps);
+                    CK(hipEventRecord(e1));
+                    CK(hipDeviceSynchronize());
+                    CK(hipEventElapsedTime(&ms, e0, e1));
+                    if (ms < best) best = ms;
+                }
+                printf("%-72s: %8.3f ms for %lld x %d permutations = %7.3f G permutations/s\n", pn[v], best, count, reps, (double)count * reps / (best * 1e-3) / 1e9);
+            }
+        }
     }
     return bad ? 1 : 0;
 }
+

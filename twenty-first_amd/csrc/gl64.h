@@ -427,6 +427,61 @@ __device__ __forceinline__ void mont_mul4(const u64 (&a)[4], const u64 (&b)[4], 
 #pragma unroll
     for (int i = 0; i < 4; ++i) r[i] = ((u64)r1[i] << 32) | r0[i];
 }
+
+// Three independent Montgomery products per block (the three x^7 words a lane owns in the matrix-pipe Tip5 layout): mont_mul4
+// without its third chain.  Round-robin over three chains still puts two instructions between a carry mask's write and its read,
+// which is what gfx950 wants, so this block needs no s_nop either.  Same operand contract as mont_mul4.
+__device__ __forceinline__ void mont_mul3(const u64 (&a)[3], const u64 (&b)[3], u64 (&r)[3]) {
+    u64 p[3], h[3], m[3], cm[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const u32 a0 = (u32)a[i], a1 = (u32)(a[i] >> 32), b0 = (u32)b[i], b1 = (u32)(b[i] >> 32);
+        p[i] = (u64)a0 * b0;
+        const u64 q = (u64)a1 * b0;
+        h[i] = (u64)a1 * b1;
+        asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(m[i]), "=s"(cm[i]) : "v"(a0), "v"(b1), "v"(q));
+    }
+    u32 r0[3], r1[3], u[3], w[3];
+    u64 ca, cb, ka, kb, kd;  // carry masks of chains A, B (chain D: vcc) and the masks of the final correction
+#define TF_M3_STEP(A, B, D) A "\n\t" B "\n\t" D "\n\t"
+    asm(TF_M3_STEP("v_add_co_u32_e64 %[ua], %[ca], %[pha], %[mla]", "v_add_co_u32_e64 %[ub], %[cb], %[phb], %[mlb]",
+                   "v_add_co_u32_e32 %[ud], vcc, %[phd], %[mld]")
+        TF_M3_STEP("v_addc_co_u32_e64 %[r0a], %[ca], %[hla], %[mha], %[ca]", "v_addc_co_u32_e64 %[r0b], %[cb], %[hlb], %[mhb], %[cb]",
+                   "v_addc_co_u32_e32 %[r0d], vcc, %[hld], %[mhd], vcc")
+        TF_M3_STEP("v_addc_co_u32_e64 %[r1a], %[ca], 0, %[hha], %[ca]", "v_addc_co_u32_e64 %[r1b], %[cb], 0, %[hhb], %[cb]",
+                   "v_addc_co_u32_e32 %[r1d], vcc, 0, %[hhd], vcc")
+        TF_M3_STEP("v_addc_co_u32_e64 %[r1a], %[ka], 0, %[r1a], %[cma]", "v_addc_co_u32_e64 %[r1b], %[kb], 0, %[r1b], %[cmb]",
+                   "v_addc_co_u32_e64 %[r1d], %[kd], 0, %[r1d], %[cmd]")
+        TF_M3_STEP("v_add_co_u32_e64 %[ua], %[ca], %[ua], %[pla]", "v_add_co_u32_e64 %[ub], %[cb], %[ub], %[plb]",
+                   "v_add_co_u32_e32 %[ud], vcc, %[ud], %[pld]")
+        TF_M3_STEP("v_subb_co_u32_e64 %[wa], %[ca], %[pla], %[ua], %[ca]", "v_subb_co_u32_e64 %[wb], %[cb], %[plb], %[ub], %[cb]",
+                   "v_subb_co_u32_e32 %[wd], vcc, %[pld], %[ud], vcc")
+        TF_M3_STEP("v_subbrev_co_u32_e64 %[ua], %[ca], 0, %[ua], %[ca]", "v_subbrev_co_u32_e64 %[ub], %[cb], 0, %[ub], %[cb]",
+                   "v_subbrev_co_u32_e32 %[ud], vcc, 0, %[ud], vcc")
+        TF_M3_STEP("v_sub_co_u32_e64 %[r0a], %[ca], %[r0a], %[wa]", "v_sub_co_u32_e64 %[r0b], %[cb], %[r0b], %[wb]",
+                   "v_sub_co_u32_e32 %[r0d], vcc, %[r0d], %[wd]")
+        TF_M3_STEP("v_subb_co_u32_e64 %[r1a], %[ca], %[r1a], %[ua], %[ca]", "v_subb_co_u32_e64 %[r1b], %[cb], %[r1b], %[ub], %[cb]",
+                   "v_subb_co_u32_e32 %[r1d], vcc, %[r1d], %[ud], vcc")
+        TF_M3_STEP("v_addc_co_u32_e64 %[r0a], %[ka], 0, %[r0a], %[ca]", "v_addc_co_u32_e64 %[r0b], %[kb], 0, %[r0b], %[cb]",
+                   "v_addc_co_u32_e64 %[r0d], %[kd], 0, %[r0d], vcc")
+        TF_M3_STEP("s_andn2_b64 %[ca], %[ca], %[ka]", "s_andn2_b64 %[cb], %[cb], %[kb]",
+                   "s_andn2_b64 vcc, vcc, %[kd]")
+        "v_subbrev_co_u32_e64 %[r1a], %[ka], 0, %[r1a], %[ca]\n\t"                                                                // 12  r1 -= borrow & ~k
+        "v_subbrev_co_u32_e64 %[r1b], %[kb], 0, %[r1b], %[cb]\n\t"
+        "v_subbrev_co_u32_e32 %[r1d], vcc, 0, %[r1d], vcc"
+        : [r0a] "=&v"(r0[0]), [r1a] "=&v"(r1[0]), [ua] "=&v"(u[0]), [wa] "=&v"(w[0]), [r0b] "=&v"(r0[1]), [r1b] "=&v"(r1[1]), [ub] "=&v"(u[1]),
+          [wb] "=&v"(w[1]), [r0d] "=&v"(r0[2]), [r1d] "=&v"(r1[2]),
+          [ud] "=&v"(u[2]), [wd] "=&v"(w[2]), [ca] "=&s"(ca), [cb] "=&s"(cb), [ka] "=&s"(ka), [kb] "=&s"(kb), [kd] "=&s"(kd)
+        : [pla] "v"((u32)p[0]), [pha] "v"((u32)(p[0] >> 32)), [mla] "v"((u32)m[0]), [mha] "v"((u32)(m[0] >> 32)), [hla] "v"((u32)h[0]),
+          [hha] "v"((u32)(h[0] >> 32)), [cma] "s"(cm[0]), [plb] "v"((u32)p[1]), [phb] "v"((u32)(p[1] >> 32)), [mlb] "v"((u32)m[1]),
+          [mhb] "v"((u32)(m[1] >> 32)), [hlb] "v"((u32)h[1]), [hhb] "v"((u32)(h[1] >> 32)), [cmb] "s"(cm[1]), [pld] "v"((u32)p[2]), [phd] "v"((u32)(p[2] >> 32)), [mld] "v"((u32)m[2]), [mhd] "v"((u32)(m[2] >> 32)),
+          [hld] "v"((u32)h[2]), [hhd] "v"((u32)(h[2] >> 32)), [cmd] "s"(cm[2])
+        : "vcc", "scc");
+#undef TF_M3_STEP
+#pragma unroll
+    for (int i = 0; i < 3; ++i) r[i] = ((u64)r1[i] << 32) | r0[i];
+}
+
 #endif
 
 GL_HD u64 to_mont(u64 v) { return mont_mul(v, R2); }     // BFieldElement::new  (:235-237)

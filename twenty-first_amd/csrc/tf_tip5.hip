@@ -42,6 +42,9 @@ int ensure_tip5(DeviceCtx* ctx) {
     }
     memcpy(c.lut, lut, 256);
     HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(tfk::g_tip5), &c, sizeof(c)));
+    tfk::Tip5MxConsts mx;
+    tfk::fill_tip5_mx(mx, c.rc);
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(tfk::g_tip5_mx), &mx, sizeof(mx)));
     HIPCHK(hipDeviceSynchronize());
     ctx->tip5_ready = true;
     return TF_OK;
@@ -49,9 +52,33 @@ int ensure_tip5(DeviceCtx* ctx) {
 
 
 // ------------------------------------------------------------------------------------ Tip5 / Merkle
-// Launches of at most this many permutation chains use the 16-lanes-per-permutation kernels (measured crossover: one
-// permutation per lane costs ~19 us however few there are; 2^15 items x 16 lanes = 2 waves per SIMD)
-constexpr long long kCoopMaxCount = 1ll << 15;
+// Two kernel families (tip5_kernels.h).  Launches of at most kCoopMaxCount permutation chains are latency-bound (fewer chains
+// than the chip has SIMD slots): 16 lanes per permutation, ~2.5 us per permutation of a chain.  Everything larger runs in the
+// matrix-pipe form (4 lanes per permutation, MDS on v_mfma_f64_16x16x4_f64): measured crossover 2^13 chains
+// (profiles/r05_tip5_small_times.txt: hash_varlen of 33 words, 2^13 rows 24.4 vs 25.6 us, 2^14 rows 34.6 vs 26.3 us).
+constexpr long long kCoopMaxCount = 1ll << 13;
+
+// per_tree = 2^shift, or -1
+inline int shift_of(long long per_tree) { return (per_tree > 0 && !(per_tree & (per_tree - 1))) ? __builtin_ctzll((unsigned long long)per_tree) : -1; }
+
+// grid of a matrix-pipe launch: one workgroup (4 waves x 16 permutations) per 64 items, capped at kMxBlocksPerCu per CU -- beyond
+// that the waves walk the items with a grid stride, so the tables are staged once per wave and not once per 16 items (8 workgroups
+// are resident per CU at the kernels' VGPR count; 56 keeps the hardware's dynamic balancing: measured 7 / 14 / 28 / 56 / no cap on
+// the 2^24-leaf tree: 4.87 / 5.00 / 5.06 / 5.07 / 5.06 G leaves/s, profiles/r05_tip5_grid_cap.txt)
+constexpr long long kMxBlocksPerCu = 56;
+inline unsigned mx_blocks(long long count) {
+    static const long long cap = [] {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        return (long long)cus * kMxBlocksPerCu;
+    }();
+    const long long want = (count + 63) / 64;
+    return (unsigned)(want < cap ? want : cap);
+}
+
+void launch_permute_mx(u64* d_states, u64* d_trace, long long count, hipStream_t s) {
+    hipLaunchKernelGGL(tfk::tip5_permute_mx_kernel<1>, dim3(mx_blocks(count)), dim3(256), 0, s, d_states, d_trace, count);
+}
 
 int tip5_permute_dev(u64* d_states, size_t count, void* stream) {
     if (count == 0) return TF_OK;
@@ -65,9 +92,7 @@ int tip5_permute_dev(u64* d_states, size_t count, void* stream) {
         hipLaunchKernelGGL(tfk::tip5_permute_coop_kernel, dim3((unsigned)((count + 15) / 16)), dim3(256), 0,
                            static_cast<hipStream_t>(stream), d_states, (long long)count);
     } else {
-        const long long blocks = ((long long)count + 255) / 256;
-        hipLaunchKernelGGL(tfk::tip5_permute_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
-                           d_states, (long long)count);
+        launch_permute_mx(d_states, nullptr, (long long)count, static_cast<hipStream_t>(stream));
     }
     HIPCHK(hipGetLastError());
     return TF_OK;
@@ -81,9 +106,7 @@ int tip5_trace_dev(u64* d_states, u64* d_trace, size_t count, void* stream) {
     if (rc) return rc;
     rc = ensure_tip5(ctx);
     if (rc) return rc;
-    const long long blocks = ((long long)count + 255) / 256;
-    hipLaunchKernelGGL(tfk::tip5_trace_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), d_states, d_trace,
-                       (long long)count);
+    launch_permute_mx(d_states, d_trace, (long long)count, static_cast<hipStream_t>(stream));
     HIPCHK(hipGetLastError());
     return TF_OK;
 }
@@ -99,9 +122,8 @@ int launch_hash_pairs(const u64* in, u64* out, u64* leaf_copy, long long count, 
         HIPCHK(hipGetLastError());
         return TF_OK;
     }
-    const long long blocks = (count + 255) / 256;
-    hipLaunchKernelGGL(tfk::tip5_hash_pairs_kernel, dim3((unsigned)blocks), dim3(256), 0, s, in, out, leaf_copy, count,
-                       per_tree, in_ts, out_ts, copy_ts);
+    hipLaunchKernelGGL(tfk::tip5_hash_pairs_mx_kernel<1>, dim3(mx_blocks(count)), dim3(256), 0, s, in, out, leaf_copy, count, per_tree,
+                       shift_of(per_tree), in_ts, out_ts, copy_ts);
     HIPCHK(hipGetLastError());
     return TF_OK;
 }
@@ -114,8 +136,8 @@ int launch_hash_varlen_rows(const u64* rows, long long row_len, long long n_rows
         hipLaunchKernelGGL(tfk::tip5_hash_varlen_rows_coop_kernel, dim3((unsigned)((n_rows + 15) / 16)), dim3(256), 0, s, rows, row_len,
                            n_rows, out, per_tree, out_ts);
     } else {
-        hipLaunchKernelGGL(tfk::tip5_hash_varlen_rows_kernel, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, s, rows, row_len,
-                           n_rows, out, per_tree, out_ts);
+        hipLaunchKernelGGL(tfk::tip5_hash_varlen_rows_mx_kernel<1>, dim3(mx_blocks(n_rows)), dim3(256), 0, s, rows, row_len, n_rows, out,
+                           per_tree, shift_of(per_tree), out_ts);
     }
     HIPCHK(hipGetLastError());
     return TF_OK;
@@ -178,8 +200,8 @@ int launch_hash_table_rows(const u64* table, long long n_rows, long long n_cols,
         hipLaunchKernelGGL(tfk::tip5_hash_table_rows_coop_kernel, dim3((unsigned)((total + 15) / 16)), dim3(256), 0, s, table, n_rows, n_cols,
                            width, col_stride, table_stride, total, out, out_ts);
     } else {
-        hipLaunchKernelGGL(tfk::tip5_hash_table_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, table, n_rows, n_cols,
-                           width, col_stride, table_stride, total, out, out_ts);
+        hipLaunchKernelGGL(tfk::tip5_hash_table_rows_mx_kernel<1>, dim3(mx_blocks(total)), dim3(256), 0, s, table, n_rows, shift_of(n_rows),
+                           n_cols, width, col_stride, table_stride, total, out, out_ts);
     }
     HIPCHK(hipGetLastError());
     return TF_OK;

@@ -6,13 +6,17 @@
 //   hash_10 :559-569; hash_pair :577-586; hash_varlen :617-623 + util_types/sponge.rs:41-55.
 // Merkle: twenty-first/src/util_types/merkle_tree.rs:149-222 (nodes[i] = hash_pair(nodes[2i], nodes[2i+1])).
 //
-// GPU mapping: one lane = one permutation, whole state in registers (16 x u64), 64-bit integer VALU
-// only (no MFMA: there is no dense contraction).  The MDS is the plain integer circulant product
-//   out[r] = sum_c M[(r-c) mod 16] * raw[c]        (tip5/naive.rs:54-68, mod.rs:154-157)
-// accumulated per 32-bit half with v_mad_u64_u32 (16-bit x 32-bit + 64-bit; a half-sum is < 2^52, the
-// same bound mds_generated relies on, mod.rs:244), then reduced with 2^64 = 2^32 - 1 and made canonical
-// explicitly after adding the round constant (the reference gets there through a quirk of Add,
-// mod.rs:222-242 / :1098-1142; the canonical result is the same word).
+// Three formulations of the same round, all producing the reference's words:
+//   * matrix-pipe form (throughput; every launch of more than 2^13 permutation chains): FOUR lanes per permutation, the MDS --
+//     the one dense contraction on this path, out = M * state with the constant circulant M (tip5/naive.rs:54-68, mod.rs:154-157)
+//     -- on v_mfma_f64_16x16x4_f64: products of a 16-bit entry and a 32-bit half are < 2^48, a sum of 16 is < 2^52, exact in f64
+//   * cooperative form (latency; small launches and the top of a tree): 16 lanes of a DPP row per permutation, the circulant as
+//     16 row rotations + v_mad_u64_u32
+//   * lane-per-permutation form (tip5_round below): the whole state in one lane's registers, 512 v_mad_u64_u32 per MDS.  It was
+//     the throughput kernel through round 4; the library no longer launches it -- tools/microbench_mds.hip keeps it as the
+//     yardstick the matrix-pipe form is measured against (profiles/r05_microbench_mds_mfma.txt).
+// In every form a half-sum is reduced with 2^64 = 2^32 - 1 and made canonical explicitly after adding the round constant (the
+// reference gets there through a quirk of Add, mod.rs:222-242 / :1098-1142; the canonical result is the same word).
 #pragma once
 
 #include "gl64.h"
@@ -102,107 +106,10 @@ __device__ __forceinline__ void stage_lut(unsigned char* lut_lds) {
     __syncthreads();
 }
 
-// states: count x 16 words, permuted in place (Tip5::permutation, mod.rs:529-533)
-__global__ void __launch_bounds__(256) tip5_permute_kernel(u64* states, long long count) {
-    __shared__ __attribute__((aligned(16))) unsigned char lut[256];
-    stage_lut(lut);
-    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= count) return;
-    u64 s[16];
-    u64* p = states + i * 16;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) s[k] = p[k];
-    tip5_permutation(s, lut);
-#pragma unroll
-    for (int k = 0; k < 16; ++k) p[k] = s[k];
-}
-
-// Tip5::trace (mod.rs:538-548): trace[i][0] = the state before the permutation, trace[i][1 + r] = the state after round r;
-// states[i] ends as the permuted state.  6 x 16 words per permutation, the rows a hash-table arithmetisation is filled from.
-__global__ void __launch_bounds__(256) tip5_trace_kernel(u64* states, u64* trace, long long count) {
-    __shared__ __attribute__((aligned(16))) unsigned char lut[256];
-    stage_lut(lut);
-    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= count) return;
-    u64 s[16];
-    u64* p = states + i * 16;
-    u64* t = trace + i * 96;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        s[k] = p[k];
-        t[k] = s[k];
-    }
-#pragma unroll 1
-    for (int r = 0; r < 5; ++r) {
-        tip5_round(s, r, lut);
-#pragma unroll
-        for (int k = 0; k < 16; ++k) t[16 * (r + 1) + k] = s[k];
-    }
-#pragma unroll
-    for (int k = 0; k < 16; ++k) p[k] = s[k];
-}
-
-// out[i] = hash_10(in[10 i .. 10 i + 10)) = hash_pair(left, right)  (mod.rs:559-586).
-// If leaf_copy != null the 10 input words are also copied there (Merkle leaf level, merkle_tree.rs:426).
-// Addressing: item i belongs to tree i / per_tree; its input is in + tree * in_ts + 10 * (i % per_tree), etc.
-__global__ void __launch_bounds__(256) tip5_hash_pairs_kernel(const u64* in, u64* out, u64* leaf_copy, long long count,
-                                                              long long per_tree, long long in_ts, long long out_ts,
-                                                              long long copy_ts) {
-    __shared__ __attribute__((aligned(16))) unsigned char lut[256];
-    stage_lut(lut);
-    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= count) return;
-    const long long tree = i / per_tree, j = i - tree * per_tree;
-    const u64* p = in + tree * in_ts + 10 * j;
-    u64 s[16];
-#pragma unroll
-    for (int k = 0; k < 10; ++k) s[k] = p[k];
-    if (leaf_copy) {
-        u64* q = leaf_copy + tree * copy_ts + 10 * j;
-#pragma unroll
-        for (int k = 0; k < 10; ++k) q[k] = s[k];
-    }
-#pragma unroll
-    for (int k = 10; k < 16; ++k) s[k] = gl::ONE;  // Tip5::new(Domain::FixedLength), mod.rs:511-526
-    tip5_permutation(s, lut);
-    u64* o = out + tree * out_ts + 5 * j;
-#pragma unroll
-    for (int k = 0; k < 5; ++k) o[k] = s[k];
-}
-
-// hash_varlen of n_rows rows of row_len words each (mod.rs:617-623; padding sponge.rs:41-55)
-// Row i belongs to tree i / per_tree; its digest goes to out + tree * out_ts + 5 * (i % per_tree)  (out_ts = 0 and
-// per_tree = n_rows: a flat digest array; out_ts = 10 n, out = nodes + 5 n: straight into the leaf level of a tree).
-__global__ void __launch_bounds__(256) tip5_hash_varlen_rows_kernel(const u64* rows, long long row_len, long long n_rows,
-                                                                    u64* out, long long per_tree, long long out_ts) {
-    __shared__ __attribute__((aligned(16))) unsigned char lut[256];
-    stage_lut(lut);
-    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_rows) return;
-    const u64* p = rows + i * row_len;
-    u64 s[16];
-#pragma unroll
-    for (int k = 0; k < 16; ++k) s[k] = 0;  // Domain::VariableLength
-    long long full = row_len / 10;
-    for (long long c = 0; c < full; ++c) {
-#pragma unroll
-        for (int k = 0; k < 10; ++k) s[k] = p[c * 10 + k];  // overwrite-mode absorb, mod.rs:684-691
-        tip5_permutation(s, lut);
-    }
-    const int rem = (int)(row_len - full * 10);
-#pragma unroll
-    for (int k = 0; k < 10; ++k) s[k] = (k < rem) ? p[full * 10 + k] : ((k == rem) ? gl::ONE : 0);
-    tip5_permutation(s, lut);
-    const long long tree = i / per_tree;
-    u64* o = out + tree * out_ts + (i - tree * per_tree) * 5;
-#pragma unroll
-    for (int k = 0; k < 5; ++k) o[k] = s[k];
-}
-
-// hash_varlen of every ROW of a COLUMN-MAJOR table: column j is n_rows contiguous elements of `width` words (1 =
+// Rows of a COLUMN-MAJOR table (tip5_hash_table_rows_*_kernel): column j is n_rows contiguous elements of `width` words (1 =
 // BFieldElement, 3 = XFieldElement, flattened as x_field_element.rs:217-231) starting at table + j * col_stride; row i is
 // the concatenation over the columns of element i's words.  This is the layout a batch of coset evaluations leaves in HBM
-// (one codeword per column), and the lanes -- one row each -- read every column coalesced.
+// (one codeword per column); the 16 columns of a wave are 16 consecutive rows, so every table column is read in 128-byte runs.
 // Word w of a row is word (w % width) of the element in column w / width.
 __device__ __forceinline__ u64 table_word(const u64* table, long long i, long long w, int width, long long col_stride) {
     const long long j = width == 1 ? w : (long long)(((unsigned long long)w * 0xAAAAAAABull) >> 33);  // w / 3 for w < 2^31
@@ -210,32 +117,377 @@ __device__ __forceinline__ u64 table_word(const u64* table, long long i, long lo
     return table[j * col_stride + i * width + k];
 }
 
-__global__ void __launch_bounds__(256) tip5_hash_table_rows_kernel(const u64* table, long long n_rows, long long n_cols, int width,
-                                                                   long long col_stride, long long table_stride, long long total,
-                                                                   u64* out, long long out_ts) {
-    __shared__ __attribute__((aligned(16))) unsigned char lut[256];
-    stage_lut(lut);
-    const long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (id >= total) return;
-    const long long tree = id / n_rows, i = id - tree * n_rows;
-    const u64* tb = table + tree * table_stride;
-    const long long row_len = n_cols * width;
-    u64 s[16];
+// ---- matrix-pipe form: FOUR lanes hold one permutation, the MDS runs on v_mfma_f64_16x16x4_f64 ---------------------------------
+// The MDS layer is the one dense contraction on this path: a constant 16 x 16 matrix times the state (tip5/naive.rs:54-68,
+// mod.rs:210-253).  A wave is a 16-column x 4-quarter grid: lane l = (column j = l & 15, quarter q = l >> 4) holds the words
+// 4 i + q (i = 0..3) of the permutation in column j, so register 0 of every lane is a split_and_lookup word and registers 1..3 are
+// x^7 words -- no divergence in the S-box layer.  For the MDS each 32-bit half of a word becomes an f64 (v_cvt_f64_u32) and is the
+// B operand of K-block i (B[k][j]: lane (j, k) -- exactly where the word lives); A is the circulant itself, A_i[r][k] =
+// M[(r - 4 i - k) mod 16], one constant per lane and K-block; D[r][j] comes back in lane (j, r & 3) register r >> 2 -- again exactly
+// the strided layout (MI355X f64 C/D map: row = (lane >> 4) + 4 * reg).  Products are < 2^48 and a sum of 16 is < 2^51.01, so the
+// f64 arithmetic is exact; the accumulator starts at 2^52 + (half of the round constant, adjusted), which makes the raw bits of
+// the result  0x433 << 52 | integer sum.  The recombination works on those raw bits: with B = 0x433 << 52,
+//     rawlo + 2^32 rawhi = (lo-sum + 2^32 hi-sum + x) + B (1 + 2^32),     x = (rc - B (1 + 2^32)) mod p  split into the two starts,
+// so   h1 * (2^32 - 1) + rawlo  (one v_mad_u64_u32; < 2^64: no carry)  + h0 * 2^32  (one add with carry k)  is congruent to
+// MDS(state)[r] + rc[r], and one conditional "+ (2^32 - 1)" (carry, or >= p) makes it the canonical word -- the word the
+// lane-per-permutation round above produces.  8 MFMA per 16 permutations and round; measured (tools/microbench_mds.hip,
+// profiles/r05_microbench_mds_mfma.txt) the f64 matrix pipe does NOT overlap with the vector ALU on gfx950 (it runs at the vector
+// f64 rate and blocks VALU issue), so the gain is what the layout saves -- 8 MFMA (512 cycles) replace 128 v_mad_u64_u32 (~600
+// cycles) per 16 permutations, the round constant and the 85-bit recombination shrink to 6 instructions per word -- not a second pipe.
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+struct Tip5MxConsts {
+    double c[5][4][8];  // accumulator starts [round][quarter q][lo-half reg 0..3 | hi-half reg 0..3] for state word 4 reg + q
+    double a[16];       // MDS_MATRIX_FIRST_COLUMN as f64
+};
+__constant__ Tip5MxConsts g_tip5_mx;
+
+// host side of the table above; rc_mont = Montgomery form of ROUND_CONSTANTS (the g_tip5.rc words)
+inline void fill_tip5_mx(Tip5MxConsts& t, const u64* rc_mont) {
+    constexpr u32 col[16] = {61402, 1108, 28750, 33823, 7454, 43244, 53865, 12034, 56951, 27521, 41351, 40901, 12021, 59689, 26798, 17845};
+    const u64 B = 0x4330000000000000ULL;
+    const u64 Bp = B % gl::P;
+    const u64 K = (u64)(((unsigned __int128)Bp * ((1ull << 32) + 1)) % gl::P);
+    for (int i = 0; i < 16; ++i) t.a[i] = (double)col[i];
+    for (int round = 0; round < 5; ++round)
+        for (int q = 0; q < 4; ++q)
+            for (int v = 0; v < 4; ++v) {
+                const u64 rc = rc_mont[round * 16 + 4 * v + q];
+                const u64 x = rc >= K ? rc - K : rc + (gl::P - K);
+                t.c[round][q][v] = 4503599627370496.0 + (double)(u32)x;
+                t.c[round][q][4 + v] = 4503599627370496.0 + (double)(u32)(x >> 32);
+            }
+}
+
+struct Tip5MxLds {
+    Tip5MxConsts t;
+    unsigned char lut[256];
+};
+
+__device__ __forceinline__ void stage_mx(Tip5MxLds* l) {
+    const double* src = reinterpret_cast<const double*>(&g_tip5_mx);
+    double* dst = reinterpret_cast<double*>(&l->t);
+    for (int i = threadIdx.x; i < (int)(sizeof(Tip5MxConsts) / 8); i += blockDim.x) dst[i] = src[i];
+    stage_lut(l->lut);  // ends in __syncthreads()
+}
+
+// per-lane A operands: K-block i, lane (r = l & 15, k = l >> 4) holds M[(r - 4 i - k) mod 16]
+__device__ __forceinline__ void mx_a_operands(const Tip5MxLds* l, double (&a)[4]) {
+    const int lane = threadIdx.x & 63, r = lane & 15, k = lane >> 4;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) s[k] = 0;  // Domain::VariableLength
-    const long long full = row_len / 10;
-    for (long long c = 0; c < full; ++c) {
+    for (int i = 0; i < 4; ++i) a[i] = l->t.a[(r - 4 * i - k) & 15];
+}
+
+// four accumulator registers of the lo-half and hi-half products -> the four state words of this lane.  Word 0 (register 0: the
+// next round's split_and_lookup input, whose bytes must be those of the canonical word) is always made canonical; words 1..3
+// (x^7 inputs) only when CANON: in between any 64-bit representative serves -- mont_mul3 accepts them (a Montgomery product of two
+// arbitrary 64-bit words is a correct, possibly non-canonical, 64-bit representative: montyred's subtrahend is < p, so at most one
+// "+ p" is ever needed), and the MDS is linear in the integer value of a word, so a representative that is p too large changes a
+// sum by a multiple of p.  The last round of a permutation runs with CANON: everything that leaves the registers is canonical.
+template <bool CANON>
+__device__ __forceinline__ void mx_fold4(const d4 dlo, const d4 dhi, u64* out) {
+    u32 tl[4], th[4], h0[4], rl[4], rh[4];
 #pragma unroll
-        for (int k = 0; k < 10; ++k) s[k] = table_word(tb, i, c * 10 + k, width, col_stride);  // overwrite-mode absorb, mod.rs:684-691
-        tip5_permutation(s, lut);
+    for (int v = 0; v < 4; ++v) {
+        const u64 rawlo = (u64)__double_as_longlong(dlo[v]), rawhi = (u64)__double_as_longlong(dhi[v]);
+        const u64 t1 = (u64)(u32)(rawhi >> 32) * 0xffffffffu + rawlo;  // < 2^63.1: rawlo < 2^62.1, (rawhi >> 32) < 2^30.1
+        tl[v] = (u32)t1;
+        th[v] = (u32)(t1 >> 32);
+        h0[v] = (u32)rawhi;
     }
-    const int rem = (int)(row_len - full * 10);
+    u64 ka, kb, kc, kd, ea, na, nb, nc, nd;
+    if constexpr (CANON) {
+        u64 eb, ec, ed;
+#define TF_MX_STEP(A, B, C, D) A "\n\t" B "\n\t" C "\n\t" D "\n\t"
+        asm(TF_MX_STEP("v_add_co_u32_e64 %[tha], %[ka], %[tha], %[h0a]", "v_add_co_u32_e64 %[thb], %[kb], %[thb], %[h0b]",  // th += h0, carry k: the value is t + k 2^64
+                       "v_add_co_u32_e64 %[thc], %[kc], %[thc], %[h0c]", "v_add_co_u32_e64 %[thd], %[kd], %[thd], %[h0d]")
+            TF_MX_STEP("v_cmp_ne_u32_e64 %[na], 0, %[tla]", "v_cmp_ne_u32_e64 %[nb], 0, %[tlb]", "v_cmp_ne_u32_e64 %[nc], 0, %[tlc]",
+                       "v_cmp_ne_u32_e64 %[nd], 0, %[tld]")
+            TF_MX_STEP("v_cmp_eq_u32_e64 %[ea], -1, %[tha]", "v_cmp_eq_u32_e64 %[eb], -1, %[thb]", "v_cmp_eq_u32_e64 %[ec], -1, %[thc]",
+                       "v_cmp_eq_u32_e64 %[ed], -1, %[thd]")
+            TF_MX_STEP("s_and_b64 %[ea], %[ea], %[na]", "s_and_b64 %[eb], %[eb], %[nb]", "s_and_b64 %[ec], %[ec], %[nc]",      // t >= p
+                       "s_and_b64 %[ed], %[ed], %[nd]")
+            TF_MX_STEP("s_or_b64 %[ea], %[ea], %[ka]", "s_or_b64 %[eb], %[eb], %[kb]", "s_or_b64 %[ec], %[ec], %[kc]",           // ... or carry: add 2^32 - 1
+                       "s_or_b64 %[ed], %[ed], %[kd]")
+            TF_MX_STEP("v_subbrev_co_u32_e64 %[rla], %[na], 0, %[tla], %[ea]", "v_subbrev_co_u32_e64 %[rlb], %[nb], 0, %[tlb], %[eb]",  // lo -= cond, borrow n
+                       "v_subbrev_co_u32_e64 %[rlc], %[nc], 0, %[tlc], %[ec]", "v_subbrev_co_u32_e64 %[rld], %[nd], 0, %[tld], %[ed]")
+            TF_MX_STEP("s_andn2_b64 %[ea], %[ea], %[na]", "s_andn2_b64 %[eb], %[eb], %[nb]", "s_andn2_b64 %[ec], %[ec], %[nc]",
+                       "s_andn2_b64 %[ed], %[ed], %[nd]")
+            "v_addc_co_u32_e64 %[rha], %[na], 0, %[tha], %[ea]\n\t"                                                                  // hi += cond & ~borrow
+            "v_addc_co_u32_e64 %[rhb], %[nb], 0, %[thb], %[eb]\n\t"
+            "v_addc_co_u32_e64 %[rhc], %[nc], 0, %[thc], %[ec]\n\t"
+            "v_addc_co_u32_e64 %[rhd], %[nd], 0, %[thd], %[ed]"
+            : [tha] "+v"(th[0]), [thb] "+v"(th[1]), [thc] "+v"(th[2]), [thd] "+v"(th[3]), [rla] "=&v"(rl[0]), [rlb] "=&v"(rl[1]),
+              [rlc] "=&v"(rl[2]), [rld] "=&v"(rl[3]), [rha] "=&v"(rh[0]), [rhb] "=&v"(rh[1]), [rhc] "=&v"(rh[2]), [rhd] "=&v"(rh[3]),
+              [ka] "=&s"(ka), [kb] "=&s"(kb), [kc] "=&s"(kc), [kd] "=&s"(kd), [ea] "=&s"(ea), [eb] "=&s"(eb), [ec] "=&s"(ec), [ed] "=&s"(ed),
+              [na] "=&s"(na), [nb] "=&s"(nb), [nc] "=&s"(nc), [nd] "=&s"(nd)
+            : [tla] "v"(tl[0]), [tlb] "v"(tl[1]), [tlc] "v"(tl[2]), [tld] "v"(tl[3]), [h0a] "v"(h0[0]), [h0b] "v"(h0[1]), [h0c] "v"(h0[2]),
+              [h0d] "v"(h0[3])
+            : "scc");
+#undef TF_MX_STEP
+    } else {
+        // chain a as above; chains b..d only fold the carry (t + k 2^64 = t + k (2^32 - 1), which cannot carry again: t < 2^63.1 then)
+        asm("v_add_co_u32_e64 %[tha], %[ka], %[tha], %[h0a]\n\t"
+            "v_add_co_u32_e64 %[thb], %[kb], %[thb], %[h0b]\n\t"
+            "v_add_co_u32_e64 %[thc], %[kc], %[thc], %[h0c]\n\t"
+            "v_add_co_u32_e64 %[thd], %[kd], %[thd], %[h0d]\n\t"
+            "v_cmp_ne_u32_e64 %[na], 0, %[tla]\n\t"
+            "v_cmp_eq_u32_e64 %[ea], -1, %[tha]\n\t"
+            "v_subbrev_co_u32_e64 %[rlb], %[nb], 0, %[tlb], %[kb]\n\t"   // lo -= k, borrow n
+            "v_subbrev_co_u32_e64 %[rlc], %[nc], 0, %[tlc], %[kc]\n\t"
+            "v_subbrev_co_u32_e64 %[rld], %[nd], 0, %[tld], %[kd]\n\t"
+            "s_and_b64 %[ea], %[ea], %[na]\n\t"
+            "s_or_b64 %[ea], %[ea], %[ka]\n\t"
+            "s_andn2_b64 %[kb], %[kb], %[nb]\n\t"
+            "s_andn2_b64 %[kc], %[kc], %[nc]\n\t"
+            "s_andn2_b64 %[kd], %[kd], %[nd]\n\t"
+            "v_subbrev_co_u32_e64 %[rla], %[na], 0, %[tla], %[ea]\n\t"
+            "v_addc_co_u32_e64 %[rhb], %[nb], 0, %[thb], %[kb]\n\t"       // hi += k & ~borrow
+            "v_addc_co_u32_e64 %[rhc], %[nc], 0, %[thc], %[kc]\n\t"
+            "v_addc_co_u32_e64 %[rhd], %[nd], 0, %[thd], %[kd]\n\t"
+            "s_andn2_b64 %[ea], %[ea], %[na]\n\t"
+            "v_addc_co_u32_e64 %[rha], %[na], 0, %[tha], %[ea]"
+            : [tha] "+v"(th[0]), [thb] "+v"(th[1]), [thc] "+v"(th[2]), [thd] "+v"(th[3]), [rla] "=&v"(rl[0]), [rlb] "=&v"(rl[1]),
+              [rlc] "=&v"(rl[2]), [rld] "=&v"(rl[3]), [rha] "=&v"(rh[0]), [rhb] "=&v"(rh[1]), [rhc] "=&v"(rh[2]), [rhd] "=&v"(rh[3]),
+              [ka] "=&s"(ka), [kb] "=&s"(kb), [kc] "=&s"(kc), [kd] "=&s"(kd), [ea] "=&s"(ea), [na] "=&s"(na), [nb] "=&s"(nb), [nc] "=&s"(nc),
+              [nd] "=&s"(nd)
+            : [tla] "v"(tl[0]), [tlb] "v"(tl[1]), [tlc] "v"(tl[2]), [tld] "v"(tl[3]), [h0a] "v"(h0[0]), [h0b] "v"(h0[1]), [h0c] "v"(h0[2]),
+              [h0d] "v"(h0[3])
+            : "scc");
+    }
 #pragma unroll
-    for (int k = 0; k < 10; ++k) s[k] = (k < rem) ? table_word(tb, i, full * 10 + k, width, col_stride) : ((k == rem) ? gl::ONE : 0);
-    tip5_permutation(s, lut);
-    u64* o = out + tree * out_ts + i * 5;
+    for (int v = 0; v < 4; ++v) out[v] = ((u64)rh[v] << 32) | rl[v];
+}
+
+// One round on NS permutations per lane quartet: s[4 n + i] = word 4 i + q of the permutation in column j of column block n.
+template <int NS, bool LAST>
+__device__ __forceinline__ void tip5_round_mx(u64 (&s)[4 * NS], int round, const Tip5MxLds* l, const double (&a)[4], int q) {
 #pragma unroll
-    for (int k = 0; k < 5; ++k) o[k] = s[k];
+    for (int n = 0; n < NS; ++n) {  // split_and_lookup (mod.rs:197-207): words 0..3 = register 0 of the four quarters
+        const u32 lo = lookup4((u32)s[4 * n], l->lut), hi = lookup4((u32)(s[4 * n] >> 32), l->lut);
+        s[4 * n] = ((u64)hi << 32) | lo;
+    }
+#pragma unroll
+    for (int n = 0; n < NS; ++n) {  // x^7 = x * (x^2 * x^4) on registers 1..3
+        u64 x[3] = {s[4 * n + 1], s[4 * n + 2], s[4 * n + 3]}, sq[3], qu[3], t[3];
+        gl::mont_mul3(x, x, sq);
+        gl::mont_mul3(sq, sq, qu);
+        gl::mont_mul3(sq, qu, t);
+        gl::mont_mul3(x, t, x);
+        s[4 * n + 1] = x[0], s[4 * n + 2] = x[1], s[4 * n + 3] = x[2];
+    }
+    const d4* cp = reinterpret_cast<const d4*>(&l->t.c[round][q][0]);
+    const d4 c_lo = cp[0], c_hi = cp[1];
+    d4 dlo[NS], dhi[NS];
+#pragma unroll
+    for (int n = 0; n < NS; ++n) dlo[n] = c_lo, dhi[n] = c_hi;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int n = 0; n < NS; ++n) {
+            dlo[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], (double)(u32)s[4 * n + i], dlo[n], 0, 0, 0);
+            dhi[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], (double)(u32)(s[4 * n + i] >> 32), dhi[n], 0, 0, 0);
+        }
+#pragma unroll
+    for (int n = 0; n < NS; ++n) mx_fold4<LAST>(dlo[n], dhi[n], &s[4 * n]);
+}
+
+template <int NS>
+__device__ __forceinline__ void tip5_permutation_mx(u64 (&s)[4 * NS], const Tip5MxLds* l, const double (&a)[4], int q) {
+#pragma unroll 1
+    for (int r = 0; r < 4; ++r) tip5_round_mx<NS, false>(s, r, l, a, q);
+    tip5_round_mx<NS, true>(s, 4, l, a, q);
+}
+
+// item -> (tree, index in its tree).  shift >= 0: per_tree = 2^shift (every Merkle level); shift < 0: any per_tree (a flat call
+// has per_tree = count, so the quotient is 0 -- the division is uniform over the launch and only taken by odd table shapes).
+__device__ __forceinline__ void split_item(long long i, long long per_tree, int shift, long long& tree, long long& k) {
+    if (shift >= 0) {
+        tree = i >> shift;
+        k = i - (tree << shift);
+    } else if (i < per_tree) {
+        tree = 0;
+        k = i;
+    } else {
+        tree = i / per_tree;
+        k = i - tree * per_tree;
+    }
+}
+
+// Work distribution of every matrix-pipe kernel: a workgroup is 4 waves; the waves of the grid walk over groups of 16 NS
+// consecutive items with a grid stride (the host caps the grid at a few workgroups per CU, so the tables are staged and the A
+// operands fetched once per wave, not once per group); lane (j, q) serves item base + 16 n + j for n < NS.  Lanes of items past
+// the end stay in the wave (the MFMA wants all 64 lanes) on a clamped item and skip their stores.
+#define TF_MX_PROLOGUE()                                                                               \
+    __shared__ __attribute__((aligned(32))) Tip5MxLds lds;                                             \
+    stage_mx(&lds);                                                                                    \
+    const int lane = threadIdx.x & 63, j = lane & 15, q = lane >> 4;                                   \
+    double a[4];                                                                                       \
+    mx_a_operands(&lds, a)
+#define TF_MX_GROUPS(COUNT)                                                                            \
+    for (long long base = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * (16 * NS); base < (COUNT); \
+         base += (long long)gridDim.x * (4 * 16 * NS))
+
+// out[i] = hash_10(in[10 i .. 10 i + 10)) = hash_pair(left, right)  (mod.rs:559-586), item i belongs to tree i / per_tree; its input is in + tree * in_ts + 10 * (i % per_tree), its
+// digest goes to out + tree * out_ts + 5 * (i % per_tree); if leaf_copy != null the 10 input words are also copied to
+// leaf_copy + tree * copy_ts + 10 * (i % per_tree) (Merkle leaf level, merkle_tree.rs:426).
+template <int NS>
+__global__ void __launch_bounds__(256) tip5_hash_pairs_mx_kernel(const u64* in, u64* out, u64* leaf_copy, long long count,
+                                                                 long long per_tree, int shift, long long in_ts, long long out_ts,
+                                                                 long long copy_ts) {
+    TF_MX_PROLOGUE();
+    TF_MX_GROUPS(count) {
+    u64 s[4 * NS];
+    long long tree[NS], k[NS];
+    bool live[NS];
+#pragma unroll
+    for (int n = 0; n < NS; ++n) {
+        const long long item = base + 16 * n + j;
+        live[n] = item < count;
+        split_item(live[n] ? item : count - 1, per_tree, shift, tree[n], k[n]);
+        const u64* p = in + tree[n] * in_ts + 10 * k[n];
+        s[4 * n] = p[q];
+        s[4 * n + 1] = p[4 + q];
+        s[4 * n + 2] = q < 2 ? p[8 + q] : gl::ONE;  // words 10..15 = 1: Tip5::new(Domain::FixedLength), mod.rs:511-526
+        s[4 * n + 3] = gl::ONE;
+        if (leaf_copy && live[n]) {  // Merkle leaf level, merkle_tree.rs:426
+            u64* c = leaf_copy + tree[n] * copy_ts + 10 * k[n];
+            c[q] = s[4 * n];
+            c[4 + q] = s[4 * n + 1];
+            if (q < 2) c[8 + q] = s[4 * n + 2];
+        }
+    }
+    tip5_permutation_mx<NS>(s, &lds, a, q);
+#pragma unroll
+    for (int n = 0; n < NS; ++n)
+        if (live[n]) {
+            u64* o = out + tree[n] * out_ts + 5 * k[n];
+            o[q] = s[4 * n];
+            if (q == 0) o[4] = s[4 * n + 1];
+        }
+    }
+}
+
+// The sponge of hash_varlen (mod.rs:617-623, overwrite-mode absorb :684-691, padding sponge.rs:41-55) over a row whose word w is
+// WORD(w); shared by the row-major and the column-major kernels below.  Rate word w = 4 i + q < 10 lives in register i of quarter q.
+#define TF_MX_SPONGE(ROW_LEN, WORD)                                                                                     \
+    u64 s[4 * NS];                                                                                                      \
+    _Pragma("unroll") for (int t = 0; t < 4 * NS; ++t) s[t] = 0; /* Domain::VariableLength */                           \
+    const long long full = (ROW_LEN) / 10;                                                                              \
+    for (long long c = 0; c < full; ++c) {                                                                              \
+        _Pragma("unroll") for (int n = 0; n < NS; ++n) {                                                                \
+            s[4 * n] = WORD(n, c * 10 + q);                                                                             \
+            s[4 * n + 1] = WORD(n, c * 10 + 4 + q);                                                                     \
+            if (q < 2) s[4 * n + 2] = WORD(n, c * 10 + 8 + q);                                                          \
+        }                                                                                                               \
+        tip5_permutation_mx<NS>(s, &lds, a, q);                                                                         \
+    }                                                                                                                   \
+    const int rem = (int)((ROW_LEN) - full * 10);                                                                       \
+    _Pragma("unroll") for (int n = 0; n < NS; ++n) {                                                                    \
+        _Pragma("unroll") for (int i = 0; i < 3; ++i) {                                                                 \
+            const int w = 4 * i + q;                                                                                    \
+            if (w < 10) s[4 * n + i] = (w < rem) ? WORD(n, full * 10 + w) : ((w == rem) ? gl::ONE : 0);                 \
+        }                                                                                                               \
+    }                                                                                                                   \
+    tip5_permutation_mx<NS>(s, &lds, a, q)
+
+// hash_varlen of n_rows rows of row_len words each.  Row i belongs to tree i / per_tree; its digest goes to out + tree * out_ts +
+// 5 * (i % per_tree)  (out_ts = 0 and per_tree = n_rows: a flat digest array; out_ts = 10 n, out = nodes + 5 n: straight into the
+// leaf level of a tree).
+template <int NS>
+__global__ void __launch_bounds__(256) tip5_hash_varlen_rows_mx_kernel(const u64* rows, long long row_len, long long n_rows, u64* out,
+                                                                       long long per_tree, int shift, long long out_ts) {
+    TF_MX_PROLOGUE();
+    TF_MX_GROUPS(n_rows) {
+    const u64* p[NS];
+    long long item[NS];
+#pragma unroll
+    for (int n = 0; n < NS; ++n) {
+        item[n] = base + 16 * n + j;
+        p[n] = rows + (item[n] < n_rows ? item[n] : n_rows - 1) * row_len;
+    }
+#define TF_MX_ROW_WORD(n, w) p[n][w]
+    TF_MX_SPONGE(row_len, TF_MX_ROW_WORD);
+#undef TF_MX_ROW_WORD
+#pragma unroll
+    for (int n = 0; n < NS; ++n)
+        if (item[n] < n_rows) {
+            long long tree, k;
+            split_item(item[n], per_tree, shift, tree, k);
+            u64* o = out + tree * out_ts + 5 * k;
+            o[q] = s[4 * n];
+            if (q == 0) o[4] = s[4 * n + 1];
+        }
+    }
+}
+
+// hash_varlen of every row of `batch` column-major tables (layout: table_word above); row i of table t -> out + t * out_ts + 5 i.
+template <int NS>
+__global__ void __launch_bounds__(256) tip5_hash_table_rows_mx_kernel(const u64* table, long long n_rows, int shift, long long n_cols,
+                                                                      int width, long long col_stride, long long table_stride,
+                                                                      long long total, u64* out, long long out_ts) {
+    TF_MX_PROLOGUE();
+    const long long row_len = n_cols * width;
+    TF_MX_GROUPS(total) {
+    const u64* tb[NS];
+    long long tree[NS], row[NS];
+    bool live[NS];
+#pragma unroll
+    for (int n = 0; n < NS; ++n) {
+        const long long id = base + 16 * n + j;
+        live[n] = id < total;
+        split_item(live[n] ? id : total - 1, n_rows, shift, tree[n], row[n]);
+        tb[n] = table + tree[n] * table_stride;
+    }
+#define TF_MX_TABLE_WORD(n, w) table_word(tb[n], row[n], w, width, col_stride)
+    TF_MX_SPONGE(row_len, TF_MX_TABLE_WORD);
+#undef TF_MX_TABLE_WORD
+#pragma unroll
+    for (int n = 0; n < NS; ++n)
+        if (live[n]) {
+            u64* o = out + tree[n] * out_ts + 5 * row[n];
+            o[q] = s[4 * n];
+            if (q == 0) o[4] = s[4 * n + 1];
+        }
+    }
+}
+
+// states: count x 16 words, permuted in place (Tip5::permutation, mod.rs:529-533); with trace != null also Tip5::trace
+// (mod.rs:538-548): trace[i][0] = the state before the permutation, trace[i][1 + r] = the state after round r.
+template <int NS>
+__global__ void __launch_bounds__(256) tip5_permute_mx_kernel(u64* states, u64* trace, long long count) {
+    TF_MX_PROLOGUE();
+    TF_MX_GROUPS(count) {
+    u64 s[4 * NS];
+    long long item[NS];
+#pragma unroll
+    for (int n = 0; n < NS; ++n) {
+        item[n] = base + 16 * n + j;
+        const u64* p = states + (item[n] < count ? item[n] : count - 1) * 16;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s[4 * n + i] = p[4 * i + q];
+    }
+    if (trace) {
+#pragma unroll 1
+        for (int r = 0; r < 6; ++r) {
+            if (r) tip5_round_mx<NS, true>(s, r - 1, &lds, a, q);  // every traced state is canonical
+#pragma unroll
+            for (int n = 0; n < NS; ++n)
+                if (item[n] < count) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) trace[item[n] * 96 + 16 * r + 4 * i + q] = s[4 * n + i];
+                }
+        }
+    } else {
+        tip5_permutation_mx<NS>(s, &lds, a, q);
+    }
+#pragma unroll
+    for (int n = 0; n < NS; ++n)
+        if (item[n] < count) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) states[item[n] * 16 + 4 * i + q] = s[4 * n + i];
+        }
+    }
 }
 
 // ---- cooperative form: the 16 lanes of a DPP row hold the 16 state words of ONE permutation ------------------
@@ -292,7 +544,9 @@ __device__ __forceinline__ void tip5_permutation_coop(u64& s, int j, const unsig
     }
 }
 
-// hash_pair per 16-lane row: item i = blockIdx.x * 16 + threadIdx.x / 16.  Same addressing as tip5_hash_pairs_kernel.
+// hash_pair per 16-lane row: item i = blockIdx.x * 16 + threadIdx.x / 16.  Same item i belongs to tree i / per_tree; its input is in + tree * in_ts + 10 * (i % per_tree), its
+// digest goes to out + tree * out_ts + 5 * (i % per_tree); if leaf_copy != null the 10 input words are also copied to
+// leaf_copy + tree * copy_ts + 10 * (i % per_tree) (Merkle leaf level, merkle_tree.rs:426).
 __global__ void __launch_bounds__(256) tip5_hash_pairs_coop_kernel(const u64* in, u64* out, long long count, long long per_tree,
                                                                    long long in_ts, long long out_ts) {
     __shared__ __attribute__((aligned(16))) unsigned char lut[256];
