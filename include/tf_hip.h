@@ -80,6 +80,44 @@ int tf_device_count(void);
 int tf_release_caches(void);
 
 /* ---------------------------------------------------------------------------------------------
+ * Devices.  Every entry point of this header runs on the calling thread's CURRENT HIP device (hipSetDevice semantics: per host
+ * thread, default 0); the library keeps its tables, pools and streams per device, and any number of host threads may be inside it
+ * on the same or on different devices.  tf_set_device / tf_get_device are that selector for callers that do not link the HIP
+ * runtime themselves (a Rust crate binds only this library).
+ * Errors: device < 0 or >= tf_device_count() -> TF_ERR_NO_DEVICE.
+ */
+int tf_set_device(int device);
+int tf_get_device(int *device);
+
+/* ---------------------------------------------------------------------------------------------
+ * One host-resident batch over several GPUs.      replaces  the rayon fan-out over independent units in the reference's callers:
+ *                                                            par_iter over polynomials around ntt / fast_coset_evaluate
+ *                                                            (math/ntt.rs:250-274 is the unit), MerkleTree::par_new's
+ *                                                            thread split util_types/merkle_tree.rs:165-212
+ * Same arguments and results as tf_ntt_{bfe,xfe}, tf_coset_eval_{bfe,xfe}, tf_merkle_{build,root} on HOST pointers, plus a device
+ * list: `devices` = n_devices device indices, or NULL for every visible device (n_devices is then ignored).  The `batch` units
+ * (transforms, polynomials, trees) are independent; they are cut into n_devices contiguous slices by tf_shard_range's rule
+ * (slice g takes units [g*base + min(g, extra), ...) with base = batch / G, extra = batch % G: the first `extra` slices hold one
+ * more unit) and one worker thread per slice runs the single-device entry point on devices[g]: its own stream, its own H2D /
+ * compute / D2H, all slices concurrently -- a host-resident batch crosses every listed GPU's PCIe link at once.  Nothing is
+ * exchanged between devices and no collective library is involved; every result lands in the caller's buffer at its unit's
+ * offset, so the output is word for word that of the single-device call.  A device may be listed more than once (several
+ * workers, i.e. several copy/compute streams, on one GPU).  The calling thread's current device is not changed.
+ * Errors: argument errors exactly as the single-device call (checked before any worker starts); a device index out of range ->
+ * TF_ERR_NO_DEVICE; if workers fail, the status of the first failing slice in batch order is returned and tf_last_error() names
+ * the device and slice.
+ */
+int tf_shard_range(size_t total_units, int n_shards, int shard, size_t *begin, size_t *end);
+int tf_ntt_bfe_multi(uint64_t *x, size_t n, size_t batch, int inverse, const int *devices, int n_devices);
+int tf_ntt_xfe_multi(uint64_t *x, size_t n, size_t batch, int inverse, const int *devices, int n_devices);
+int tf_coset_eval_bfe_multi(const uint64_t *coeffs, size_t n_coeffs, uint64_t offset_raw, uint64_t *out, size_t order, size_t batch,
+                            const int *devices, int n_devices);
+int tf_coset_eval_xfe_multi(const uint64_t *coeffs, size_t n_coeffs, uint64_t offset_raw, uint64_t *out, size_t order, size_t batch,
+                            const int *devices, int n_devices);
+int tf_merkle_build_multi(const uint64_t *leaves, size_t n_leaves, uint64_t *nodes_out, size_t batch, const int *devices, int n_devices);
+int tf_merkle_root_multi(const uint64_t *leaves, size_t n_leaves, uint64_t *root_out, size_t batch, const int *devices, int n_devices);
+
+/* ---------------------------------------------------------------------------------------------
  * NTT / iNTT            replaces  pub fn ntt<FF>(x: &mut [FF])   math/ntt.rs:67-82
  *                                 pub fn intt<FF>(x: &mut [FF])  math/ntt.rs:109-125
  * x: `batch` contiguous slices of n elements each, transformed in place, natural order in and out.

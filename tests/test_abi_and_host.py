@@ -56,7 +56,7 @@ def test_library_is_native_gfx950_code():
     so = os.path.join(ROOT, "twenty-first_amd", "libtf_hip.so")
     blob = open(so, "rb").read()
     assert b"gfx950" in blob
-    assert b"ntt_pass_kernel" in blob and b"tip5_hash_pairs_kernel" in blob
+    assert b"ntt_pass_kernel" in blob and b"tip5_hash_pairs_mx_kernel" in blob and b"tip5_hash_pairs_coop_kernel" in blob
 
 
 def test_product_does_not_import_the_oracle():
@@ -128,6 +128,43 @@ def test_shard_ranges():
     assert shard_range(4096, 8, 3) == (1536, 2048)  # BASELINE config 5: 4096 NTTs over 8 GPUs
     with pytest.raises(ValueError):
         shard_range(4, 2, 2)
+
+
+def test_c_abi_shard_range_is_the_python_split(tf):
+    """tf_shard_range (the split of the tf_*_multi entry points, include/tf_hip.h) == sharding.shard_range, ragged batches included"""
+    from twenty_first_amd.sharding import shard_range
+
+    for total in [0, 1, 2, 7, 8, 9, 255, 256, 257, 4096, 4099, (1 << 40) + 5]:
+        for world in [1, 2, 3, 4, 7, 8, 16]:
+            got = [tf.shard_range(total, world, r) for r in range(world)]
+            assert got == [shard_range(total, world, r) for r in range(world)]
+            assert got[0][0] == 0 and got[-1][1] == total
+    import ctypes as C
+    lo, hi = C.c_size_t(0), C.c_size_t(0)
+    lib = tf.lib()
+    assert lib.tf_shard_range(10, 0, 0, C.byref(lo), C.byref(hi)) == 8      # no shards
+    assert lib.tf_shard_range(10, 2, 2, C.byref(lo), C.byref(hi)) == 8      # shard out of range
+    assert lib.tf_shard_range(10, 2, 1, None, C.byref(hi)) == 7             # TF_ERR_NULL_POINTER
+
+
+def test_multi_device_entry_points_without_a_device(tf):
+    """argument errors of the tf_*_multi calls are those of the single-device calls and come first; with no GPU the rest is
+    TF_ERR_NO_DEVICE -- never a CPU fallback"""
+    if tf.lib().tf_device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(tf.NttPanic):
+        tf.ntt(np.zeros(6, dtype=np.uint64), devices="all")
+    with pytest.raises(tf.MerkleTreeError) as e:
+        tf.MerkleTree.build_batch(np.zeros(15, dtype=np.uint64), 3, devices=[0])
+    assert e.value.variant == "IncorrectNumberOfLeafs"
+    for call in (lambda: tf.ntt(np.zeros(8, dtype=np.uint64), devices="all"),
+                 lambda: tf.ntt(np.zeros(8, dtype=np.uint64), devices=[0, 0]),
+                 lambda: tf.fast_coset_evaluate(np.zeros(8, dtype=np.uint64), 7, 8, devices=[0]),
+                 lambda: tf.MerkleTree.roots_batch(np.zeros(20, dtype=np.uint64), 2, devices="all"),
+                 lambda: tf.set_device(0)):
+        with pytest.raises(tf.TwentyFirstError) as e:
+            call()
+        assert e.value.code == 8  # TF_ERR_NO_DEVICE
 
 
 def test_length_checks_precede_any_device_work(tf):

@@ -30,3 +30,5 @@ def test_selftest_on_gpu():
     assert r.returncode == 0, r.stdout + r.stderr
     assert "all reference KATs pass" in r.stdout
     assert "host threads" in r.stdout and "same words as one device alone" in r.stdout  # the multi-device section ran
+    assert "tf_*_multi slice" in r.stdout and "same words as the single-device calls" in r.stdout  # ... and the one-call split
+    assert "FAIL" not in r.stdout

@@ -932,3 +932,81 @@ def test_chained_column_pass_gives_the_same_words(tf, oracle):
                 assert torch.equal(x, src if inverse else ref), (k, inverse)
     finally:
         lib.tf_set_ntt_chain(0)
+
+
+# ---- one host-resident batch over several GPUs at the C ABI (tf_*_multi, include/tf_hip.h) ------------------------------
+# A one-GPU box lists device 0 several times: several worker threads, streams and copies in flight on one device.
+@pytest.mark.parametrize("devices", [[0], [0, 0], [0, 0, 0], "all"])
+@pytest.mark.parametrize("width", [1, 3])
+def test_multi_device_ntt_matches_oracle(tf, oracle, devices, width):
+    """tf_ntt_{bfe,xfe}_multi: a ragged batch (7 transforms: slices of 3 + 2 + 2 over three workers), forward and inverse"""
+    n, batch = 1 << 12, 7
+    x = oracle.fill_random(n * batch * width, 3100 + width)
+    got = x.copy()
+    tf.ntt(got, width=width, batch=batch, devices=devices)
+    assert np.array_equal(got, oracle.ntt(x, width=width, batch=batch, threads=4))
+    tf.intt(got, width=width, batch=batch, devices=devices)
+    assert np.array_equal(got, x)
+
+
+def test_multi_device_fewer_units_than_workers(tf, oracle):
+    """two transforms over five workers (three empty slices), one unit, an empty batch"""
+    n = 1 << 10
+    x = oracle.fill_random(2 * n, 3200)
+    got = x.copy()
+    tf.ntt(got, batch=2, devices=[0, 0, 0, 0, 0])
+    assert np.array_equal(got, oracle.ntt(x, batch=2))
+    one = x[:n].copy()
+    tf.ntt(one, batch=1, devices=[0, 0])
+    assert np.array_equal(one, oracle.ntt(x[:n]))
+    tf.ntt(np.zeros(0, dtype=np.uint64), batch=0, devices=[0, 0])
+
+
+@pytest.mark.parametrize("devices", [[0, 0], [0, 0, 0, 0], "all"])
+def test_multi_device_merkle_and_coset_match_oracle(tf, oracle, devices):
+    """tf_merkle_{build,root}_multi and tf_coset_eval_{bfe,xfe}_multi: every word of every unit, ragged splits"""
+    n, batch = 1 << 9, 5
+    leafs = oracle.fill_random(batch * n * 5, 3300)
+    nodes = tf.MerkleTree.build_batch(leafs, n, devices=devices)
+    roots = tf.MerkleTree.roots_batch(leafs, n, devices=devices)
+    for b in range(batch):
+        want = oracle.merkle_build(leafs[b * n * 5:(b + 1) * n * 5])
+        assert np.array_equal(nodes[b].reshape(-1), want)
+        assert np.array_equal(roots[b], want[5:10])
+    off = oracle.bfe_new(7)
+    for width in (1, 3):
+        nc, order, polys = 300, 1 << 10, 6
+        c = oracle.fill_random(polys * nc * width, 3400 + width)
+        got = tf.fast_coset_evaluate(c, off, order, width=width, batch=polys, devices=devices)
+        assert np.array_equal(got, oracle.coset_evaluate_batch(c, off, order, polys, width=width, threads=2))
+
+
+def test_multi_device_errors_and_current_device(tf, oracle):
+    """argument errors as the single-device calls; a device index out of range is TF_ERR_NO_DEVICE and names the index; the
+    caller's current device is untouched"""
+    assert tf.get_device() == 0
+    with pytest.raises(tf.NttPanic):
+        tf.ntt(np.zeros(12, dtype=np.uint64), devices=[0, 0])
+    with pytest.raises(tf.MerkleTreeError):
+        tf.MerkleTree.build_batch(np.zeros(30, dtype=np.uint64), 3, devices=[0, 0])
+    with pytest.raises(tf.NttPanic):  # order below the coefficient count
+        tf.fast_coset_evaluate(oracle.fill_random(64, 1), oracle.bfe_new(7), 16, batch=2, devices=[0, 0])
+    bad = tf.lib().tf_device_count()
+    with pytest.raises(tf.TwentyFirstError) as e:
+        tf.ntt(np.zeros(16, dtype=np.uint64), batch=2, devices=[0, bad])
+    assert e.value.code == 8 and str(bad) in tf.lib().tf_last_error().decode()
+    with pytest.raises(tf.TwentyFirstError):
+        tf.set_device(bad)
+    tf.set_device(0)
+    assert tf.get_device() == 0
+
+
+def test_multi_device_matches_single_device_at_size(tf, oracle):
+    """64 transforms of 2^16 points over four workers: the words of the one-call result"""
+    n, batch = 1 << 16, 64
+    x = oracle.fill_random(n * batch, 3500)
+    a, b = x.copy(), x.copy()
+    tf.ntt(a, batch=batch)
+    tf.ntt(b, batch=batch, devices=[0, 0, 0, 0])
+    assert np.array_equal(a, b)
+    assert np.array_equal(a[:n], oracle.ntt(x[:n]))

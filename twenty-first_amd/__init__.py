@@ -27,7 +27,7 @@ from . import _lib
 
 __all__ = [
     "P", "BFieldElement", "ntt", "intt", "Polynomial", "ZerofierTree", "barycentric_evaluate", "fast_coset_evaluate", "fast_coset_interpolate", "fast_multiply", "fast_square", "Tip5", "Tip5Sponge", "Digest", "MerkleTree",
-    "MerkleTreeError", "TwentyFirstError", "NttPanic", "lib", "device",
+    "MerkleTreeError", "TwentyFirstError", "NttPanic", "lib", "device", "set_device", "get_device", "shard_range",
 ]
 
 P = 0xFFFFFFFF00000001  # BFieldElement::P, math/b_field_element.rs:225
@@ -117,23 +117,61 @@ def _ptr(a: np.ndarray):
     return C.c_void_p(a.ctypes.data) if a.size else C.c_void_p(0)
 
 
+# ----------------------------------------------------------------------------- devices
+def set_device(device: int) -> None:
+    """Select the GPU every later call of this host thread runs on (include/tf_hip.h: tf_set_device)."""
+    _check(lib().tf_set_device(int(device)), "set_device")
+
+
+def get_device() -> int:
+    d = C.c_int(0)
+    _check(lib().tf_get_device(C.byref(d)), "get_device")
+    return d.value
+
+
+def shard_range(total_units: int, n_shards: int, shard: int):
+    """[lo, hi) of slice `shard` when `total_units` independent units are split over `n_shards` devices: the rule of the
+    multi-device entry points (tf_shard_range), the same as sharding.shard_range."""
+    lo, hi = C.c_size_t(0), C.c_size_t(0)
+    _check(lib().tf_shard_range(total_units, n_shards, shard, C.byref(lo), C.byref(hi)), "shard_range")
+    return lo.value, hi.value
+
+
+def _devices(devices):
+    """devices="all" -> (NULL, 0): every visible GPU; a sequence of indices -> (int array, count).  The same index may repeat."""
+    if isinstance(devices, str):
+        if devices != "all":
+            raise ValueError('devices must be "all" or a sequence of device indices')
+        return C.cast(C.c_void_p(0), C.POINTER(C.c_int)), 0
+    ids = [int(d) for d in devices]
+    if not ids:
+        raise ValueError("devices must not be empty")
+    return (C.c_int * len(ids))(*ids), len(ids)
+
+
 # ----------------------------------------------------------------------------- NTT
-def ntt(x: np.ndarray, width: int = 1, batch: int = 1, _inverse: bool = False) -> None:
+def ntt(x: np.ndarray, width: int = 1, batch: int = 1, _inverse: bool = False, devices=None) -> None:
     """In-place NTT of `batch` contiguous slices (math/ntt.rs:67-82).  width 1 = BFieldElement slice,
-    3 = XFieldElement slice.  Raises NttPanic where the reference panics."""
+    3 = XFieldElement slice.  Raises NttPanic where the reference panics.
+    devices: None = the current GPU; "all" or a list of device indices = the batch split over those GPUs (tf_ntt_*_multi)."""
     x = _words(x)
     if width not in (1, 3):
         raise ValueError("width must be 1 (BFieldElement) or 3 (XFieldElement)")
     if batch < 0 or (batch and x.size % (batch * width)):
         raise ValueError("array size is not batch * n * width")
     n = x.size // (batch * width) if batch else 0
+    if devices is not None:
+        ids, k = _devices(devices)
+        fn = lib().tf_ntt_bfe_multi if width == 1 else lib().tf_ntt_xfe_multi
+        _check(fn(_ptr(x), n, batch, int(_inverse), ids, k), "intt" if _inverse else "ntt")
+        return
     fn = lib().tf_ntt_bfe if width == 1 else lib().tf_ntt_xfe
     _check(fn(_ptr(x), n, batch, int(_inverse)), "intt" if _inverse else "ntt")
 
 
-def intt(x: np.ndarray, width: int = 1, batch: int = 1) -> None:
+def intt(x: np.ndarray, width: int = 1, batch: int = 1, devices=None) -> None:
     """In-place inverse NTT (math/ntt.rs:109-125)."""
-    ntt(x, width=width, batch=batch, _inverse=True)
+    ntt(x, width=width, batch=batch, _inverse=True, devices=devices)
 
 
 def _xfe_offset(offset, width: int):
@@ -149,7 +187,7 @@ def _xfe_offset(offset, width: int):
     return off
 
 
-def fast_coset_evaluate(coeffs: np.ndarray, offset_raw, order: int, width: int = 1, batch: int = 1) -> np.ndarray:
+def fast_coset_evaluate(coeffs: np.ndarray, offset_raw, order: int, width: int = 1, batch: int = 1, devices=None) -> np.ndarray:
     """`batch` polynomials of equal length -> `batch` x `order` evaluations (math/polynomial.rs:1374-1399).
     The reference compares `order` with the DEGREE (:1388): high-order zero coefficients common to the whole batch are
     trimmed here before the length reaches the C ABI, as Polynomial::degree() does for one polynomial."""
@@ -170,6 +208,11 @@ def fast_coset_evaluate(coeffs: np.ndarray, offset_raw, order: int, width: int =
         _check(lib().tf_coset_eval_xfe_xoffset(_ptr(coeffs), n_coeffs, _ptr(xoff), _ptr(out), order, batch), "fast_coset_evaluate")
         return out
     offset_raw = int(np.asarray(offset_raw).reshape(-1)[0])
+    if devices is not None:  # the polynomials of the batch split over several GPUs (tf_coset_eval_*_multi)
+        ids, k = _devices(devices)
+        fn = lib().tf_coset_eval_bfe_multi if width == 1 else lib().tf_coset_eval_xfe_multi
+        _check(fn(_ptr(coeffs), n_coeffs, C.c_uint64(offset_raw), _ptr(out), order, batch, ids, k), "fast_coset_evaluate")
+        return out
     fn = lib().tf_coset_eval_bfe if width == 1 else lib().tf_coset_eval_xfe
     _check(fn(_ptr(coeffs), n_coeffs, C.c_uint64(offset_raw), _ptr(out), order, batch), "fast_coset_evaluate")
     return out
@@ -614,8 +657,8 @@ class MerkleTree:
     sequential_new = par_new  # :149-153 -- same result by construction (tests :1059-1087)
 
     @staticmethod
-    def build_batch(leafs: np.ndarray, n_leafs: int) -> np.ndarray:
-        """`batch` independent trees of n_leafs leaves each -> (batch, 2n, 5)."""
+    def build_batch(leafs: np.ndarray, n_leafs: int, devices=None) -> np.ndarray:
+        """`batch` independent trees of n_leafs leaves each -> (batch, 2n, 5); devices: as ntt()."""
         leafs = _words(leafs, "leafs")
         if n_leafs <= 0 or leafs.size % (5 * n_leafs):
             if n_leafs == 0:
@@ -623,7 +666,11 @@ class MerkleTree:
             raise ValueError("leafs size is not batch * n_leafs * 5")
         batch = leafs.size // (5 * n_leafs)
         nodes = np.empty(batch * 10 * n_leafs, dtype=np.uint64)
-        _check(lib().tf_merkle_build(_ptr(leafs), n_leafs, _ptr(nodes), batch), "MerkleTree::par_new")
+        if devices is not None:
+            ids, k = _devices(devices)
+            _check(lib().tf_merkle_build_multi(_ptr(leafs), n_leafs, _ptr(nodes), batch, ids, k), "MerkleTree::par_new")
+        else:
+            _check(lib().tf_merkle_build(_ptr(leafs), n_leafs, _ptr(nodes), batch), "MerkleTree::par_new")
         return nodes.reshape(batch, 2 * n_leafs, 5)
 
     @staticmethod
@@ -642,11 +689,15 @@ class MerkleTree:
         return MerkleTree.sequential_frugal_root(leafs)
 
     @staticmethod
-    def roots_batch(leafs: np.ndarray, n_leafs: int) -> np.ndarray:
+    def roots_batch(leafs: np.ndarray, n_leafs: int, devices=None) -> np.ndarray:
         leafs = _words(leafs, "leafs")
         batch = leafs.size // (5 * n_leafs) if n_leafs else 0
         roots = np.empty(max(batch, 1) * 5, dtype=np.uint64)
-        _check(lib().tf_merkle_root(_ptr(leafs), n_leafs, _ptr(roots), batch), "MerkleTree::par_frugal_root")
+        if devices is not None:
+            ids, k = _devices(devices)
+            _check(lib().tf_merkle_root_multi(_ptr(leafs), n_leafs, _ptr(roots), batch, ids, k), "MerkleTree::par_frugal_root")
+        else:
+            _check(lib().tf_merkle_root(_ptr(leafs), n_leafs, _ptr(roots), batch), "MerkleTree::par_frugal_root")
         return roots[: batch * 5].reshape(batch, 5)
 
     @classmethod

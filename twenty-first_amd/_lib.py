@@ -24,6 +24,15 @@ SIGNATURES = {
     "tf_version": (C.c_int, []),
     "tf_source_hash": (C.c_char_p, []),
     "tf_device_count": (C.c_int, []),
+    "tf_set_device": (C.c_int, [C.c_int]),
+    "tf_get_device": (C.c_int, [C.POINTER(C.c_int)]),
+    "tf_shard_range": (C.c_int, [_sz, C.c_int, C.c_int, C.POINTER(_sz), C.POINTER(_sz)]),
+    "tf_ntt_bfe_multi": (C.c_int, [_vp, _sz, _sz, C.c_int, C.POINTER(C.c_int), C.c_int]),
+    "tf_ntt_xfe_multi": (C.c_int, [_vp, _sz, _sz, C.c_int, C.POINTER(C.c_int), C.c_int]),
+    "tf_coset_eval_bfe_multi": (C.c_int, [_vp, _sz, C.c_uint64, _vp, _sz, _sz, C.POINTER(C.c_int), C.c_int]),
+    "tf_coset_eval_xfe_multi": (C.c_int, [_vp, _sz, C.c_uint64, _vp, _sz, _sz, C.POINTER(C.c_int), C.c_int]),
+    "tf_merkle_build_multi": (C.c_int, [_vp, _sz, _vp, _sz, C.POINTER(C.c_int), C.c_int]),
+    "tf_merkle_root_multi": (C.c_int, [_vp, _sz, _vp, _sz, C.POINTER(C.c_int), C.c_int]),
     "tf_ntt_bfe": (C.c_int, [_vp, _sz, _sz, C.c_int]),
     "tf_ntt_xfe": (C.c_int, [_vp, _sz, _sz, C.c_int]),
     "tf_ntt_bfe_dev": (C.c_int, [_vp, _sz, _sz, C.c_int, _vp]),

@@ -30,18 +30,26 @@ int h2d(u64* d, const u64* h, size_t words, hipStream_t s) {
     return TF_OK;
 }
 
-// One private non-blocking stream per (host thread, device) for the host-pointer entry points.
+// One private non-blocking stream per (host thread, device) for the host-pointer entry points; destroyed with the thread
+// (the workers of tf_*_multi are short-lived threads).
+struct HostStreams {
+    hipStream_t s[kMaxDevices] = {};
+    ~HostStreams() {
+        for (int d = 0; d < kMaxDevices; ++d)
+            if (s[d]) (void)hipStreamDestroy(s[d]);
+    }
+};
 hipStream_t host_stream() {
-    thread_local hipStream_t streams[kMaxDevices] = {};
+    thread_local HostStreams streams;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return nullptr;
-    if (!streams[dev]) {
-        if (hipStreamCreateWithFlags(&streams[dev], hipStreamNonBlocking) != hipSuccess) {
+    if (!streams.s[dev]) {
+        if (hipStreamCreateWithFlags(&streams.s[dev], hipStreamNonBlocking) != hipSuccess) {
             (void)hipGetLastError();
-            streams[dev] = nullptr;
+            streams.s[dev] = nullptr;
         }
     }
-    return streams[dev];
+    return streams.s[dev];
 }
 int d2h(u64* h, const u64* d, size_t words, hipStream_t s) {
     if (!words) return TF_OK;

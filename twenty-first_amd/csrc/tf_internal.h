@@ -5,6 +5,7 @@
 //   tf_tip5.hip   Tip5 / Merkle launchers (tip5_kernels.h), authentication structures
 //   tf_poly.hip   the callers on either side of the path, SURVEY 8(f) (poly_kernels.h)
 //   tf_abi.hip    host-pointer wrappers and the extern "C" entry points
+//   tf_multi.hip  one host-resident batch over several GPUs (tf_*_multi), device selection
 #pragma once
 #include <hip/hip_runtime.h>
 

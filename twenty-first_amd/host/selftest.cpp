@@ -3,6 +3,7 @@
 // Exit code 0 = all passed; 77 = no GPU (skipped); anything else = failure.
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <thread>
 #include <vector>
@@ -76,6 +77,43 @@ static void multi_device_check(const std::vector<int>& devs) {
                ok ? "PASS, same words as device 0 alone" : "FAIL", res[i].rc, (unsigned long long)(res[i].nodes.size() > 5 ? res[i].nodes[5] : 0));
     }
     (void)hipSetDevice(devs[0]);
+}
+
+// One host-resident batch over every device of the node in ONE C call (tf_ntt_bfe_multi / tf_merkle_root_multi / tf_coset_eval_bfe_multi,
+// include/tf_hip.h): the words must be those of the single-device call on device devs[0].  13 units over the device list: a ragged
+// split whatever the device count.
+static void multi_call_check(const std::vector<int>& devs) {
+    const size_t n = size_t(1) << 14, batch = 13, leaves = size_t(1) << 10, nc = 1000, order = size_t(1) << 11;
+    std::vector<uint64_t> x(n * batch), lv(5 * leaves * batch), co(nc * batch);
+    uint64_t st = 0x7F210006ull;
+    auto next = [&]() { st += 0x9e3779b97f4a7c15ull; uint64_t z = st; z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull; z = (z ^ (z >> 27)) * 0x94d049bb133111ebull; z ^= z >> 31; return z % 0xffffffff00000001ull; };
+    for (auto& v : x) v = next();
+    for (auto& v : lv) v = next();
+    for (auto& v : co) v = next();
+    (void)hipSetDevice(devs[0]);
+    std::vector<uint64_t> x1 = x, xm = x, r1(5 * batch), rm(5 * batch), e1(order * batch), em(order * batch);
+    const uint64_t off = BFieldElement::new_(7).raw;
+    EXPECT(tf_ntt_bfe(x1.data(), n, batch, 0) == TF_OK);
+    EXPECT(tf_merkle_root(lv.data(), leaves, r1.data(), batch) == TF_OK);
+    EXPECT(tf_coset_eval_bfe(co.data(), nc, off, e1.data(), order, batch) == TF_OK);
+    const int rc_n = tf_ntt_bfe_multi(xm.data(), n, batch, 0, devs.data(), (int)devs.size());
+    const int rc_m = tf_merkle_root_multi(lv.data(), leaves, rm.data(), batch, devs.data(), (int)devs.size());
+    const int rc_c = tf_coset_eval_bfe_multi(co.data(), nc, off, em.data(), order, batch, devs.data(), (int)devs.size());
+    EXPECT(rc_n == TF_OK && xm == x1);
+    EXPECT(rc_m == TF_OK && rm == r1);
+    EXPECT(rc_c == TF_OK && em == e1);
+    int cur = -1;
+    EXPECT(tf_get_device(&cur) == TF_OK && cur == devs[0]);  // the caller's device is untouched
+    for (size_t g = 0; g < devs.size(); ++g) {
+        size_t lo = 0, hi = 0;
+        EXPECT(tf_shard_range(batch, (int)devs.size(), (int)g, &lo, &hi) == TF_OK);
+        const bool ok = rc_n == TF_OK && rc_m == TF_OK && rc_c == TF_OK &&
+                        std::equal(xm.begin() + lo * n, xm.begin() + hi * n, x1.begin() + lo * n) &&
+                        std::equal(rm.begin() + lo * 5, rm.begin() + hi * 5, r1.begin() + lo * 5) &&
+                        std::equal(em.begin() + lo * order, em.begin() + hi * order, e1.begin() + lo * order);
+        printf("  tf_*_multi slice %zu on device %d, units [%zu, %zu) of %zu: %s (tf_ntt_bfe_multi 2^14, tf_merkle_root_multi 2^10 leaves, tf_coset_eval_bfe_multi 1000 -> 2^11)\n",
+               g, devs[g], lo, hi, batch, ok ? "PASS, same words as the single-device call" : "FAIL");
+    }
 }
 
 int main() {
@@ -298,6 +336,8 @@ int main() {
         multi_device_check(devs);
         printf("C ABI from %zu host threads on %d device(s)%s: same words as one device alone\n", devs.size(), nd,
                nd > 1 ? "" : " (one GPU here: both threads on device 0; the per-device path first runs on a multi-GPU node)");
+        multi_call_check(devs);
+        printf("tf_*_multi over %zu worker(s) on %d device(s): same words as the single-device calls\n", devs.size(), nd);
     }
     if (failures) {
         fprintf(stderr, "%d failure(s)\n", failures);

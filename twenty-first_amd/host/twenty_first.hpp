@@ -110,6 +110,16 @@ inline void intt(std::vector<XFieldElement>& x) { check(tf_ntt_xfe(reinterpret_c
 inline void ntt_batch(BFieldElement* x, size_t n, size_t batch, bool inverse = false) {
     check(tf_ntt_bfe(reinterpret_cast<uint64_t*>(x), n, batch, inverse), inverse ? "intt" : "ntt");
 }
+// ... and the same batch over several GPUs of the node: `devices` empty = every visible device (tf_ntt_bfe_multi: contiguous
+// slices of the batch, one worker thread + stream per listed device, results in place at each slice's offset)
+inline void ntt_batch_multi(BFieldElement* x, size_t n, size_t batch, const std::vector<int>& devices = {}, bool inverse = false) {
+    check(tf_ntt_bfe_multi(reinterpret_cast<uint64_t*>(x), n, batch, inverse, devices.empty() ? nullptr : devices.data(), (int)devices.size()),
+          inverse ? "intt" : "ntt");
+}
+inline void ntt_batch_multi(XFieldElement* x, size_t n, size_t batch, const std::vector<int>& devices = {}, bool inverse = false) {
+    check(tf_ntt_xfe_multi(reinterpret_cast<uint64_t*>(x), n, batch, inverse, devices.empty() ? nullptr : devices.data(), (int)devices.size()),
+          inverse ? "intt" : "ntt");
+}
 
 // ---- Polynomial (math/polynomial.rs:78-84): only the hot-path members ------------------------------
 template <class FF>
@@ -363,6 +373,14 @@ struct MerkleTree {
         return t;
     }
     static MerkleTree sequential_new(const std::vector<Digest>& leafs) { return par_new(leafs); }  // :149-153, same result
+    // `batch` trees of n_leafs leaves each, split over the GPUs of the node (tf_merkle_root_multi); devices empty = all
+    static std::vector<Digest> roots_multi(const std::vector<Digest>& leafs, size_t n_leafs, const std::vector<int>& devices = {}) {
+        const size_t batch = n_leafs ? leafs.size() / n_leafs : 0;
+        std::vector<Digest> roots(batch);
+        check(tf_merkle_root_multi(reinterpret_cast<const uint64_t*>(leafs.data()), n_leafs, reinterpret_cast<uint64_t*>(roots.data()), batch,
+                                   devices.empty() ? nullptr : devices.data(), (int)devices.size()), "MerkleTree::par_frugal_root");
+        return roots;
+    }
     static Digest sequential_frugal_root(const std::vector<Digest>& leafs) {  // :299-309
         Digest r;
         check(tf_merkle_root(reinterpret_cast<const uint64_t*>(leafs.data()), leafs.size(), reinterpret_cast<uint64_t*>(r.values.data()), 1), "MerkleTree::sequential_frugal_root");
