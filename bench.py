@@ -49,6 +49,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICRO
 # and Tip5 kernels, profiles/) at the 2.4 GHz peak engine clock.
 VALU_PEAK_GWIPS = 256 * 4 * 2.4 / 4.0  # 614.4 G wave-instructions/s
 SEED_C2, SEED_C3, SEED_C4, SEED_C5 = 0x7F210002, 0x7F210003, 0x7F210004, 0x7F210005  # seed_c = 0x7F21_0000 + c
+SEED_CP = 0x7F210006  # the commitment-pipeline leg (not a BASELINE config)
 
 
 def self_spawn(args):
@@ -340,8 +341,19 @@ def main():
             except Exception as e:
                 out["config5"] = {"error": repr(e)}
         if world == 1:
+            try:
+                out["commit_pipeline"] = commit_pipeline_leg(ctx)
+            except SystemExit:
+                raise
+            except Exception as e:
+                out["commit_pipeline"] = {"error": repr(e)}
             out["extra"] = side_measurements(tf, torch, dev)
     if use_dist:
+        # the first multi-GPU record must be complete on its own: rank 0 runs the C++ host mirror's self-test (every visible device
+        # driven through the C ABI from its own host thread, and one tf_*_multi call over all of them) and embeds its evidence lines
+        if rank == 0:
+            out["c_abi_selftest"] = c_abi_selftest(tf, np)
+        barrier()
         dist.destroy_process_group()
     sys.stdout.flush()
     if rank == 0:
@@ -445,10 +457,12 @@ def ntt_headline(ctx):
     busy = [b for b in busy if b is not None]
     # `bound`: SURVEY.md 8(d) prices this kernel against HBM (16 B/element) and achieved / peak / frac are that roofline; the
     # resource that actually limits it, by the stored counters of this build, is VALU issue (two resident workgroups per CU keep
-    # the vector ALU busy ~0.88 of the cycles while HBM runs at about half its rate) -- the field says which one the profile shows.
+    # the vector ALU busy ~0.88 of the cycles while HBM runs at about half its rate) -- `limiting_resource` says which one the
+    # profile shows, and `valu_bound` below is that second roofline.
     valu_limited = bool(busy) and min(busy) >= 0.75
     roofline = {
-        "bound": "valu" if valu_limited else "hbm",
+        "bound": "hbm",  # what achieved / peak / frac below are priced against (16 B per element and transform)
+        "limiting_resource": "valu" if valu_limited else "hbm",
         "priced_against": "hbm (SURVEY.md 8(d): 16 B per element and transform)",
         "bound_evidence": (f"stored PMC profile of this build: VALU busy {min(busy):.2f}-{max(busy):.2f} of the cycles at 4 cycles per instruction on the two pass kernels "
                            "(profiles/hbm_traffic_ntt.json per_kernel)") if busy else "no stored profile of this build: the HBM roofline named by SURVEY.md 8(d)",
@@ -520,11 +534,13 @@ def ntt_headline(ctx):
         out["cpu_baseline"] = None
         return out
     first, last = rank * batch, rank * batch + batch - 1
-    units = sorted(set(list(range(first, first + min(batch, 32))) + [last])) if world == 1 else sorted({first, last})
+    # several ranks: the first two and the last transform of the shard -- three transforms, so that the check call is above the
+    # 2^21 words under which the planner switches to its narrow-tile kernels and runs the SAME pass kernels as the timed batch
+    units = sorted(set(list(range(first, first + min(batch, 32))) + [last])) if world == 1 else sorted({first, min(first + 1, last), last})
     ok = check_ntt_units(ctx, SEED_C2, units, n, threads=max(1, min(32, cores // world)))
     all_ok = sharding_all_true(ctx, ok)
     out["parity"] = (("bit-exact vs oracle, word for word, on " + (f"{len(units)} transforms (the first {len(units) - 1} and the last of the batch)" if world == 1 else
-                      f"the first and the last transform of each of the {world} ranks' shards ({2 * world} transforms; every rank checked its own)"))
+                      f"the first two and the last transform of each of the {world} ranks' shards ({len(units) * world} transforms in calls of {len(units)}, the timed plan; every rank checked its own)"))
                      if all_ok else "MISMATCH")
     if not all_ok:
         if rank == 0:
@@ -591,19 +607,24 @@ def merkle_leg(ctx):
     vc = load_profile_json("valu_counts.json")
     res["profile_matches_library"] = {"valu_counts.json": bool(vc) and profile_matches(vc, ctx["ident"])}
     if vc and profile_matches(vc, ctx["ident"]) and vc.get("merkle_valu_wave_instr_per_tree_2p24") and log_nl == 24:
+        # Issue-cycle roofline of the level sweep.  The f64 matrix pipe of gfx950 does not run beside the vector ALU (measured:
+        # profiles/r05_mfma_valu_mix.txt, both = sum), so one SIMD offers one stream of issue cycles: 64 per v_mfma_f64_16x16x4_f64,
+        # 4 per other VALU instruction.  Counts: SQ_INSTS_VALU (which includes the MFMAs) and SQ_INSTS_MFMA of a stored profile.
         wi = vc["merkle_valu_wave_instr_per_tree_2p24"]
-        gw = wi / (e0.elapsed_time(e1) / iters * 1e-3) / 1e9
-        res["roofline"] = {"bound": "valu", "kernel": "tfk::tip5_hash_pairs_kernel (level sweep) + merkle_top_kernel",
-                           "achieved": round(gw, 1), "peak": VALU_PEAK_GWIPS, "unit": "G wave-instr/s", "frac": round(gw / VALU_PEAK_GWIPS, 3),
-                           "wave_instr_per_tree": wi, "valu_instr_per_hash_pair": round(wi * 64.0 / (nl - 1), 1),
-                           "frac_at_2_cycle_issue": round(gw / (2 * VALU_PEAK_GWIPS), 3),
-                           "status": "at its instruction floor: 8 093 VALU instructions per hash_pair (48 Montgomery products for x^7, 512 multiply-adds "
-                                     "for the MDS, the byte look-ups and one recombination per word, per round), the vector ALU issuing every cycle it is "
-                                     "offered; the alternatives (Karatsuba / CRT MDS) were built and measured slower (DESIGN.md 4.3)",
-                           "source": "instruction count: SQ_INSTS_VALU under rocprofv3 --pmc (profiles/valu_counts.json, a stored profile of this library build, NOT this run) x "
-                                     "this run's time.  `peak` prices every instruction at 4 cycles per wave64 (1024 SIMDs x 2.4 GHz / 4), "
-                                     "frac_at_2_cycle_issue at the 2-cycle rate of plain 32-bit VALU; the Tip5 mix (v_mad_u64_u32 and carry chains at 4 "
-                                     "cycles, logic / right shifts / v_add_u32 at 2: profiles/r03_instr_rates.txt) sits between, so neither is a hard ceiling"}
+        mf = vc.get("merkle_mfma_wave_instr_per_tree_2p24") or 0.0
+        secs = e0.elapsed_time(e1) / iters * 1e-3
+        cyc = 4.0 * (wi - mf) + 64.0 * mf
+        g = cyc / secs / 1e9
+        peak = 1024 * 2.4  # G issue cycles / s: 1024 SIMDs x 2.4 GHz
+        res["roofline"] = {"bound": "valu", "kernel": "tfk::tip5_hash_pairs_mx_kernel (level sweep, 4 lanes per permutation, MDS on v_mfma_f64_16x16x4_f64) + 16-lane kernels near the top",
+                           "achieved": round(g, 1), "peak": round(peak, 1), "unit": "G issue cycles/s (4 per VALU instruction, 64 per f64 MFMA)", "frac": round(g / peak, 3),
+                           "valu_wave_instr_per_tree": wi, "mfma_wave_instr_per_tree": mf,
+                           "valu_instr_per_hash_pair_per_lane_quartet": round((wi - mf) * 16.0 / (nl - 1), 1), "mfma_per_16_hash_pairs": round(mf * 16.0 / (nl - 1), 2),
+                           "status": "per 16 hash_pairs and round: 8 MFMA (512 cycles) + ~220 VALU instructions (180 of them the twelve x^7 = 36 Montgomery products "
+                                     "per quartet column, the rest byte look-ups, 8 conversions and the 6-instruction recombinations); frac < 1 is the clock "
+                                     "the chip holds under this mix and the ramp of the small levels, not idle issue slots (DESIGN.md 4.3)",
+                           "source": "instruction counts: SQ_INSTS_VALU / SQ_INSTS_MFMA under rocprofv3 --pmc (profiles/valu_counts.json, a stored profile of this library build, "
+                                     "NOT this run) x this run's time; peak = 1024 SIMDs x 2.4 GHz"}
     if use_dist and world & (world - 1) == 0:
         # the same 2^24-leaf tree as ONE tree across the ranks (reference's subtree split, sharding.sharded_tree): rank g builds
         # the subtree over leaves [g n / G, (g + 1) n / G), the G subtree roots are all-gathered, every rank finishes the top
@@ -672,14 +693,14 @@ def merkle_leg(ctx):
 
 # ------------------------------------------------------------------------------------------------ configs[3]: XFE coset evaluation
 def coset_bound(ctx):
-    """`bound` of the configs[3] roofline: priced against HBM (48 B/point); "valu" when the stored PMC profile of
-    this library build shows both PRE2 pass kernels VALU-busy (profiles/valu_counts.json: coset_eval_valu_busy)."""
+    """The configs[3] roofline is priced against HBM (48 B/point): `bound` says so; `limiting_resource` is "valu"
+    when the stored PMC profile of this library build shows both PRE2 pass kernels VALU-busy (profiles/valu_counts.json)."""
     vc = load_profile_json("valu_counts.json")
     busy = (vc or {}).get("coset_eval_valu_busy_frac_at_4_cycles") if profile_matches(vc, ctx["ident"]) else None
     if busy and min(busy) >= 0.75:
-        return {"bound": "valu", "priced_against": "hbm (48 B per point)",
+        return {"bound": "hbm", "limiting_resource": "valu", "priced_against": "hbm (48 B per point)",
                 "bound_evidence": f"stored PMC profile of this build: VALU busy {min(busy):.2f}-{max(busy):.2f} on the two pass kernels (profiles/valu_counts.json)"}
-    return {"bound": "hbm", "priced_against": "hbm (48 B per point)",
+    return {"bound": "hbm", "limiting_resource": "hbm", "priced_against": "hbm (48 B per point)",
             "bound_evidence": "no stored profile of this build" if not busy else f"stored profile: VALU busy {min(busy):.2f}-{max(busy):.2f}"}
 
 
@@ -856,12 +877,13 @@ def config5_leg(ctx, steps, warmup, headline):
     cores = os.cpu_count() or 1
     th = max(1, min(16, cores // world))
     ok = bool(np.array_equal(digest.cpu().numpy().view(np.uint64), tfo.hash_varlen(roots.cpu().numpy().view(np.uint64).reshape(-1))))
-    ok = ok and check_ntt_units(ctx, SEED_C5, sorted({t_lo, t_hi - 1}) if nt else [], n, threads=2)
+    # (three transforms per check call: above 2^21 words, i.e. the pass kernels of the timed batch, not the narrow-tile plan)
+    ok = ok and check_ntt_units(ctx, SEED_C5, sorted({t_lo, min(t_lo + 1, t_hi - 1), t_hi - 1}) if nt else [], n, threads=3)
     tree_units = sorted({m_lo, m_hi - 1}) if nm else []
     ok = ok and check_tree_units(ctx, SEED_C5 ^ (1 << 40), tree_units, nl, threads=th)
     # ... and the gathered roots of those trees are the ones this rank just rebuilt and checked node by node
     all_ok = sharding_all_true(ctx, ok)
-    res["parity"] = ((f"bit-exact vs oracle on every rank: first + last transform and first + last tree (all 2^{log_n5 + 1} nodes) of each of the {world} shard(s), "
+    res["parity"] = ((f"bit-exact vs oracle on every rank: first two + last transform and first + last tree (all 2^{log_n5 + 1} nodes) of each of the {world} shard(s), "
                       "and the roots digest (oracle hash_varlen of the gathered roots)") if all_ok else "MISMATCH")
     if not all_ok:
         raise SystemExit(f"rank {rank}: config 5 differs from the oracle" if not ok else f"rank {rank}: another rank reported a config-5 mismatch")
@@ -893,6 +915,135 @@ def config5_leg(ctx, steps, warmup, headline):
         res["cpu_baseline"] = info
     barrier()
     return res
+
+
+def commit_pipeline_leg(ctx):
+    """One prover-shaped composite, device-resident end to end: 128 columns of 2^18 values on the coset 1 * <w>
+    -> low-degree extension to 2^21 points on 7 * <w'> (tf_lde_bfe_dev = fast_coset_interpolate + fast_coset_evaluate,
+    math/polynomial.rs:1907-1918, :1374-1399) -> hash_varlen of every row of that column-major table (tip5/mod.rs:617-623)
+    -> Merkle tree over the 2^21 row digests (util_types/merkle_tree.rs:165-212).  The root is compared with the oracle's, the oracle
+    pipeline is timed on all host cores, and each half is priced against its roofline."""
+    tf, torch, np, dev, args = ctx["tf"], ctx["torch"], ctx["np"], ctx["dev"], ctx["args"]
+    cols, log_n, log_m = 128, 18, 21
+    n, m = 1 << log_n, 1 << log_m
+    one, seven = tf.BFieldElement.new(1), tf.BFieldElement.new(7)
+    vals = torch.empty(cols * n, dtype=torch.int64, device=dev)
+    tf.device.fill_random(vals, SEED_CP)
+    ext = torch.empty(cols * m, dtype=torch.int64, device=dev)
+    nodes = torch.empty(10 * m, dtype=torch.int64, device=dev)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+
+    def step(timed=False):
+        if timed:
+            ev[0].record()
+        tf.device.lde(vals, n, one, ext, m, seven, batch=cols)
+        if timed:
+            ev[1].record()
+        tf.device.merkle_from_columns(ext, m, cols, nodes)
+        if timed:
+            ev[2].record()
+
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    iters, lde_ms, tree_ms = 8, 0.0, 0.0
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        step(True)
+        torch.cuda.synchronize()
+        lde_ms += ev[0].elapsed_time(ev[1])
+        tree_ms += ev[1].elapsed_time(ev[2])
+    wall_ms = (time.perf_counter() - t0) / iters * 1e3
+    lde_ms, tree_ms = lde_ms / iters, tree_ms / iters
+    row_len = cols
+    perms = m * (row_len // 10 + 1) + (m - 1)  # hash_varlen of a 128-word row absorbs 13 chunks (12 full + the padded one); the tree adds m - 1
+    lde_bytes = 16.0 * cols * (n + m)          # SURVEY.md 8(d): 16 B per element and transform (iNTT over 2^18, NTT over 2^21)
+    res = {
+        "metric": "commit_pipeline_rows_per_s", "value": round(m / ((lde_ms + tree_ms) * 1e-3), 1), "unit": "rows/s",
+        "ms_per_step": round(lde_ms + tree_ms, 4), "wall_ms_per_step": round(wall_ms, 4),
+        "config": {"workload": f"{cols} BFieldElement columns x 2^{log_n} values -> LDE to 2^{log_m} points (coset 7) -> hash_varlen of the 2^{log_m} rows -> Merkle tree; device-resident",
+                   "inputs": f"SplitMix64, seed 0x{SEED_CP:X}"},
+        "lde": {"ms": round(lde_ms, 4), "g_points_per_s": round(cols * m / lde_ms / 1e6, 3),
+                "roofline": {"bound": "hbm", "achieved": round(lde_bytes / (lde_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": round(lde_bytes / (lde_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes": lde_bytes,
+                             "note": "16 B per element and transform: the inverse transforms over 2^18 points and the forward transforms over 2^21 points (the zero-padded "
+                                     "7/8 of every forward input is never read from HBM, so this counts bytes the kernels do not move: a ceiling on the fraction)"}},
+        "rows_and_tree": {"ms": round(tree_ms, 4), "permutations": perms, "g_permutations_per_s": round(perms / tree_ms / 1e6, 3),
+                          "hbm_frac": round((8.0 * cols * m + 120.0 * m) / (tree_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+    }
+    vc = load_profile_json("valu_counts.json")
+    if vc and profile_matches(vc, ctx["ident"]) and vc.get("merkle_valu_wave_instr_per_tree_2p24"):
+        wi, mf = vc["merkle_valu_wave_instr_per_tree_2p24"], vc.get("merkle_mfma_wave_instr_per_tree_2p24") or 0.0
+        cyc_per_perm = (4.0 * (wi - mf) + 64.0 * mf) / float((1 << 24) - 1)  # SIMD issue cycles per permutation, from the 2^24-leaf tree's counters
+        g = perms * cyc_per_perm / (tree_ms * 1e-3) / 1e9
+        res["rows_and_tree"]["roofline"] = {"bound": "valu", "achieved": round(g, 1), "peak": round(1024 * 2.4, 1), "unit": "G issue cycles/s (4 per VALU instruction, 64 per f64 MFMA)",
+                                            "frac": round(g / (1024 * 2.4), 3), "issue_cycles_per_permutation": round(cyc_per_perm, 1),
+                                            "source": "per-permutation instruction counts of the 2^24-leaf tree (profiles/valu_counts.json, a stored profile of this library build) x this run's permutations and time"}
+    if args.no_cpu_baseline:
+        res["parity"] = "not checked (--no-cpu-baseline)"
+        res["cpu_baseline"] = None
+        return res
+    from oracle import tfo
+
+    flags = tfo.use_native_build()
+    cores = os.cpu_count() or 1
+    th = max(1, min(64, cores))
+    got_root = nodes[5:10].cpu().numpy().view(np.uint64)
+    got_ext_col0 = ext[:m].cpu().numpy().view(np.uint64)
+    del vals, ext, nodes
+    hv = tfo.fill_random(cols * n, SEED_CP)
+    tfo.ntt(hv[:n].copy())
+    tfo.ntt(np.zeros(m, dtype=np.uint64))  # twiddle caches outside the timed region
+    t0 = time.perf_counter()
+    co = tfo.intt(hv, batch=cols, threads=th)            # offset 1: fast_coset_interpolate is the inverse transform
+    hext = tfo.coset_evaluate_batch(co, seven, m, cols, threads=th)
+    t_lde = time.perf_counter() - t0
+    rows = np.ascontiguousarray(hext.reshape(cols, m).T).reshape(-1)  # the same table row-major (not timed: a CPU prover would keep it that way)
+    t0 = time.perf_counter()
+    digs = tfo.hash_varlen_rows(rows, row_len, threads=cores)
+    t_rows = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    want_nodes = tfo.merkle_build(digs, threads=th)
+    t_tree = time.perf_counter() - t0
+    ok = bool(np.array_equal(got_root, want_nodes[5:10]) and np.array_equal(got_ext_col0, hext[:m]))
+    res["root"] = tf.Digest.to_hex(got_root)
+    res["parity"] = "root of the tree and all 2^21 points of codeword 0 match the oracle pipeline (inverse transform -> coset evaluation -> hash_varlen rows -> par_new)" if ok else "MISMATCH"
+    res["cpu_baseline"] = {"value": round(m / (t_lde + t_rows + t_tree), 1), "unit": "rows/s", "cores": cores, "kind": "port",
+                           "seconds": {"lde": round(t_lde, 3), "hash_rows": round(t_rows, 3), "tree": round(t_tree, 3)},
+                           "sample": f"the whole pipeline once: {cols} columns, one per thread on {th} threads for the transforms (intt + coset evaluation restatements), "
+                                     f"the 2^{log_m} rows dealt to {cores} threads for hash_varlen, par_new on {th} threads; the column-major -> row-major copy in between is not timed",
+                           "build_flags": flags}
+    if not ok:
+        raise SystemExit("commit pipeline: GPU result differs from the oracle")
+    return res
+
+
+def c_abi_selftest(tf, np):
+    """twenty-first_amd/host/selftest (C++ mirror over the C ABI) + one tf_ntt_bfe_multi / tf_merkle_root_multi call over every
+    visible device from this process, compared with the single-device words."""
+    rec = {}
+    try:
+        exe = os.path.join(ROOT, "twenty-first_amd", "host", "selftest")
+        r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+        keep = [l.strip() for l in r.stdout.splitlines() if ("host thread" in l or "tf_*_multi" in l or "C ABI from" in l or "selftest:" in l)]
+        rec["selftest"] = {"rc": r.returncode, "lines": keep, "stderr_tail": r.stderr.strip().splitlines()[-3:]}
+    except Exception as e:
+        rec["selftest"] = {"error": repr(e)}
+    try:
+        n, batch, nl = 1 << 16, 24, 1 << 12
+        x = np.random.default_rng(11).integers(0, P, size=n * batch, dtype=np.uint64)
+        lv = np.random.default_rng(12).integers(0, P, size=5 * nl * batch, dtype=np.uint64)
+        a, b = x.copy(), x.copy()
+        tf.ntt(a, batch=batch)
+        tf.ntt(b, batch=batch, devices="all")
+        ra, rb = tf.MerkleTree.roots_batch(lv, nl), tf.MerkleTree.roots_batch(lv, nl, devices="all")
+        rec["multi_call"] = {"devices": int(tf.lib().tf_device_count()), "units": batch,
+                             "ntt_same_words_as_single_device": bool(np.array_equal(a, b)),
+                             "merkle_roots_same_as_single_device": bool(np.array_equal(ra, rb)),
+                             "what": "tf_ntt_bfe_multi (24 x 2^16) and tf_merkle_root_multi (24 trees of 2^12 leaves) over every visible device, host-resident batch"}
+    except Exception as e:
+        rec["multi_call"] = {"error": repr(e)}
+    return rec
 
 
 def side_measurements(tf, torch, dev):
@@ -982,6 +1133,22 @@ def side_measurements(tf, torch, dev):
         dt = time.perf_counter() - t0
         extra["host_pointer_ntt_32x2p20"] = {"ms": round(dt * 1e3, 2), "gfelts_per_s": round(hb * (1 << 20) / dt / 1e9, 3),
                                              "note": "tf_ntt_bfe on pageable host memory: H2D + 2 passes + D2H, synchronous"}
+        # the same host-resident batch through the multi-device entry point (tf_ntt_bfe_multi): every visible GPU, and -- the
+        # shape a one-GPU box can show -- two and four workers on device 0 (separate streams: copies of one slice beside compute
+        # of another).  The words must be those of the single-device call.
+        want = hx.copy()                       # hx has been transformed twice by the single-device entry point
+        multi = {}
+        ndev = int(tf.lib().tf_device_count())
+        for label, devs in (("all_devices", "all"), ("two_workers_on_device_0", [0, 0]), ("four_workers_on_device_0", [0, 0, 0, 0])):
+            hy = _np.random.default_rng(5).integers(0, 2 ** 63, size=hb * (1 << 20), dtype=_np.uint64)
+            tf.ntt(hy, batch=hb, devices=devs)
+            t0 = time.perf_counter()
+            tf.ntt(hy, batch=hb, devices=devs)
+            dt = time.perf_counter() - t0
+            multi[label] = {"ms": round(dt * 1e3, 2), "gfelts_per_s": round(hb * (1 << 20) / dt / 1e9, 3), "same_words_as_single_device": bool(_np.array_equal(hy, want))}
+        multi["visible_devices"] = ndev
+        multi["note"] = "tf_ntt_bfe_multi, 32 x 2^20 BFE on pageable host memory, contiguous slices, one worker thread + stream per listed device"
+        extra["host_pointer_multi"] = multi
     except Exception as e:  # side measurements never invalidate the headline line
         extra["error"] = repr(e)
     return extra

@@ -299,6 +299,19 @@ static int ntt_any(u64 *x, size_t n, int width, int inverse) {
 int tfo_ntt(uint64_t *x, size_t n, int width) { return ntt_any(x, n, width, 0); }
 int tfo_intt(uint64_t *x, size_t n, int width) { return ntt_any(x, n, width, 1); }
 
+/* Run `worker(job)` on `threads` threads: threads - 1 created ones and the caller's.  A thread that cannot be created (a
+ * cgroup-limited host) is simply not used -- nothing uninitialised is ever joined, and with none at all the caller does the job. */
+static void fan_out(void *(*worker)(void *), void *job, int threads) {
+    pthread_t *tid = threads > 1 ? (pthread_t *)malloc(sizeof(pthread_t) * (size_t)(threads - 1)) : NULL;
+    int made = 0;
+    if (tid)
+        for (int t = 0; t < threads - 1; t++)
+            if (pthread_create(&tid[made], NULL, worker, job) == 0) made++;
+    worker(job);
+    for (int t = 0; t < made; t++) pthread_join(tid[t], NULL);
+    free(tid);
+}
+
 typedef struct {
     u64 *x;
     size_t n, batch;
@@ -316,7 +329,11 @@ static void *ntt_worker(void *arg) {
         pthread_mutex_unlock(job->lock);
         if (b >= job->batch) break;
         int rc = ntt_any(job->x + b * job->n * (size_t)job->width, job->n, job->width, job->inverse);
-        if (rc) job->rc = rc;
+        if (rc) {
+            pthread_mutex_lock(job->lock);
+            job->rc = rc;
+            pthread_mutex_unlock(job->lock);
+        }
     }
     return NULL;
 }
@@ -334,10 +351,7 @@ int tfo_ntt_batch(uint64_t *x, size_t n, size_t batch, int width, int inverse, i
     if (n > 1) (void)get_twiddles((uint32_t)n, inverse); /* build the cache before fan-out */
     pthread_mutex_t lock = PTHREAD_MUTEX_INITIALIZER;
     ntt_job_t job = {x, n, batch, width, inverse, 0, &lock, 0};
-    pthread_t *tid = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)threads);
-    for (int t = 0; t < threads; t++) pthread_create(&tid[t], NULL, ntt_worker, &job);
-    for (int t = 0; t < threads; t++) pthread_join(tid[t], NULL);
-    free(tid);
+    fan_out(ntt_worker, &job, threads);
     return job.rc;
 }
 
@@ -400,7 +414,11 @@ static void *coset_worker(void *arg) {
         if (b >= job->batch) break;
         int rc = tfo_coset_evaluate(job->coeffs + b * job->n_coeffs * (size_t)job->width, job->n_coeffs, job->width, job->offset,
                                     job->out + b * job->order * (size_t)job->width, job->order);
-        if (rc) job->rc = rc;
+        if (rc) {
+            pthread_mutex_lock(job->lock);
+            job->rc = rc;
+            pthread_mutex_unlock(job->lock);
+        }
     }
     return NULL;
 }
@@ -412,14 +430,7 @@ int tfo_coset_evaluate_batch(const uint64_t *coeffs, size_t n_coeffs, int width,
     if (order > 1) (void)get_twiddles((uint32_t)order, 0); /* build the cache before fan-out */
     pthread_mutex_t lock = PTHREAD_MUTEX_INITIALIZER;
     coset_job_t job = {coeffs, out, n_coeffs, order, batch, width, offset, 0, &lock, 0};
-    if (threads <= 1) {
-        coset_worker(&job);
-        return job.rc;
-    }
-    pthread_t *tid = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)threads);
-    for (int t = 0; t < threads; t++) pthread_create(&tid[t], NULL, coset_worker, &job);
-    for (int t = 0; t < threads; t++) pthread_join(tid[t], NULL);
-    free(tid);
+    fan_out(coset_worker, &job, threads);
     return job.rc;
 }
 
@@ -735,6 +746,36 @@ void tfo_tip5_hash_pairs(const uint64_t *in, uint64_t *out, size_t count) {
 
 void tfo_tip5_hash_varlen_rows(const uint64_t *rows, size_t row_len, size_t n_rows, uint64_t *out) {
     for (size_t i = 0; i < n_rows; i++) tfo_tip5_hash_varlen(rows + i * row_len, row_len, out + 5 * i);
+}
+
+/* the same, the rows dealt out to `threads` threads in blocks of 256 (what a rayon caller of hash_varlen does: the rows are
+ * independent); used for the all-cores CPU leg of bench.py's commitment pipeline */
+typedef struct {
+    const u64 *rows;
+    u64 *out;
+    size_t row_len, n_rows, next;
+    pthread_mutex_t *lock;
+} rows_job_t;
+
+static void *rows_worker(void *arg) {
+    rows_job_t *job = (rows_job_t *)arg;
+    for (;;) {
+        pthread_mutex_lock(job->lock);
+        size_t lo = job->next;
+        job->next += 256;
+        pthread_mutex_unlock(job->lock);
+        if (lo >= job->n_rows) break;
+        size_t hi = lo + 256 < job->n_rows ? lo + 256 : job->n_rows;
+        for (size_t i = lo; i < hi; i++) tfo_tip5_hash_varlen(job->rows + i * job->row_len, job->row_len, job->out + 5 * i);
+    }
+    return NULL;
+}
+
+void tfo_tip5_hash_varlen_rows_par(const uint64_t *rows, size_t row_len, size_t n_rows, uint64_t *out, int threads) {
+    pthread_once(&g_tip5_once, tip5_init_tables); /* before the fan-out */
+    pthread_mutex_t lock = PTHREAD_MUTEX_INITIALIZER;
+    rows_job_t job = {rows, out, row_len, n_rows, 0, &lock};
+    fan_out(rows_worker, &job, threads);
 }
 
 /* ------------------------------------------------------------------ MerkleTree */

@@ -80,6 +80,7 @@ void tfo_tip5_absorb(uint64_t state[16], const uint64_t in[10]);            /* :
 /* batch helpers (plain loops over the above) */
 void tfo_tip5_hash_pairs(const uint64_t *in, uint64_t *out, size_t count);
 void tfo_tip5_hash_varlen_rows(const uint64_t *rows, size_t row_len, size_t n_rows, uint64_t *out);
+void tfo_tip5_hash_varlen_rows_par(const uint64_t *rows, size_t row_len, size_t n_rows, uint64_t *out, int threads);
 
 /* ---- MerkleTree (util_types/merkle_tree.rs) ----
  * error codes: 1 TooFewLeafs, 2 IncorrectNumberOfLeafs, 3 TreeTooHigh (:933-965) */

@@ -93,6 +93,7 @@ def lib() -> C.CDLL:
             "tfo_tip5_absorb": (None, [pu, pu]),
             "tfo_tip5_hash_pairs": (None, [pu, pu, sz]),
             "tfo_tip5_hash_varlen_rows": (None, [pu, sz, sz, pu]),
+            "tfo_tip5_hash_varlen_rows_par": (None, [pu, sz, sz, pu, C.c_int]),
             "tfo_merkle_build": (i32, [pu, sz, pu]),
             "tfo_merkle_build_par": (i32, [pu, sz, pu, i32, sz]),
             "tfo_merkle_frugal_root": (i32, [pu, sz, pu]),
@@ -348,11 +349,13 @@ def hash_pairs(inp) -> np.ndarray:
     return out
 
 
-def hash_varlen_rows(rows, row_len: int) -> np.ndarray:
+def hash_varlen_rows(rows, row_len: int, threads: int = 1) -> np.ndarray:
     r = _arr(rows).reshape(-1)
     n_rows = r.size // row_len if row_len else 0
     out = np.zeros(n_rows * 5, dtype=np.uint64)
-    if n_rows:
+    if n_rows and threads > 1:
+        lib().tfo_tip5_hash_varlen_rows_par(_p(r), row_len, n_rows, _p(out), threads)
+    elif n_rows:
         lib().tfo_tip5_hash_varlen_rows(_p(r), row_len, n_rows, _p(out))
     return out
 

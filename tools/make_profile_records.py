@@ -30,6 +30,16 @@ for f in glob.glob(os.path.join(src, "pmc_sq/**/*counter_collection.csv"), recur
             mer[r["Kernel_Name"]] += float(r["Counter_Value"])
             if "merkle_top_kernel" in r["Kernel_Name"]:
                 trees += 1
+mfma, mfma_busy, mtrees = 0.0, 0.0, 0
+for f in glob.glob(os.path.join(src, "pmc_mfma/**/*counter_collection.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        if "tip5" in r["Kernel_Name"] or "merkle" in r["Kernel_Name"]:
+            if r["Counter_Name"] == "SQ_INSTS_MFMA":
+                mfma += float(r["Counter_Value"])
+                if "merkle_top_kernel" in r["Kernel_Name"]:
+                    mtrees += 1
+            elif r["Counter_Name"] == "SQ_VALU_MFMA_BUSY_CYCLES":
+                mfma_busy += float(r["Counter_Value"])
 # configs[3]: the two PRE2 pass kernels of the 64 x 2^22 XFE coset evaluation (SCALE 1 column pass, LAST1024 pass)
 coset_busy = [e["derived"]["valu_busy_frac_at_4_cycles"] for k, e in summ["kernels"].items()
               if "ntt_pass_kernel" in k and "valu_busy_frac_at_4_cycles" in e.get("derived", {})
@@ -47,8 +57,13 @@ if trees:
     m = sum(mer.values()) / trees
     rec["merkle_valu_wave_instr_per_tree_2p24"] = m
     rec["merkle_valu_instr_per_hash_pair"] = m * 64 / (2 ** 24 - 1)
+    if mtrees:
+        rec["merkle_mfma_wave_instr_per_tree_2p24"] = mfma / mtrees
+        rec["merkle_mfma_busy_cycles_per_tree_2p24"] = mfma_busy / mtrees
+        rec["merkle_note"] = ("SQ_INSTS_VALU counts the v_mfma_f64_16x16x4_f64 of the matrix-pipe Tip5 kernels as VALU instructions; per 16 hash_pairs "
+                              "(one wave): %.1f VALU instructions of which %.1f MFMA" % (m * 16 / (2 ** 24 - 1), mfma / mtrees * 16 / (2 ** 24 - 1)))
 else:  # NTT-only profile: keep the Merkle figures of the last record
-    for k in ("merkle_valu_wave_instr_per_tree_2p24", "merkle_valu_instr_per_hash_pair"):
+    for k in ("merkle_valu_wave_instr_per_tree_2p24", "merkle_valu_instr_per_hash_pair", "merkle_mfma_wave_instr_per_tree_2p24", "merkle_mfma_busy_cycles_per_tree_2p24", "merkle_note"):
         if k in old:
             rec[k] = old[k]
 json.dump(rec, open(os.path.join(root, "profiles", "valu_counts.json"), "w"), indent=1)
