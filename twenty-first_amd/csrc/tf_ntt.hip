@@ -1144,7 +1144,9 @@ void choose_split(int log_n, int P, int L, int (&a)[4]) {
         // their rows by whole 128-byte lines (tools/xfe_sweep.sh: 2^15 1.62 vs 1.83 ms, 2^23 2.62 vs 2.71, 2^25 2.71 vs 2.86 per
         // 3 * 2^26 words); the sweep still prefers R = 32 for n < 2^15 and R = 512 for 2^16 .. 2^19 (all within 1 % of R = 1024).
         int last = std::min(10, log_n - 5 * (P - 1));
-        if (L == 3 && P == 2 && log_n < 20 && log_n != 15) last = log_n < 15 ? 5 : 9;
+        // (round 5, profiles/r05_xfe_split2_sweep.txt: 2^13 has no better split than (8, 5) -- 1.61 ms against 1.61-1.75 for every other --
+        // it is simply the first length that no longer fits one workgroup's LDS; 2^14 prefers (5, 9): 1.325 vs 1.367 ms)
+        if (L == 3 && P == 2 && log_n < 20 && log_n != 15) last = log_n < 14 ? 5 : 9;
         a[P - 1] = last;
         int rest = log_n - last;
         if (P == 3 && last == 10 && log_n <= (L == 3 ? 25 : 23)) {

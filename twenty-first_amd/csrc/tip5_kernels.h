@@ -570,14 +570,20 @@ __global__ void __launch_bounds__(256) tip5_hash_varlen_rows_coop_kernel(const u
     if (i >= n_rows) return;
     const u64* p = rows + i * row_len;
     u64 s = 0;  // Domain::VariableLength
-    const long long full = row_len / 10;
-    for (long long c = 0; c < full; ++c) {
-        if (j < 10) s = p[c * 10 + j];  // overwrite-mode absorb, mod.rs:684-691
+    // The absorb chain is sequential (mod.rs:617-623): chunk c overwrites the rate words with input words 10 c .. 10 c + 9, the
+    // padded last chunk included (sponge.rs:41-55: a one after the input, then zeros).  The next chunk is fetched BEFORE the
+    // permutation of the current one, so a long single input pays the memory latency once, not once per permutation.
+    const long long chunks = row_len / 10 + 1;
+    auto rate_word = [&](long long c) -> u64 {
+        const long long w = c * 10 + j;
+        return w < row_len ? p[w] : (w == row_len ? gl::ONE : 0);
+    };
+    u64 nxt = j < 10 ? rate_word(0) : 0;
+    for (long long c = 0; c < chunks; ++c) {
+        if (j < 10) s = nxt;  // overwrite-mode absorb, mod.rs:684-691
+        if (j < 10 && c + 1 < chunks) nxt = rate_word(c + 1);
         tip5_permutation_coop(s, j, lut);
     }
-    const int rem = (int)(row_len - full * 10);
-    if (j < 10) s = (j < rem) ? p[full * 10 + j] : ((j == rem) ? gl::ONE : 0);
-    tip5_permutation_coop(s, j, lut);
     const long long tree = i / per_tree;
     if (j < 5) out[tree * out_ts + (i - tree * per_tree) * 5 + j] = s;
 }
@@ -595,14 +601,17 @@ __global__ void __launch_bounds__(256) tip5_hash_table_rows_coop_kernel(const u6
     const u64* tb = table + tree * table_stride;
     const long long row_len = n_cols * width;
     u64 s = 0;
-    const long long full = row_len / 10;
-    for (long long c = 0; c < full; ++c) {
-        if (j < 10) s = table_word(tb, i, c * 10 + j, width, col_stride);
+    const long long chunks = row_len / 10 + 1;  // as tip5_hash_varlen_rows_coop_kernel: the next chunk is in flight during a permutation
+    auto rate_word = [&](long long c) -> u64 {
+        const long long w = c * 10 + j;
+        return w < row_len ? table_word(tb, i, w, width, col_stride) : (w == row_len ? gl::ONE : 0);
+    };
+    u64 nxt = j < 10 ? rate_word(0) : 0;
+    for (long long c = 0; c < chunks; ++c) {
+        if (j < 10) s = nxt;
+        if (j < 10 && c + 1 < chunks) nxt = rate_word(c + 1);
         tip5_permutation_coop(s, j, lut);
     }
-    const int rem = (int)(row_len - full * 10);
-    if (j < 10) s = (j < rem) ? table_word(tb, i, full * 10 + j, width, col_stride) : ((j == rem) ? gl::ONE : 0);
-    tip5_permutation_coop(s, j, lut);
     if (j < 5) out[tree * out_ts + i * 5 + j] = s;
 }
 
