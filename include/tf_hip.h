@@ -406,8 +406,10 @@ void tf_set_ntt_two_pass(int mode);
  * XFieldElement), ntt_lat2_kernel for 2^13 .. 2^20-point transforms in calls below a per-length threshold (tf_ntt.hip:
  * lat_wanted / lat2_wanted hold the measured crossovers).  -1 = automatic (default), 0 = never, 1 = whenever the shape allows. */
 void tf_set_ntt_latency_kernel(int mode);
-/* Number of ntt_pass_kernel launches one tf_ntt_*_dev call enqueues for this shape (diagnostic; used by
- * bench.py to turn a HIP-event interval into an average launch duration). */
+/* Number of transform-kernel launches one plain tf_ntt_*_dev call enqueues for this shape, by the planner's own predicates in
+ * the planner's order (tiny / rows / latency-shaped kernels, whole-transform-per-workgroup kernels, tiles x passes of
+ * ntt_pass_kernel, the narrow-tile three-pass plan of small 2^21 / 2^22 calls).  Diagnostic; bench.py uses it to turn a
+ * HIP-event interval into an average launch duration.  Table builders of a first call are not counted. */
 int tf_ntt_launch_count(size_t n, size_t batch, int width);
 /* Planner introspection (no device needed): number of global passes of one n-point transform (0 for lengths ntt rejects)
  * and log2 of each pass's radix in log2_radix_out[0..3] (unused entries 0).  The radices multiply to n.  This is the plan of a

@@ -270,19 +270,25 @@ int tf_ntt_plan(size_t n, int width, int* log2_radix_out) {
 }
 
 int tf_ntt_launch_count(size_t n, size_t batch, int width) {
+    // the same predicates, in the same order, as run_ntt (tf_ntt.hip) for a plain in-place call
     if (check_len(n) || n <= 1 || batch == 0 || (width != 1 && width != 3)) return 0;
     const int log_n = ilog2(n);
+    read_env();
+    if (log_n <= 4) return 1;                                                                              // ntt_tiny_kernel
+    if (log_n == 5 && width == 1) return (int)((batch + (size_t(512) << 30) - 1) / (size_t(512) << 30));   // ntt_rows32_kernel
+    if (g_min_passes.load(std::memory_order_relaxed) == 0) {
+        if (lat_wanted(log_n, batch, width)) return (int)((batch + (size_t(1) << 22) - 1) >> 22);          // ntt_lat_kernel
+        if (lat2_wanted(log_n, batch, width)) return 2;                                                    // ntt_lat2_kernel: column pass + last pass
+    }
     if (log_n <= 10) return (int)((batch + (size_t(1) << 24) - 1) >> 24);
     int radix[4];
-    if (tf_ntt_plan(n, width, radix) == 1) return 1;  // whole transform per workgroup (BFE 2^11 .. 2^14)
-    read_env();
+    if (tf_ntt_plan(n, width, radix) == 1) return 1;  // whole transform per workgroup (BFE 2^11 .. 2^14, XFE 2^11 / 2^12)
     const size_t poly_bytes = n * size_t(width) * sizeof(u64);
     size_t tb = std::min(std::max<size_t>(1, g_tile_bytes / poly_bytes), batch);
     const size_t tiles = (batch + tb - 1) / tb;
     int P = pass_count(log_n);
     if (P == 4) return (int)(tiles * 3 + batch);  // the last pass of a four-pass plan is launched per polynomial
-    const bool small_call = (unsigned long long)n * batch * width <= (1ull << 21) && g_small_launch_mode.load(std::memory_order_relaxed) != 0;
-    if (!small_call && pre2_plan_ok(log_n, width, n, 1, false, -1, false, false, false)) P = 2;
+    if (!small_launch_for(n, 1, batch, width, -1) && pre2_plan_ok(log_n, width, n, 1, false, -1, false, false, false)) P = 2;
     return (int)(tiles * P);
 }
 

@@ -122,6 +122,7 @@ int ntt_dev(u64* d_x, size_t n, size_t batch, int L, int inverse, void* stream);
 int coset_eval_dev(const u64* d_coeffs, size_t n_coeffs, u64 offset_raw, u64* d_out, size_t order, size_t batch, int L, void* stream);
 // ------------------------------------------------------------------------------------ tf_lat.hip
 // latency-shaped transforms and the one-launch-per-level kernels of the zerofier-tree walks
+bool small_launch_for(size_t n, size_t cosets, size_t batch, int L, long long n_out);
 bool lat_wanted(int log_n, size_t batch, int L);
 bool lat2_wanted(int log_n, size_t batch, int L);
 int launch_lat2(DeviceCtx* ctx, const u64* in, u64* out, long long in_bs, long long out_bs, int log_n, size_t batch, int L, bool inverse,
