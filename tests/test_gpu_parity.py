@@ -872,6 +872,15 @@ def test_latency_shaped_transform_matches_oracle(tf, oracle, log_n, width):
             off = oracle.bfe_new(7)
             ev = tf.fast_coset_evaluate(a, off, n, width=width)
             assert np.array_equal(ev, oracle.coset_evaluate(a, off, n, width=width)), (mode, "coset")
+            # the coset scalings ride in the latency kernel's load / store (round 5): full-length and ragged batches, and back
+            for nc, polys in ((n, 1), (n - 3, 3), (max(1, n // 3), 2)):
+                c = x[: polys * nc * width]
+                evb = tf.fast_coset_evaluate(c, off, n, width=width, batch=polys)
+                assert np.array_equal(evb, oracle.coset_evaluate_batch(c, off, n, polys, width=width, threads=polys)), (mode, "coset batch", nc)
+                back = tf.fast_coset_interpolate(evb, off, width=width, batch=polys)
+                for k in range(polys):
+                    assert np.array_equal(back[k * n * width:(k + 1) * n * width], oracle.coset_interpolate(evb[k * n * width:(k + 1) * n * width], off, width=width)), (mode, "interpolate", nc)
+                    assert np.array_equal(back[k * n * width: k * n * width + nc * width], c[k * nc * width:(k + 1) * nc * width])
     finally:
         lib.tf_set_ntt_latency_kernel(-1)
     assert np.array_equal(got[0], got[1])
@@ -898,6 +907,16 @@ def test_latency_shaped_two_pass_plan_matches_oracle(tf, oracle, log_n, width, b
             tf.intt(y, width=width, batch=batch)
             assert np.array_equal(y, x), (mode, "inverse")
             got[mode] = tf.fast_multiply(a, b, width=width)
+            # coset evaluation / interpolation with the scalings fused into the two latency-shaped passes (round 5)
+            off = oracle.bfe_new(7)
+            for nc in (n, n - 5):
+                c = x[: batch * nc * width]
+                ev = tf.fast_coset_evaluate(c, off, n, width=width, batch=batch)
+                assert np.array_equal(ev, oracle.coset_evaluate_batch(c, off, n, batch, width=width, threads=batch)), (mode, "coset", nc)
+                back = tf.fast_coset_interpolate(ev, off, width=width, batch=batch)
+                assert np.array_equal(back[: n * width], oracle.coset_interpolate(ev[: n * width], off, width=width)), (mode, "interpolate", nc)
+                for k in range(batch):
+                    assert np.array_equal(back[k * n * width: k * n * width + nc * width], c[k * nc * width:(k + 1) * nc * width])
     finally:
         lib.tf_set_ntt_latency_kernel(-1)
     assert np.array_equal(got[0], got[1])

@@ -99,6 +99,7 @@ __global__ void __launch_bounds__(LOGN == 12 ? 512 : 256) ntt_lat_kernel(const N
             } else if (A.n_coeffs < 0 || idx < A.n_coeffs) {
                 v = src[(long long)idx * L];
                 if (A.in2) v = gl::mont_mul(v, (A.in2 + b * A.in_bs + limb)[(long long)idx * L]);
+                if (A.pre_scale) v = gl::mont_mul(v, A.pre_scale[idx]);
             }
             x[lat_brev<3>(r)] = v;
         }
@@ -161,7 +162,7 @@ __global__ void __launch_bounds__(LOGN == 12 ? 512 : 256) ntt_lat_kernel(const N
                         if (A.store_mode == 1) {
                             if (idx < A.keep) dst[(long long)idx * L] = gl::sub((A.sub_src + (b >> 1) * A.sub_bs + limb)[(long long)idx * L], x[a * R + r]);
                         } else {
-                            dst[(long long)idx * L] = x[a * R + r];
+                            dst[(long long)idx * L] = A.post_scale ? gl::mont_mul(x[a * R + r], A.post_scale[idx]) : x[a * R + r];
                         }
                     }
                 } else {
@@ -616,6 +617,10 @@ struct NttLat2Args {
     const u64* in2;            // or null: second operand laid out like `in`, multiplied in on load (first pass, L = 1)
     const u64* tw;             // [2][N]: w_N^(+-e), then scale * w_N^(+-e)
     const u64* post_tw;        // column pass: T[k * tw_rs + b]
+    const u64* scale_tab;      // or null.  Column pass: input element (idx, column chi) times scale_tab[idx * scale_es + chi] (the offset^j of
+                               // fast_coset_evaluate on coefficient j = idx * N2 + chi); last pass: output element likewise (the offset^-j
+                               // of fast_coset_interpolate on coefficient j = idx * N1 + row)
+    long long scale_es;
     long long n_coeffs;        // column pass: < 0 none; else input element index i * nc_es + c / L >= n_coeffs reads as zero
     long long nc_es;
     long long in_bs, out_bs;   // words between batch entries
@@ -678,6 +683,7 @@ __global__ void __launch_bounds__(WG) ntt_lat2_kernel(const NttLat2Args A) {
             if (LAST || A.n_coeffs < 0 || (long long)idx * A.nc_es + chi < A.n_coeffs) {
                 v = src[(long long)idx * A.in_es];
                 if (!LAST && A.in2) v = gl::mont_mul(v, (A.in2 + entry * A.in_bs + chi * A.in_lhi + clo)[(long long)idx * A.in_es]);
+                if (!LAST && A.scale_tab) v = gl::mont_mul(v, A.scale_tab[(long long)idx * A.scale_es + chi]);
             }
             x[lat_brev<3>(r)] = v;
         }
@@ -745,6 +751,7 @@ __global__ void __launch_bounds__(WG) ntt_lat2_kernel(const NttLat2Args A) {
                     if (act) {
                         u64 val = x[a * R + r];
                         if (!LAST) val = gl::mont_mul(val, ptw[a * R + r]);
+                        else if (A.scale_tab) val = gl::mont_mul(val, A.scale_tab[(long long)idx * A.scale_es + chi]);
                         dst[(long long)idx * A.out_es] = val;
                     }
                 } else {

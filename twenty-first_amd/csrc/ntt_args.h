@@ -14,6 +14,10 @@ struct NttLatArgs {
     const u64* in;
     u64* out;
     const u64* in2;        // or null: second operand laid out like `in`, multiplied in on load (L = 1 only)
+    const u64* pre_scale;  // or null: input element idx of every slice and limb times pre_scale[idx] (Polynomial::scale fused into the
+                           // load of fast_coset_evaluate, polynomial.rs:760-773, :1374-1399); load_mode 0 only
+    const u64* post_scale; // or null: output element idx times post_scale[idx] (the offset^-idx of fast_coset_interpolate, :1907-1918);
+                           // store_mode 0 only
     const u64* tw;         // [2][n]: w_n^(+-e), then n^-1 w_n^(+-e) (the inverse's last stage)
     long long n_coeffs;    // < 0: none; else elements >= n_coeffs read as zero
     long long in_bs, out_bs;  // words between consecutive slices

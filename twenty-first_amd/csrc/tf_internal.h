@@ -126,9 +126,10 @@ bool small_launch_for(size_t n, size_t cosets, size_t batch, int L, long long n_
 bool lat_wanted(int log_n, size_t batch, int L);
 bool lat2_wanted(int log_n, size_t batch, int L);
 int launch_lat2(DeviceCtx* ctx, const u64* in, u64* out, long long in_bs, long long out_bs, int log_n, size_t batch, int L, bool inverse,
-                long long n_coeffs, const u64* in2, hipStream_t stream);
+                long long n_coeffs, const u64* in2, hipStream_t stream, const u64* pre_scale = nullptr, const u64* post_scale = nullptr);
 int launch_lat(DeviceCtx* ctx, const u64* in, u64* out, long long in_bs, long long out_bs, int log_n, size_t batch, int L, bool inverse,
-               long long n_coeffs, const u64* in2, hipStream_t stream, const tfk::NttLatArgs* mods = nullptr);
+               long long n_coeffs, const u64* in2, hipStream_t stream, const tfk::NttLatArgs* mods = nullptr, const u64* pre_scale = nullptr,
+               const u64* post_scale = nullptr);
 bool tree_level_wanted(long long order, long long lines, int L = 1, bool up = false);
 template <bool UP>
 int launch_tree_level(DeviceCtx* ctx, int log_n, tfk::TreeLevelArgs a, hipStream_t s, int L = 1);

@@ -82,7 +82,7 @@ bool lat_wanted(int log_n, size_t batch, int L) {
 }
 // mods (tree walks only): the load / store modifier fields of NttLatArgs; such calls are one launch (batch < 2^22)
 int launch_lat(DeviceCtx* ctx, const u64* in, u64* out, long long in_bs, long long out_bs, int log_n, size_t batch, int L, bool inverse,
-               long long n_coeffs, const u64* in2, hipStream_t stream, const tfk::NttLatArgs* mods) {
+               long long n_coeffs, const u64* in2, hipStream_t stream, const tfk::NttLatArgs* mods, const u64* pre_scale, const u64* post_scale) {
     const u64* tw = nullptr;
     int rc = get_lat_table(ctx, log_n, inverse, &tw);
     if (rc) return rc;
@@ -95,6 +95,8 @@ int launch_lat(DeviceCtx* ctx, const u64* in, u64* out, long long in_bs, long lo
         a.in = in + (long long)b0 * in_bs;
         a.out = out + (long long)b0 * out_bs;
         a.in2 = in2 ? in2 + (long long)b0 * in_bs : nullptr;
+        a.pre_scale = pre_scale;
+        a.post_scale = post_scale;
         a.tw = tw;
         a.n_coeffs = n_coeffs;
         a.in_bs = in_bs;
@@ -293,7 +295,7 @@ bool lat2_wanted(int log_n, size_t batch, int L) {
     return (long long)(batch * size_t(L)) << log_n <= limit;
 }
 int launch_lat2(DeviceCtx* ctx, const u64* in, u64* out, long long in_bs, long long out_bs, int log_n, size_t batch, int L, bool inverse,
-                long long n_coeffs, const u64* in2, hipStream_t stream) {
+                long long n_coeffs, const u64* in2, hipStream_t stream, const u64* pre_scale, const u64* post_scale) {
     const int a1 = (log_n + 1) / 2, a2 = log_n - a1;
     const long long N1 = 1ll << a1, N2 = 1ll << a2, n = 1ll << log_n;
     const u64 *tw1 = nullptr, *tw2 = nullptr, *post = nullptr;
@@ -322,6 +324,8 @@ int launch_lat2(DeviceCtx* ctx, const u64* in, u64* out, long long in_bs, long l
     c.in_es = c.out_es = N2 * L;
     c.in_lhi = c.out_lhi = L;
     c.tw_rs = N2;
+    c.scale_tab = pre_scale;
+    c.scale_es = N2;
     c.L = L;
     c.cfast = 1;
     rc = inverse ? launch_lat2_dir<true, false>(a1, c, batch, stream) : launch_lat2_dir<false, false>(a1, c, batch, stream);
@@ -339,6 +343,8 @@ int launch_lat2(DeviceCtx* ctx, const u64* in, u64* out, long long in_bs, long l
         r.out_es = N1 * L;
         r.out_lhi = L;
         r.scale = inverse ? gl::mont_inverse(gl::to_mont(u64(1) << log_n)) : 0;
+        r.scale_tab = post_scale;
+        r.scale_es = N1;
         r.L = L;
         r.cfast = 0;
         rc = inverse ? launch_lat2_dir<true, true>(a2, r, batch, stream) : launch_lat2_dir<false, true>(a2, r, batch, stream);

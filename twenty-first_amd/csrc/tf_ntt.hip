@@ -1280,12 +1280,14 @@ int run_ntt(DeviceCtx* ctx, const u64* in, u64* out, long long in_bs, long long 
         static const bool no_rows32 = ab_env("TF_NTT_NO_ROWS32") != nullptr;  // A/B switch
         if (!no_rows32) return launch_rows32(in, out, batch, L, inverse, stream);
     }
-    if (!pre_scale && !post_scale && n_out < 0 && cosets == 1 && (!in2 || L == 1) && g_min_passes.load(std::memory_order_relaxed) == 0 &&
-        lat_wanted(log_n, batch, L))
-        return launch_lat(ctx, in, out, in_bs, out_bs, log_n, batch, L, inverse, n_coeffs, in2, stream);
-    if (!pre_scale && !post_scale && n_out < 0 && cosets == 1 && (!in2 || L == 1) && g_min_passes.load(std::memory_order_relaxed) == 0 &&
-        lat2_wanted(log_n, batch, L))
-        return launch_lat2(ctx, in, out, in_bs, out_bs, log_n, batch, L, inverse, n_coeffs, in2, stream);
+    // (the latency-shaped kernel also takes the coset scalings of fast_coset_evaluate / fast_coset_interpolate: a 2^10-point coset
+    //  evaluation is one launch of 8-element threads, 8 us, instead of one 32-element-thread workgroup, 19 us)
+    if (n_out < 0 && cosets == 1 && (!in2 || L == 1) && g_min_passes.load(std::memory_order_relaxed) == 0 && !(pre_scale && inverse) &&
+        !(post_scale && !inverse) && lat_wanted(log_n, batch, L))
+        return launch_lat(ctx, in, out, in_bs, out_bs, log_n, batch, L, inverse, n_coeffs, in2, stream, nullptr, pre_scale, post_scale);
+    if (n_out < 0 && cosets == 1 && (!in2 || L == 1) && g_min_passes.load(std::memory_order_relaxed) == 0 && !(pre_scale && inverse) &&
+        !(post_scale && !inverse) && lat2_wanted(log_n, batch, L))
+        return launch_lat2(ctx, in, out, in_bs, out_bs, log_n, batch, L, inverse, n_coeffs, in2, stream, pre_scale, post_scale);
     if (log_n <= 10) {
         const u64* inner = nullptr;
         rc = get_inner_table(ctx, log_n, inverse, inverse ? log_n : 0, &inner);
