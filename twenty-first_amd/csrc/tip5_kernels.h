@@ -139,6 +139,8 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 struct Tip5MxConsts {
     double c[5][4][8];  // accumulator starts [round][quarter q][lo-half reg 0..3 | hi-half reg 0..3] for state word 4 reg + q
     double a[16];       // MDS_MATRIX_FIRST_COLUMN as f64
+    double cf[4][8];    // round 0 of a FIXED-LENGTH hash (hash_10 / hash_pair): c[0] plus the MDS contribution of words 12..15, which
+                        // are the constant 1 there (Tip5::new(Domain::FixedLength), mod.rs:511-526, and 1^7 = 1)
 };
 __constant__ Tip5MxConsts g_tip5_mx;
 
@@ -157,6 +159,15 @@ inline void fill_tip5_mx(Tip5MxConsts& t, const u64* rc_mont) {
                 t.c[round][q][v] = 4503599627370496.0 + (double)(u32)x;
                 t.c[round][q][4 + v] = 4503599627370496.0 + (double)(u32)(x >> 32);
             }
+    // words 12..15 = ONE = 0x00000000ffffffff (Montgomery form of 1): low half 2^32 - 1, high half 0
+    for (int q = 0; q < 4; ++q)
+        for (int v = 0; v < 4; ++v) {
+            const int r = 4 * v + q;
+            u64 m = 0;
+            for (int c = 12; c < 16; ++c) m += col[(r - c) & 15];
+            t.cf[q][v] = t.c[0][q][v] + (double)(m * 0xffffffffULL);  // < 2^50: exact, and the half-sum bound is that of the full product
+            t.cf[q][4 + v] = t.c[0][q][4 + v];
+        }
 }
 
 struct Tip5MxLds {
@@ -260,7 +271,49 @@ __device__ __forceinline__ void mx_fold4(const d4 dlo, const d4 dhi, u64* out) {
 }
 
 // One round on NS permutations per lane quartet: s[4 n + i] = word 4 i + q of the permutation in column j of column block n.
-template <int NS, bool LAST>
+// the canonical recombination of words 0 and 1 only: the last round of hash_10 / hash_pair, whose digest is state words 0..4
+// (registers 0 of the four quarters and register 1 of quarter 0)
+__device__ __forceinline__ void mx_fold2_canon(const d4 dlo, const d4 dhi, u64* out) {
+    u32 tl[2], th[2], h0[2], rl[2], rh[2];
+#pragma unroll
+    for (int v = 0; v < 2; ++v) {
+        const u64 rawlo = (u64)__double_as_longlong(dlo[v]), rawhi = (u64)__double_as_longlong(dhi[v]);
+        const u64 t1 = (u64)(u32)(rawhi >> 32) * 0xffffffffu + rawlo;
+        tl[v] = (u32)t1;
+        th[v] = (u32)(t1 >> 32);
+        h0[v] = (u32)rawhi;
+    }
+    u64 ka, kb, ea, eb, na, nb;
+    asm("v_add_co_u32_e64 %[tha], %[ka], %[tha], %[h0a]\n\t"
+        "v_add_co_u32_e64 %[thb], %[kb], %[thb], %[h0b]\n\t"
+        "v_cmp_ne_u32_e64 %[na], 0, %[tla]\n\t"
+        "v_cmp_ne_u32_e64 %[nb], 0, %[tlb]\n\t"
+        "v_cmp_eq_u32_e64 %[ea], -1, %[tha]\n\t"
+        "v_cmp_eq_u32_e64 %[eb], -1, %[thb]\n\t"
+        "s_and_b64 %[ea], %[ea], %[na]\n\t"
+        "s_and_b64 %[eb], %[eb], %[nb]\n\t"
+        "s_or_b64 %[ea], %[ea], %[ka]\n\t"
+        "s_or_b64 %[eb], %[eb], %[kb]\n\t"
+        "v_subbrev_co_u32_e64 %[rla], %[na], 0, %[tla], %[ea]\n\t"
+        "v_subbrev_co_u32_e64 %[rlb], %[nb], 0, %[tlb], %[eb]\n\t"
+        "s_andn2_b64 %[ea], %[ea], %[na]\n\t"
+        "s_andn2_b64 %[eb], %[eb], %[nb]\n\t"
+        "v_addc_co_u32_e64 %[rha], %[na], 0, %[tha], %[ea]\n\t"
+        "v_addc_co_u32_e64 %[rhb], %[nb], 0, %[thb], %[eb]"
+        : [tha] "+v"(th[0]), [thb] "+v"(th[1]), [rla] "=&v"(rl[0]), [rlb] "=&v"(rl[1]), [rha] "=&v"(rh[0]), [rhb] "=&v"(rh[1]), [ka] "=&s"(ka),
+          [kb] "=&s"(kb), [ea] "=&s"(ea), [eb] "=&s"(eb), [na] "=&s"(na), [nb] "=&s"(nb)
+        : [tla] "v"(tl[0]), [tlb] "v"(tl[1]), [h0a] "v"(h0[0]), [h0b] "v"(h0[1])
+        : "scc");
+    out[0] = ((u64)rh[0] << 32) | rl[0];
+    out[1] = ((u64)rh[1] << 32) | rl[1];
+}
+
+// FIXED0 = 1: round 0 of a fixed-length hash, where state words 10..15 are the constant 1.  Register 3 of every lane (words 12..15)
+// then needs no x^7 (1^7 = 1) and no MFMA: its MDS contribution is a constant that rides in the accumulator start (Tip5MxConsts::cf).
+// FIXED0 = 2: round 0 of the FIRST permutation of a variable-length sponge, whose capacity words 10..15 are still 0 (0^7 = 0, no
+// contribution at all).  The same words as the general round on such a state -- one Montgomery chain of three and 2 of the 8 MFMA
+// saved in one round of five.
+template <int NS, bool LAST, int FIXED0 = 0, bool DIGEST = false>
 __device__ __forceinline__ void tip5_round_mx(u64 (&s)[4 * NS], int round, const Tip5MxLds* l, const double (&a)[4], int q) {
 #pragma unroll
     for (int n = 0; n < NS; ++n) {  // split_and_lookup (mod.rs:197-207): words 0..3 = register 0 of the four quarters
@@ -269,27 +322,38 @@ __device__ __forceinline__ void tip5_round_mx(u64 (&s)[4 * NS], int round, const
     }
 #pragma unroll
     for (int n = 0; n < NS; ++n) {  // x^7 = x * (x^2 * x^4) on registers 1..3
-        u64 x[3] = {s[4 * n + 1], s[4 * n + 2], s[4 * n + 3]}, sq[3], qu[3], t[3];
-        gl::mont_mul3(x, x, sq);
-        gl::mont_mul3(sq, sq, qu);
-        gl::mont_mul3(sq, qu, t);
-        gl::mont_mul3(x, t, x);
-        s[4 * n + 1] = x[0], s[4 * n + 2] = x[1], s[4 * n + 3] = x[2];
+        if constexpr (FIXED0) {
+            u64 &x0 = s[4 * n + 1], &x1 = s[4 * n + 2], sq0, sq1, qu0, qu1, t0, t1;
+            gl::mont_mul2(x0, x0, x1, x1, sq0, sq1);
+            gl::mont_mul2(sq0, sq0, sq1, sq1, qu0, qu1);
+            gl::mont_mul2(sq0, qu0, sq1, qu1, t0, t1);
+            gl::mont_mul2(x0, t0, x1, t1, x0, x1);
+        } else {
+            u64 x[3] = {s[4 * n + 1], s[4 * n + 2], s[4 * n + 3]}, sq[3], qu[3], t[3];
+            gl::mont_mul3(x, x, sq);
+            gl::mont_mul3(sq, sq, qu);
+            gl::mont_mul3(sq, qu, t);
+            gl::mont_mul3(x, t, x);
+            s[4 * n + 1] = x[0], s[4 * n + 2] = x[1], s[4 * n + 3] = x[2];
+        }
     }
-    const d4* cp = reinterpret_cast<const d4*>(&l->t.c[round][q][0]);
+    const d4* cp = reinterpret_cast<const d4*>(FIXED0 == 1 ? &l->t.cf[q][0] : &l->t.c[round][q][0]);
     const d4 c_lo = cp[0], c_hi = cp[1];
     d4 dlo[NS], dhi[NS];
 #pragma unroll
     for (int n = 0; n < NS; ++n) dlo[n] = c_lo, dhi[n] = c_hi;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < (FIXED0 ? 3 : 4); ++i)
 #pragma unroll
         for (int n = 0; n < NS; ++n) {
             dlo[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], (double)(u32)s[4 * n + i], dlo[n], 0, 0, 0);
             dhi[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], (double)(u32)(s[4 * n + i] >> 32), dhi[n], 0, 0, 0);
         }
 #pragma unroll
-    for (int n = 0; n < NS; ++n) mx_fold4<LAST>(dlo[n], dhi[n], &s[4 * n]);
+    for (int n = 0; n < NS; ++n) {
+        if constexpr (DIGEST) mx_fold2_canon(dlo[n], dhi[n], &s[4 * n]);  // (words 8..15 of the final state are not part of a digest)
+        else mx_fold4<LAST>(dlo[n], dhi[n], &s[4 * n]);
+    }
 }
 
 template <int NS>
@@ -297,6 +361,26 @@ __device__ __forceinline__ void tip5_permutation_mx(u64 (&s)[4 * NS], const Tip5
 #pragma unroll 1
     for (int r = 0; r < 4; ++r) tip5_round_mx<NS, false>(s, r, l, a, q);
     tip5_round_mx<NS, true>(s, 4, l, a, q);
+}
+
+// the permutation of hash_10 / hash_pair: on entry words 10..15 of every state are 1 (register 3 = 1 in every lane, register 2 = 1 in
+// quarters 2 and 3); register 3 need not even be initialised by the caller.  On exit only registers 0 and 1 (state words 0..7, of
+// which 0..4 are the digest) are defined.
+template <int NS>
+__device__ __forceinline__ void tip5_permutation_mx_fixed(u64 (&s)[4 * NS], const Tip5MxLds* l, const double (&a)[4], int q) {
+    tip5_round_mx<NS, false, 1>(s, 0, l, a, q);
+#pragma unroll 1
+    for (int r = 1; r < 4; ++r) tip5_round_mx<NS, false>(s, r, l, a, q);
+    tip5_round_mx<NS, true, 0, true>(s, 4, l, a, q);  // only the digest words are finished
+}
+
+// the permutations of a variable-length sponge: FIRST = capacity words still 0 on entry, FINAL = only the digest is read afterwards
+template <int NS, bool FIRST, bool FINAL>
+__device__ __forceinline__ void tip5_permutation_mx_sponge(u64 (&s)[4 * NS], const Tip5MxLds* l, const double (&a)[4], int q) {
+    tip5_round_mx<NS, false, FIRST ? 2 : 0>(s, 0, l, a, q);
+#pragma unroll 1
+    for (int r = 1; r < 4; ++r) tip5_round_mx<NS, false>(s, r, l, a, q);
+    tip5_round_mx<NS, true, 0, FINAL>(s, 4, l, a, q);
 }
 
 // item -> (tree, index in its tree).  shift >= 0: per_tree = 2^shift (every Merkle level); shift < 0: any per_tree (a flat call
@@ -357,7 +441,7 @@ __global__ void __launch_bounds__(256) tip5_hash_pairs_mx_kernel(const u64* in, 
             if (q < 2) c[8 + q] = s[4 * n + 2];
         }
     }
-    tip5_permutation_mx<NS>(s, &lds, a, q);
+    tip5_permutation_mx_fixed<NS>(s, &lds, a, q);
 #pragma unroll
     for (int n = 0; n < NS; ++n)
         if (live[n]) {
@@ -380,7 +464,8 @@ __global__ void __launch_bounds__(256) tip5_hash_pairs_mx_kernel(const u64* in, 
             s[4 * n + 1] = WORD(n, c * 10 + 4 + q);                                                                     \
             if (q < 2) s[4 * n + 2] = WORD(n, c * 10 + 8 + q);                                                          \
         }                                                                                                               \
-        tip5_permutation_mx<NS>(s, &lds, a, q);                                                                         \
+        if (c == 0) tip5_permutation_mx_sponge<NS, true, false>(s, &lds, a, q); /* capacity still zero */               \
+        else tip5_permutation_mx<NS>(s, &lds, a, q);                                                                    \
     }                                                                                                                   \
     const int rem = (int)((ROW_LEN) - full * 10);                                                                       \
     _Pragma("unroll") for (int n = 0; n < NS; ++n) {                                                                    \
@@ -389,7 +474,8 @@ __global__ void __launch_bounds__(256) tip5_hash_pairs_mx_kernel(const u64* in, 
             if (w < 10) s[4 * n + i] = (w < rem) ? WORD(n, full * 10 + w) : ((w == rem) ? gl::ONE : 0);                 \
         }                                                                                                               \
     }                                                                                                                   \
-    tip5_permutation_mx<NS>(s, &lds, a, q)
+    if (full == 0) tip5_permutation_mx_sponge<NS, true, true>(s, &lds, a, q);                                           \
+    else tip5_permutation_mx_sponge<NS, false, true>(s, &lds, a, q)
 
 // hash_varlen of n_rows rows of row_len words each.  Row i belongs to tree i / per_tree; its digest goes to out + tree * out_ts +
 // 5 * (i % per_tree)  (out_ts = 0 and per_tree = n_rows: a flat digest array; out_ts = 10 n, out = nodes + 5 n: straight into the
