@@ -7,7 +7,7 @@ REPO=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$REPO/gpurun_out/profbench_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o b -- python $REPO/bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-extra > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats.log"
+timeout -k 5 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o b -- python $REPO/bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-extra > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats.log"
 python3 - "$OUT" <<'PY'
 import csv, glob, json, os, statistics, sys
 out = sys.argv[1]
