@@ -411,9 +411,6 @@ int main() {
         tfk::Tip5Consts c;
         u64 z = 12345;
         for (int i = 0; i < 80; ++i) { z = z * 6364136223846793005ULL + 1442695040888963407ULL; c.rc[i] = z % gl::P; }
-        unsigned char lutb[256];
-        for (int x = 0; x < 256; ++x) { u64 xx = (u64)x + 1; lutb[x] = (unsigned char)(((xx * xx * xx) + 256) % 257); }
-        memcpy(c.lut, lutb, 256);
         CK(hipMemcpyToSymbol(HIP_SYMBOL(tfk::g_tip5), &c, sizeof(c)));
         const long long count = 1ll << 22;
         std::vector<u64> hs((size_t)count * 16);

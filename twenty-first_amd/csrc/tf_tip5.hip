@@ -35,12 +35,7 @@ int ensure_tip5(DeviceCtx* ctx) {
     if (ctx->tip5_ready) return TF_OK;
     tfk::Tip5Consts c;
     for (int i = 0; i < 80; ++i) c.rc[i] = gl::to_mont(kRoundConstants[i]);
-    unsigned char lut[256];
-    for (int x = 0; x < 256; ++x) {  // L(x) = ((x+1)^3 mod 257) - 1, tip5/mod.rs:1022-1026 (table :50-64)
-        u64 xx = u64(x) + 1;
-        lut[x] = (unsigned char)(((xx * xx * xx) + 256) % 257);
-    }
-    memcpy(c.lut, lut, 256);
+    // (the lookup table, L(x) = ((x+1)^3 mod 257) - 1, tip5/mod.rs:1022-1026, is computed by the kernels themselves: stage_lut)
     HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(tfk::g_tip5), &c, sizeof(c)));
     tfk::Tip5MxConsts mx;
     tfk::fill_tip5_mx(mx, c.rc);
@@ -117,8 +112,8 @@ int launch_hash_pairs(const u64* in, u64* out, u64* leaf_copy, long long count, 
     if (count <= kCoopMaxCount && !leaf_copy) {
         // fewer permutations than the GPU has lanes: latency, not throughput, is what this launch costs -> 16 lanes each
         const long long blocks = (count + 15) / 16;
-        hipLaunchKernelGGL(tfk::tip5_hash_pairs_coop_kernel, dim3((unsigned)blocks), dim3(256), 0, s, in, out, count, per_tree, in_ts,
-                           out_ts);
+        hipLaunchKernelGGL(tfk::tip5_hash_pairs_coop_kernel, dim3((unsigned)blocks), dim3(256), 0, s, in, out, count, per_tree,
+                           shift_of(per_tree), in_ts, out_ts);
         HIPCHK(hipGetLastError());
         return TF_OK;
     }
@@ -134,7 +129,7 @@ int launch_hash_varlen_rows(const u64* rows, long long row_len, long long n_rows
     if (n_rows == 0) return TF_OK;
     if (n_rows <= kCoopMaxCount) {
         hipLaunchKernelGGL(tfk::tip5_hash_varlen_rows_coop_kernel, dim3((unsigned)((n_rows + 15) / 16)), dim3(256), 0, s, rows, row_len,
-                           n_rows, out, per_tree, out_ts);
+                           n_rows, out, per_tree, shift_of(per_tree), out_ts);
     } else {
         hipLaunchKernelGGL(tfk::tip5_hash_varlen_rows_mx_kernel<1>, dim3(mx_blocks(n_rows)), dim3(256), 0, s, rows, row_len, n_rows, out,
                            per_tree, shift_of(per_tree), out_ts);
@@ -173,7 +168,13 @@ int check_leaves(size_t n) {
     return TF_OK;
 }
 
-constexpr long long kTopWidth = 256;  // levels of at most this many nodes finish in one workgroup per tree
+// Levels of at most this many nodes finish in one workgroup per tree (merkle_top_kernel).  Measured 256 / 128 / 64 / 32 on trees of
+// height 4..24 (profiles/r05_top_width_ab.txt): the wide levels are faster as launches of their own (one CU is slow at 64+ concurrent
+// 16-lane permutations), the narrow ones inside the workgroup (no launch between them): 64 and 128 tie, 8-10 us ahead of 256.
+#ifndef TF_TOP_WIDTH
+#define TF_TOP_WIDTH 64
+#endif
+constexpr long long kTopWidth = TF_TOP_WIDTH;
 
 // Levels above the leaf level for trees whose leaves are already at nodes[n..2n) (nodes[0] gets zeroed).
 int merkle_levels_in_place(u64* d_nodes, long long N, size_t batch, hipStream_t s) {
@@ -197,8 +198,8 @@ int launch_hash_table_rows(const u64* table, long long n_rows, long long n_cols,
     const long long total = n_rows * batch;
     if (total == 0) return TF_OK;
     if (total <= kCoopMaxCount) {
-        hipLaunchKernelGGL(tfk::tip5_hash_table_rows_coop_kernel, dim3((unsigned)((total + 15) / 16)), dim3(256), 0, s, table, n_rows, n_cols,
-                           width, col_stride, table_stride, total, out, out_ts);
+        hipLaunchKernelGGL(tfk::tip5_hash_table_rows_coop_kernel, dim3((unsigned)((total + 15) / 16)), dim3(256), 0, s, table, n_rows, shift_of(n_rows),
+                           n_cols, width, col_stride, table_stride, total, out, out_ts);
     } else {
         hipLaunchKernelGGL(tfk::tip5_hash_table_rows_mx_kernel<1>, dim3(mx_blocks(total)), dim3(256), 0, s, table, n_rows, shift_of(n_rows),
                            n_cols, width, col_stride, table_stride, total, out, out_ts);

@@ -28,7 +28,6 @@ using gl::u64;
 
 struct Tip5Consts {
     u64 rc[80];        // Montgomery form of ROUND_CONSTANTS (mod.rs:68-149)
-    u32 lut[64];       // LOOKUP_TABLE (mod.rs:50-64) packed 4 bytes per word
 };
 __constant__ Tip5Consts g_tip5;
 
@@ -100,9 +99,14 @@ __device__ __forceinline__ void tip5_permutation(u64 (&s)[16], const unsigned ch
 }
 
 __device__ __forceinline__ void stage_lut(unsigned char* lut_lds) {
-    // 256-byte table into LDS; every workgroup does this once.
-    u32* w = reinterpret_cast<u32*>(lut_lds);
-    for (int i = threadIdx.x; i < 64; i += blockDim.x) w[i] = g_tip5.lut[i];
+    // LOOKUP_TABLE (mod.rs:50-64) into LDS, once per workgroup, from its definition L(x) = ((x + 1)^3 mod 257) - 1
+    // (mod.rs:1022-1026; the reference's lookup_table_is_correct test :1035-1053 pins the literal table to it): a dozen integer
+    // instructions per entry instead of a trip to memory, so a small launch does not wait for a table before it waits for its input.
+    // Every Tip5 kernel runs workgroups of at least 256 threads: thread x writes entry x.
+    if (threadIdx.x < 256) {
+        const u32 v = threadIdx.x + 1u;
+        lut_lds[threadIdx.x] = (unsigned char)((v * v * v) % 257u - 1u);  // (x + 1)^3 mod 257 is never 0 for x < 256
+    }
     __syncthreads();
 }
 
@@ -595,11 +599,14 @@ __device__ __forceinline__ void mds_coop_terms(u32 lo, u32 hi, u64& alo, u64& ah
     }
 }
 
-// s = state[j] of the permutation shared by the 16 lanes of this row; all 16 lanes must be active.
-__device__ __forceinline__ void tip5_permutation_coop(u64& s, int j, const unsigned char* lut) {
-    u64 rcs[5];
+// the five round constants of state word j: fetched once per kernel, before anything waits (the loads fly with the kernel's input)
+__device__ __forceinline__ void coop_round_constants(int j, u64 (&rcs)[5]) {
 #pragma unroll
     for (int r = 0; r < 5; ++r) rcs[r] = g_tip5.rc[r * 16 + j];
+}
+
+// s = state[j] of the permutation shared by the 16 lanes of this row; all 16 lanes must be active.
+__device__ __forceinline__ void tip5_permutation_coop(u64& s, int j, const unsigned char* lut, const u64 (&rcs)[5]) {
 #pragma unroll 1
     for (int round = 0; round < 5; ++round) {
         if (j < 4) {  // split_and_lookup (mod.rs:197-207)
@@ -634,27 +641,30 @@ __device__ __forceinline__ void tip5_permutation_coop(u64& s, int j, const unsig
 // digest goes to out + tree * out_ts + 5 * (i % per_tree); if leaf_copy != null the 10 input words are also copied to
 // leaf_copy + tree * copy_ts + 10 * (i % per_tree) (Merkle leaf level, merkle_tree.rs:426).
 __global__ void __launch_bounds__(256) tip5_hash_pairs_coop_kernel(const u64* in, u64* out, long long count, long long per_tree,
-                                                                   long long in_ts, long long out_ts) {
+                                                                   int shift, long long in_ts, long long out_ts) {
     __shared__ __attribute__((aligned(16))) unsigned char lut[256];
-    stage_lut(lut);
     const int j = threadIdx.x & 15;
     const long long i = (long long)blockIdx.x * 16 + (threadIdx.x >> 4);
-    if (i >= count) return;  // whole rows leave together
-    const long long tree = i / per_tree, k = i - tree * per_tree;
-    u64 s = j < 10 ? in[tree * in_ts + 10 * k + j] : gl::ONE;
-    tip5_permutation_coop(s, j, lut);
+    const bool live = i < count;  // whole rows are live or not
+    long long tree, k;
+    split_item(live ? i : count - 1, per_tree, shift, tree, k);
+    u64 s = j < 10 ? in[tree * in_ts + 10 * k + j] : gl::ONE;  // the input and the round constants are in flight while the table is built
+    u64 rcs[5];
+    coop_round_constants(j, rcs);
+    stage_lut(lut);
+    if (!live) return;
+    tip5_permutation_coop(s, j, lut, rcs);
     if (j < 5) out[tree * out_ts + 5 * k + j] = s;
 }
 
 // hash_varlen of row i by the 16 lanes of row-group i (few rows, or one long input: the absorb chain is sequential)
 __global__ void __launch_bounds__(256) tip5_hash_varlen_rows_coop_kernel(const u64* rows, long long row_len, long long n_rows,
-                                                                         u64* out, long long per_tree, long long out_ts) {
+                                                                         u64* out, long long per_tree, int shift, long long out_ts) {
     __shared__ __attribute__((aligned(16))) unsigned char lut[256];
-    stage_lut(lut);
     const int j = threadIdx.x & 15;
     const long long i = (long long)blockIdx.x * 16 + (threadIdx.x >> 4);
-    if (i >= n_rows) return;
-    const u64* p = rows + i * row_len;
+    const bool live = i < n_rows;
+    const u64* p = rows + (live ? i : n_rows - 1) * row_len;
     u64 s = 0;  // Domain::VariableLength
     // The absorb chain is sequential (mod.rs:617-623): chunk c overwrites the rate words with input words 10 c .. 10 c + 9, the
     // padded last chunk included (sponge.rs:41-55: a one after the input, then zeros).  The next chunk is fetched BEFORE the
@@ -665,25 +675,30 @@ __global__ void __launch_bounds__(256) tip5_hash_varlen_rows_coop_kernel(const u
         return w < row_len ? p[w] : (w == row_len ? gl::ONE : 0);
     };
     u64 nxt = j < 10 ? rate_word(0) : 0;
+    u64 rcs[5];
+    coop_round_constants(j, rcs);
+    stage_lut(lut);
+    if (!live) return;
     for (long long c = 0; c < chunks; ++c) {
         if (j < 10) s = nxt;  // overwrite-mode absorb, mod.rs:684-691
         if (j < 10 && c + 1 < chunks) nxt = rate_word(c + 1);
-        tip5_permutation_coop(s, j, lut);
+        tip5_permutation_coop(s, j, lut, rcs);
     }
-    const long long tree = i / per_tree;
-    if (j < 5) out[tree * out_ts + (i - tree * per_tree) * 5 + j] = s;
+    long long tree, k;
+    split_item(i, per_tree, shift, tree, k);
+    if (j < 5) out[tree * out_ts + k * 5 + j] = s;
 }
 
 // the same for few rows: 16 lanes per row
-__global__ void __launch_bounds__(256) tip5_hash_table_rows_coop_kernel(const u64* table, long long n_rows, long long n_cols, int width,
-                                                                        long long col_stride, long long table_stride, long long total,
-                                                                        u64* out, long long out_ts) {
+__global__ void __launch_bounds__(256) tip5_hash_table_rows_coop_kernel(const u64* table, long long n_rows, int shift, long long n_cols,
+                                                                        int width, long long col_stride, long long table_stride,
+                                                                        long long total, u64* out, long long out_ts) {
     __shared__ __attribute__((aligned(16))) unsigned char lut[256];
-    stage_lut(lut);
     const int j = threadIdx.x & 15;
     const long long id = (long long)blockIdx.x * 16 + (threadIdx.x >> 4);
-    if (id >= total) return;
-    const long long tree = id / n_rows, i = id - tree * n_rows;
+    const bool live = id < total;
+    long long tree, i;
+    split_item(live ? id : total - 1, n_rows, shift, tree, i);
     const u64* tb = table + tree * table_stride;
     const long long row_len = n_cols * width;
     u64 s = 0;
@@ -693,10 +708,14 @@ __global__ void __launch_bounds__(256) tip5_hash_table_rows_coop_kernel(const u6
         return w < row_len ? table_word(tb, i, w, width, col_stride) : (w == row_len ? gl::ONE : 0);
     };
     u64 nxt = j < 10 ? rate_word(0) : 0;
+    u64 rcs[5];
+    coop_round_constants(j, rcs);
+    stage_lut(lut);
+    if (!live) return;
     for (long long c = 0; c < chunks; ++c) {
         if (j < 10) s = nxt;
         if (j < 10 && c + 1 < chunks) nxt = rate_word(c + 1);
-        tip5_permutation_coop(s, j, lut);
+        tip5_permutation_coop(s, j, lut, rcs);
     }
     if (j < 5) out[tree * out_ts + i * 5 + j] = s;
 }
@@ -704,12 +723,15 @@ __global__ void __launch_bounds__(256) tip5_hash_table_rows_coop_kernel(const u6
 // Tip5::permutation of state i by row-group i
 __global__ void __launch_bounds__(256) tip5_permute_coop_kernel(u64* states, long long count) {
     __shared__ __attribute__((aligned(16))) unsigned char lut[256];
-    stage_lut(lut);
     const int j = threadIdx.x & 15;
     const long long i = (long long)blockIdx.x * 16 + (threadIdx.x >> 4);
-    if (i >= count) return;
-    u64 s = states[i * 16 + j];
-    tip5_permutation_coop(s, j, lut);
+    const bool live = i < count;
+    u64 s = states[(live ? i : count - 1) * 16 + j];
+    u64 rcs[5];
+    coop_round_constants(j, rcs);
+    stage_lut(lut);
+    if (!live) return;
+    tip5_permutation_coop(s, j, lut, rcs);
     states[i * 16 + j] = s;
 }
 
@@ -724,25 +746,26 @@ __global__ void __launch_bounds__(1024) merkle_top_kernel(const u64* level_in, l
     __shared__ __attribute__((aligned(16))) unsigned char lut[256];
     __shared__ u64 buf[2][256 * 5];
     (void)leaves_ts;  // leaves_to_copy != null only says that level_in IS the leaf level, to be copied into nodes[width..2 width)
-    stage_lut(lut);
     const long long tree = blockIdx.x;
     const int t = threadIdx.x, j = t & 15, row = t >> 4;  // 64 rows of 16 lanes: one hash_pair per row at a time
     const u64* src = level_in + tree * in_ts;
     u64* nd = nodes ? nodes + tree * nodes_ts : nullptr;
+    u64 rcs[5];
+    coop_round_constants(j, rcs);  // once for all levels
     for (int k = t; k < width * 5; k += blockDim.x) {
         u64 v = src[k];
         buf[0][k] = v;
         if (leaves_to_copy && nd) nd[(long long)width * 5 + k] = v;  // starting level is the leaf level
     }
     if (nd && t < 5) nd[t] = 0;
-    __syncthreads();
+    stage_lut(lut);  // ends in the barrier that also publishes buf[0]
     int cur = 0;
     for (int w = width / 2; w >= 1; w /= 2) {
         for (int base = 0; base < w; base += 64) {
             const int i = base + row;
             if (i < w) {  // whole rows take the branch together
                 u64 s = j < 10 ? buf[cur][10 * i + j] : gl::ONE;
-                tip5_permutation_coop(s, j, lut);
+                tip5_permutation_coop(s, j, lut, rcs);
                 if (j < 5) {
                     buf[cur ^ 1][5 * i + j] = s;
                     if (nd) nd[(long long)(w + i) * 5 + j] = s;
