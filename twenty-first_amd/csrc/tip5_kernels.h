@@ -588,13 +588,15 @@ __global__ void __launch_bounds__(256) tip5_permute_mx_kernel(u64* states, u64* 
 // v_mad_u64_u32 with the same constant M[k] in every lane.  ~1 600 instructions per permutation (the lookup lanes and
 // the x^7 lanes take turns): 3x the total work of the lane-per-permutation form, 1/5 of its latency -- measured 4.6 us
 // per tree level instead of 19 us.  Used for launches of at most kCoopMaxCount permutation chains (tf_tip5.hip).
+// the circulant as two interleaved pairs of accumulators (even and odd rotations): four independent v_mad_u64_u32 chains in
+// flight instead of two -- one permutation is a latency chain, and a v_mad_u64_u32 that waits for its own previous result stalls
 template <int K>
-__device__ __forceinline__ void mds_coop_terms(u32 lo, u32 hi, u64& alo, u64& ahi) {
+__device__ __forceinline__ void mds_coop_terms(u32 lo, u32 hi, u64 (&alo)[2], u64 (&ahi)[2]) {
     if constexpr (K < 16) {
         const u32 rl = (u32)__builtin_amdgcn_mov_dpp((int)lo, 0x120 + K, 0xf, 0xf, true);  // row_ror:K: lane r <- lane (r - K) mod 16
         const u32 rh = (u32)__builtin_amdgcn_mov_dpp((int)hi, 0x120 + K, 0xf, 0xf, true);
-        alo += (u64)mds_entry(K) * rl;
-        ahi += (u64)mds_entry(K) * rh;
+        alo[K & 1] += (u64)mds_entry(K) * rl;
+        ahi[K & 1] += (u64)mds_entry(K) * rh;
         mds_coop_terms<K + 1>(lo, hi, alo, ahi);
     }
 }
@@ -606,26 +608,32 @@ __device__ __forceinline__ void coop_round_constants(int j, u64 (&rcs)[5]) {
 }
 
 // s = state[j] of the permutation shared by the 16 lanes of this row; all 16 lanes must be active.
+// Latency shape (one permutation is what a tree level near the root, or a chunk of one long sponge, waits for):
+//   * no divergence in the S-box layer: every lane runs BOTH the split_and_lookup of its word and its x^7 and keeps the one its
+//     position calls for -- a wave issues both paths either way (every row has lanes of both kinds), but as one instruction stream
+//     the eight LDS lookups and their packing fill the wait states of the multiply chain instead of following it;
+//   * x^7 = (x^2 * x) * (x^2)^2: three products deep instead of four, the two in the middle as one hand-scheduled pair;
+//   * the five rounds unrolled: the round constant is a register, not a select chain.
 __device__ __forceinline__ void tip5_permutation_coop(u64& s, int j, const unsigned char* lut, const u64 (&rcs)[5]) {
-#pragma unroll 1
+#pragma unroll
     for (int round = 0; round < 5; ++round) {
-        if (j < 4) {  // split_and_lookup (mod.rs:197-207)
-            const u32 l = lookup4((u32)s, lut), h = lookup4((u32)(s >> 32), lut);
-            s = ((u64)h << 32) | l;
-        } else {  // x^7
-            const u64 sq = gl::mont_mul(s, s);
-            const u64 qu = gl::mont_mul(sq, sq);
-            s = gl::mont_mul(s, gl::mont_mul(sq, qu));
-        }
+        const u32 ll = lookup4((u32)s, lut), lh = lookup4((u32)(s >> 32), lut);  // split_and_lookup (mod.rs:197-207), kept by lanes 0..3
+        const u64 sq = gl::mont_mul(s, s);
+        u64 cu, qu;
+        gl::mont_mul2(sq, s, sq, sq, cu, qu);
+        const u64 x7 = gl::mont_mul(cu, qu);
+        s = j < 4 ? (((u64)lh << 32) | ll) : x7;
         const u32 lo = (u32)s, hi = (u32)(s >> 32);
-        u64 alo = (u64)mds_entry(0) * lo, ahi = (u64)mds_entry(0) * hi;
+        u64 alo[2] = {(u64)mds_entry(0) * lo, 0}, ahi[2] = {(u64)mds_entry(0) * hi, 0};
         mds_coop_terms<1>(lo, hi, alo, ahi);
+        asm("" : "+v"(alo[1]), "+v"(ahi[1]));  // (keeps the compiler from folding the odd chains back into the even ones)
+        const u64 slo = alo[0] + alo[1], shi = ahi[0] + ahi[1];  // < 2^52 each
         // same single-fold reduction as tip5_round
         const u64 rc = rcs[round];
         unsigned c0, c1, c2, c3, c4;
-        const u32 w1 = __builtin_addc((u32)(alo >> 32), (u32)ahi, 0u, &c0);
-        const u32 w2 = __builtin_addc((u32)(ahi >> 32), 0u, c0, &c1);
-        const u32 t0 = __builtin_addc((u32)alo, (u32)rc, 0u, &c2);
+        const u32 w1 = __builtin_addc((u32)(slo >> 32), (u32)shi, 0u, &c0);
+        const u32 w2 = __builtin_addc((u32)(shi >> 32), 0u, c0, &c1);
+        const u32 t0 = __builtin_addc((u32)slo, (u32)rc, 0u, &c2);
         const u32 t1 = __builtin_addc(w1, (u32)(rc >> 32), c2, &c3);
         const u32 t2 = __builtin_addc(w2, 0u, c3, &c4);
         const u64 l64 = ((u64)t1 << 32) | t0;
