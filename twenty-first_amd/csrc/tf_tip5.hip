@@ -168,28 +168,69 @@ int check_leaves(size_t n) {
     return TF_OK;
 }
 
-// Levels of at most this many nodes finish in one workgroup per tree (merkle_top_kernel).  Measured 256 / 128 / 64 / 32 on trees of
-// height 4..24 (profiles/r05_top_width_ab.txt): the wide levels are faster as launches of their own (one CU is slow at 64+ concurrent
-// 16-lane permutations), the narrow ones inside the workgroup (no launch between them): 64 and 128 tie, 8-10 us ahead of 256.
-#ifndef TF_TOP_WIDTH
-#define TF_TOP_WIDTH 64
+// Near the root a level is one permutation latency whatever its width, and what it costs is the launch around it.  Once a level has
+// at most kCoopMaxCount pairs (all trees of the call together) the remaining levels run as SUBTREES: a workgroup takes 2^k consecutive
+// nodes and computes the k levels above them through LDS (merkle_subtree_kernel; the last launch is merkle_top_kernel, one workgroup
+// per tree), k <= kSubtreeMaxLog and the levels split evenly over the launches.  Measured (profiles/r05_top_width_ab.txt,
+// r05_subtree_ab.txt): a workgroup is slow at 64+ concurrent 16-lane permutations (so 256-node tops lost 8-10 us to 64-node ones), and
+// a launch per level costs ~2 us per level more than a barrier per level.
+#ifndef TF_SUBTREE_MAX_LOG
+#define TF_SUBTREE_MAX_LOG 6
 #endif
-constexpr long long kTopWidth = TF_TOP_WIDTH;
+constexpr int kSubtreeMaxLog = TF_SUBTREE_MAX_LOG;
+constexpr long long kTopWidth = 1ll << kSubtreeMaxLog;  // a tree of at most this many leaves is one merkle_top_kernel launch
+
+inline int ilog2ll(long long v) { return 63 - __builtin_clzll((unsigned long long)v); }
+inline unsigned subtree_threads(int chunk_log) { return (unsigned)std::min(1024, std::max(256, 8 << chunk_log)); }  // 16 lanes per pair
+
+// Every level above the level of w nodes per tree (`level`: its digests, in_ts words from tree to tree), w a power of two with
+// w <= kTopWidth or (w / 2) * batch <= kCoopMaxCount.  With d_nodes: in place in the heap-ordered node arrays (copy_input: `level` is
+// the leaf level, to be copied to nodes[w .. 2 w) on the way); without: root only, subtree roots ping-pong through scratch (>= w / 2
+// digests per tree when more than one launch is needed) and the roots land in d_root.
+int merkle_narrow_levels(const u64* level, long long in_ts, long long w, u64* d_nodes, long long nodes_ts, u64* d_root, u64* scratch,
+                         size_t batch, bool copy_input, hipStream_t s) {
+    int remaining = ilog2ll(w);
+    int launches = std::max(1, (remaining + kSubtreeMaxLog - 1) / kSubtreeMaxLog);
+    u64* sa = scratch;
+    u64* sb = scratch ? scratch + size_t(batch) * 5 * size_t(w >> 1) / 2 : nullptr;  // the second buffer: at most w / 4 digests per tree
+    for (; launches > 1; --launches) {
+        const int k = (remaining + launches - 1) / launches, chunks_log = remaining - k;
+        const long long nw = w >> k;
+        u64* out = d_nodes ? nullptr : sa;
+        hipLaunchKernelGGL(tfk::merkle_subtree_kernel, dim3((unsigned)(batch << chunks_log)), dim3(subtree_threads(k)), 0, s, level, in_ts, k,
+                           chunks_log, d_nodes, nodes_ts, out, 5 * nw, copy_input ? 1 : 0);
+        HIPCHK(hipGetLastError());
+        w = nw;
+        remaining -= k;
+        copy_input = false;
+        if (d_nodes) {
+            level = d_nodes + 5 * w;
+            in_ts = nodes_ts;
+        } else {
+            level = sa;
+            in_ts = 5 * w;
+            std::swap(sa, sb);
+        }
+    }
+    hipLaunchKernelGGL(tfk::merkle_top_kernel, dim3((unsigned)batch), dim3(subtree_threads(remaining)), 0, s, level, in_ts, (int)w, d_nodes,
+                       nodes_ts, d_root, copy_input ? level : (const u64*)nullptr, in_ts);
+    HIPCHK(hipGetLastError());
+    return TF_OK;
+}
+
+inline bool narrow_from(long long w, size_t batch) { return w <= kTopWidth || (w / 2) * (long long)batch <= kCoopMaxCount; }
 
 // Levels above the leaf level for trees whose leaves are already at nodes[n..2n) (nodes[0] gets zeroed).
 int merkle_levels_in_place(u64* d_nodes, long long N, size_t batch, hipStream_t s) {
     const long long nodes_ts = 10 * N;
     long long w = N;
-    while (w > kTopWidth) {  // nodes[w/2 .. w) from nodes[w .. 2w)
+    while (!narrow_from(w, batch)) {  // nodes[w/2 .. w) from nodes[w .. 2w)
         const long long nw = w / 2;
         int rc = launch_hash_pairs(d_nodes + 5 * w, d_nodes + 5 * nw, nullptr, nw * (long long)batch, nw, nodes_ts, nodes_ts, 0, s);
         if (rc) return rc;
         w = nw;
     }
-    hipLaunchKernelGGL(tfk::merkle_top_kernel, dim3((unsigned)batch), dim3(1024), 0, s, d_nodes + 5 * w, nodes_ts, (int)w,
-                       d_nodes, nodes_ts, (u64*)nullptr, (const u64*)nullptr, 0ll);
-    HIPCHK(hipGetLastError());
-    return TF_OK;
+    return merkle_narrow_levels(d_nodes + 5 * w, nodes_ts, w, d_nodes, nodes_ts, nullptr, nullptr, batch, false, s);
 }
 
 // hash_varlen of the rows of `batch` column-major tables (one codeword per column): digests to out + t * out_ts + 5 * i
@@ -279,28 +320,21 @@ int merkle_build_dev(const u64* d_leaves, size_t n, u64* d_nodes, size_t batch, 
     if (rc) return rc;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const long long N = (long long)n, nodes_ts = 10 * N, leaves_ts = 5 * N;
-    if (N <= kTopWidth) {
-        hipLaunchKernelGGL(tfk::merkle_top_kernel, dim3((unsigned)batch), dim3(1024), 0, s, d_leaves, leaves_ts, (int)N,
-                           d_nodes, nodes_ts, (u64*)nullptr, d_leaves, leaves_ts);
-        HIPCHK(hipGetLastError());
-        return TF_OK;
-    }
+    if (narrow_from(N, batch))  // small trees: subtrees from the leaf level on (the leaves are copied into nodes[n..2n) on the way)
+        return merkle_narrow_levels(d_leaves, leaves_ts, N, d_nodes, nodes_ts, nullptr, nullptr, batch, true, s);
     // first level: read leaves, write the leaf copy nodes[n..2n) and the parents nodes[n/2..n)
     long long w = N / 2;
     rc = launch_hash_pairs(d_leaves, d_nodes + 5 * w, d_nodes + 5 * N, w * (long long)batch, w, leaves_ts, nodes_ts,
                            nodes_ts, s);
     if (rc) return rc;
-    while (w > kTopWidth) {  // nodes[w/2 .. w) from nodes[w .. 2w)
+    while (!narrow_from(w, batch)) {  // nodes[w/2 .. w) from nodes[w .. 2w)
         const long long nw = w / 2;
         rc = launch_hash_pairs(d_nodes + 5 * w, d_nodes + 5 * nw, nullptr, nw * (long long)batch, nw, nodes_ts, nodes_ts, 0,
                                s);
         if (rc) return rc;
         w = nw;
     }
-    hipLaunchKernelGGL(tfk::merkle_top_kernel, dim3((unsigned)batch), dim3(1024), 0, s, d_nodes + 5 * w, nodes_ts, (int)w,
-                       d_nodes, nodes_ts, (u64*)nullptr, (const u64*)nullptr, 0ll);
-    HIPCHK(hipGetLastError());
-    return TF_OK;
+    return merkle_narrow_levels(d_nodes + 5 * w, nodes_ts, w, d_nodes, nodes_ts, nullptr, nullptr, batch, false, s);
 }
 
 int merkle_root_dev(const u64* d_leaves, size_t n, u64* d_root, size_t batch, void* stream) {
@@ -315,12 +349,7 @@ int merkle_root_dev(const u64* d_leaves, size_t n, u64* d_root, size_t batch, vo
     if (rc) return rc;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const long long N = (long long)n, leaves_ts = 5 * N;
-    if (N <= kTopWidth) {
-        hipLaunchKernelGGL(tfk::merkle_top_kernel, dim3((unsigned)batch), dim3(1024), 0, s, d_leaves, leaves_ts, (int)N,
-                           (u64*)nullptr, 0ll, d_root, (const u64*)nullptr, 0ll);
-        HIPCHK(hipGetLastError());
-        return TF_OK;
-    }
+    if (N <= kTopWidth) return merkle_narrow_levels(d_leaves, leaves_ts, N, nullptr, 0, d_root, nullptr, batch, false, s);
     // ping-pong level buffers: n/2 + n/4 digests per tree
     u64* buf = nullptr;
     const size_t words = size_t(batch) * size_t(5) * size_t(N / 2 + N / 4);
@@ -329,21 +358,21 @@ int merkle_root_dev(const u64* d_leaves, size_t n, u64* d_root, size_t batch, vo
         hip_fail(e, "pool_malloc_async(merkle levels)", __FILE__, __LINE__);
         return TF_ERR_TREE_TOO_HIGH;
     }
-    u64* a = buf;
-    u64* b = buf + size_t(batch) * 5 * size_t(N / 2);
-    long long w = N / 2;
-    rc = launch_hash_pairs(d_leaves, a, nullptr, w * (long long)batch, w, leaves_ts, 5 * w, 0, s);
-    while (rc == TF_OK && w > kTopWidth) {
-        const long long nw = w / 2;
-        rc = launch_hash_pairs(a, b, nullptr, nw * (long long)batch, nw, 5 * w, 5 * nw, 0, s);
-        std::swap(a, b);
-        w = nw;
-    }
-    if (rc == TF_OK) {
-        hipLaunchKernelGGL(tfk::merkle_top_kernel, dim3((unsigned)batch), dim3(1024), 0, s, a, 5 * w, (int)w, (u64*)nullptr,
-                           0ll, d_root, (const u64*)nullptr, 0ll);
-        hipError_t le = hipGetLastError();
-        if (le != hipSuccess) rc = hip_fail(le, "merkle_top_kernel", __FILE__, __LINE__);
+    if (narrow_from(N, batch)) {  // subtrees from the leaf level on
+        rc = merkle_narrow_levels(d_leaves, leaves_ts, N, nullptr, 0, d_root, buf, batch, false, s);
+    } else {
+        u64* a = buf;
+        u64* b = buf + size_t(batch) * 5 * size_t(N / 2);
+        long long w = N / 2;
+        rc = launch_hash_pairs(d_leaves, a, nullptr, w * (long long)batch, w, leaves_ts, 5 * w, 0, s);
+        while (rc == TF_OK && !narrow_from(w, batch)) {
+            const long long nw = w / 2;
+            rc = launch_hash_pairs(a, b, nullptr, nw * (long long)batch, nw, 5 * w, 5 * nw, 0, s);
+            std::swap(a, b);
+            w = nw;
+        }
+        // `a` holds the level of w digests per tree; the other buffer (>= w / 2 digests per tree) is free for the subtree roots
+        if (rc == TF_OK) rc = merkle_narrow_levels(a, 5 * w, w, nullptr, 0, d_root, b, batch, false, s);
     }
     e = hipFreeAsync(buf, s);
     if (rc) return rc;

@@ -743,9 +743,46 @@ __global__ void __launch_bounds__(256) tip5_permute_coop_kernel(u64* states, lon
     states[i * 16 + j] = s;
 }
 
-// Top of a tree in one workgroup per tree: given level `width` (<= 256 nodes, i.e. nodes[width .. 2 width)),
-// compute nodes[1 .. width) level by level through LDS and write them out; also zero nodes[0]
-// (merkle_tree.rs:415-419).  Mirrors sequentially_fill_tree (:216-222) below the parallelisation cutoff.
+// A whole subtree in one workgroup (sequentially_fill_tree, merkle_tree.rs:216-222, below the parallelisation cutoff): the workgroup
+// takes `chunk` consecutive nodes of a level of `w` nodes (chunk c of tree `tree`: nodes[w + c chunk .. w + (c + 1) chunk)), computes
+// the log2(chunk) levels above them through LDS -- one hash_pair per 16-lane row, a barrier per level, no launch between levels --
+// and writes every node it computed to its place in the heap-ordered array (if nd != null) and the subtree's root to `out` (if
+// != null).  Near the root of a tree a level is one permutation latency (~2.2 us) whatever its width, so what a level costs is the
+// launch around it: a workgroup per subtree pays it once per log2(chunk) levels.
+__device__ __forceinline__ void merkle_subtree(const u64* src, int chunk, u64* nd, long long w, long long c, bool copy_input, u64* out,
+                                               u64 (*buf)[256 * 5], unsigned char* lut) {
+    const int t = threadIdx.x, j = t & 15, row = t >> 4, rows = blockDim.x >> 4;
+    u64 rcs[5];
+    coop_round_constants(j, rcs);  // once for all levels
+    for (int k = t; k < chunk * 5; k += blockDim.x) {
+        const u64 v = src[k];
+        buf[0][k] = v;
+        if (copy_input && nd) nd[(w + c * chunk) * 5 + k] = v;  // the input level is the leaf level (merkle_tree.rs:426)
+    }
+    stage_lut(lut);  // ends in the barrier that also publishes buf[0]
+    int cur = 0;
+    long long lw = w;  // nodes in the level being read
+    for (int cw = chunk / 2; cw >= 1; cw /= 2) {
+        lw /= 2;
+        for (int base = 0; base < cw; base += rows) {
+            const int i = base + row;
+            if (i < cw) {  // whole rows take the branch together
+                u64 s = j < 10 ? buf[cur][10 * i + j] : gl::ONE;
+                tip5_permutation_coop(s, j, lut, rcs);
+                if (j < 5) {
+                    buf[cur ^ 1][5 * i + j] = s;
+                    if (nd) nd[(lw + c * cw + i) * 5 + j] = s;
+                }
+            }
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    if (out && t < 5) out[t] = buf[cur][t];
+}
+
+// Top of a tree in one workgroup per tree: given the level of `width` (<= 256) nodes, i.e. nodes[width .. 2 width), compute
+// nodes[1 .. width) and write them out; also zero nodes[0] (merkle_tree.rs:415-419).
 // level_in: pointer to the `width` digests of the starting level for tree 0, stride in_ts words per tree.
 // nodes: node array (may be null when only the root is wanted); root_out: 5 words per tree or null.
 __global__ void __launch_bounds__(1024) merkle_top_kernel(const u64* level_in, long long in_ts, int width, u64* nodes,
@@ -755,35 +792,23 @@ __global__ void __launch_bounds__(1024) merkle_top_kernel(const u64* level_in, l
     __shared__ u64 buf[2][256 * 5];
     (void)leaves_ts;  // leaves_to_copy != null only says that level_in IS the leaf level, to be copied into nodes[width..2 width)
     const long long tree = blockIdx.x;
-    const int t = threadIdx.x, j = t & 15, row = t >> 4;  // 64 rows of 16 lanes: one hash_pair per row at a time
-    const u64* src = level_in + tree * in_ts;
     u64* nd = nodes ? nodes + tree * nodes_ts : nullptr;
-    u64 rcs[5];
-    coop_round_constants(j, rcs);  // once for all levels
-    for (int k = t; k < width * 5; k += blockDim.x) {
-        u64 v = src[k];
-        buf[0][k] = v;
-        if (leaves_to_copy && nd) nd[(long long)width * 5 + k] = v;  // starting level is the leaf level
-    }
-    if (nd && t < 5) nd[t] = 0;
-    stage_lut(lut);  // ends in the barrier that also publishes buf[0]
-    int cur = 0;
-    for (int w = width / 2; w >= 1; w /= 2) {
-        for (int base = 0; base < w; base += 64) {
-            const int i = base + row;
-            if (i < w) {  // whole rows take the branch together
-                u64 s = j < 10 ? buf[cur][10 * i + j] : gl::ONE;
-                tip5_permutation_coop(s, j, lut, rcs);
-                if (j < 5) {
-                    buf[cur ^ 1][5 * i + j] = s;
-                    if (nd) nd[(long long)(w + i) * 5 + j] = s;
-                }
-            }
-        }
-        __syncthreads();
-        cur ^= 1;
-    }
-    if (root_out && t < 5) root_out[tree * 5 + t] = buf[cur][t];
+    if (nd && threadIdx.x < 5) nd[threadIdx.x] = 0;
+    merkle_subtree(level_in + tree * in_ts, width, nd, width, 0, leaves_to_copy != nullptr, root_out ? root_out + tree * 5 : nullptr, buf, lut);
+}
+
+// The levels between the wide ones (one launch each) and the top: workgroup (tree, c) takes chunk = 2^chunk_log nodes of the level of
+// w = chunk << chunks_log nodes and leaves the subtree root in out + tree * out_ts + 5 c (if out != null: the root-only builders keep
+// no node array; with one the root is already at nodes[(w >> chunk_log) + c]).
+__global__ void __launch_bounds__(1024) merkle_subtree_kernel(const u64* level_in, long long in_ts, int chunk_log, int chunks_log, u64* nodes,
+                                                              long long nodes_ts, u64* out, long long out_ts, int copy_input) {
+    __shared__ __attribute__((aligned(16))) unsigned char lut[256];
+    __shared__ u64 buf[2][256 * 5];
+    const long long tree = blockIdx.x >> chunks_log, c = blockIdx.x - (tree << chunks_log);
+    const int chunk = 1 << chunk_log;
+    const long long w = (long long)chunk << chunks_log;
+    merkle_subtree(level_in + tree * in_ts + c * chunk * 5, chunk, nodes ? nodes + tree * nodes_ts : nullptr, w, c, copy_input != 0,
+                   out ? out + tree * out_ts + 5 * c : nullptr, buf, lut);
 }
 
 // out[k] = nodes[idx[k]] for digests (5 words): authentication structures from a device-resident tree
