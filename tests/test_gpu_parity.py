@@ -235,7 +235,7 @@ def test_hash_varlen_rows(tf, oracle, row_len):
 
 # ------------------------------------------------------------------ Merkle
 
-@pytest.mark.parametrize("height", list(range(0, 14)) + [16])
+@pytest.mark.parametrize("height", list(range(0, 17)))
 def test_merkle_build_matches_oracle(tf, oracle, height):
     n = 1 << height
     leaves = oracle.fill_random(5 * n, 300 + height)
@@ -249,7 +249,8 @@ def test_merkle_build_matches_oracle(tf, oracle, height):
 
 
 def test_merkle_batch_of_trees(tf, oracle):
-    for n, batch in [(1, 3), (8, 5), (256, 3), (512, 3), (4096, 7)]:
+    # (the levels near the root run as subtrees, merkle_subtree_kernel: one, two and three launches, with and without a node array)
+    for n, batch in [(1, 3), (8, 5), (64, 9), (128, 5), (256, 3), (512, 3), (2048, 4), (4096, 7), (16384, 2), (65536, 3)]:
         leaves = oracle.fill_random(5 * n * batch, 17 * n + batch)
         got = tf.MerkleTree.build_batch(leaves, n)
         roots = tf.MerkleTree.roots_batch(leaves, n)
