@@ -192,7 +192,9 @@ int merkle_narrow_levels(const u64* level, long long in_ts, long long w, u64* d_
     int remaining = ilog2ll(w);
     int launches = std::max(1, (remaining + kSubtreeMaxLog - 1) / kSubtreeMaxLog);
     u64* sa = scratch;
-    u64* sb = scratch ? scratch + size_t(batch) * 5 * size_t(w >> 1) / 2 : nullptr;  // the second buffer: at most w / 4 digests per tree
+    // more than one launch means >= 7 levels, so every launch but the last takes >= 4: the first leaves <= w / 16 digests per tree (in
+    // sa), the second <= w / 256 (in sb, which starts w / 4 digests per tree into the scratch block)
+    u64* sb = scratch ? scratch + size_t(batch) * 5 * size_t(w >> 2) : nullptr;
     for (; launches > 1; --launches) {
         const int k = (remaining + launches - 1) / launches, chunks_log = remaining - k;
         const long long nw = w >> k;
