@@ -26,7 +26,7 @@
 //
 // Kernels in this file and the lengths they serve (planner: run_ntt in tf_ntt.hip):
 //   ntt_tiny_kernel    n <= 16                the reference's radix-2 sweeps, one transform per thread
-//   ntt_rows32_kernel  n == 32, BFE           tiles of 512 transforms staged through LDS, one per thread, no exchange
+//   ntt_rows32w_kernel n == 32                wave-private tiles of 64 (limb-)transforms through LDS, one per lane, no barrier
 //   ntt_pass_kernel    32 <= n <= 1024        one pass, rows of T whole transforms per workgroup
 //                      n > 2^14 (and XFE > 1024): 2-4 passes as described above; the R = 1024 instantiations
 //                      (LAST1024: row-major load roles / column-major store roles, stores fused with the last radix-2
@@ -1209,11 +1209,6 @@ __global__ void __launch_bounds__(512, 4) ntt_block_kernel(const NttBlockArgs A)
     }
 }
 
-// ---- n = 32, contiguous transforms: one transform (one limb of it for XFE) per thread, staged through LDS ---------------
-// A thread's 32 elements are contiguous in memory, so direct loads are 8-byte pieces 256 bytes apart (1.94 ms per 2^28 words).
-// Here the workgroup streams its tile (512 BFE transforms or 170 XFE transforms = 510 limb-transforms) through LDS in two
-// halves: coalesced loads into rows of pitch 33, each thread picks up its row, transforms it in registers, puts it back, and
-// the tile leaves with coalesced stores.
 struct NttRows32Args {
     const u64* in;
     u64* out;
@@ -1221,6 +1216,13 @@ struct NttRows32Args {
     u64 scale;                   // Montgomery 32^-1 for the inverse, 0 = none
     int L;
 };
+
+#ifdef TF_AB_BUILD
+// ---- n = 32, contiguous transforms: one transform (one limb of it for XFE) per thread, staged through LDS ---------------
+// A thread's 32 elements are contiguous in memory, so direct loads are 8-byte pieces 256 bytes apart (1.94 ms per 2^28 words).
+// Here the workgroup streams its tile (512 BFE transforms or 170 XFE transforms = 510 limb-transforms) through LDS in two
+// halves: coalesced loads into rows of pitch 33, each thread picks up its row, transforms it in registers, puts it back, and
+// the tile leaves with coalesced stores.
 
 template <bool INV>
 __global__ void __launch_bounds__(512, 4) ntt_rows32_kernel(const NttRows32Args A) {
@@ -1290,6 +1292,106 @@ __global__ void __launch_bounds__(512, 4) ntt_rows32_kernel(const NttRows32Args 
             }
             dst[w] = lds[(lt - h * half_lt) * 33 + e];
         }
+    }
+}
+#endif
+
+// ---- n <= 32, wave-private tiles ----------------------------------------------------------------------------------------------
+// A thread's 32 elements are contiguous in memory, so direct loads would be 8-byte pieces 256 bytes apart (1.94 ms per 2^28 words),
+// and a workgroup that moves its tile through LDS in barrier-separated phases (load | pick up rows | transform | put rows back |
+// store; round 2's ntt_rows32_kernel, kept in the laboratory build) leaves the memory pipe or the vector ALU idle in every phase:
+// 1.21 ms per 2^28 words against the 0.87 ms of one coalesced round trip.  Here a WAVE owns its tile -- 64 BFieldElement transforms,
+// or 21 XFieldElement transforms = 63 limb-transforms (a limb-transform is what one lane computes) -- and its own 64 x 33 words of
+// LDS: no barrier anywhere, and the loads of the wave's next tile are issued before the current one is touched, so every wave keeps
+// 16 KiB in flight while it computes.  Measured 0.867 ms per 2^28 words (profiles/r05_rows32_ab.txt): the floor.
+template <int L>
+__device__ __forceinline__ int rows32_slot(int w) {  // word w of a tile -> its place (row = limb-transform, column = element) in LDS
+    if constexpr (L == 1) {
+        return (w >> 5) * 33 + (w & 31);
+    } else {
+        const int el = (int)__umulhi((u32)w, 0x55555556u), limb = w - 3 * el;  // w / 3, w % 3 (w < 2^31 / 3)
+        return ((el >> 5) * 3 + limb) * 33 + (el & 31);
+    }
+}
+
+// n = 2^LOGN <= 32: a lane's 32 consecutive elements are 32 / n whole transforms -- levels 1 .. LOGN of the network over all 32
+// register slots are exactly those transforms side by side (inputs bit-reversed within each group of n slots).
+template <int LOGN>
+__device__ __forceinline__ constexpr int rows32_src(int q) {  // slot q reads element (q / n) n + brev_LOGN(q % n) of the lane's row
+    int r = 0;
+    for (int b = 0; b < LOGN; ++b) r |= ((q >> b) & 1) << (LOGN - 1 - b);
+    return (q >> LOGN << LOGN) | r;
+}
+template <bool INV, int LOGN, int LVL = 1>
+__device__ __forceinline__ void rows32_network(u64 (&x)[32]) {
+    if constexpr (LVL <= LOGN) {
+        dit_level<INV, LVL, INV>(x);  // the inverse multiplies every word by n^-1 afterwards: lazy network
+        rows32_network<INV, LOGN, LVL + 1>(x);
+    }
+}
+
+template <bool INV, int L, int LOGN>
+__global__ void __launch_bounds__(256, 2) ntt_rows32w_kernel(const NttRows32Args A) {
+    extern __shared__ __attribute__((aligned(16))) u64 lds[];
+    constexpr int kRows = L == 1 ? 64 : 21, kWords = kRows * 32 * L;  // rows of 32 elements and words per tile (2048 / 2016)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    u64* my = lds + wave * (64 * 33);
+    const long long total_words = A.total_transforms * L << LOGN;
+    const long long tiles = (total_words + kWords - 1) / kWords, stride = (long long)gridDim.x * 4;
+    long long tile = (long long)blockIdx.x * 4 + wave;
+    if (tile >= tiles) return;
+    int slot[32];  // where word lane + 64 q of a tile goes (the same for every tile)
+#pragma unroll
+    for (int q = 0; q < 32; ++q) slot[q] = rows32_slot<L>(lane + 64 * q);
+    u64 nxt[32];
+    {
+        const long long base = tile * kWords;
+#pragma unroll
+        for (int q = 0; q < 32; ++q) {
+            const long long w = base + lane + 64 * q;
+            nxt[q] = (lane + 64 * q < kWords && w < total_words) ? A.in[w] : 0;
+        }
+    }
+    for (; tile < tiles; tile += stride) {
+        const long long base = tile * kWords;
+        u64 x[32];
+#pragma unroll
+        for (int q = 0; q < 32; ++q) x[q] = nxt[q];
+        if (tile + stride < tiles) {
+            const long long nb = (tile + stride) * kWords;
+#pragma unroll
+            for (int q = 0; q < 32; ++q) {
+                const long long w = nb + lane + 64 * q;
+                nxt[q] = (lane + 64 * q < kWords && w < total_words) ? A.in[w] : 0;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 32; ++q)
+            if (L == 1 || lane + 64 * q < kWords) my[slot[q]] = x[q];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int q = 0; q < 32; ++q) x[q] = my[lane * 33 + rows32_src<LOGN>(q)];  // (lane 63 of an XFieldElement tile transforms a stale row nobody reads)
+        rows32_network<INV, LOGN>(x);
+        if (INV) {
+#pragma unroll
+            for (int q = 0; q < 32; q += 4) mul4_inplace(x, q, A.scale, A.scale, A.scale, A.scale);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int q = 0; q < 32; ++q) my[lane * 33 + q] = x[q];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int q = 0; q < 32; ++q) {
+            const long long w = base + lane + 64 * q;
+            if (lane + 64 * q < kWords && w < total_words) A.out[w] = my[slot[q]];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     }
 }
 

@@ -1037,6 +1037,7 @@ int check_len(size_t n) {
     return TF_OK;
 }
 
+#ifdef TF_AB_BUILD
 // n = 32, contiguous transforms: LDS-staged rows (ntt_rows32_kernel)
 template <bool INV>
 int launch_rows32_t(const tfk::NttRows32Args& a, unsigned grid, hipStream_t stream) {
@@ -1046,23 +1047,62 @@ int launch_rows32_t(const tfk::NttRows32Args& a, unsigned grid, hipStream_t stre
     HIPCHK(hipGetLastError());
     return TF_OK;
 }
+#endif
 
-int launch_rows32(const u64* in, u64* out, size_t batch, int L, bool inverse, hipStream_t stream) {
-    const size_t per_tile = L == 1 ? 512 : 170;
-    const size_t max_grid = size_t(1) << 30;
-    for (size_t b0 = 0; b0 < batch; b0 += max_grid * per_tile) {
-        const size_t nb = std::min(batch - b0, max_grid * per_tile);
-        tfk::NttRows32Args a{};
-        a.in = in + b0 * 32 * L;
-        a.out = out + b0 * 32 * L;
-        a.total_transforms = (long long)nb;
-        a.scale = inverse ? gl::mont_inverse(gl::to_mont(32)) : 0;
-        a.L = L;
-        const unsigned grid = (unsigned)((nb + per_tile - 1) / per_tile);
-        int rc = inverse ? launch_rows32_t<true>(a, grid, stream) : launch_rows32_t<false>(a, grid, stream);
-        if (rc) return rc;
-    }
+// n <= 32: wave-private tiles (ntt_rows32w_kernel), a grid-stride walk of two workgroups per CU
+template <bool INV, int L, int LOGN>
+int launch_rows32w_t(const tfk::NttRows32Args& a, unsigned grid, hipStream_t stream) {
+    static std::atomic<unsigned long long> done_mask{0};
+    if (int rc_attr = ensure_dynamic_lds(reinterpret_cast<const void*>(&tfk::ntt_rows32w_kernel<INV, L, LOGN>), (int)(160 * 1024), done_mask)) return rc_attr;
+    hipLaunchKernelGGL((tfk::ntt_rows32w_kernel<INV, L, LOGN>), dim3(grid), dim3(256), size_t(4) * 64 * 33 * sizeof(u64), stream, a);
+    HIPCHK(hipGetLastError());
     return TF_OK;
+}
+template <bool INV, int L>
+int launch_rows32w_n(const tfk::NttRows32Args& a, unsigned grid, int log_n, hipStream_t stream) {
+    switch (log_n) {
+        case 1: return launch_rows32w_t<INV, L, 1>(a, grid, stream);
+        case 2: return launch_rows32w_t<INV, L, 2>(a, grid, stream);
+        case 3: return launch_rows32w_t<INV, L, 3>(a, grid, stream);
+        case 4: return launch_rows32w_t<INV, L, 4>(a, grid, stream);
+        default: return launch_rows32w_t<INV, L, 5>(a, grid, stream);
+    }
+}
+
+// batch contiguous transforms of n = 2^log_n <= 32 points
+int launch_rows32(const u64* in, u64* out, size_t batch, int L, int log_n, bool inverse, hipStream_t stream) {
+#ifdef TF_AB_BUILD
+    if (log_n == 5 && ab_env("TF_NTT_ROWS32_WG")) {  // round 2's workgroup-tile kernel (1.21 vs 0.87 ms per 2^28 words, profiles/r05_rows32_ab.txt)
+        const size_t per_tile = L == 1 ? 512 : 170;
+        const size_t max_grid = size_t(1) << 30;
+        for (size_t b0 = 0; b0 < batch; b0 += max_grid * per_tile) {
+            const size_t nb = std::min(batch - b0, max_grid * per_tile);
+            tfk::NttRows32Args a{};
+            a.in = in + b0 * 32 * L;
+            a.out = out + b0 * 32 * L;
+            a.total_transforms = (long long)nb;
+            a.scale = inverse ? gl::mont_inverse(gl::to_mont(32)) : 0;
+            a.L = L;
+            const unsigned grid = (unsigned)((nb + per_tile - 1) / per_tile);
+            int rc = inverse ? launch_rows32_t<true>(a, grid, stream) : launch_rows32_t<false>(a, grid, stream);
+            if (rc) return rc;
+        }
+        return TF_OK;
+    }
+#endif
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    tfk::NttRows32Args a{};
+    a.in = in;
+    a.out = out;
+    a.total_transforms = (long long)batch;
+    a.scale = inverse ? gl::mont_inverse(gl::to_mont(u64(1) << log_n)) : 0;
+    a.L = L;
+    const size_t words = (batch << log_n) * size_t(L), per_tile = L == 1 ? 2048 : 2016;  // words per wave and tile
+    const size_t tiles = (words + per_tile - 1) / per_tile, wgs = (tiles + 3) / 4;
+    const unsigned grid = (unsigned)std::min(wgs, size_t(cus) * 2);  // two workgroups are resident per CU (LDS); they walk the tiles
+    if (L == 1) return inverse ? launch_rows32w_n<true, 1>(a, grid, log_n, stream) : launch_rows32w_n<false, 1>(a, grid, log_n, stream);
+    return inverse ? launch_rows32w_n<true, 3>(a, grid, log_n, stream) : launch_rows32w_n<false, 3>(a, grid, log_n, stream);
 }
 
 // 2^11 <= n <= 2^14, contiguous BFieldElement transforms: whole transform per workgroup (ntt_block_kernel)
@@ -1254,6 +1294,12 @@ int run_ntt(DeviceCtx* ctx, const u64* in, u64* out, long long in_bs, long long 
     if (n == 0 || batch == 0) return TF_OK;
     const int log_n = ilog2(n);
     int rc;
+    // batches of short contiguous transforms: wave-private tiles, one coalesced round trip (a handful of them stay on the tiny kernel)
+    if (log_n >= 1 && log_n <= 5 && !pre_scale && !post_scale && n_coeffs < 0 && !in2 && n_out < 0 && in_bs == (long long)n * L &&
+        out_bs == (long long)n * L && (log_n == 5 || (batch << log_n) * size_t(L) >= 4096)) {
+        static const bool no_rows32 = ab_env("TF_NTT_NO_ROWS32") != nullptr;  // A/B switch
+        if (!no_rows32) return launch_rows32(in, out, batch, L, log_n, inverse, stream);
+    }
     if (log_n <= 4) {
         const u64* tw = nullptr;
         rc = get_tiny_table(ctx, log_n, inverse, &tw);
@@ -1275,10 +1321,6 @@ int run_ntt(DeviceCtx* ctx, const u64* in, u64* out, long long in_bs, long long 
         hipLaunchKernelGGL(tfk::ntt_tiny_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, A);
         HIPCHK(hipGetLastError());
         return TF_OK;
-    }
-    if (log_n == 5 && L == 1 && !pre_scale && !post_scale && n_coeffs < 0 && !in2 && in_bs == 32 && out_bs == 32) {  // XFE: 0.98 vs 0.90 ms, not used
-        static const bool no_rows32 = ab_env("TF_NTT_NO_ROWS32") != nullptr;  // A/B switch
-        if (!no_rows32) return launch_rows32(in, out, batch, L, inverse, stream);
     }
     // (the latency-shaped kernel also takes the coset scalings of fast_coset_evaluate / fast_coset_interpolate: a 2^10-point coset
     //  evaluation is one launch of 8-element threads, 8 us, instead of one 32-element-thread workgroup, 19 us)
