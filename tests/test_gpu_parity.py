@@ -114,12 +114,13 @@ def test_ntt_xfe_matches_oracle(tf, oracle, log_n, inverse):
     assert np.array_equal(got, want)
 
 
-@pytest.mark.parametrize("n", [2, 4, 8, 16, 32])
+@pytest.mark.parametrize("n", [2, 4, 8, 16, 32, 64])
 @pytest.mark.parametrize("width", [1, 3])
 def test_short_transforms_in_wave_private_tiles(tf, oracle, n, width):
     """Batches of transforms of at most 32 points (ntt_rows32w_kernel: a wave moves 64 rows of 32 elements -- 21 element rows of an
-    XFieldElement batch -- through its own LDS): batches that end inside a row, inside a tile, one past a tile, both directions; the
-    handful-of-transforms calls below 4096 words stay on ntt_tiny_kernel and are compared all the same."""
+    XFieldElement batch -- through its own LDS; 64-point BFieldElement transforms on lane pairs with one DIF stage across the pair):
+    batches that end inside a row, inside a tile, one past a tile, both directions; the handful-of-transforms calls below 4096 words
+    stay on ntt_tiny_kernel (64 points: the latency-shaped kernel; XFieldElement: the row pass) and are compared all the same."""
     for batch in (1, 3, 21, 22, 63, 64, 65, 127, 2048 // n, 2048 // n + 1, 4096 // n + 3, 1000, (1 << 16) + 5):
         for inverse in (False, True):
             x = oracle.fill_random(n * batch * width, 7000 + 13 * n + batch)

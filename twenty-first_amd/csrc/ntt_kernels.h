@@ -1296,7 +1296,7 @@ __global__ void __launch_bounds__(512, 4) ntt_rows32_kernel(const NttRows32Args 
 }
 #endif
 
-// ---- n <= 32, wave-private tiles ----------------------------------------------------------------------------------------------
+// ---- n <= 64, wave-private tiles ----------------------------------------------------------------------------------------------
 // A thread's 32 elements are contiguous in memory, so direct loads would be 8-byte pieces 256 bytes apart (1.94 ms per 2^28 words),
 // and a workgroup that moves its tile through LDS in barrier-separated phases (load | pick up rows | transform | put rows back |
 // store; round 2's ntt_rows32_kernel, kept in the laboratory build) leaves the memory pipe or the vector ALU idle in every phase:
@@ -1330,8 +1330,26 @@ __device__ __forceinline__ void rows32_network(u64 (&x)[32]) {
     }
 }
 
+// n = 64 (BFieldElement): two lanes per transform -- lane 2 t + h holds elements 32 h .. 32 h + 31 of transform t.  One DIF stage
+// across the lane pair (a quad_perm DPP exchange: a' = a + b in the even lane, b' = (a - b) w_64^i in the odd one), then each lane
+// runs the 32-point network on what it holds: the even lane comes out with X[2 k], the odd one with X[2 k + 1].
+template <bool INV, int Q = 0>
+__device__ __forceinline__ void rows64_dif_stage(u64 (&x)[32], bool odd) {
+    if constexpr (Q < 32) {
+        const u64 own = x[Q];
+        const u32 ol = (u32)__builtin_amdgcn_mov_dpp((int)(u32)own, 0xB1, 0xf, 0xf, true);          // quad_perm [1, 0, 3, 2]: lane ^ 1
+        const u32 oh = (u32)__builtin_amdgcn_mov_dpp((int)(u32)(own >> 32), 0xB1, 0xf, 0xf, true);
+        const u64 other = ((u64)oh << 32) | ol;
+        u64 sum, diff;
+        gl::add_sub(odd ? other : own, odd ? own : other, sum, diff);
+        x[Q] = odd ? gl::mul_pow2<TwExp<INV, 6, brev5(Q)>::value>(diff) : sum;  // slot Q holds element brev5(Q) of the lane's half
+        rows64_dif_stage<INV, Q + 1>(x, odd);
+    }
+}
+
 template <bool INV, int L, int LOGN>
 __global__ void __launch_bounds__(256, 2) ntt_rows32w_kernel(const NttRows32Args A) {
+    static_assert(LOGN <= 5 || (LOGN == 6 && L == 1), "n = 64: BFieldElement only");
     extern __shared__ __attribute__((aligned(16))) u64 lds[];
     constexpr int kRows = L == 1 ? 64 : 21, kWords = kRows * 32 * L;  // rows of 32 elements and words per tile (2048 / 2016)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1372,8 +1390,9 @@ __global__ void __launch_bounds__(256, 2) ntt_rows32w_kernel(const NttRows32Args
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
-        for (int q = 0; q < 32; ++q) x[q] = my[lane * 33 + rows32_src<LOGN>(q)];  // (lane 63 of an XFieldElement tile transforms a stale row nobody reads)
-        rows32_network<INV, LOGN>(x);
+        for (int q = 0; q < 32; ++q) x[q] = my[lane * 33 + rows32_src<LOGN < 5 ? LOGN : 5>(q)];  // (lane 63 of an XFieldElement tile transforms a stale row nobody reads)
+        if constexpr (LOGN == 6) rows64_dif_stage<INV>(x, (lane & 1) != 0);
+        rows32_network<INV, LOGN < 5 ? LOGN : 5>(x);
         if (INV) {
 #pragma unroll
             for (int q = 0; q < 32; q += 4) mul4_inplace(x, q, A.scale, A.scale, A.scale, A.scale);
@@ -1381,7 +1400,10 @@ __global__ void __launch_bounds__(256, 2) ntt_rows32w_kernel(const NttRows32Args
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int q = 0; q < 32; ++q) my[lane * 33 + q] = x[q];
+        for (int q = 0; q < 32; ++q) {
+            if constexpr (LOGN == 6) my[((lane & ~1) + (q >> 4)) * 33 + 2 * (q & 15) + (lane & 1)] = x[q];  // X[2 q + h] of transform lane / 2
+            else my[lane * 33 + q] = x[q];
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");

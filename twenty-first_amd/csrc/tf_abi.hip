@@ -274,7 +274,7 @@ int tf_ntt_launch_count(size_t n, size_t batch, int width) {
     if (check_len(n) || n <= 1 || batch == 0 || (width != 1 && width != 3)) return 0;
     const int log_n = ilog2(n);
     read_env();
-    if (log_n <= 5) return 1;                                                                              // ntt_rows32w_kernel (a grid-stride walk) / ntt_tiny_kernel
+    if (log_n <= 5 || (log_n == 6 && width == 1 && batch >= 64)) return 1;                                 // ntt_rows32w_kernel (a grid-stride walk) / ntt_tiny_kernel
     if (g_min_passes.load(std::memory_order_relaxed) == 0) {
         if (lat_wanted(log_n, batch, width)) return (int)((batch + (size_t(1) << 22) - 1) >> 22);          // ntt_lat_kernel
         if (lat2_wanted(log_n, batch, width)) return 2;                                                    // ntt_lat2_kernel: column pass + last pass

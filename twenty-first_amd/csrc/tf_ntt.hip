@@ -1065,11 +1065,14 @@ int launch_rows32w_n(const tfk::NttRows32Args& a, unsigned grid, int log_n, hipS
         case 2: return launch_rows32w_t<INV, L, 2>(a, grid, stream);
         case 3: return launch_rows32w_t<INV, L, 3>(a, grid, stream);
         case 4: return launch_rows32w_t<INV, L, 4>(a, grid, stream);
+        case 6:
+            if constexpr (L == 1) return launch_rows32w_t<INV, 1, 6>(a, grid, stream);
+            return TF_ERR_NULL_POINTER;  // (not reached: run_ntt sends XFieldElement transforms of 64 points to the row pass)
         default: return launch_rows32w_t<INV, L, 5>(a, grid, stream);
     }
 }
 
-// batch contiguous transforms of n = 2^log_n <= 32 points
+// batch contiguous transforms of n = 2^log_n <= 32 points (BFieldElement: <= 64)
 int launch_rows32(const u64* in, u64* out, size_t batch, int L, int log_n, bool inverse, hipStream_t stream) {
 #ifdef TF_AB_BUILD
     if (log_n == 5 && ab_env("TF_NTT_ROWS32_WG")) {  // round 2's workgroup-tile kernel (1.21 vs 0.87 ms per 2^28 words, profiles/r05_rows32_ab.txt)
@@ -1295,8 +1298,8 @@ int run_ntt(DeviceCtx* ctx, const u64* in, u64* out, long long in_bs, long long 
     const int log_n = ilog2(n);
     int rc;
     // batches of short contiguous transforms: wave-private tiles, one coalesced round trip (a handful of them stay on the tiny kernel)
-    if (log_n >= 1 && log_n <= 5 && !pre_scale && !post_scale && n_coeffs < 0 && !in2 && n_out < 0 && in_bs == (long long)n * L &&
-        out_bs == (long long)n * L && (log_n == 5 || (batch << log_n) * size_t(L) >= 4096)) {
+    if (log_n >= 1 && (log_n <= 5 || (log_n == 6 && L == 1)) && !pre_scale && !post_scale && n_coeffs < 0 && !in2 && n_out < 0 &&
+        in_bs == (long long)n * L && out_bs == (long long)n * L && (log_n == 5 || (batch << log_n) * size_t(L) >= 4096)) {
         static const bool no_rows32 = ab_env("TF_NTT_NO_ROWS32") != nullptr;  // A/B switch
         if (!no_rows32) return launch_rows32(in, out, batch, L, log_n, inverse, stream);
     }
