@@ -423,41 +423,64 @@ template <int NS>
 __global__ void __launch_bounds__(256) tip5_hash_pairs_mx_kernel(const u64* in, u64* out, u64* leaf_copy, long long count,
                                                                  long long per_tree, int shift, long long in_ts, long long out_ts,
                                                                  long long copy_ts) {
-    TF_MX_PROLOGUE();
-    TF_MX_GROUPS(count) {
-    u64 s[4 * NS];
+    // The input of a wave's NEXT group is fetched before the current one is permuted, and the first group's before the tables are
+    // staged: a launch of one group per wave (a tree level of 2^14 .. 2^16 pairs) waits for memory once, not twice.
+    __shared__ __attribute__((aligned(32))) Tip5MxLds lds;
+    const int lane = threadIdx.x & 63, j = lane & 15, q = lane >> 4;
+    const long long first = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * (16 * NS), step = (long long)gridDim.x * (4 * 16 * NS);
+    u64 pre[3 * NS];
     long long tree[NS], k[NS];
     bool live[NS];
+    auto fetch = [&](long long base) {
 #pragma unroll
-    for (int n = 0; n < NS; ++n) {
-        const long long item = base + 16 * n + j;
-        live[n] = item < count;
-        split_item(live[n] ? item : count - 1, per_tree, shift, tree[n], k[n]);
-        const u64* p = in + tree[n] * in_ts + 10 * k[n];
-        s[4 * n] = p[q];
-        s[4 * n + 1] = p[4 + q];
-        s[4 * n + 2] = q < 2 ? p[8 + q] : gl::ONE;  // words 10..15 = 1: Tip5::new(Domain::FixedLength), mod.rs:511-526
-        s[4 * n + 3] = gl::ONE;
-        if (leaf_copy && live[n]) {  // Merkle leaf level, merkle_tree.rs:426
-            u64* c = leaf_copy + tree[n] * copy_ts + 10 * k[n];
-            c[q] = s[4 * n];
-            c[4 + q] = s[4 * n + 1];
-            if (q < 2) c[8 + q] = s[4 * n + 2];
+        for (int n = 0; n < NS; ++n) {
+            const long long item = base + 16 * n + j;
+            live[n] = item < count;
+            split_item(live[n] ? item : count - 1, per_tree, shift, tree[n], k[n]);
+            const u64* p = in + tree[n] * in_ts + 10 * k[n];
+            pre[3 * n] = p[q];
+            pre[3 * n + 1] = p[4 + q];
+            pre[3 * n + 2] = q < 2 ? p[8 + q] : gl::ONE;  // words 10..15 = 1: Tip5::new(Domain::FixedLength), mod.rs:511-526
         }
-    }
-    tip5_permutation_mx_fixed<NS>(s, &lds, a, q);
+    };
+    if (first < count) fetch(first);
+    stage_mx(&lds);
+    double a[4];
+    mx_a_operands(&lds, a);
+    for (long long base = first; base < count; base += step) {
+        u64 s[4 * NS];
+        long long otree[NS], ok[NS];
+        bool olive[NS];
 #pragma unroll
-    for (int n = 0; n < NS; ++n)
-        if (live[n]) {
-            u64* o = out + tree[n] * out_ts + 5 * k[n];
-            o[q] = s[4 * n];
-            if (q == 0) o[4] = s[4 * n + 1];
+        for (int n = 0; n < NS; ++n) {
+            s[4 * n] = pre[3 * n];
+            s[4 * n + 1] = pre[3 * n + 1];
+            s[4 * n + 2] = pre[3 * n + 2];
+            s[4 * n + 3] = gl::ONE;
+            otree[n] = tree[n], ok[n] = k[n], olive[n] = live[n];
+            if (leaf_copy && live[n]) {  // Merkle leaf level, merkle_tree.rs:426
+                u64* c = leaf_copy + tree[n] * copy_ts + 10 * k[n];
+                c[q] = s[4 * n];
+                c[4 + q] = s[4 * n + 1];
+                if (q < 2) c[8 + q] = s[4 * n + 2];
+            }
         }
+        if (base + step < count) fetch(base + step);
+        tip5_permutation_mx_fixed<NS>(s, &lds, a, q);
+#pragma unroll
+        for (int n = 0; n < NS; ++n)
+            if (olive[n]) {
+                u64* o = out + otree[n] * out_ts + 5 * ok[n];
+                o[q] = s[4 * n];
+                if (q == 0) o[4] = s[4 * n + 1];
+            }
     }
 }
 
 // The sponge of hash_varlen (mod.rs:617-623, overwrite-mode absorb :684-691, padding sponge.rs:41-55) over a row whose word w is
 // WORD(w); shared by the row-major and the column-major kernels below.  Rate word w = 4 i + q < 10 lives in register i of quarter q.
+// (Fetching the NEXT chunk before the current permutation was measured as a loss here: 16-25 more registers, one wave per SIMD fewer,
+// -1.3 % on 2^21 rows of 128 columns -- profiles/r05_mx_prefetch_ab.txt.  The launches are large; other waves hide the latency.)
 #define TF_MX_SPONGE(ROW_LEN, WORD)                                                                                     \
     u64 s[4 * NS];                                                                                                      \
     _Pragma("unroll") for (int t = 0; t < 4 * NS; ++t) s[t] = 0; /* Domain::VariableLength */                           \
