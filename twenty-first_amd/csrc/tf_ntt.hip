@@ -1093,8 +1093,11 @@ int launch_rows32(const u64* in, u64* out, size_t batch, int L, int log_n, bool 
         return TF_OK;
     }
 #endif
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    static const int cus = [] {  // (the devices of a node are alike)
+        int dev = 0, n = 256;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) (void)hipGetLastError();
+        return n > 0 ? n : 256;
+    }();
     tfk::NttRows32Args a{};
     a.in = in;
     a.out = out;
