@@ -29,7 +29,8 @@ run "TF_COSET_EVAL_NO_SPLIT=1" "blown-up coset evaluation by zero padding instea
 run "TF_POLY_MUL_NO_FUSE=1" "fast_multiply with separate pad / Hadamard / truncate passes"
 run "TF_NTT_NO_BLOCK=1" "two-pass plans instead of the whole-transform-per-workgroup kernel, 2^11..2^14"
 run "TF_NTT_NO_XFE_BLOCK=1" "XFE slices of 2^11 / 2^12 points through two-pass plans instead of the block kernel's limb transforms"
-run "TF_NTT_NO_ROWS32=1" "direct loads instead of LDS-staged rows for 32-point BFE transforms"
+run "TF_NTT_NO_ROWS32=1" "ntt_tiny_kernel / the row pass instead of the wave-private tile kernel for transforms of at most 64 points"
+run "TF_NTT_ROWS32_WG=1" "round 2's workgroup-tile kernel for batches of 32-point transforms (round 5: laboratory only)"
 run "TF_NTT_NO_WORDS16=1" "XFE rows through the last passes as tiles of whole elements, not whole cache lines"
 run "TF_NTT_NO_COL_SHIFT=1" "last-pass tile boundaries not shifted to the output's cache-line alignment"
 run "TF_NTT_NO_SCALED_LAST1024=1" "generic last pass for fast_coset_interpolate instead of the R = 1024 kernel's scaled tail"
