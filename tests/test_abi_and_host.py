@@ -212,6 +212,10 @@ def test_planner_splits_are_valid_for_every_length(tf):
     # the headline transform: two passes of radix 1024; launches per call follow the plan
     assert lib.tf_ntt_plan(1 << 20, 1, radix) == 2 and list(radix)[:2] == [10, 10]
     assert lib.tf_ntt_launch_count(1 << 13, 1000, 1) == 1 and lib.tf_ntt_launch_count(1 << 13, 1000, 3) == 2
+    # batches of short transforms are ONE launch whatever the batch (a grid-stride walk of wave-private tiles, round 5)
+    for n in (2, 4, 8, 16, 32):
+        assert lib.tf_ntt_launch_count(n, 1 << 24, 1) == 1 and lib.tf_ntt_launch_count(n, 1 << 22, 3) == 1
+    assert lib.tf_ntt_launch_count(64, 1 << 22, 1) == 1
 
 
 def test_batch_evaluation_router_is_host_logic_with_the_measured_crossovers(tf):
