@@ -9,7 +9,7 @@ P = 0xFFFFFFFF00000001
 seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 budget = float(sys.argv[2]) if len(sys.argv) > 2 else 150.0
 rng = random.Random(seed)
-KINDS = ["ntt", "ntt", "coset", "coset", "interp", "mul", "merkle", "varlen", "eval", "extrap", "lde", "auth", "square", "mulb", "nttu", "interpu",
+KINDS = ["short", "ntt", "ntt", "coset", "coset", "interp", "mul", "merkle", "varlen", "eval", "extrap", "lde", "auth", "square", "mulb", "nttu", "interpu",
          "zerofier", "lagrange", "treeeval", "cdiv", "xoff", "trace", "handle", "bary"]
 if len(sys.argv) > 3:
     KINDS = sys.argv[3].split(",")
@@ -30,6 +30,14 @@ while time.time() < t_end:
         x = oracle.fill_random(n * width * batch, rng.getrandbits(40))
         got = x.copy(); tf.ntt(got, width=width, batch=batch, _inverse=inverse)
         assert np.array_equal(got, oracle.ntt(x, width=width, inverse=inverse, batch=batch, threads=16)), (kind, log_n, width, batch, inverse)
+    elif kind == "short":  # batches of short transforms: the wave-private tile kernel (n <= 32, BFieldElement <= 64), ragged ends
+        n = 1 << rng.randint(1, 6)
+        batch = rng.choice([rng.randint(1, 300), rng.randint(300, 70000), (2048 // n) * rng.randint(1, 40) + rng.randint(-1, 1)])
+        batch = max(1, batch)
+        inverse = rng.random() < 0.5
+        x = oracle.fill_random(n * width * batch, rng.getrandbits(40))
+        got = x.copy(); tf.ntt(got, width=width, batch=batch, _inverse=inverse)
+        assert np.array_equal(got, oracle.ntt(x, width=width, inverse=inverse, batch=batch, threads=16)), (kind, n, width, batch, inverse)
     elif kind == "coset":
         log_order = rng.randint(0, 22)
         order = 1 << log_order
