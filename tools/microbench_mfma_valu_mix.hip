@@ -11,8 +11,9 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef float f16v __attribute__((ext_vector_type(16)));
 typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+typedef int i4v __attribute__((ext_vector_type(4)));
 typedef uint64_t u64; typedef uint32_t u32;
-// mode bit0: MFMA waves work, bit1: VALU waves work.  KIND 0 = f64 mfma, 1 = f32 16x16x4 mfma, 2 = bf16 32x32x16 mfma
+// mode bit0: MFMA waves work, bit1: VALU waves work.  KIND 0 = f64 mfma, 1 = f32 16x16x4 mfma, 2 = bf16 32x32x16 mfma, 3 = i8 16x16x64 mfma
 // VK: 0 v_mad_u64_u32, 1 v_addc_co_u32, 2 v_and_b32
 template <int KIND, int VK>
 __global__ void __launch_bounds__(256) mix(double* out, int it_m, int it_v, int mode) {
@@ -29,6 +30,15 @@ __global__ void __launch_bounds__(256) mix(double* out, int it_m, int it_v, int 
                     for (int r = 0; r < 8; ++r) { acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[0], 0, 0, 0); acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[1], 0, 0, 0); }
                 }
                 res = acc[0][0] + acc[1][1];
+            } else if (KIND == 3) {
+                i4v acc[2] = {i4v{0,0,0,0}, i4v{0,0,0,0}};
+                const i4v a = {(int)threadIdx.x * 0x01010101, 0x01020304, 0x7f007f00, 0x11111111}, b = {0x01010101, 0x02020202, 0x03030303, 0x04040404};
+#pragma unroll 1
+                for (int it = 0; it < it_m; ++it) {
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) { acc[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, acc[0], 0, 0, 0); acc[1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, acc[1], 0, 0, 0); }
+                }
+                res = (double)(acc[0][0] + acc[1][1]);
             } else if (KIND == 2) {
                 f16v acc[2];
 #pragma unroll
@@ -92,7 +102,7 @@ void run(double* d, int cus, int blocks_per_cu, int it_m, int it_v) {
         }
     }
     const char* vn[3] = {"v_mad_u64_u32", "v_addc_co_u32", "v_and_b32"};
-    const char* mn[3] = {"f64 16x16x4", "f32 16x16x4", "bf16 32x32x16"};
+    const char* mn[4] = {"f64 16x16x4", "f32 16x16x4", "bf16 32x32x16", "i8 16x16x64"};
     printf("%-13s mfma + %-13s, %d blocks/CU (%d mfma waves + %d valu waves per SIMD): mfma only %7.3f ms, valu only %7.3f ms, both %7.3f ms  (sum %7.3f, max %7.3f)\n",
            mn[KIND], vn[VK], blocks_per_cu, blocks_per_cu / 2, blocks_per_cu / 2, ms[1], ms[2], ms[3], ms[1] + ms[2], ms[1] > ms[2] ? ms[1] : ms[2]);
 }
@@ -107,5 +117,7 @@ int main() {
     for (int b : {2, 8}) run<1, 0>(d, cus, b, 4000, 2000 * 7);
     for (int b : {2, 8}) run<2, 0>(d, cus, b, 4000, 2000 * 7);
     for (int b : {2, 8}) run<2, 1>(d, cus, b, 4000, 2000 * 7);
+    for (int b : {2, 8}) run<3, 0>(d, cus, b, 8000, 2000 * 7);
+    for (int b : {2, 8}) run<3, 1>(d, cus, b, 8000, 2000 * 7);
     return 0;
 }
