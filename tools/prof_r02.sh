@@ -13,7 +13,7 @@ OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 export TF_PROF_IDENTITY=$OUT/library.json   # tools/prof_target.py writes the library's tf_version + source hash here
-CMD="python $REPO/tools/prof_target.py $*"
+CMD=${TF_PROF_CMD:-"python $REPO/tools/prof_target.py $*"}   # TF_PROF_CMD: another target (tools/small_n_target.py)
 timeout -k 5 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o t -- $CMD > "$OUT/stats.log" 2>&1
 timeout -k 5 400 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --output-format csv -d "$OUT/pmc_sq" -o t -- $CMD > "$OUT/pmc_sq.log" 2>&1
 timeout -k 5 400 rocprofv3 --kernel-trace --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INST_LEVEL_VMEM --output-format csv -d "$OUT/pmc_sq2" -o t -- $CMD > "$OUT/pmc_sq2.log" 2>&1
