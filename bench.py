@@ -357,8 +357,65 @@ def main():
         dist.destroy_process_group()
     sys.stdout.flush()
     if rank == 0:
+        out["summary"] = summary_block(out)  # LAST key: the driver keeps the tail of the line
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     os.close(json_fd)
+
+
+SUMMARY_LEGS = ("headline", "merkle", "coset_eval", "config5", "commit_pipeline")
+
+
+def _short_parity(p):
+    if not isinstance(p, str):
+        return None
+    if p.startswith("MISMATCH"):
+        return "MISMATCH"
+    if p.startswith("not checked"):
+        return "not checked"
+    return "green: " + p[:70]
+
+
+def summary_block(out):
+    """Every leg's number in <= 1.5 KB, emitted as the LAST key of the line: value / unit, ms_per_step, roofline.frac, cpu_baseline.value +
+    cores, parity.  (The driver's record keeps only the tail of a long line; round 5's lost `merkle.value` that way.)"""
+    def leg(d):
+        if not isinstance(d, dict):
+            return None
+        if "error" in d:
+            return {"error": str(d["error"])[:80]}
+        cb = d.get("cpu_baseline") or {}
+        rf = d.get("roofline") or {}
+        r = {"value": d.get("value"), "unit": d.get("unit"), "ms": d.get("ms_per_step"), "frac": rf.get("frac"), "bound": rf.get("bound"),
+             "cpu": cb.get("value"), "cores": cb.get("cores"), "parity": _short_parity(d.get("parity"))}
+        return {k: v for k, v in r.items() if v is not None}
+    sm = {"headline": leg(out)}
+    for k in SUMMARY_LEGS[1:]:
+        if k in out:
+            sm[k] = leg(out[k])
+    c5 = out.get("config5")
+    if isinstance(c5, dict) and isinstance(c5.get("merkle"), dict):
+        sm["config5"]["trees_leaves_per_s"] = c5["merkle"].get("value")
+    cp = out.get("commit_pipeline")
+    if isinstance(cp, dict) and "error" not in cp:
+        for part in ("lde", "rows_and_tree"):
+            if isinstance(cp.get(part), dict):
+                sm["commit_pipeline"][part + "_ms"] = cp[part].get("ms")
+                sm["commit_pipeline"][part + "_frac"] = (cp[part].get("roofline") or {}).get("frac")
+    sm["n_gpus"] = out.get("n_gpus")
+    sm["library"] = (out.get("roofline") or {}).get("profile_matches_library", {}).get("library", {}).get("source_hash")
+    return sm
+
+
+def parse_summary_from_tail(text):
+    """The `summary` object out of the (possibly truncated) tail of a bench line: what a reader of the driver's record does."""
+    key = '"summary": '
+    at = text.rfind(key)
+    if at < 0:
+        return None
+    body = text[at + len(key):].strip()
+    if body.endswith("}"):
+        body = body[:-1]  # the closing brace of the whole record
+    return json.loads(body)
 
 
 # ------------------------------------------------------------------------------------------------ headline: configs[1]
@@ -424,22 +481,30 @@ def ntt_headline(ctx):
     t1 = time.perf_counter()
     elapsed = t1 - t0
     ev_ms = ev0.elapsed_time(ev1)
-    # per-step spread, measured AFTER the timed region (an event per step costs ~2 % when it sits inside it)
-    evs = [torch.cuda.Event(enable_timing=True) for _ in range(11)]
+    # "median of >= 10 runs".  A SECOND pass of the same K steps, an event after every step (an event per step costs
+    # ~2 % when it sits inside the timed region, so the single interval above stays free of them): `value` is priced on the median of
+    # these K per-step intervals (max over ranks), the single-interval mean of the first pass is reported beside it.
+    k2 = max(args.steps, 10)
+    barrier()
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(k2 + 1)]
     evs[0].record()
-    for i in range(10):
+    for i in range(k2):
         tf.device.ntt_(x, n, batch=batch)
         evs[i + 1].record()
     torch.cuda.synchronize()
-    step_ms = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(10))
+    step_ms = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(k2))
+    median_ms = 0.5 * (step_ms[(k2 - 1) // 2] + step_ms[k2 // 2])
     sclk_after = tf.lib().tf_debug_sclk_mhz()
     copy_after = copy_gbs()
     barrier()
     elapsed = ctx["max_over_ranks"](elapsed)
+    median_ms = ctx["max_over_ranks"](median_ms * 1e-3) * 1e3
 
     total_elems = world * batch * n * args.steps
-    value = total_elems / elapsed / 1e9
-    ms_per_step = elapsed / args.steps * 1e3
+    mean_value = total_elems / elapsed / 1e9
+    mean_ms_per_step = elapsed / args.steps * 1e3
+    value = world * batch * n / (median_ms * 1e-3) / 1e9
+    ms_per_step = median_ms
 
     # roofline of the dominant kernel (this rank)
     launches = launches_per_step * args.steps
@@ -516,8 +581,10 @@ def ntt_headline(ctx):
             "inputs": f"SplitMix64, seed 0x{SEED_C2:X} (SURVEY.md 8(d)), generated on the device",
         },
         "roofline": roofline,
-        "step_ms_after": {"min": round(step_ms[0], 4), "median": round(step_ms[len(step_ms) // 2], 4), "max": round(step_ms[-1], 4),
-                          "note": "10 extra steps with an event each, after the timed region"},
+        "timing": {"value_from": f"median of {k2} per-step event intervals (second pass of the same steps), max over ranks",
+                   "per_step_ms": {"min": round(step_ms[0], 4), "median": round(median_ms, 4), "max": round(step_ms[-1], 4), "n": k2},
+                   "single_interval": {"ms_per_step": round(mean_ms_per_step, 4), "value": round(mean_value, 3),
+                                       "note": f"the contract's region: {args.steps} steps between two barriers + synchronisations, wall clock, max over ranks"}},
         "settle_steps": settle,
         "sclk_mhz": {"before_settle": round(sclk_before, 0), "after_timed_region": round(sclk_after, 0),
                      "note": "one-wave idle probe; the clock under load is in roofline.valu_bound (from GRBM_GUI_ACTIVE)"},

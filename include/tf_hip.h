@@ -399,7 +399,10 @@ void tf_set_ntt_small_launch(int mode);
  * input) instead of three; -1 = automatic (default), 0 = never (the three-pass plan, which also serves the shapes the
  * two-pass plan does not: small launches, truncated products), 1 = the 2048-point pairs whenever the shape supports them.
  * (2: laboratory build only -- every FORWARD 2^22-point transform on the 1024 x 4096 plan whose last pass runs as four 1024-point
- * classes per tile, a measured loss, profiles/r04_c4_plan_ab.txt; the product library treats 2 as 1.) */
+ * classes per tile, a measured loss, profiles/r04_c4_plan_ab.txt; the product library treats 2 as 1.)
+ * 3 = the two-pass plan with its FIRST pass as one workgroup per 2048-row x 8-column tile (every element loaded and scaled once,
+ * DESIGN 4.1b, round 6) wherever the two-pass plan applies; the automatic plan takes that kernel for coset evaluations of 2^22 points,
+ * where it measured faster (profiles/r06_c4_cols8_ab.txt). */
 void tf_set_ntt_two_pass(int mode);
 /* The latency-shaped kernels (8 elements per thread, radix-8 stages through LDS) instead of the 32-elements-per-thread
  * pass kernels: ntt_lat_kernel for 64 .. 4096-point transforms in calls of up to 2^22 words (BFieldElement; 3 * 2^19 words

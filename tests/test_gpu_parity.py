@@ -424,8 +424,9 @@ def test_deeper_pass_plans_match_oracle(tf, oracle, passes, log_n, width, batch)
 @pytest.mark.parametrize("log_n,width,batch", [(21, 1, 2), (21, 3, 1), (22, 1, 1), (22, 3, 2)])
 def test_two_pass_plan_for_2p21_2p22_matches_oracle(tf, oracle, log_n, width, batch):
     """2^21 / 2^22 points in two global passes (a 2048-point pass = pairs of 1024-point workgroups that share their input,
-    DESIGN 4.1; tf_set_ntt_two_pass): forward, inverse, coset evaluation (full and zero-padded coefficient lists) and
-    interpolation against the oracle's radix-2 sweeps (math/ntt.rs:153-228, polynomial.rs:1374-1399, :1907-1918), and word
+    DESIGN 4.1b, tf_set_ntt_two_pass(1) -- or, mode 3, its first pass as ONE workgroup per 2048-row x 8-column tile that loads and
+    scales every element once, ntt_col2048_kernel): forward, inverse, coset evaluation (full and zero-padded coefficient lists)
+    and interpolation against the oracle's radix-2 sweeps (math/ntt.rs:153-228, polynomial.rs:1374-1399, :1907-1918), and word
     for word against the three-pass plan."""
     import ctypes as C
     n = 1 << log_n
@@ -434,10 +435,12 @@ def test_two_pass_plan_for_2p21_2p22_matches_oracle(tf, oracle, log_n, width, ba
     radix = (C.c_int * 4)()
     got = {}
     try:
-        for mode in (1, 0):
+        for mode in (3, 1, 0):
             lib.tf_set_ntt_two_pass(mode)
             passes = lib.tf_ntt_plan(n, width, radix)  # (an A/B switch in the environment may rule the two-pass plan out: then three)
             assert passes == 3 if mode == 0 else passes in (2, 3)
+            if mode == 3 and passes == 2:
+                assert list(radix)[:2] == [11, log_n - 11]
             y = x.copy()
             tf.ntt(y, width=width, batch=batch)
             fwd = y.copy()
@@ -452,8 +455,9 @@ def test_two_pass_plan_for_2p21_2p22_matches_oracle(tf, oracle, log_n, width, ba
             got[mode] = (fwd, ev_full, ev_pad, ev_short, ci)
     finally:
         lib.tf_set_ntt_two_pass(-1)
-    for a, b in zip(got[0], got[1]):
+    for a, b, c8 in zip(got[0], got[1], got[3]):
         assert np.array_equal(a, b)
+        assert np.array_equal(a, c8)
     fwd, ev_full, ev_pad, ev_short, ci = got[1]
     assert np.array_equal(fwd, oracle.ntt(x, width=width, batch=batch, threads=8))
     off = oracle.bfe_new(7)

@@ -11,7 +11,7 @@ import statistics
 import sys
 
 out = sys.argv[1]
-WANT = ("ntt_pass_kernel", "ntt_block_kernel", "tip5_", "merkle_", "fill_random")
+WANT = ("ntt_pass_kernel", "ntt_col2048_kernel", "ntt_block_kernel", "ntt_lat", "tip5_", "merkle_", "fill_random")
 
 
 def short(name):

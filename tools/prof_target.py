@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--coset", type=int, default=2)
     ap.add_argument("--tile-mib", type=int, default=0)
     ap.add_argument("--pipe", type=int, default=0)
+    ap.add_argument("--two-pass", type=int, default=-1, help="tf_set_ntt_two_pass mode for the coset leg (3: one-workgroup 2048 x 8 first pass)")
     a = ap.parse_args()
     import torch
 
@@ -28,6 +29,8 @@ def main():
         tf.lib().tf_set_ntt_tile_bytes(a.tile_mib << 20)
     if a.pipe:
         tf.lib().tf_set_ntt_pipe(a.pipe)
+    if a.two_pass >= 0:
+        tf.lib().tf_set_ntt_two_pass(a.two_pass)
     dev = torch.device("cuda", 0)
     ident_path = os.environ.get("TF_PROF_IDENTITY")  # tools/prof_r02.sh: which library these counters belong to
     if ident_path:

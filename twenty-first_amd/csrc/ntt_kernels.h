@@ -337,7 +337,13 @@ __global__ void __launch_bounds__(512, TF_NTT_WAVES) ntt_pass_kernel(const NttPa
         const u32 ngrp = A.d2 / (8u * G);
         const u32 grp = A.xcd_colfast ? slot % ngrp : slot / (G * A.d01);
         const u32 within = A.xcd_colfast ? slot / ngrp : slot % (G * A.d01);
-        i2 = ((grp << 3) | xcd) * G + within % G;
+#ifndef TF_XCD_SKEW
+#define TF_XCD_SKEW 0  // experiment (tools/build_variant.sh): XCD x takes column tile (x + SKEW * grp) mod 8 of column group grp
+#endif
+#ifndef TF_NAT_SKEW
+#define TF_NAT_SKEW 0  // experiment: the natural order with the column tile rotated by SKEW * (outer index) within its group of 8
+#endif
+        i2 = ((grp << 3) | (TF_XCD_SKEW ? ((xcd + grp * TF_XCD_SKEW) & 7u) : xcd)) * G + within % G;
         const u32 rest = within / G;
         i1 = rest % A.d1;
         i0 = rest / A.d1;
@@ -347,6 +353,7 @@ __global__ void __launch_bounds__(512, TF_NTT_WAVES) ntt_pass_kernel(const NttPa
         const u32 rest = tile / A.d2;
         i1 = rest % A.d1;
         i0 = rest / A.d1;
+        if (TF_NAT_SKEW && (A.d2 & 7u) == 0) i2 = (i2 & ~7u) | ((i2 + (i2 >> 3) * TF_NAT_SKEW + rest * TF_NAT_SKEW) & 7u);
     }
     const u64* in = A.in + (long long)i0 * A.ib0 + (long long)i1 * A.ib1 + (long long)i2 * A.ib2;
     u64* out = A.out + (long long)i0 * A.ob0 + (long long)i1 * A.ob1 + (long long)i2 * A.ob2;
@@ -1024,6 +1031,306 @@ __global__ void __launch_bounds__(512, TF_NTT_WAVES) ntt_col1024_chain_kernel(co
 
 #endif  // TF_AB_BUILD
 
+// ---- a 2048-point COLUMN pass in ONE workgroup: 2048 rows x 8 word-columns (round 6, the first pass of the 2^21 / 2^22 plans) ----
+// PRE2 runs a 2048-point pass as two 1024-point workgroups that both load (and, in a coset evaluation, both SCALE) the tile's
+// 32 Ki elements.  Here the tile is 2048 rows x 8 word-columns = the same 16 Ki elements a 1024 x 16 tile holds, every element is
+// loaded and scaled ONCE, and the extra radix-2 stage sits where the data crosses threads anyway -- on the reading side of the LDS
+// exchange:
+//   r = g + 64 i (g < 64, i < 32),  k = k1 + 32 k2 (k1 < 32, k2 < 64):   w_2048^(r k) = w_32^(i k1) * w_2048^(g k1) * w_64^(g k2)
+//   step 1   thread (g, c): radix 32 over i in registers (shift-only network), times the inner twiddle w_2048^(g k1).  The [64][32]
+//            table does not fit the LDS BESIDE the exchange buffer with two workgroups per CU, so it is staged INSIDE it: the table is
+//            dead once the products are taken, one barrier separates them from the first exchange write.
+//   exchange two rounds of 4 columns: element (k1, g, cc) at k1 * 260 + 4 g + cc.
+//   step 2   thread (h, k1, c), h = the wave-uniform top thread bit: the 64-point DFT over g with ONE decimation-in-frequency
+//            stage fused into the LDS reads -- a_g' = Y[g'] + Y[g' + 32] (h = 0: outputs k2 = 2 k2'),  (Y[g'] - Y[g' + 32]) w_64^g'
+//            (h = 1: k2 = 2 k2' + 1) -- exactly the combination pre2_combine8 / pre2_shift make from global loads; both halves read
+//            all 64 words (LDS traffic, not HBM / L2 traffic) and each does half of the butterfly, so no arithmetic is duplicated.
+//            Then radix 32 over g' (shift-only), the inter-pass twiddle, and stores to rows k1 + 32 h + 64 k2'.
+// Global segments are 64 bytes (8 word-columns): the planner's xcd_order = 2 dispatches the two tiles that share every 128-byte line
+// back to back on one XCD.  Same words as every other plan (tests: tf_set_ntt_two_pass(3)).
+#ifndef TF_C8_LOAD_AUX
+#define TF_C8_LOAD_AUX 0  // default cache policy: the neighbouring tile's read of the other half of every 128-byte line should find it in the L2
+#endif
+#ifndef TF_C8_STORE_AUX
+#define TF_C8_STORE_AUX TF_AUX_COL_STORE
+#endif
+#ifndef TF_C8_ABLATE
+#define TF_C8_ABLATE 0  // measurement builds only (tools/build_variant.sh): 1 no scale-table loads, 2 no inter-pass table loads, 4 no arithmetic networks
+#endif
+constexpr int kC8Nc = 8, kC8Cpr = 4, kC8Rounds = 2, kC8S1 = 260;
+// A workgroup barrier that orders LDS traffic only.  __syncthreads() carries a workgroup-scope fence over every address space, i.e.
+// s_waitcnt vmcnt(0): every global load in flight is waited for at the barrier -- which is what made table words requested ahead of the
+// exchange a LOSS (8.6 ms against 7.7 on BASELINE configs[3] with sixteen words prefetched, profiles/r06_c4_cols8_ab.txt).
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+// The radix-2 stage on the words just read from the exchange buffer (canonical: Montgomery products), slots Q0 .. Q0+7: x = low word
+// (g'), w = high word (g' + 32).  Odd half: x -+ w with the sign of the slot's power-of-two twiddle folded in, as lazy differences (the
+// shift that follows takes any representative; slot 0 has no shift and is the first operand of a lazy butterfly).  Even half: the sums
+// feed level 1 of a lazy network -- its first operands (even slots) lazy, its second operands (odd slots) canonical.
+template <bool INV, int Q0>
+__device__ __forceinline__ void c8_combine8(u64 (&x)[32], const u64 (&w)[8], bool odd) {
+    if (odd) {
+#pragma unroll
+        for (int h = 0; h < 8; h += 4) {
+            const bool n0 = h ? Pre2Slot<INV, Q0 + 4>::neg : Pre2Slot<INV, Q0>::neg, n1 = h ? Pre2Slot<INV, Q0 + 5>::neg : Pre2Slot<INV, Q0 + 1>::neg;
+            const bool n2 = h ? Pre2Slot<INV, Q0 + 6>::neg : Pre2Slot<INV, Q0 + 2>::neg, n3 = h ? Pre2Slot<INV, Q0 + 7>::neg : Pre2Slot<INV, Q0 + 3>::neg;
+            const u64 a4[4] = {n0 ? w[h] : x[Q0 + h], n1 ? w[h + 1] : x[Q0 + h + 1], n2 ? w[h + 2] : x[Q0 + h + 2], n3 ? w[h + 3] : x[Q0 + h + 3]};
+            const u64 v4[4] = {n0 ? x[Q0 + h] : w[h], n1 ? x[Q0 + h + 1] : w[h + 1], n2 ? x[Q0 + h + 2] : w[h + 2], n3 ? x[Q0 + h + 3] : w[h + 3]};
+            u64 r4[4];
+            gl::sub_lazy4(a4, v4, r4);
+            x[Q0 + h] = r4[0], x[Q0 + h + 1] = r4[1], x[Q0 + h + 2] = r4[2], x[Q0 + h + 3] = r4[3];
+        }
+    } else {
+        const u64 a4[4] = {x[Q0], x[Q0 + 2], x[Q0 + 4], x[Q0 + 6]}, v4[4] = {w[0], w[2], w[4], w[6]};
+        u64 r4[4];
+        gl::add_lazy4(a4, v4, r4);
+        x[Q0] = r4[0], x[Q0 + 2] = r4[1], x[Q0 + 4] = r4[2], x[Q0 + 6] = r4[3];
+        x[Q0 + 1] = gl::add(x[Q0 + 1], w[1]), x[Q0 + 3] = gl::add(x[Q0 + 3], w[3]), x[Q0 + 5] = gl::add(x[Q0 + 5], w[5]), x[Q0 + 7] = gl::add(x[Q0 + 7], w[7]);
+    }
+}
+#ifndef TF_C8_LDS_BARRIER
+#define TF_C8_LDS_BARRIER 1
+#endif
+#if TF_C8_LDS_BARRIER
+#define TF_C8_BARRIER lds_barrier
+#else
+#define TF_C8_BARRIER __syncthreads
+#endif
+template <bool INV, int SCALE>
+__global__ void __launch_bounds__(512, TF_NTT_WAVES) ntt_col2048_kernel(const NttPassArgs A) {
+    extern __shared__ __attribute__((aligned(16))) u64 lds[];
+    static_assert(SCALE == 0 || (SCALE == 1 && !INV), "plain passes, or the scaling / zero-padding first pass of a coset evaluation");
+    const int t = threadIdx.x;
+    const int L = A.L;
+    const int c = t & 7, g = t >> 3;          // step 1: rows g + 64 i of word-column c
+    const int k1 = g & 31;                    // step 2: outputs k1 + 32 (2 k2' + half)
+    const u32 half = (u32)t >> 8;             // wave-uniform
+    u64* const ltw = lds;                     // the inner table [64][32], overlaid on the exchange buffer (dead before the first exchange write)
+    u32 i0, i1, i2;
+    {
+        const u32 bid = blockIdx.x;
+        if (A.xcd_order) {  // (see ntt_pass_kernel)
+            const u32 G = (u32)A.xcd_order, xcd = bid & 7u, slot = bid >> 3, ngrp = A.d2 / (8u * G);
+#ifndef TF_C8_XCD_SKEW
+#define TF_C8_XCD_SKEW 3  // XCD x takes column pair (x + 3 grp) mod 8 of column group grp instead of pair x of every group: its tiles then spread over
+                           // more of its L2's channels (measured 0.945-0.955 of the PRE2 time against 0.965-0.973 without, profiles/r06_c4_cols8_ab.txt)
+#endif
+#ifndef TF_C8_COLBLOCK
+#define TF_C8_COLBLOCK 1  // column groups an XCD walks interleaved (their inter-pass table slices share its L2); must divide ngrp
+#endif
+            u32 grp, within;
+            if (A.xcd_colfast) {
+                grp = slot % ngrp, within = slot / ngrp;
+            } else if (TF_C8_COLBLOCK > 1 && ngrp % TF_C8_COLBLOCK == 0) {
+                const u32 per = G * A.d01 * TF_C8_COLBLOCK, blk = slot / per, r = slot % per;
+                grp = blk * TF_C8_COLBLOCK + r % TF_C8_COLBLOCK, within = r / TF_C8_COLBLOCK;
+            } else {
+                grp = slot / (G * A.d01), within = slot % (G * A.d01);
+            }
+            i2 = ((grp << 3) | (TF_C8_XCD_SKEW ? ((xcd + grp * TF_C8_XCD_SKEW) & 7u) : xcd)) * G + within % G;
+            const u32 rest = within / G;
+            i1 = rest % A.d1;
+            i0 = rest / A.d1;
+        } else {
+            i2 = bid % A.d2;
+            const u32 rest = bid / A.d2;
+            i1 = rest % A.d1;
+            i0 = rest / A.d1;
+        }
+    }
+    const u64* in = A.in + (long long)i0 * A.ib0 + (long long)i1 * A.ib1 + (long long)i2 * A.ib2;
+    u64* out = A.out + (long long)i0 * A.ob0 + (long long)i1 * A.ob1 + (long long)i2 * A.ob2;
+    const int col0 = (int)i2 * kC8Nc;
+    const bool act = c < min(kC8Nc, A.col_limit - col0);
+    const int ch = (int)div_by_L((u32)c, L), cl = c - ch * L;
+    const long long bcol = (long long)div_by_L((u32)(col0 + c), L);
+    // Coset scaling (SCALE 1, polynomial.rs:760-773): coefficient j = (g + 64 i) B + b is multiplied by offset^j = offset^(64 B i) *
+    // offset^(B g) * offset^b.  The first factor is uniform per register slot (32 scalar loads of the power table), the second is
+    // constant over a thread's 32 inputs, commutes with the radix-32 network over i and is multiplied into the staged inner table
+    // (four products per thread), the third is constant along the whole column, commutes with the pass and comes with the inter-pass
+    // table (the planner passes T[k B + b] * offset^b).  No per-element vector load of the power table is left: in this kernel they
+    // were eight exposed L2 round trips per tile (measured: 0.57 ms of 7.95 on BASELINE configs[3], profiles/r06_c4_cols8_ab.txt).
+    // Rows at or beyond n_coeffs are zero (the data buffer's record count), so a clamped table index there changes nothing.
+    const u64* ps = nullptr;
+    if constexpr (SCALE == 1) ps = A.pre_scale ? A.pre_scale + (long long)i1 * A.ps_i1 : nullptr;
+    const auto ps_at = [&](long long j) { return ps[(A.n_coeffs < 0 || j < A.n_coeffs) ? j : 0]; };
+    // (uniform index: through the constant address space these are scalar loads -- s_load_dwordx2 -- not 64 lanes reading one word)
+    typedef const u64 __attribute__((address_space(4)))* cptr_t;
+    const cptr_t cps = (cptr_t)(unsigned long long)ps;
+    const auto ps_uniform = [&](long long j) { return cps[(A.n_coeffs < 0 || j < A.n_coeffs) ? j : 0]; };
+    // ---- the inner table's words (4 per thread) are requested first, the tile's data right behind them
+    u64 st[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) st[m] = A.inner_tw[t + 512 * m];
+    if constexpr (SCALE == 1) {
+        if (ps) {  // uniform
+            u64 sg[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) sg[m] = ps_at((long long)((t + 512 * m) >> 5) * A.ps_rs);
+            u64 r4[4];
+            gl::mont_mul4(st, sg, r4);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) st[m] = r4[m];
+        }
+    }
+    u64 x[32];
+#pragma unroll
+    for (int q = 0; q < 32; ++q) x[q] = 0;
+    // ------------------------------------------------------------------ load (+ scale) + step 1
+    __builtin_amdgcn_s_setprio(TF_PRIO_LOAD);
+    if (act) {
+        const u32 toff = (u32)(((long long)ch * A.in_cs_hi + cl + (long long)g * A.in_rs) * 8);
+        if constexpr (SCALE == 1) {
+            u32 nrec = 0xffffffffu;
+            if (A.n_coeffs >= 0) {  // rows beyond the coefficients read as zero: the buffer's record count does it
+                const long long rem = (A.n_coeffs * L - (long long)(in - (A.in + (long long)i0 * A.ib0))) * 8;
+                nrec = rem <= 0 ? 0u : (u32)min(rem, 0xffffffffll);
+            }
+            const __amdgpu_buffer_rsrc_t ri = buf_rsrc_n(in, nrec);
+            // (the range check of a raw buffer covers the per-lane offset only: the whole offset goes through the VGPR)
+#pragma unroll
+            for (int q = 0; q < 32; ++q) x[q] = buf_load<TF_C8_LOAD_AUX>(ri, toff + (u32)((long long)(brev5(q) << 6) * A.in_rs * 8), 0);
+        } else {
+            const __amdgpu_buffer_rsrc_t ri = buf_rsrc(in);
+#pragma unroll
+            for (int q = 0; q < 32; ++q) x[q] = buf_load<TF_C8_LOAD_AUX>(ri, toff, (u32)((long long)(brev5(q) << 6) * A.in_rs * 8));
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < 4; ++m) ltw[((t + 512 * m) >> 5) * kLdsTwStride + ((t + 512 * m) & 31)] = st[m];
+    if constexpr (SCALE == 1) {
+        if (ps) {  // uniform; slot q holds row g + 64 brev5(q): the uniform factor offset^(64 B brev5(q))
+#pragma unroll
+            for (int q0 = 0; q0 < 32; q0 += 4) {
+                const u64 u0 = ps_uniform((long long)(brev5(q0) << 6) * A.ps_rs), u1 = ps_uniform((long long)(brev5(q0 + 1) << 6) * A.ps_rs);
+                const u64 u2 = ps_uniform((long long)(brev5(q0 + 2) << 6) * A.ps_rs), u3 = ps_uniform((long long)(brev5(q0 + 3) << 6) * A.ps_rs);
+                mul4_inplace(x, q0, u0, u1, u2, u3);
+            }
+        }
+    }
+    __builtin_amdgcn_s_setprio(0);
+    if constexpr (!(TF_C8_ABLATE & 4)) {
+        dit_half<INV, 0, true>(x);
+        __builtin_amdgcn_sched_barrier(0);
+        dit_half<INV, 16, true>(x);
+        dit_level<INV, 5, true>(x);
+    }
+    TF_C8_BARRIER();  // the staged table is complete
+    {
+        const u64* tw = ltw + g * kLdsTwStride;
+#pragma unroll
+        for (int q = 0; q < 32; q += 4) mul4_inplace(x, q, tw[q], tw[q + 1], tw[q + 2], tw[q + 3]);
+    }
+    TF_C8_BARRIER();  // every wave has read its table rows: the exchange may overwrite them
+    // the inter-pass table's first words are requested before the exchange: they arrive under it and under step 2
+    const int krow = k1 + 32 * (int)half;  // slot q holds output row krow + 64 q
+    const u32 twoff = (u32)(((long long)krow * A.tw_rs + bcol) * 8);
+    const __amdgpu_buffer_rsrc_t rt = buf_rsrc(A.post_tw);
+    const auto tw_load = [&](int q) { return (TF_C8_ABLATE & 2) ? (u64)(q + 5) : buf_load_tab(rt, twoff, (u32)((long long)(q << 6) * A.tw_rs * 8)); };
+#ifndef TF_C8_PREFETCH
+#define TF_C8_PREFETCH 0  // inter-pass table words requested ahead of step 2 (0 / 8 / 16): measured 7.60 / 7.75 / 8.04 ms on BASELINE configs[3] -- more of them in flight is SLOWER (profiles/r06_c4_cols8_ab.txt)
+#endif
+#ifndef TF_C8_PREFETCH_AT
+#define TF_C8_PREFETCH_AT 1  // 0: request them before the exchange, 1: after it (in front of step 2's networks)
+#endif
+    u64 wa[8], wb[8];
+    const auto prefetch = [&]() {
+        if constexpr (TF_C8_PREFETCH >= 8) {
+            if (act) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) wa[i] = tw_load(i);
+            }
+        }
+        if constexpr (TF_C8_PREFETCH >= 16) {
+            if (act) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) wb[i] = tw_load(8 + i);
+            }
+        }
+    };
+    if constexpr (TF_C8_PREFETCH_AT == 0) prefetch();
+    // ------------------------------------------------------------------ exchange + the fused radix-2 stage
+    {
+        const int myround = c >> 2, cc = c & 3;
+        u64* const wr = lds + g * kC8Cpr + cc;
+        const u64* const rd = lds + k1 * kC8S1 + cc;
+#pragma unroll 1
+        for (int r = 0; r < kC8Rounds; ++r) {
+            if (r) TF_C8_BARRIER();
+            if (myround == r) {
+#pragma unroll
+                for (int q = 0; q < 32; ++q) wr[q * kC8S1] = x[q];
+            }
+            TF_C8_BARRIER();
+            if (myround == r) {
+                const auto group = [&](auto q0c) {
+                    constexpr int Q0 = decltype(q0c)::value;
+                    u64 w[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        x[Q0 + i] = rd[brev5(Q0 + i) * kC8Cpr];
+                        w[i] = rd[(brev5(Q0 + i) + 32) * kC8Cpr];
+                    }
+                    c8_combine8<INV, Q0>(x, w, half != 0);
+                };
+                group(std::integral_constant<int, 0>{});
+                group(std::integral_constant<int, 8>{});
+                group(std::integral_constant<int, 16>{});
+                group(std::integral_constant<int, 24>{});
+            }
+        }
+    }
+    if constexpr (TF_C8_PREFETCH_AT == 1) prefetch();
+    if (half) pre2_shift<INV>(x);
+    // ------------------------------------------------------------------ step 2 (radix 32 over g') + inter-pass twiddle + store
+    __builtin_amdgcn_s_setprio(TF_PRIO_STEP2);
+    if constexpr (!(TF_C8_ABLATE & 4)) {
+        dit_level<INV, 1, true>(x);
+        dit_level<INV, 2, true>(x);
+        dit_level<INV, 3, true>(x);
+        dit_level<INV, 4, true>(x);
+        dit_level<INV, 5, true>(x);
+    }
+    if (act) {
+        const u32 toff = (u32)(((long long)ch * A.out_cs_hi + cl + (long long)krow * A.out_rs) * 8);
+        const __amdgpu_buffer_rsrc_t ro = buf_rsrc(out);
+        // group G's products and stores; the table words of a later group are requested before them (two buffers, wa / wb)
+        const auto mul_store = [&](int q0, const u64 (&w)[8]) {
+#pragma unroll
+            for (int i = 0; i < 8; i += 4) {
+                const int q = q0 + i;
+                const u64 a4[4] = {x[q], x[q + 1], x[q + 2], x[q + 3]}, b4[4] = {w[i], w[i + 1], w[i + 2], w[i + 3]};
+                u64 r4[4];
+                gl::mont_mul4(a4, b4, r4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) buf_store<TF_C8_STORE_AUX>(ro, toff, (u32)((long long)((q + e) << 6) * A.out_rs * 8), r4[e]);
+            }
+        };
+        if constexpr (TF_C8_PREFETCH < 8) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) wa[i] = tw_load(i);
+        }
+        if constexpr (TF_C8_PREFETCH < 16) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) wb[i] = tw_load(8 + i);
+        }
+        mul_store(0, wa);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) wa[i] = tw_load(16 + i);
+        __builtin_amdgcn_sched_barrier(0);
+        mul_store(8, wb);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) wb[i] = tw_load(24 + i);
+        __builtin_amdgcn_sched_barrier(0);
+        mul_store(16, wa);
+        __builtin_amdgcn_sched_barrier(0);
+        mul_store(24, wb);
+    }
+}
+
 // ---- 2^11 <= n <= 2^14, contiguous BFieldElement transforms: the WHOLE transform in one workgroup pass --------------
 // 16 384 elements are exactly one 512-thread tile, so n = 32 * 32 * P3 (P3 = 2 .. 16) runs as three register stages joined by
 // two LDS exchanges and touches HBM once instead of twice:
@@ -1484,6 +1791,14 @@ __global__ void __launch_bounds__(256) build_post_tw_kernel(u64* out, const u64*
     long long k = id / B, b = id - k * B;
     unsigned long long e = ((unsigned long long)k * (unsigned long long)b) % (unsigned long long)(R * B);
     out[id] = gl::mont_mul(hi[e >> h], lo[e & ((1ull << h) - 1)]);
+}
+
+// out[k * B + b] = T[k * B + b] * S[b]: the inter-pass table with the column part offset^b of a coset evaluation's scaling folded in
+// (ntt_col2048_kernel; B a power of two)
+__global__ void __launch_bounds__(256) scale_post_tw_kernel(u64* out, const u64* T, const u64* S, long long B, long long M) {
+    const long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= M) return;
+    out[id] = gl::mont_mul(T[id], S[id & (B - 1)]);
 }
 
 // out[c * n + j] = HI_c[j >> h] * LO_c[j & (2^h - 1)]   (base_c^j; grid.y = c; tabs = [c][nhi + nlo] split tables)

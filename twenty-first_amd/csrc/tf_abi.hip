@@ -241,7 +241,7 @@ void tf_set_ntt_min_passes(int passes) { g_min_passes.store(passes, std::memory_
 void tf_set_ntt_chain(int tiles_per_workgroup) { g_chain.store(std::max(0, tiles_per_workgroup), std::memory_order_relaxed); }
 #endif
 void tf_set_ntt_latency_kernel(int mode) { g_lat_mode.store(mode < 0 ? -1 : (mode ? 1 : 0), std::memory_order_relaxed); }
-void tf_set_ntt_two_pass(int mode) { g_pre2_mode.store(mode < 0 ? -1 : (mode > 2 ? 1 : mode), std::memory_order_relaxed); }
+void tf_set_ntt_two_pass(int mode) { g_pre2_mode.store(mode < 0 ? -1 : (mode > 3 ? 1 : mode), std::memory_order_relaxed); }
 void tf_set_ntt_small_launch(int mode) { g_small_launch_mode.store(mode < 0 ? -1 : (mode ? 1 : 0), std::memory_order_relaxed); }
 // The plan of one transform: number of global passes and log2 of each pass's radix (planner introspection for the CPU tests).
 // The route tf_poly_batch_evaluate_* takes for this shape: 1 Horner, 2 zerofier tree; 0 for a width that is not 1 / 3.  Host logic

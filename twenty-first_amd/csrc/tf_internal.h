@@ -66,6 +66,8 @@ struct DeviceCtx {
     std::mutex mu;
     std::map<u64, u64*> tables;           // twiddle tables, never freed while the process lives
     std::map<std::pair<u64, u64>, u64*> pow_tables;  // (offset_raw, n) -> offset^j table
+    std::map<std::pair<u64, u64>, u64*> scaled_post;  // (offset_raw, log_m << 8 | a) -> T[k B + b] * offset^b (get_scaled_post_table)
+    size_t cached_scaled_post_bytes = 0;
     bool tip5_ready = false;               // guarded by mu
     std::atomic<bool> pool_ready{false};  // double-checked under mu
     hipMemPool_t pool = nullptr;           // the library's stream-ordered temporaries (current_ctx); written once before pool_ready
@@ -113,11 +115,12 @@ int check_len(size_t n);
 int pass_count(int log_n);
 void choose_split(int log_n, int P, int L, int (&a)[4]);
 void pre2_split(int log_n, int (&a)[4]);
+void pre2_split(int log_n, int (&a)[4], bool c8);
 bool pre2_plan_ok(int log_n, int L, size_t n, size_t cosets, bool has_in2, long long n_out, bool inverse, bool load_work, bool store_scale);
 bool can_truncate(size_t n, int L);
 int run_ntt(DeviceCtx* ctx, const u64* in, u64* out, long long in_bs, long long out_bs, size_t n, size_t batch, int L, bool inverse,
             const u64* pre_scale, long long n_coeffs, hipStream_t stream, const u64* post_scale = nullptr, size_t cosets = 1,
-            const u64* in2 = nullptr, long long n_out = -1);
+            const u64* in2 = nullptr, long long n_out = -1, const u64* coset_offset = nullptr);
 int ntt_dev(u64* d_x, size_t n, size_t batch, int L, int inverse, void* stream);
 int coset_eval_dev(const u64* d_coeffs, size_t n_coeffs, u64 offset_raw, u64* d_out, size_t order, size_t batch, int L, void* stream);
 // ------------------------------------------------------------------------------------ tf_lat.hip

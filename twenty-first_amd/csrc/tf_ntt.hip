@@ -211,6 +211,9 @@ int release_caches(DeviceCtx* ctx) {
         for (auto& kv : ctx->pow_tables) tabs.push_back(kv.second);
         ctx->pow_tables.clear();
         ctx->cached_pow_bytes = 0;
+        for (auto& kv : ctx->scaled_post) tabs.push_back(kv.second);
+        ctx->scaled_post.clear();
+        ctx->cached_scaled_post_bytes = 0;
     }
     for (auto& b : drop) {
         (void)hipEventDestroy(b.ready);
@@ -577,6 +580,68 @@ int get_pow_table(DeviceCtx* ctx, u64 offset_raw, size_t n, hipStream_t stream, 
     return TF_OK;
 }
 
+// The inter-pass table of a forward first pass with the COLUMN part of a coset evaluation's scaling folded in: T'[k B + b] =
+// w_M^(k b) * offset^b (ntt_col2048_kernel: the factor is constant along a column, so it commutes with the column pass).  One table per
+// (offset, M, R); at most four / kScaledPostBudget bytes stay cached (a prover evaluates on one coset), anything beyond is a
+// stream-ordered temporary the caller frees after the pass.  Built on `stream`; the first build of a cached table synchronises it once.
+constexpr size_t kScaledPostBudget = size_t(512) << 20;
+int get_scaled_post_table(DeviceCtx* ctx, int log_m, int a, u64 offset_raw, hipStream_t stream, const u64** out, bool* temp) {
+    *temp = false;
+    const auto key = std::make_pair(offset_raw, (u64(log_m) << 8) | u64(a));
+    {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        auto it = ctx->scaled_post.find(key);
+        if (it != ctx->scaled_post.end()) {
+            *out = it->second;
+            return TF_OK;
+        }
+    }
+    const long long M = 1ll << log_m, B = M >> a;
+    const u64* T = nullptr;
+    bool t_temp = false;
+    int rc = get_post_table(ctx, log_m, a, false, stream, &T, &t_temp);
+    if (rc) return rc;
+    const u64* S = nullptr;
+    bool s_temp = false;
+    rc = get_pow_table(ctx, offset_raw, (size_t)B, stream, &S, &s_temp);
+    if (rc) {
+        if (t_temp) (void)hipFreeAsync(const_cast<u64*>(T), stream);
+        return rc;
+    }
+    bool cache;
+    {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        cache = ctx->scaled_post.size() < 4 && ctx->cached_scaled_post_bytes + size_t(M) * sizeof(u64) <= kScaledPostBudget;
+    }
+    u64* d = nullptr;
+    hipError_t e = cache ? hipMalloc(&d, size_t(M) * sizeof(u64)) : pool_malloc_async(reinterpret_cast<void**>(&d), size_t(M) * sizeof(u64), stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(tfk::scale_post_tw_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, stream, d, T, S, B, M);
+        e = hipGetLastError();
+        if (e == hipSuccess && cache) e = hipStreamSynchronize(stream);  // other streams may use the cached table from now on
+    }
+    if (t_temp) (void)hipFreeAsync(const_cast<u64*>(T), stream);
+    if (s_temp) (void)hipFreeAsync(const_cast<u64*>(S), stream);
+    if (e != hipSuccess) {
+        if (d) { if (cache) (void)hipFree(d); else (void)hipFreeAsync(d, stream); }
+        return hip_fail(e, "scale_post_tw_kernel", __FILE__, __LINE__);
+    }
+    if (cache) {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        auto it = ctx->scaled_post.find(key);
+        if (it != ctx->scaled_post.end()) {  // another host thread built it meanwhile
+            (void)hipFree(d);
+            d = it->second;
+        } else {
+            ctx->scaled_post[key] = d;
+            ctx->cached_scaled_post_bytes += size_t(M) * sizeof(u64);
+        }
+    } else {
+        *temp = true;
+    }
+    *out = d;
+    return TF_OK;
+}
 
 // ------------------------------------------------------------------------------------ NTT planner
 struct Launch {
@@ -716,8 +781,10 @@ bool fits_buffer_offsets(const Launch& l) {
         const unsigned long long cols = (unsigned long long)(cs_hi_words < 0 ? 0 : cs_hi_words) * 8ull * 16ull;  // ch < 16 columns of a tile
         return rows * (unsigned long long)rs_words * 8ull + cols + col_span < lim;
     };
-    // (a PRE2 launch also reads the partner rows, 1024 rows further)
-    return ok(l.a.in_rs, l.a.in_cs_hi, l.a.pre2_map ? (l.a.pre4_stw ? 4096ull : 2048ull) : 1024ull) && ok(l.a.out_rs, l.a.out_cs_hi) && ok(l.a.tw_rs, 0);
+    // (a PRE2 launch also reads the partner rows, 1024 rows further; the one-workgroup 2048-point column pass, p2 = 6, spans 2048 rows
+    //  on every side)
+    const unsigned long long rows = l.a.p2 == 6 ? 2048ull : 1024ull;
+    return ok(l.a.in_rs, l.a.in_cs_hi, l.a.pre2_map ? (l.a.pre4_stw ? 4096ull : 2048ull) : rows) && ok(l.a.out_rs, l.a.out_cs_hi, rows) && ok(l.a.tw_rs, 0, rows);
 }
 
 // the specialised R = 1024 last-pass kernel (LAST1024) is available unless an A/B switch or an ablation run disables it
@@ -888,6 +955,17 @@ int launch_pass_t(const Launch& l, hipStream_t stream) {
     return TF_OK;
 }
 
+// the 2048-point column pass in one workgroup (2048 rows x 8 word-columns, ntt_col2048_kernel)
+template <bool INV, int SCALE>
+int launch_col2048_t(const Launch& l, hipStream_t stream) {
+    static std::atomic<unsigned long long> done_mask{0};
+    if (int rc_attr = ensure_dynamic_lds(reinterpret_cast<const void*>(&tfk::ntt_col2048_kernel<INV, SCALE>), (int)(160 * 1024), done_mask)) return rc_attr;
+    const size_t lds_bytes = size_t(32) * tfk::kC8S1 * sizeof(u64);  // (the inner table is staged inside the exchange buffer)
+    hipLaunchKernelGGL((tfk::ntt_col2048_kernel<INV, SCALE>), dim3(l.tiles), dim3(512), lds_bytes, stream, l.a);
+    HIPCHK(hipGetLastError());
+    return TF_OK;
+}
+
 #ifdef TF_AB_BUILD
 // the R = 1024 column pass as a chain of `k` tiles per workgroup with the next tile's loads inside the store phase
 // (ntt_col1024_chain_kernel); k from TF_NTT_PERSIST / tf_set_ntt_chain (0 or 1: the one-tile kernel)
@@ -940,6 +1018,20 @@ int launch_pass(const Launch& l, bool inverse, hipStream_t stream) {
                          l.a.s1 == tfk::kR1024S1 && l.a.s2 == tfk::kR1024Cpr && l.a.s3 == 1 && !l.a.gfast;
     const bool plain_last1024 = l.a.p2 == 5 && !l.a.post_tw && !l.a.gfast && !l.a.pre_scale && l.a.n_coeffs < 0 && !l.a.in2 &&
                                 (!l.a.post_scale || (inverse && scaled_last1024_enabled())) && last1024_enabled() && fits;
+    if (l.a.p2 == 6) {
+        // a 2048-point column pass in ONE workgroup of 2048 rows x 8 word-columns (ntt_kernels.h, ntt_col2048_kernel): planned by
+        // run_ntt only, with exactly the geometry the kernel's immediates assume
+        const bool geo = l.threads == 512 && l.a.nc == tfk::kC8Nc && l.a.cpr == tfk::kC8Cpr && l.a.nrounds == tfk::kC8Rounds && l.a.s1 == tfk::kC8S1 &&
+                         l.a.s2 == tfk::kC8Cpr && l.a.s3 == 1 && !l.a.gfast && !l.a.wtiles;
+        const bool load_work = l.a.pre_scale || l.a.n_coeffs >= 0;
+        if (!geo || !fits || g_ablate || !l.a.post_tw || !l.a.inner_tw || l.a.in2 || l.a.n_out >= 0 || l.a.post_scale || l.a.pre2_map ||
+            (load_work && inverse) || (l.a.pre_scale && l.a.ps_col)) {
+            t_last_error = "internal: one-workgroup 2048-point column pass outside the shapes it supports";
+            return TF_ERR_HIP;
+        }
+        if (load_work) return launch_col2048_t<false, 1>(l, stream);
+        return inverse ? launch_col2048_t<true, 0>(l, stream) : launch_col2048_t<false, 0>(l, stream);
+    }
     if (l.a.pre2_map && l.a.pre4_stw) {
         // a 4096-point last pass as four 1024-point classes per tile (ntt_kernels.h, PRE4): forward, plain, planned by run_ntt only
         if (l.a.p2 != 5 || !fits || g_ablate || l.a.in2 || l.a.n_out >= 0 || l.a.gfast || l.a.post_tw || l.a.pre_scale || l.a.n_coeffs >= 0 ||
@@ -1246,7 +1338,11 @@ bool small_launch_for(size_t n, size_t cosets, size_t batch, int L, long long n_
 }
 
 // Two-pass plans for 2^21 / 2^22 points (a 2048-point pass = pairs of 1024-point workgroups, ntt_kernels.h PRE2).
-std::atomic<int> g_pre2_mode{-1};  // tf_set_ntt_two_pass: -1 automatic (TF_NTT_NO_PRE2 disables), 0 never, 1 whenever supported
+std::atomic<int> g_pre2_mode{-1};  // tf_set_ntt_two_pass: -1 automatic (TF_NTT_NO_PRE2 disables), 0 never, 1 whenever supported (pairs), 3 (one-workgroup first pass)
+#ifndef TF_C8_DEFAULT
+#define TF_C8_DEFAULT 1
+#endif
+constexpr bool kC8Default = TF_C8_DEFAULT != 0;
 bool pre2_plan_ok(int log_n, int L, size_t n, size_t cosets, bool has_in2, long long n_out, bool inverse, bool load_work, bool store_scale) {
     static const bool off = ab_env("TF_NTT_NO_PRE2") != nullptr;  // A/B switch
     const int mode = g_pre2_mode.load(std::memory_order_relaxed);
@@ -1268,7 +1364,7 @@ bool pre4_plan_ok(int log_n, int L, size_t n, size_t cosets, bool has_in2, long 
 #ifdef TF_AB_BUILD
     static const bool on = ab_env("TF_NTT_PRE4") != nullptr;
     const int mode = g_pre2_mode.load(std::memory_order_relaxed);
-    if (mode == 0 || mode == 1 || (mode < 0 && !(on && load_work))) return false;
+    if (mode == 0 || mode == 1 || mode == 3 || (mode < 0 && !(on && load_work))) return false;
     if (log_n != 22 || cosets != 1 || has_in2 || n_out >= 0 || inverse || store_scale) return false;
     if (!last1024_enabled() || ablate_mode() != 0 || wg_threads() != 512) return false;
     if (g_min_passes.load(std::memory_order_relaxed) > 2) return false;
@@ -1278,9 +1374,25 @@ bool pre4_plan_ok(int log_n, int L, size_t n, size_t cosets, bool has_in2, long 
     return false;
 #endif
 }
-void pre2_split(int log_n, int (&a)[4]) {
+// Round 6: the FIRST pass of a two-pass plan as ONE workgroup per 2048 x 8 tile (ntt_col2048_kernel): every element is loaded (and,
+// in a coset evaluation, scaled) once, where a PRE2 pair does both twice.  2^22 = 2048 (this kernel) x 2048 (the PRE2 last pass);
+// 2^21 = 2048 (this kernel) x 1024 (the plain R = 1024 last pass, no pair anywhere).  MEASURED (profiles/r06_c4_cols8_ab.txt, same
+// process, same words, ms per 2^28 / 3 * 2^26 words): it wins where the first pass SCALES, at 2^22 -- XFE coset evaluation 1.84 vs 1.94
+// (BASELINE configs[3]: 7.40 vs 7.80), BFE 2.53 vs 2.65 -- ties on BFE 2^21 / 2^22 plain transforms and loses 2-9 % on XFE plain
+// transforms and everything XFE at 2^21 (its 64-byte segments cost more there than the pair's second read).  So the automatic plan
+// takes it for coset evaluations of 2^22 points only; tf_set_ntt_two_pass(3) forces it wherever the two-pass plan applies, (1) forces
+// the round-3 pairs.
+bool c8_first_pass(int log_n, bool scaled) {
+    const int mode = g_pre2_mode.load(std::memory_order_relaxed);
+    if (mode == 3) return true;
+    if (mode >= 0) return false;
+    return kC8Default && log_n == 22 && scaled;
+}
+void pre2_split(int log_n, int (&a)[4]) { pre2_split(log_n, a, c8_first_pass(log_n, false)); }
+void pre2_split(int log_n, int (&a)[4], bool c8) {
     // 2^21: the 2048-point pass last (the first pass of a coset evaluation then scales every coefficient once); 2^22: both
     a[0] = log_n == 22 ? 11 : 10, a[1] = 11, a[2] = a[3] = 0;
+    if (c8) a[0] = 11, a[1] = log_n - 11;
     if (const char* e = exp_env("TF_NTT_PRE2_FIRST")) {
         if (log_n == 21 && atoi(e)) a[0] = 11, a[1] = 10;
     }
@@ -1294,7 +1406,7 @@ void pre2_split(int log_n, int (&a)[4]) {
 // reads the coefficients once per c and writes rows (k_1, c); from there on it is the ordinary plan with N_1 * C rows.
 int run_ntt(DeviceCtx* ctx, const u64* in, u64* out, long long in_bs, long long out_bs, size_t n, size_t batch, int L,
             bool inverse, const u64* pre_scale, long long n_coeffs, hipStream_t stream, const u64* post_scale,
-            size_t cosets, const u64* in2, long long n_out) {
+            size_t cosets, const u64* in2, long long n_out, const u64* coset_offset) {
     // n_out >= 0 (only with can_truncate(n, L)): the last pass stores output elements j < n_out only and out_bs may be
     // n_out * L -- the truncation of fast_multiply without a copy; `in` is then used as work space and clobbered
     if (n == 0 || batch == 0) return TF_OK;
@@ -1385,6 +1497,7 @@ int run_ntt(DeviceCtx* ctx, const u64* in, u64* out, long long in_bs, long long 
     // 2^21 and 2^22 points in TWO passes: a 2048-point pass runs as pairs of 1024-point workgroups that share their input
     // (ntt_kernels.h, PRE2; a[i] = 11 below).  Plain transforms, coset evaluation (forward) and coset interpolation (inverse).
     bool pre2[4] = {false, false, false, false};
+    bool c8 = false;         // the first pass is the one-workgroup 2048-point column pass (ntt_col2048_kernel)
     bool pre4_last = false;  // the last pass is a 4096-point one in four classes (a[P - 1] = 12)
     const u64* pre4_stw = nullptr;
     if (pre4_plan_ok(log_n, L, n, cosets, in2 != nullptr, n_out, inverse, pre_scale != nullptr || n_coeffs >= 0, post_scale != nullptr)) {
@@ -1393,8 +1506,10 @@ int run_ntt(DeviceCtx* ctx, const u64* in, u64* out, long long in_bs, long long 
         pre4_last = true;
     } else if (pre2_plan_ok(log_n, L, n, cosets, in2 != nullptr, n_out, inverse, pre_scale != nullptr || n_coeffs >= 0, post_scale != nullptr)) {
         P = 2;
-        pre2_split(log_n, a);
-        pre2[0] = a[0] == 11, pre2[1] = a[1] == 11;
+        // (a scaling first pass on the one-workgroup kernel needs the offset itself, for the inter-pass table with offset^b folded in)
+        c8 = c8_first_pass(log_n, pre_scale != nullptr) && (!pre_scale || coset_offset);
+        pre2_split(log_n, a, c8);
+        pre2[0] = a[0] == 11 && !c8, pre2[1] = a[1] == 11;
     }
     const u64* inner[4] = {nullptr, nullptr, nullptr, nullptr};
     for (int i = 0; i < P; ++i) {
@@ -1412,7 +1527,8 @@ int run_ntt(DeviceCtx* ctx, const u64* in, u64* out, long long in_bs, long long 
     {
         int rest = log_n;
         for (int i = 0; i + 1 < P; ++i) {
-            rc = get_post_table(ctx, rest, a[i], inverse, stream, &post[i], &post_temp[i]);
+            if (i == 0 && c8 && pre_scale) rc = get_scaled_post_table(ctx, rest, a[i], *coset_offset, stream, &post[i], &post_temp[i]);
+            else rc = get_post_table(ctx, rest, a[i], inverse, stream, &post[i], &post_temp[i]);
             if (rc) {
                 release_tables();
                 return rc;
@@ -1505,6 +1621,7 @@ int run_ntt(DeviceCtx* ctx, const u64* in, u64* out, long long in_bs, long long 
             if (i == 0 && src != dst) p.a.nt = g_nt.load(std::memory_order_relaxed) & 1;  // the caller's input is read once
             if (i == 0) {
                 p.a.pre_scale = pre_scale;
+                if (c8 && pre_scale) p.a.ps_col = 0;  // the column part offset^b of the scaling comes with the inter-pass table
                 p.a.n_coeffs = n_coeffs;
                 p.a.in2 = in2 ? in2 + (long long)b0 * in_bs : nullptr;
                 if (cosets > 1) {  // "outer" index = coset c: same input for every c, output row (k_1, c), scale table c
@@ -1651,7 +1768,7 @@ int coset_eval_dev(const u64* d_coeffs, size_t n_coeffs, u64 offset_raw, u64* d_
         rc = get_pow_table(ctx, offset_raw, n_coeffs, s, &pw, &temp);
         if (rc) return rc;
         rc = run_ntt(ctx, d_coeffs, d_out, (long long)n_coeffs * L, (long long)order * L, order, batch, L, false, pw,
-                     (long long)n_coeffs, s);
+                     (long long)n_coeffs, s, nullptr, 1, nullptr, -1, &offset_raw);
     }
     if (temp) (void)hipFreeAsync(const_cast<u64*>(pw), s);
     return rc;
