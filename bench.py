@@ -1092,7 +1092,7 @@ def c_abi_selftest(tf, np):
     try:
         exe = os.path.join(ROOT, "twenty-first_amd", "host", "selftest")
         r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
-        keep = [l.strip() for l in r.stdout.splitlines() if ("host thread" in l or "tf_*_multi" in l or "C ABI from" in l or "selftest:" in l)]
+        keep = [l.strip() for l in r.stdout.splitlines() if ("host thread" in l or "tf_*_multi" in l or "C ABI from" in l or "selftest:" in l or "subtree" in l)]
         rec["selftest"] = {"rc": r.returncode, "lines": keep, "stderr_tail": r.stderr.strip().splitlines()[-3:]}
     except Exception as e:
         rec["selftest"] = {"error": repr(e)}
@@ -1110,6 +1110,20 @@ def c_abi_selftest(tf, np):
                              "what": "tf_ntt_bfe_multi (24 x 2^16) and tf_merkle_root_multi (24 trees of 2^12 leaves) over every visible device, host-resident batch"}
     except Exception as e:
         rec["multi_call"] = {"error": repr(e)}
+    try:
+        # ONE tree over every visible device (at least four workers: a one-GPU box lists device 0 four times) in one C call -- the
+        # subtree split of MerkleTree::par_new at the C ABI (tf_merkle_build_multi with fewer trees than devices)
+        nl = 1 << 20
+        nd = int(tf.lib().tf_device_count())
+        devs = [g % nd for g in range(max(4, nd))]
+        lv = np.random.default_rng(13).integers(0, P, size=5 * nl, dtype=np.uint64)
+        one = tf.MerkleTree.build_batch(lv, nl)
+        many = tf.MerkleTree.build_batch(lv, nl, devices=devs)
+        rec["single_tree_multi_call"] = {"devices": devs, "subtrees": int(tf.lib().tf_merkle_multi_subtrees(nl, 1, len(devs))),
+                                         "every_node_same_as_single_device": bool(np.array_equal(one, many)),
+                                         "what": "tf_merkle_build_multi, ONE tree of 2^20 leaves cut into subtrees (util_types/merkle_tree.rs:165-212, :247-275), host-resident"}
+    except Exception as e:
+        rec["single_tree_multi_call"] = {"error": repr(e)}
     return rec
 
 

@@ -54,7 +54,8 @@ enum tf_status {
     TF_ERR_BUFFER_TOO_SMALL = 13,
     TF_ERR_EMPTY_DOMAIN = 14,              /* interpolate panic: "interpolation must happen through more than zero points"  math/polynomial.rs:1503-1506 */
     TF_ERR_DIVISION_BY_ZERO = 15,          /* naive_divide panic: "divisor should be non-zero"  math/polynomial.rs:556-559 */
-    TF_ERR_DIVISION_NOT_CLEAN = 16         /* clean_divide panic: the quotient does not come back to the base field  math/polynomial.rs:2374, :2410 */
+    TF_ERR_DIVISION_NOT_CLEAN = 16,        /* clean_divide panic: the quotient does not come back to the base field  math/polynomial.rs:2374, :2410 */
+    TF_ERR_INVALID_ARGUMENT = 17           /* an index / count argument of a host-logic helper (tf_shard_range, tf_merkle_subtree_layer_range) is out of range */
 };
 
 /* Human-readable name of a status code. */
@@ -90,6 +91,17 @@ int tf_set_device(int device);
 int tf_get_device(int *device);
 
 /* ---------------------------------------------------------------------------------------------
+ * Warm-up.  The FIRST call of a shape on a device builds that shape's tables, opens kernel attributes, uploads the Tip5 constants and
+ * creates the library's pool / side streams / scratch on that device -- steps that wait for the device and may synchronise it as a whole.
+ * tf_prepare_* runs the shape once on zeroed scratch of the same size on the CURRENT device and returns when it is done; afterwards every
+ * tf_*_dev call of that shape (same n, batch, width, direction / offset) on that device only enqueues work on the caller's stream.  A host
+ * thread that drives several GPUs round-robin ("eight GPUs from one thread") calls these once per device at start-up.
+ * Errors: as the call they prepare; width not 1 / 3 -> TF_ERR_INVALID_ARGUMENT; scratch allocation -> TF_ERR_OUT_OF_MEMORY. */
+int tf_prepare_ntt(size_t n, size_t batch, int width, int inverse);
+int tf_prepare_coset_eval(size_t n_coeffs, uint64_t offset_raw, size_t order, size_t batch, int width);
+int tf_prepare_merkle(size_t n_leaves, size_t batch);
+
+/* ---------------------------------------------------------------------------------------------
  * One host-resident batch over several GPUs.      replaces  the rayon fan-out over independent units in the reference's callers:
  *                                                            par_iter over polynomials around ntt / fast_coset_evaluate
  *                                                            (math/ntt.rs:250-274 is the unit), MerkleTree::par_new's
@@ -105,9 +117,21 @@ int tf_get_device(int *device);
  * workers, i.e. several copy/compute streams, on one GPU).  The calling thread's current device is not changed.
  * Errors: argument errors exactly as the single-device call (checked before any worker starts); a device index out of range ->
  * TF_ERR_NO_DEVICE; if workers fail, the status of the first failing slice in batch order is returned and tf_last_error() names
- * the device and slice.
+ * the device and slice.  tf_shard_range: n_shards <= 0 or shard outside [0, n_shards) -> TF_ERR_INVALID_ARGUMENT.
+ *
+ * FEWER TREES THAN DEVICES (in particular ONE tree): tf_merkle_{build,root}_multi cut every tree into S subtrees, S the largest power of
+ * two with batch * S <= n_devices and at least two leaves per subtree -- exactly the cut MerkleTree::par_new makes over its threads
+ * (util_types/merkle_tree.rs:165-212; layer l of subtree s of S is the run [(S + s) 2^l, (S + s + 1) 2^l) of the heap-ordered node
+ * array, subtrees_mut :247-275).  Unit u = (tree u / S, subtree u % S); the batch * S units are dealt to the listed devices by
+ * tf_shard_range's rule; every worker copies its subtrees' layers straight to their place in the caller's node array; the S subtree
+ * roots of a tree (40 bytes each) are gathered on the host and the top log2 S layers are built on devices[0].  Same words as the
+ * single-device call.  tf_merkle_multi_subtrees returns S for a shape (host logic, no device touched); tf_merkle_subtree_layer_range
+ * the node-index run of one layer of one subtree (errors: TF_ERR_INVALID_ARGUMENT for a subtree / layer that does not exist, the
+ * leaf-count errors of tf_merkle_build).
  */
 int tf_shard_range(size_t total_units, int n_shards, int shard, size_t *begin, size_t *end);
+int tf_merkle_multi_subtrees(size_t n_leaves, size_t batch, int n_devices);
+int tf_merkle_subtree_layer_range(size_t n_leaves, size_t n_subtrees, size_t subtree, unsigned layer, size_t *begin, size_t *end);
 int tf_ntt_bfe_multi(uint64_t *x, size_t n, size_t batch, int inverse, const int *devices, int n_devices);
 int tf_ntt_xfe_multi(uint64_t *x, size_t n, size_t batch, int inverse, const int *devices, int n_devices);
 int tf_coset_eval_bfe_multi(const uint64_t *coeffs, size_t n_coeffs, uint64_t offset_raw, uint64_t *out, size_t order, size_t batch,

@@ -142,9 +142,61 @@ def test_c_abi_shard_range_is_the_python_split(tf):
     import ctypes as C
     lo, hi = C.c_size_t(0), C.c_size_t(0)
     lib = tf.lib()
-    assert lib.tf_shard_range(10, 0, 0, C.byref(lo), C.byref(hi)) == 8      # no shards
-    assert lib.tf_shard_range(10, 2, 2, C.byref(lo), C.byref(hi)) == 8      # shard out of range
+    assert lib.tf_shard_range(10, 0, 0, C.byref(lo), C.byref(hi)) == 17     # no shards: TF_ERR_INVALID_ARGUMENT (not NO_DEVICE)
+    assert lib.tf_shard_range(10, 2, 2, C.byref(lo), C.byref(hi)) == 17     # shard out of range
     assert lib.tf_shard_range(10, 2, 1, None, C.byref(hi)) == 7             # TF_ERR_NULL_POINTER
+    assert lib.tf_status_string(17) == b"TF_ERR_INVALID_ARGUMENT"
+
+
+def test_single_tree_subtree_split_is_the_reference_s(tf):
+    """tf_merkle_{build,root}_multi with fewer trees than devices cut every tree into subtrees.  The node-index run of every layer of every
+    subtree (tf_merkle_subtree_layer_range) must be the slicing of MerkleTree::subtrees_mut, restated here from
+    util_types/merkle_tree.rs:247-275: skip num_trees nodes, then for layer 0, 1, ... hand every tree in turn the next 2^layer nodes.
+    Together the layers tile [num_trees, 2 n) exactly once (the reference's debug_assert!(nodes.is_empty())), as its own test
+    merkle_subtrees_are_sliced_correctly (:1537-1592) checks.  Also the number of subtrees the multi call picks (host logic)."""
+    import ctypes as C
+    lib = tf.lib()
+    lo, hi = C.c_size_t(0), C.c_size_t(0)
+
+    def reference_slicing(num_leafs, num_trees):  # merkle_tree.rs:247-275
+        height = num_leafs.bit_length() - 1
+        sub_height = height - (num_trees.bit_length() - 1)
+        layers = [[] for _ in range(num_trees)]
+        at = num_trees  # nodes_to_skip: includes the dummy node at index 0
+        for layer_idx in range(sub_height + 1):
+            for tree in range(num_trees):
+                layers[tree].append((at, at + (1 << layer_idx)))
+                at += 1 << layer_idx
+        assert at == 2 * num_leafs
+        return layers
+
+    for log_n in range(1, 9):
+        n = 1 << log_n
+        for log_s in range(0, log_n + 1):
+            S = 1 << log_s
+            want = reference_slicing(n, S)
+            seen = []
+            for sub in range(S):
+                for layer, (a, b) in enumerate(want[sub]):
+                    assert lib.tf_merkle_subtree_layer_range(n, S, sub, layer, C.byref(lo), C.byref(hi)) == 0
+                    assert (lo.value, hi.value) == (a, b)
+                    seen.extend(range(a, b))
+                assert lib.tf_merkle_subtree_layer_range(n, S, sub, len(want[sub]), C.byref(lo), C.byref(hi)) == 17  # no such layer
+            assert sorted(seen) == list(range(S, 2 * n))
+            assert lib.tf_merkle_subtree_layer_range(n, S, S, 0, C.byref(lo), C.byref(hi)) == 17  # no such subtree
+    assert lib.tf_merkle_subtree_layer_range(8, 3, 0, 0, C.byref(lo), C.byref(hi)) == 17      # not a power of two
+    assert lib.tf_merkle_subtree_layer_range(12, 2, 0, 0, C.byref(lo), C.byref(hi)) == 2      # leaf-count errors as tf_merkle_build
+    assert lib.tf_merkle_subtree_layer_range(0, 1, 0, 0, C.byref(lo), C.byref(hi)) == 1
+    # subtrees per tree: the largest power of two with batch * S <= devices and at least two leaves per subtree (merkle_tree.rs:182)
+    assert lib.tf_merkle_multi_subtrees(1 << 24, 1, 8) == 8          # BASELINE configs[2] on eight GPUs
+    assert lib.tf_merkle_multi_subtrees(1 << 24, 1, 7) == 4
+    assert lib.tf_merkle_multi_subtrees(1 << 20, 2, 8) == 4
+    assert lib.tf_merkle_multi_subtrees(1 << 20, 3, 8) == 2
+    assert lib.tf_merkle_multi_subtrees(1 << 20, 8, 8) == 1          # a tree per device: the batch split
+    assert lib.tf_merkle_multi_subtrees(1 << 20, 256, 8) == 1
+    assert lib.tf_merkle_multi_subtrees(4, 1, 8) == 2                # two leaves per subtree at least
+    assert lib.tf_merkle_multi_subtrees(2, 1, 8) == 1 and lib.tf_merkle_multi_subtrees(1, 1, 8) == 1
+    assert lib.tf_merkle_multi_subtrees(1 << 20, 0, 8) == 1
 
 
 def test_multi_device_entry_points_without_a_device(tf):

@@ -52,3 +52,36 @@ def test_library_reports_the_hash_of_its_sources(tf):
         h.update(open(os.path.join(csrc, name), "rb").read())
     got = tf.lib().tf_source_hash().decode()
     assert got in (h.hexdigest()[:16], h.hexdigest()[:16] + "-ab"), "libtf_hip.so is older than its sources: rebuild (make -C twenty-first_amd/csrc)"
+
+
+def test_every_leg_survives_in_the_tail_of_the_bench_line():
+    """The driver's record keeps only the tail of a long line (round 5's lost `merkle.value` that way): bench.py emits a compact `summary`
+    as the LAST key -- every leg's value, ms_per_step, roofline.frac, cpu_baseline.value + cores, parity -- in at most 1.5 KB.  Here: a
+    captured full record (profiles/r05_bench_final.json), the summary rebuilt by bench.summary_block, the line cut to its last 6 KB as a
+    reader of the driver's record sees it, and all legs found again by bench.parse_summary_from_tail; the headline keys still come first."""
+    import importlib.util
+    import json
+    import os
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    rec = json.load(open(os.path.join(root, "profiles", "r05_bench_final.json")))
+    rec.pop("summary", None)
+    rec["summary"] = bench.summary_block(rec)
+    line = json.dumps(rec)
+    assert len(line) > 8192, "the point of the test: the line is longer than what the driver keeps"
+    assert len(json.dumps(rec["summary"])) <= 1536
+    assert list(rec.keys())[:5] == ["metric", "value", "unit", "n_gpus", "steps"] and list(rec.keys())[-1] == "summary"
+    got = bench.parse_summary_from_tail(line[-6144:])
+    assert got == rec["summary"]
+    for leg in ("headline", "merkle", "coset_eval", "config5", "commit_pipeline"):
+        assert got[leg]["value"] and got[leg]["ms"] and got[leg]["cpu"] and got[leg]["cores"] and got[leg]["parity"].startswith("green")
+    assert got["merkle"]["value"] == rec["merkle"]["value"] and got["merkle"]["frac"] == rec["merkle"]["roofline"]["frac"]
+    assert got["coset_eval"]["frac"] == rec["coset_eval"]["roofline"]["frac"] and got["headline"]["frac"] == rec["roofline"]["frac"]
+    assert got["config5"]["trees_leaves_per_s"] == rec["config5"]["merkle"]["value"]
+    # a failed leg and an unchecked one stay readable
+    rec2 = dict(rec, merkle={"error": "RuntimeError('x')"}, coset_eval=dict(rec["coset_eval"], parity="not checked (--no-cpu-baseline)", cpu_baseline=None))
+    sm = bench.summary_block(rec2)
+    assert "error" in sm["merkle"] and sm["coset_eval"]["parity"] == "not checked" and "cpu" not in sm["coset_eval"]

@@ -1021,6 +1021,115 @@ def test_multi_device_merkle_and_coset_match_oracle(tf, oracle, devices):
         assert np.array_equal(got, oracle.coset_evaluate_batch(c, off, order, polys, width=width, threads=2))
 
 
+@pytest.mark.parametrize("log_n,batch,devices", [(20, 1, [0, 0, 0, 0]), (12, 1, [0, 0]), (10, 3, [0] * 8), (3, 1, [0] * 8), (2, 1, [0, 0, 0, 0]),
+                                                  (1, 1, [0, 0]), (9, 2, [0, 0, 0, 0, 0])])
+def test_multi_device_single_tree_is_split_into_subtrees(tf, oracle, log_n, batch, devices):
+    """Fewer trees than listed devices: tf_merkle_{build,root}_multi cut every tree into subtrees the way MerkleTree::par_new cuts it over
+    its threads (util_types/merkle_tree.rs:165-212, :247-275), one subtree per worker, the top layers on devices[0]; EVERY node of
+    every tree equals the oracle's par_new and the single-device call, nodes[0] is the zero digest, the roots agree."""
+    n = 1 << log_n
+    S = tf.lib().tf_merkle_multi_subtrees(n, batch, len(devices))
+    assert S >= 1 and batch * S <= len(devices) and (S == 1 or n // S >= 2)
+    if (log_n, batch) in ((20, 1), (12, 1), (10, 3), (3, 1), (2, 1)):
+        assert S > 1  # these shapes do take the split
+    leafs = oracle.fill_random(batch * n * 5, 3600 + log_n)
+    nodes = tf.MerkleTree.build_batch(leafs, n, devices=devices)
+    roots = tf.MerkleTree.roots_batch(leafs, n, devices=devices)
+    single = tf.MerkleTree.build_batch(leafs, n)
+    assert np.array_equal(nodes, single)
+    for b in range(batch):
+        want = oracle.merkle_build(leafs[b * n * 5:(b + 1) * n * 5], threads=4)
+        assert np.array_equal(nodes[b].reshape(-1), want)
+        assert not nodes[b][0].any()
+        assert np.array_equal(roots[b], want[5:10])
+
+
+def test_multi_device_one_2p24_leaf_tree_over_four_workers(tf, oracle):
+    """BASELINE configs[2] through the one-call form: ONE 2^24-leaf tree over devices = [0, 0, 0, 0] (four subtrees of 2^22 leaves, two
+    top layers on the first device), all 2^25 nodes against the oracle's par_new."""
+    n = 1 << 24
+    leafs = oracle.fill_random(n * 5, 0x7F210003)
+    nodes = tf.MerkleTree.build_batch(leafs, n, devices=[0, 0, 0, 0])
+    want = oracle.merkle_build(leafs, threads=min(64, os.cpu_count() or 1))
+    assert np.array_equal(nodes.reshape(-1), want)
+    assert np.array_equal(tf.MerkleTree.roots_batch(leafs, n, devices=[0, 0, 0, 0])[0], want[5:10])
+
+
+def test_one_host_thread_round_robin_never_blocks(tf, oracle):
+    """BASELINE configs[4]'s shape at the boundary a one-process caller binds, WITHOUT PCIe in the loop ("eight GPUs from
+    one thread"; the reference's callers are one process, math/ntt.rs:250-274): one host thread, one device buffer + stream per listed
+    device -- device 0 four times here --, tf_set_device(g); tf_ntt_bfe_dev / tf_merkle_build_dev / tf_coset_eval_xfe_dev round-robin, three
+    rounds deep.  After tf_prepare_* every call must only ENQUEUE: its stream is still busy when it returns (hipStreamQuery), and the
+    host spends a small fraction of the time the queued work takes -- a first-use table build, a hipMemcpyToSymbol or a hipMalloc
+    hiding a device-wide synchronisation in any of them would fail one or the other.  Results word for word against the oracle."""
+    import time
+
+    import torch
+
+    lib = tf.lib()
+    devs = [0, 0, 0, 0]
+    n, batch, nl, trees, nc, order, polys = 1 << 20, 48, 1 << 18, 8, 1 << 15, 1 << 16, 24
+    off = oracle.bfe_new(7)
+    for d in sorted(set(devs)):  # start-up: once per device and shape
+        tf.set_device(d)
+        assert lib.tf_prepare_ntt(n, batch, 1, 0) == 0
+        assert lib.tf_prepare_merkle(nl, trees) == 0
+        assert lib.tf_prepare_coset_eval(nc, off, order, polys, 3) == 0
+    streams = [torch.cuda.Stream(device=d) for d in devs]
+    x = [torch.empty(n * batch, dtype=torch.int64, device=f"cuda:{d}") for d in devs]
+    leaves = [torch.empty(5 * nl * trees, dtype=torch.int64, device=f"cuda:{d}") for d in devs]
+    nodes = [torch.empty(10 * nl * trees, dtype=torch.int64, device=f"cuda:{d}") for d in devs]
+    coeffs = [torch.empty(3 * nc * polys, dtype=torch.int64, device=f"cuda:{d}") for d in devs]
+    evals = [torch.empty(3 * order * polys, dtype=torch.int64, device=f"cuda:{d}") for d in devs]
+    for g, d in enumerate(devs):
+        tf.set_device(d)
+        tf.device.fill_random(x[g], 5000 + g, stream=streams[g])
+        tf.device.fill_random(leaves[g], 5100 + g, stream=streams[g])
+        tf.device.fill_random(coeffs[g], 5200 + g, stream=streams[g])
+    for st in streams:
+        st.synchronize()
+    host_us = []
+
+    def one_round(record):
+        for g, d in enumerate(devs):
+            tf.set_device(d)
+            for kind, call in (("ntt", lambda: tf.device.ntt_(x[g], n, batch=batch, stream=streams[g])),
+                               ("merkle_build", lambda: tf.device.merkle_build(leaves[g], nl, nodes[g], batch=trees, stream=streams[g])),
+                               ("coset_evaluate", lambda: tf.device.coset_evaluate(coeffs[g], nc, off, evals[g], order, batch=polys, width=3, stream=streams[g]))):
+                t = time.perf_counter()
+                call()
+                host_us.append((round((time.perf_counter() - t) * 1e6), kind, g))
+                record.append(not streams[g].query())
+
+    # one untimed round first: with ONE physical device listed four times, four calls in flight need four scratch blocks of that
+    # device's cache where tf_prepare_* left one (on four devices each has its own); the blocks are allocated here, once
+    one_round([])
+    for st in streams:
+        st.synchronize()
+    pending, rounds = [], 3
+    host_us.clear()
+    t0 = time.perf_counter()
+    for _ in range(rounds):
+        one_round(pending)
+    t_host = time.perf_counter() - t0
+    for st in streams:
+        st.synchronize()
+    t_all = time.perf_counter() - t0
+    tf.set_device(0)
+    assert all(pending), f"{pending.count(False)} of {len(pending)} calls returned with their stream idle: something waited for the device"
+    assert t_host < 0.5 * t_all, (f"the host spent {t_host * 1e3:.2f} ms enqueueing {t_all * 1e3:.2f} ms of device work; slowest calls (us, kind, slot): "
+                                  f"{sorted(host_us, reverse=True)[:6]}")
+    for g in (0, len(devs) - 1):  # four forward transforms in a row; the tree; the evaluation
+        want = oracle.fill_random(n * 2, 5000 + g)
+        for _ in range(rounds + 1):
+            want = oracle.ntt(want, batch=2, threads=2)
+        assert np.array_equal(x[g][: 2 * n].cpu().numpy().view(np.uint64), want)
+        lv = oracle.fill_random(5 * nl * trees, 5100 + g)
+        assert np.array_equal(nodes[g][-10 * nl:].cpu().numpy().view(np.uint64), oracle.merkle_build(lv[-5 * nl:], threads=8))
+        cf = oracle.fill_random(3 * nc * polys, 5200 + g)
+        assert np.array_equal(evals[g][: 3 * order].cpu().numpy().view(np.uint64), oracle.coset_evaluate(cf[: 3 * nc], off, order, width=3))
+
+
 def test_multi_device_errors_and_current_device(tf, oracle):
     """argument errors as the single-device calls; a device index out of range is TF_ERR_NO_DEVICE and names the index; the
     caller's current device is untouched"""

@@ -27,6 +27,11 @@ SIGNATURES = {
     "tf_set_device": (C.c_int, [C.c_int]),
     "tf_get_device": (C.c_int, [C.POINTER(C.c_int)]),
     "tf_shard_range": (C.c_int, [_sz, C.c_int, C.c_int, C.POINTER(_sz), C.POINTER(_sz)]),
+    "tf_merkle_multi_subtrees": (C.c_int, [_sz, _sz, C.c_int]),
+    "tf_prepare_ntt": (C.c_int, [_sz, _sz, C.c_int, C.c_int]),
+    "tf_prepare_coset_eval": (C.c_int, [_sz, C.c_uint64, _sz, _sz, C.c_int]),
+    "tf_prepare_merkle": (C.c_int, [_sz, _sz]),
+    "tf_merkle_subtree_layer_range": (C.c_int, [_sz, _sz, _sz, C.c_uint, C.POINTER(_sz), C.POINTER(_sz)]),
     "tf_ntt_bfe_multi": (C.c_int, [_vp, _sz, _sz, C.c_int, C.POINTER(C.c_int), C.c_int]),
     "tf_ntt_xfe_multi": (C.c_int, [_vp, _sz, _sz, C.c_int, C.POINTER(C.c_int), C.c_int]),
     "tf_coset_eval_bfe_multi": (C.c_int, [_vp, _sz, C.c_uint64, _vp, _sz, _sz, C.POINTER(C.c_int), C.c_int]),

@@ -94,6 +94,7 @@ struct NttPassArgs {
     const u64* pre2_cp;                      // SCALE 1: -> offset^(index distance of partner rows), multiplies the partner coefficient
     int pre2_map;                            // 0: not a PRE2 launch; 1: half = bit 3 of the block id (a pair shares an XCD); 2: bit 0
                                              // (PRE4: the residue class q = bits 3-4 / bits 0-1)
+    const u64* post_tw_u;                    // ntt_col2048_kernel: the UNSCALED inter-pass table (rows 64 q are read from it; post_tw may carry offset^b)
     const u64* pre4_stw;                     // PRE4 only: [2][32] Montgomery words w_128^(+-q i), q = 1, 3 (the per-slot part of w_4096^(q c))
 };
 
@@ -1229,7 +1230,22 @@ __global__ void __launch_bounds__(512, TF_NTT_WAVES) ntt_col2048_kernel(const Nt
     const int krow = k1 + 32 * (int)half;  // slot q holds output row krow + 64 q
     const u32 twoff = (u32)(((long long)krow * A.tw_rs + bcol) * 8);
     const __amdgpu_buffer_rsrc_t rt = buf_rsrc(A.post_tw);
-    const auto tw_load = [&](int q) { return (TF_C8_ABLATE & 2) ? (u64)(q + 5) : buf_load_tab(rt, twoff, (u32)((long long)(q << 6) * A.tw_rs * 8)); };
+#ifndef TF_C8_UV
+#define TF_C8_UV 0  // 1: T[(krow + 64 q) B + b] = T[krow B + b] * T[64 q B + b] -- ONE word per thread from its own row (with offset^b when the pass
+                    //    scales) and 32 words from rows 64 q that every thread of the tile shares (32 lines per tile instead of 2 048 32-byte
+                    //    segments), one more product per element.  MEASURED as a loss: 7.58-7.75 ms against 7.34-7.36 on BASELINE configs[3]
+                    //    (profiles/r06_c4_cols8_ab.txt); 0: one table word per element
+#endif
+    const __amdgpu_buffer_rsrc_t rtu = buf_rsrc(A.post_tw_u ? A.post_tw_u : A.post_tw);
+    const u32 uoff = (u32)(bcol * 8);
+    const auto tw_load = [&](int q) {
+        if constexpr (TF_C8_UV) return (TF_C8_ABLATE & 2) ? (u64)(q + 5) : buf_load_tab(rtu, uoff, (u32)((long long)(q << 6) * A.tw_rs * 8));
+        else return (TF_C8_ABLATE & 2) ? (u64)(q + 5) : buf_load_tab(rt, twoff, (u32)((long long)(q << 6) * A.tw_rs * 8));
+    };
+    u64 vrow = 0;
+    if constexpr (TF_C8_UV) {
+        if (act) vrow = buf_load_tab(rt, twoff, 0);
+    }
 #ifndef TF_C8_PREFETCH
 #define TF_C8_PREFETCH 0  // inter-pass table words requested ahead of step 2 (0 / 8 / 16): measured 7.60 / 7.75 / 8.04 ms on BASELINE configs[3] -- more of them in flight is SLOWER (profiles/r06_c4_cols8_ab.txt)
 #endif
@@ -1305,6 +1321,10 @@ __global__ void __launch_bounds__(512, TF_NTT_WAVES) ntt_col2048_kernel(const Nt
                 const u64 a4[4] = {x[q], x[q + 1], x[q + 2], x[q + 3]}, b4[4] = {w[i], w[i + 1], w[i + 2], w[i + 3]};
                 u64 r4[4];
                 gl::mont_mul4(a4, b4, r4);
+                if constexpr (TF_C8_UV) {
+                    const u64 c4[4] = {r4[0], r4[1], r4[2], r4[3]}, v4[4] = {vrow, vrow, vrow, vrow};
+                    gl::mont_mul4(c4, v4, r4);
+                }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) buf_store<TF_C8_STORE_AUX>(ro, toff, (u32)((long long)((q + e) << 6) * A.out_rs * 8), r4[e]);
             }
@@ -1808,6 +1828,37 @@ __global__ void __launch_bounds__(256) build_pow_tables_kernel(u64* out, const u
     const u64* hi = tabs + (long long)blockIdx.y * (nhi + nlo);
     const u64* lo = hi + nhi;
     out[(long long)blockIdx.y * n + id] = gl::mont_mul(hi[id >> h], lo[id & ((1ll << h) - 1)]);
+}
+
+// tab[i] = base^(i << shift), i < count, by square-and-multiply in every thread: the two split tables of a TEMPORARY inter-pass table
+// (get_post_table: tables beyond the cache budget, transforms of 2^29 points and more), built on the caller's stream -- no host-built
+// table, no upload, nothing waits; build_post_tw_kernel above then takes them as it takes the uploaded ones
+__global__ void __launch_bounds__(256) build_split_powers_kernel(u64* tab, u64 base, int shift, long long count) {
+    const long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= count) return;
+    u64 acc = gl::ONE, sq = base;
+    for (int i = 0; i < shift; ++i) sq = gl::mont_mul(sq, sq);  // base^(2^shift)
+    for (unsigned long long e = (unsigned long long)id; e; e >>= 1) {
+        if (e & 1) acc = gl::mont_mul(acc, sq);
+        sq = gl::mont_mul(sq, sq);
+    }
+    tab[id] = acc;
+}
+
+// out[c * n + j] = base_c^j by square-and-multiply in every thread (at most 2 log2 n products per word): the TEMPORARY power tables of
+// get_pow_table, which must not leave the caller's stream (the split-table builder above uploads host-built tables and waits for them)
+struct PowBases {
+    u64 base[64];  // kMaxCosetSplit
+};
+__global__ void __launch_bounds__(256) build_pow_tables_direct_kernel(u64* out, const PowBases bases, long long n) {
+    const long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= n) return;
+    u64 acc = gl::ONE, sq = bases.base[blockIdx.y];
+    for (unsigned long long e = (unsigned long long)id; e; e >>= 1) {
+        if (e & 1) acc = gl::mont_mul(acc, sq);
+        sq = gl::mont_mul(sq, sq);
+    }
+    out[(long long)blockIdx.y * n + id] = acc;
 }
 
 }  // namespace tfk

@@ -2,6 +2,8 @@
 #include "tf_internal.h"
 #include "aux_kernels.h"
 
+#include <functional>
+
 namespace tfi {
 
 // ------------------------------------------------------------------------------------ host-pointer wrappers
@@ -139,6 +141,7 @@ const char* tf_status_string(int status) {
         case TF_ERR_EMPTY_DOMAIN: return "TF_ERR_EMPTY_DOMAIN";
         case TF_ERR_DIVISION_BY_ZERO: return "TF_ERR_DIVISION_BY_ZERO";
         case TF_ERR_DIVISION_NOT_CLEAN: return "TF_ERR_DIVISION_NOT_CLEAN";
+        case TF_ERR_INVALID_ARGUMENT: return "TF_ERR_INVALID_ARGUMENT";
         default: return "TF_ERR_UNKNOWN";
     }
 }
@@ -389,6 +392,46 @@ int tf_tip5_hash_varlen_rows(const uint64_t* rows, size_t row_len, size_t n_rows
     return sync(s);
 }
 
+// ---- warm-up: one blocking call per shape, so that the *_dev calls of that shape never leave the stream ---------------------------
+// The first call of a shape on a device builds its twiddle / power tables (hipMalloc + a build kernel the host waits for), opens the
+// dynamic LDS of the kernels it launches (hipFuncSetAttribute), uploads the Tip5 constants, creates the library's memory pool, side
+// streams and scratch blocks.  Some of those synchronise the whole DEVICE.  A caller that drives several GPUs from one host thread
+// ("eight GPUs from one thread") calls tf_prepare_* once per device and shape at start-up; every later *_dev call of that
+// shape only enqueues (tests/test_gpu_parity.py::test_one_host_thread_round_robin_never_blocks).  Implementation: the shape itself, once,
+// on zeroed scratch of the same size (the plan -- passes, tile sizes, tables -- depends on n, batch and width, so nothing smaller is exact).
+static int prepare_run(size_t in_words, size_t out_words, const std::function<int(u64*, u64*, hipStream_t)>& body) {
+    DeviceCtx* ctx = nullptr;
+    TRY(current_ctx(&ctx));
+    hipStream_t s = host_stream();
+    DevBuf a(s), b(s);
+    if (a.alloc(in_words) || b.alloc(out_words)) return TF_ERR_OUT_OF_MEMORY;
+    if (in_words) HIPCHK(hipMemsetAsync(a.p, 0, in_words * sizeof(u64), s));
+    TRY(body(a.p, b.p, s));
+    return sync(s);
+}
+int tf_prepare_ntt(size_t n, size_t batch, int width, int inverse) {
+    if (width != 1 && width != 3) return TF_ERR_INVALID_ARGUMENT;
+    TRY(check_len(n));
+    if (n <= 1 || batch == 0) return TF_OK;
+    return prepare_run(n * batch * (size_t)width, 0, [=](u64* x, u64*, hipStream_t s) { return ntt_dev(x, n, batch, width, inverse, s); });
+}
+int tf_prepare_coset_eval(size_t n_coeffs, uint64_t offset_raw, size_t order, size_t batch, int width) {
+    if (width != 1 && width != 3) return TF_ERR_INVALID_ARGUMENT;
+    if (n_coeffs > order) return TF_ERR_ORDER_NOT_ABOVE_DEGREE;
+    TRY(check_len(order));
+    if (order == 0 || batch == 0) return TF_OK;
+    return prepare_run(n_coeffs * batch * (size_t)width, order * batch * (size_t)width,
+                       [=](u64* c, u64* o, hipStream_t s) { return coset_eval_dev(c, n_coeffs, offset_raw, o, order, batch, width, s); });
+}
+int tf_prepare_merkle(size_t n_leaves, size_t batch) {
+    TRY(check_leaves(n_leaves));
+    if (batch == 0) return TF_OK;
+    return prepare_run(n_leaves * batch * 5, n_leaves * batch * 10, [=](u64* l, u64* nd, hipStream_t s) {
+        TRY(merkle_build_dev(l, n_leaves, nd, batch, s));
+        return merkle_root_dev(l, n_leaves, nd, batch, s);  // (the root-only route has kernels and scratch of its own)
+    });
+}
+
 int tf_merkle_build(const uint64_t* leaves, size_t n, uint64_t* nodes_out, size_t batch) {
     TRY(check_leaves(n));
     if (batch == 0) return TF_OK;
@@ -403,6 +446,40 @@ int tf_merkle_build(const uint64_t* leaves, size_t n, uint64_t* nodes_out, size_
     TRY(d2h(nodes_out, dout.p, n * batch * 10, s));
     return sync(s);
 }
+
+}  // extern "C"  (closed for one internal helper of tf_multi.hip that needs this unit's host-pointer plumbing)
+namespace tfi {
+// ONE subtree of a host-resident tree on the calling thread's current device (tf_merkle_{build,root}_multi when there are more
+// devices than trees): subtree `sub` of `n_sub` of a tree whose node array starts at nodes_tree (heap order, 2 n words-of-5; or null for
+// a root-only build).  `leaves_sub` = its m = n / n_sub leaves.  Layer l of the subtree is the run [(n_sub + sub) 2^l, (n_sub + sub + 1) 2^l)
+// of the whole tree's array -- the reference's own slicing, util_types/merkle_tree.rs:247-275 (subtrees_mut) -- so the D2H copies put every
+// node where par_new would have written it; the subtree's root also goes to root_out (5 words).
+int merkle_subtree_host(const u64* leaves_sub, size_t m, u64* nodes_tree, size_t n_sub, size_t sub, u64* root_out) {
+    TRY(check_leaves(m));
+    if (!leaves_sub || !root_out) return TF_ERR_NULL_POINTER;
+    DeviceCtx* ctx = nullptr;
+    TRY(current_ctx(&ctx));
+    hipStream_t s = host_stream();
+    DevBuf din(s), dout(s);
+    if (din.alloc(m * 5)) return TF_ERR_TREE_TOO_HIGH;
+    TRY(h2d(din.p, leaves_sub, m * 5, s));
+    if (!nodes_tree) {
+        TRY(dout.alloc(5));
+        TRY(merkle_root_dev(din.p, m, dout.p, 1, s));
+        TRY(d2h(root_out, dout.p, 5, s));
+        return sync(s);
+    }
+    if (dout.alloc(m * 10)) return TF_ERR_TREE_TOO_HIGH;
+    TRY(merkle_build_dev(din.p, m, dout.p, 1, s));
+    for (size_t l = 0; (size_t(1) << l) <= m; ++l) {
+        const size_t w = size_t(1) << l;  // nodes of layer l: local heap indices [w, 2 w)
+        TRY(d2h(nodes_tree + ((n_sub + sub) << l) * 5, dout.p + w * 5, w * 5, s));
+    }
+    TRY(d2h(root_out, dout.p + 5, 5, s));
+    return sync(s);
+}
+}  // namespace tfi
+extern "C" {
 
 int tf_merkle_root(const uint64_t* leaves, size_t n, uint64_t* root_out, size_t batch) {
     TRY(check_leaves(n));

@@ -81,6 +81,7 @@ struct DeviceCtx {
     size_t scratch_bytes = 0;                // bytes held by blocks in scratch_free
     size_t cached_post_bytes = 0;          // inter-pass twiddle tables kept for the life of the process (guarded by mu)
     size_t cached_pow_bytes = 0;           // coset power tables kept for the life of the process (guarded by mu)
+    std::map<const u64*, ScratchBlock> temp_pow;  // temporary power tables in flight: scratch blocks, given back by release_pow_table (guarded by mu)
 };
 
 constexpr int kMaxDevices = 64;
@@ -95,6 +96,7 @@ int release_caches(DeviceCtx* ctx);
 void read_env();
 int ensure_dynamic_lds(const void* fn, int bytes, std::atomic<unsigned long long>& done_mask);
 int get_pow_table(DeviceCtx* ctx, u64 offset_raw, size_t n, hipStream_t stream, const u64** out, bool* temp, size_t cosets = 1, int log_order = 0);
+void release_pow_table(DeviceCtx* ctx, const u64* table, bool temp, hipStream_t stream);  // after the launches that read a table get_pow_table returned
 
 // configuration (tf_set_* hooks of the ABI; TF_* environment variables read once by read_env)
 constexpr int kMaxPipe = 4;
@@ -147,6 +149,7 @@ int tip5_hash_pairs_dev(const u64* d_in, u64* d_out, size_t count, void* stream)
 int tip5_hash_varlen_rows_dev(const u64* d_rows, size_t row_len, size_t n_rows, u64* d_out, void* stream);
 int hash_table_rows_dev(const u64* d_table, size_t n_rows, size_t n_cols, int width, size_t col_stride, u64* d_digests, size_t batch, void* stream);
 int merkle_build_dev(const u64* d_leaves, size_t n, u64* d_nodes, size_t batch, void* stream);
+int merkle_subtree_host(const u64* leaves_sub, size_t m, u64* nodes_tree, size_t n_sub, size_t sub, u64* root_out);  // tf_abi.hip
 int merkle_root_dev(const u64* d_leaves, size_t n, u64* d_root, size_t batch, void* stream);
 int merkle_from_rows_dev(const u64* d_rows, size_t row_len, size_t n_rows, u64* d_nodes, size_t batch, void* stream);
 int merkle_from_columns_dev(const u64* d_table, size_t n_rows, size_t n_cols, int width, size_t col_stride, u64* d_nodes, size_t batch, void* stream);

@@ -171,14 +171,30 @@ void scratch_release(DeviceCtx* ctx, DeviceCtx::ScratchBlock blk, hipStream_t st
         (void)hipFree(blk.p);
         return;
     }
+    // The block that comes back is the one most likely to be wanted again: it is always kept (unless it alone exceeds the budget) and the
+    // OLDEST cached blocks make room for it.  Round 5 dropped the NEW block when the cache was full -- after sixteen blocks of other sizes
+    // had accumulated (a long-lived process, the test suite) every release then waited for its stream and every acquire allocated from
+    // the device, for ever (0.9 ms of host time per call in test_one_host_thread_round_robin_never_blocks).  The evicted blocks were
+    // released long ago, so waiting for their events does not wait for anything.
+    std::vector<DeviceCtx::ScratchBlock> evict;
     bool keep;
     {
         std::lock_guard<std::mutex> lk(ctx->mu);
-        keep = ctx->scratch_bytes + blk.bytes <= kScratchCacheBytes && ctx->scratch_free.size() < 16;
+        keep = blk.bytes <= kScratchCacheBytes;
         if (keep) {
+            while (!ctx->scratch_free.empty() && (ctx->scratch_bytes + blk.bytes > kScratchCacheBytes || ctx->scratch_free.size() >= 16)) {
+                evict.push_back(ctx->scratch_free.front());  // (release order = vector order: the front is the least recently used)
+                ctx->scratch_bytes -= ctx->scratch_free.front().bytes;
+                ctx->scratch_free.erase(ctx->scratch_free.begin());
+            }
             ctx->scratch_free.push_back(blk);
             ctx->scratch_bytes += blk.bytes;
         }
+    }
+    for (auto& b : evict) {
+        (void)hipEventSynchronize(b.ready);
+        (void)hipEventDestroy(b.ready);
+        (void)hipFree(b.p);
     }
     if (!keep) {
         (void)hipEventSynchronize(blk.ready);
@@ -359,6 +375,12 @@ int get_inner_table(DeviceCtx* ctx, int a, bool inverse, int scale_log_n, const 
 // and cached; larger ones (single transforms of 2^29 .. 2^31 points) are stream-ordered temporaries: *temp = true and
 // the caller releases them with hipFreeAsync after the pass that reads them.
 constexpr int kMaxCachedPostLog = 28;
+// Tables of up to 2^22 words (32 MiB) are cached whatever the budget says: round 6 found that a process which had once transformed
+// 2^27 / 2^28 points (two tables of 1-2 GiB) ran every LATER shape on temporaries -- each call then built its table, and the builder of
+// that time uploaded host-computed split tables and waited for the stream (0.85 ms of host time per call of a 2^16-point coset
+// evaluation in tests/test_gpu_parity.py::test_one_host_thread_round_robin_never_blocks).  Temporaries are now built entirely on the
+// caller's stream (their split tables by square-and-multiply on the device) and nothing waits.
+constexpr int kAlwaysCachedPostLog = 22;
 int get_post_table(DeviceCtx* ctx, int log_m, int a, bool inverse, hipStream_t stream, const u64** out, bool* temp) {
     *temp = log_m > kMaxCachedPostLog;
     const u64 key = make_key(TAG_POST, log_m, a, inverse, 0);
@@ -369,14 +391,42 @@ int get_post_table(DeviceCtx* ctx, int log_m, int a, bool inverse, hipStream_t s
             *out = it->second;
             return TF_OK;
         }
-        if (ctx->cached_post_bytes + (sizeof(u64) << log_m) > kPostCacheBudget) *temp = true;  // over budget: temporary
+        if (log_m > kAlwaysCachedPostLog && ctx->cached_post_bytes + (sizeof(u64) << log_m) > kPostCacheBudget) *temp = true;  // over budget: temporary
     }
     u64 w = root_of_unity_mont(log_m);
     if (inverse) w = gl::mont_inverse(w);
+    const long long M = 1ll << log_m, R = 1ll << a, B = M / R;
+    const int threads = 256;
+    const long long blocks = (M + threads - 1) / threads;
+    u64* d = nullptr;
+    if (*temp) {
+        lk.unlock();
+        // hi[i] = w^(i << h), lo[i] = w^i (split_powers), computed ON the device and freed behind the build, all on the caller's stream
+        const int h = (log_m + 1) / 2;
+        const long long nlo = 1ll << h, nhi = 1ll << (log_m - h);
+        u64* d_split = nullptr;
+        hipError_t e = pool_malloc_async(reinterpret_cast<void**>(&d_split), size_t(nlo + nhi) * sizeof(u64), stream);
+        if (e == hipSuccess) e = pool_malloc_async(reinterpret_cast<void**>(&d), size_t(M) * sizeof(u64), stream);
+        if (e != hipSuccess) {
+            if (d_split) (void)hipFreeAsync(d_split, stream);
+            return hip_fail(e, "pool_malloc_async(twiddle table)", __FILE__, __LINE__);
+        }
+        hipLaunchKernelGGL(tfk::build_split_powers_kernel, dim3((unsigned)((nhi + 255) / 256)), dim3(256), 0, stream, d_split, w, h, nhi);
+        hipLaunchKernelGGL(tfk::build_split_powers_kernel, dim3((unsigned)((nlo + 255) / 256)), dim3(256), 0, stream, d_split + nhi, w, 0, nlo);
+        hipLaunchKernelGGL(tfk::build_post_tw_kernel, dim3((unsigned)blocks), dim3(threads), 0, stream, d, d_split, d_split + nhi, h, R, B);
+        e = hipGetLastError();
+        (void)hipFreeAsync(d_split, stream);
+        if (e != hipSuccess) {
+            (void)hipFreeAsync(d, stream);
+            return hip_fail(e, "build_post_tw_kernel (temporary)", __FILE__, __LINE__);
+        }
+        *out = d;
+        return TF_OK;
+    }
     int h = 0;
     std::vector<u64> hi, lo;
     split_powers(w, log_m, &h, &hi, &lo);
-    u64 *d_hi = nullptr, *d_lo = nullptr, *d = nullptr;
+    u64 *d_hi = nullptr, *d_lo = nullptr;
     int rc = upload_table(hi, &d_hi);
     if (rc) return rc;
     rc = upload_table(lo, &d_lo);
@@ -384,39 +434,23 @@ int get_post_table(DeviceCtx* ctx, int log_m, int a, bool inverse, hipStream_t s
         (void)hipFree(d_hi);
         return rc;
     }
-    const long long M = 1ll << log_m, R = 1ll << a, B = M / R;
-    if (*temp) {
-        lk.unlock();
-        hipError_t e = pool_malloc_async(reinterpret_cast<void**>(&d), size_t(M) * sizeof(u64), stream);
-        if (e != hipSuccess) {
-            (void)hipFree(d_hi);
-            (void)hipFree(d_lo);
-            return hip_fail(e, "pool_malloc_async(twiddle table)", __FILE__, __LINE__);
-        }
-    } else {
-        hipError_t e = hipMalloc(&d, size_t(M) * sizeof(u64));
-        if (e != hipSuccess) {
-            (void)hipFree(d_hi);
-            (void)hipFree(d_lo);
-            return hip_fail(e, "hipMalloc(twiddle table)", __FILE__, __LINE__);
-        }
+    hipError_t e = hipMalloc(&d, size_t(M) * sizeof(u64));
+    if (e != hipSuccess) {
+        (void)hipFree(d_hi);
+        (void)hipFree(d_lo);
+        return hip_fail(e, "hipMalloc(twiddle table)", __FILE__, __LINE__);
     }
-    const int threads = 256;
-    const long long blocks = (M + threads - 1) / threads;
-    hipStream_t bs = *temp ? stream : hipStream_t(0);
-    hipLaunchKernelGGL(tfk::build_post_tw_kernel, dim3((unsigned)blocks), dim3(threads), 0, bs, d, d_hi, d_lo, h, R, B);
-    hipError_t e = hipGetLastError();
-    if (e == hipSuccess) e = hipStreamSynchronize(bs);
+    hipLaunchKernelGGL(tfk::build_post_tw_kernel, dim3((unsigned)blocks), dim3(threads), 0, hipStream_t(0), d, d_hi, d_lo, h, R, B);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(hipStream_t(0));
     (void)hipFree(d_hi);
     (void)hipFree(d_lo);
     if (e != hipSuccess) {
-        if (*temp) (void)hipFreeAsync(d, stream); else (void)hipFree(d);
+        (void)hipFree(d);
         return hip_fail(e, "build_post_tw_kernel", __FILE__, __LINE__);
     }
-    if (!*temp) {
-        ctx->tables[key] = d;
-        ctx->cached_post_bytes += size_t(M) * sizeof(u64);
-    }
+    ctx->tables[key] = d;
+    ctx->cached_post_bytes += size_t(M) * sizeof(u64);
     *out = d;
     return TF_OK;
 }
@@ -568,16 +602,48 @@ int get_pow_table(DeviceCtx* ctx, u64 offset_raw, size_t n, hipStream_t stream, 
         return TF_OK;
     }
     lk.unlock();  // a temporary is private to this call: build it without holding the device context
-    hipError_t e = pool_malloc_async(reinterpret_cast<void**>(&d), words * sizeof(u64), stream);
-    if (e != hipSuccess) return hip_fail(e, "pool_malloc_async(pow table)", __FILE__, __LINE__);
-    int rc = build_pow_tables(offset_raw, w, cosets, n, d, stream);
-    if (rc) {
-        (void)hipFreeAsync(d, stream);
-        return rc;
+    // ... and without leaving the caller's stream.  Round 6 (tests/test_gpu_parity.py::test_one_host_thread_round_robin_never_blocks, a
+    // process whose cache is full): (1) the split-table builder uploads host-built tables and WAITS for the stream -- the temporary is
+    // built by one kernel instead, every word by square-and-multiply; (2) hipFreeAsync of a pool block behind the launches blocked the
+    // host for the depth of the queue (0.8-1.0 ms per call, measured around that one call) when several streams share the pool -- the
+    // temporary therefore lives in a block of the scratch cache (hipMalloc'ed blocks handed on with event fences, no stream-ordered free).
+    DeviceCtx::ScratchBlock blk;
+    int rc = scratch_acquire(ctx, words * sizeof(u64), stream, &blk);
+    if (rc) return rc;
+    d = blk.p;
+    {
+        tfk::PowBases pb{};
+        u64 base = offset_raw;
+        for (size_t c = 0; c < cosets && c < 64; ++c) {
+            pb.base[c] = base;
+            base = gl::mont_mul(base, w);
+        }
+        if (n) hipLaunchKernelGGL(tfk::build_pow_tables_direct_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)cosets), dim3(256), 0, stream, d, pb, (long long)n);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) {
+            scratch_release(ctx, blk, stream);
+            return hip_fail(e, "build_pow_tables_direct_kernel", __FILE__, __LINE__);
+        }
+    }
+    {
+        std::lock_guard<std::mutex> lk2(ctx->mu);
+        ctx->temp_pow[d] = blk;
     }
     *temp = true;
     *out = d;
     return TF_OK;
+}
+void release_pow_table(DeviceCtx* ctx, const u64* table, bool temp, hipStream_t stream) {
+    if (!temp || !table) return;
+    DeviceCtx::ScratchBlock blk;
+    {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        auto it = ctx->temp_pow.find(table);
+        if (it == ctx->temp_pow.end()) return;
+        blk = it->second;
+        ctx->temp_pow.erase(it);
+    }
+    scratch_release(ctx, blk, stream);
 }
 
 // The inter-pass table of a forward first pass with the COLUMN part of a coset evaluation's scaling folded in: T'[k B + b] =
@@ -621,7 +687,7 @@ int get_scaled_post_table(DeviceCtx* ctx, int log_m, int a, u64 offset_raw, hipS
         if (e == hipSuccess && cache) e = hipStreamSynchronize(stream);  // other streams may use the cached table from now on
     }
     if (t_temp) (void)hipFreeAsync(const_cast<u64*>(T), stream);
-    if (s_temp) (void)hipFreeAsync(const_cast<u64*>(S), stream);
+    release_pow_table(ctx, S, s_temp, stream);
     if (e != hipSuccess) {
         if (d) { if (cache) (void)hipFree(d); else (void)hipFreeAsync(d, stream); }
         return hip_fail(e, "scale_post_tw_kernel", __FILE__, __LINE__);
@@ -1520,15 +1586,23 @@ int run_ntt(DeviceCtx* ctx, const u64* in, u64* out, long long in_bs, long long 
     }
     const u64* post[3] = {nullptr, nullptr, nullptr};
     bool post_temp[3] = {false, false, false};
+    const u64* post_u = nullptr;  // the plain table beside a scaled post[0] (one-workgroup scaling first pass)
+    bool post_u_temp = false;
     auto release_tables = [&]() {
         for (int i = 0; i < 3; ++i)
             if (post_temp[i] && post[i]) (void)hipFreeAsync(const_cast<u64*>(post[i]), stream);
+        if (post_u_temp && post_u) (void)hipFreeAsync(const_cast<u64*>(post_u), stream);
     };
     {
         int rest = log_n;
         for (int i = 0; i + 1 < P; ++i) {
-            if (i == 0 && c8 && pre_scale) rc = get_scaled_post_table(ctx, rest, a[i], *coset_offset, stream, &post[i], &post_temp[i]);
-            else rc = get_post_table(ctx, rest, a[i], inverse, stream, &post[i], &post_temp[i]);
+            if (i == 0 && c8 && pre_scale) {
+                // the scaled table for every thread's own row, the plain one for the rows all threads share (ntt_col2048_kernel, TF_C8_UV)
+                rc = get_scaled_post_table(ctx, rest, a[i], *coset_offset, stream, &post[i], &post_temp[i]);
+                if (!rc) rc = get_post_table(ctx, rest, a[i], inverse, stream, &post_u, &post_u_temp);
+            } else {
+                rc = get_post_table(ctx, rest, a[i], inverse, stream, &post[i], &post_temp[i]);
+            }
             if (rc) {
                 release_tables();
                 return rc;
@@ -1614,6 +1688,7 @@ int run_ntt(DeviceCtx* ctx, const u64* in, u64* out, long long in_bs, long long 
             Launch p = plan_column_pass(src, dst, src_bs, dst_bs, nb, (i == 0) ? (long long)cosets : outer, a[i], B, L, pre2[i]);
             p.a.inner_tw = inner[i];
             p.a.post_tw = post[i];
+            p.a.post_tw_u = (i == 0 && post_u) ? post_u : nullptr;
             if (pre2[i]) {
                 // partner coefficients are n / 2 apart: offset^(n/2) is word n / 2 of the scale table when the polynomial is that long
                 p.a.pre2_cp = pre_scale ? pre_scale + ((long long)(n / 2) < n_coeffs ? (long long)(n / 2) : 0) : nullptr;
@@ -1770,7 +1845,7 @@ int coset_eval_dev(const u64* d_coeffs, size_t n_coeffs, u64 offset_raw, u64* d_
         rc = run_ntt(ctx, d_coeffs, d_out, (long long)n_coeffs * L, (long long)order * L, order, batch, L, false, pw,
                      (long long)n_coeffs, s, nullptr, 1, nullptr, -1, &offset_raw);
     }
-    if (temp) (void)hipFreeAsync(const_cast<u64*>(pw), s);
+    release_pow_table(ctx, pw, temp, s);
     return rc;
 }
 

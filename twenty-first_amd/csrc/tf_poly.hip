@@ -22,7 +22,7 @@ int coset_interp_dev(const u64* d_values, size_t n, u64 offset_raw, u64* d_out, 
     rc = get_pow_table(ctx, gl::mont_inverse(offset_raw), n, s, &pw, &temp);
     if (rc) return rc;
     rc = run_ntt(ctx, d_values, d_out, (long long)n * L, (long long)n * L, n, batch, L, true, nullptr, -1, s, pw);
-    if (temp) (void)hipFreeAsync(const_cast<u64*>(pw), s);
+    release_pow_table(ctx, pw, temp, s);
     return rc;
 }
 

@@ -116,6 +116,40 @@ static void multi_call_check(const std::vector<int>& devs) {
     }
 }
 
+// ONE tree over the device list in one C call (fewer trees than devices: tf_merkle_{build,root}_multi cut the tree into subtrees the way
+// MerkleTree::par_new cuts it over its threads, util_types/merkle_tree.rs:165-212, :247-275): every node must be the single-device call's.
+// On a one-GPU box the list is device 0 four times, so the split is exercised either way.
+static void single_tree_multi_check(const std::vector<int>& devs_in) {
+    std::vector<int> devs = devs_in;
+    while (devs.size() < 4) devs.push_back(devs_in[devs.size() % devs_in.size()]);
+    const size_t leaves = size_t(1) << 16;
+    std::vector<uint64_t> lv(5 * leaves);
+    uint64_t st = 0x7F210007ull;
+    auto next = [&]() { st += 0x9e3779b97f4a7c15ull; uint64_t z = st; z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull; z = (z ^ (z >> 27)) * 0x94d049bb133111ebull; z ^= z >> 31; return z % 0xffffffff00000001ull; };
+    for (auto& v : lv) v = next();
+    (void)hipSetDevice(devs[0]);
+    std::vector<uint64_t> n1(10 * leaves), nm(10 * leaves, 0xABABABABABABABABull), r1(5), rm(5);
+    EXPECT(tf_merkle_build(lv.data(), leaves, n1.data(), 1) == TF_OK);
+    const int S = tf_merkle_multi_subtrees(leaves, 1, (int)devs.size());
+    const int rc_b = tf_merkle_build_multi(lv.data(), leaves, nm.data(), 1, devs.data(), (int)devs.size());
+    const int rc_r = tf_merkle_root_multi(lv.data(), leaves, rm.data(), 1, devs.data(), (int)devs.size());
+    EXPECT(S >= 4 && rc_b == TF_OK && rc_r == TF_OK && nm == n1 && std::equal(rm.begin(), rm.end(), n1.begin() + 5));
+    for (int sub = 0; sub < S; ++sub) {
+        bool ok = rc_b == TF_OK;
+        for (unsigned layer = 0; (leaves / (size_t)S) >> layer; ++layer) {
+            size_t a = 0, b = 0;
+            EXPECT(tf_merkle_subtree_layer_range(leaves, (size_t)S, (size_t)sub, layer, &a, &b) == TF_OK);
+            ok = ok && std::equal(nm.begin() + a * 5, nm.begin() + b * 5, n1.begin() + a * 5);
+        }
+        size_t lo = 0, hi = 0;
+        int worker = -1;
+        for (size_t g = 0; g < devs.size(); ++g)
+            if (tf_shard_range((size_t)S, (int)devs.size(), (int)g, &lo, &hi) == TF_OK && (size_t)sub >= lo && (size_t)sub < hi) worker = (int)g;
+        printf("  one 2^16-leaf tree, subtree %d of %d on device %d (worker %d): %s\n", sub, S, worker >= 0 ? devs[(size_t)worker] : -1, worker,
+               ok ? "PASS, every layer where MerkleTree::par_new puts it" : "FAIL");
+    }
+}
+
 int main() {
     if (tf_device_count() <= 0) {
         fprintf(stderr, "no HIP device: the backend has no CPU fallback; skipping\n");
@@ -338,6 +372,7 @@ int main() {
                nd > 1 ? "" : " (one GPU here: both threads on device 0; the per-device path first runs on a multi-GPU node)");
         multi_call_check(devs);
         printf("tf_*_multi over %zu worker(s) on %d device(s): same words as the single-device calls\n", devs.size(), nd);
+        single_tree_multi_check(devs);
     }
     if (failures) {
         fprintf(stderr, "%d failure(s)\n", failures);
