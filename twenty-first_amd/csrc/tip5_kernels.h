@@ -19,6 +19,9 @@
 // reference gets there through a quirk of Add, mod.rs:222-242 / :1098-1142; the canonical result is the same word).
 #pragma once
 
+#include <cstddef>
+#include <type_traits>
+
 #include "gl64.h"
 
 namespace tfk {
@@ -138,7 +141,103 @@ __device__ __forceinline__ u64 table_word(const u64* table, long long i, long lo
 // profiles/r05_microbench_mds_mfma.txt) the f64 matrix pipe does NOT overlap with the vector ALU on gfx950 (it runs at the vector
 // f64 rate and blocks VALU issue), so the gain is what the layout saves -- 8 MFMA (512 cycles) replace 128 v_mad_u64_u32 (~600
 // cycles) per 16 permutations, the round constant and the 85-bit recombination shrink to 6 instructions per word -- not a second pipe.
+#ifndef TF_TIP5_I8
+#define TF_TIP5_I8 1  // 1: the MDS on v_mfma_i32_16x16x64_i8 (round 6); 0: on v_mfma_f64_16x16x4_f64 (round 5; the yardstick of tools/microbench_mds.hip)
+#endif
 typedef double d4 __attribute__((ext_vector_type(4)));
+typedef int v4i __attribute__((ext_vector_type(4)));
+#if TF_TIP5_I8
+// ---- round 6: the MDS on the i8 matrix pipe --------------------------------------------------------------------------------------
+// Same lane layout.  The state goes in byte by byte, the matrix entries as three SIGNED base-256 digits (M = m0 + 256 m1 + 65536 m2,
+// |m| <= 128), and output plane p = a + b (0..9) collects
+//     P_p[r][j] = sum_c sum_{a <= 2} m_a[(r - c) mod 16] * d_{p - a}[c][j],   d_b = (byte b of word c) - 128 = the byte XOR 0x80 as an i8,
+// ONE v_mfma_i32_16x16x64_i8 per plane with K = (c, a): 48 of the 64 products used, |P_p| < 2^20, so
+//     MDS(state)[r] = sum_p 256^p P_p + 128 * (sum of the row) * (2^64 - 1) / 255.
+//   B operand of plane p, lane (j, q), dword i: bytes [d_p, d_{p-1}, d_{p-2}, 0] of word 4 i + q -- one v_perm_b32 with a constant selector
+//     on the word XOR 0x80..80 (two v_xor per word and MDS layer); bytes outside the word select the constant 0;
+//   A operand: digit a of M[(pi(r') - (4 i + q)) mod 16] at byte 4 i + a -- the SAME four registers for all ten planes.  A and B index K by
+//     the same function of (lane >> 4, byte), whatever the hardware's is, so only "lane & 15 = row of A / column of B" is assumed; the row
+//     permutation pi(r') = 4 (r' & 3) + (r' >> 2) makes D row r' (lane (j, r' >> 2), register r' & 3) the word 4 t + q of THIS lane's layout:
+//     nothing moves between lanes;
+//   C operand (from LDS): 2^21 + byte p of (rc + K1 - K2) mod p, K1 the constant above, K2 = 2^21 sum_p 256^p: every plane comes back
+//     non-negative (< 2^22) and the round constant costs nothing.
+// Recombination per word: L0 = Q0 + 2^8 Q1 + 2^16 Q2 + 2^24 Q3 (one v_lshl_add_u32, two v_mad_u64_u32), L1 from Q4..Q7, L2 = Q8 + 2^8 Q9;
+//   value = L0 + 2^32 L1 + 2^64 L2 = L0 + 2^32 lo(L1) + (2^32 - 1) (hi(L1) + L2) (mod p): one add, one v_mad_u64_u32 (< 2^64), then the same
+//   "add to the high word, fold the carry" tail as the f64 form (mx_fold4_tail).  Ten MFMA of 16 cycles instead of eight of 64, and unlike
+//   the f64 pipe the i8 pipe runs BESIDE the vector ALU (profiles/r05_mfma_valu_mix.txt).  Measured (tools/microbench_mds.hip,
+//   profiles/r06_microbench_mds_i8.txt): MDS layer alone 49.6 -> 73.8 G layers/s, whole permutations 5.57 -> 6.42 G/s (+15 %), every word
+//   that of 128-bit arithmetic / of the lane-per-permutation round.
+constexpr u32 kMdsCol[16] = {61402, 1108, 28750, 33823, 7454, 43244, 53865, 12034, 56951, 27521, 41351, 40901, 12021, 59689, 26798, 17845};
+struct Tip5MxConsts {
+    int c[5][10][4][4];  // accumulator starts [round][plane][quarter q][register t] for state word 4 t + q
+    int cf[10][4][4];    // round 0 of a FIXED-LENGTH hash (hash_10 / hash_pair): words 12..15 (register 3 of every lane) are the constant 1
+                         // there (Tip5::new(Domain::FixedLength), mod.rs:511-526; 1^7 = 1): their bytes are left out of B and their MDS
+                         // contribution rides here
+    int cz[10][4][4];    // round 0 of the first permutation of a variable-length sponge: words 12..15 are 0, left out of B
+    int a[64][4];        // the A operand of lane l
+};
+__constant__ Tip5MxConsts g_tip5_mx;
+typedef v4i MxA;
+
+inline int mds_digit(u32 M, int a) {  // signed base-256 digits of a matrix entry
+    const int m0 = (int)(signed char)(M & 0xff);
+    const u32 M1 = (u32)((int)M - m0) >> 8;
+    const int m1 = (int)(signed char)(M1 & 0xff);
+    const u32 M2 = (u32)((int)M1 - m1) >> 8;
+    return a == 0 ? m0 : (a == 1 ? m1 : (int)M2);
+}
+// host side of the table above; rc_mont = Montgomery form of ROUND_CONSTANTS (the g_tip5.rc words)
+inline void fill_tip5_mx(Tip5MxConsts& t, const u64* rc_mont) {
+    typedef unsigned __int128 u128;
+    const u128 ones8 = 0x0101010101010101ULL;  // sum_{b < 8} 256^b
+    u128 k2 = 0;
+    for (int p = 9; p >= 0; --p) k2 = (k2 * 256 + ((u128)1 << 21)) % gl::P;
+    const u64 K2 = (u64)k2;
+    // skip = 1: the words 12..15 are not in B; fixed_one = their value is ONE (0x00000000ffffffff, Montgomery 1) instead of 0
+    const auto starts = [&](int (*dst)[4][4], const u64* rc16, bool skip, bool fixed_one) {
+        for (int q = 0; q < 4; ++q)
+            for (int v = 0; v < 4; ++v) {
+                const int r = 4 * v + q;
+                u64 rowsum = 0, tail = 0;
+                for (int c = 0; c < 16; ++c) (c >= 12 ? tail : rowsum) += kMdsCol[(r - c) & 15];
+                if (!skip) rowsum += tail;
+                u128 adj = (u128)rc16[r] + (u128)(128 * rowsum) % gl::P * (ones8 % gl::P) % gl::P + gl::P - K2;
+                if (skip && fixed_one) adj += (u128)tail * 0xffffffffULL;
+                const u64 x = (u64)(adj % gl::P);
+                for (int p = 0; p < 10; ++p) dst[p][q][v] = (1 << 21) + (p < 8 ? (int)((x >> (8 * p)) & 0xff) : 0);
+            }
+    };
+    for (int round = 0; round < 5; ++round) starts(t.c[round], rc_mont + 16 * round, false, false);
+    starts(t.cf, rc_mont, true, true);
+    starts(t.cz, rc_mont, true, false);
+    for (int l = 0; l < 64; ++l) {
+        const int rp = l & 15, qa = l >> 4, r = 4 * (rp & 3) + (rp >> 2);
+        for (int i = 0; i < 4; ++i) {
+            const u32 M = kMdsCol[(r - (4 * i + qa)) & 15];
+            t.a[l][i] = (int)(((u32)mds_digit(M, 0) & 0xff) | (((u32)mds_digit(M, 1) & 0xff) << 8) | (((u32)mds_digit(M, 2) & 0xff) << 16));
+        }
+    }
+}
+
+struct Tip5MxLds {
+    int c[5][10][4][4];
+    int cf[10][4][4];
+    int cz[10][4][4];
+    unsigned char lut[256];
+};
+
+__device__ __forceinline__ void stage_mx(Tip5MxLds* l) {
+    const int* src = &g_tip5_mx.c[0][0][0][0];
+    int* dst = &l->c[0][0][0][0];
+    for (int i = threadIdx.x; i < (5 + 2) * 160; i += blockDim.x) dst[i] = src[i];  // c, cf, cz are contiguous in both records
+    stage_lut(l->lut);  // ends in __syncthreads()
+}
+static_assert(offsetof(Tip5MxConsts, cf) == 5 * 160 * 4 && offsetof(Tip5MxConsts, cz) == 6 * 160 * 4 && offsetof(Tip5MxLds, cz) == 6 * 160 * 4, "stage_mx copies c, cf, cz as one run");
+
+__device__ __forceinline__ void mx_a_operands(const Tip5MxLds*, MxA& a) {
+    a = *reinterpret_cast<const v4i*>(&g_tip5_mx.a[threadIdx.x & 63][0]);
+}
+#else  // ---- the f64 form of round 5 ------------------------------------------------------------------------------------------------
 
 struct Tip5MxConsts {
     double c[5][4][8];  // accumulator starts [round][quarter q][lo-half reg 0..3 | hi-half reg 0..3] for state word 4 reg + q
@@ -187,11 +286,18 @@ __device__ __forceinline__ void stage_mx(Tip5MxLds* l) {
 }
 
 // per-lane A operands: K-block i, lane (r = l & 15, k = l >> 4) holds M[(r - 4 i - k) mod 16]
-__device__ __forceinline__ void mx_a_operands(const Tip5MxLds* l, double (&a)[4]) {
+struct MxA {
+    double v[4];
+    __device__ __forceinline__ double operator[](int i) const { return v[i]; }
+};
+__device__ __forceinline__ void mx_a_operands(const Tip5MxLds* l, MxA& aa) {
+    double (&a)[4] = aa.v;
     const int lane = threadIdx.x & 63, r = lane & 15, k = lane >> 4;
 #pragma unroll
     for (int i = 0; i < 4; ++i) a[i] = l->t.a[(r - 4 * i - k) & 15];
 }
+
+#endif  // TF_TIP5_I8
 
 // four accumulator registers of the lo-half and hi-half products -> the four state words of this lane.  Word 0 (register 0: the
 // next round's split_and_lookup input, whose bytes must be those of the canonical word) is always made canonical; words 1..3
@@ -200,8 +306,11 @@ __device__ __forceinline__ void mx_a_operands(const Tip5MxLds* l, double (&a)[4]
 // "+ p" is ever needed), and the MDS is linear in the integer value of a word, so a representative that is p too large changes a
 // sum by a multiple of p.  The last round of a permutation runs with CANON: everything that leaves the registers is canonical.
 template <bool CANON>
+__device__ __forceinline__ void mx_fold4_tail(u32 (&tl)[4], u32 (&th)[4], const u32 (&h0)[4], u64* out);
+#if !TF_TIP5_I8
+template <bool CANON>
 __device__ __forceinline__ void mx_fold4(const d4 dlo, const d4 dhi, u64* out) {
-    u32 tl[4], th[4], h0[4], rl[4], rh[4];
+    u32 tl[4], th[4], h0[4];
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
         const u64 rawlo = (u64)__double_as_longlong(dlo[v]), rawhi = (u64)__double_as_longlong(dhi[v]);
@@ -210,6 +319,14 @@ __device__ __forceinline__ void mx_fold4(const d4 dlo, const d4 dhi, u64* out) {
         th[v] = (u32)(t1 >> 32);
         h0[v] = (u32)rawhi;
     }
+    mx_fold4_tail<CANON>(tl, th, h0, out);
+}
+#endif
+// value = (th : tl) + h0 * 2^32, th : tl < 2^63.1 + 2^47: add h0 to the high word (carry k: the value is t + k 2^64 = t + k (2^32 - 1)),
+// fold the carry; word 0 canonical always, words 1..3 when CANON
+template <bool CANON>
+__device__ __forceinline__ void mx_fold4_tail(u32 (&tl)[4], u32 (&th)[4], const u32 (&h0)[4], u64* out) {
+    u32 rl[4], rh[4];
     u64 ka, kb, kc, kd, ea, na, nb, nc, nd;
     if constexpr (CANON) {
         u64 eb, ec, ed;
@@ -277,8 +394,10 @@ __device__ __forceinline__ void mx_fold4(const d4 dlo, const d4 dhi, u64* out) {
 // One round on NS permutations per lane quartet: s[4 n + i] = word 4 i + q of the permutation in column j of column block n.
 // the canonical recombination of words 0 and 1 only: the last round of hash_10 / hash_pair, whose digest is state words 0..4
 // (registers 0 of the four quarters and register 1 of quarter 0)
+__device__ __forceinline__ void mx_fold2_tail(u32 (&tl)[2], u32 (&th)[2], const u32 (&h0)[2], u64* out);
+#if !TF_TIP5_I8
 __device__ __forceinline__ void mx_fold2_canon(const d4 dlo, const d4 dhi, u64* out) {
-    u32 tl[2], th[2], h0[2], rl[2], rh[2];
+    u32 tl[2], th[2], h0[2];
 #pragma unroll
     for (int v = 0; v < 2; ++v) {
         const u64 rawlo = (u64)__double_as_longlong(dlo[v]), rawhi = (u64)__double_as_longlong(dhi[v]);
@@ -287,6 +406,11 @@ __device__ __forceinline__ void mx_fold2_canon(const d4 dlo, const d4 dhi, u64* 
         th[v] = (u32)(t1 >> 32);
         h0[v] = (u32)rawhi;
     }
+    mx_fold2_tail(tl, th, h0, out);
+}
+#endif
+__device__ __forceinline__ void mx_fold2_tail(u32 (&tl)[2], u32 (&th)[2], const u32 (&h0)[2], u64* out) {
+    u32 rl[2], rh[2];
     u64 ka, kb, ea, eb, na, nb;
     asm("v_add_co_u32_e64 %[tha], %[ka], %[tha], %[h0a]\n\t"
         "v_add_co_u32_e64 %[thb], %[kb], %[thb], %[h0b]\n\t"
@@ -318,7 +442,7 @@ __device__ __forceinline__ void mx_fold2_canon(const d4 dlo, const d4 dhi, u64* 
 // contribution at all).  The same words as the general round on such a state -- one Montgomery chain of three and 2 of the 8 MFMA
 // saved in one round of five.
 template <int NS, bool LAST, int FIXED0 = 0, bool DIGEST = false>
-__device__ __forceinline__ void tip5_round_mx(u64 (&s)[4 * NS], int round, const Tip5MxLds* l, const double (&a)[4], int q) {
+__device__ __forceinline__ void tip5_round_mx(u64 (&s)[4 * NS], int round, const Tip5MxLds* l, const MxA& a, int q) {
 #pragma unroll
     for (int n = 0; n < NS; ++n) {  // split_and_lookup (mod.rs:197-207): words 0..3 = register 0 of the four quarters
         const u32 lo = lookup4((u32)s[4 * n], l->lut), hi = lookup4((u32)(s[4 * n] >> 32), l->lut);
@@ -341,6 +465,61 @@ __device__ __forceinline__ void tip5_round_mx(u64 (&s)[4 * NS], int round, const
             s[4 * n + 1] = x[0], s[4 * n + 2] = x[1], s[4 * n + 3] = x[2];
         }
     }
+#if TF_TIP5_I8
+    // ---- the MDS on the i8 matrix pipe (see Tip5MxConsts): ten planes, one MFMA each
+    const int* cp = FIXED0 == 1 ? &l->cf[0][q][0] : (FIXED0 == 2 ? &l->cz[0][q][0] : &l->c[round][0][q][0]);  // [plane][q][t]: 16 ints per plane
+    constexpr int NW = FIXED0 ? 3 : 4;  // registers that go into B (FIXED0: register 3 -- words 12..15 -- is a constant, folded into the starts)
+    u32 wl[NS][4], wh[NS][4];
+#pragma unroll
+    for (int n = 0; n < NS; ++n)
+#pragma unroll
+        for (int i = 0; i < NW; ++i) wl[n][i] = (u32)s[4 * n + i] ^ 0x80808080u, wh[n][i] = (u32)(s[4 * n + i] >> 32) ^ 0x80808080u;
+    v4i d[NS][10];
+    const auto plane = [&](auto pc) {
+        constexpr int P = decltype(pc)::value;
+        // bytes [P, P - 1, P - 2, zero] of the word hi : lo; a byte outside the word selects the constant 0 (selector 0x0c)
+        constexpr u32 s0 = (P <= 7) ? (u32)P : 0x0cu, s1 = (P >= 1 && P - 1 <= 7) ? (u32)(P - 1) : 0x0cu, s2 = (P >= 2 && P - 2 <= 7) ? (u32)(P - 2) : 0x0cu;
+        constexpr u32 sel = s0 | (s1 << 8) | (s2 << 16) | (0x0cu << 24);
+        const v4i c = *reinterpret_cast<const v4i*>(cp + P * 16);
+#pragma unroll
+        for (int n = 0; n < NS; ++n) {
+            v4i b;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) b[i] = i < NW ? (int)__builtin_amdgcn_perm(wh[n][i], wl[n][i], sel) : 0;
+            d[n][P] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, c, 0, 0, 0);
+        }
+    };
+    plane(std::integral_constant<int, 0>{}); plane(std::integral_constant<int, 1>{}); plane(std::integral_constant<int, 2>{});
+    plane(std::integral_constant<int, 3>{}); plane(std::integral_constant<int, 4>{}); plane(std::integral_constant<int, 5>{});
+    plane(std::integral_constant<int, 6>{}); plane(std::integral_constant<int, 7>{}); plane(std::integral_constant<int, 8>{});
+    plane(std::integral_constant<int, 9>{});
+    // ---- recombination: (th : tl) = L0 + (2^32 - 1) (hi(L1) + L2), h0 = lo(L1), then the shared tail
+    // x * y + z as ONE v_mad_u64_u32.  NOT inline assembly: these are the first readers of the MFMA results, and the compiler only counts
+    // the wait states between a matrix instruction and a reader it can see (an asm block reading d[] too early returned garbage in the
+    // two-permutations-per-quartet build of tools/microbench_mds.hip).  The multipliers are made opaque instead (an SGPR the optimiser
+    // cannot see through), so that the products by 2^16 / 2^24 are not strength-reduced into 64-bit shift-and-add sequences.
+    u32 k16 = 1u << 16, k24 = 1u << 24, kff = 0xffffffffu;
+    asm volatile("" : "+s"(k16), "+s"(k24), "+s"(kff));
+    const auto mad = [](u32 x, u32 y, u64 z) { return (u64)x * y + z; };
+#pragma unroll
+    for (int n = 0; n < NS; ++n) {
+        constexpr int NT = DIGEST ? 2 : 4;  // (words 8..15 of the final state are not part of a digest)
+        u32 tl[NT], th[NT], h0[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const auto Q = [&](int p) { return (u32)d[n][p][t]; };
+            u64 L0 = mad(Q(2), k16, (u64)((Q(1) << 8) + Q(0)));
+            L0 = mad(Q(3), k24, L0);
+            u64 L1 = mad(Q(6), k16, (u64)((Q(5) << 8) + Q(4)));
+            L1 = mad(Q(7), k24, L1);
+            const u32 hsum = (u32)(L1 >> 32) + ((Q(9) << 8) + Q(8));  // < 2^15 + 2^31
+            const u64 u = mad(hsum, kff, L0);                           // < 2^64: hsum (2^32 - 1) < 2^63.1, L0 < 2^47
+            tl[t] = (u32)u, th[t] = (u32)(u >> 32), h0[t] = (u32)L1;
+        }
+        if constexpr (DIGEST) mx_fold2_tail(tl, th, h0, &s[4 * n]);
+        else mx_fold4_tail<LAST>(tl, th, h0, &s[4 * n]);
+    }
+#else
     const d4* cp = reinterpret_cast<const d4*>(FIXED0 == 1 ? &l->t.cf[q][0] : &l->t.c[round][q][0]);
     const d4 c_lo = cp[0], c_hi = cp[1];
     d4 dlo[NS], dhi[NS];
@@ -358,10 +537,11 @@ __device__ __forceinline__ void tip5_round_mx(u64 (&s)[4 * NS], int round, const
         if constexpr (DIGEST) mx_fold2_canon(dlo[n], dhi[n], &s[4 * n]);  // (words 8..15 of the final state are not part of a digest)
         else mx_fold4<LAST>(dlo[n], dhi[n], &s[4 * n]);
     }
+#endif
 }
 
 template <int NS>
-__device__ __forceinline__ void tip5_permutation_mx(u64 (&s)[4 * NS], const Tip5MxLds* l, const double (&a)[4], int q) {
+__device__ __forceinline__ void tip5_permutation_mx(u64 (&s)[4 * NS], const Tip5MxLds* l, const MxA& a, int q) {
 #pragma unroll 1
     for (int r = 0; r < 4; ++r) tip5_round_mx<NS, false>(s, r, l, a, q);
     tip5_round_mx<NS, true>(s, 4, l, a, q);
@@ -371,7 +551,7 @@ __device__ __forceinline__ void tip5_permutation_mx(u64 (&s)[4 * NS], const Tip5
 // quarters 2 and 3); register 3 need not even be initialised by the caller.  On exit only registers 0 and 1 (state words 0..7, of
 // which 0..4 are the digest) are defined.
 template <int NS>
-__device__ __forceinline__ void tip5_permutation_mx_fixed(u64 (&s)[4 * NS], const Tip5MxLds* l, const double (&a)[4], int q) {
+__device__ __forceinline__ void tip5_permutation_mx_fixed(u64 (&s)[4 * NS], const Tip5MxLds* l, const MxA& a, int q) {
     tip5_round_mx<NS, false, 1>(s, 0, l, a, q);
 #pragma unroll 1
     for (int r = 1; r < 4; ++r) tip5_round_mx<NS, false>(s, r, l, a, q);
@@ -380,7 +560,7 @@ __device__ __forceinline__ void tip5_permutation_mx_fixed(u64 (&s)[4 * NS], cons
 
 // the permutations of a variable-length sponge: FIRST = capacity words still 0 on entry, FINAL = only the digest is read afterwards
 template <int NS, bool FIRST, bool FINAL>
-__device__ __forceinline__ void tip5_permutation_mx_sponge(u64 (&s)[4 * NS], const Tip5MxLds* l, const double (&a)[4], int q) {
+__device__ __forceinline__ void tip5_permutation_mx_sponge(u64 (&s)[4 * NS], const Tip5MxLds* l, const MxA& a, int q) {
     tip5_round_mx<NS, false, FIRST ? 2 : 0>(s, 0, l, a, q);
 #pragma unroll 1
     for (int r = 1; r < 4; ++r) tip5_round_mx<NS, false>(s, r, l, a, q);
@@ -410,7 +590,7 @@ __device__ __forceinline__ void split_item(long long i, long long per_tree, int 
     __shared__ __attribute__((aligned(32))) Tip5MxLds lds;                                             \
     stage_mx(&lds);                                                                                    \
     const int lane = threadIdx.x & 63, j = lane & 15, q = lane >> 4;                                   \
-    double a[4];                                                                                       \
+    MxA a;                                                                                             \
     mx_a_operands(&lds, a)
 #define TF_MX_GROUPS(COUNT)                                                                            \
     for (long long base = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * (16 * NS); base < (COUNT); \
@@ -445,7 +625,7 @@ __global__ void __launch_bounds__(256) tip5_hash_pairs_mx_kernel(const u64* in, 
     };
     if (first < count) fetch(first);
     stage_mx(&lds);
-    double a[4];
+    MxA a;
     mx_a_operands(&lds, a);
     for (long long base = first; base < count; base += step) {
         u64 s[4 * NS];
