@@ -842,17 +842,23 @@ int tfo_merkle_build_par(const uint64_t *leaves, size_t n, uint64_t *nodes, int 
         while (num_threads > num_remaining / 2) num_threads /= 2; /* :181-183 */
         subtree_job_t *jobs = (subtree_job_t *)malloc(sizeof(subtree_job_t) * num_threads);
         pthread_t *tid = (pthread_t *)malloc(sizeof(pthread_t) * num_threads);
+        char *made = (char *)calloc(num_threads, 1);
+        /* every subtree is a job of its own (it owns its slice of the node array): a thread that cannot be created -- a cgroup-limited
+         * host, or no memory for the bookkeeping -- is not joined, and its subtree is built inline by the caller instead */
         for (size_t t = 0; t < num_threads; t++) {
-            jobs[t] = (subtree_job_t){nodes, num_remaining, num_threads, t};
-            if (num_threads == 1)
-                subtree_worker(&jobs[t]);
-            else
-                pthread_create(&tid[t], NULL, subtree_worker, &jobs[t]);
+            if (jobs) jobs[t] = (subtree_job_t){nodes, num_remaining, num_threads, t};
+            if (jobs && tid && made && num_threads > 1 && pthread_create(&tid[t], NULL, subtree_worker, &jobs[t]) == 0) {
+                made[t] = 1;
+            } else {
+                subtree_job_t mine = {nodes, num_remaining, num_threads, t};
+                subtree_worker(&mine);
+            }
         }
-        if (num_threads > 1)
-            for (size_t t = 0; t < num_threads; t++) pthread_join(tid[t], NULL);
+        for (size_t t = 0; t < num_threads; t++)
+            if (made && made[t]) pthread_join(tid[t], NULL);
         free(jobs);
         free(tid);
+        free(made);
         size_t cur_h = 0, th = 0;
         for (size_t v = num_remaining; v > 1; v >>= 1) cur_h++;
         for (size_t v = num_threads; v > 1; v >>= 1) th++;

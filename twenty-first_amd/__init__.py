@@ -205,6 +205,8 @@ def fast_coset_evaluate(coeffs: np.ndarray, offset_raw, order: int, width: int =
     out = np.empty(batch * order * width, dtype=np.uint64)
     xoff = _xfe_offset(offset_raw, width)
     if xoff is not None:  # S = XFieldElement (:1374-1378)
+        if devices is not None:  # (this used to run on the current GPU only, without saying so)
+            raise NotImplementedError("fast_coset_evaluate with an XFieldElement offset is a single-device call: there is no tf_coset_eval_xfe_xoffset_multi")
         _check(lib().tf_coset_eval_xfe_xoffset(_ptr(coeffs), n_coeffs, _ptr(xoff), _ptr(out), order, batch), "fast_coset_evaluate")
         return out
     offset_raw = int(np.asarray(offset_raw).reshape(-1)[0])

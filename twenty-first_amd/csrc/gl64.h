@@ -364,8 +364,11 @@ __device__ __forceinline__ void mont_mul2(u64 a, u64 b, u64 c, u64 d, u64& ab, u
 #if defined(__HIPCC__)
 // Four independent Montgomery products per block: the same fifteen VALU instructions per product as mont_mul2, but the four
 // carry chains are issued round-robin, so every carry mask is read four instructions after it was written and the block needs
-// none of the seven wait-state s_nop per pair that mont_mul2 spends.  First operands may be any 64-bit representatives, second
-// operands canonical; canonical results.
+// none of the seven wait-state s_nop per pair that mont_mul2 spends.  Operand contract: ANY two 64-bit words are multiplied
+// correctly -- montyred's subtrahend is < p whatever the 128-bit product, so the result is always a valid 64-bit representative of
+// a b 2^-64 --; the result is CANONICAL when at least one operand is (the product is then < p 2^64 and montyred returns a word < p).
+// The NTT kernels rely on the canonical case (lazy first operand x canonical twiddle), Tip5's x^7 on the general one (both operands
+// any representative, result any representative; tools/microbench_mds.hip checks it on operands in [p, 2^64), mask 16).
 #ifndef TF_MONT4
 #define TF_MONT4 1
 #endif
@@ -430,7 +433,8 @@ __device__ __forceinline__ void mont_mul4(const u64 (&a)[4], const u64 (&b)[4], 
 
 // Three independent Montgomery products per block (the three x^7 words a lane owns in the matrix-pipe Tip5 layout): mont_mul4
 // without its third chain.  Round-robin over three chains still puts two instructions between a carry mask's write and its read,
-// which is what gfx950 wants, so this block needs no s_nop either.  Same operand contract as mont_mul4.
+// which is what gfx950 wants, so this block needs no s_nop either.  Same operand contract as mont_mul4: any 64-bit operands, a valid
+// representative out, canonical when one operand is canonical -- tip5_round_mx squares non-canonical words with it.
 __device__ __forceinline__ void mont_mul3(const u64 (&a)[3], const u64 (&b)[3], u64 (&r)[3]) {
     u64 p[3], h[3], m[3], cm[3];
 #pragma unroll

@@ -89,6 +89,7 @@ extern DeviceCtx g_ctx[kMaxDevices];
 
 // ------------------------------------------------------------------------------------ tf_ntt.hip
 int current_ctx(DeviceCtx** out);
+int device_cus();  // compute units of the calling thread's CURRENT device (cached per device; 256 if the runtime will not say)
 hipError_t pool_malloc_async(void** p, size_t bytes, hipStream_t stream);  // every stream-ordered temporary of the library
 int scratch_acquire(DeviceCtx* ctx, size_t bytes, hipStream_t stream, DeviceCtx::ScratchBlock* out);
 void scratch_release(DeviceCtx* ctx, DeviceCtx::ScratchBlock blk, hipStream_t stream);

@@ -43,6 +43,26 @@ constexpr size_t kPowCacheBudget = size_t(1) << 30;    // offset^j tables (n_coe
 
 DeviceCtx g_ctx[kMaxDevices];
 
+// Grids that are sized from the CU count (launch_rows32, mx_blocks) take the CURRENT device's: round 5 cached the count of whichever
+// device made the first call, which on a heterogeneous or partitioned node sized every other device's grids wrong (only
+// speed was at stake -- those kernels walk their work with a grid stride).
+int device_cus() {
+    static std::atomic<int> cus[kMaxDevices];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) {
+        (void)hipGetLastError();
+        return 256;
+    }
+    int n = cus[dev].load(std::memory_order_relaxed);
+    if (n > 0) return n;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        n = 256;
+    }
+    cus[dev].store(n, std::memory_order_relaxed);
+    return n;
+}
+
 int current_ctx(DeviceCtx** out) {
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
@@ -1251,11 +1271,7 @@ int launch_rows32(const u64* in, u64* out, size_t batch, int L, int log_n, bool 
         return TF_OK;
     }
 #endif
-    static const int cus = [] {  // (the devices of a node are alike)
-        int dev = 0, n = 256;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) (void)hipGetLastError();
-        return n > 0 ? n : 256;
-    }();
+    const int cus = device_cus();
     tfk::NttRows32Args a{};
     a.in = in;
     a.out = out;

@@ -52,6 +52,7 @@ int ensure_tip5(DeviceCtx* ctx) {
 // matrix-pipe form (4 lanes per permutation, MDS on v_mfma_f64_16x16x4_f64): measured crossover 2^13 chains
 // (profiles/r05_tip5_small_times.txt: hash_varlen of 33 words, 2^13 rows 24.4 vs 25.6 us, 2^14 rows 34.6 vs 26.3 us).
 constexpr long long kCoopMaxCount = 1ll << 13;
+static_assert(kCoopMaxCount >= 64 && (kCoopMaxCount & (kCoopMaxCount - 1)) == 0, "a power of two: the level at which a tree narrows is found by halving");
 
 // per_tree = 2^shift, or -1
 inline int shift_of(long long per_tree) { return (per_tree > 0 && !(per_tree & (per_tree - 1))) ? __builtin_ctzll((unsigned long long)per_tree) : -1; }
@@ -62,11 +63,7 @@ inline int shift_of(long long per_tree) { return (per_tree > 0 && !(per_tree & (
 // the 2^24-leaf tree: 4.87 / 5.00 / 5.06 / 5.07 / 5.06 G leaves/s, profiles/r05_tip5_grid_cap.txt)
 constexpr long long kMxBlocksPerCu = 56;
 inline unsigned mx_blocks(long long count) {
-    static const long long cap = [] {
-        int dev = 0, cus = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-        return (long long)cus * kMxBlocksPerCu;
-    }();
+    const long long cap = (long long)device_cus() * kMxBlocksPerCu;
     const long long want = (count + 63) / 64;
     return (unsigned)(want < cap ? want : cap);
 }
@@ -178,6 +175,11 @@ int check_leaves(size_t n) {
 #define TF_SUBTREE_MAX_LOG 6
 #endif
 constexpr int kSubtreeMaxLog = TF_SUBTREE_MAX_LOG;
+// What the subtree launches assume about the two constants: merkle_subtree_kernel keeps two levels of at most 2^8 digests in
+// LDS (buf[2][256 * 5]); merkle_narrow_levels lays its two scratch halves out for launches that shrink a level by >= 16 x -- with
+// several launches (>= kSubtreeMaxLog + 1 levels) every launch but the last takes ceil(levels / launches) >= 4 levels only if
+// kSubtreeMaxLog >= 4 --, and it is entered with at most 2 kCoopMaxCount digests per call above kTopWidth.
+static_assert(kSubtreeMaxLog >= 4 && kSubtreeMaxLog <= 8, "merkle_subtree_kernel's LDS buffer and merkle_narrow_levels' scratch layout");
 constexpr long long kTopWidth = 1ll << kSubtreeMaxLog;  // a tree of at most this many leaves is one merkle_top_kernel launch
 
 inline int ilog2ll(long long v) { return 63 - __builtin_clzll((unsigned long long)v); }
