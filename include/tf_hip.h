@@ -405,7 +405,9 @@ size_t tf_get_ntt_tile_bytes(void);
 /*   TF_NTT_PIPE       : K = 1..4 side streams the batch tiles of a multi-pass NTT are dealt to round-robin (each with its own
  *                       scratch tile), so the column pass of tile t + 1 overlaps the transposing pass of tile t and a tile
  *                       sized for the Infinity Cache is re-read out of it; the caller's stream forks/joins with events. */
-void tf_set_ntt_pipe(int streams);  /* K > 1 is for ONE caller per device: all callers share the device's K side streams */
+void tf_set_ntt_pipe(int streams);  /* 0 = automatic (the default: two streams for the two-pass plans of 2^21 / 2^22 points when a call has
+                                     * several batch tiles, one otherwise; profiles/r06_pipe_tiles.txt).  All callers of a device share
+                                     * its K side streams: concurrent callers stay correct (event forks / joins) but wait for each other */
 int tf_get_ntt_pipe(void);
 
 /* ---------------------------------------------------------------------------------------------

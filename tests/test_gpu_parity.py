@@ -793,7 +793,7 @@ def test_pipelined_batch_tiles_are_bit_exact(tf, oracle, tile_mib, pipe):
             assert np.array_equal(_to_host(out[b * 3 * 4096:(b + 1) * 3 * 4096]), oracle.coset_evaluate(c[b * 3000:(b + 1) * 3000], oracle.bfe_new(7), 4096, width=3))
     finally:
         L.tf_set_ntt_tile_bytes(0)
-        L.tf_set_ntt_pipe(1)
+        L.tf_set_ntt_pipe(0)  # automatic
 
 
 def test_wrapper_size_checks_raise_before_the_abi(tf):

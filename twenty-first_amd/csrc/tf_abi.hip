@@ -186,7 +186,7 @@ void tf_set_ntt_nt(int mask) {
 #endif
 void tf_set_ntt_pipe(int streams) {
     read_env();
-    g_pipe.store(std::min(std::max(streams, 1), kMaxPipe), std::memory_order_relaxed);
+    g_pipe.store(std::min(std::max(streams, 0), kMaxPipe), std::memory_order_relaxed);  // 0 = automatic
 }
 int tf_get_ntt_pipe(void) {
     read_env();

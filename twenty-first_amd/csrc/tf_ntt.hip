@@ -275,10 +275,9 @@ void read_env() {
             g_tile_bytes = s ? strtoull(s, nullptr, 10) : (size_t(2048) << 20);
             if (g_tile_bytes == 0) g_tile_bytes = size_t(2048) << 20;
         }
-        if (g_pipe.load() == 0) {
+        if (g_pipe.load() == 0) {  // 0 = automatic (run_ntt decides by plan); TF_NTT_PIPE / tf_set_ntt_pipe pin it
             const char* s = getenv("TF_NTT_PIPE");
-            const int k = s ? atoi(s) : 1;
-            g_pipe.store(std::min(std::max(k, 1), kMaxPipe));
+            if (s && atoi(s) > 0) g_pipe.store(std::min(atoi(s), kMaxPipe));
         }
         if (g_nt.load() < 0) {
             const char* s = ab_env("TF_NTT_NT");
@@ -1635,7 +1634,13 @@ int run_ntt(DeviceCtx* ctx, const u64* in, u64* out, long long in_bs, long long 
     // the side streams before the first tile and joins them after the last (event edges only, no host synchronisation)
     const size_t ntiles = (batch + tb - 1) / tb;
     tb = (batch + ntiles - 1) / ntiles;  // equal tiles: 64 polynomials at 21 per tile are 4 x 16, not 21 + 21 + 21 + 1
-    int K = (P < 4) ? (int)std::min<size_t>((size_t)g_pipe.load(std::memory_order_relaxed), ntiles) : 1;
+    // Automatic (round 6, profiles/r06_pipe_tiles.txt): two streams for the two-pass plans of 2^21 / 2^22 points -- their first pass is bound
+    // by the memory pipe (0.68-0.76 of the issue slots busy) and their last pass by the vector ALU (0.80), so tile t + 1's first pass beside
+    // tile t's last pass gains 2.6-3.4 % (configs[3] 7.27-7.36 -> 7.06-7.08 ms, 64 x 2^22 XFE ntt 6.67 -> 6.49) -- and one stream for
+    // everything else (1024 x 2^20 BFE: 7.20-7.30 vs 7.24-7.32 ms, both passes VALU-bound).
+    int pipe = g_pipe.load(std::memory_order_relaxed);
+    if (pipe <= 0) pipe = (P == 2 && log_n >= 21) ? 2 : 1;
+    int K = (P < 4) ? (int)std::min<size_t>((size_t)pipe, ntiles) : 1;
     hipStream_t side[kMaxPipe] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[kMaxPipe] = {nullptr, nullptr, nullptr, nullptr};
     if (K > 1) {
