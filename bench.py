@@ -401,6 +401,7 @@ def summary_block(out):
             if isinstance(cp.get(part), dict):
                 sm["commit_pipeline"][part + "_ms"] = cp[part].get("ms")
                 sm["commit_pipeline"][part + "_frac"] = (cp[part].get("roofline") or {}).get("frac")
+        sm["commit_pipeline"]["lde_traffic_x"] = (cp.get("lde", {}).get("roofline") or {}).get("traffic_over_compulsory")
     sm["n_gpus"] = out.get("n_gpus")
     sm["library"] = (out.get("roofline") or {}).get("profile_matches_library", {}).get("library", {}).get("source_hash")
     return sm
@@ -674,22 +675,24 @@ def merkle_leg(ctx):
     vc = load_profile_json("valu_counts.json")
     res["profile_matches_library"] = {"valu_counts.json": bool(vc) and profile_matches(vc, ctx["ident"])}
     if vc and profile_matches(vc, ctx["ident"]) and vc.get("merkle_valu_wave_instr_per_tree_2p24") and log_nl == 24:
-        # Issue-cycle roofline of the level sweep.  The f64 matrix pipe of gfx950 does not run beside the vector ALU (measured:
-        # profiles/r05_mfma_valu_mix.txt, both = sum), so one SIMD offers one stream of issue cycles: 64 per v_mfma_f64_16x16x4_f64,
-        # 4 per other VALU instruction.  Counts: SQ_INSTS_VALU (which includes the MFMAs) and SQ_INSTS_MFMA of a stored profile.
+        # Vector-ALU roofline of the level sweep.  Since round 6 the MDS runs on v_mfma_i32_16x16x64_i8, a pipe that -- unlike the f64 one --
+        # works BESIDE the vector ALU (profiles/r05_mfma_valu_mix.txt): the bound is the vector instructions alone, 4 issue cycles each;
+        # the matrix pipe's own occupancy (16 cycles per MFMA) is reported beside it.  Counts: SQ_INSTS_VALU (which includes the MFMAs)
+        # and SQ_INSTS_MFMA of a stored profile of this library build.
         wi = vc["merkle_valu_wave_instr_per_tree_2p24"]
         mf = vc.get("merkle_mfma_wave_instr_per_tree_2p24") or 0.0
         secs = e0.elapsed_time(e1) / iters * 1e-3
-        cyc = 4.0 * (wi - mf) + 64.0 * mf
+        cyc = 4.0 * (wi - mf)
         g = cyc / secs / 1e9
         peak = 1024 * 2.4  # G issue cycles / s: 1024 SIMDs x 2.4 GHz
-        res["roofline"] = {"bound": "valu", "kernel": "tfk::tip5_hash_pairs_mx_kernel (level sweep, 4 lanes per permutation, MDS on v_mfma_f64_16x16x4_f64) + 16-lane kernels near the top",
-                           "achieved": round(g, 1), "peak": round(peak, 1), "unit": "G issue cycles/s (4 per VALU instruction, 64 per f64 MFMA)", "frac": round(g / peak, 3),
+        res["roofline"] = {"bound": "valu", "kernel": "tfk::tip5_hash_pairs_mx_kernel (level sweep, 4 lanes per permutation, MDS on v_mfma_i32_16x16x64_i8) + 16-lane kernels near the top",
+                           "achieved": round(g, 1), "peak": round(peak, 1), "unit": "G vector-ALU issue cycles/s (4 per VALU instruction)", "frac": round(g / peak, 3),
+                           "matrix_pipe_frac": round(16.0 * mf / secs / 1e9 / peak, 3),
                            "valu_wave_instr_per_tree": wi, "mfma_wave_instr_per_tree": mf,
                            "valu_instr_per_hash_pair_per_lane_quartet": round((wi - mf) * 16.0 / (nl - 1), 1), "mfma_per_16_hash_pairs": round(mf * 16.0 / (nl - 1), 2),
-                           "status": "per 16 hash_pairs and round: 8 MFMA (512 cycles) + ~220 VALU instructions (180 of them the twelve x^7 = 36 Montgomery products "
-                                     "per quartet column, the rest byte look-ups, 8 conversions and the 6-instruction recombinations); frac < 1 is the clock "
-                                     "the chip holds under this mix and the ramp of the small levels, not idle issue slots (DESIGN.md 4.3)",
+                           "status": "per 16 hash_pairs and round: 10 i8 MFMA (160 cycles, beside the vector ALU) + ~325 VALU instructions (180 of them the twelve x^7 = 36 "
+                                     "Montgomery products per quartet column, 48 the byte windows of the ten planes, 56 + 20 their recombination, the rest byte look-ups); "
+                                     "frac < 1 is the clock the chip holds under this mix and the ramp of the small levels (DESIGN.md 4.3)",
                            "source": "instruction counts: SQ_INSTS_VALU / SQ_INSTS_MFMA under rocprofv3 --pmc (profiles/valu_counts.json, a stored profile of this library build, "
                                      "NOT this run) x this run's time; peak = 1024 SIMDs x 2.4 GHz"}
     if use_dist and world & (world - 1) == 0:
@@ -1024,7 +1027,7 @@ def commit_pipeline_leg(ctx):
     lde_ms, tree_ms = lde_ms / iters, tree_ms / iters
     row_len = cols
     perms = m * (row_len // 10 + 1) + (m - 1)  # hash_varlen of a 128-word row absorbs 13 chunks (12 full + the padded one); the tree adds m - 1
-    lde_bytes = 16.0 * cols * (n + m)          # 16 B per element and transform (iNTT over 2^18, NTT over 2^21)
+    lde_bytes = 8.0 * cols * (n + m)           # compulsory: 2^18 words read and 2^21 words written per column (verdict r5 item 6)
     res = {
         "metric": "commit_pipeline_rows_per_s", "value": round(m / ((lde_ms + tree_ms) * 1e-3), 1), "unit": "rows/s",
         "ms_per_step": round(lde_ms + tree_ms, 4), "wall_ms_per_step": round(wall_ms, 4),
@@ -1033,19 +1036,28 @@ def commit_pipeline_leg(ctx):
         "lde": {"ms": round(lde_ms, 4), "g_points_per_s": round(cols * m / lde_ms / 1e6, 3),
                 "roofline": {"bound": "hbm", "achieved": round(lde_bytes / (lde_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": round(lde_bytes / (lde_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes": lde_bytes,
-                             "note": "16 B per element and transform: the inverse transforms over 2^18 points and the forward transforms over 2^21 points (the zero-padded "
-                                     "7/8 of every forward input is never read from HBM, so this counts bytes the kernels do not move: a ceiling on the fraction)"}},
+                             "note": "compulsory bytes of the whole low-degree extension: every column's 2^18 values read once, its 2^21 evaluations written once "
+                                     "(8 B each).  The kernels move more: two passes of the inverse transform over 2^18 points and two of the 8-coset forward "
+                                     "transform, whose first pass reads the coefficients once per coset -- `traffic` below is what the memory side saw"}},
         "rows_and_tree": {"ms": round(tree_ms, 4), "permutations": perms, "g_permutations_per_s": round(perms / tree_ms / 1e6, 3),
                           "hbm_frac": round((8.0 * cols * m + 120.0 * m) / (tree_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
     }
-    vc = load_profile_json("valu_counts.json")
-    if vc and profile_matches(vc, ctx["ident"]) and vc.get("merkle_valu_wave_instr_per_tree_2p24"):
-        wi, mf = vc["merkle_valu_wave_instr_per_tree_2p24"], vc.get("merkle_mfma_wave_instr_per_tree_2p24") or 0.0
-        cyc_per_perm = (4.0 * (wi - mf) + 64.0 * mf) / float((1 << 24) - 1)  # SIMD issue cycles per permutation, from the 2^24-leaf tree's counters
-        g = perms * cyc_per_perm / (tree_ms * 1e-3) / 1e9
-        res["rows_and_tree"]["roofline"] = {"bound": "valu", "achieved": round(g, 1), "peak": round(1024 * 2.4, 1), "unit": "G issue cycles/s (4 per VALU instruction, 64 per f64 MFMA)",
-                                            "frac": round(g / (1024 * 2.4), 3), "issue_cycles_per_permutation": round(cyc_per_perm, 1),
-                                            "source": "per-permutation instruction counts of the 2^24-leaf tree (profiles/valu_counts.json, a stored profile of this library build) x this run's permutations and time"}
+    pj = load_profile_json("pipeline_counters.json")  # tools/prof_r02.sh on tools/prof_target.py --pipeline (make_profile_records.py)
+    if pj and profile_matches(pj, ctx["ident"]):
+        if pj.get("lde_hbm_bytes_per_call"):
+            res["lde"]["roofline"]["traffic"] = pj["lde_hbm_bytes_per_call"]
+            res["lde"]["roofline"]["traffic_over_compulsory"] = round(pj["lde_hbm_bytes_per_call"] / lde_bytes, 2)
+            res["lde"]["roofline"]["traffic_source"] = "profiles/pipeline_counters.json (FETCH_SIZE x 2 + WRITE_SIZE of the LDE's kernels, a stored profile of this library build)"
+            res["lde"]["per_kernel"] = pj.get("lde_kernels")
+        if pj.get("rows_valu_wave_instr_per_call"):
+            wi, mf = pj["rows_valu_wave_instr_per_call"], pj.get("rows_mfma_wave_instr_per_call") or 0.0
+            g = 4.0 * (wi - mf) / (tree_ms * 1e-3) / 1e9
+            res["rows_and_tree"]["roofline"] = {"bound": "valu", "achieved": round(g, 1), "peak": round(1024 * 2.4, 1), "unit": "G vector-ALU issue cycles/s (4 per VALU instruction)",
+                                                "frac": round(g / (1024 * 2.4), 3), "matrix_pipe_frac": round(16.0 * mf / (tree_ms * 1e-3) / 1e9 / (1024 * 2.4), 3),
+                                                "valu_instr_per_permutation_per_lane_quartet": round((wi - mf) * 16.0 / perms, 1),
+                                                "per_kernel": pj.get("rows_kernels"),
+                                                "source": "SQ_INSTS_VALU / SQ_INSTS_MFMA of tip5_hash_table_rows_mx_kernel and the tree's kernels under rocprofv3 --pmc "
+                                                          "(profiles/pipeline_counters.json, a stored profile of this library build) x this run's time"}
     if args.no_cpu_baseline:
         res["parity"] = "not checked (--no-cpu-baseline)"
         res["cpu_baseline"] = None

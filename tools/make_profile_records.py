@@ -60,7 +60,7 @@ if trees:
     if mtrees:
         rec["merkle_mfma_wave_instr_per_tree_2p24"] = mfma / mtrees
         rec["merkle_mfma_busy_cycles_per_tree_2p24"] = mfma_busy / mtrees
-        rec["merkle_note"] = ("SQ_INSTS_VALU counts the v_mfma_f64_16x16x4_f64 of the matrix-pipe Tip5 kernels as VALU instructions; per 16 hash_pairs "
+        rec["merkle_note"] = ("SQ_INSTS_VALU counts the v_mfma_i32_16x16x64_i8 of the matrix-pipe Tip5 kernels as VALU instructions; per 16 hash_pairs "
                               "(one wave): %.1f VALU instructions of which %.1f MFMA" % (m * 16 / (2 ** 24 - 1), mfma / mtrees * 16 / (2 ** 24 - 1)))
 else:  # NTT-only profile: keep the Merkle figures of the last record
     for k in ("merkle_valu_wave_instr_per_tree_2p24", "merkle_valu_instr_per_hash_pair", "merkle_mfma_wave_instr_per_tree_2p24", "merkle_mfma_busy_cycles_per_tree_2p24", "merkle_note"):

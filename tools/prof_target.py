@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--coset", type=int, default=2)
     ap.add_argument("--tile-mib", type=int, default=0)
     ap.add_argument("--pipe", type=int, default=0)
+    ap.add_argument("--pipeline", type=int, default=0, help="repetitions of bench.py's commit_pipeline shapes: 128 columns x 2^18 -> LDE to 2^21 -> hash rows -> tree")
     ap.add_argument("--two-pass", type=int, default=-1, help="tf_set_ntt_two_pass mode for the coset leg (3: one-workgroup 2048 x 8 first pass)")
     a = ap.parse_args()
     import torch
@@ -54,6 +55,17 @@ def main():
             tf.device.merkle_build(leaves, nl, nodes)
         torch.cuda.synchronize()
         del leaves, nodes
+    if a.pipeline:
+        cols, n, m = 128, 1 << 18, 1 << 21
+        vals = torch.empty(cols * n, dtype=torch.int64, device=dev)
+        tf.device.fill_random(vals, 0x7F210007)
+        ext = torch.empty(cols * m, dtype=torch.int64, device=dev)
+        nodes = torch.empty(10 * m, dtype=torch.int64, device=dev)
+        for _ in range(a.pipeline):
+            tf.device.lde(vals, n, tf.BFieldElement.new(1), ext, m, tf.BFieldElement.new(7), batch=cols)
+            tf.device.merkle_from_columns(ext, m, cols, nodes)
+        torch.cuda.synchronize()
+        del vals, ext, nodes
     if a.coset:
         n, b = 1 << 22, 64
         c = torch.empty(3 * n * b, dtype=torch.int64, device=dev)
