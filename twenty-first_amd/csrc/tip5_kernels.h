@@ -151,14 +151,18 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 // Same lane layout.  The state goes in byte by byte, the matrix entries as three SIGNED base-256 digits (M = m0 + 256 m1 + 65536 m2,
 // |m| <= 128), and output plane p = a + b (0..9) collects
 //     P_p[r][j] = sum_c sum_{a <= 2} m_a[(r - c) mod 16] * d_{p - a}[c][j],   d_b = (byte b of word c) - 128 = the byte XOR 0x80 as an i8,
-// ONE v_mfma_i32_16x16x64_i8 per plane with K = (c, a): 48 of the 64 products used, |P_p| < 2^20, so
+// on v_mfma_i32_16x16x64_i8 with K = (c, b) (16 words x 4 bytes), at most 48 non-zero products per plane, |P_p| < 2^20, so
 //     MDS(state)[r] = sum_p 256^p P_p + 128 * (sum of the row) * (2^64 - 1) / 255.
-//   B operand of plane p, lane (j, q), dword i: bytes [d_p, d_{p-1}, d_{p-2}, 0] of word 4 i + q -- one v_perm_b32 with a constant selector
-//     on the word XOR 0x80..80 (two v_xor per word and MDS layer); bytes outside the word select the constant 0;
-//   A operand: digit a of M[(pi(r') - (4 i + q)) mod 16] at byte 4 i + a -- the SAME four registers for all ten planes.  A and B index K by
-//     the same function of (lane >> 4, byte), whatever the hardware's is, so only "lane & 15 = row of A / column of B" is assumed; the row
-//     permutation pi(r') = 4 (r' & 3) + (r' >> 2) makes D row r' (lane (j, r' >> 2), register r' & 3) the word 4 t + q of THIS lane's layout:
-//     nothing moves between lanes;
+//   B operands: NO byte shuffling.  B_lo = the low dwords of the lane's four words XOR 0x80808080 (bytes b = 0..3 at K slot (i, b)), B_hi =
+//     the high dwords (bytes 4..7): two v_xor per word and MDS layer, nothing else.  The plane is selected on the CONSTANT side instead:
+//   A operand of plane p: digit p - b of M[(pi(r') - (4 i + q)) mod 16] at byte 4 i + b (zero where p - b is not a digit), p = 0..5 -- six
+//     constant operands (24 VGPRs) that serve B_lo for planes 0..5 and, as A_{p-4}, B_hi for planes 4..9.  Planes 4 and 5 take both (their
+//     second MFMA accumulates onto the first): TWELVE MFMA per layer.  [The first i8 form of this round kept ONE A operand and built a
+//     byte window [d_p, d_{p-1}, d_{p-2}, 0] per plane and word with v_perm_b32: ten MFMA but forty permutes per lane and layer -- 12 % of
+//     the round's vector instructions, on the pipe that binds it; the matrix pipe has the room (profiles/r06_microbench_mds_i8.txt).]
+//     A and B index K by the same function of (lane >> 4, byte), whatever the hardware's is, so only "lane & 15 = row of A / column of B"
+//     is assumed; the row permutation pi(r') = 4 (r' & 3) + (r' >> 2) makes D row r' (lane (j, r' >> 2), register r' & 3) the word
+//     4 t + q of THIS lane's layout: nothing moves between lanes;
 //   C operand (from LDS): 2^21 + byte p of (rc + K1 - K2) mod p, K1 the constant above, K2 = 2^21 sum_p 256^p: every plane comes back
 //     non-negative (< 2^22) and the round constant costs nothing.
 // Recombination per word: L0 = Q0 + 2^8 Q1 + 2^16 Q2 + 2^24 Q3 (one v_lshl_add_u32, two v_mad_u64_u32), L1 from Q4..Q7, L2 = Q8 + 2^8 Q9;
@@ -174,10 +178,12 @@ struct Tip5MxConsts {
                          // there (Tip5::new(Domain::FixedLength), mod.rs:511-526; 1^7 = 1): their bytes are left out of B and their MDS
                          // contribution rides here
     int cz[10][4][4];    // round 0 of the first permutation of a variable-length sponge: words 12..15 are 0, left out of B
-    int a[64][4];        // the A operand of lane l
+    int a[6][64][4];     // the A operand of plane p (0..5) for lane l
 };
 __constant__ Tip5MxConsts g_tip5_mx;
-typedef v4i MxA;
+struct MxA {
+    v4i p[6];
+};
 
 inline int mds_digit(u32 M, int a) {  // signed base-256 digits of a matrix entry
     const int m0 = (int)(signed char)(M & 0xff);
@@ -210,13 +216,17 @@ inline void fill_tip5_mx(Tip5MxConsts& t, const u64* rc_mont) {
     for (int round = 0; round < 5; ++round) starts(t.c[round], rc_mont + 16 * round, false, false);
     starts(t.cf, rc_mont, true, true);
     starts(t.cz, rc_mont, true, false);
-    for (int l = 0; l < 64; ++l) {
-        const int rp = l & 15, qa = l >> 4, r = 4 * (rp & 3) + (rp >> 2);
-        for (int i = 0; i < 4; ++i) {
-            const u32 M = kMdsCol[(r - (4 * i + qa)) & 15];
-            t.a[l][i] = (int)(((u32)mds_digit(M, 0) & 0xff) | (((u32)mds_digit(M, 1) & 0xff) << 8) | (((u32)mds_digit(M, 2) & 0xff) << 16));
+    for (int p = 0; p < 6; ++p)
+        for (int l = 0; l < 64; ++l) {
+            const int rp = l & 15, qa = l >> 4, r = 4 * (rp & 3) + (rp >> 2);
+            for (int i = 0; i < 4; ++i) {
+                const u32 M = kMdsCol[(r - (4 * i + qa)) & 15];
+                u32 w = 0;
+                for (int b = 0; b < 4; ++b)
+                    if (p - b >= 0 && p - b <= 2) w |= ((u32)mds_digit(M, p - b) & 0xff) << (8 * b);
+                t.a[p][l][i] = (int)w;
+            }
         }
-    }
 }
 
 struct Tip5MxLds {
@@ -235,7 +245,8 @@ __device__ __forceinline__ void stage_mx(Tip5MxLds* l) {
 static_assert(offsetof(Tip5MxConsts, cf) == 5 * 160 * 4 && offsetof(Tip5MxConsts, cz) == 6 * 160 * 4 && offsetof(Tip5MxLds, cz) == 6 * 160 * 4, "stage_mx copies c, cf, cz as one run");
 
 __device__ __forceinline__ void mx_a_operands(const Tip5MxLds*, MxA& a) {
-    a = *reinterpret_cast<const v4i*>(&g_tip5_mx.a[threadIdx.x & 63][0]);
+#pragma unroll
+    for (int p = 0; p < 6; ++p) a.p[p] = *reinterpret_cast<const v4i*>(&g_tip5_mx.a[p][threadIdx.x & 63][0]);
 }
 #else  // ---- the f64 form of round 5 ------------------------------------------------------------------------------------------------
 
@@ -466,33 +477,31 @@ __device__ __forceinline__ void tip5_round_mx(u64 (&s)[4 * NS], int round, const
         }
     }
 #if TF_TIP5_I8
-    // ---- the MDS on the i8 matrix pipe (see Tip5MxConsts): ten planes, one MFMA each
+    // ---- the MDS on the i8 matrix pipe (see Tip5MxConsts): ten planes, twelve MFMA
     const int* cp = FIXED0 == 1 ? &l->cf[0][q][0] : (FIXED0 == 2 ? &l->cz[0][q][0] : &l->c[round][0][q][0]);  // [plane][q][t]: 16 ints per plane
     constexpr int NW = FIXED0 ? 3 : 4;  // registers that go into B (FIXED0: register 3 -- words 12..15 -- is a constant, folded into the starts)
-    u32 wl[NS][4], wh[NS][4];
+    v4i blo[NS], bhi[NS];
 #pragma unroll
     for (int n = 0; n < NS; ++n)
 #pragma unroll
-        for (int i = 0; i < NW; ++i) wl[n][i] = (u32)s[4 * n + i] ^ 0x80808080u, wh[n][i] = (u32)(s[4 * n + i] >> 32) ^ 0x80808080u;
+        for (int i = 0; i < 4; ++i) {
+            blo[n][i] = i < NW ? (int)((u32)s[4 * n + i] ^ 0x80808080u) : 0;
+            bhi[n][i] = i < NW ? (int)((u32)(s[4 * n + i] >> 32) ^ 0x80808080u) : 0;
+        }
     v4i d[NS][10];
-    const auto plane = [&](auto pc) {
-        constexpr int P = decltype(pc)::value;
-        // bytes [P, P - 1, P - 2, zero] of the word hi : lo; a byte outside the word selects the constant 0 (selector 0x0c)
-        constexpr u32 s0 = (P <= 7) ? (u32)P : 0x0cu, s1 = (P >= 1 && P - 1 <= 7) ? (u32)(P - 1) : 0x0cu, s2 = (P >= 2 && P - 2 <= 7) ? (u32)(P - 2) : 0x0cu;
-        constexpr u32 sel = s0 | (s1 << 8) | (s2 << 16) | (0x0cu << 24);
-        const v4i c = *reinterpret_cast<const v4i*>(cp + P * 16);
+#pragma unroll
+    for (int p = 0; p < 10; ++p) {
+        const v4i c = *reinterpret_cast<const v4i*>(cp + p * 16);
 #pragma unroll
         for (int n = 0; n < NS; ++n) {
-            v4i b;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) b[i] = i < NW ? (int)__builtin_amdgcn_perm(wh[n][i], wl[n][i], sel) : 0;
-            d[n][P] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, c, 0, 0, 0);
+            if (p < 6) {
+                d[n][p] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a.p[p], blo[n], c, 0, 0, 0);
+                if (p >= 4) d[n][p] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a.p[p - 4], bhi[n], d[n][p], 0, 0, 0);
+            } else {
+                d[n][p] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a.p[p - 4], bhi[n], c, 0, 0, 0);
+            }
         }
-    };
-    plane(std::integral_constant<int, 0>{}); plane(std::integral_constant<int, 1>{}); plane(std::integral_constant<int, 2>{});
-    plane(std::integral_constant<int, 3>{}); plane(std::integral_constant<int, 4>{}); plane(std::integral_constant<int, 5>{});
-    plane(std::integral_constant<int, 6>{}); plane(std::integral_constant<int, 7>{}); plane(std::integral_constant<int, 8>{});
-    plane(std::integral_constant<int, 9>{});
+    }
     // ---- recombination: (th : tl) = L0 + (2^32 - 1) (hi(L1) + L2), h0 = lo(L1), then the shared tail
     // x * y + z as ONE v_mad_u64_u32.  NOT inline assembly: these are the first readers of the MFMA results, and the compiler only counts
     // the wait states between a matrix instruction and a reader it can see (an asm block reading d[] too early returned garbage in the
