@@ -44,6 +44,9 @@ for f in glob.glob(os.path.join(src, "pmc_mfma/**/*counter_collection.csv"), rec
 coset_busy = [e["derived"]["valu_busy_frac_at_4_cycles"] for k, e in summ["kernels"].items()
               if "ntt_pass_kernel" in k and "valu_busy_frac_at_4_cycles" in e.get("derived", {})
               and (k.startswith("ntt_pass_kernel<false, 1, 0, false, true, false, true") or k.startswith("ntt_pass_kernel<false, 0, 0, true, false, false, true"))]
+# (round 6: the first pass of configs[3] is ntt_col2048_kernel<false, 1>, bound by the memory pipe at ~0.68 busy; the last pass stays the PRE2 kernel)
+coset_busy += [e["derived"]["valu_busy_frac_at_4_cycles"] for k, e in summ["kernels"].items()
+               if k.startswith("ntt_col2048_kernel<false, 1>") and "valu_busy_frac_at_4_cycles" in e.get("derived", {})]
 rec = {"library": library, "coset_eval_valu_busy_frac_at_4_cycles": coset_busy or None, "source": f"rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_VALU ... (tools/prof_r02.sh {tag} -> profiles/{tag}_rocprof_summary.json): SQ_INSTS_VALU summed over the dispatches of one step / one tree",
        "ntt_valu_wave_instr_per_transform_2p20": ntt / 256, "ntt_valu_instr_per_element": ntt * 64 / 2 ** 28,
        "ntt_clock_under_load_mhz": round(sum(clocks) / len(clocks), 1) if clocks else None,
