@@ -49,7 +49,7 @@ int ensure_tip5(DeviceCtx* ctx) {
 // ------------------------------------------------------------------------------------ Tip5 / Merkle
 // Two kernel families (tip5_kernels.h).  Launches of at most kCoopMaxCount permutation chains are latency-bound (fewer chains
 // than the chip has SIMD slots): 16 lanes per permutation, ~2.5 us per permutation of a chain.  Everything larger runs in the
-// matrix-pipe form (4 lanes per permutation, MDS on v_mfma_f64_16x16x4_f64): measured crossover 2^13 chains
+// matrix-pipe form (4 lanes per permutation, MDS on v_mfma_i32_16x16x64_i8 since round 6): crossover measured at 2^13 chains with the f64 form
 // (profiles/r05_tip5_small_times.txt: hash_varlen of 33 words, 2^13 rows 24.4 vs 25.6 us, 2^14 rows 34.6 vs 26.3 us).
 constexpr long long kCoopMaxCount = 1ll << 13;
 static_assert(kCoopMaxCount >= 64 && (kCoopMaxCount & (kCoopMaxCount - 1)) == 0, "a power of two: the level at which a tree narrows is found by halving");
