@@ -26,6 +26,9 @@
  *
  * Return value: 0 on success, otherwise one of the codes below.  Codes 1-3 are the reference's
  * MerkleTreeError variants (util_types/merkle_tree.rs:933-965); codes 4-6 replace panics.
+ * No C++ exception leaves the library: every status-returning entry point catches what its host-side C++ (tables, caches,
+ * worker threads) may throw and returns TF_ERR_OUT_OF_MEMORY (a failed host allocation) or TF_ERR_INTERNAL, with the
+ * message in tf_last_error() (csrc/tf_guard.h) -- a Rust `extern "C"` caller never sees an unwind.
  */
 #ifndef TF_HIP_H
 #define TF_HIP_H
@@ -55,7 +58,8 @@ enum tf_status {
     TF_ERR_EMPTY_DOMAIN = 14,              /* interpolate panic: "interpolation must happen through more than zero points"  math/polynomial.rs:1503-1506 */
     TF_ERR_DIVISION_BY_ZERO = 15,          /* naive_divide panic: "divisor should be non-zero"  math/polynomial.rs:556-559 */
     TF_ERR_DIVISION_NOT_CLEAN = 16,        /* clean_divide panic: the quotient does not come back to the base field  math/polynomial.rs:2374, :2410 */
-    TF_ERR_INVALID_ARGUMENT = 17           /* an index / count argument of a host-logic helper (tf_shard_range, tf_merkle_subtree_layer_range) is out of range */
+    TF_ERR_INVALID_ARGUMENT = 17,          /* an index / count argument of a host-logic helper (tf_shard_range, tf_merkle_subtree_layer_range) is out of range */
+    TF_ERR_INTERNAL = 18                   /* a C++ exception other than an allocation failure was caught at the ABI (csrc/tf_guard.h); see tf_last_error() */
 };
 
 /* Human-readable name of a status code. */

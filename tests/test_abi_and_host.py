@@ -304,3 +304,71 @@ def test_batch_evaluation_router_is_host_logic_with_the_measured_crossovers(tf):
         assert plan(1 << 12, 1 << 12, 1, 1) == 2 and plan(1 << 12, 511, 1, 1) == 1 and plan(1 << 12, 255, 1, 3) == 1
     finally:
         lib.tf_set_batch_eval_route(0)
+
+
+# ---------------------------------------------------------------------------------- no C++ exception crosses the C ABI (csrc/tf_guard.h)
+CSRC = os.path.join(ROOT, "twenty-first_amd", "csrc")
+# int-returning entry points whose value is not a status (they cannot fail and own nothing that throws)
+NOT_A_STATUS = {"tf_version", "tf_device_count", "tf_get_ntt_pipe", "tf_batch_eval_plan", "tf_ntt_plan", "tf_ntt_launch_count",
+                "tf_zerofier_tree_width", "tf_merkle_multi_subtrees"}
+
+
+def test_every_status_returning_entry_point_is_a_function_try_block():
+    """Structure check on the two translation units that define extern "C" functions: each `int tf_xxx(...)` whose value is a status opens
+    with `try {` and closes with TF_ABI_CATCH, so std::bad_alloc / std::system_error / ... come back as TF_ERR_OUT_OF_MEMORY /
+    TF_ERR_INTERNAL instead of unwinding into a C or Rust caller."""
+    seen = set()
+    for unit in ("tf_abi.hip", "tf_multi.hip"):
+        text = open(os.path.join(CSRC, unit)).read()
+        for m in re.finditer(r"^int (tf_[a-z0-9_]+)\(", text, flags=re.M):
+            name = m.group(1)
+            depth, j = 1, m.end()
+            while depth:
+                depth += {"(": 1, ")": -1}.get(text[j], 0)
+                j += 1
+            opens = text[j:j + 8].split()
+            seen.add(name)
+            if name in NOT_A_STATUS:
+                assert opens[0] == "{", name
+            else:
+                assert opens[:2] == ["try", "{"], f"{name} is not guarded"
+        assert text.count(" TF_ABI_CATCH") == len([n for n in re.findall(r"^int (tf_[a-z0-9_]+)\(", text, flags=re.M) if n not in NOT_A_STATUS])
+    declared_ints = set(re.findall(r"^int\s+(tf_[a-z0-9_]+)\s*\(", re.sub(r"#ifdef TF_AB_BUILD.*?#endif", "", open(HEADER).read(), flags=re.S), flags=re.M))
+    assert declared_ints <= seen, sorted(declared_ints - seen)
+
+
+def test_abi_guard_turns_exceptions_into_statuses(tmp_path, tf):
+    """The mechanism itself, compiled with g++ alone (tf_guard.h depends on the status codes only): bad_alloc / length_error ->
+    TF_ERR_OUT_OF_MEMORY (10), any other exception -> TF_ERR_INTERNAL (18), no exception -> the body's own value."""
+    src = tmp_path / "guard_check.cpp"
+    src.write_text(r'''
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include <system_error>
+#include "include/tf_hip.h"
+#include "twenty-first_amd/csrc/tf_guard.h"
+static std::string g_msg;
+namespace tfi { int abi_caught(const char* what, int status) noexcept { try { g_msg = what; } catch (...) {} return status; } }
+extern "C" int f_ok(int v) try { return v; } TF_ABI_CATCH
+extern "C" int f_alloc(void) try { throw std::bad_alloc(); } TF_ABI_CATCH
+extern "C" int f_len(void) try { std::vector<int> v; v.reserve(v.max_size() + 1); return TF_OK; } TF_ABI_CATCH
+extern "C" int f_sys(void) try { throw std::system_error(std::make_error_code(std::errc::resource_unavailable_try_again), "thread"); } TF_ABI_CATCH
+extern "C" int f_int(void) try { throw 42; } TF_ABI_CATCH
+int main() {
+    if (f_ok(TF_ERR_NULL_POINTER) != TF_ERR_NULL_POINTER || f_ok(TF_OK) != TF_OK) return 1;
+    if (f_alloc() != TF_ERR_OUT_OF_MEMORY || g_msg.find("bad_alloc") == std::string::npos) return 2;
+    if (f_len() != TF_ERR_OUT_OF_MEMORY) return 3;
+    if (f_sys() != TF_ERR_INTERNAL || g_msg.find("thread") == std::string::npos) return 4;
+    if (f_int() != TF_ERR_INTERNAL || g_msg != "unknown C++ exception") return 5;
+    std::puts("guard ok");
+    return 0;
+}
+''')
+    import subprocess
+    exe = tmp_path / "guard_check"
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", ROOT, "-o", str(exe), str(src)])
+    assert subprocess.run([str(exe)], capture_output=True, text=True).stdout.strip() == "guard ok"
+    lib = tf.lib()
+    assert lib.tf_status_string(18) == b"TF_ERR_INTERNAL" and lib.tf_status_string(10) == b"TF_ERR_OUT_OF_MEMORY"

@@ -56,7 +56,18 @@ run "TF_BATCH_EVAL=horner" "Horner everywhere"
 run "TF_BATCH_EVAL=tree TF_TREE_UNIT_SLAB=3000" "zerofier tree with the units of a walk cut into slabs of a few units"
 run "TF_TREE_LEAF_LOG=6" "64-point leaves in the zerofier tree (deeper trees)"
 run "TF_TREE_LEAF_LOG=10" "1024-point leaves"
+run "TF_NTT_PRE4=1" "2^22-point coset evaluations as 1024 x 4096 with the radix-4 last pass (round 4, measured loss)"
+run "TF_NTT_PIPE=1" "batch tiles of every multi-pass plan on ONE stream (round 6 deals the 2^21 / 2^22 two-pass tiles to two)"
+run "TF_NTT_PIPE=4 TF_NTT_TILE_BYTES=268435456" "256 MiB tiles on four side streams"
 unset TF_HIP_LIBRARY
+# round 6: the f64 form of the Tip5 MDS (round 5's product, -DTF_TIP5_I8=0) is still a buildable variant; built where hipcc is
+# (twenty-first_amd/variants/ travels to the GPU box): the whole suite on it
+V=$REPO/twenty-first_amd/variants/libtf_hip_tip5f64.so
+if [ -f "$V" ]; then
+  export TF_HIP_LIBRARY=$V
+  run "TF_DEFAULT=1" "variant library: Tip5 MDS on v_mfma_f64_16x16x4_f64 (-DTF_TIP5_I8=0), everything else the product"
+  unset TF_HIP_LIBRARY
+fi
 echo "--- long randomised parity run on the product library (tools/fuzz_long.py, 3 seeds x 120 s)" | tee -a "$OUT"
 for seed in 11 12 13; do
   timeout 400 python tools/fuzz_long.py $seed 120 2>&1 | grep -v amdgpu.ids | tail -n 3 | tee -a "$OUT"

@@ -142,6 +142,7 @@ const char* tf_status_string(int status) {
         case TF_ERR_DIVISION_BY_ZERO: return "TF_ERR_DIVISION_BY_ZERO";
         case TF_ERR_DIVISION_NOT_CLEAN: return "TF_ERR_DIVISION_NOT_CLEAN";
         case TF_ERR_INVALID_ARGUMENT: return "TF_ERR_INVALID_ARGUMENT";
+        case TF_ERR_INTERNAL: return "TF_ERR_INTERNAL";
         default: return "TF_ERR_UNKNOWN";
     }
 }
@@ -153,12 +154,12 @@ int tf_version(void) { return 1001; }
 #endif
 const char* tf_source_hash(void) { return TF_SOURCE_HASH; }
 
-int tf_release_caches(void) {
+int tf_release_caches(void) try {
     DeviceCtx* ctx = nullptr;
     const int rc = current_ctx(&ctx);
     if (rc) return rc;
     return release_caches(ctx);
-}
+} TF_ABI_CATCH
 
 int tf_device_count(void) {
     int count = 0;
@@ -211,7 +212,7 @@ double tf_debug_sclk_mhz(void) {
 }
 
 // synthetic-input helper (not part of the drop-in boundary): d_out[i] = new(splitmix64(seed ^ (first_index + i)) mod p)
-int tf_debug_fill_random_dev(uint64_t* d_out, size_t count, uint64_t seed, uint64_t first_index, void* stream) {
+int tf_debug_fill_random_dev(uint64_t* d_out, size_t count, uint64_t seed, uint64_t first_index, void* stream) try {
     if (count == 0) return TF_OK;
     if (!d_out) return TF_ERR_NULL_POINTER;
     DeviceCtx* ctx = nullptr;
@@ -222,11 +223,11 @@ int tf_debug_fill_random_dev(uint64_t* d_out, size_t count, uint64_t seed, uint6
                        (unsigned long long)count, (u64)seed, (unsigned long long)first_index);
     HIPCHK(hipGetLastError());
     return TF_OK;
-}
+} TF_ABI_CATCH
 
 #ifdef TF_AB_BUILD
 // measurement helper (not part of the drop-in boundary): allocate / fetch the MODE-3 stamp buffer
-int tf_debug_stamps(unsigned long long* host_out, size_t words) {
+int tf_debug_stamps(unsigned long long* host_out, size_t words) try {
     if (!g_dbg_buf) {
         if (hipMalloc(reinterpret_cast<void**>(&g_dbg_buf), 4096 * 8 * 6 * 8) != hipSuccess) return TF_ERR_HIP;
         (void)hipMemset(g_dbg_buf, 0, 4096 * 8 * 6 * 8);
@@ -236,7 +237,7 @@ int tf_debug_stamps(unsigned long long* host_out, size_t words) {
         if (hipMemcpy(host_out, g_dbg_buf, std::min<size_t>(words, 4096 * 8 * 6) * 8, hipMemcpyDeviceToHost) != hipSuccess) return TF_ERR_HIP;
     }
     return TF_OK;
-}
+} TF_ABI_CATCH
 #endif
 
 void tf_set_ntt_min_passes(int passes) { g_min_passes.store(passes, std::memory_order_relaxed); }
@@ -294,46 +295,46 @@ int tf_ntt_launch_count(size_t n, size_t batch, int width) {
     return (int)(tiles * P);
 }
 
-int tf_ntt_bfe(uint64_t* x, size_t n, size_t batch, int inverse) { return ntt_host(x, n, batch, 1, inverse); }
-int tf_ntt_xfe(uint64_t* x, size_t n, size_t batch, int inverse) { return ntt_host(x, n, batch, 3, inverse); }
-int tf_ntt_bfe_dev(uint64_t* d_x, size_t n, size_t batch, int inverse, void* stream) {
+int tf_ntt_bfe(uint64_t* x, size_t n, size_t batch, int inverse) try { return ntt_host(x, n, batch, 1, inverse); } TF_ABI_CATCH
+int tf_ntt_xfe(uint64_t* x, size_t n, size_t batch, int inverse) try { return ntt_host(x, n, batch, 3, inverse); } TF_ABI_CATCH
+int tf_ntt_bfe_dev(uint64_t* d_x, size_t n, size_t batch, int inverse, void* stream) try {
     return ntt_dev(d_x, n, batch, 1, inverse, stream);
-}
-int tf_ntt_xfe_dev(uint64_t* d_x, size_t n, size_t batch, int inverse, void* stream) {
+} TF_ABI_CATCH
+int tf_ntt_xfe_dev(uint64_t* d_x, size_t n, size_t batch, int inverse, void* stream) try {
     return ntt_dev(d_x, n, batch, 3, inverse, stream);
-}
+} TF_ABI_CATCH
 
-int tf_coset_eval_bfe(const uint64_t* c, size_t nc, uint64_t off, uint64_t* out, size_t order, size_t batch) {
+int tf_coset_eval_bfe(const uint64_t* c, size_t nc, uint64_t off, uint64_t* out, size_t order, size_t batch) try {
     return coset_eval_host(c, nc, off, out, order, batch, 1);
-}
-int tf_coset_eval_xfe(const uint64_t* c, size_t nc, uint64_t off, uint64_t* out, size_t order, size_t batch) {
+} TF_ABI_CATCH
+int tf_coset_eval_xfe(const uint64_t* c, size_t nc, uint64_t off, uint64_t* out, size_t order, size_t batch) try {
     return coset_eval_host(c, nc, off, out, order, batch, 3);
-}
+} TF_ABI_CATCH
 int tf_coset_eval_bfe_dev(const uint64_t* c, size_t nc, uint64_t off, uint64_t* out, size_t order, size_t batch,
-                          void* stream) {
+                          void* stream) try {
     return coset_eval_dev(c, nc, off, out, order, batch, 1, stream);
-}
+} TF_ABI_CATCH
 int tf_coset_eval_xfe_dev(const uint64_t* c, size_t nc, uint64_t off, uint64_t* out, size_t order, size_t batch,
-                          void* stream) {
+                          void* stream) try {
     return coset_eval_dev(c, nc, off, out, order, batch, 3, stream);
-}
+} TF_ABI_CATCH
 
-int tf_tip5_permute_dev(uint64_t* d_states, size_t count, void* stream) { return tip5_permute_dev(d_states, count, stream); }
-int tf_tip5_hash_pairs_dev(const uint64_t* d_in, uint64_t* d_out, size_t count, void* stream) {
+int tf_tip5_permute_dev(uint64_t* d_states, size_t count, void* stream) try { return tip5_permute_dev(d_states, count, stream); } TF_ABI_CATCH
+int tf_tip5_hash_pairs_dev(const uint64_t* d_in, uint64_t* d_out, size_t count, void* stream) try {
     return tip5_hash_pairs_dev(d_in, d_out, count, stream);
-}
-int tf_tip5_hash_varlen_rows_dev(const uint64_t* d_rows, size_t row_len, size_t n_rows, uint64_t* d_out, void* stream) {
+} TF_ABI_CATCH
+int tf_tip5_hash_varlen_rows_dev(const uint64_t* d_rows, size_t row_len, size_t n_rows, uint64_t* d_out, void* stream) try {
     return tip5_hash_varlen_rows_dev(d_rows, row_len, n_rows, d_out, stream);
-}
-int tf_merkle_build_dev(const uint64_t* d_leaves, size_t n, uint64_t* d_nodes, size_t batch, void* stream) {
+} TF_ABI_CATCH
+int tf_merkle_build_dev(const uint64_t* d_leaves, size_t n, uint64_t* d_nodes, size_t batch, void* stream) try {
     return merkle_build_dev(d_leaves, n, d_nodes, batch, stream);
-}
-int tf_merkle_root_dev(const uint64_t* d_leaves, size_t n, uint64_t* d_root, size_t batch, void* stream) {
+} TF_ABI_CATCH
+int tf_merkle_root_dev(const uint64_t* d_leaves, size_t n, uint64_t* d_root, size_t batch, void* stream) try {
     return merkle_root_dev(d_leaves, n, d_root, batch, stream);
-}
+} TF_ABI_CATCH
 
-int tf_tip5_trace_dev(uint64_t* d_states, uint64_t* d_trace, size_t count, void* stream) { return tip5_trace_dev(d_states, d_trace, count, stream); }
-int tf_tip5_trace(uint64_t* states, uint64_t* trace, size_t count) {
+int tf_tip5_trace_dev(uint64_t* d_states, uint64_t* d_trace, size_t count, void* stream) try { return tip5_trace_dev(d_states, d_trace, count, stream); } TF_ABI_CATCH
+int tf_tip5_trace(uint64_t* states, uint64_t* trace, size_t count) try {
     if (count == 0) return TF_OK;
     if (!states || !trace) return TF_ERR_NULL_POINTER;
     DeviceCtx* ctx = nullptr;
@@ -347,8 +348,8 @@ int tf_tip5_trace(uint64_t* states, uint64_t* trace, size_t count) {
     TRY(d2h(states, d.p, count * 16, s));
     TRY(d2h(trace, t.p, count * 96, s));
     return sync(s);
-}
-int tf_tip5_permute(uint64_t* states, size_t count) {
+} TF_ABI_CATCH
+int tf_tip5_permute(uint64_t* states, size_t count) try {
     if (count == 0) return TF_OK;
     if (!states) return TF_ERR_NULL_POINTER;
     DeviceCtx* ctx = nullptr;
@@ -360,9 +361,9 @@ int tf_tip5_permute(uint64_t* states, size_t count) {
     TRY(tip5_permute_dev(d.p, count, s));
     TRY(d2h(states, d.p, count * 16, s));
     return sync(s);
-}
+} TF_ABI_CATCH
 
-int tf_tip5_hash_pairs(const uint64_t* in, uint64_t* out, size_t count) {
+int tf_tip5_hash_pairs(const uint64_t* in, uint64_t* out, size_t count) try {
     if (count == 0) return TF_OK;
     if (!in || !out) return TF_ERR_NULL_POINTER;
     DeviceCtx* ctx = nullptr;
@@ -375,9 +376,9 @@ int tf_tip5_hash_pairs(const uint64_t* in, uint64_t* out, size_t count) {
     TRY(tip5_hash_pairs_dev(din.p, dout.p, count, s));
     TRY(d2h(out, dout.p, count * 5, s));
     return sync(s);
-}
+} TF_ABI_CATCH
 
-int tf_tip5_hash_varlen_rows(const uint64_t* rows, size_t row_len, size_t n_rows, uint64_t* out) {
+int tf_tip5_hash_varlen_rows(const uint64_t* rows, size_t row_len, size_t n_rows, uint64_t* out) try {
     if (n_rows == 0) return TF_OK;
     if (!out || (row_len && !rows)) return TF_ERR_NULL_POINTER;
     DeviceCtx* ctx = nullptr;
@@ -390,7 +391,7 @@ int tf_tip5_hash_varlen_rows(const uint64_t* rows, size_t row_len, size_t n_rows
     TRY(tip5_hash_varlen_rows_dev(din.p, row_len, n_rows, dout.p, s));
     TRY(d2h(out, dout.p, n_rows * 5, s));
     return sync(s);
-}
+} TF_ABI_CATCH
 
 // ---- warm-up: one blocking call per shape, so that the *_dev calls of that shape never leave the stream ---------------------------
 // The first call of a shape on a device builds its twiddle / power tables (hipMalloc + a build kernel the host waits for), opens the
@@ -409,30 +410,30 @@ static int prepare_run(size_t in_words, size_t out_words, const std::function<in
     TRY(body(a.p, b.p, s));
     return sync(s);
 }
-int tf_prepare_ntt(size_t n, size_t batch, int width, int inverse) {
+int tf_prepare_ntt(size_t n, size_t batch, int width, int inverse) try {
     if (width != 1 && width != 3) return TF_ERR_INVALID_ARGUMENT;
     TRY(check_len(n));
     if (n <= 1 || batch == 0) return TF_OK;
     return prepare_run(n * batch * (size_t)width, 0, [=](u64* x, u64*, hipStream_t s) { return ntt_dev(x, n, batch, width, inverse, s); });
-}
-int tf_prepare_coset_eval(size_t n_coeffs, uint64_t offset_raw, size_t order, size_t batch, int width) {
+} TF_ABI_CATCH
+int tf_prepare_coset_eval(size_t n_coeffs, uint64_t offset_raw, size_t order, size_t batch, int width) try {
     if (width != 1 && width != 3) return TF_ERR_INVALID_ARGUMENT;
     if (n_coeffs > order) return TF_ERR_ORDER_NOT_ABOVE_DEGREE;
     TRY(check_len(order));
     if (order == 0 || batch == 0) return TF_OK;
     return prepare_run(n_coeffs * batch * (size_t)width, order * batch * (size_t)width,
                        [=](u64* c, u64* o, hipStream_t s) { return coset_eval_dev(c, n_coeffs, offset_raw, o, order, batch, width, s); });
-}
-int tf_prepare_merkle(size_t n_leaves, size_t batch) {
+} TF_ABI_CATCH
+int tf_prepare_merkle(size_t n_leaves, size_t batch) try {
     TRY(check_leaves(n_leaves));
     if (batch == 0) return TF_OK;
     return prepare_run(n_leaves * batch * 5, n_leaves * batch * 10, [=](u64* l, u64* nd, hipStream_t s) {
         TRY(merkle_build_dev(l, n_leaves, nd, batch, s));
         return merkle_root_dev(l, n_leaves, nd, batch, s);  // (the root-only route has kernels and scratch of its own)
     });
-}
+} TF_ABI_CATCH
 
-int tf_merkle_build(const uint64_t* leaves, size_t n, uint64_t* nodes_out, size_t batch) {
+int tf_merkle_build(const uint64_t* leaves, size_t n, uint64_t* nodes_out, size_t batch) try {
     TRY(check_leaves(n));
     if (batch == 0) return TF_OK;
     if (!leaves || !nodes_out) return TF_ERR_NULL_POINTER;
@@ -445,7 +446,7 @@ int tf_merkle_build(const uint64_t* leaves, size_t n, uint64_t* nodes_out, size_
     TRY(merkle_build_dev(din.p, n, dout.p, batch, s));
     TRY(d2h(nodes_out, dout.p, n * batch * 10, s));
     return sync(s);
-}
+} TF_ABI_CATCH
 
 }  // extern "C"  (closed for one internal helper of tf_multi.hip that needs this unit's host-pointer plumbing)
 namespace tfi {
@@ -481,7 +482,7 @@ int merkle_subtree_host(const u64* leaves_sub, size_t m, u64* nodes_tree, size_t
 }  // namespace tfi
 extern "C" {
 
-int tf_merkle_root(const uint64_t* leaves, size_t n, uint64_t* root_out, size_t batch) {
+int tf_merkle_root(const uint64_t* leaves, size_t n, uint64_t* root_out, size_t batch) try {
     TRY(check_leaves(n));
     if (batch == 0) return TF_OK;
     if (!leaves || !root_out) return TF_ERR_NULL_POINTER;
@@ -495,131 +496,131 @@ int tf_merkle_root(const uint64_t* leaves, size_t n, uint64_t* root_out, size_t 
     TRY(merkle_root_dev(din.p, n, dout.p, batch, s));
     TRY(d2h(root_out, dout.p, batch * 5, s));
     return sync(s);
-}
+} TF_ABI_CATCH
 
 // ---- SURVEY 8(f1)-(f3) ---------------------------------------------------------------------------
-int tf_coset_interpolate_bfe_dev(const uint64_t* v, size_t n, uint64_t off, uint64_t* out, size_t batch, void* stream) {
+int tf_coset_interpolate_bfe_dev(const uint64_t* v, size_t n, uint64_t off, uint64_t* out, size_t batch, void* stream) try {
     return coset_interp_dev(v, n, off, out, batch, 1, stream);
-}
-int tf_coset_interpolate_xfe_dev(const uint64_t* v, size_t n, uint64_t off, uint64_t* out, size_t batch, void* stream) {
+} TF_ABI_CATCH
+int tf_coset_interpolate_xfe_dev(const uint64_t* v, size_t n, uint64_t off, uint64_t* out, size_t batch, void* stream) try {
     return coset_interp_dev(v, n, off, out, batch, 3, stream);
-}
-int tf_hadamard_bfe_dev(const uint64_t* a, const uint64_t* b, uint64_t* out, size_t count, void* stream) {
+} TF_ABI_CATCH
+int tf_hadamard_bfe_dev(const uint64_t* a, const uint64_t* b, uint64_t* out, size_t count, void* stream) try {
     return hadamard_dev(a, b, out, count, 1, stream);
-}
-int tf_hadamard_xfe_dev(const uint64_t* a, const uint64_t* b, uint64_t* out, size_t count, void* stream) {
+} TF_ABI_CATCH
+int tf_hadamard_xfe_dev(const uint64_t* a, const uint64_t* b, uint64_t* out, size_t count, void* stream) try {
     return hadamard_dev(a, b, out, count, 3, stream);
-}
-int tf_poly_mul_bfe_dev(const uint64_t* a, size_t na, const uint64_t* b, size_t nb, uint64_t* out, size_t batch, void* stream) {
+} TF_ABI_CATCH
+int tf_poly_mul_bfe_dev(const uint64_t* a, size_t na, const uint64_t* b, size_t nb, uint64_t* out, size_t batch, void* stream) try {
     return poly_mul_dev(a, na, b, nb, out, batch, 1, stream);
-}
-int tf_poly_mul_xfe_dev(const uint64_t* a, size_t na, const uint64_t* b, size_t nb, uint64_t* out, size_t batch, void* stream) {
+} TF_ABI_CATCH
+int tf_poly_mul_xfe_dev(const uint64_t* a, size_t na, const uint64_t* b, size_t nb, uint64_t* out, size_t batch, void* stream) try {
     return poly_mul_dev(a, na, b, nb, out, batch, 3, stream);
-}
-int tf_poly_square_bfe_dev(const uint64_t* a, size_t na, uint64_t* out, size_t batch, void* stream) {
+} TF_ABI_CATCH
+int tf_poly_square_bfe_dev(const uint64_t* a, size_t na, uint64_t* out, size_t batch, void* stream) try {
     return poly_square_dev(a, na, out, batch, 1, stream);
-}
-int tf_poly_square_xfe_dev(const uint64_t* a, size_t na, uint64_t* out, size_t batch, void* stream) {
+} TF_ABI_CATCH
+int tf_poly_square_xfe_dev(const uint64_t* a, size_t na, uint64_t* out, size_t batch, void* stream) try {
     return poly_square_dev(a, na, out, batch, 3, stream);
-}
-int tf_lde_bfe_dev(const uint64_t* v, size_t n, uint64_t off_in, uint64_t* out, size_t m, uint64_t off_out, size_t batch, void* stream) {
+} TF_ABI_CATCH
+int tf_lde_bfe_dev(const uint64_t* v, size_t n, uint64_t off_in, uint64_t* out, size_t m, uint64_t off_out, size_t batch, void* stream) try {
     return lde_dev(v, n, off_in, out, m, off_out, batch, 1, stream);
-}
-int tf_lde_xfe_dev(const uint64_t* v, size_t n, uint64_t off_in, uint64_t* out, size_t m, uint64_t off_out, size_t batch, void* stream) {
+} TF_ABI_CATCH
+int tf_lde_xfe_dev(const uint64_t* v, size_t n, uint64_t off_in, uint64_t* out, size_t m, uint64_t off_out, size_t batch, void* stream) try {
     return lde_dev(v, n, off_in, out, m, off_out, batch, 3, stream);
-}
-int tf_poly_batch_evaluate_bfe_dev(const uint64_t* c, size_t nc, const uint64_t* pts, size_t np, uint64_t* out, void* stream) {
+} TF_ABI_CATCH
+int tf_poly_batch_evaluate_bfe_dev(const uint64_t* c, size_t nc, const uint64_t* pts, size_t np, uint64_t* out, void* stream) try {
     return batch_evaluate_dev(c, nc, nc, 1, pts, np, out, 1, stream);
-}
-int tf_poly_batch_evaluate_xfe_dev(const uint64_t* c, size_t nc, const uint64_t* pts, size_t np, uint64_t* out, void* stream) {
+} TF_ABI_CATCH
+int tf_poly_batch_evaluate_xfe_dev(const uint64_t* c, size_t nc, const uint64_t* pts, size_t np, uint64_t* out, void* stream) try {
     return batch_evaluate_dev(c, nc, 3 * nc, 1, pts, np, out, 3, stream);
-}
+} TF_ABI_CATCH
 int tf_coset_extrapolate_bfe_dev(uint64_t offset, const uint64_t* cw, size_t n, size_t batch, const uint64_t* pts, size_t np,
-                                 uint64_t* out, void* stream) {
+                                 uint64_t* out, void* stream) try {
     return coset_extrapolate_dev(offset, cw, n, batch, pts, np, out, 1, stream);
-}
+} TF_ABI_CATCH
 int tf_coset_extrapolate_xfe_dev(uint64_t offset, const uint64_t* cw, size_t n, size_t batch, const uint64_t* pts, size_t np,
-                                 uint64_t* out, void* stream) {
+                                 uint64_t* out, void* stream) try {
     return coset_extrapolate_dev(offset, cw, n, batch, pts, np, out, 3, stream);
-}
+} TF_ABI_CATCH
 int tf_tip5_hash_table_rows_dev(const uint64_t* d_table, size_t n_rows, size_t n_cols, int width, size_t col_stride, uint64_t* d_digests,
-                                size_t batch, void* stream) {
+                                size_t batch, void* stream) try {
     return hash_table_rows_dev(d_table, n_rows, n_cols, width, col_stride, d_digests, batch, stream);
-}
+} TF_ABI_CATCH
 int tf_merkle_from_columns_dev(const uint64_t* d_table, size_t n_rows, size_t n_cols, int width, size_t col_stride, uint64_t* d_nodes,
-                               size_t batch, void* stream) {
+                               size_t batch, void* stream) try {
     return merkle_from_columns_dev(d_table, n_rows, n_cols, width, col_stride, d_nodes, batch, stream);
-}
-int tf_merkle_from_rows_dev(const uint64_t* d_rows, size_t row_len, size_t n_rows, uint64_t* d_nodes, size_t batch, void* stream) {
+} TF_ABI_CATCH
+int tf_merkle_from_rows_dev(const uint64_t* d_rows, size_t row_len, size_t n_rows, uint64_t* d_nodes, size_t batch, void* stream) try {
     return merkle_from_rows_dev(d_rows, row_len, n_rows, d_nodes, batch, stream);
-}
+} TF_ABI_CATCH
 
-int tf_coset_interpolate_bfe(const uint64_t* v, size_t n, uint64_t off, uint64_t* out, size_t batch) {
+int tf_coset_interpolate_bfe(const uint64_t* v, size_t n, uint64_t off, uint64_t* out, size_t batch) try {
     TRY(check_len(n));
     if (n == 0 || batch == 0) return TF_OK;
     if (!v || !out) return TF_ERR_NULL_POINTER;
     if (off == 0) return TF_ERR_INVERSE_OF_ZERO;
     return host_roundtrip(v, n * batch, nullptr, 0, out, n * batch,
                           [&](u64* a, u64*, u64* o, hipStream_t s) { return coset_interp_dev(a, n, off, o, batch, 1, s); });
-}
-int tf_coset_interpolate_xfe(const uint64_t* v, size_t n, uint64_t off, uint64_t* out, size_t batch) {
+} TF_ABI_CATCH
+int tf_coset_interpolate_xfe(const uint64_t* v, size_t n, uint64_t off, uint64_t* out, size_t batch) try {
     TRY(check_len(n));
     if (n == 0 || batch == 0) return TF_OK;
     if (!v || !out) return TF_ERR_NULL_POINTER;
     if (off == 0) return TF_ERR_INVERSE_OF_ZERO;
     return host_roundtrip(v, 3 * n * batch, nullptr, 0, out, 3 * n * batch,
                           [&](u64* a, u64*, u64* o, hipStream_t s) { return coset_interp_dev(a, n, off, o, batch, 3, s); });
-}
-int tf_poly_mul_bfe(const uint64_t* a, size_t na, const uint64_t* b, size_t nb, uint64_t* out, size_t batch) {
+} TF_ABI_CATCH
+int tf_poly_mul_bfe(const uint64_t* a, size_t na, const uint64_t* b, size_t nb, uint64_t* out, size_t batch) try {
     if (batch == 0 || na == 0 || nb == 0) return TF_OK;
     if (!a || !b || !out) return TF_ERR_NULL_POINTER;
     return host_roundtrip(a, na * batch, b, nb * batch, out, (na + nb - 1) * batch,
                           [&](u64* x, u64* y, u64* o, hipStream_t s) { return poly_mul_dev(x, na, y, nb, o, batch, 1, s); });
-}
-int tf_poly_mul_xfe(const uint64_t* a, size_t na, const uint64_t* b, size_t nb, uint64_t* out, size_t batch) {
+} TF_ABI_CATCH
+int tf_poly_mul_xfe(const uint64_t* a, size_t na, const uint64_t* b, size_t nb, uint64_t* out, size_t batch) try {
     if (batch == 0 || na == 0 || nb == 0) return TF_OK;
     if (!a || !b || !out) return TF_ERR_NULL_POINTER;
     return host_roundtrip(a, 3 * na * batch, b, 3 * nb * batch, out, 3 * (na + nb - 1) * batch,
                           [&](u64* x, u64* y, u64* o, hipStream_t s) { return poly_mul_dev(x, na, y, nb, o, batch, 3, s); });
-}
-int tf_poly_square_bfe(const uint64_t* a, size_t na, uint64_t* out, size_t batch) {
+} TF_ABI_CATCH
+int tf_poly_square_bfe(const uint64_t* a, size_t na, uint64_t* out, size_t batch) try {
     if (batch == 0 || na == 0) return TF_OK;
     if (!a || !out) return TF_ERR_NULL_POINTER;
     return host_roundtrip(a, na * batch, nullptr, 0, out, (2 * na - 1) * batch,
                           [&](u64* x, u64*, u64* o, hipStream_t s) { return poly_square_dev(x, na, o, batch, 1, s); });
-}
-int tf_poly_square_xfe(const uint64_t* a, size_t na, uint64_t* out, size_t batch) {
+} TF_ABI_CATCH
+int tf_poly_square_xfe(const uint64_t* a, size_t na, uint64_t* out, size_t batch) try {
     if (batch == 0 || na == 0) return TF_OK;
     if (!a || !out) return TF_ERR_NULL_POINTER;
     return host_roundtrip(a, 3 * na * batch, nullptr, 0, out, 3 * (2 * na - 1) * batch,
                           [&](u64* x, u64*, u64* o, hipStream_t s) { return poly_square_dev(x, na, o, batch, 3, s); });
-}
-int tf_poly_batch_evaluate_bfe(const uint64_t* c, size_t nc, const uint64_t* pts, size_t np, uint64_t* out) {
+} TF_ABI_CATCH
+int tf_poly_batch_evaluate_bfe(const uint64_t* c, size_t nc, const uint64_t* pts, size_t np, uint64_t* out) try {
     if (np == 0) return TF_OK;
     if (!pts || !out || (nc && !c)) return TF_ERR_NULL_POINTER;
     return host_roundtrip(c, nc, pts, np, out, np,
                           [&](u64* dc, u64* dp, u64* o, hipStream_t s) { return batch_evaluate_dev(dc, nc, nc, 1, dp, np, o, 1, s); });
-}
-int tf_poly_batch_evaluate_xfe(const uint64_t* c, size_t nc, const uint64_t* pts, size_t np, uint64_t* out) {
+} TF_ABI_CATCH
+int tf_poly_batch_evaluate_xfe(const uint64_t* c, size_t nc, const uint64_t* pts, size_t np, uint64_t* out) try {
     if (np == 0) return TF_OK;
     if (!pts || !out || (nc && !c)) return TF_ERR_NULL_POINTER;
     return host_roundtrip(c, 3 * nc, pts, 3 * np, out, 3 * np,
                           [&](u64* dc, u64* dp, u64* o, hipStream_t s) { return batch_evaluate_dev(dc, nc, 3 * nc, 1, dp, np, o, 3, s); });
-}
-int tf_poly_zerofier_bfe_dev(const uint64_t* r, size_t n, uint64_t* out, void* stream) { return zerofier_dev(r, n, out, 1, stream); }
-int tf_poly_zerofier_xfe_dev(const uint64_t* r, size_t n, uint64_t* out, void* stream) { return zerofier_dev(r, n, out, 3, stream); }
+} TF_ABI_CATCH
+int tf_poly_zerofier_bfe_dev(const uint64_t* r, size_t n, uint64_t* out, void* stream) try { return zerofier_dev(r, n, out, 1, stream); } TF_ABI_CATCH
+int tf_poly_zerofier_xfe_dev(const uint64_t* r, size_t n, uint64_t* out, void* stream) try { return zerofier_dev(r, n, out, 3, stream); } TF_ABI_CATCH
 static int zerofier_host(const uint64_t* r, size_t n, uint64_t* out, int L) {
     if (!out || (n && !r)) return TF_ERR_NULL_POINTER;
     return host_roundtrip(r, n * L, nullptr, 0, out, (n + 1) * L, [&](u64* dr, u64*, u64* o, hipStream_t s) { return zerofier_dev(dr, n, o, L, s); });
 }
-int tf_poly_zerofier_bfe(const uint64_t* r, size_t n, uint64_t* out) { return zerofier_host(r, n, out, 1); }
-int tf_poly_zerofier_xfe(const uint64_t* r, size_t n, uint64_t* out) { return zerofier_host(r, n, out, 3); }
-int tf_poly_interpolate_bfe_dev(const uint64_t* d, const uint64_t* v, size_t n, size_t rows, uint64_t* out, void* stream) {
+int tf_poly_zerofier_bfe(const uint64_t* r, size_t n, uint64_t* out) try { return zerofier_host(r, n, out, 1); } TF_ABI_CATCH
+int tf_poly_zerofier_xfe(const uint64_t* r, size_t n, uint64_t* out) try { return zerofier_host(r, n, out, 3); } TF_ABI_CATCH
+int tf_poly_interpolate_bfe_dev(const uint64_t* d, const uint64_t* v, size_t n, size_t rows, uint64_t* out, void* stream) try {
     return interpolate_dev(d, v, n, rows, out, 1, stream);
-}
-int tf_poly_interpolate_xfe_dev(const uint64_t* d, const uint64_t* v, size_t n, size_t rows, uint64_t* out, void* stream) {
+} TF_ABI_CATCH
+int tf_poly_interpolate_xfe_dev(const uint64_t* d, const uint64_t* v, size_t n, size_t rows, uint64_t* out, void* stream) try {
     return interpolate_dev(d, v, n, rows, out, 3, stream);
-}
+} TF_ABI_CATCH
 static int interpolate_host(const uint64_t* d, const uint64_t* v, size_t n, size_t rows, uint64_t* out, int L) {
     if (n == 0) return TF_ERR_EMPTY_DOMAIN;
     if (rows == 0) return TF_OK;
@@ -627,8 +628,8 @@ static int interpolate_host(const uint64_t* d, const uint64_t* v, size_t n, size
     return host_roundtrip(d, n * L, v, rows * n * L, out, rows * n * L,
                           [&](u64* dd, u64* dv, u64* o, hipStream_t s) { return interpolate_dev(dd, dv, n, rows, o, L, s); });
 }
-int tf_poly_interpolate_bfe(const uint64_t* d, const uint64_t* v, size_t n, size_t rows, uint64_t* out) { return interpolate_host(d, v, n, rows, out, 1); }
-int tf_poly_interpolate_xfe(const uint64_t* d, const uint64_t* v, size_t n, size_t rows, uint64_t* out) { return interpolate_host(d, v, n, rows, out, 3); }
+int tf_poly_interpolate_bfe(const uint64_t* d, const uint64_t* v, size_t n, size_t rows, uint64_t* out) try { return interpolate_host(d, v, n, rows, out, 1); } TF_ABI_CATCH
+int tf_poly_interpolate_xfe(const uint64_t* d, const uint64_t* v, size_t n, size_t rows, uint64_t* out) try { return interpolate_host(d, v, n, rows, out, 3); } TF_ABI_CATCH
 static int tree_new_any(const uint64_t* domain, size_t n, int L, bool on_device, void* stream, tf_zerofier_tree** tree) {
     if (!tree) return TF_ERR_NULL_POINTER;
     *tree = nullptr;
@@ -662,60 +663,60 @@ static int tree_new_async(const uint64_t* d_domain, size_t n, int L, void* strea
     return TF_OK;
 }
 static TreeHandle* tree_of(const tf_zerofier_tree* t) { return const_cast<TreeHandle*>(reinterpret_cast<const TreeHandle*>(t)); }
-int tf_zerofier_tree_new_bfe(const uint64_t* domain, size_t n, tf_zerofier_tree** tree) { return tree_new_any(domain, n, 1, false, nullptr, tree); }
-int tf_zerofier_tree_new_xfe(const uint64_t* domain, size_t n, tf_zerofier_tree** tree) { return tree_new_any(domain, n, 3, false, nullptr, tree); }
-int tf_zerofier_tree_new_bfe_dev(const uint64_t* d_domain, size_t n, void* stream, tf_zerofier_tree** tree) {
+int tf_zerofier_tree_new_bfe(const uint64_t* domain, size_t n, tf_zerofier_tree** tree) try { return tree_new_any(domain, n, 1, false, nullptr, tree); } TF_ABI_CATCH
+int tf_zerofier_tree_new_xfe(const uint64_t* domain, size_t n, tf_zerofier_tree** tree) try { return tree_new_any(domain, n, 3, false, nullptr, tree); } TF_ABI_CATCH
+int tf_zerofier_tree_new_bfe_dev(const uint64_t* d_domain, size_t n, void* stream, tf_zerofier_tree** tree) try {
     return tree_new_any(d_domain, n, 1, true, stream, tree);
-}
-int tf_zerofier_tree_new_xfe_dev(const uint64_t* d_domain, size_t n, void* stream, tf_zerofier_tree** tree) {
+} TF_ABI_CATCH
+int tf_zerofier_tree_new_xfe_dev(const uint64_t* d_domain, size_t n, void* stream, tf_zerofier_tree** tree) try {
     return tree_new_any(d_domain, n, 3, true, stream, tree);
-}
+} TF_ABI_CATCH
 void tf_zerofier_tree_free(tf_zerofier_tree* tree) { tree_handle_free(tree_of(tree)); }
 size_t tf_zerofier_tree_num_points(const tf_zerofier_tree* tree) { return tree ? tree_handle_num_points(tree_of(tree)) : 0; }
 int tf_zerofier_tree_width(const tf_zerofier_tree* tree) { return tree ? tree_handle_width(tree_of(tree)) : 0; }
-int tf_zerofier_tree_zerofier_dev(const tf_zerofier_tree* tree, uint64_t* d_out, void* stream) { return tree_handle_zerofier(tree_of(tree), d_out, stream); }
+int tf_zerofier_tree_zerofier_dev(const tf_zerofier_tree* tree, uint64_t* d_out, void* stream) try { return tree_handle_zerofier(tree_of(tree), d_out, stream); } TF_ABI_CATCH
 int tf_zerofier_tree_batch_evaluate_dev(const tf_zerofier_tree* tree, const uint64_t* d_coeffs, size_t n_coeffs, size_t batch, uint64_t* d_out,
-                                        void* stream) {
+                                        void* stream) try {
     return tree_handle_batch_evaluate(tree_of(tree), d_coeffs, n_coeffs, batch, d_out, stream);
-}
-int tf_zerofier_tree_interpolate_dev(tf_zerofier_tree* tree, const uint64_t* d_values, size_t rows, uint64_t* d_out, void* stream) {
+} TF_ABI_CATCH
+int tf_zerofier_tree_interpolate_dev(tf_zerofier_tree* tree, const uint64_t* d_values, size_t rows, uint64_t* d_out, void* stream) try {
     return tree_handle_interpolate(tree_of(tree), d_values, rows, d_out, stream);
-}
+} TF_ABI_CATCH
 // ---- enqueue-and-return variants (tf_hip.h): panic cases go to *d_status on the device, nothing synchronises
-int tf_poly_interpolate_bfe_dev_async(const uint64_t* d, const uint64_t* v, size_t n, size_t rows, uint64_t* out, void* stream, int* d_status) {
+int tf_poly_interpolate_bfe_dev_async(const uint64_t* d, const uint64_t* v, size_t n, size_t rows, uint64_t* out, void* stream, int* d_status) try {
     if (!d_status) return TF_ERR_NULL_POINTER;
     return interpolate_dev(d, v, n, rows, out, 1, stream, d_status);
-}
-int tf_poly_interpolate_xfe_dev_async(const uint64_t* d, const uint64_t* v, size_t n, size_t rows, uint64_t* out, void* stream, int* d_status) {
+} TF_ABI_CATCH
+int tf_poly_interpolate_xfe_dev_async(const uint64_t* d, const uint64_t* v, size_t n, size_t rows, uint64_t* out, void* stream, int* d_status) try {
     if (!d_status) return TF_ERR_NULL_POINTER;
     return interpolate_dev(d, v, n, rows, out, 3, stream, d_status);
-}
-int tf_poly_clean_divide_bfe_dev_async(const uint64_t* a, size_t na, const uint64_t* b, size_t nb, uint64_t* out, void* stream, int* d_status) {
+} TF_ABI_CATCH
+int tf_poly_clean_divide_bfe_dev_async(const uint64_t* a, size_t na, const uint64_t* b, size_t nb, uint64_t* out, void* stream, int* d_status) try {
     if (!d_status) return TF_ERR_NULL_POINTER;
     return clean_divide_dev(a, na, b, nb, out, stream, 1, d_status);
-}
+} TF_ABI_CATCH
 int tf_poly_clean_divide_many_bfe_dev_async(const uint64_t* a, size_t na, size_t batch, const uint64_t* b, size_t nb, uint64_t* out, void* stream,
-                                            int* d_status) {
+                                            int* d_status) try {
     if (!d_status) return TF_ERR_NULL_POINTER;
     return clean_divide_dev(a, na, b, nb, out, stream, batch, d_status);
-}
-int tf_zerofier_tree_new_bfe_dev_async(const uint64_t* d_domain, size_t n, void* stream, tf_zerofier_tree** tree) {
+} TF_ABI_CATCH
+int tf_zerofier_tree_new_bfe_dev_async(const uint64_t* d_domain, size_t n, void* stream, tf_zerofier_tree** tree) try {
     return tree_new_async(d_domain, n, 1, stream, tree);
-}
-int tf_zerofier_tree_new_xfe_dev_async(const uint64_t* d_domain, size_t n, void* stream, tf_zerofier_tree** tree) {
+} TF_ABI_CATCH
+int tf_zerofier_tree_new_xfe_dev_async(const uint64_t* d_domain, size_t n, void* stream, tf_zerofier_tree** tree) try {
     return tree_new_async(d_domain, n, 3, stream, tree);
-}
-int tf_zerofier_tree_interpolate_dev_async(tf_zerofier_tree* tree, const uint64_t* d_values, size_t rows, uint64_t* d_out, void* stream, int* d_status) {
+} TF_ABI_CATCH
+int tf_zerofier_tree_interpolate_dev_async(tf_zerofier_tree* tree, const uint64_t* d_values, size_t rows, uint64_t* d_out, void* stream, int* d_status) try {
     if (!d_status) return TF_ERR_NULL_POINTER;
     return tree_handle_interpolate(tree_of(tree), d_values, rows, d_out, stream, d_status);
-}
-int tf_zerofier_tree_zerofier(const tf_zerofier_tree* tree, uint64_t* out) {
+} TF_ABI_CATCH
+int tf_zerofier_tree_zerofier(const tf_zerofier_tree* tree, uint64_t* out) try {
     if (!tree || !out) return TF_ERR_NULL_POINTER;
     TreeHandle* H = tree_of(tree);
     const size_t hn = tree_handle_num_points(H), hl = (size_t)tree_handle_width(H);
     return host_roundtrip(nullptr, 0, nullptr, 0, out, (hn + 1) * hl, [&](u64*, u64*, u64* o, hipStream_t s) { return tree_handle_zerofier(H, o, s); });
-}
-int tf_zerofier_tree_batch_evaluate(const tf_zerofier_tree* tree, const uint64_t* coeffs, size_t n_coeffs, size_t batch, uint64_t* out) {
+} TF_ABI_CATCH
+int tf_zerofier_tree_batch_evaluate(const tf_zerofier_tree* tree, const uint64_t* coeffs, size_t n_coeffs, size_t batch, uint64_t* out) try {
     if (!tree) return TF_ERR_NULL_POINTER;
     TreeHandle* H = tree_of(tree);
     const size_t hn = tree_handle_num_points(H), hl = (size_t)tree_handle_width(H);
@@ -723,8 +724,8 @@ int tf_zerofier_tree_batch_evaluate(const tf_zerofier_tree* tree, const uint64_t
     if (!out || (n_coeffs && !coeffs)) return TF_ERR_NULL_POINTER;
     return host_roundtrip(coeffs, batch * n_coeffs * hl, nullptr, 0, out, batch * hn * hl,
                           [&](u64* dc, u64*, u64* o, hipStream_t s) { return tree_handle_batch_evaluate(H, dc, n_coeffs, batch, o, s); });
-}
-int tf_zerofier_tree_interpolate(tf_zerofier_tree* tree, const uint64_t* values, size_t rows, uint64_t* out) {
+} TF_ABI_CATCH
+int tf_zerofier_tree_interpolate(tf_zerofier_tree* tree, const uint64_t* values, size_t rows, uint64_t* out) try {
     if (!tree) return TF_ERR_NULL_POINTER;
     TreeHandle* H = tree_of(tree);
     const size_t hn = tree_handle_num_points(H), hl = (size_t)tree_handle_width(H);
@@ -733,14 +734,14 @@ int tf_zerofier_tree_interpolate(tf_zerofier_tree* tree, const uint64_t* values,
     if (!values || !out) return TF_ERR_NULL_POINTER;
     return host_roundtrip(values, rows * hn * hl, nullptr, 0, out, rows * hn * hl,
                           [&](u64* dv, u64*, u64* o, hipStream_t s) { return tree_handle_interpolate(H, dv, rows, o, s); });
-}
-int tf_coset_eval_xfe_xoffset_dev(const uint64_t* c, size_t nc, const uint64_t offset[3], uint64_t* out, size_t order, size_t batch, void* stream) {
+} TF_ABI_CATCH
+int tf_coset_eval_xfe_xoffset_dev(const uint64_t* c, size_t nc, const uint64_t offset[3], uint64_t* out, size_t order, size_t batch, void* stream) try {
     return coset_eval_xoffset_dev(c, nc, offset, out, order, batch, stream);
-}
-int tf_coset_interpolate_xfe_xoffset_dev(const uint64_t* v, size_t n, const uint64_t offset[3], uint64_t* out, size_t batch, void* stream) {
+} TF_ABI_CATCH
+int tf_coset_interpolate_xfe_xoffset_dev(const uint64_t* v, size_t n, const uint64_t offset[3], uint64_t* out, size_t batch, void* stream) try {
     return coset_interp_xoffset_dev(v, n, offset, out, batch, stream);
-}
-int tf_coset_eval_xfe_xoffset(const uint64_t* c, size_t nc, const uint64_t offset[3], uint64_t* out, size_t order, size_t batch) {
+} TF_ABI_CATCH
+int tf_coset_eval_xfe_xoffset(const uint64_t* c, size_t nc, const uint64_t offset[3], uint64_t* out, size_t order, size_t batch) try {
     if (nc > order) return TF_ERR_ORDER_NOT_ABOVE_DEGREE;
     int rc = check_len(order);
     if (rc) return rc;
@@ -748,21 +749,21 @@ int tf_coset_eval_xfe_xoffset(const uint64_t* c, size_t nc, const uint64_t offse
     if (!out || !offset || (nc && !c)) return TF_ERR_NULL_POINTER;
     return host_roundtrip(c, 3 * nc * batch, nullptr, 0, out, 3 * order * batch,
                           [&](u64* dc, u64*, u64* o, hipStream_t s) { return coset_eval_xoffset_dev(dc, nc, offset, o, order, batch, s); });
-}
-int tf_coset_interpolate_xfe_xoffset(const uint64_t* v, size_t n, const uint64_t offset[3], uint64_t* out, size_t batch) {
+} TF_ABI_CATCH
+int tf_coset_interpolate_xfe_xoffset(const uint64_t* v, size_t n, const uint64_t offset[3], uint64_t* out, size_t batch) try {
     int rc = check_len(n);
     if (rc) return rc;
     if (n == 0 || batch == 0) return TF_OK;
     if (!v || !out || !offset) return TF_ERR_NULL_POINTER;
     return host_roundtrip(v, 3 * n * batch, nullptr, 0, out, 3 * n * batch,
                           [&](u64* dv, u64*, u64* o, hipStream_t s) { return coset_interp_xoffset_dev(dv, n, offset, o, batch, s); });
-}
-int tf_barycentric_evaluate_bfe_dev(const uint64_t* cw, size_t n, size_t batch, const uint64_t x[3], uint64_t* out, void* stream) {
+} TF_ABI_CATCH
+int tf_barycentric_evaluate_bfe_dev(const uint64_t* cw, size_t n, size_t batch, const uint64_t x[3], uint64_t* out, void* stream) try {
     return barycentric_dev(cw, n, batch, 1, x, out, stream);
-}
-int tf_barycentric_evaluate_xfe_dev(const uint64_t* cw, size_t n, size_t batch, const uint64_t x[3], uint64_t* out, void* stream) {
+} TF_ABI_CATCH
+int tf_barycentric_evaluate_xfe_dev(const uint64_t* cw, size_t n, size_t batch, const uint64_t x[3], uint64_t* out, void* stream) try {
     return barycentric_dev(cw, n, batch, 3, x, out, stream);
-}
+} TF_ABI_CATCH
 static int barycentric_host(const uint64_t* cw, size_t n, size_t batch, int width, const uint64_t x[3], uint64_t* out) {
     int rc = check_len(n);
     if (rc) return rc;
@@ -773,51 +774,51 @@ static int barycentric_host(const uint64_t* cw, size_t n, size_t batch, int widt
     return host_roundtrip(cw, batch * n * width, nullptr, 0, out, 3 * batch,
                           [&](u64* dc, u64*, u64* o, hipStream_t s) { return barycentric_dev(dc, n, batch, width, x, o, s); });
 }
-int tf_barycentric_evaluate_bfe(const uint64_t* cw, size_t n, size_t batch, const uint64_t x[3], uint64_t* out) { return barycentric_host(cw, n, batch, 1, x, out); }
-int tf_barycentric_evaluate_xfe(const uint64_t* cw, size_t n, size_t batch, const uint64_t x[3], uint64_t* out) { return barycentric_host(cw, n, batch, 3, x, out); }
+int tf_barycentric_evaluate_bfe(const uint64_t* cw, size_t n, size_t batch, const uint64_t x[3], uint64_t* out) try { return barycentric_host(cw, n, batch, 1, x, out); } TF_ABI_CATCH
+int tf_barycentric_evaluate_xfe(const uint64_t* cw, size_t n, size_t batch, const uint64_t x[3], uint64_t* out) try { return barycentric_host(cw, n, batch, 3, x, out); } TF_ABI_CATCH
 // Polynomial<BFieldElement>::evaluate::<XFieldElement, XFieldElement> (polynomial.rs:309-320) for `batch` polynomials at n_points
 // extension-field points: out[(b * n_points + i) * 3] = f_b(points[i]).  Horner (the shape of the use: every column polynomial
 // of a table at a few out-of-domain points).
-int tf_poly_evaluate_bfe_at_xfe_dev(const uint64_t* c, size_t nc, size_t batch, const uint64_t* pts, size_t np, uint64_t* out, void* stream) {
+int tf_poly_evaluate_bfe_at_xfe_dev(const uint64_t* c, size_t nc, size_t batch, const uint64_t* pts, size_t np, uint64_t* out, void* stream) try {
     if (np == 0 || batch == 0) return TF_OK;
     if (!pts || !out || (nc && !c)) return TF_ERR_NULL_POINTER;
     DeviceCtx* ctx = nullptr;
     int rc = current_ctx(&ctx);
     if (rc) return rc;
     return batch_evaluate_horner(c, nc, nc, batch, pts, np, out, 3, stream, 1);
-}
-int tf_poly_evaluate_bfe_at_xfe(const uint64_t* c, size_t nc, size_t batch, const uint64_t* pts, size_t np, uint64_t* out) {
+} TF_ABI_CATCH
+int tf_poly_evaluate_bfe_at_xfe(const uint64_t* c, size_t nc, size_t batch, const uint64_t* pts, size_t np, uint64_t* out) try {
     if (np == 0 || batch == 0) return TF_OK;
     if (!pts || !out || (nc && !c)) return TF_ERR_NULL_POINTER;
     return host_roundtrip(c, batch * nc, pts, 3 * np, out, 3 * batch * np,
                           [&](u64* dc, u64* dp, u64* o, hipStream_t s) { return batch_evaluate_horner(dc, nc, nc, batch, dp, np, o, 3, s, 1); });
-}
-int tf_poly_clean_divide_bfe_dev(const uint64_t* a, size_t na, const uint64_t* b, size_t nb, uint64_t* out, void* stream) {
+} TF_ABI_CATCH
+int tf_poly_clean_divide_bfe_dev(const uint64_t* a, size_t na, const uint64_t* b, size_t nb, uint64_t* out, void* stream) try {
     return clean_divide_dev(a, na, b, nb, out, stream);
-}
-int tf_poly_mul_shared_bfe_dev(const uint64_t* a, size_t na, size_t batch, const uint64_t* b, size_t nb, uint64_t* out, void* stream) {
+} TF_ABI_CATCH
+int tf_poly_mul_shared_bfe_dev(const uint64_t* a, size_t na, size_t batch, const uint64_t* b, size_t nb, uint64_t* out, void* stream) try {
     return poly_mul_shared_dev(a, na, batch, b, nb, out, 1, stream);
-}
-int tf_poly_mul_shared_xfe_dev(const uint64_t* a, size_t na, size_t batch, const uint64_t* b, size_t nb, uint64_t* out, void* stream) {
+} TF_ABI_CATCH
+int tf_poly_mul_shared_xfe_dev(const uint64_t* a, size_t na, size_t batch, const uint64_t* b, size_t nb, uint64_t* out, void* stream) try {
     return poly_mul_shared_dev(a, na, batch, b, nb, out, 3, stream);
-}
-int tf_poly_clean_divide_many_bfe_dev(const uint64_t* a, size_t na, size_t batch, const uint64_t* b, size_t nb, uint64_t* out, void* stream) {
+} TF_ABI_CATCH
+int tf_poly_clean_divide_many_bfe_dev(const uint64_t* a, size_t na, size_t batch, const uint64_t* b, size_t nb, uint64_t* out, void* stream) try {
     return clean_divide_dev(a, na, b, nb, out, stream, batch);
-}
-int tf_poly_clean_divide_many_bfe(const uint64_t* a, size_t na, size_t batch, const uint64_t* b, size_t nb, uint64_t* out) {
+} TF_ABI_CATCH
+int tf_poly_clean_divide_many_bfe(const uint64_t* a, size_t na, size_t batch, const uint64_t* b, size_t nb, uint64_t* out) try {
     if (nb == 0) return TF_ERR_DIVISION_BY_ZERO;
     if (na < nb) return na ? TF_ERR_DIVISION_NOT_CLEAN : TF_OK;
     if (batch == 0) return TF_OK;
     if (!a || !b || !out) return TF_ERR_NULL_POINTER;
     return host_roundtrip(a, batch * na, b, nb, out, batch * (na - nb + 1),
                           [&](u64* da, u64* db, u64* o, hipStream_t s) { return clean_divide_dev(da, na, db, nb, o, s, batch); });
-}
-int tf_poly_clean_divide_bfe(const uint64_t* a, size_t na, const uint64_t* b, size_t nb, uint64_t* out) {
+} TF_ABI_CATCH
+int tf_poly_clean_divide_bfe(const uint64_t* a, size_t na, const uint64_t* b, size_t nb, uint64_t* out) try {
     if (nb == 0) return TF_ERR_DIVISION_BY_ZERO;
     if (na < nb) return na ? TF_ERR_DIVISION_NOT_CLEAN : TF_OK;
     if (!a || !b || !out) return TF_ERR_NULL_POINTER;
     return host_roundtrip(a, na, b, nb, out, na - nb + 1, [&](u64* da, u64* db, u64* o, hipStream_t s) { return clean_divide_dev(da, na, db, nb, o, s); });
-}
+} TF_ABI_CATCH
 static int coset_extrapolate_host(uint64_t offset, const uint64_t* cw, size_t n, size_t batch, const uint64_t* pts, size_t np,
                                   uint64_t* out, int L) {
     if (n == 0) return TF_ERR_LEN_NOT_POWER_OF_TWO;
@@ -830,22 +831,22 @@ static int coset_extrapolate_host(uint64_t offset, const uint64_t* cw, size_t n,
         return coset_extrapolate_dev(offset, dc, n, batch, dp, np, o, L, s);
     });
 }
-int tf_coset_extrapolate_bfe(uint64_t offset, const uint64_t* cw, size_t n, size_t batch, const uint64_t* pts, size_t np, uint64_t* out) {
+int tf_coset_extrapolate_bfe(uint64_t offset, const uint64_t* cw, size_t n, size_t batch, const uint64_t* pts, size_t np, uint64_t* out) try {
     return coset_extrapolate_host(offset, cw, n, batch, pts, np, out, 1);
-}
-int tf_coset_extrapolate_xfe(uint64_t offset, const uint64_t* cw, size_t n, size_t batch, const uint64_t* pts, size_t np, uint64_t* out) {
+} TF_ABI_CATCH
+int tf_coset_extrapolate_xfe(uint64_t offset, const uint64_t* cw, size_t n, size_t batch, const uint64_t* pts, size_t np, uint64_t* out) try {
     return coset_extrapolate_host(offset, cw, n, batch, pts, np, out, 3);
-}
+} TF_ABI_CATCH
 int tf_tip5_hash_table_rows(const uint64_t* table, size_t n_rows, size_t n_cols, int width, size_t col_stride, uint64_t* digests,
-                            size_t batch) {
+                            size_t batch) try {
     if (width != 1 && width != 3) return TF_ERR_NULL_POINTER;
     if (n_rows == 0 || batch == 0) return TF_OK;
     if (!digests || (n_cols && !table)) return TF_ERR_NULL_POINTER;
     return host_roundtrip(table, batch * n_cols * col_stride, nullptr, 0, digests, batch * n_rows * 5,
                           [&](u64* dt, u64*, u64* o, hipStream_t s) { return hash_table_rows_dev(dt, n_rows, n_cols, width, col_stride, o, batch, s); });
-}
+} TF_ABI_CATCH
 int tf_merkle_from_columns(const uint64_t* table, size_t n_rows, size_t n_cols, int width, size_t col_stride, uint64_t* nodes_out,
-                           size_t batch) {
+                           size_t batch) try {
     if (width != 1 && width != 3) return TF_ERR_NULL_POINTER;
     int rc = check_leaves(n_rows);
     if (rc) return rc;
@@ -853,17 +854,17 @@ int tf_merkle_from_columns(const uint64_t* table, size_t n_rows, size_t n_cols, 
     if (!nodes_out || (n_cols && !table)) return TF_ERR_NULL_POINTER;
     return host_roundtrip(table, batch * n_cols * col_stride, nullptr, 0, nodes_out, batch * n_rows * 10,
                           [&](u64* dt, u64*, u64* o, hipStream_t s) { return merkle_from_columns_dev(dt, n_rows, n_cols, width, col_stride, o, batch, s); });
-}
-int tf_merkle_from_rows(const uint64_t* rows, size_t row_len, size_t n_rows, uint64_t* nodes_out, size_t batch) {
+} TF_ABI_CATCH
+int tf_merkle_from_rows(const uint64_t* rows, size_t row_len, size_t n_rows, uint64_t* nodes_out, size_t batch) try {
     TRY(check_leaves(n_rows));
     if (batch == 0) return TF_OK;
     if (!nodes_out || (row_len && !rows)) return TF_ERR_NULL_POINTER;
     return host_roundtrip(rows, n_rows * row_len * batch, nullptr, 0, nodes_out, n_rows * batch * 10,
                           [&](u64* r, u64*, u64* o, hipStream_t s) { return merkle_from_rows_dev(r, row_len, n_rows, o, batch, s); });
-}
+} TF_ABI_CATCH
 
 int tf_merkle_auth_structure_indices(size_t num_leafs, const uint64_t* leaf_indices, size_t k, uint64_t* out_indices,
-                                     size_t capacity, size_t* out_count) {
+                                     size_t capacity, size_t* out_count) try {
     if ((k && !leaf_indices) || !out_count) return TF_ERR_NULL_POINTER;
     std::vector<unsigned long long> idx;
     TRY(auth_structure_indices(num_leafs, leaf_indices, k, &idx));
@@ -872,10 +873,10 @@ int tf_merkle_auth_structure_indices(size_t num_leafs, const uint64_t* leaf_indi
     if (capacity < idx.size()) return TF_ERR_BUFFER_TOO_SMALL;  // nothing is written; *out_count says what is needed
     for (size_t i = 0; i < idx.size(); ++i) out_indices[i] = idx[i];
     return TF_OK;
-}
+} TF_ABI_CATCH
 
 int tf_merkle_authentication_structure_dev(const uint64_t* d_nodes, size_t num_leafs, const uint64_t* leaf_indices, size_t k,
-                                           uint64_t* out_digests, size_t capacity_digests, size_t* out_count, void* stream) {
+                                           uint64_t* out_digests, size_t capacity_digests, size_t* out_count, void* stream) try {
     if (!d_nodes || (k && !leaf_indices) || !out_count) return TF_ERR_NULL_POINTER;
     std::vector<unsigned long long> idx;
     TRY(auth_structure_indices(num_leafs, leaf_indices, k, &idx));
@@ -892,7 +893,7 @@ int tf_merkle_authentication_structure_dev(const uint64_t* d_nodes, size_t num_l
     TRY(gather_digests_dev(d_nodes, reinterpret_cast<const unsigned long long*>(didx.p), idx.size(), dout.p, s));
     TRY(d2h(out_digests, dout.p, idx.size() * 5, s));
     return sync(s);
-}
+} TF_ABI_CATCH
 
 }  // extern "C"
 

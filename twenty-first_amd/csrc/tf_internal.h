@@ -26,6 +26,7 @@
 #pragma GCC visibility pop
 #include "gl64.h"
 #include "ntt_args.h"
+#include "tf_guard.h"
 
 namespace tfi {
 

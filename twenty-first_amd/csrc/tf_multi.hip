@@ -121,18 +121,30 @@ int run_on_devices(size_t batch, const int* devices, int n_devices, F&& body) {
         shard_range(batch, G, g, &lo, &hi);
         if (lo == hi) continue;
         const int dev = devs[(size_t)g];
-        const bool ok = pool().submit([call, g, lo, hi, dev, &body] {
+        bool ok = false;
+        try {  // (queueing allocates: a failure here must not unwind past the wait below, the slices already queued reference `body`)
+          ok = pool().submit([call, g, lo, hi, dev, &body] {
             int rc;
-            hipError_t e = hipSetDevice(dev);
-            if (e != hipSuccess) rc = hip_fail(e, "hipSetDevice", __FILE__, __LINE__);
-            else rc = body(lo, hi);
-            std::string msg = rc != TF_OK ? t_last_error : std::string();
+            std::string msg;
+            try {  // (a worker has no caller to unwind to: whatever is thrown here becomes the slice's status, and the latch below is always released)
+                hipError_t e = hipSetDevice(dev);
+                if (e != hipSuccess) rc = hip_fail(e, "hipSetDevice", __FILE__, __LINE__);
+                else rc = body(lo, hi);
+                if (rc != TF_OK) msg = t_last_error;
+            } catch (const std::bad_alloc&) {
+                rc = TF_ERR_OUT_OF_MEMORY;
+            } catch (...) {
+                rc = TF_ERR_INTERNAL;
+            }
             std::lock_guard<std::mutex> lk(call->mu);
             call->rc[(size_t)g] = rc;
-            call->err[(size_t)g] = std::move(msg);
+            call->err[(size_t)g].swap(msg);
             if (--call->remaining == 0) call->cv.notify_all();
-        }, std::min(G, slices));
-        if (!ok) {  // not a single worker thread could be started: this slice will never run
+          }, std::min(G, slices));
+        } catch (...) {
+            ok = false;
+        }
+        if (!ok) {  // not a single worker thread could be started, or the slice could not be queued: it will never run
             std::lock_guard<std::mutex> lk(call->mu);
             --call->remaining;
             no_worker = true;
@@ -143,7 +155,7 @@ int run_on_devices(size_t batch, const int* devices, int n_devices, F&& body) {
         call->cv.wait(lk, [&] { return call->remaining == 0; });
     }
     if (no_worker) {
-        t_last_error = "could not start a worker thread";
+        t_last_error = "could not start a worker thread / queue a slice";
         return TF_ERR_HIP;
     }
     for (int g = 0; g < G; ++g)
@@ -160,7 +172,7 @@ using namespace tfi;
 
 extern "C" {
 
-int tf_set_device(int device) {
+int tf_set_device(int device) try {
     int visible = 0;
     if (hipGetDeviceCount(&visible) != hipSuccess || visible <= 0) {
         (void)hipGetLastError();
@@ -169,20 +181,20 @@ int tf_set_device(int device) {
     if (device < 0 || device >= visible || device >= kMaxDevices) return TF_ERR_NO_DEVICE;
     HIPCHK(hipSetDevice(device));
     return TF_OK;
-}
+} TF_ABI_CATCH
 
-int tf_get_device(int* device) {
+int tf_get_device(int* device) try {
     if (!device) return TF_ERR_NULL_POINTER;
     HIPCHK(hipGetDevice(device));
     return TF_OK;
-}
+} TF_ABI_CATCH
 
-int tf_shard_range(size_t total_units, int n_shards, int shard, size_t* begin, size_t* end) {
+int tf_shard_range(size_t total_units, int n_shards, int shard, size_t* begin, size_t* end) try {
     if (!begin || !end) return TF_ERR_NULL_POINTER;
     if (n_shards <= 0 || shard < 0 || shard >= n_shards) return TF_ERR_INVALID_ARGUMENT;
     shard_range(total_units, n_shards, shard, begin, end);
     return TF_OK;
-}
+} TF_ABI_CATCH
 
 static int ntt_multi(uint64_t* x, size_t n, size_t batch, int L, int inverse, const int* devices, int n_devices) {
     if (batch && n > 1 && !x) return TF_ERR_NULL_POINTER;
@@ -194,12 +206,12 @@ static int ntt_multi(uint64_t* x, size_t n, size_t batch, int L, int inverse, co
         return L == 1 ? tf_ntt_bfe(x + lo * unit, n, hi - lo, inverse) : tf_ntt_xfe(x + lo * unit, n, hi - lo, inverse);
     });
 }
-int tf_ntt_bfe_multi(uint64_t* x, size_t n, size_t batch, int inverse, const int* devices, int n_devices) {
+int tf_ntt_bfe_multi(uint64_t* x, size_t n, size_t batch, int inverse, const int* devices, int n_devices) try {
     return ntt_multi(x, n, batch, 1, inverse, devices, n_devices);
-}
-int tf_ntt_xfe_multi(uint64_t* x, size_t n, size_t batch, int inverse, const int* devices, int n_devices) {
+} TF_ABI_CATCH
+int tf_ntt_xfe_multi(uint64_t* x, size_t n, size_t batch, int inverse, const int* devices, int n_devices) try {
     return ntt_multi(x, n, batch, 3, inverse, devices, n_devices);
-}
+} TF_ABI_CATCH
 
 static int coset_eval_multi(const uint64_t* c, size_t nc, uint64_t off, uint64_t* out, size_t order, size_t batch, int L, const int* devices,
                             int n_devices) {
@@ -214,13 +226,13 @@ static int coset_eval_multi(const uint64_t* c, size_t nc, uint64_t off, uint64_t
     });
 }
 int tf_coset_eval_bfe_multi(const uint64_t* c, size_t nc, uint64_t off, uint64_t* out, size_t order, size_t batch, const int* devices,
-                            int n_devices) {
+                            int n_devices) try {
     return coset_eval_multi(c, nc, off, out, order, batch, 1, devices, n_devices);
-}
+} TF_ABI_CATCH
 int tf_coset_eval_xfe_multi(const uint64_t* c, size_t nc, uint64_t off, uint64_t* out, size_t order, size_t batch, const int* devices,
-                            int n_devices) {
+                            int n_devices) try {
     return coset_eval_multi(c, nc, off, out, order, batch, 3, devices, n_devices);
-}
+} TF_ABI_CATCH
 
 // Subtrees per tree when there are more listed devices than trees: the largest power of two S with batch * S <= devices, every subtree
 // at least two leaves (the reference's own bound on its thread count, merkle_tree.rs:182: num_threads <= num_remaining_nodes / 2).
@@ -239,7 +251,7 @@ static int listed_workers(const int* devices, int n_devices) {
     return visible < kMaxDevices ? visible : kMaxDevices;
 }
 int tf_merkle_multi_subtrees(size_t n_leaves, size_t batch, int n_devices) { return (int)subtrees_per_tree(n_leaves, batch, n_devices); }
-int tf_merkle_subtree_layer_range(size_t n_leaves, size_t n_subtrees, size_t subtree, unsigned layer, size_t* begin, size_t* end) {
+int tf_merkle_subtree_layer_range(size_t n_leaves, size_t n_subtrees, size_t subtree, unsigned layer, size_t* begin, size_t* end) try {
     if (!begin || !end) return TF_ERR_NULL_POINTER;
     if (int rc = check_leaves(n_leaves)) return rc;
     if (n_subtrees == 0 || (n_subtrees & (n_subtrees - 1)) || n_subtrees > n_leaves || subtree >= n_subtrees ||
@@ -248,7 +260,7 @@ int tf_merkle_subtree_layer_range(size_t n_leaves, size_t n_subtrees, size_t sub
     *begin = (n_subtrees + subtree) << layer;
     *end = (n_subtrees + subtree + 1) << layer;
     return TF_OK;
-}
+} TF_ABI_CATCH
 
 // One tree (or fewer trees than devices): every tree is cut into S subtrees exactly as MerkleTree::par_new cuts it over its threads
 // (util_types/merkle_tree.rs:165-212, :247-275); unit u = tree u / S, subtree u % S; the units are dealt to the listed devices like any
@@ -289,17 +301,17 @@ static int merkle_multi(const uint64_t* leaves, size_t n, uint64_t* nodes_out, u
     return TF_OK;
 }
 
-int tf_merkle_build_multi(const uint64_t* leaves, size_t n, uint64_t* nodes_out, size_t batch, const int* devices, int n_devices) {
+int tf_merkle_build_multi(const uint64_t* leaves, size_t n, uint64_t* nodes_out, size_t batch, const int* devices, int n_devices) try {
     int rc = tf_merkle_build(leaves, n, nodes_out, 0);  // leaf-count errors first, whatever the split
     if (rc) return rc;
     if (batch && (!leaves || !nodes_out)) return TF_ERR_NULL_POINTER;
     return merkle_multi(leaves, n, nodes_out, nullptr, batch, devices, n_devices);
-}
-int tf_merkle_root_multi(const uint64_t* leaves, size_t n, uint64_t* root_out, size_t batch, const int* devices, int n_devices) {
+} TF_ABI_CATCH
+int tf_merkle_root_multi(const uint64_t* leaves, size_t n, uint64_t* root_out, size_t batch, const int* devices, int n_devices) try {
     int rc = tf_merkle_root(leaves, n, root_out, 0);
     if (rc) return rc;
     if (batch && (!leaves || !root_out)) return TF_ERR_NULL_POINTER;
     return merkle_multi(leaves, n, nullptr, root_out, batch, devices, n_devices);
-}
+} TF_ABI_CATCH
 
 }  // extern "C"

@@ -23,6 +23,15 @@ int hip_fail(hipError_t e, const char* what, const char* file, int line) {
     return TF_ERR_HIP;
 }
 
+// what TF_ABI_CATCH (tf_guard.h) calls for an exception that reached an entry point
+int abi_caught(const char* what, int status) noexcept {
+    try {
+        t_last_error = std::string("C++ exception at the C ABI: ") + (what ? what : "?");
+    } catch (...) {  // (not even the message could be allocated: the status alone reports)
+    }
+    return status;
+}
+
 // ------------------------------------------------------------------------------------ field helpers (host)
 // w_n = 7^((p-1)/n): equals every entry of PRIMITIVE_ROOTS (b_field_element.rs:43-78).
 u64 root_of_unity_mont(int log_n) { return gl::mont_pow(gl::to_mont(7), (gl::P - 1) >> log_n); }
