@@ -9,8 +9,12 @@ OUT=${1:-$REPO/gpurun_out/switch_matrix.txt}
 mkdir -p "$(dirname "$OUT")"
 cd "$REPO"
 : > "$OUT"
+ROW=0
 run() {  # <env assignment> <description>
   local res
+  ROW=$((ROW + 1))
+  # TF_MATRIX_FROM / TF_MATRIX_TO: only rows FROM..TO (1-based) -- a GPU call has a time limit, the matrix is longer than one call
+  if [ "$ROW" -lt "${TF_MATRIX_FROM:-1}" ] || [ "$ROW" -gt "${TF_MATRIX_TO:-9999}" ]; then return; fi
   res=$(env $1 timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -n 1)
   printf "%-34s %-100s %s\n" "$1" "($2)" "$res" | tee -a "$OUT"
 }
@@ -68,6 +72,7 @@ if [ -f "$V" ]; then
   run "TF_DEFAULT=1" "variant library: Tip5 MDS on v_mfma_f64_16x16x4_f64 (-DTF_TIP5_I8=0), everything else the product"
   unset TF_HIP_LIBRARY
 fi
+[ -n "${TF_MATRIX_NO_FUZZ:-}" ] && exit 0
 echo "--- long randomised parity run on the product library (tools/fuzz_long.py, 3 seeds x 120 s)" | tee -a "$OUT"
 for seed in 11 12 13; do
   timeout 400 python tools/fuzz_long.py $seed 120 2>&1 | grep -v amdgpu.ids | tail -n 3 | tee -a "$OUT"
