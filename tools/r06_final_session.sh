@@ -3,11 +3,15 @@
 # (profiles/valu_counts.json, hbm_traffic_ntt.json, pipeline_counters.json, stamped with this build's source hash) are written on the box, so
 # the bench line that follows quotes library-matched counters.  Then: the suites, the C++ self-test, the bench line, the --force-dist records,
 # the rocprofv3 kernel trace of the bench command, the A/B tables of this round's adoptions, sweeps, randomised parity and thread stress.
+# A GPU call is limited to 60 minutes: `r06_final_session.sh a` = counters, records, suites, bench lines (what bench.py and DESIGN quote);
+# `r06_final_session.sh b` = the A/B tables, sweeps, randomised parity, thread stress and the laboratory library's suite.  No argument: both.
 set -u
 REPO=$(cd "$(dirname "$0")/.." && pwd)
 cd "$REPO"
 mkdir -p gpurun_out
 T=r06
+PART=${1:-ab}
+if [[ $PART == *a* ]]; then
 timeout 1500 bash tools/prof_r02.sh ${T}p > gpurun_out/${T}p_prof.log 2>&1
 python tools/make_profile_records.py gpurun_out/prof_${T}p ${T}p > gpurun_out/${T}p_records.log 2>&1
 timeout 900 bash tools/prof_r02.sh ${T}pipe --ntt 0 --merkle 0 --coset 0 --pipeline 3 > gpurun_out/${T}pipe_prof.log 2>&1
@@ -30,6 +34,13 @@ echo "bench rc=$?" >> gpurun_out/${T}_final_suites.txt
 python bench.py --force-dist --config 5 2> /dev/null | tail -1 > gpurun_out/${T}_c5_forcedist.json
 python bench.py --force-dist --no-extra 2> /dev/null | tail -1 > gpurun_out/${T}_c2_forcedist.json
 timeout 900 bash tools/profile_bench.sh ${T} > gpurun_out/${T}_profile_bench.log 2>&1
+cat gpurun_out/${T}_final_suites.txt
+fi
+if [[ $PART == *b* ]]; then
+# configs[3] on ONE stream (its two kernels do not share the chip), under the counters
+timeout 900 bash tools/prof_r02.sh ${T}c4 --ntt 0 --merkle 0 --coset 3 --pipe 1 > gpurun_out/${T}c4_prof.log 2>&1
+cp gpurun_out/prof_${T}c4/summary.txt gpurun_out/${T}c4_rocprof_summary.txt 2>/dev/null
+cp gpurun_out/prof_${T}c4/summary.json gpurun_out/${T}c4_rocprof_summary.json 2>/dev/null
 python tools/c8_ab.py 10 --parity 2>&1 | grep -v amdgpu.ids > gpurun_out/${T}_c8_ab_final.txt
 python tools/pipe_c5.py 2>&1 | grep -v amdgpu.ids > gpurun_out/${T}_pipe_tiles_final.txt
 python tools/round_robin_latency.py 4 2>&1 | grep -v amdgpu.ids > gpurun_out/${T}_round_robin_latency_final.txt
@@ -52,6 +63,7 @@ make -C twenty-first_amd/csrc ab -j8 > gpurun_out/${T}_make_ab.log 2>&1
 {
   echo "== laboratory library (TF_HIP_LIBRARY=libtf_hip_ab.so)"
   TF_HIP_LIBRARY=$REPO/twenty-first_amd/libtf_hip_ab.so python -m pytest tests -m gpu -q 2>&1 | tail -n 2
-} >> gpurun_out/${T}_final_suites.txt 2>&1
-cat gpurun_out/${T}_final_suites.txt
+} > gpurun_out/${T}_final_suites_lab.txt 2>&1
+cat gpurun_out/${T}_final_suites_lab.txt
 tail -n 8 gpurun_out/${T}_fuzz_long.txt
+fi
