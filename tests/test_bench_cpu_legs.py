@@ -85,3 +85,15 @@ def test_every_leg_survives_in_the_tail_of_the_bench_line():
     rec2 = dict(rec, merkle={"error": "RuntimeError('x')"}, coset_eval=dict(rec["coset_eval"], parity="not checked (--no-cpu-baseline)", cpu_baseline=None))
     sm = bench.summary_block(rec2)
     assert "error" in sm["merkle"] and sm["coset_eval"]["parity"] == "not checked" and "cpu" not in sm["coset_eval"]
+
+
+def test_stored_counter_records_belong_to_this_build(tf):
+    """bench.py quotes `roofline.traffic`, `valu_bound` and the Tip5 / composite fractions from stored rocprofv3 records only when their
+    `library.source_hash` is tf_source_hash() of the library it times (a comment-only edit of a source once left the three records one
+    build behind: the line then drops those keys instead of going stale, but the committed state should never be in that position)."""
+    import json
+
+    want = tf.lib().tf_source_hash().decode().replace("-ab", "")
+    for name in ("hbm_traffic_ntt.json", "valu_counts.json", "pipeline_counters.json"):
+        rec = json.load(open(os.path.join(ROOT, "profiles", name)))
+        assert rec["library"]["source_hash"] == want, f"profiles/{name} was recorded on build {rec['library']['source_hash']}, the sources are {want}: re-run tools/r06_final_session.sh a"
