@@ -690,8 +690,8 @@ def merkle_leg(ctx):
                            "matrix_pipe_frac": round(16.0 * mf / secs / 1e9 / peak, 3),
                            "valu_wave_instr_per_tree": wi, "mfma_wave_instr_per_tree": mf,
                            "valu_instr_per_hash_pair_per_lane_quartet": round((wi - mf) * 16.0 / (nl - 1), 1), "mfma_per_16_hash_pairs": round(mf * 16.0 / (nl - 1), 2),
-                           "status": "per 16 hash_pairs and round: 10 i8 MFMA (160 cycles, beside the vector ALU) + ~325 VALU instructions (180 of them the twelve x^7 = 36 "
-                                     "Montgomery products per quartet column, 48 the byte windows of the ten planes, 56 + 20 their recombination, the rest byte look-ups); "
+                           "status": "per 16 hash_pairs and round: 12 i8 MFMA (192 cycles, beside the vector ALU) + ~285 VALU instructions (180 of them the twelve x^7 = 36 "
+                                     "Montgomery products per quartet column, 8 the XORs that bias the bytes, 56 + 20 the recombination of the ten planes, the rest byte look-ups); "
                                      "frac < 1 is the clock the chip holds under this mix and the ramp of the small levels (DESIGN.md 4.3)",
                            "source": "instruction counts: SQ_INSTS_VALU / SQ_INSTS_MFMA under rocprofv3 --pmc (profiles/valu_counts.json, a stored profile of this library build, "
                                      "NOT this run) x this run's time; peak = 1024 SIMDs x 2.4 GHz"}
