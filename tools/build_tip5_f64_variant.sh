@@ -1,6 +1,6 @@
 #!/bin/bash
 # tools/build_tip5_f64_variant.sh -- the product's sources with the Tip5 MDS on v_mfma_f64_16x16x4_f64 (-DTF_TIP5_I8=0, round 5's form, the
-# yardstick of tools/microbench_mds.hip) -> twenty-first_amd/variants/libtf_hip_tip5f64.so (git-ignored; travels to the GPU box; loaded through
+# yardstick of tools/microbench_mds.hip) -> twenty-first_amd/variants/libtf_hip_tip5f64.so (git-ignored and gpurun-ignored: built where it is needed; loaded through
 # TF_HIP_LIBRARY; tools/switch_matrix.sh runs the whole GPU suite on it).  Only the Tip5 unit (and the ABI unit, which carries the hash) differ.
 set -eu
 REPO=$(cd "$(dirname "$0")/.." && pwd)

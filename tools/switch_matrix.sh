@@ -65,8 +65,9 @@ run "TF_NTT_PIPE=1" "batch tiles of every multi-pass plan on ONE stream (round 6
 run "TF_NTT_PIPE=4 TF_NTT_TILE_BYTES=268435456" "256 MiB tiles on four side streams"
 unset TF_HIP_LIBRARY
 # round 6: the f64 form of the Tip5 MDS (round 5's product, -DTF_TIP5_I8=0) is still a buildable variant; built where hipcc is
-# (twenty-first_amd/variants/ travels to the GPU box): the whole suite on it
+# (tools/build_tip5_f64_variant.sh, built on the box when missing): the whole suite on it
 V=$REPO/twenty-first_amd/variants/libtf_hip_tip5f64.so
+[ -f "$V" ] || bash "$REPO/tools/build_tip5_f64_variant.sh" > /dev/null 2>&1   # (variants/ does not travel to the GPU box: built where it is needed)
 if [ -f "$V" ]; then
   export TF_HIP_LIBRARY=$V
   run "TF_DEFAULT=1" "variant library: Tip5 MDS on v_mfma_f64_16x16x4_f64 (-DTF_TIP5_I8=0), everything else the product"
