@@ -45,7 +45,7 @@ class TwentyFirstError(RuntimeError):
         name = lib().tf_status_string(code).decode()
         detail = lib().tf_last_error().decode()
         msg = f"{where}: {name}" if where else name
-        if detail and 8 <= code <= 10:  # tf_last_error() is the text of a HIP failure; codes 11+ carry none
+        if detail and (8 <= code <= 10 or code == 18):  # tf_last_error() is the text of a HIP failure / of an exception caught at the ABI; the other codes carry none
             msg += f" ({detail})"
         super().__init__(msg)
         self.code = code

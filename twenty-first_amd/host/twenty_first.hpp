@@ -81,8 +81,8 @@ struct BackendError : std::runtime_error {
     int code;
     BackendError(int c, const std::string& where)
         : std::runtime_error(where + ": " + tf_status_string(c) +
-                             ((c >= TF_ERR_NO_DEVICE && c <= TF_ERR_OUT_OF_MEMORY) ? std::string(" (") + tf_last_error() + ")" : "")),
-          code(c) {}  // tf_last_error() belongs to the HIP failures (codes 8..10) only
+                             (((c >= TF_ERR_NO_DEVICE && c <= TF_ERR_OUT_OF_MEMORY) || c == TF_ERR_INTERNAL) ? std::string(" (") + tf_last_error() + ")" : "")),
+          code(c) {}  // tf_last_error() belongs to the HIP failures (codes 8..10) and to an exception caught at the ABI (18) only
 };
 // where the reference panics (math/ntt.rs:135-140, math/polynomial.rs:1388-1392)
 struct NttPanic : BackendError {
@@ -97,7 +97,7 @@ struct MerkleTreeError : BackendError {
 inline void check(int rc, const char* where) {
     if (rc == TF_OK) return;
     if ((rc >= 1 && rc <= 3) || rc == TF_ERR_LEAF_INDEX_INVALID) throw MerkleTreeError(rc, where);  // merkle_tree.rs:933-965
-    if ((rc >= 4 && rc <= 6) || rc == TF_ERR_INVERSE_OF_ZERO || rc >= TF_ERR_EMPTY_DOMAIN) throw NttPanic(rc, where);  // the reference panics here
+    if ((rc >= 4 && rc <= 6) || rc == TF_ERR_INVERSE_OF_ZERO || (rc >= TF_ERR_EMPTY_DOMAIN && rc <= TF_ERR_DIVISION_NOT_CLEAN)) throw NttPanic(rc, where);  // the reference panics here
     throw BackendError(rc, where);
 }
 
