@@ -266,7 +266,9 @@ def test_merkle_build_matches_oracle(tf, oracle, height):
 
 def test_merkle_batch_of_trees(tf, oracle):
     # (the levels near the root run as subtrees, merkle_subtree_kernel: one, two and three launches, with and without a node array)
-    for n, batch in [(1, 3), (8, 5), (64, 9), (128, 5), (256, 3), (512, 3), (2048, 4), (4096, 7), (16384, 2), (65536, 3)]:
+    # (a subtree workgroup hashes a level on row PAIRS where it has the rows to spare -- only while every workgroup has a compute unit of its
+    #  own: batches of more than 256 small trees keep the 16-lane rows)
+    for n, batch in [(1, 3), (8, 5), (64, 9), (128, 5), (256, 3), (512, 3), (2048, 4), (4096, 7), (16384, 2), (65536, 3), (64, 300), (32, 257), (1024, 70)]:
         leaves = oracle.fill_random(5 * n * batch, 17 * n + batch)
         got = tf.MerkleTree.build_batch(leaves, n)
         roots = tf.MerkleTree.roots_batch(leaves, n)
@@ -537,11 +539,13 @@ def test_sponge_absorb_squeeze_matches_oracle(tf, oracle, length):
     assert list(fixed.state[0]) == [0] * 10 + [0xFFFFFFFF] * 6  # Tip5::new(Domain::FixedLength), mod.rs:511-526
 
 
-@pytest.mark.parametrize("count", [1, 15, 17, 8192, 8193, 8207, 8208, 40000, 65599])
+@pytest.mark.parametrize("count", [1, 7, 8, 9, 15, 17, 2040, 2047, 2048, 2049, 2063, 8192, 8193, 8207, 8208, 40000, 65599])
 def test_tip5_both_kernel_shapes_match_oracle(tf, oracle, count):
-    """launches of <= 2^13 permutation chains run 16 lanes per permutation, larger ones in the matrix-pipe form (4 lanes per
-    permutation, 16 permutations per wave: counts that are not multiples of 16 leave clamped lanes in the last wave):
-    permutation, hash_pair and hash_varlen on both sides of the switch, every output word"""
+    """launches of <= 2^13 permutation chains run 16 lanes per permutation -- 32 lanes (a row pair, the circulant's rotation terms split over
+    the two rows) up to 8 chains per compute unit, i.e. 2048 on an MI355X: counts around that switch and counts that leave a workgroup of
+    8 / 16 chains ragged --, larger ones in the matrix-pipe form (4 lanes per permutation, 16 permutations per wave: counts that are not
+    multiples of 16 leave clamped lanes in the last wave): permutation, hash_pair and hash_varlen on both sides of every switch, every
+    output word"""
     states = oracle.fill_random(count * 16, 900 + count)
     got = states.copy()
     tf.Tip5.permute_states(got)

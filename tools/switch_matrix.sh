@@ -60,6 +60,7 @@ run "TF_BATCH_EVAL=horner" "Horner everywhere"
 run "TF_BATCH_EVAL=tree TF_TREE_UNIT_SLAB=3000" "zerofier tree with the units of a walk cut into slabs of a few units"
 run "TF_TREE_LEAF_LOG=6" "64-point leaves in the zerofier tree (deeper trees)"
 run "TF_TREE_LEAF_LOG=10" "1024-point leaves"
+run "TF_TIP5_NO_COOP2=1" "16 lanes per permutation in every small Tip5 launch and subtree level (round 6 puts a permutation on a row pair where rows idle)"
 run "TF_NTT_PRE4=1" "2^22-point coset evaluations as 1024 x 4096 with the radix-4 last pass (round 4, measured loss)"
 run "TF_NTT_PIPE=1" "batch tiles of every multi-pass plan on ONE stream (round 6 deals the 2^21 / 2^22 two-pass tiles to two)"
 run "TF_NTT_PIPE=4 TF_NTT_TILE_BYTES=268435456" "256 MiB tiles on four side streams"

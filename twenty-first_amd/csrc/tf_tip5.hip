@@ -54,6 +54,19 @@ int ensure_tip5(DeviceCtx* ctx) {
 constexpr long long kCoopMaxCount = 1ll << 13;
 static_assert(kCoopMaxCount >= 64 && (kCoopMaxCount & (kCoopMaxCount - 1)) == 0, "a power of two: the level at which a tree narrows is found by halving");
 
+// Round 6: a launch of at most 8 permutation chains per compute unit leaves half the chip's 16-lane rows idle; it runs every chain on a row
+// PAIR instead (tip5_permutation_coop2: the circulant's sixteen rotation terms split over the two rows; 2.01 -> 1.68 us per permutation,
+// profiles/r06_microbench_coop2.txt).  A workgroup then holds 8 chains, so up to this count every workgroup still has a CU of its own.
+inline bool coop_two_rows(long long chains) {
+    static const bool off = ab_env("TF_TIP5_NO_COOP2") != nullptr;  // A/B switch
+    return !off && chains <= 8ll * device_cus();
+}
+// ... and the subtree launches use a row pair per hash_pair at the levels that have the rows to spare, when every workgroup has a CU of its own
+inline int subtree_two_rows(long long workgroups) {
+    static const bool off = ab_env("TF_TIP5_NO_COOP2") != nullptr;  // A/B switch
+    return (!off && workgroups <= (long long)device_cus()) ? 1 : 0;
+}
+
 // per_tree = 2^shift, or -1
 inline int shift_of(long long per_tree) { return (per_tree > 0 && !(per_tree & (per_tree - 1))) ? __builtin_ctzll((unsigned long long)per_tree) : -1; }
 
@@ -81,8 +94,12 @@ int tip5_permute_dev(u64* d_states, size_t count, void* stream) {
     rc = ensure_tip5(ctx);
     if (rc) return rc;
     if ((long long)count <= kCoopMaxCount) {
-        hipLaunchKernelGGL(tfk::tip5_permute_coop_kernel, dim3((unsigned)((count + 15) / 16)), dim3(256), 0,
-                           static_cast<hipStream_t>(stream), d_states, (long long)count);
+        if (coop_two_rows((long long)count))
+            hipLaunchKernelGGL(tfk::tip5_permute_coop_kernel<2>, dim3((unsigned)((count + 7) / 8)), dim3(256), 0, static_cast<hipStream_t>(stream), d_states,
+                               (long long)count);
+        else
+            hipLaunchKernelGGL(tfk::tip5_permute_coop_kernel<1>, dim3((unsigned)((count + 15) / 16)), dim3(256), 0, static_cast<hipStream_t>(stream), d_states,
+                               (long long)count);
     } else {
         launch_permute_mx(d_states, nullptr, (long long)count, static_cast<hipStream_t>(stream));
     }
@@ -108,9 +125,12 @@ int launch_hash_pairs(const u64* in, u64* out, u64* leaf_copy, long long count, 
     if (count == 0) return TF_OK;
     if (count <= kCoopMaxCount && !leaf_copy) {
         // fewer permutations than the GPU has lanes: latency, not throughput, is what this launch costs -> 16 lanes each
-        const long long blocks = (count + 15) / 16;
-        hipLaunchKernelGGL(tfk::tip5_hash_pairs_coop_kernel, dim3((unsigned)blocks), dim3(256), 0, s, in, out, count, per_tree,
-                           shift_of(per_tree), in_ts, out_ts);
+        if (coop_two_rows(count))
+            hipLaunchKernelGGL(tfk::tip5_hash_pairs_coop_kernel<2>, dim3((unsigned)((count + 7) / 8)), dim3(256), 0, s, in, out, count, per_tree, shift_of(per_tree),
+                               in_ts, out_ts);
+        else
+            hipLaunchKernelGGL(tfk::tip5_hash_pairs_coop_kernel<1>, dim3((unsigned)((count + 15) / 16)), dim3(256), 0, s, in, out, count, per_tree, shift_of(per_tree),
+                               in_ts, out_ts);
         HIPCHK(hipGetLastError());
         return TF_OK;
     }
@@ -125,8 +145,12 @@ int launch_hash_varlen_rows(const u64* rows, long long row_len, long long n_rows
                             hipStream_t s) {
     if (n_rows == 0) return TF_OK;
     if (n_rows <= kCoopMaxCount) {
-        hipLaunchKernelGGL(tfk::tip5_hash_varlen_rows_coop_kernel, dim3((unsigned)((n_rows + 15) / 16)), dim3(256), 0, s, rows, row_len,
-                           n_rows, out, per_tree, shift_of(per_tree), out_ts);
+        if (coop_two_rows(n_rows))
+            hipLaunchKernelGGL(tfk::tip5_hash_varlen_rows_coop_kernel<2>, dim3((unsigned)((n_rows + 7) / 8)), dim3(256), 0, s, rows, row_len, n_rows, out, per_tree,
+                               shift_of(per_tree), out_ts);
+        else
+            hipLaunchKernelGGL(tfk::tip5_hash_varlen_rows_coop_kernel<1>, dim3((unsigned)((n_rows + 15) / 16)), dim3(256), 0, s, rows, row_len, n_rows, out, per_tree,
+                               shift_of(per_tree), out_ts);
     } else {
         hipLaunchKernelGGL(tfk::tip5_hash_varlen_rows_mx_kernel<1>, dim3(mx_blocks(n_rows)), dim3(256), 0, s, rows, row_len, n_rows, out,
                            per_tree, shift_of(per_tree), out_ts);
@@ -202,7 +226,7 @@ int merkle_narrow_levels(const u64* level, long long in_ts, long long w, u64* d_
         const long long nw = w >> k;
         u64* out = d_nodes ? nullptr : sa;
         hipLaunchKernelGGL(tfk::merkle_subtree_kernel, dim3((unsigned)(batch << chunks_log)), dim3(subtree_threads(k)), 0, s, level, in_ts, k,
-                           chunks_log, d_nodes, nodes_ts, out, 5 * nw, copy_input ? 1 : 0);
+                           chunks_log, d_nodes, nodes_ts, out, 5 * nw, copy_input ? 1 : 0, subtree_two_rows((long long)(batch << chunks_log)));
         HIPCHK(hipGetLastError());
         w = nw;
         remaining -= k;
@@ -217,7 +241,7 @@ int merkle_narrow_levels(const u64* level, long long in_ts, long long w, u64* d_
         }
     }
     hipLaunchKernelGGL(tfk::merkle_top_kernel, dim3((unsigned)batch), dim3(subtree_threads(remaining)), 0, s, level, in_ts, (int)w, d_nodes,
-                       nodes_ts, d_root, copy_input ? level : (const u64*)nullptr, in_ts);
+                       nodes_ts, d_root, copy_input ? level : (const u64*)nullptr, in_ts, subtree_two_rows((long long)batch));
     HIPCHK(hipGetLastError());
     return TF_OK;
 }
@@ -243,8 +267,12 @@ int launch_hash_table_rows(const u64* table, long long n_rows, long long n_cols,
     const long long total = n_rows * batch;
     if (total == 0) return TF_OK;
     if (total <= kCoopMaxCount) {
-        hipLaunchKernelGGL(tfk::tip5_hash_table_rows_coop_kernel, dim3((unsigned)((total + 15) / 16)), dim3(256), 0, s, table, n_rows, shift_of(n_rows),
-                           n_cols, width, col_stride, table_stride, total, out, out_ts);
+        if (coop_two_rows(total))
+            hipLaunchKernelGGL(tfk::tip5_hash_table_rows_coop_kernel<2>, dim3((unsigned)((total + 7) / 8)), dim3(256), 0, s, table, n_rows, shift_of(n_rows), n_cols,
+                               width, col_stride, table_stride, total, out, out_ts);
+        else
+            hipLaunchKernelGGL(tfk::tip5_hash_table_rows_coop_kernel<1>, dim3((unsigned)((total + 15) / 16)), dim3(256), 0, s, table, n_rows, shift_of(n_rows), n_cols,
+                               width, col_stride, table_stride, total, out, out_ts);
     } else {
         hipLaunchKernelGGL(tfk::tip5_hash_table_rows_mx_kernel<1>, dim3(mx_blocks(total)), dim3(256), 0, s, table, n_rows, shift_of(n_rows),
                            n_cols, width, col_stride, table_stride, total, out, out_ts);

@@ -9,9 +9,10 @@
 // Three formulations of the same round, all producing the reference's words:
 //   * matrix-pipe form (throughput; every launch of more than 2^13 permutation chains): FOUR lanes per permutation, the MDS --
 //     the one dense contraction on this path, out = M * state with the constant circulant M (tip5/naive.rs:54-68, mod.rs:154-157)
-//     -- on v_mfma_f64_16x16x4_f64: products of a 16-bit entry and a 32-bit half are < 2^48, a sum of 16 is < 2^52, exact in f64
+//     -- on the matrix pipe: v_mfma_i32_16x16x64_i8 on byte planes since round 6 (round 5: v_mfma_f64_16x16x4_f64, kept as -DTF_TIP5_I8=0)
 //   * cooperative form (latency; small launches and the top of a tree): 16 lanes of a DPP row per permutation, the circulant as
-//     16 row rotations + v_mad_u64_u32
+//     16 row rotations + v_mad_u64_u32; where half the rows would idle anyway, a row PAIR per permutation (the rotation terms split
+//     over the two rows, v_permlane16_swap_b32 joins them: tip5_permutation_coop2)
 //   * lane-per-permutation form (tip5_round below): the whole state in one lane's registers, 512 v_mad_u64_u32 per MDS.  It was
 //     the throughput kernel through round 4; the library no longer launches it -- tools/microbench_mds.hip keeps it as the
 //     yardstick the matrix-pipe form is measured against (profiles/r05_microbench_mds_mfma.txt).
@@ -857,32 +858,118 @@ __device__ __forceinline__ void tip5_permutation_coop(u64& s, int j, const unsig
     }
 }
 
+// ---- the same permutation on TWO rows (32 lanes) -- round 6, for launches that leave half the chip's rows idle anyway ----------------
+// One permutation is an issue chain of ~920 cycles a round, and the circulant is half of it (16 row rotations + 32 v_mad_u64_u32).  Both
+// rows of a pair hold the state and run the S-box layer side by side (one instruction stream: no extra time); row h takes the eight
+// rotation terms k = 8 h .. 8 h + 7 -- the state rotated by 8 first in row 1, the matrix entries M[k + 8 h] as per-lane registers -- and
+// gfx950's v_permlane16_swap_b32 joins the two partial sums (four swaps, two 64-bit additions): 16 rotations + 16 products per lane
+// instead of 32 + 32.  Measured (tools/microbench_coop2.hip, profiles/r06_microbench_coop2.txt: a chain of 20 000 dependent permutations
+// in one wave, word for word the 16-lane form and the lane-per-permutation round): 2.01 -> 1.68 us per permutation.  It halves the
+// permutations per wave, so it is used where the rows would otherwise idle: launches of at most 8 chains per compute unit
+// (tf_tip5.hip: coop_two_rows) and the levels of a subtree that have at most half as many pairs as the workgroup has rows.
+struct CoopHalfMatrix {
+    u32 m[8];  // M[k + 8 half], k = 0..7
+};
+__device__ __forceinline__ void coop_half_matrix(int half, CoopHalfMatrix& hm) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) hm.m[k] = half ? mds_entry(k + 8) : mds_entry(k);
+}
+template <int K>
+__device__ __forceinline__ void mds_coop_half_terms(u32 lo, u32 hi, const CoopHalfMatrix& hm, u64 (&alo)[2], u64 (&ahi)[2]) {
+    if constexpr (K < 8) {
+        const u32 rl = (u32)__builtin_amdgcn_mov_dpp((int)lo, 0x120 + K, 0xf, 0xf, true);  // row_ror:K
+        const u32 rh = (u32)__builtin_amdgcn_mov_dpp((int)hi, 0x120 + K, 0xf, 0xf, true);
+        alo[K & 1] += (u64)hm.m[K] * rl;
+        ahi[K & 1] += (u64)hm.m[K] * rh;
+        mds_coop_half_terms<K + 1>(lo, hi, hm, alo, ahi);
+    }
+}
+// x of this row + x of the partner row (lane ^ 16): after  a = b = x;  v_permlane16_swap a, b  the odd row of a and the even row of b have
+// changed places -- a = (x_even, x_even), b = (x_odd, x_odd) in both rows of a pair -- so a + b is the sum, in both rows
+__device__ __forceinline__ u64 coop_add_partner_row(u64 x) {
+    const u32 xl = (u32)x, xh = (u32)(x >> 32);
+    const auto l = __builtin_amdgcn_permlane16_swap(xl, xl, false, false);
+    const auto h = __builtin_amdgcn_permlane16_swap(xh, xh, false, false);
+    return (((u64)h[0] << 32) | l[0]) + (((u64)h[1] << 32) | l[1]);
+}
+// s = state[j] of the permutation shared by the 32 lanes of this row pair (BOTH rows hold it, both must be active); half = (lane >> 4) & 1
+__device__ __forceinline__ void tip5_permutation_coop2(u64& s, int j, int half, const unsigned char* lut, const u64 (&rcs)[5], const CoopHalfMatrix& hm) {
+#pragma unroll
+    for (int round = 0; round < 5; ++round) {
+        const u32 ll = lookup4((u32)s, lut), lh = lookup4((u32)(s >> 32), lut);
+        const u64 sq = gl::mont_mul(s, s);
+        u64 cu, qu;
+        gl::mont_mul2(sq, s, sq, sq, cu, qu);
+        const u64 x7 = gl::mont_mul(cu, qu);
+        s = j < 4 ? (((u64)lh << 32) | ll) : x7;
+        u32 lo = (u32)s, hi = (u32)(s >> 32);
+        // row 1 works on the state rotated by 8: M[8 + k] state[(r - 8 - k) mod 16]
+        const u32 lo8 = (u32)__builtin_amdgcn_mov_dpp((int)lo, 0x128, 0xf, 0xf, true), hi8 = (u32)__builtin_amdgcn_mov_dpp((int)hi, 0x128, 0xf, 0xf, true);
+        lo = half ? lo8 : lo;
+        hi = half ? hi8 : hi;
+        u64 alo[2] = {(u64)hm.m[0] * lo, 0}, ahi[2] = {(u64)hm.m[0] * hi, 0};
+        mds_coop_half_terms<1>(lo, hi, hm, alo, ahi);
+        asm("" : "+v"(alo[1]), "+v"(ahi[1]));
+        const u64 slo = coop_add_partner_row(alo[0] + alo[1]), shi = coop_add_partner_row(ahi[0] + ahi[1]);  // < 2^52 each
+        const u64 rc = rcs[round];
+        unsigned c0, c1, c2, c3, c4;
+        const u32 w1 = __builtin_addc((u32)(slo >> 32), (u32)shi, 0u, &c0);
+        const u32 w2 = __builtin_addc((u32)(shi >> 32), 0u, c0, &c1);
+        const u32 t0 = __builtin_addc((u32)slo, (u32)rc, 0u, &c2);
+        const u32 t1 = __builtin_addc(w1, (u32)(rc >> 32), c2, &c3);
+        const u32 t2 = __builtin_addc(w2, 0u, c3, &c4);
+        const u64 l64 = ((u64)t1 << 32) | t0;
+        const u64 t = (u64)t2 * 0xffffffffu + l64;
+        const bool ca = t < l64;
+        const u64 u = t + gl::EPS;
+        const bool cb = u < t;
+        s = (ca | cb) ? u : t;
+    }
+}
+// ROWS = 1: 16 lanes per chain (tip5_permutation_coop); ROWS = 2: 32 lanes (tip5_permutation_coop2).  A workgroup of 256 threads holds
+// 16 / ROWS chains; chain index and half of a thread:
+template <int ROWS>
+struct CoopGeom {
+    static constexpr int kShift = ROWS == 2 ? 5 : 4, kPerBlock = 256 >> kShift;
+    __device__ static __forceinline__ long long item() { return (long long)blockIdx.x * kPerBlock + (threadIdx.x >> kShift); }
+    __device__ static __forceinline__ int half() { return ROWS == 2 ? (int)((threadIdx.x >> 4) & 1) : 0; }
+};
+template <int ROWS>
+__device__ __forceinline__ void tip5_permutation_coop_n(u64& s, int j, int half, const unsigned char* lut, const u64 (&rcs)[5], const CoopHalfMatrix& hm) {
+    if constexpr (ROWS == 2) tip5_permutation_coop2(s, j, half, lut, rcs, hm);
+    else tip5_permutation_coop(s, j, lut, rcs);
+}
+
 // hash_pair per 16-lane row: item i = blockIdx.x * 16 + threadIdx.x / 16.  Same item i belongs to tree i / per_tree; its input is in + tree * in_ts + 10 * (i % per_tree), its
 // digest goes to out + tree * out_ts + 5 * (i % per_tree); if leaf_copy != null the 10 input words are also copied to
 // leaf_copy + tree * copy_ts + 10 * (i % per_tree) (Merkle leaf level, merkle_tree.rs:426).
+template <int ROWS>
 __global__ void __launch_bounds__(256) tip5_hash_pairs_coop_kernel(const u64* in, u64* out, long long count, long long per_tree,
                                                                    int shift, long long in_ts, long long out_ts) {
     __shared__ __attribute__((aligned(16))) unsigned char lut[256];
-    const int j = threadIdx.x & 15;
-    const long long i = (long long)blockIdx.x * 16 + (threadIdx.x >> 4);
-    const bool live = i < count;  // whole rows are live or not
+    const int j = threadIdx.x & 15, half = CoopGeom<ROWS>::half();
+    const long long i = CoopGeom<ROWS>::item();
+    const bool live = i < count;  // whole rows (row pairs) are live or not
     long long tree, k;
     split_item(live ? i : count - 1, per_tree, shift, tree, k);
     u64 s = j < 10 ? in[tree * in_ts + 10 * k + j] : gl::ONE;  // the input and the round constants are in flight while the table is built
     u64 rcs[5];
     coop_round_constants(j, rcs);
+    CoopHalfMatrix hm;
+    coop_half_matrix(half, hm);
     stage_lut(lut);
     if (!live) return;
-    tip5_permutation_coop(s, j, lut, rcs);
-    if (j < 5) out[tree * out_ts + 5 * k + j] = s;
+    tip5_permutation_coop_n<ROWS>(s, j, half, lut, rcs, hm);
+    if (j < 5 && !half) out[tree * out_ts + 5 * k + j] = s;
 }
 
 // hash_varlen of row i by the 16 lanes of row-group i (few rows, or one long input: the absorb chain is sequential)
+template <int ROWS>
 __global__ void __launch_bounds__(256) tip5_hash_varlen_rows_coop_kernel(const u64* rows, long long row_len, long long n_rows,
                                                                          u64* out, long long per_tree, int shift, long long out_ts) {
     __shared__ __attribute__((aligned(16))) unsigned char lut[256];
-    const int j = threadIdx.x & 15;
-    const long long i = (long long)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int j = threadIdx.x & 15, half = CoopGeom<ROWS>::half();
+    const long long i = CoopGeom<ROWS>::item();
     const bool live = i < n_rows;
     const u64* p = rows + (live ? i : n_rows - 1) * row_len;
     u64 s = 0;  // Domain::VariableLength
@@ -897,25 +984,28 @@ __global__ void __launch_bounds__(256) tip5_hash_varlen_rows_coop_kernel(const u
     u64 nxt = j < 10 ? rate_word(0) : 0;
     u64 rcs[5];
     coop_round_constants(j, rcs);
+    CoopHalfMatrix hm;
+    coop_half_matrix(half, hm);
     stage_lut(lut);
     if (!live) return;
     for (long long c = 0; c < chunks; ++c) {
         if (j < 10) s = nxt;  // overwrite-mode absorb, mod.rs:684-691
         if (j < 10 && c + 1 < chunks) nxt = rate_word(c + 1);
-        tip5_permutation_coop(s, j, lut, rcs);
+        tip5_permutation_coop_n<ROWS>(s, j, half, lut, rcs, hm);
     }
     long long tree, k;
     split_item(i, per_tree, shift, tree, k);
-    if (j < 5) out[tree * out_ts + k * 5 + j] = s;
+    if (j < 5 && !half) out[tree * out_ts + k * 5 + j] = s;
 }
 
 // the same for few rows: 16 lanes per row
+template <int ROWS>
 __global__ void __launch_bounds__(256) tip5_hash_table_rows_coop_kernel(const u64* table, long long n_rows, int shift, long long n_cols,
                                                                         int width, long long col_stride, long long table_stride,
                                                                         long long total, u64* out, long long out_ts) {
     __shared__ __attribute__((aligned(16))) unsigned char lut[256];
-    const int j = threadIdx.x & 15;
-    const long long id = (long long)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int j = threadIdx.x & 15, half = CoopGeom<ROWS>::half();
+    const long long id = CoopGeom<ROWS>::item();
     const bool live = id < total;
     long long tree, i;
     split_item(live ? id : total - 1, n_rows, shift, tree, i);
@@ -930,29 +1020,34 @@ __global__ void __launch_bounds__(256) tip5_hash_table_rows_coop_kernel(const u6
     u64 nxt = j < 10 ? rate_word(0) : 0;
     u64 rcs[5];
     coop_round_constants(j, rcs);
+    CoopHalfMatrix hm;
+    coop_half_matrix(half, hm);
     stage_lut(lut);
     if (!live) return;
     for (long long c = 0; c < chunks; ++c) {
         if (j < 10) s = nxt;
         if (j < 10 && c + 1 < chunks) nxt = rate_word(c + 1);
-        tip5_permutation_coop(s, j, lut, rcs);
+        tip5_permutation_coop_n<ROWS>(s, j, half, lut, rcs, hm);
     }
-    if (j < 5) out[tree * out_ts + i * 5 + j] = s;
+    if (j < 5 && !half) out[tree * out_ts + i * 5 + j] = s;
 }
 
 // Tip5::permutation of state i by row-group i
+template <int ROWS>
 __global__ void __launch_bounds__(256) tip5_permute_coop_kernel(u64* states, long long count) {
     __shared__ __attribute__((aligned(16))) unsigned char lut[256];
-    const int j = threadIdx.x & 15;
-    const long long i = (long long)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int j = threadIdx.x & 15, half = CoopGeom<ROWS>::half();
+    const long long i = CoopGeom<ROWS>::item();
     const bool live = i < count;
     u64 s = states[(live ? i : count - 1) * 16 + j];
     u64 rcs[5];
     coop_round_constants(j, rcs);
+    CoopHalfMatrix hm;
+    coop_half_matrix(half, hm);
     stage_lut(lut);
     if (!live) return;
-    tip5_permutation_coop(s, j, lut, rcs);
-    states[i * 16 + j] = s;
+    tip5_permutation_coop_n<ROWS>(s, j, half, lut, rcs, hm);
+    if (!half) states[i * 16 + j] = s;
 }
 
 // A whole subtree in one workgroup (sequentially_fill_tree, merkle_tree.rs:216-222, below the parallelisation cutoff): the workgroup
@@ -962,10 +1057,12 @@ __global__ void __launch_bounds__(256) tip5_permute_coop_kernel(u64* states, lon
 // != null).  Near the root of a tree a level is one permutation latency (~2.2 us) whatever its width, so what a level costs is the
 // launch around it: a workgroup per subtree pays it once per log2(chunk) levels.
 __device__ __forceinline__ void merkle_subtree(const u64* src, int chunk, u64* nd, long long w, long long c, bool copy_input, u64* out,
-                                               u64 (*buf)[256 * 5], unsigned char* lut) {
-    const int t = threadIdx.x, j = t & 15, row = t >> 4, rows = blockDim.x >> 4;
+                                               u64 (*buf)[256 * 5], unsigned char* lut, bool two_rows) {
+    const int t = threadIdx.x, j = t & 15, row = t >> 4, rows = blockDim.x >> 4, half = row & 1;
     u64 rcs[5];
     coop_round_constants(j, rcs);  // once for all levels
+    CoopHalfMatrix hm;
+    coop_half_matrix(half, hm);
     for (int k = t; k < chunk * 5; k += blockDim.x) {
         const u64 v = src[k];
         buf[0][k] = v;
@@ -976,14 +1073,28 @@ __device__ __forceinline__ void merkle_subtree(const u64* src, int chunk, u64* n
     long long lw = w;  // nodes in the level being read
     for (int cw = chunk / 2; cw >= 1; cw /= 2) {
         lw /= 2;
-        for (int base = 0; base < cw; base += rows) {
-            const int i = base + row;
-            if (i < cw) {  // whole rows take the branch together
+        if (two_rows && 2 * cw <= rows) {
+            // at most half as many pairs as the workgroup has rows: a row PAIR per hash_pair (tip5_permutation_coop2; rows 2 i and
+            // 2 i + 1 are in one wave), the level costs 1.7 us instead of 2.0
+            const int i = row >> 1;
+            if (i < cw) {  // whole row pairs take the branch together
                 u64 s = j < 10 ? buf[cur][10 * i + j] : gl::ONE;
-                tip5_permutation_coop(s, j, lut, rcs);
-                if (j < 5) {
+                tip5_permutation_coop2(s, j, half, lut, rcs, hm);
+                if (j < 5 && !half) {
                     buf[cur ^ 1][5 * i + j] = s;
                     if (nd) nd[(lw + c * cw + i) * 5 + j] = s;
+                }
+            }
+        } else {
+            for (int base = 0; base < cw; base += rows) {
+                const int i = base + row;
+                if (i < cw) {  // whole rows take the branch together
+                    u64 s = j < 10 ? buf[cur][10 * i + j] : gl::ONE;
+                    tip5_permutation_coop(s, j, lut, rcs);
+                    if (j < 5) {
+                        buf[cur ^ 1][5 * i + j] = s;
+                        if (nd) nd[(lw + c * cw + i) * 5 + j] = s;
+                    }
                 }
             }
         }
@@ -999,28 +1110,28 @@ __device__ __forceinline__ void merkle_subtree(const u64* src, int chunk, u64* n
 // nodes: node array (may be null when only the root is wanted); root_out: 5 words per tree or null.
 __global__ void __launch_bounds__(1024) merkle_top_kernel(const u64* level_in, long long in_ts, int width, u64* nodes,
                                                           long long nodes_ts, u64* root_out, const u64* leaves_to_copy,
-                                                          long long leaves_ts) {
+                                                          long long leaves_ts, int two_rows) {
     __shared__ __attribute__((aligned(16))) unsigned char lut[256];
     __shared__ u64 buf[2][256 * 5];
     (void)leaves_ts;  // leaves_to_copy != null only says that level_in IS the leaf level, to be copied into nodes[width..2 width)
     const long long tree = blockIdx.x;
     u64* nd = nodes ? nodes + tree * nodes_ts : nullptr;
     if (nd && threadIdx.x < 5) nd[threadIdx.x] = 0;
-    merkle_subtree(level_in + tree * in_ts, width, nd, width, 0, leaves_to_copy != nullptr, root_out ? root_out + tree * 5 : nullptr, buf, lut);
+    merkle_subtree(level_in + tree * in_ts, width, nd, width, 0, leaves_to_copy != nullptr, root_out ? root_out + tree * 5 : nullptr, buf, lut, two_rows != 0);
 }
 
 // The levels between the wide ones (one launch each) and the top: workgroup (tree, c) takes chunk = 2^chunk_log nodes of the level of
 // w = chunk << chunks_log nodes and leaves the subtree root in out + tree * out_ts + 5 c (if out != null: the root-only builders keep
 // no node array; with one the root is already at nodes[(w >> chunk_log) + c]).
 __global__ void __launch_bounds__(1024) merkle_subtree_kernel(const u64* level_in, long long in_ts, int chunk_log, int chunks_log, u64* nodes,
-                                                              long long nodes_ts, u64* out, long long out_ts, int copy_input) {
+                                                              long long nodes_ts, u64* out, long long out_ts, int copy_input, int two_rows) {
     __shared__ __attribute__((aligned(16))) unsigned char lut[256];
     __shared__ u64 buf[2][256 * 5];
     const long long tree = blockIdx.x >> chunks_log, c = blockIdx.x - (tree << chunks_log);
     const int chunk = 1 << chunk_log;
     const long long w = (long long)chunk << chunks_log;
     merkle_subtree(level_in + tree * in_ts + c * chunk * 5, chunk, nodes ? nodes + tree * nodes_ts : nullptr, w, c, copy_input != 0,
-                   out ? out + tree * out_ts + 5 * c : nullptr, buf, lut);
+                   out ? out + tree * out_ts + 5 * c : nullptr, buf, lut, two_rows != 0);
 }
 
 // out[k] = nodes[idx[k]] for digests (5 words): authentication structures from a device-resident tree
