@@ -279,10 +279,11 @@ def test_hadamard_bfe_alignment_and_odd_counts(tf, oracle, count, shift):
 
 
 @pytest.mark.parametrize("width", [1, 3])
-@pytest.mark.parametrize("n_rows,n_cols", [(1, 1), (8, 0), (8, 3), (64, 10), (256, 7), (1 << 12, 11), (1 << 16, 4)])
+@pytest.mark.parametrize("n_rows,n_cols", [(1, 1), (8, 0), (8, 3), (64, 10), (256, 7), (1 << 11, 5), (1 << 12, 11), (1 << 16, 4)])
 def test_rows_of_column_major_tables(tf, oracle, width, n_rows, n_cols):
     """hash_varlen (tip5/mod.rs:617-623) of the rows of a column-major table (XFE rows flattened as
-    x_field_element.rs:217-231) and the tree over them; both kernel shapes (16 lanes per row up to 2^13 rows)"""
+    x_field_element.rs:217-231) and the tree over them; every kernel shape (a row pair per table row up to 8 rows per compute unit --
+    2^11 on an MI355X --, 16 lanes per row up to 2^13 rows, the matrix-pipe form above)"""
     cols = oracle.fill_random(max(1, n_cols * n_rows * width), 60 + n_rows + n_cols)[: n_cols * n_rows * width]
     # the same table row-major on the host: row i = [col_0[i], col_1[i], ...]
     rows = cols.reshape(n_cols, n_rows, width).transpose(1, 0, 2).reshape(-1) if n_cols else np.zeros(0, dtype=np.uint64)
